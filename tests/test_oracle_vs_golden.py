@@ -1,0 +1,78 @@
+"""Pins the numpy oracle against outputs of the reference itself (tests/golden/*.npz, produced by
+oracle/make_goldens.py from /root/reference).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from chattts_amd import rng
+from oracle import cases, codec_np, generate_np, llama_np, sampling_np
+
+
+@pytest.mark.parametrize("name", list(cases.SAMPLING_CASES))
+def test_sampling_chain(golden, name):
+    c = cases.SAMPLING_CASES[name]
+    logits, hist, temp = cases.sampling_inputs(c)
+    rows, V = logits.shape
+    q = rng.ExpDraws(rows, V, c["seed"]).step(0).numpy()
+    pt = rng.penalty_table(c["rep"])
+    idx, proc = sampling_np.sample_step(
+        logits, hist, q, temperature=temp, top_p=c["top_P"], top_k=c["top_K"],
+        pow_table=None if pt is None else pt.numpy(), max_input_ids=V - 1, mask_eos=c["mask_eos"],
+        return_processed=True)
+    kept = np.unpackbits(golden["sampling"][name + ".kept"], axis=1)[:, :V].astype(bool)
+    assert np.array_equal(np.isfinite(proc), kept)
+    assert np.array_equal(idx, golden["sampling"][name + ".idx"])
+
+
+@pytest.fixture(scope="module")
+def np_model(weights):
+    llama = llama_np.LlamaWeights({k: v.numpy() for k, v in weights["gpt"].items()})
+    esd = {k: v.numpy() for k, v in weights["embed"].items()}
+    return llama, esd, generate_np.fold_heads(esd)
+
+
+@pytest.mark.parametrize("name", list(cases.GEN_CASES))
+def test_generate(golden, np_model, name):
+    llama, esd, heads = np_model
+    c = cases.GEN_CASES[name]
+    G = golden["generate"]
+    ids, mask, tmask = cases.gen_inputs(c)
+    emb = generate_np.embed_prompt(esd, ids, tmask)
+    assert np.array_equal(emb[0], G[name + ".emb_row0"])
+    B = ids.shape[0]
+    if c["manual_seed"] is None:
+        torch.manual_seed(c["global_seed"])
+    draws = rng.ExpDraws(B * 4, 626, c["manual_seed"])
+    res = generate_np.generate(
+        llama, esd, heads, emb, ids, mask, temperature=np.array(c["temperature"], np.float32),
+        draw_q=lambda i: draws.step(i).numpy(), top_p=c["top_P"], top_k=c["top_K"],
+        pow_table=rng.penalty_table(c["rep"]).numpy(), max_new_token=c["max_new"], min_new_token=c["min_new"],
+        keep_logits=True)
+    lens = np.array([r.shape[0] for r in res.ids])
+    assert np.array_equal(lens, G[name + ".lens"])
+    assert np.array_equal(np.concatenate(res.ids, 0), G[name + ".ids"])  # bit-exact token ids
+    for b in c["keep_hidden_rows"]:
+        ref = G[name + f".hid{b}"]
+        err = np.abs(res.hiddens[b] - ref).max()
+        assert err < 2e-4, (b, err)
+    temp_rows = np.tile(np.array(c["temperature"], np.float32), B)
+    for s in c["keep_logit_steps"]:
+        key = name + f".tlogits{s}"
+        if key in G.files and s < len(res.logits):
+            got = res.logits[s] / temp_rows[:, None]
+            assert np.abs(got - G[key]).max() < 2e-3, s
+
+
+@pytest.mark.parametrize("name", list(cases.CODEC_CASES))
+def test_codec(golden, weights, name):
+    c = cases.CODEC_CASES[name]
+    hid = cases.codec_inputs(c)
+    dsd = {k: v.numpy() for k, v in weights["decoder"].items()}
+    vsd = {k: v.numpy() for k, v in weights["vocos"].items()}
+    mel = codec_np.dvae_decode(dsd, hid)
+    ref_mel = golden["codec"][name + ".mel"].transpose(0, 2, 1)
+    assert np.abs(mel - ref_mel).max() < 1e-4 * max(1.0, np.abs(ref_mel).max())
+    wav = codec_np.vocos_decode(vsd, mel)
+    ref = golden["codec"][name + ".wav"]
+    rms = np.sqrt(np.mean((wav - ref) ** 2))
+    assert wav.shape == ref.shape and rms < 1e-4, rms  # north_star bar: float32 waveform within 1e-4 RMS
