@@ -1,0 +1,213 @@
+#!/usr/bin/env python
+"""bench.py -- audio-seconds per wall-second of the hot path on N MI355X GPUs (one process per GPU).
+
+A "step" = one pass of the whole hot path over one batch of synthetic input: prefill + autoregressive
+decode (hipGraph replay) of a 64-utterance mixed-length batch, then DVAE + Vocos decode of all 64
+rows to float32 waveforms (BASELINE.json configs[2], "batch=64 mixed-length utterances ... hipGraph-
+captured decode, top-p sampling"; the metric is quoted on batch=64).  Inputs (weights, prompts, the
+Exp(1) draws of the seeded CPU generator) are resident in HBM before the timed region starts.
+
+N > 1: `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` -- the global batch
+of 64*N utterances is sharded in contiguous row blocks (weak scaling), weights are broadcast once
+from rank 0 over RCCL, there is no collective on the data path.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from chattts_amd import synth, weights as W  # noqa: E402
+from chattts_amd.config import GPT, SAMPLE_RATE  # noqa: E402
+
+TAGS = {0: "embed", 1: "qkv_gemm", 2: "rope_append", 3: "attention", 4: "o_proj_gemm", 5: "gate_up_gemm", 6: "down_gemm",
+        7: "final_norm", 8: "heads_gemm", 9: "sample"}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s peak (about 6.3 TB/s achievable)
+
+
+def audio_seconds(lens) -> float:
+    return float(sum(256 * (2 * int(t) - 1) for t in lens if t > 0)) / SAMPLE_RATE
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=64, help="utterances per GPU")
+    ap.add_argument("--min-len", type=int, default=128)
+    ap.add_argument("--max-len", type=int, default=512)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from chattts_amd import dist as D
+    from chattts_amd import engine as E
+
+    # ---- weights: rank 0 builds the synthetic checkpoint, everyone else receives it over RCCL ----
+    if world > 1:
+        sds = W.synthetic_all() if rank == 0 else None
+        sds = D.broadcast_state_dicts(sds, src=0, device=dev, meta=D.weights_meta(GPT.n_layers))
+    else:
+        sds = W.synthetic_all()
+    gpt = E.GptEngine(sds["gpt"], sds["embed"], dev, dtype=args.dtype)
+    codec = E.CodecEngine(sds["decoder"], sds["vocos"], dev)
+
+    # ---- workload: global batch sharded in contiguous row blocks ----
+    Bg = args.batch * world
+    ids, mask, tmask = synth.make_prompts(Bg, 16, 48, seed=0)
+    stop = synth.make_stop_lengths(Bg, args.min_len, args.max_len, seed=0)
+    lo, hi = D.shard_bounds(Bg, world, rank)
+    ids_t, mask_t, tm_t = torch.from_numpy(ids[lo:hi]), torch.from_numpy(mask[lo:hi]), torch.from_numpy(tmask[lo:hi])
+    stop_t = torch.from_numpy(stop[lo:hi])
+    warpers, procs = E.gen_logits(625, 0.7, 20, 1.05)
+    temp = torch.tensor([0.3] * 4)
+    max_new = int(stop.max()) + 1
+    emb = gpt.embed_prompt(ids_t, tm_t)
+    ids_d, mask_d = ids_t.to(dev), mask_t
+
+    def one_pass(use_graph=True, profile_tag=None, decode_audio=True, max_new_override=None):
+        out = None
+        for out in gpt.generate(emb, ids_d, temp, 625, mask_d, max_new_override or max_new, 0, (*procs, *warpers), return_hidden=True,
+                                manual_seed=42, use_graph=use_graph, stop_at=stop_t, row_offset=lo * 4, total_rows=Bg * 4,
+                                profile_tag=profile_tag):
+            pass
+        lens = [int(t.shape[0]) for t in out.ids]
+        wav = codec.decode_to_wavs(out.hiddens) if decode_audio else None
+        return lens, wav
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        lens, wav = one_pass(use_graph=not args.no_graph)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        lens, wav = one_pass(use_graph=not args.no_graph)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert lens == stop[lo:hi].tolist(), "forced lengths not honoured"
+    assert wav is not None and bool(torch.isfinite(wav).all())
+    total_audio = audio_seconds(stop) * args.steps  # all ranks, all steps
+    value = total_audio / dt
+    gpt_steps = gpt.last_stats.get("steps", 0)
+
+    result = {
+        "metric": "audio seconds/sec (RTF), batch=64 per GPU", "value": round(value, 2), "unit": "audio-s/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000.0 * dt / args.steps, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "C3: batch=64/GPU mixed-length (prompts 16-48 tok, outputs U{%d..%d} tok), top-p .7/top-k 20/rep 1.05/"
+                               "temp .3, manual_seed 42, hipGraph decode + DVAE + Vocos" % (args.min_len, args.max_len),
+                   "global_batch": Bg, "decode_steps_per_pass": gpt_steps, "parallelism": f"dp{world}",
+                   "tokens_per_pass": int(stop.sum()), "audio_s_per_pass": round(audio_seconds(stop), 2)},
+    }
+
+    # ---- roofline of the dominant decode kernel: HIP events around each launch on the launch stream ----
+    if rank == 0 and not args.no_roofline:
+        prof_steps = 97  # eager pass length (prefill + 96 decode steps): 96*20 = 1920 attention launches sampled
+        per_tag = {}
+        for tag in (1, 3, 4, 5, 6, 8, 9, 2):
+            one_pass(use_graph=False, profile_tag=tag, decode_audio=False, max_new_override=prof_steps)
+            n, tot = gpt.last_stats.get("profile", (0, 0.0))
+            per_tag[tag] = (n, tot)
+        calls_per_step = {t: (1 if t in (8, 9) else GPT.n_layers) for t in per_tag}
+        step_ms = {TAGS[t]: round(per_tag[t][1] / max(1, per_tag[t][0]) * calls_per_step[t], 4) for t in per_tag}
+        dom = max(per_tag, key=lambda t: per_tag[t][1] / max(1, per_tag[t][0]) * calls_per_step[t])
+        n, tot = per_tag[dom]
+        avg_ms = tot / max(1, n)
+        es = 2 if args.dtype == "bf16" else 4
+        B = hi - lo
+        valid_prompt = mask[lo:hi].sum(1).astype(np.int64)
+        n_steps_sampled = max(1, n // calls_per_step[dom])
+        if dom == 3:
+            # KV read 2*768*s*c_b per row per layer + KV write is done by rope_append; q read + out write
+            ctx = [(valid_prompt + i).sum() for i in range(1, n_steps_sampled + 1)]  # context incl. the current token
+            alg = float(np.mean(ctx)) * 2 * 768 * es + B * (768 * 4 * 2)
+        else:
+            wbytes = {1: 3 * 768 * 768, 4: 768 * 768, 5: 2 * 3072 * 768, 6: 768 * 3072, 8: 2504 * 768 * (4 // es)}.get(dom, 0) * es
+            act = {1: B * (768 + 2304) * 4, 4: B * 768 * 3 * 4, 5: B * (768 + 3072) * 4, 6: B * (3072 + 2 * 768) * 4,
+                   8: B * (768 + 2504) * 4, 9: B * 4 * 626 * 8, 2: B * 2304 * 4 * 2}.get(dom, 0)
+            alg = float(wbytes + act)
+        achieved = alg / (avg_ms * 1e-3) / 1e9
+        result["roofline"] = {"kernel": TAGS[dom], "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "avg_launch_us": round(avg_ms * 1e3, 2),
+                              "launches_timed": n, "alg_bytes_per_launch": int(alg)}
+        result["decode_kernel_ms_per_step"] = step_ms
+
+    # ---- same-box CPU baseline: the numpy port of the reference path, bounded sample ----
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(sds, ids[lo:hi], mask[lo:hi], tmask[lo:hi])
+
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(sds, ids, mask, tmask, n_steps: int = 12, codec_rows: int = 2, codec_T: int = 96):
+    """oracle/ (numpy float32 port of GPT.generate + DVAE + Vocos) timed on this box's host cores:
+    batch-64 prefill + `n_steps` decode steps, plus DVAE+Vocos on a [codec_rows, codec_T] slice;
+    rate = tokens / (gpt_time + codec_time_per_token * tokens) / 46.875."""
+    from chattts_amd import rng
+    from oracle import codec_np, generate_np, llama_np
+
+    cores = os.cpu_count() or 1
+    llama = llama_np.LlamaWeights({k: v.float().cpu().numpy() for k, v in sds["gpt"].items()})
+    esd = {k: v.float().cpu().numpy() for k, v in sds["embed"].items()}
+    heads = generate_np.fold_heads(esd)
+    emb = generate_np.embed_prompt(esd, ids, tmask)
+    B = ids.shape[0]
+    draws = rng.ExpDraws(B * 4, 626, 42)
+    t0 = time.perf_counter()
+    res = generate_np.generate(llama, esd, heads, emb, ids, mask, temperature=np.array([0.3] * 4, np.float32),
+                               draw_q=lambda i: draws.step(i).numpy(), pow_table=rng.penalty_table(1.05).numpy(),
+                               max_new_token=n_steps, min_new_token=n_steps)
+    t_gpt = time.perf_counter() - t0
+    tokens = B * n_steps
+    dsd = {k: v.float().cpu().numpy() for k, v in sds["decoder"].items()}
+    vsd = {k: v.float().cpu().numpy() for k, v in sds["vocos"].items()}
+    hid = np.random.RandomState(0).standard_normal((codec_rows, codec_T, 768)).astype(np.float32)
+    t0 = time.perf_counter()
+    codec_np.vocos_decode(vsd, codec_np.dvae_decode(dsd, hid))
+    t_codec_per_tok = (time.perf_counter() - t0) / (codec_rows * codec_T)
+    wall = t_gpt + t_codec_per_tok * tokens
+    return {"value": round(tokens / 46.875 / wall, 3), "unit": "audio-s/s", "cores": cores, "kind": "port",
+            "sample": f"numpy oracle: B={B} prefill + {n_steps} decode steps ({t_gpt:.1f}s) + DVAE/Vocos on {codec_rows}x{codec_T} tokens "
+                      f"({t_codec_per_tok * 1e3:.2f} ms/token); note: short contexts (<= {ids.shape[1] + n_steps}) favour the CPU"}
+
+
+if __name__ == "__main__":
+    main()

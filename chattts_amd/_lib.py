@@ -1,0 +1,121 @@
+"""ctypes binding of libchattts_amd.so (include/chattts_amd.h).  There is NO fallback: if the HIP
+library is missing or fails to load, importing this module's `lib()` raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libchattts_amd.so")
+
+F32, BF16 = 0, 1
+P = C.c_void_p
+PP = C.POINTER(C.c_void_p)
+
+
+class GptWeights(C.Structure):
+    _fields_ = [
+        ("n_layers", C.c_int32), ("weight_dtype", C.c_int32), ("kv_dtype", C.c_int32), ("max_pos", C.c_int32),
+        ("wqkv", PP), ("wo", PP), ("wgu", PP), ("wd", PP), ("ln1", PP), ("ln2", PP),
+        ("norm", P), ("emb_code", P), ("heads", P), ("rope_cos", P), ("rope_sin", P),
+        ("rms_eps", C.c_float),
+    ]
+
+
+class GenState(C.Structure):
+    _fields_ = [
+        ("B", C.c_int32), ("T", C.c_int32), ("max_new", C.c_int32),
+        ("ids_buf", P), ("len", P), ("kv_start", P), ("finish", P), ("end_idx", P), ("hiddens", P),
+        ("kcache", P), ("vcache", P), ("q", P), ("nq", C.c_int32),
+        ("temperature", P), ("pow_table", P),
+        ("top_p_thr", C.c_float), ("use_top_p", C.c_int32), ("top_k", C.c_int32), ("use_top_k", C.c_int32),
+        ("min_new", C.c_int32), ("eos", C.c_int32), ("row_offset", C.c_int32),
+        ("stop_at", P), ("workspace", P), ("workspace_bytes", C.c_size_t),
+    ]
+
+
+class CodecWeights(C.Structure):
+    _fields_ = [
+        ("conv_in0_w", P), ("conv_in0_b", P), ("conv_in2_w", P), ("conv_in2_b", P),
+        ("n_dvae_blocks", C.c_int32),
+        ("d_dw_w", PP), ("d_dw_b", PP), ("d_ln_w", PP), ("d_ln_b", PP), ("d_pw1_w", PP), ("d_pw1_b", PP),
+        ("d_pw2_w", PP), ("d_pw2_b", PP), ("d_gamma", PP),
+        ("conv_out_w", P), ("out_conv_w", P), ("coef", P),
+        ("v_embed_w", P), ("v_embed_b", P), ("v_norm_w", P), ("v_norm_b", P),
+        ("n_vocos_blocks", C.c_int32),
+        ("v_dw_w", PP), ("v_dw_b", PP), ("v_ln_w", PP), ("v_ln_b", PP), ("v_pw1_w", PP), ("v_pw1_b", PP),
+        ("v_pw2_w", PP), ("v_pw2_b", PP), ("v_gamma", PP),
+        ("v_final_w", P), ("v_final_b", P), ("head_w", P), ("head_b", P), ("window", P), ("twiddle", P),
+    ]
+
+
+I32, F, SZ = C.c_int32, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes): every symbol include/chattts_amd.h declares
+SIGNATURES = {
+    "ctts_last_error": (C.c_char_p, []),
+    "ctts_version": (C.c_int, []),
+    "ctts_gpt_create": (C.c_int, [PP, C.POINTER(GptWeights)]),
+    "ctts_gpt_destroy": (None, [P]),
+    "ctts_gpt_workspace_bytes": (SZ, [I32, I32]),
+    "ctts_gpt_prefill": (C.c_int, [P, C.POINTER(GenState), P, P]),
+    "ctts_gpt_decode_step": (C.c_int, [P, C.POINTER(GenState), P]),
+    "ctts_gpt_graph_build": (C.c_int, [P, C.POINTER(GenState), P]),
+    "ctts_gpt_graph_launch": (C.c_int, [P, I32, P]),
+    "ctts_gpt_graph_destroy": (None, [P]),
+    "ctts_gpt_profile_begin": (C.c_int, [P, I32, I32]),
+    "ctts_gpt_profile_end": (C.c_int, [P, C.POINTER(I32), C.POINTER(C.c_double)]),
+    "ctts_codec_create": (C.c_int, [PP, C.POINTER(CodecWeights)]),
+    "ctts_codec_destroy": (None, [P]),
+    "ctts_codec_workspace_bytes": (SZ, [I32, I32]),
+    "ctts_dvae_decode": (C.c_int, [P, P, P, I32, I32, P, SZ, P]),
+    "ctts_vocos_decode": (C.c_int, [P, P, P, I32, I32, P, SZ, P]),
+    "ctts_k_gemm": (C.c_int, [I32, P, P, P, I32, I32, I32, I32, I32, I32, I32, P, F, P, I32, P, P, I32, I32, I32, I32, I32, P]),
+    "ctts_k_rope_append": (C.c_int, [P, P, P, I32, I32, P, P, I32, P, P, I32, P]),
+    "ctts_k_attention": (C.c_int, [P, P, P, I32, I32, P, I32, P, P, I32, P]),
+    "ctts_k_embed_codes": (C.c_int, [P, P, I32, P, P, I32, P]),
+    "ctts_k_final_norm": (C.c_int, [P, I32, P, F, P, P, I32, P, I32, I32, P]),
+    "ctts_k_sample": (C.c_int, [C.POINTER(GenState), P, P]),
+    "ctts_k_dwconv_ln": (C.c_int, [P, P, P, P, P, F, I32, P, I32, I32, P]),
+    "ctts_k_layernorm": (C.c_int, [P, P, P, F, P, I32, P]),
+    "ctts_k_istft": (C.c_int, [P, P, P, P, P, I32, I32, P]),
+}
+
+_lib = None
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def lib() -> C.CDLL:
+    """Loads the HIP library (once).  Raises if it is absent -- the product has no CPU path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise EngineError(
+                f"{LIB_PATH} not found: build it with `python -m chattts_amd.build` "
+                "(hipcc --offload-arch=gfx950).  chattts_amd has no CPU/eager fallback.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)  # AttributeError if the .so does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().ctts_last_error()
+        raise EngineError(f"{what}: {msg.decode() if msg else 'unknown error'}")
+
+
+def ptr(t) -> int:
+    """Device/host pointer of a torch tensor (or None)."""
+    return None if t is None else t.data_ptr()
+
+
+def ptr_array(tensors):
+    arr = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    return arr

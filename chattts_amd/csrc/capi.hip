@@ -1,0 +1,408 @@
+// extern "C" boundary of libchattts_amd.so (declared in include/chattts_amd.h) and the launch
+// sequences of the GPT step / DVAE / Vocos.  No device allocation, no device synchronisation.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+
+#include "../../include/chattts_amd.h"
+#include "kernels.hpp"
+
+static thread_local char g_err[512] = "";
+static int fail(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return -1;
+}
+#define CK(expr)                                                                                   \
+  do {                                                                                             \
+    hipError_t _e = (expr);                                                                        \
+    if (_e != hipSuccess) return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+  } while (0)
+
+extern "C" const char* ctts_last_error(void) { return g_err; }
+extern "C" int ctts_version(void) { return 1; }
+
+static const int HID = 768, INTER = 3072, NHEAD = 12, HDIM = 64, NVQ = 4, NAUDIO = 626;
+
+// ------------------------------------------------------------------------------------------------
+struct ctts_gpt {
+  ctts_gpt_weights w;
+  std::vector<const void*> wqkv, wo, wgu, wd;
+  std::vector<const float*> ln1, ln2;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  // profiling (eager decode only)
+  int prof_tag = -1;
+  int prof_max = 0;
+  std::vector<hipEvent_t> ev0, ev1;
+  int prof_n = 0;
+};
+
+static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct GptWs {
+  float *x, *qkv, *ao, *act, *hfin, *logits;
+  size_t bytes;
+};
+static GptWs carve(void* base, int B, int T) {
+  const size_t M = (size_t)B * (T > 1 ? T : 1);
+  GptWs w;
+  size_t off = 0;
+  char* p = (char*)base;
+  w.x = (float*)(p + off); off += align_up(M * HID * 4);
+  w.qkv = (float*)(p + off); off += align_up(M * 3 * HID * 4);
+  w.ao = (float*)(p + off); off += align_up(M * HID * 4);
+  w.act = (float*)(p + off); off += align_up(M * INTER * 4);
+  w.hfin = (float*)(p + off); off += align_up((size_t)B * HID * 4);
+  w.logits = (float*)(p + off); off += align_up((size_t)B * NVQ * NAUDIO * 4);
+  w.bytes = off;
+  return w;
+}
+
+extern "C" size_t ctts_gpt_workspace_bytes(int32_t B, int32_t T) { return carve(nullptr, B, T).bytes; }
+
+extern "C" int ctts_gpt_create(ctts_gpt** out, const ctts_gpt_weights* w) {
+  if (!out || !w || w->n_layers <= 0) return fail("ctts_gpt_create: bad arguments");
+  ctts_gpt* g = new ctts_gpt();
+  g->w = *w;
+  const int L = w->n_layers;
+  g->wqkv.assign(w->wqkv, w->wqkv + L);
+  g->wo.assign(w->wo, w->wo + L);
+  g->wgu.assign(w->wgu, w->wgu + L);
+  g->wd.assign(w->wd, w->wd + L);
+  g->ln1.assign(w->ln1, w->ln1 + L);
+  g->ln2.assign(w->ln2, w->ln2 + L);
+  *out = g;
+  return 0;
+}
+
+extern "C" void ctts_gpt_graph_destroy(ctts_gpt* g) {
+  if (!g) return;
+  if (g->exec) { hipGraphExecDestroy(g->exec); g->exec = nullptr; }
+  if (g->graph) { hipGraphDestroy(g->graph); g->graph = nullptr; }
+}
+
+extern "C" void ctts_gpt_destroy(ctts_gpt* g) {
+  if (!g) return;
+  ctts_gpt_graph_destroy(g);
+  for (auto e : g->ev0) hipEventDestroy(e);
+  for (auto e : g->ev1) hipEventDestroy(e);
+  delete g;
+}
+
+struct Prof {
+  ctts_gpt* g; hipStream_t st; bool on; int idx;
+  Prof(ctts_gpt* g_, int tag, hipStream_t st_, bool allow) : g(g_), st(st_), on(false), idx(0) {
+    if (allow && g->prof_tag == tag && g->prof_n < g->prof_max) {
+      on = true; idx = g->prof_n;
+      hipEventRecord(g->ev0[idx], st);
+    }
+  }
+  ~Prof() {
+    if (on) { hipEventRecord(g->ev1[idx], st); g->prof_n++; }
+  }
+};
+
+static SampleArgs make_sample_args(const ctts_gen_state* s, const float* logits) {
+  SampleArgs a;
+  a.logits = logits; a.ids_buf = s->ids_buf; a.tcap = s->T + s->max_new; a.T = s->T; a.len = s->len; a.finish = s->finish;
+  a.end_idx = s->end_idx; a.q = s->q; a.nq = s->nq; a.temperature = s->temperature; a.pow_table = s->pow_table;
+  a.top_p_thr = s->top_p_thr; a.use_top_p = s->use_top_p; a.top_k = s->top_k; a.use_top_k = s->use_top_k;
+  a.min_new = s->min_new; a.eos = s->eos; a.row_offset = s->row_offset; a.max_input_ids = NAUDIO - 1; a.stop_at = s->stop_at;
+  a.B = s->B;
+  return a;
+}
+
+static int check_state(const ctts_gpt* g, const ctts_gen_state* s) {
+  if (!g || !s) return fail("null engine/state");
+  if (s->B <= 0 || s->T <= 0 || s->max_new <= 0) return fail("bad B/T/max_new");
+  if (s->T + s->max_new > g->w.max_pos) return fail("T + max_new (%d) exceeds the RoPE table (%d)", s->T + s->max_new, g->w.max_pos);
+  if (s->workspace_bytes < ctts_gpt_workspace_bytes(s->B, s->T)) return fail("workspace too small");
+  if (s->nq <= 0 || !s->q) return fail("q draws missing");
+  return 0;
+}
+
+// the 20-layer body + heads + sampling over M = B * q_per_b rows
+static int run_step(ctts_gpt* g, const ctts_gen_state* s, int q_per_b, hipStream_t st, bool prof_ok) {
+  const GptWs ws = carve(s->workspace, s->B, s->T);
+  const int B = s->B, M = B * q_per_b, cmax = s->T + s->max_new;
+  const int wt = g->w.weight_dtype, kt = g->w.kv_dtype;
+  const size_t kv_layer = (size_t)B * NHEAD * cmax * HDIM * (kt == CTTS_BF16 ? 2 : 4);
+  GptRowMap rm{q_per_b, s->len, s->kv_start};
+  for (int l = 0; l < g->w.n_layers; ++l) {
+    void* kc = (char*)s->kcache + kv_layer * l;
+    void* vc = (char*)s->vcache + kv_layer * l;
+    GemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.taps = 1;
+    // RMSNorm + QKV
+    a.A = ws.x; a.lda = HID; a.W = g->wqkv[l]; a.C = ws.qkv; a.ldc = 3 * HID; a.M = M; a.N = 3 * HID; a.K = HID; a.wt = wt;
+    a.epi = EPI_STORE; a.norm_w = g->ln1[l]; a.eps = g->w.rms_eps;
+    { Prof p(g, 1, st, prof_ok); CK(launch_gemm_skinny(a, st)); }
+    { Prof p(g, 2, st, prof_ok); CK(launch_rope_append(ws.qkv, kc, vc, kt, cmax, g->w.rope_cos, g->w.rope_sin, rm, M, st)); }
+    { Prof p(g, 3, st, prof_ok); CK(launch_attention(ws.qkv, kc, vc, kt, cmax, ws.ao, rm, M, st)); }
+    // o_proj + residual
+    a.A = ws.ao; a.lda = HID; a.W = g->wo[l]; a.C = ws.x; a.ldc = HID; a.N = HID; a.K = HID; a.epi = EPI_RES; a.norm_w = nullptr;
+    a.res = ws.x; a.ldr = HID;
+    { Prof p(g, 4, st, prof_ok); CK(launch_gemm_skinny(a, st)); }
+    // RMSNorm + gate/up + SiLU*up
+    a.A = ws.x; a.W = g->wgu[l]; a.C = ws.act; a.ldc = INTER; a.N = INTER; a.K = HID; a.epi = EPI_SILU_MUL; a.norm_w = g->ln2[l];
+    a.res = nullptr;
+    { Prof p(g, 5, st, prof_ok); CK(launch_gemm_skinny(a, st)); }
+    // down_proj + residual
+    a.A = ws.act; a.lda = INTER; a.W = g->wd[l]; a.C = ws.x; a.ldc = HID; a.N = HID; a.K = INTER; a.epi = EPI_RES; a.norm_w = nullptr;
+    a.res = ws.x; a.ldr = HID;
+    { Prof p(g, 6, st, prof_ok); CK(launch_gemm_skinny(a, st)); }
+  }
+  { Prof p(g, 7, st, prof_ok);
+    CK(launch_final_norm(ws.x, q_per_b, g->w.norm, g->w.rms_eps, ws.hfin, s->hiddens, s->max_new, s->len, s->T, B, st)); }
+  {
+    GemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.taps = 1;
+    a.A = ws.hfin; a.lda = HID; a.W = g->w.heads; a.C = ws.logits; a.ldc = NVQ * NAUDIO; a.M = B; a.N = NVQ * NAUDIO; a.K = HID;
+    a.wt = WT_F32; a.epi = EPI_STORE;
+    Prof p(g, 8, st, prof_ok);
+    CK(launch_gemm_skinny(a, st));
+  }
+  { Prof p(g, 9, st, prof_ok); CK(launch_sample(make_sample_args(s, ws.logits), st)); }
+  return 0;
+}
+
+extern "C" int ctts_gpt_prefill(ctts_gpt* g, const ctts_gen_state* s, const float* emb, void* stream) {
+  if (check_state(g, s)) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  const GptWs ws = carve(s->workspace, s->B, s->T);
+  CK(hipMemcpyAsync(ws.x, emb, (size_t)s->B * s->T * HID * 4, hipMemcpyDeviceToDevice, st));
+  return run_step(g, s, s->T, st, false);
+}
+
+static int decode_body(ctts_gpt* g, const ctts_gen_state* s, hipStream_t st, bool prof_ok) {
+  const GptWs ws = carve(s->workspace, s->B, s->T);
+  { Prof p(g, 0, st, prof_ok); CK(launch_embed_codes(g->w.emb_code, s->ids_buf, s->T + s->max_new, s->len, ws.x, s->B, st)); }
+  return run_step(g, s, 1, st, prof_ok);
+}
+
+extern "C" int ctts_gpt_decode_step(ctts_gpt* g, const ctts_gen_state* s, void* stream) {
+  if (check_state(g, s)) return -1;
+  return decode_body(g, s, (hipStream_t)stream, true);
+}
+
+extern "C" int ctts_gpt_graph_build(ctts_gpt* g, const ctts_gen_state* s, void* stream) {
+  if (check_state(g, s)) return -1;
+  ctts_gpt_graph_destroy(g);
+  hipStream_t st = (hipStream_t)stream;
+  if (st == nullptr) return fail("graph capture needs a non-default stream");
+  CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+  const int rc = decode_body(g, s, st, false);
+  hipGraph_t graph = nullptr;
+  hipError_t e = hipStreamEndCapture(st, &graph);
+  if (rc != 0) { if (graph) (void)hipGraphDestroy(graph); return -1; }
+  if (e != hipSuccess) return fail("hipStreamEndCapture: %s", hipGetErrorString(e));
+  g->graph = graph;
+  CK(hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0));
+  return 0;
+}
+
+extern "C" int ctts_gpt_graph_launch(ctts_gpt* g, int32_t n_steps, void* stream) {
+  if (!g || !g->exec) return fail("no captured graph");
+  for (int i = 0; i < n_steps; ++i) CK(hipGraphLaunch(g->exec, (hipStream_t)stream));
+  return 0;
+}
+
+extern "C" int ctts_gpt_profile_begin(ctts_gpt* g, int32_t tag, int32_t max_samples) {
+  if (!g || max_samples <= 0) return fail("bad profile args");
+  while ((int)g->ev0.size() < max_samples) {
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a));
+    CK(hipEventCreate(&b));
+    g->ev0.push_back(a);
+    g->ev1.push_back(b);
+  }
+  g->prof_tag = tag; g->prof_max = max_samples; g->prof_n = 0;
+  return 0;
+}
+
+extern "C" int ctts_gpt_profile_end(ctts_gpt* g, int32_t* n_samples, double* total_ms) {
+  if (!g) return fail("null engine");
+  double tot = 0.0;
+  for (int i = 0; i < g->prof_n; ++i) {
+    CK(hipEventSynchronize(g->ev1[i]));
+    float ms = 0.f;
+    CK(hipEventElapsedTime(&ms, g->ev0[i], g->ev1[i]));
+    tot += ms;
+  }
+  if (n_samples) *n_samples = g->prof_n;
+  if (total_ms) *total_ms = tot;
+  g->prof_tag = -1; g->prof_n = 0;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+struct ctts_codec {
+  ctts_codec_weights w;
+  std::vector<const float*> d[9], v[9];
+};
+
+extern "C" int ctts_codec_create(ctts_codec** out, const ctts_codec_weights* w) {
+  if (!out || !w) return fail("ctts_codec_create: bad arguments");
+  ctts_codec* c = new ctts_codec();
+  c->w = *w;
+  const float* const* dsrc[9] = {w->d_dw_w, w->d_dw_b, w->d_ln_w, w->d_ln_b, w->d_pw1_w, w->d_pw1_b, w->d_pw2_w, w->d_pw2_b, w->d_gamma};
+  const float* const* vsrc[9] = {w->v_dw_w, w->v_dw_b, w->v_ln_w, w->v_ln_b, w->v_pw1_w, w->v_pw1_b, w->v_pw2_w, w->v_pw2_b, w->v_gamma};
+  for (int i = 0; i < 9; ++i) {
+    c->d[i].assign(dsrc[i], dsrc[i] + w->n_dvae_blocks);
+    c->v[i].assign(vsrc[i], vsrc[i] + w->n_vocos_blocks);
+  }
+  *out = c;
+  return 0;
+}
+extern "C" void ctts_codec_destroy(ctts_codec* c) { delete c; }
+
+struct CodecWs {
+  float *a, *b, *big, *mid, *frames;
+  size_t bytes;
+};
+static CodecWs carve_codec(void* base, int B, int F) {
+  const size_t R = (size_t)B * F;
+  CodecWs w;
+  size_t off = 0;
+  char* p = (char*)base;
+  w.a = (float*)(p + off); off += align_up(R * 512 * 4);
+  w.b = (float*)(p + off); off += align_up(R * 512 * 4);
+  w.big = (float*)(p + off); off += align_up(R * 2048 * 4);
+  w.mid = (float*)(p + off); off += align_up(R * 384 * 4);
+  w.frames = (float*)(p + off); off += align_up(R * 1024 * 4);
+  w.bytes = off;
+  return w;
+}
+extern "C" size_t ctts_codec_workspace_bytes(int32_t B, int32_t F) { return carve_codec(nullptr, B, F).bytes; }
+
+static GemmArgs lin(const float* A, int lda, const float* W, float* C, int ldc, int M, int N, int K, int epi) {
+  GemmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.A = A; a.lda = lda; a.W = W; a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.wt = WT_F32; a.epi = epi; a.taps = 1;
+  return a;
+}
+static GemmArgs conv(const float* X, int cin, const float* W, float* C, int cout, int B, int F, int taps, int pad, int epi) {
+  GemmArgs a = lin(X, cin, W, C, cout, B * F, cout, taps * cin, epi);
+  a.taps = taps; a.cin = cin; a.frames = F; a.pad = pad; a.dil = 1;
+  return a;
+}
+
+static int convnext_stack(int n, std::vector<const float*>* p, int inter, int dil, CodecWs& ws, int B, int F, hipStream_t st) {
+  const int R = B * F;
+  for (int i = 0; i < n; ++i) {
+    CK(launch_dwconv_ln(ws.a, p[0][i], p[1][i], p[2][i], p[3][i], 1e-6f, dil, ws.b, B, F, 512, st));
+    GemmArgs g1 = lin(ws.b, 512, p[4][i], ws.big, inter, R, inter, 512, EPI_BIAS_GELU);
+    g1.bias = p[5][i];
+    CK(launch_gemm_tiled(g1, st));
+    GemmArgs g2 = lin(ws.big, inter, p[6][i], ws.a, 512, R, 512, inter, EPI_BIAS_SCALE_RES);
+    g2.bias = p[7][i]; g2.gamma = p[8][i]; g2.res = ws.a; g2.ldr = 512;
+    CK(launch_gemm_tiled(g2, st));
+  }
+  return 0;
+}
+
+extern "C" int ctts_dvae_decode(ctts_codec* c, const float* hid, float* mel, int32_t B, int32_t T, void* workspace, size_t ws_bytes,
+                                void* stream) {
+  if (!c || B <= 0 || T <= 0) return fail("ctts_dvae_decode: bad arguments");
+  const int F = 2 * T;
+  if (ws_bytes < ctts_codec_workspace_bytes(B, F)) return fail("codec workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  CodecWs ws = carve_codec(workspace, B, F);
+  // dvae.py:281-287: [B,T,768] viewed as [B,2T,384] channels-last
+  GemmArgs c0 = conv(hid, 384, c->w.conv_in0_w, ws.big, 128, B, F, 3, 1, EPI_BIAS_GELU);
+  c0.bias = c->w.conv_in0_b;
+  CK(launch_gemm_tiled(c0, st));
+  GemmArgs c2 = conv(ws.big, 128, c->w.conv_in2_w, ws.a, 512, B, F, 3, 1, EPI_BIAS);
+  c2.bias = c->w.conv_in2_b;
+  CK(launch_gemm_tiled(c2, st));
+  if (convnext_stack(c->w.n_dvae_blocks, c->d, 2048, 2, ws, B, F, st)) return -1;
+  CK(launch_gemm_tiled(lin(ws.a, 512, c->w.conv_out_w, ws.mid, 384, B * F, 384, 512, EPI_STORE), st));
+  GemmArgs oc = conv(ws.mid, 384, c->w.out_conv_w, mel, 100, B, F, 3, 1, EPI_SCALE);
+  oc.gamma = c->w.coef;
+  CK(launch_gemm_tiled(oc, st));
+  return 0;
+}
+
+extern "C" int ctts_vocos_decode(ctts_codec* c, const float* mel, float* wav, int32_t B, int32_t F, void* workspace, size_t ws_bytes,
+                                 void* stream) {
+  if (!c || B <= 0 || F < 2) return fail("ctts_vocos_decode: bad arguments");
+  if (ws_bytes < ctts_codec_workspace_bytes(B, F)) return fail("codec workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  CodecWs ws = carve_codec(workspace, B, F);
+  GemmArgs e = conv(mel, 100, c->w.v_embed_w, ws.b, 512, B, F, 7, 3, EPI_BIAS);
+  e.bias = c->w.v_embed_b;
+  CK(launch_gemm_tiled(e, st));
+  CK(launch_layernorm(ws.b, c->w.v_norm_w, c->w.v_norm_b, 1e-6f, ws.a, B * F, 512, st));
+  if (convnext_stack(c->w.n_vocos_blocks, c->v, 1536, 1, ws, B, F, st)) return -1;
+  CK(launch_layernorm(ws.a, c->w.v_final_w, c->w.v_final_b, 1e-6f, ws.b, B * F, 512, st));
+  GemmArgs h = lin(ws.b, 512, c->w.head_w, ws.big, 1026, B * F, 1026, 512, EPI_BIAS);
+  h.bias = c->w.head_b;
+  CK(launch_gemm_tiled(h, st));
+  CK(launch_istft(ws.big, c->w.window, c->w.twiddle, ws.frames, wav, B, F, st));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// single-kernel entry points
+// ------------------------------------------------------------------------------------------------
+extern "C" int ctts_k_gemm(int32_t tiled, const float* A, const void* W, float* C, int32_t M, int32_t N, int32_t K, int32_t lda,
+                           int32_t ldc, int32_t wt, int32_t epi, const float* norm_w, float eps, const float* res, int32_t ldr,
+                           const float* bias, const float* gamma, int32_t taps, int32_t cin, int32_t frames, int32_t pad, int32_t dil,
+                           void* stream) {
+  GemmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.A = A; a.W = W; a.C = C; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldc = ldc; a.wt = wt; a.epi = epi; a.norm_w = norm_w; a.eps = eps;
+  a.res = res; a.ldr = ldr; a.bias = bias; a.gamma = gamma; a.taps = taps > 0 ? taps : 1; a.cin = cin; a.frames = frames; a.pad = pad;
+  a.dil = dil;
+  CK(tiled ? launch_gemm_tiled(a, (hipStream_t)stream) : launch_gemm_skinny(a, (hipStream_t)stream));
+  return 0;
+}
+extern "C" int ctts_k_rope_append(float* qkv, void* kcache, void* vcache, int32_t kv_dtype, int32_t cmax, const float* cos_tab,
+                                  const float* sin_tab, int32_t q_per_b, const int32_t* len, const int32_t* kv_start, int32_t M,
+                                  void* stream) {
+  GptRowMap rm{q_per_b, len, kv_start};
+  CK(launch_rope_append(qkv, kcache, vcache, kv_dtype, cmax, cos_tab, sin_tab, rm, M, (hipStream_t)stream));
+  return 0;
+}
+extern "C" int ctts_k_attention(const float* qkv, const void* kcache, const void* vcache, int32_t kv_dtype, int32_t cmax, float* out,
+                                int32_t q_per_b, const int32_t* len, const int32_t* kv_start, int32_t M, void* stream) {
+  GptRowMap rm{q_per_b, len, kv_start};
+  CK(launch_attention(qkv, kcache, vcache, kv_dtype, cmax, out, rm, M, (hipStream_t)stream));
+  return 0;
+}
+extern "C" int ctts_k_embed_codes(const float* emb_code, const int64_t* ids_buf, int32_t tcap, const int32_t* len, float* x, int32_t B,
+                                  void* stream) {
+  CK(launch_embed_codes(emb_code, ids_buf, tcap, len, x, B, (hipStream_t)stream));
+  return 0;
+}
+extern "C" int ctts_k_final_norm(const float* x, int32_t q_per_b, const float* w, float eps, float* hfin, float* hiddens,
+                                 int32_t max_new, const int32_t* len, int32_t T, int32_t B, void* stream) {
+  CK(launch_final_norm(x, q_per_b, w, eps, hfin, hiddens, max_new, len, T, B, (hipStream_t)stream));
+  return 0;
+}
+extern "C" int ctts_k_sample(const ctts_gen_state* s, const float* logits, void* stream) {
+  if (!s || !logits) return fail("ctts_k_sample: bad arguments");
+  CK(launch_sample(make_sample_args(s, logits), (hipStream_t)stream));
+  return 0;
+}
+extern "C" int ctts_k_dwconv_ln(const float* x, const float* w, const float* b, const float* ln_w, const float* ln_b, float eps,
+                                int32_t dil, float* y, int32_t B, int32_t F, void* stream) {
+  CK(launch_dwconv_ln(x, w, b, ln_w, ln_b, eps, dil, y, B, F, 512, (hipStream_t)stream));
+  return 0;
+}
+extern "C" int ctts_k_layernorm(const float* x, const float* w, const float* b, float eps, float* y, int32_t rows, void* stream) {
+  CK(launch_layernorm(x, w, b, eps, y, rows, 512, (hipStream_t)stream));
+  return 0;
+}
+extern "C" int ctts_k_istft(const float* head, const float* window, const float* twiddle, float* frames, float* wav, int32_t B,
+                            int32_t F, void* stream) {
+  CK(launch_istft(head, window, twiddle, frames, wav, B, F, (hipStream_t)stream));
+  return 0;
+}

@@ -1,0 +1,160 @@
+// Acoustic-decoder kernels for gfx950 that are not GEMMs (channels-last [B, F, C] layout):
+//   dwconv_ln : ConvNeXt depthwise Conv1d(k7, dilation d, zero pad 3d) + LayerNorm(512, eps 1e-6)
+//               (/root/reference/ChatTTS/model/dvae.py:26-35,49-52 and vocos.modules.ConvNeXtBlock)
+//   layernorm : LayerNorm(512) (VocosBackbone.norm / final_layer_norm)
+//   istft     : ISTFTHead tail -- mag = min(exp(.), 1e2), S = mag (cos p + i sin p), per-frame
+//               irfft(1024) x hann window, overlap-add, / window envelope, trim 512 each side
+//               (/root/reference/examples/onnx/exporter.py:395-404 + torch.istft(center=True)).
+// All three are HBM-bound streaming kernels: one wave per frame, 8 contiguous channels per lane
+// (two 16-byte loads), wave-shuffle reductions for the LayerNorm statistics.
+#include "common.hpp"
+#include "kernels.hpp"
+
+#define CCH 512  // channel count of both ConvNeXt stacks
+
+__device__ __forceinline__ void ln_finish(float* y, const float* __restrict__ lw, const float* __restrict__ lb, float eps, int c0,
+                                          float* __restrict__ dst) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += y[i];
+  const float mean = wave_sum(s) * (1.0f / CCH);
+  float v = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { const float d = y[i] - mean; v += d * d; }
+  const float rstd = 1.0f / sqrtf(wave_sum(v) * (1.0f / CCH) + eps);
+  const float4 w0 = *reinterpret_cast<const float4*>(lw + c0), w1 = *reinterpret_cast<const float4*>(lw + c0 + 4);
+  const float4 b0 = *reinterpret_cast<const float4*>(lb + c0), b1 = *reinterpret_cast<const float4*>(lb + c0 + 4);
+  float4 o0, o1;
+  o0.x = (y[0] - mean) * rstd * w0.x + b0.x; o0.y = (y[1] - mean) * rstd * w0.y + b0.y;
+  o0.z = (y[2] - mean) * rstd * w0.z + b0.z; o0.w = (y[3] - mean) * rstd * w0.w + b0.w;
+  o1.x = (y[4] - mean) * rstd * w1.x + b1.x; o1.y = (y[5] - mean) * rstd * w1.y + b1.y;
+  o1.z = (y[6] - mean) * rstd * w1.z + b1.z; o1.w = (y[7] - mean) * rstd * w1.w + b1.w;
+  *reinterpret_cast<float4*>(dst + c0) = o0;
+  *reinterpret_cast<float4*>(dst + c0 + 4) = o1;
+}
+
+// w is the depthwise kernel transposed on the host to [7][C] so that a lane's 8 channels are contiguous
+__global__ __launch_bounds__(256) void dwconv_ln_k(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                                   const float* __restrict__ lw, const float* __restrict__ lb, float eps, int dil,
+                                                   float* __restrict__ y, int F, int rows) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63, c0 = lane * 8;
+  const int bi = row / F, f = row - bi * F;
+  float acc[8];
+  {
+    const float4 b0 = *reinterpret_cast<const float4*>(b + c0), b1 = *reinterpret_cast<const float4*>(b + c0 + 4);
+    acc[0] = b0.x; acc[1] = b0.y; acc[2] = b0.z; acc[3] = b0.w; acc[4] = b1.x; acc[5] = b1.y; acc[6] = b1.z; acc[7] = b1.w;
+  }
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    const int fs = f + (j - 3) * dil;
+    if (fs >= 0 && fs < F) {
+      const float* xp = x + ((size_t)bi * F + fs) * CCH + c0;
+      const float4 x0 = *reinterpret_cast<const float4*>(xp), x1 = *reinterpret_cast<const float4*>(xp + 4);
+      const float4 w0 = *reinterpret_cast<const float4*>(w + j * CCH + c0), w1 = *reinterpret_cast<const float4*>(w + j * CCH + c0 + 4);
+      acc[0] = fmaf(w0.x, x0.x, acc[0]); acc[1] = fmaf(w0.y, x0.y, acc[1]); acc[2] = fmaf(w0.z, x0.z, acc[2]); acc[3] = fmaf(w0.w, x0.w, acc[3]);
+      acc[4] = fmaf(w1.x, x1.x, acc[4]); acc[5] = fmaf(w1.y, x1.y, acc[5]); acc[6] = fmaf(w1.z, x1.z, acc[6]); acc[7] = fmaf(w1.w, x1.w, acc[7]);
+    }
+  }
+  ln_finish(acc, lw, lb, eps, c0, y + (size_t)row * CCH);
+}
+
+hipError_t launch_dwconv_ln(const float* x, const float* w, const float* b, const float* ln_w, const float* ln_b, float eps, int dil,
+                            float* y, int B, int F, int C, hipStream_t st) {
+  if (C != CCH) return hipErrorInvalidValue;
+  const int rows = B * F;
+  hipLaunchKernelGGL(dwconv_ln_k, dim3((rows + 3) / 4), dim3(256), 0, st, x, w, b, ln_w, ln_b, eps, dil, y, F, rows);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void layernorm_k(const float* __restrict__ x, const float* __restrict__ lw, const float* __restrict__ lb,
+                                                   float eps, float* __restrict__ y, int rows) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63, c0 = lane * 8;
+  const float* xp = x + (size_t)row * CCH + c0;
+  const float4 x0 = *reinterpret_cast<const float4*>(xp), x1 = *reinterpret_cast<const float4*>(xp + 4);
+  float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+  ln_finish(v, lw, lb, eps, c0, y + (size_t)row * CCH);
+}
+
+hipError_t launch_layernorm(const float* x, const float* w, const float* b, float eps, float* y, int rows, int C, hipStream_t st) {
+  if (C != CCH) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(layernorm_k, dim3((rows + 3) / 4), dim3(256), 0, st, x, w, b, eps, y, rows);
+  return hipGetLastError();
+}
+
+// ---- ISTFT -----------------------------------------------------------------------------------
+#define NFFT 1024
+#define NBIN 513
+#define HOP 256
+
+// one workgroup per frame: build the Hermitian-extended spectrum in LDS, 1024-point inverse complex
+// radix-2 DIT FFT (10 stages, 512 butterflies per stage, 2 per thread), keep the real part, scale by
+// window / N.  twiddle[k] = (cos, sin)(2 pi k / 1024), k < 512, computed in double on the host.
+__global__ __launch_bounds__(256) void istft_frames_k(const float* __restrict__ head, const float* __restrict__ window,
+                                                      const float2* __restrict__ tw, float* __restrict__ frames) {
+  __shared__ float re[NFFT], im[NFFT];
+  const int fr = blockIdx.x, t = threadIdx.x;
+  const float* hp = head + (size_t)fr * (2 * NBIN);
+  for (int k = t; k < NBIN; k += 256) {
+    const float mag = fminf(expf(hp[k]), 100.0f);
+    const float ph = hp[NBIN + k];
+    float xr = mag * cosf(ph), xi = mag * sinf(ph);
+    if (k == 0 || k == NFFT / 2) xi = 0.f;  // c2r ignores the imaginary part of DC and Nyquist
+    const int r0 = __brev((unsigned)k) >> 22;  // 10-bit bit reversal
+    re[r0] = xr; im[r0] = xi;
+    if (k > 0 && k < NFFT / 2) {
+      const int r1 = __brev((unsigned)(NFFT - k)) >> 22;
+      re[r1] = xr; im[r1] = -xi;
+    }
+  }
+  __syncthreads();
+#pragma unroll 1
+  for (int s = 1; s <= 10; ++s) {
+    const int half = 1 << (s - 1);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int bt = t + 256 * u;
+      const int pos = bt & (half - 1);
+      const int i = ((bt >> (s - 1)) << s) + pos, j = i + half;
+      const float2 w = tw[pos << (10 - s)];  // e^{+2 pi i pos / 2^s}
+      const float ur = re[i], ui = im[i];
+      const float vr = re[j] * w.x - im[j] * w.y, vi = re[j] * w.y + im[j] * w.x;
+      re[i] = ur + vr; im[i] = ui + vi;
+      re[j] = ur - vr; im[j] = ui - vi;
+    }
+    __syncthreads();
+  }
+  float* fp = frames + (size_t)fr * NFFT;
+  for (int n = t; n < NFFT; n += 256) fp[n] = re[n] * (1.0f / NFFT) * window[n];
+}
+
+// overlap-add + envelope division + center trim:  wav[b, n], n in [0, HOP*(F-1))
+__global__ __launch_bounds__(256) void istft_ola_k(const float* __restrict__ frames, const float* __restrict__ window,
+                                                   float* __restrict__ wav, int F, int wlen) {
+  const int b = blockIdx.y;
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= wlen) return;
+  const int tt = n + NFFT / 2;
+  int f_hi = tt / HOP; if (f_hi > F - 1) f_hi = F - 1;
+  int f_lo = (tt - (NFFT - 1) + HOP - 1) / HOP; if (f_lo < 0) f_lo = 0;
+  float y = 0.f, env = 0.f;
+  for (int f = f_lo; f <= f_hi; ++f) {
+    const int o = tt - f * HOP;
+    y += frames[((size_t)b * F + f) * NFFT + o];
+    const float w = window[o];
+    env += w * w;
+  }
+  wav[(size_t)b * wlen + n] = y / env;
+}
+
+hipError_t launch_istft(const float* head, const float* window, const float* twiddle, float* frames, float* wav, int B, int F,
+                        hipStream_t st) {
+  if (F < 2) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(istft_frames_k, dim3(B * F), dim3(256), 0, st, head, window, (const float2*)twiddle, frames);
+  const int wlen = HOP * (F - 1);
+  hipLaunchKernelGGL(istft_ola_k, dim3((wlen + 255) / 256, B), dim3(256), 0, st, frames, window, wav, F, wlen);
+  return hipGetLastError();
+}

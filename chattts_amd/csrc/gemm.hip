@@ -1,0 +1,288 @@
+// GEMM kernels for gfx950:  C[M,N] = epi( pro(A)[M,K] * W[N,K]^T ),  A/C float32, W float32 or bf16.
+//
+//  gemm_skinny : the decode/prefill projection kernel of the GPT path (reference: the nn.Linear calls
+//     inside HF LlamaModel.forward reached from /root/reference/ChatTTS/model/gpt.py:419-427 and the
+//     heads of gpt.py:438-454).  M is the number of live token rows (<= 64 per tile), so the kernel is
+//     weight-streaming bound: one workgroup owns 16 output columns, its 4 waves split K (interleaved
+//     chunks, so the workgroup reads 256 contiguous bytes of every W row per iteration), every lane
+//     pulls its W fragment straight from HBM with one 16-byte load per chunk (no LDS round trip for an
+//     operand that is used once), MFMA 16x16x32 bf16 / 16x16x4 f32 accumulates, the 4 partial tiles are
+//     reduced through LDS in a fixed order (deterministic), and RMSNorm / residual / SiLU*up are fused
+//     as prologue / epilogue so a decoder layer is 6 launches.
+//  gemm_tiled  : 64x64x32 LDS-tiled f32 MFMA (32x32x2) kernel for the large-M dense layers of the
+//     acoustic decoder (DVAE /root/reference/ChatTTS/model/dvae.py:145-161, Vocos backbone/head), with
+//     conv-as-GEMM gather on the A side and bias / GELU / layer-scale+residual / coef epilogues.
+//
+// f32-input MFMA is an exact k-ordered fmaf chain on gfx950 (MI355X guide), which is what the f32
+// "parity" mode relies on.
+#include "common.hpp"
+#include "kernels.hpp"
+
+// ------------------------------------------------------------------------------------------------
+// skinny
+// ------------------------------------------------------------------------------------------------
+template <typename WT> struct WTraits;
+template <> struct WTraits<float>  { static constexpr int EPL = 4; };  // elements per 16-byte lane load
+template <> struct WTraits<bf16_t> { static constexpr int EPL = 8; };
+
+template <typename WT, int MB, bool RMS, int EPI>
+__global__ __launch_bounds__(256) void gemm_skinny_k(GemmArgs a) {
+  constexpr int EPL = WTraits<WT>::EPL;
+  constexpr int KC = EPL * 4;  // k covered by one lane-load step of the wave (4 lane groups)
+  constexpr int NACC = (EPI == EPI_SILU_MUL) ? 2 : 1;
+  constexpr int U = 3;         // chunks in flight per wave
+  __shared__ float red[4][NACC][MB][64][4];
+  __shared__ float rstd_s[16 * MB];
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 15, g = lane >> 4;
+  const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16 * MB;
+  const int M = a.M, N = a.N, K = a.K;
+
+  if (RMS) {
+    for (int r = wave; r < 16 * MB; r += 4) {
+      const int m = min(m0 + r, M - 1);
+      const float* row = a.A + (size_t)m * a.lda;
+      float ss = 0.f;
+      for (int k = lane * 4; k < K; k += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(row + k);
+        ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+      }
+      ss = wave_sum(ss);
+      if (lane == 0) rstd_s[r] = 1.0f / sqrtf(ss / (float)K + a.eps);
+    }
+    __syncthreads();
+  }
+
+  const WT* W = reinterpret_cast<const WT*>(a.W);
+  const int n = min(n0 + li, N - 1);
+  const WT* wrow = W + (size_t)n * K;
+  const WT* wrow2 = wrow + (size_t)N * K;  // "up" rows (EPI_SILU_MUL only)
+  const float* arow[MB];
+  float rs[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    arow[mb] = a.A + (size_t)min(m0 + 16 * mb + li, M - 1) * a.lda;
+    rs[mb] = RMS ? rstd_s[16 * mb + li] : 1.0f;
+  }
+
+  f32x4 acc[NACC][MB];
+#pragma unroll
+  for (int na = 0; na < NACC; ++na)
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) acc[na][mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nper = K / (KC * 4);  // chunks per wave (launcher guarantees divisibility by U)
+  for (int i = 0; i < nper; i += U) {
+    u128 wf[NACC][U];
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      const int k0 = ((i + j) * 4 + wave) * KC + g * EPL;
+      wf[0][j] = *reinterpret_cast<const u128*>(wrow + k0);
+      if (NACC == 2) wf[1][j] = *reinterpret_cast<const u128*>(wrow2 + k0);
+    }
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      const int k0 = ((i + j) * 4 + wave) * KC + g * EPL;
+      if constexpr (EPL == 8) {
+        float4 nw0, nw1;
+        if (RMS) {
+          nw0 = *reinterpret_cast<const float4*>(a.norm_w + k0);
+          nw1 = *reinterpret_cast<const float4*>(a.norm_w + k0 + 4);
+        }
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+          float4 a0 = *reinterpret_cast<const float4*>(arow[mb] + k0);
+          float4 a1 = *reinterpret_cast<const float4*>(arow[mb] + k0 + 4);
+          if (RMS) {
+            const float s = rs[mb];
+            a0.x = nw0.x * (a0.x * s); a0.y = nw0.y * (a0.y * s); a0.z = nw0.z * (a0.z * s); a0.w = nw0.w * (a0.w * s);
+            a1.x = nw1.x * (a1.x * s); a1.y = nw1.y * (a1.y * s); a1.z = nw1.z * (a1.z * s); a1.w = nw1.w * (a1.w * s);
+          }
+          bf16x8 af;
+          af[0] = (__bf16)a0.x; af[1] = (__bf16)a0.y; af[2] = (__bf16)a0.z; af[3] = (__bf16)a0.w;
+          af[4] = (__bf16)a1.x; af[5] = (__bf16)a1.y; af[6] = (__bf16)a1.z; af[7] = (__bf16)a1.w;
+#pragma unroll
+          for (int na = 0; na < NACC; ++na) {
+            const bf16x8 bfv = *reinterpret_cast<const bf16x8*>(&wf[na][j]);
+            acc[na][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfv, acc[na][mb], 0, 0, 0);
+          }
+        }
+      } else {
+        float4 nw0;
+        if (RMS) nw0 = *reinterpret_cast<const float4*>(a.norm_w + k0);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+          float4 a0 = *reinterpret_cast<const float4*>(arow[mb] + k0);
+          if (RMS) {
+            const float s = rs[mb];
+            a0.x = nw0.x * (a0.x * s); a0.y = nw0.y * (a0.y * s); a0.z = nw0.z * (a0.z * s); a0.w = nw0.w * (a0.w * s);
+          }
+#pragma unroll
+          for (int na = 0; na < NACC; ++na) {
+            const float4 b = *reinterpret_cast<const float4*>(&wf[na][j]);
+            f32x4 c = acc[na][mb];
+            c = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b.x, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b.y, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b.z, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b.w, c, 0, 0, 0);
+            acc[na][mb] = c;
+          }
+        }
+      }
+    }
+  }
+
+  // cross-wave (split-K) reduction, fixed order w = 0..3
+#pragma unroll
+  for (int na = 0; na < NACC; ++na)
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[wave][na][mb][lane][r] = acc[na][mb][r];
+  __syncthreads();
+  if (wave < MB) {
+    const int mb = wave;
+    const int col = n0 + li;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = m0 + 16 * mb + 4 * g + r;  // C/D map of 16x16 MFMA: col = lane&15, row = 4*(lane>>4)+reg
+      float v = ((red[0][0][mb][lane][r] + red[1][0][mb][lane][r]) + red[2][0][mb][lane][r]) + red[3][0][mb][lane][r];
+      if (row < M && col < N) {
+        if (EPI == EPI_SILU_MUL) {
+          const float u = ((red[0][NACC - 1][mb][lane][r] + red[1][NACC - 1][mb][lane][r]) + red[2][NACC - 1][mb][lane][r]) +
+                          red[3][NACC - 1][mb][lane][r];
+          v = silu_f(v) * u;
+        } else if (EPI == EPI_RES) {
+          v = a.res[(size_t)row * a.ldr + col] + v;
+        }
+        a.C[(size_t)row * a.ldc + col] = v;
+      }
+    }
+  }
+}
+
+template <typename WT, int MB>
+static hipError_t skinny_dispatch(const GemmArgs& a, hipStream_t st) {
+  dim3 grid((a.N + 15) / 16, (a.M + 16 * MB - 1) / (16 * MB)), block(256);
+  const bool rms = a.norm_w != nullptr;
+  if (a.epi == EPI_STORE && rms) hipLaunchKernelGGL((gemm_skinny_k<WT, MB, true, EPI_STORE>), grid, block, 0, st, a);
+  else if (a.epi == EPI_STORE) hipLaunchKernelGGL((gemm_skinny_k<WT, MB, false, EPI_STORE>), grid, block, 0, st, a);
+  else if (a.epi == EPI_RES && !rms) hipLaunchKernelGGL((gemm_skinny_k<WT, MB, false, EPI_RES>), grid, block, 0, st, a);
+  else if (a.epi == EPI_SILU_MUL && rms) hipLaunchKernelGGL((gemm_skinny_k<WT, MB, true, EPI_SILU_MUL>), grid, block, 0, st, a);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+hipError_t launch_gemm_skinny(const GemmArgs& a, hipStream_t st) {
+  const int epl = (a.wt == WT_BF16) ? 8 : 4;
+  if (a.M <= 0 || a.N <= 0 || a.K % (epl * 4 * 4 * 3) != 0 || (a.lda % 4) != 0) return hipErrorInvalidValue;
+  if (a.wt == WT_BF16) {
+    if (a.M <= 16) return skinny_dispatch<bf16_t, 1>(a, st);
+    if (a.M <= 32) return skinny_dispatch<bf16_t, 2>(a, st);
+    return skinny_dispatch<bf16_t, 4>(a, st);
+  }
+  if (a.M <= 16) return skinny_dispatch<float, 1>(a, st);
+  if (a.M <= 32) return skinny_dispatch<float, 2>(a, st);
+  return skinny_dispatch<float, 4>(a, st);
+}
+
+// ------------------------------------------------------------------------------------------------
+// tiled (f32 weights)
+// ------------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_tiled_f32_k(GemmArgs a) {
+  constexpr int BM = 64, BN = 64, BK = 32, LD = BK + 1;  // +1 pad: conflict-free ds_read_b32 of MFMA fragments
+  __shared__ float As[BM][LD];
+  __shared__ float Ws[BN][LD];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int M = a.M, N = a.N, K = a.K;
+  const float* W = reinterpret_cast<const float*>(a.W);
+
+  // loader coordinates: 8 lanes cover one 128-byte row segment (32 floats)
+  const int lr = tid >> 3, lk = (tid & 7) * 4;
+  // per-thread gather bases for its two A rows (rows lr and lr+32)
+  int ab[2], af[2];
+  bool aval[2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int m = m0 + lr + 32 * p;
+    aval[p] = m < M;
+    if (a.taps > 1) { ab[p] = m / a.frames; af[p] = m - ab[p] * a.frames; } else { ab[p] = 0; af[p] = m; }
+  }
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  for (int k0 = 0; k0 < K; k0 += BK) {
+    const int k = k0 + lk;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (aval[p] && k < K) {
+        if (a.taps > 1) {
+          const int tap = k / a.cin, c = k - tap * a.cin;
+          const int fs = af[p] + (tap - a.pad) * a.dil;
+          if (fs >= 0 && fs < a.frames) v = *reinterpret_cast<const float4*>(a.A + ((size_t)ab[p] * a.frames + fs) * a.lda + c);
+        } else {
+          v = *reinterpret_cast<const float4*>(a.A + (size_t)af[p] * a.lda + k);
+        }
+      }
+      float* dst = &As[lr + 32 * p][lk];
+      dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+      float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int nn = n0 + lr + 32 * p;
+      if (nn < N && k < K) w = *reinterpret_cast<const float4*>(W + (size_t)nn * K + k);
+      float* dw = &Ws[lr + 32 * p][lk];
+      dw[0] = w.x; dw[1] = w.y; dw[2] = w.z; dw[3] = w.w;
+    }
+    __syncthreads();
+    const int ri = lane & 31, kh = lane >> 5;
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      const float av = As[wm * 32 + ri][kk + kh];
+      const float bv = Ws[wn * 32 + ri][kk + kh];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  const int col = n0 + wn * 32 + (lane & 31);
+  if (col < N) {
+    float bias = 0.f, gam = 1.f;
+    if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_SCALE_RES) bias = a.bias[col];
+    if (EPI == EPI_BIAS_SCALE_RES || EPI == EPI_SCALE) gam = a.gamma[col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);  // C/D map of 32x32 MFMA
+      if (row < M) {
+        float v = acc[r];
+        if (EPI == EPI_BIAS) v = v + bias;
+        else if (EPI == EPI_BIAS_GELU) v = gelu_erf(v + bias);
+        else if (EPI == EPI_BIAS_SCALE_RES) v = a.res[(size_t)row * a.ldr + col] + gam * (v + bias);
+        else if (EPI == EPI_RES) v = a.res[(size_t)row * a.ldr + col] + v;
+        else if (EPI == EPI_SCALE) v = v * gam;
+        a.C[(size_t)row * a.ldc + col] = v;
+      }
+    }
+  }
+}
+
+hipError_t launch_gemm_tiled(const GemmArgs& a, hipStream_t st) {
+  if (a.wt != WT_F32 || a.K % 4 != 0 || a.lda % 4 != 0 || a.norm_w != nullptr) return hipErrorInvalidValue;
+  if (a.taps > 1 && (a.cin % 4 != 0 || a.K != a.taps * a.cin)) return hipErrorInvalidValue;
+  dim3 grid((a.N + 63) / 64, (a.M + 63) / 64), block(256);
+  switch (a.epi) {
+    case EPI_STORE: hipLaunchKernelGGL((gemm_tiled_f32_k<EPI_STORE>), grid, block, 0, st, a); break;
+    case EPI_RES: hipLaunchKernelGGL((gemm_tiled_f32_k<EPI_RES>), grid, block, 0, st, a); break;
+    case EPI_BIAS: hipLaunchKernelGGL((gemm_tiled_f32_k<EPI_BIAS>), grid, block, 0, st, a); break;
+    case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm_tiled_f32_k<EPI_BIAS_GELU>), grid, block, 0, st, a); break;
+    case EPI_BIAS_SCALE_RES: hipLaunchKernelGGL((gemm_tiled_f32_k<EPI_BIAS_SCALE_RES>), grid, block, 0, st, a); break;
+    case EPI_SCALE: hipLaunchKernelGGL((gemm_tiled_f32_k<EPI_SCALE>), grid, block, 0, st, a); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}

@@ -1,0 +1,458 @@
+// GPT-step kernels for gfx950 other than the projections: code-embedding sum, RoPE + KV append,
+// decode/prefill attention, final RMSNorm + hidden capture, and the fused sampling chain.
+// Reference call sites are cited per kernel; all of them live in the per-step body of
+// /root/reference/ChatTTS/model/gpt.py:396-577 or in the HF LlamaModel forward it calls.
+#include "common.hpp"
+#include "kernels.hpp"
+
+#define HID 768
+#define NHEAD 12
+#define HDIM 64
+#define NVQ 4
+#define NAUDIO 626
+
+__device__ __forceinline__ void row_to_b_slot(const GptRowMap& rm, int m, int& b, int& slot) {
+  if (rm.q_per_b == 1) { b = m; slot = rm.len[b] - 1; }
+  else { b = m / rm.q_per_b; slot = m - b * rm.q_per_b; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// G1  x[b] = sum_k emb_code[k][ids_buf[b, len[b]-1, k]]     (gpt.py:403-415; k-ordered f32 adds
+//     like torch.stack(code_emb, 3).sum(3))
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(192) void embed_codes_k(const float* __restrict__ emb, const int64_t* __restrict__ ids_buf,
+                                                     int tcap, const int32_t* __restrict__ len, float* __restrict__ x) {
+  const int b = blockIdx.x, t = threadIdx.x;
+  const int64_t* tok = ids_buf + ((size_t)b * tcap + (len[b] - 1)) * NVQ;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int k = 0; k < NVQ; ++k) {
+    int id = (int)tok[k];
+    id = min(max(id, 0), NAUDIO - 1);
+    const float4 v = *reinterpret_cast<const float4*>(emb + ((size_t)k * NAUDIO + id) * HID + t * 4);
+    if (k == 0) s = v; else { s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+  }
+  *reinterpret_cast<float4*>(x + (size_t)b * HID + t * 4) = s;
+}
+
+hipError_t launch_embed_codes(const float* emb_code, const int64_t* ids_buf, int tcap, const int32_t* len, float* x, int B,
+                              hipStream_t st) {
+  hipLaunchKernelGGL(embed_codes_k, dim3(B), dim3(192), 0, st, emb_code, ids_buf, tcap, len, x);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// G4  RoPE (rotate-half, HF modeling_llama apply_rotary_pos_emb; in-tree twin
+//     /root/reference/examples/onnx/modeling_llama.py:239-256) on q (in place) and k, then append k,v
+//     to the cache at `slot`.  Position = slot - kv_start[b] (gpt.py:234-241; pad slots get 1).
+//     cos/sin come from a host table built with the reference's own f32 ops.
+// ------------------------------------------------------------------------------------------------
+template <typename KT> __device__ __forceinline__ KT to_kt(float v);
+template <> __device__ __forceinline__ float to_kt<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t to_kt<bf16_t>(float v) { return f32_to_bf16(v); }
+
+template <typename KT>
+__global__ __launch_bounds__(384) void rope_append_k(float* __restrict__ qkv, KT* __restrict__ kc, KT* __restrict__ vc, int cmax,
+                                                     const float* __restrict__ cos_t, const float* __restrict__ sin_t,
+                                                     GptRowMap rm) {
+  const int m = blockIdx.x, t = threadIdx.x;  // t: head = t / 32, pair d = t % 32
+  int b, slot;
+  row_to_b_slot(rm, m, b, slot);
+  int pos = slot - rm.kv_start[b];
+  if (pos < 0) pos = 1;
+  const int h = t >> 5, d = t & 31;
+  const float c = cos_t[pos * 32 + d], s = sin_t[pos * 32 + d];
+  float* row = qkv + (size_t)m * (3 * HID);
+  // q
+  {
+    float* q = row + h * HDIM;
+    const float x1 = q[d], x2 = q[d + 32];
+    q[d] = x1 * c - x2 * s;
+    q[d + 32] = x2 * c + x1 * s;
+  }
+  const size_t base = (((size_t)b * NHEAD + h) * cmax + slot) * HDIM;
+  {
+    const float* k = row + HID + h * HDIM;
+    const float x1 = k[d], x2 = k[d + 32];
+    kc[base + d] = to_kt<KT>(x1 * c - x2 * s);
+    kc[base + d + 32] = to_kt<KT>(x2 * c + x1 * s);
+  }
+  {
+    const float* v = row + 2 * HID + h * HDIM;
+    vc[base + d] = to_kt<KT>(v[d]);
+    vc[base + d + 32] = to_kt<KT>(v[d + 32]);
+  }
+}
+
+hipError_t launch_rope_append(float* qkv, void* kcache, void* vcache, int kv_wt, int cmax, const float* cos_tab,
+                              const float* sin_tab, GptRowMap rm, int M, hipStream_t st) {
+  if (kv_wt == WT_BF16)
+    hipLaunchKernelGGL((rope_append_k<bf16_t>), dim3(M), dim3(384), 0, st, qkv, (bf16_t*)kcache, (bf16_t*)vcache, cmax, cos_tab,
+                       sin_tab, rm);
+  else
+    hipLaunchKernelGGL((rope_append_k<float>), dim3(M), dim3(384), 0, st, qkv, (float*)kcache, (float*)vcache, cmax, cos_tab,
+                       sin_tab, rm);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// G5  attention for one query row and one head: softmax_f32(q.K^T / 8 + mask) V with the causal +
+//     left-pad mask of the reference (keys in [kv_start[b], slot]).  KV is streamed from HBM with
+//     fully coalesced 16-byte lane loads: LPK lanes share one key row (128 B bf16 / 256 B f32), a wave
+//     load instruction covers 64/LPK consecutive keys = 1 KiB contiguous, 8 K-loads + 8 V-loads are in
+//     flight per wave per block; the dot product is finished with log2(LPK) xor-shuffles, softmax is
+//     online (running max / sum per wave) and the NW waves of a workgroup split the key blocks and
+//     merge through LDS.
+// ------------------------------------------------------------------------------------------------
+template <typename KT> struct KTraits;
+template <> struct KTraits<float>  { static constexpr int DPL = 4; };  // dims per lane (16 B)
+template <> struct KTraits<bf16_t> { static constexpr int DPL = 8; };
+
+template <typename KT, int DPL> __device__ __forceinline__ void unpack16(const u128& r, float* f);
+template <> __device__ __forceinline__ void unpack16<float, 4>(const u128& r, float* f) {
+  f[0] = __uint_as_float(r.x); f[1] = __uint_as_float(r.y); f[2] = __uint_as_float(r.z); f[3] = __uint_as_float(r.w);
+}
+template <> __device__ __forceinline__ void unpack16<bf16_t, 8>(const u128& r, float* f) {
+  f[0] = __uint_as_float(r.x << 16); f[1] = __uint_as_float(r.x & 0xffff0000u);
+  f[2] = __uint_as_float(r.y << 16); f[3] = __uint_as_float(r.y & 0xffff0000u);
+  f[4] = __uint_as_float(r.z << 16); f[5] = __uint_as_float(r.z & 0xffff0000u);
+  f[6] = __uint_as_float(r.w << 16); f[7] = __uint_as_float(r.w & 0xffff0000u);
+}
+
+template <typename KT, int NW>
+__global__ __launch_bounds__(64 * NW) void attention_k(const float* __restrict__ qkv, const KT* __restrict__ kc,
+                                                       const KT* __restrict__ vc, int cmax, float* __restrict__ out, GptRowMap rm) {
+  constexpr int DPL = KTraits<KT>::DPL;
+  constexpr int LPK = HDIM / DPL;   // lanes per key: 8 (bf16) / 16 (f32)
+  constexpr int KPI = 64 / LPK;     // keys per load instruction: 8 / 4
+  constexpr int NI = 8;             // load instructions per block
+  constexpr int KB = KPI * NI;      // keys per wave-block: 64 / 32
+  __shared__ float sm_m[NW], sm_l[NW], sm_acc[NW][HDIM];
+
+  const int h = blockIdx.x, m = blockIdx.y;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int kg = lane / LPK, dl = lane % LPK;
+  int b, slot;
+  row_to_b_slot(rm, m, b, slot);
+  int jlo = rm.kv_start[b];
+  if (jlo > slot) jlo = slot;  // pad query row: sees only itself (its output is never consumed)
+
+  float q[DPL];
+  {
+    const float* qp = qkv + (size_t)m * (3 * HID) + h * HDIM + dl * DPL;
+#pragma unroll
+    for (int i = 0; i < DPL; ++i) q[i] = qp[i] * 0.125f;  // 1/sqrt(64), exact power of two
+  }
+  const KT* kbase = kc + ((size_t)b * NHEAD + h) * cmax * HDIM + dl * DPL;
+  const KT* vbase = vc + ((size_t)b * NHEAD + h) * cmax * HDIM + dl * DPL;
+
+  float mrun = -INFINITY, lrun = 0.f, acc[DPL];
+#pragma unroll
+  for (int i = 0; i < DPL; ++i) acc[i] = 0.f;
+
+  for (int j0 = jlo + wave * KB; j0 <= slot; j0 += KB * NW) {
+    u128 kr[NI], vr[NI];
+    bool ok[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int j = j0 + i * KPI + kg;
+      ok[i] = j <= slot;
+      if (ok[i]) kr[i] = *reinterpret_cast<const u128*>(kbase + (size_t)j * HDIM);
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int j = j0 + i * KPI + kg;
+      if (ok[i]) vr[i] = *reinterpret_cast<const u128*>(vbase + (size_t)j * HDIM);
+    }
+    float s[NI];
+    float bmax = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      float kf[DPL];
+      float d = 0.f;
+      if (ok[i]) {
+        unpack16<KT, DPL>(kr[i], kf);
+#pragma unroll
+        for (int e = 0; e < DPL; ++e) d = fmaf(q[e], kf[e], d);
+      }
+#pragma unroll
+      for (int o = 1; o < LPK; o <<= 1) d += __shfl_xor(d, o, 64);
+      s[i] = ok[i] ? d : -INFINITY;
+      bmax = fmaxf(bmax, s[i]);
+    }
+#pragma unroll
+    for (int o = LPK; o < 64; o <<= 1) bmax = fmaxf(bmax, __shfl_xor(bmax, o, 64));
+    // bmax is finite: key j0 (i = 0, kg = 0) is always <= slot inside this loop
+    const float mnew = fmaxf(mrun, bmax);
+    const float alpha = expf(mrun - mnew);  // exp(-inf) = 0 on the first block
+    lrun *= alpha;
+#pragma unroll
+    for (int e = 0; e < DPL; ++e) acc[e] *= alpha;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      if (ok[i]) {
+        const float p = expf(s[i] - mnew);
+        lrun += p;
+        float vf[DPL];
+        unpack16<KT, DPL>(vr[i], vf);
+#pragma unroll
+        for (int e = 0; e < DPL; ++e) acc[e] = fmaf(p, vf[e], acc[e]);
+      }
+    }
+    mrun = mnew;
+  }
+  // merge the key groups of this wave (same running max in every lane)
+#pragma unroll
+  for (int o = LPK; o < 64; o <<= 1) {
+    lrun += __shfl_xor(lrun, o, 64);
+#pragma unroll
+    for (int e = 0; e < DPL; ++e) acc[e] += __shfl_xor(acc[e], o, 64);
+  }
+  // lrun was accumulated identically by the LPK lanes of a key group -> it already is the per-wave sum
+  if (NW == 1) {
+    if (kg == 0) {
+      const float inv = 1.0f / lrun;
+      float* op = out + (size_t)m * HID + h * HDIM + dl * DPL;
+#pragma unroll
+      for (int e = 0; e < DPL; ++e) op[e] = acc[e] * inv;
+    }
+    return;
+  }
+  if (kg == 0) {
+    if (dl == 0) { sm_m[wave] = mrun; sm_l[wave] = lrun; }
+#pragma unroll
+    for (int e = 0; e < DPL; ++e) sm_acc[wave][dl * DPL + e] = acc[e];
+  }
+  __syncthreads();
+  if (tid < HDIM) {
+    float M = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) M = fmaxf(M, sm_m[w]);
+    float L = 0.f, o = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const float sc = (sm_m[w] == -INFINITY) ? 0.f : expf(sm_m[w] - M);
+      L += sm_l[w] * sc;
+      o += sm_acc[w][tid] * sc;
+    }
+    out[(size_t)m * HID + h * HDIM + tid] = o / L;
+  }
+}
+
+hipError_t launch_attention(const float* qkv, const void* kcache, const void* vcache, int kv_wt, int cmax, float* out,
+                            GptRowMap rm, int M, hipStream_t st) {
+  dim3 grid(NHEAD, M);
+  const bool decode = rm.q_per_b == 1;
+  if (kv_wt == WT_BF16) {
+    if (decode) hipLaunchKernelGGL((attention_k<bf16_t, 4>), grid, dim3(256), 0, st, qkv, (const bf16_t*)kcache, (const bf16_t*)vcache, cmax, out, rm);
+    else hipLaunchKernelGGL((attention_k<bf16_t, 1>), grid, dim3(64), 0, st, qkv, (const bf16_t*)kcache, (const bf16_t*)vcache, cmax, out, rm);
+  } else {
+    if (decode) hipLaunchKernelGGL((attention_k<float, 4>), grid, dim3(256), 0, st, qkv, (const float*)kcache, (const float*)vcache, cmax, out, rm);
+    else hipLaunchKernelGGL((attention_k<float, 1>), grid, dim3(64), 0, st, qkv, (const float*)kcache, (const float*)vcache, cmax, out, rm);
+  }
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// G8  final RMSNorm of the last position of every row; the f32 result is the step's hidden state
+//     (gpt.py:430-436) -> hiddens[b, gen] and the staging row read by the heads GEMM.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(192) void final_norm_k(const float* __restrict__ x, int q_per_b, const float* __restrict__ w, float eps,
+                                                    float* __restrict__ hfin, float* __restrict__ hiddens, int max_new,
+                                                    const int32_t* __restrict__ len, int T) {
+  __shared__ float part[3];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const float* row = x + ((size_t)b * q_per_b + (q_per_b - 1)) * HID;
+  const float4 v = *reinterpret_cast<const float4*>(row + t * 4);
+  float ss = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  ss = wave_sum(ss);
+  if ((t & 63) == 0) part[t >> 6] = ss;
+  __syncthreads();
+  const float rstd = 1.0f / sqrtf(((part[0] + part[1]) + part[2]) / (float)HID + eps);
+  const float4 g = *reinterpret_cast<const float4*>(w + t * 4);
+  float4 o;
+  o.x = g.x * (v.x * rstd); o.y = g.y * (v.y * rstd); o.z = g.z * (v.z * rstd); o.w = g.w * (v.w * rstd);
+  *reinterpret_cast<float4*>(hfin + (size_t)b * HID + t * 4) = o;
+  const int gen = len[b] - T;
+  if (hiddens != nullptr && gen >= 0 && gen < max_new)
+    *reinterpret_cast<float4*>(hiddens + ((size_t)b * max_new + gen) * HID + t * 4) = o;
+}
+
+hipError_t launch_final_norm(const float* x, int q_per_b, const float* w, float eps, float* hfin, float* hiddens, int max_new,
+                             const int32_t* len, int T, int B, hipStream_t st) {
+  hipLaunchKernelGGL(final_norm_k, dim3(B), dim3(192), 0, st, x, q_per_b, w, eps, hfin, hiddens, max_new, len, T);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// G10 + G11  fused sampling chain, one wave per (b, k) row, one workgroup per batch row b.
+//   logits / temperature                                   gpt.py:487
+//   repetition penalty over the last <=16 generated ids    processors.py:18-35 (rows >= 625: none)
+//   TopP(min_keep 3) then TopK(min_keep 3)                 processors.py:38-58 + transformers warpers
+//   EOS mask while gen < min_new_token                     gpt.py:494-495
+//   softmax, argmax(p / q), q ~ Exp(1) from the CPU stream gpt.py:497-508 (host draws q)
+//   finish |= any(tok == eos); ids_buf[:, T+gen] = tok; end_idx += !finish; len += 1   gpt.py:512-577
+//
+// The sort the reference does per row (626 logits) is replaced by an exact equivalent that needs
+// no sort: both warpers keep a PREFIX of the descending order, so the kept set is found by
+// repeatedly extracting the wave-wide maximum (ties: lowest index first) while accumulating the
+// probability mass above it in double -- cum_ascending(v) = fl32(S_all - mass_above(v)), the same
+// value ATen's double-accumulated cumsum rounds to float.  At most max(top_k,3)+ties extractions.
+// ------------------------------------------------------------------------------------------------
+#define SLOTS 10  // ceil(626 / 64)
+
+__device__ __forceinline__ void wave_argmax(float v, int idx, float& bv, int& bi) {
+  // max value, ties -> lowest index; result uniform across the wave
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(v, o, 64);
+    const int oi = __shfl_xor(idx, o, 64);
+    if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+  }
+  bv = v; bi = idx;
+}
+
+__global__ __launch_bounds__(256) void sample_k(SampleArgs a) {
+  __shared__ int tok_s[NVQ];
+  const int b = blockIdx.x;
+  const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int len = a.len[b];
+  const int gen = len - a.T;  // tokens generated so far == step index i of gpt.py:394
+  const float* lrow = a.logits + ((size_t)b * NVQ + k) * NAUDIO;
+  const float temp = a.temperature[k];
+
+  float x[SLOTS];
+  int cnt[SLOTS];
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s) {
+    const int v = s * 64 + lane;
+    x[s] = (v < NAUDIO) ? lrow[v] / temp : -INFINITY;
+    cnt[s] = 0;
+  }
+  // repetition penalty
+  const int grow = a.row_offset + b * NVQ + k;
+  if (a.pow_table != nullptr && grow < a.max_input_ids) {
+    const int nh = min(gen, 16);
+    for (int j = 0; j < nh; ++j) {
+      const int t = (int)a.ids_buf[((size_t)b * a.tcap + (len - 1 - j)) * NVQ + k];
+#pragma unroll
+      for (int s = 0; s < SLOTS; ++s) cnt[s] += (t == s * 64 + lane) ? 1 : 0;
+    }
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+      const float al = a.pow_table[cnt[s]];
+      x[s] = (x[s] < 0.f) ? x[s] * al : x[s] / al;
+    }
+  }
+
+  // softmax statistics over the whole row (needed by top-p)
+  float mx = -INFINITY;
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s) mx = fmaxf(mx, x[s]);
+  mx = wave_max(mx);
+  float e[SLOTS];
+  float zs = 0.f;
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s) { e[s] = (s * 64 + lane < NAUDIO) ? expf(x[s] - mx) : 0.f; zs += e[s]; }
+  zs = wave_sum(zs);
+  const float rz = 1.0f / zs;
+  double sall = 0.0;
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s) { e[s] = e[s] * rz; sall += (double)e[s]; }  // e = softmax prob (f32)
+  sall = wave_sum_d(sall);
+
+  // prefix extraction in descending order
+  const int kk = a.use_top_k ? min(max(a.top_k, 3), NAUDIO) : NAUDIO;
+  const float thr = a.top_p_thr;  // float32(1 - top_p): `cum <= (1 - top_p)` on a float tensor casts the scalar to float
+  unsigned taken = 0;                // bit s: slot s of this lane already extracted
+  unsigned kept = 0;
+  double mass_above = 0.0;
+  float kth_val = 0.f;
+  int n = 0;
+  const bool any_filter = a.use_top_p || a.use_top_k;
+  while (any_filter && n < NAUDIO) {
+    float bv = -INFINITY; int bi = 0x7fffffff;
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+      const bool avail = !((taken >> s) & 1u) && (s * 64 + lane < NAUDIO);
+      if (avail && (x[s] > bv)) { bv = x[s]; bi = s * 64 + lane; }  // ascending s => lowest index on ties
+    }
+    float wv; int wi;
+    wave_argmax(bv, bi, wv, wi);
+    // top-p decision for the n-th largest element
+    bool keep = true;
+    if (a.use_top_p && n >= 3) {
+      const float cum = (float)(sall - mass_above);  // ascending cumulative prob up to and including it
+      keep = !(cum <= thr);
+    }
+    if (!keep) break;  // everything below is removed by top-p as well
+    if (a.use_top_k && n >= kk) {
+      if (!(wv == kth_val)) break;  // below the k-th largest value; ties with it survive
+    }
+    // accept
+    const int ws = wi >> 6, wl = wi & 63;
+    float pe = 0.f;
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) if (s == ws) pe = e[s];
+    pe = __shfl(pe, wl, 64);
+    mass_above += (double)pe;
+    if (lane == wl) { taken |= 1u << ws; kept |= 1u << ws; }
+    if (n == kk - 1) kth_val = wv;
+    ++n;
+  }
+  if (!any_filter) kept = 0x3ffu;
+
+  // EOS handling (min_new_token and the bench harness's stop_at hook)
+  bool mask_eos = gen < a.min_new;
+  bool force_eos = false;
+  if (a.stop_at != nullptr) {
+    const int sa = a.stop_at[b];
+    if (sa >= 0) { mask_eos = mask_eos || (gen < sa); force_eos = gen >= sa; }
+  }
+  // final softmax over the kept set and argmax(p / q)
+  const float* qrow = a.q + ((size_t)(gen % a.nq) * a.B * NVQ + (size_t)b * NVQ + k) * NAUDIO;
+  float m2 = -INFINITY;
+  bool live[SLOTS];
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s) {
+    const int v = s * 64 + lane;
+    live[s] = ((kept >> s) & 1u) && v < NAUDIO && !(mask_eos && v == a.eos);
+    if (live[s]) m2 = fmaxf(m2, x[s]);
+  }
+  m2 = wave_max(m2);
+  float z2 = 0.f, p2[SLOTS];
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s) { p2[s] = live[s] ? expf(x[s] - m2) : 0.f; z2 += p2[s]; }
+  z2 = wave_sum(z2);
+  const float rz2 = 1.0f / z2;
+  float bv = -1.f; int bi = 0x7fffffff;
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s) {
+    const int v = s * 64 + lane;
+    if (v < NAUDIO) {
+      const float r = (p2[s] * rz2) / qrow[v];
+      if (r > bv) { bv = r; bi = v; }
+    }
+  }
+  float wv; int wi;
+  wave_argmax(bv, bi, wv, wi);
+  if (force_eos) wi = a.eos;
+  if (lane == 0) {
+    a.ids_buf[((size_t)b * a.tcap + len) * NVQ + k] = (int64_t)wi;
+    tok_s[k] = wi;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    bool fin = a.finish[b] != 0;
+#pragma unroll
+    for (int c = 0; c < NVQ; ++c) fin = fin || (tok_s[c] == a.eos);
+    a.finish[b] = fin ? 1 : 0;
+    if (!fin) a.end_idx[b] += 1;
+    a.len[b] = len + 1;
+  }
+}
+
+hipError_t launch_sample(const SampleArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(sample_k, dim3(a.B), dim3(256), 0, st, a);
+  return hipGetLastError();
+}

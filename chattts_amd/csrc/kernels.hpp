@@ -1,0 +1,89 @@
+// Internal launcher interface between the kernel translation units and capi.hip.
+// Every launcher enqueues on `st` and returns hipGetLastError(); none allocates or synchronises,
+// so all of them are legal inside hipStreamBeginCapture/EndCapture.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+enum { WT_F32 = 0, WT_BF16 = 1 };
+
+// ---- GEMM  C[M,N] = epi( pro(A)[M,K] * W[N,K]^T ) ------------------------------------------
+enum GemmEpi {
+  EPI_STORE = 0,       // C = acc
+  EPI_RES = 1,         // C = res + acc                               (o_proj / down_proj)
+  EPI_SILU_MUL = 2,    // C[:, n] = silu(acc_gate[n]) * acc_up[n]     (W = [gate; up], N = rows of gate)
+  EPI_BIAS = 3,        // C = acc + bias[n]
+  EPI_BIAS_GELU = 4,   // C = gelu(acc + bias[n])
+  EPI_BIAS_SCALE_RES = 5,  // C = res + gamma[n] * (acc + bias[n])    (ConvNeXt pwconv2)
+  EPI_SCALE = 6,       // C = acc * scale[n]                          (DVAE out_conv * coef)
+};
+
+struct GemmArgs {
+  const float* A;      // [rows, lda] f32
+  const void* W;       // [N(, 2N for SILU), K] f32 or bf16, row-major
+  float* C;            // [M, ldc]
+  int M, N, K;
+  int lda, ldc;
+  int wt;              // WT_F32 | WT_BF16
+  int epi;             // GemmEpi
+  // prologue: RMSNorm over K of each A row (skinny kernel only): a' = norm_w[k] * (a * rsqrt(mean(a^2)+eps))
+  const float* norm_w;
+  float eps;
+  // epilogue operands
+  const float* res; int ldr;
+  const float* bias;   // [N]
+  const float* gamma;  // [N] (EPI_BIAS_SCALE_RES) or scale (EPI_SCALE)
+  // conv-as-GEMM gather (tiled kernel only): logical row m = b*F + f, k = tap*Cin + c reads
+  // X[b, f + (tap - pad)*dil, c] (zero outside [0,F)); taps == 1 -> plain GEMM.
+  int taps, cin, frames, pad, dil;
+};
+
+hipError_t launch_gemm_skinny(const GemmArgs& a, hipStream_t st);  // weight-streaming, M-tiles of <=64 rows
+hipError_t launch_gemm_tiled(const GemmArgs& a, hipStream_t st);   // 64x64 LDS-tiled f32 MFMA, large M
+
+// ---- GPT step kernels -------------------------------------------------------------------------
+struct GptRowMap {
+  // query row m of a launch maps to (b, slot): prefill (q_per_b = T): b = m / T, slot = m % T;
+  // decode (q_per_b = 1): b = m, slot = len[b] - 1.
+  int q_per_b;
+  const int32_t* len;       // [B] tokens present in ids_buf (prompt + generated)   (decode)
+  const int32_t* kv_start;  // [B] left-pad slots (attention_mask == 0 there)
+};
+
+hipError_t launch_embed_codes(const float* emb_code /*[4,626,768]*/, const int64_t* ids_buf, int ids_row_stride /*Tcap*/,
+                              const int32_t* len, float* x, int B, hipStream_t st);
+hipError_t launch_rope_append(float* qkv /*[M,2304]*/, void* kcache, void* vcache, int kv_wt, int cmax,
+                              const float* cos_tab, const float* sin_tab /*[max_pos,32]*/, GptRowMap rm, int M, hipStream_t st);
+hipError_t launch_attention(const float* qkv, const void* kcache, const void* vcache, int kv_wt, int cmax,
+                            float* out /*[M,768]*/, GptRowMap rm, int M, hipStream_t st);
+hipError_t launch_final_norm(const float* x, int q_per_b, const float* w, float eps, float* hfin /*[B,768]*/,
+                             float* hiddens /*[B,max_new,768]*/, int max_new, const int32_t* len, int T, int B, hipStream_t st);
+
+struct SampleArgs {
+  const float* logits;      // [B, 4*626]
+  int64_t* ids_buf;         // [B, Tcap, 4]
+  int tcap, T;              // T = prompt length (history starts at slot T)
+  int32_t* len;             // [B]  in/out (++)
+  uint8_t* finish;          // [B]  in/out
+  int32_t* end_idx;         // [B]  in/out
+  const float* q;           // [nq, B*4, 626] Exp(1) draws; step uses slab (gen % nq)
+  int nq;
+  const float* temperature; // [4]
+  const float* pow_table;   // [17] or null (no repetition penalty)
+  float top_p_thr; int use_top_p;  // thr = float32(1 - top_p), rounded on the host
+  int top_k;   int use_top_k;
+  int min_new;
+  int eos;
+  int row_offset;           // global index of row 0 (multi-GPU shards keep the rows>=625 quirk global)
+  int max_input_ids;        // 625
+  const int32_t* stop_at;   // [B] or null: bench harness length forcing
+  int B;
+};
+hipError_t launch_sample(const SampleArgs& a, hipStream_t st);
+
+// ---- codec kernels (channels-last [B, F, C]) ---------------------------------------------------
+hipError_t launch_dwconv_ln(const float* x, const float* w /*[C,7]*/, const float* b, const float* ln_w, const float* ln_b,
+                            float eps, int dil, float* y, int B, int F, int C, hipStream_t st);
+hipError_t launch_layernorm(const float* x, const float* w, const float* b, float eps, float* y, int rows, int C, hipStream_t st);
+hipError_t launch_istft(const float* head /*[B,F,1026]*/, const float* window /*[1024]*/, const float* twiddle /*[512,2]*/,
+                        float* frames /*[B,F,1024] scratch*/, float* wav /*[B,256(F-1)]*/, int B, int F, hipStream_t st);

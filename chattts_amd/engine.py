@@ -1,0 +1,531 @@
+"""Host side of the hot path: weight repacking, per-call device state, the generate loop
+(mirror of `GPT.generate`, /root/reference/ChatTTS/model/gpt.py:316-618) and the acoustic decoder
+(mirror of `Chat._decode_to_wavs`, /root/reference/ChatTTS/core.py:513-539).
+
+PyTorch is used for device memory, streams and host<->device copies only; every arithmetic op of
+the path runs in libchattts_amd.so (hand-written gfx950 kernels) through the C ABI in
+include/chattts_amd.h.  There is no eager/PyTorch fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import logging
+import math
+from dataclasses import dataclass, field
+from typing import Iterator, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config import DVAE, GPT, VOCOS
+from .rng import ExpDraws, penalty_table
+from .weights import fold_weight_norm, gpt_layer_count
+
+log = logging.getLogger("chattts_amd")
+
+
+# ---------------------------------------------------------------------------------------------
+# logits-processor descriptors (mirror of gen_logits, /root/reference/ChatTTS/model/processors.py:38-58)
+# ---------------------------------------------------------------------------------------------
+@dataclass
+class RepetitionPenalty:          # CustomRepetitionPenaltyLogitsProcessorRepeat, processors.py:6-35
+    penalty: float
+    max_input_ids: int
+    past_window: int = 16
+
+
+@dataclass
+class TopP:                       # transformers TopPLogitsWarper(top_p, min_tokens_to_keep=3)
+    top_p: float
+    min_tokens_to_keep: int = 3
+
+
+@dataclass
+class TopK:                       # transformers TopKLogitsWarper(top_k, min_tokens_to_keep=3)
+    top_k: int
+    min_tokens_to_keep: int = 3
+
+
+def gen_logits(num_code: int, top_P=0.7, top_K=20, repetition_penalty=1.0):
+    """Same signature / return shape as the reference's `gen_logits` (processors.py:38-58); returns
+    descriptors the fused sampling kernel understands instead of Python callables."""
+    warpers, procs = [], []
+    if top_P is not None:
+        warpers.append(TopP(top_P, 3))
+    if top_K is not None:
+        warpers.append(TopK(top_K, 3))
+    if repetition_penalty is not None and repetition_penalty != 1:
+        procs.append(RepetitionPenalty(repetition_penalty, num_code, 16))
+    return warpers, procs
+
+
+@dataclass
+class SamplingPlan:
+    top_p: Optional[float] = None
+    top_k: Optional[int] = None
+    penalty: Optional[float] = None
+
+
+def plan_from_processors(processors: Sequence) -> SamplingPlan:
+    """Accepts this module's descriptors AND the reference's own objects (duck-typed on the attribute
+    names of transformers' warpers / the reference's penalty class).  Anything else cannot be fused
+    into the kernel and is rejected loudly.  Order must be penalty -> top-p -> top-k (core.py:649)."""
+    plan = SamplingPlan()
+    stage = 0
+    for p in processors:
+        if hasattr(p, "penalty") and hasattr(p, "past_window"):
+            if stage > 0 or p.past_window != 16 or p.max_input_ids != GPT.n_audio - 1:
+                raise NotImplementedError("repetition penalty must come first with past_window=16, max_input_ids=625")
+            plan.penalty = float(p.penalty)
+            stage = 1
+        elif hasattr(p, "top_p"):
+            if stage > 1 or getattr(p, "min_tokens_to_keep", 3) != 3:
+                raise NotImplementedError("top-p must precede top-k and use min_tokens_to_keep=3")
+            plan.top_p = float(p.top_p)
+            stage = 2
+        elif hasattr(p, "top_k"):
+            if getattr(p, "min_tokens_to_keep", 3) != 3:
+                raise NotImplementedError("top-k must use min_tokens_to_keep=3")
+            plan.top_k = int(p.top_k)
+            stage = 3
+        else:
+            raise NotImplementedError(f"logits processor {type(p).__name__} cannot be fused into the HIP sampling kernel")
+    return plan
+
+
+@dataclass(repr=False, eq=False)
+class GenerationOutputs:          # gpt.py:276-285
+    ids: List[torch.Tensor]
+    attentions: list
+    hiddens: List[torch.Tensor]
+
+    def destroy(self):
+        self.ids.clear()
+        self.attentions.clear()
+        self.hiddens.clear()
+
+
+class Context:                    # gpt.py:103-111
+    def __init__(self):
+        self._interrupt = False
+
+    def set(self, v: bool):
+        self._interrupt = v
+
+    def get(self) -> bool:
+        return self._interrupt
+
+
+def left_pad_starts(attention_mask: torch.Tensor) -> torch.Tensor:
+    """kv_start[b] = number of leading zeros; raises unless the mask is left padding (tokenizer.py:73-110)."""
+    m = attention_mask.to(torch.bool).cpu()
+    T = m.shape[1]
+    n = m.sum(1)
+    start = T - n
+    ar = torch.arange(T)[None, :]
+    if not torch.equal(m, ar >= start[:, None]):
+        raise NotImplementedError("only left-padded attention masks (what Tokenizer.encode produces) are supported")
+    if int(n.min()) <= 0:
+        raise ValueError("empty prompt row")
+    return start.to(torch.int32)
+
+
+def rope_tables(max_pos: int, head_dim: int = GPT.head_dim, theta: float = GPT.rope_theta):
+    """cos/sin [max_pos, head_dim/2] float32, evaluated with the same torch f32 ops HF's
+    LlamaRotaryEmbedding uses (inv_freq = 1/theta^(arange(0,d,2)/d); freqs = pos * inv_freq)."""
+    inv_freq = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.int64).to(torch.float32) / head_dim))
+    pos = torch.arange(max_pos, dtype=torch.float32)
+    freqs = pos[:, None] * inv_freq[None, :]
+    return freqs.cos().contiguous(), freqs.sin().contiguous()
+
+
+# ---------------------------------------------------------------------------------------------
+class GptEngine:
+    """Device-resident, repacked GPT weights + the generate loop."""
+
+    NQ_RING = 64   # unseeded sampling: ring of per-step Exp(1) draws uploaded ahead of the GPU
+    POLL = 16      # decode steps enqueued between two looks at the device-side finish flags
+
+    def __init__(self, gpt_sd: dict, embed_sd: dict, device: torch.device, dtype: str = "bf16",
+                 max_pos: int = GPT.max_pos, logger: logging.Logger = log):
+        if dtype not in ("bf16", "f32"):
+            raise ValueError("dtype must be 'bf16' (perf) or 'f32' (parity)")
+        self.lib = _lib.lib()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.EngineError("GptEngine needs a ROCm GPU device (there is no CPU path)")
+        self.logger = logger
+        self.dtype = dtype
+        self.wdt = torch.bfloat16 if dtype == "bf16" else torch.float32
+        self.code = _lib.BF16 if dtype == "bf16" else _lib.F32
+        self.n_layers = gpt_layer_count(gpt_sd)
+        self.max_pos = max_pos
+        dev = self.device
+        f = lambda t: t.to(torch.float32).contiguous().to(dev)
+        wcast = lambda t: t.to(torch.float32).to(self.wdt).contiguous().to(dev)
+        self.wqkv, self.wo, self.wgu, self.wd, self.ln1, self.ln2 = [], [], [], [], [], []
+        for i in range(self.n_layers):
+            p = f"layers.{i}."
+            self.wqkv.append(wcast(torch.cat([gpt_sd[p + "self_attn.q_proj.weight"], gpt_sd[p + "self_attn.k_proj.weight"],
+                                              gpt_sd[p + "self_attn.v_proj.weight"]], 0)))
+            self.wo.append(wcast(gpt_sd[p + "self_attn.o_proj.weight"]))
+            self.wgu.append(wcast(torch.cat([gpt_sd[p + "mlp.gate_proj.weight"], gpt_sd[p + "mlp.up_proj.weight"]], 0)))
+            self.wd.append(wcast(gpt_sd[p + "mlp.down_proj.weight"]))
+            self.ln1.append(f(gpt_sd[p + "input_layernorm.weight"]))
+            self.ln2.append(f(gpt_sd[p + "post_attention_layernorm.weight"]))
+        self.norm = f(gpt_sd["norm.weight"])
+        self.emb_code = f(torch.stack([embed_sd[f"emb_code.{k}.weight"] for k in range(GPT.n_vq)], 0))
+        self.emb_text = f(embed_sd["emb_text.weight"])
+        self.heads = f(torch.cat([fold_weight_norm(embed_sd[f"head_code.{k}.parametrizations.weight.original0"].float(),
+                                                   embed_sd[f"head_code.{k}.parametrizations.weight.original1"].float())
+                                  for k in range(GPT.n_vq)], 0))
+        cos, sin = rope_tables(max_pos)
+        self.rope_cos, self.rope_sin = cos.to(dev), sin.to(dev)
+        self._arrs = [_lib.ptr_array(x) for x in (self.wqkv, self.wo, self.wgu, self.wd, self.ln1, self.ln2)]
+        w = _lib.GptWeights()
+        w.n_layers, w.weight_dtype, w.kv_dtype, w.max_pos = self.n_layers, self.code, self.code, max_pos
+        w.wqkv, w.wo, w.wgu, w.wd, w.ln1, w.ln2 = [C.cast(a, _lib.PP) for a in self._arrs]
+        w.norm, w.emb_code, w.heads = self.norm.data_ptr(), self.emb_code.data_ptr(), self.heads.data_ptr()
+        w.rope_cos, w.rope_sin = self.rope_cos.data_ptr(), self.rope_sin.data_ptr()
+        w.rms_eps = GPT.rms_eps
+        self._w = w
+        h = C.c_void_p()
+        _lib.check(self.lib.ctts_gpt_create(C.byref(h), C.byref(w)), "ctts_gpt_create")
+        self.handle = h
+        self.stream = torch.cuda.Stream(device=dev)
+        self.last_stats = {}
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.ctts_gpt_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def weight_bytes_per_step(self) -> int:
+        """HBM bytes of weights one decode step streams (190,698,240 params)."""
+        es = 2 if self.dtype == "bf16" else 4
+        per_layer = (3 * 768 * 768 + 768 * 768 + 2 * 3072 * 768 + 768 * 3072) * es
+        return per_layer * self.n_layers + self.heads.numel() * 4
+
+    # -- a2: Embed.forward (embed.py:52-79): gathers only, done with torch indexing on the device
+    def embed_prompt(self, input_ids: torch.Tensor, text_mask: torch.Tensor) -> torch.Tensor:
+        ids = input_ids.to(self.device)
+        tm = text_mask.to(self.device).bool()
+        et = self.emb_text[ids[..., 0].clamp(0, GPT.n_text - 1)]
+        cid = ids.clamp(0, GPT.n_audio - 1)
+        ec = self.emb_code[0][cid[..., 0]]
+        for k in range(1, GPT.n_vq):
+            ec = ec + self.emb_code[k][cid[..., k]]
+        return torch.where(tm[..., None], et, ec).contiguous()
+
+    # -- a3: GPT.generate
+    def generate(self, emb: torch.Tensor, inputs_ids: torch.Tensor, temperature: torch.Tensor, eos_token: int = GPT.n_audio - 1,
+                 attention_mask: Optional[torch.Tensor] = None, max_new_token: int = 2048, min_new_token: int = 0,
+                 logits_processors: Sequence = (), infer_text: bool = False, return_attn: bool = False,
+                 return_hidden: bool = False, stream: bool = False, show_tqdm: bool = False, ensure_non_empty: bool = True,
+                 stream_batch: int = 24, manual_seed: Optional[int] = None, context: Optional[Context] = None,
+                 *, use_graph: bool = True, stop_at: Optional[torch.Tensor] = None, row_offset: int = 0,
+                 total_rows: Optional[int] = None, profile_tag: Optional[int] = None) -> Iterator[GenerationOutputs]:
+        """Drop-in for `GPT.generate` (gpt.py:316-337), code mode.  Extra keyword-only arguments:
+        `use_graph` (hipGraph replay of the decode step), `stop_at` ([B] int32 forced output lengths,
+        benchmark hook), `row_offset`/`total_rows` (this shard's position inside a data-parallel batch:
+        keeps the CPU draw and the rows>=625 penalty quirk keyed on the global row index)."""
+        if infer_text:
+            raise NotImplementedError("refine-text generation (infer_text=True) is a 'next' row (SURVEY 8f-1)")
+        if return_attn:
+            raise NotImplementedError("return_attn is not supported by the fused attention kernel")
+        context = context or Context()
+        plan = plan_from_processors(logits_processors)
+        lib, dev = self.lib, self.device
+        B, T, nvq = inputs_ids.shape
+        assert nvq == GPT.n_vq and emb.shape == (B, T, GPT.hidden)
+        max_new = int(max_new_token)
+        tcap = T + max_new
+        if tcap > self.max_pos:
+            raise ValueError(f"T + max_new_token = {tcap} exceeds max_position_embeddings {self.max_pos}")
+        if attention_mask is None:
+            attention_mask = torch.ones((B, T), dtype=torch.bool)
+        kv_start = left_pad_starts(attention_mask).to(dev)
+
+        st = self.stream
+        caller = torch.cuda.current_stream(dev)
+        st.wait_stream(caller)
+        ctx = [torch.cuda.stream(st)]
+        ctx[0].__enter__()   # entered/left by hand so the side stream is never current while suspended in a yield
+
+        def hand_over(o):
+            """leave the side stream before control returns to the consumer"""
+            ctx[0].__exit__(None, None, None)
+            caller.wait_stream(st)
+            return o
+
+        def resume():
+            st.wait_stream(caller)
+            ctx[0] = torch.cuda.stream(st)
+            ctx[0].__enter__()
+
+        try:
+            ids_buf = torch.zeros((B, tcap, nvq), dtype=torch.int64, device=dev)  # gpt.py:372-379
+            ids_buf[:, :T] = inputs_ids.to(dev)
+            len_d = torch.full((B,), T, dtype=torch.int32, device=dev)
+            finish = torch.zeros((B,), dtype=torch.uint8, device=dev)             # gpt.py:346
+            end_idx = torch.zeros((B,), dtype=torch.int32, device=dev)            # gpt.py:343
+            hiddens = torch.empty((B, max_new, GPT.hidden), dtype=torch.float32, device=dev)
+            kv_shape = (self.n_layers, B, GPT.n_heads, tcap, GPT.head_dim)
+            kcache = torch.empty(kv_shape, dtype=self.wdt, device=dev)
+            vcache = torch.empty(kv_shape, dtype=self.wdt, device=dev)
+            ws_bytes = lib.ctts_gpt_workspace_bytes(B, T)
+            workspace = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+            temp_d = temperature.to(torch.float32).reshape(-1).to(dev)
+            assert temp_d.numel() == nvq
+            ptab = penalty_table(plan.penalty)
+            ptab_d = None if ptab is None else ptab.to(dev)
+            stop_d = None if stop_at is None else stop_at.to(torch.int32).to(dev)
+            emb_d = emb.to(torch.float32).contiguous().to(dev)
+
+            draws = ExpDraws(total_rows if total_rows is not None else B * nvq, GPT.n_audio, manual_seed,
+                             row_begin=row_offset, row_end=row_offset + B * nvq)
+            if draws.constant:
+                nq = 1
+                q_d = draws.step(0).to(dev).reshape(1, B * nvq, GPT.n_audio).contiguous()
+                q_host = None
+            else:
+                nq = self.NQ_RING
+                q_d = torch.empty((nq, B * nvq, GPT.n_audio), dtype=torch.float32, device=dev)
+                q_host = torch.empty((nq // 2, B * nvq, GPT.n_audio), dtype=torch.float32).pin_memory()
+
+            s = _lib.GenState()
+            s.B, s.T, s.max_new = B, T, max_new
+            s.ids_buf, s.len, s.kv_start = ids_buf.data_ptr(), len_d.data_ptr(), kv_start.data_ptr()
+            s.finish, s.end_idx, s.hiddens = finish.data_ptr(), end_idx.data_ptr(), hiddens.data_ptr()
+            s.kcache, s.vcache, s.q, s.nq = kcache.data_ptr(), vcache.data_ptr(), q_d.data_ptr(), nq
+            s.temperature = temp_d.data_ptr()
+            s.pow_table = _lib.ptr(ptab_d)
+            s.top_p_thr = float(np.float32(1.0 - plan.top_p)) if plan.top_p is not None else 0.0
+            s.use_top_p = int(plan.top_p is not None)
+            s.top_k = int(plan.top_k or 0)
+            s.use_top_k = int(plan.top_k is not None)
+            s.min_new, s.eos, s.row_offset = int(min_new_token), int(eos_token), int(row_offset)
+            s.stop_at = _lib.ptr(stop_d)
+            s.workspace, s.workspace_bytes = workspace.data_ptr(), ws_bytes
+            sp = st.cuda_stream
+
+            uploaded = 0  # number of steps whose q draws are on the device (unseeded mode)
+
+            def ensure_q(upto: int):
+                nonlocal uploaded
+                if q_host is None:
+                    return
+                half = nq // 2
+                while uploaded < upto:
+                    st.synchronize()  # staging buffer reuse; unseeded mode is host-RNG bound anyway
+                    n = min(half, max_new - uploaded)
+                    for j in range(n):
+                        q_host[j].copy_(draws.step(uploaded + j))
+                    slab = uploaded % nq
+                    q_d[slab: slab + n].copy_(q_host[:n], non_blocking=True)
+                    uploaded += n
+
+            ensure_q(1)
+            _lib.check(lib.ctts_gpt_prefill(self.handle, C.byref(s), emb_d.data_ptr(), sp), "ctts_gpt_prefill")
+            steps_done = 1
+            fin_host = finish.cpu()  # syncs: the step-0 rule needs it (gpt.py:527)
+            if bool(fin_host.any()):
+                self.logger.warning("unexpected end at index %s", str(fin_host.nonzero().flatten().tolist()))
+                if ensure_non_empty and manual_seed is None:
+                    self.logger.warning("regenerate in order to ensure non-empty")
+                    hand_over(None)
+                    yield from self.generate(emb, inputs_ids, temperature, eos_token, attention_mask, max_new_token,
+                                             min_new_token, logits_processors, infer_text, return_attn, return_hidden,
+                                             stream, show_tqdm, ensure_non_empty, stream_batch, manual_seed, context,
+                                             use_graph=use_graph, stop_at=stop_at, row_offset=row_offset, total_rows=total_rows)
+                    resume()
+                return  # gpt.py:570: the seeded case yields nothing
+
+            graph_ok = False
+            if use_graph and max_new > 1:
+                _lib.check(lib.ctts_gpt_graph_build(self.handle, C.byref(s), sp), "ctts_gpt_graph_build")
+                graph_ok = True
+            if profile_tag is not None:
+                _lib.check(lib.ctts_gpt_profile_begin(self.handle, int(profile_tag), 4096), "profile_begin")
+
+            def outputs() -> GenerationOutputs:
+                e = end_idx.cpu().tolist()
+                return GenerationOutputs(
+                    ids=[ids_buf[b, T: T + e[b]] for b in range(B)],                      # gpt.py:297-299
+                    attentions=[],
+                    hiddens=[hiddens[b, : e[b]] for b in range(B)] if return_hidden else [],  # gpt.py:303-307
+                )
+
+            chunk = stream_batch if stream else self.POLL
+            all_done = False
+            interrupted = False
+            while steps_done < max_new and not all_done:
+                # reference yields when (i+1) % stream_batch == 0: keep chunk ends on those steps
+                n = min(chunk - (steps_done % chunk), max_new - steps_done)
+                ensure_q(steps_done + n)
+                if graph_ok:
+                    _lib.check(lib.ctts_gpt_graph_launch(self.handle, n, sp), "ctts_gpt_graph_launch")
+                else:
+                    for _ in range(n):
+                        _lib.check(lib.ctts_gpt_decode_step(self.handle, C.byref(s), sp), "ctts_gpt_decode_step")
+                steps_done += n
+                fin_host = finish.cpu()  # stream-ordered D2H + sync
+                all_done = bool(fin_host.all())
+                if context.get():  # gpt.py:592
+                    interrupted = True
+                    break
+                if stream:
+                    emit = False
+                    if not all_done and steps_done % stream_batch == 0:
+                        emit = True                                      # gpt.py:579-589
+                    elif all_done:
+                        i_star = int(end_idx.max().item())               # step at which the last row hit EOS
+                        emit = i_star > 0 and i_star % stream_batch == 0  # the reference's duplicate yield (stream_iter quirk)
+                    if emit:
+                        yield hand_over(outputs())
+                        resume()
+            if profile_tag is not None:
+                n_s, tot = C.c_int32(0), C.c_double(0.0)
+                _lib.check(lib.ctts_gpt_profile_end(self.handle, C.byref(n_s), C.byref(tot)), "profile_end")
+                self.last_stats["profile"] = (int(n_s.value), float(tot.value))
+            if graph_ok:
+                st.synchronize()
+                lib.ctts_gpt_graph_destroy(self.handle)
+            if not all_done:
+                if interrupted:
+                    self.logger.warning("generation is interrupted")
+                else:
+                    self.logger.warning(f"incomplete result. hit max_new_token: {max_new_token}")   # gpt.py:601-607
+            self.last_stats.update(steps=steps_done, B=B, T=T)
+            out = outputs()
+        finally:
+            try:
+                ctx[0].__exit__(None, None, None)
+            except Exception:
+                pass
+        caller.wait_stream(st)
+        yield out
+
+
+# ---------------------------------------------------------------------------------------------
+class CodecEngine:
+    """DVAE decoder + Vocos on the device (channels-last)."""
+
+    def __init__(self, decoder_sd: dict, vocos_sd: dict, device: torch.device):
+        self.lib = _lib.lib()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.EngineError("CodecEngine needs a ROCm GPU device (there is no CPU path)")
+        dev = self.device
+        f = lambda t: t.to(torch.float32).contiguous().to(dev)
+        convw = lambda t: f(t.permute(0, 2, 1))          # [Cout,Cin,k] -> [Cout,k,Cin]
+        dww = lambda t: f(t[:, 0, :].t())                # [C,1,7] -> [7,C]
+        self.keep = []
+        k = self.keep.append
+        w = _lib.CodecWeights()
+
+        def P(t):
+            k(t)
+            return t.data_ptr()
+
+        def PA(ts):
+            k(ts)
+            arr = _lib.ptr_array(ts)
+            k(arr)
+            return C.cast(arr, _lib.PP)
+
+        d = decoder_sd
+        w.conv_in0_w, w.conv_in0_b = P(convw(d["decoder.conv_in.0.weight"])), P(f(d["decoder.conv_in.0.bias"]))
+        w.conv_in2_w, w.conv_in2_b = P(convw(d["decoder.conv_in.2.weight"])), P(f(d["decoder.conv_in.2.bias"]))
+        nb = 0
+        while f"decoder.decoder_block.{nb}.weight" in d:
+            nb += 1
+        w.n_dvae_blocks = nb
+        blk = lambda i, n: d[f"decoder.decoder_block.{i}.{n}"]
+        w.d_dw_w = PA([dww(blk(i, "dwconv.weight")) for i in range(nb)])
+        w.d_dw_b = PA([f(blk(i, "dwconv.bias")) for i in range(nb)])
+        w.d_ln_w = PA([f(blk(i, "norm.weight")) for i in range(nb)])
+        w.d_ln_b = PA([f(blk(i, "norm.bias")) for i in range(nb)])
+        w.d_pw1_w = PA([f(blk(i, "pwconv1.weight")) for i in range(nb)])
+        w.d_pw1_b = PA([f(blk(i, "pwconv1.bias")) for i in range(nb)])
+        w.d_pw2_w = PA([f(blk(i, "pwconv2.weight")) for i in range(nb)])
+        w.d_pw2_b = PA([f(blk(i, "pwconv2.bias")) for i in range(nb)])
+        w.d_gamma = PA([f(blk(i, "weight")) for i in range(nb)])
+        w.conv_out_w = P(f(d["decoder.conv_out.weight"][:, :, 0]))
+        w.out_conv_w = P(convw(d["out_conv.weight"]))
+        w.coef = P(f(d["coef"].reshape(-1)))
+        v = vocos_sd
+        w.v_embed_w, w.v_embed_b = P(convw(v["backbone.embed.weight"])), P(f(v["backbone.embed.bias"]))
+        w.v_norm_w, w.v_norm_b = P(f(v["backbone.norm.weight"])), P(f(v["backbone.norm.bias"]))
+        nv = 0
+        while f"backbone.convnext.{nv}.gamma" in v:
+            nv += 1
+        w.n_vocos_blocks = nv
+        vb = lambda i, n: v[f"backbone.convnext.{i}.{n}"]
+        w.v_dw_w = PA([dww(vb(i, "dwconv.weight")) for i in range(nv)])
+        w.v_dw_b = PA([f(vb(i, "dwconv.bias")) for i in range(nv)])
+        w.v_ln_w = PA([f(vb(i, "norm.weight")) for i in range(nv)])
+        w.v_ln_b = PA([f(vb(i, "norm.bias")) for i in range(nv)])
+        w.v_pw1_w = PA([f(vb(i, "pwconv1.weight")) for i in range(nv)])
+        w.v_pw1_b = PA([f(vb(i, "pwconv1.bias")) for i in range(nv)])
+        w.v_pw2_w = PA([f(vb(i, "pwconv2.weight")) for i in range(nv)])
+        w.v_pw2_b = PA([f(vb(i, "pwconv2.bias")) for i in range(nv)])
+        w.v_gamma = PA([f(vb(i, "gamma")) for i in range(nv)])
+        w.v_final_w, w.v_final_b = P(f(v["backbone.final_layer_norm.weight"])), P(f(v["backbone.final_layer_norm.bias"]))
+        w.head_w, w.head_b = P(f(v["head.out.weight"])), P(f(v["head.out.bias"]))
+        w.window = P(f(v["head.istft.window"]))
+        kk = torch.arange(VOCOS.n_fft // 2, dtype=torch.float64) * (2.0 * math.pi / VOCOS.n_fft)
+        w.twiddle = P(f(torch.stack([kk.cos(), kk.sin()], 1)))
+        self._w = w
+        h = C.c_void_p()
+        _lib.check(self.lib.ctts_codec_create(C.byref(h), C.byref(w)), "ctts_codec_create")
+        self.handle = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.ctts_codec_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def _ws(self, B, F):
+        n = self.lib.ctts_codec_workspace_bytes(B, F)
+        return torch.empty((n,), dtype=torch.uint8, device=self.device), n
+
+    def dvae_decode(self, hid: torch.Tensor) -> torch.Tensor:
+        """hid [B,T,768] f32 (zero padded rows) -> mel [B,2T,100]   (dvae.py:276-297)."""
+        B, T, H = hid.shape
+        assert H == GPT.hidden
+        hid = hid.to(torch.float32).contiguous().to(self.device)
+        mel = torch.empty((B, 2 * T, DVAE.n_mels), dtype=torch.float32, device=self.device)
+        ws, n = self._ws(B, 2 * T)
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(self.lib.ctts_dvae_decode(self.handle, hid.data_ptr(), mel.data_ptr(), B, T, ws.data_ptr(), n, st), "ctts_dvae_decode")
+        return mel
+
+    def vocos_decode(self, mel: torch.Tensor) -> torch.Tensor:
+        """mel [B,F,100] -> wav [B,256(F-1)]   (vocos.Vocos.decode, core.py:505-510)."""
+        B, F, M = mel.shape
+        assert M == VOCOS.n_mels and F >= 2
+        mel = mel.to(torch.float32).contiguous().to(self.device)
+        wav = torch.empty((B, VOCOS.hop * (F - 1)), dtype=torch.float32, device=self.device)
+        ws, n = self._ws(B, F)
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(self.lib.ctts_vocos_decode(self.handle, mel.data_ptr(), wav.data_ptr(), B, F, ws.data_ptr(), n, st), "ctts_vocos_decode")
+        return wav
+
+    def decode_to_wavs(self, result_list: List[torch.Tensor]) -> torch.Tensor:
+        """`Chat._decode_to_wavs` (core.py:513-539): zero-pad the per-row [T_b,768] hidden lists to the
+        longest row, DVAE decode, Vocos decode -> [B, 256(2Tmax-1)] float32 on the device."""
+        if len(result_list) == 0:
+            return torch.empty((0,), dtype=torch.float32)
+        Tmax = max(int(r.size(0)) for r in result_list)
+        batch = torch.zeros((len(result_list), Tmax, GPT.hidden), dtype=torch.float32, device=self.device)
+        for i, r in enumerate(result_list):
+            batch[i, : r.size(0)] = r
+        return self.vocos_decode(self.dvae_decode(batch))

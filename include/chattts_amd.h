@@ -1,0 +1,173 @@
+/* chattts_amd -- C ABI of the MI355X-native ChatTTS hot path (libchattts_amd.so).
+ *
+ * The reference (2noise/ChatTTS) is pure Python and has no FFI for this path; the boundary it
+ * offers is the Python call seam that `use_vllm` / `experimental` already use to swap engines
+ * (SURVEY.md 8b).  Each entry point below names the reference call it replaces.
+ *
+ * Conventions
+ *   - every pointer named *_dev / documented "device" is a DEVICE pointer owned by the caller (torch
+ *     tensors on the host side); the library never allocates or frees device memory, never
+ *     synchronises the device, and enqueues everything on the hipStream_t it is given (passed as
+ *     void*; NULL = the default stream), so calls are legal inside stream capture;
+ *   - return value 0 = ok, negative = error; ctts_last_error() returns a thread-local message;
+ *   - a handle is not re-entrant; use one handle per device / per concurrent generate() call.
+ */
+#ifndef CHATTTS_AMD_H
+#define CHATTTS_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CTTS_F32 0
+#define CTTS_BF16 1
+
+typedef struct ctts_gpt ctts_gpt;     /* opaque: GPT engine (weights view + captured decode graph) */
+typedef struct ctts_codec ctts_codec; /* opaque: DVAE decoder + Vocos */
+
+const char* ctts_last_error(void);
+int ctts_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * GPT speech-token generator.
+ * Replaces `GPT.generate` (ChatTTS/model/gpt.py:316-618): one prefill + N decode steps of
+ *   LlamaModel.forward (gpt.py:419-427) -> final-norm hidden capture (:430-436) -> 4 weight-normed heads
+ *   (:438-454, embed.py:27-35) -> temperature / repetition penalty / top-p / top-k / EOS mask /
+ *   softmax / multinomial (:487-508, processors.py:18-58) -> finish / write-back (:512-577).
+ * Weights arrive repacked by the host loader from the reference's safetensors layout:
+ *   wqkv[l] = [q_proj; k_proj; v_proj] rows (2304 x 768), wgu[l] = [gate_proj; up_proj] (6144 x 768),
+ *   heads = 4 folded weight-norm matrices stacked (2504 x 768, always f32), emb_code = 4 x 626 x 768 f32.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  int32_t n_layers;
+  int32_t weight_dtype;            /* CTTS_F32 (parity mode) | CTTS_BF16 (perf mode) for the Llama linears */
+  int32_t kv_dtype;                /* dtype of the KV cache */
+  int32_t max_pos;                 /* rows of the RoPE tables */
+  const void* const* wqkv;         /* host array [n_layers] of device pointers */
+  const void* const* wo;           /* [768 x 768] */
+  const void* const* wgu;          /* [6144 x 768] */
+  const void* const* wd;           /* [768 x 3072] */
+  const float* const* ln1;         /* input_layernorm.weight [768] */
+  const float* const* ln2;         /* post_attention_layernorm.weight [768] */
+  const float* norm;               /* final RMSNorm weight [768] */
+  const float* emb_code;           /* [4,626,768] */
+  const float* heads;              /* [2504,768] */
+  const float* rope_cos;           /* [max_pos,32] float32, built by the host with the reference's own ops */
+  const float* rope_sin;
+  float rms_eps;
+} ctts_gpt_weights;
+
+/* One generate() call's device state (every array is caller-allocated, device memory). */
+typedef struct {
+  int32_t B, T, max_new;           /* rows, padded prompt length, max_new_token (gpt.py:323) */
+  int64_t* ids_buf;                /* [B, T+max_new, 4]  inputs_ids_buf (gpt.py:372-379), prompt pre-filled */
+  int32_t* len;                    /* [B] tokens present per row; host initialises to T */
+  const int32_t* kv_start;         /* [B] number of left-pad slots (attention_mask == 0) */
+  uint8_t* finish;                 /* [B] (gpt.py:346) host initialises 0 */
+  int32_t* end_idx;                /* [B] (gpt.py:343) host initialises 0 */
+  float* hiddens;                  /* [B, max_new, 768] per-step hidden states (gpt.py:435-436) */
+  void* kcache;                    /* [n_layers, B, 12, T+max_new, 64] kv_dtype */
+  void* vcache;
+  const float* q;                  /* [nq, B*4, 626] Exp(1) draws of the CPU generator (gpt.py:501-508) */
+  int32_t nq;                      /* 1 when manual_seed is set (same draw every step) */
+  const float* temperature;        /* [4] (gpt.py:350-355) */
+  const float* pow_table;          /* [17] penalty^f as torch computes it, or NULL (processors.py:29) */
+  float top_p_thr;                 /* float32(1 - top_P) */
+  int32_t use_top_p;
+  int32_t top_k;
+  int32_t use_top_k;
+  int32_t min_new;                 /* min_new_token (gpt.py:494) */
+  int32_t eos;                     /* 625 */
+  int32_t row_offset;              /* global index of this shard's row 0 (b*4+k numbering, processors.py:24-27) */
+  const int32_t* stop_at;          /* [B] or NULL: benchmark length forcing, not a reference feature */
+  void* workspace;                 /* >= ctts_gpt_workspace_bytes(B, T) */
+  size_t workspace_bytes;
+} ctts_gen_state;
+
+int ctts_gpt_create(ctts_gpt** out, const ctts_gpt_weights* w);
+void ctts_gpt_destroy(ctts_gpt* g);
+size_t ctts_gpt_workspace_bytes(int32_t B, int32_t T);
+
+/* step 0 of gpt.py:394: consumes emb[B,T,768] f32 (Embed.forward output, embed.py:52-79), fills the KV
+ * cache, writes hiddens[:,0], samples token 0 into ids_buf[:,T], sets len = T+1. */
+int ctts_gpt_prefill(ctts_gpt* g, const ctts_gen_state* s, const float* emb, void* stream);
+/* one iteration i > 0 of gpt.py:394-577, eager launches */
+int ctts_gpt_decode_step(ctts_gpt* g, const ctts_gen_state* s, void* stream);
+/* capture one decode step into a hipGraph (all per-step state is read from device memory, so the
+ * same executable graph is replayed for every step), then replay it n times */
+int ctts_gpt_graph_build(ctts_gpt* g, const ctts_gen_state* s, void* stream);
+int ctts_gpt_graph_launch(ctts_gpt* g, int32_t n_steps, void* stream);
+void ctts_gpt_graph_destroy(ctts_gpt* g);
+
+/* HIP-event timing of one launch site (tag) of the eager decode step, for bench.py's roofline leg.
+ * tags: 0 embed, 1 qkv, 2 rope_append, 3 attention, 4 o_proj, 5 gate_up, 6 down, 7 final_norm, 8 heads, 9 sample */
+int ctts_gpt_profile_begin(ctts_gpt* g, int32_t tag, int32_t max_samples);
+int ctts_gpt_profile_end(ctts_gpt* g, int32_t* n_samples, double* total_ms);
+
+/* ------------------------------------------------------------------------------------------------
+ * Acoustic decoder.  Replaces `self.decoder(batch_result)` + `self.vocos.decode(mel)` of
+ * Chat._decode_to_wavs / _vocos_decode (ChatTTS/core.py:505-539), i.e. DVAE.forward decode branch
+ * (dvae.py:276-297) and vocos.Vocos.decode.  Layout is channels-last: hid [B,T,768] (the per-token
+ * hidden states, zero padded), mel [B,2T,100], wav [B,256(2T-1)].
+ * Conv weights arrive repacked [Cout][tap][Cin]; depthwise kernels [7][512].
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  /* DVAE decoder (dvae.py:145-161,239) */
+  const float* conv_in0_w; const float* conv_in0_b;   /* [128][3][384], [128] */
+  const float* conv_in2_w; const float* conv_in2_b;   /* [512][3][128], [512] */
+  int32_t n_dvae_blocks;
+  const float* const* d_dw_w; const float* const* d_dw_b;    /* [7][512], [512] */
+  const float* const* d_ln_w; const float* const* d_ln_b;
+  const float* const* d_pw1_w; const float* const* d_pw1_b;  /* [2048][512] */
+  const float* const* d_pw2_w; const float* const* d_pw2_b;  /* [512][2048] */
+  const float* const* d_gamma;                               /* ConvNeXtBlock.weight [512] */
+  const float* conv_out_w;                                   /* [384][512] */
+  const float* out_conv_w;                                   /* [100][3][384] */
+  const float* coef;                                         /* [100] */
+  /* Vocos */
+  const float* v_embed_w; const float* v_embed_b;            /* [512][7][100] */
+  const float* v_norm_w; const float* v_norm_b;
+  int32_t n_vocos_blocks;
+  const float* const* v_dw_w; const float* const* v_dw_b;
+  const float* const* v_ln_w; const float* const* v_ln_b;
+  const float* const* v_pw1_w; const float* const* v_pw1_b;  /* [1536][512] */
+  const float* const* v_pw2_w; const float* const* v_pw2_b;  /* [512][1536] */
+  const float* const* v_gamma;
+  const float* v_final_w; const float* v_final_b;
+  const float* head_w; const float* head_b;                  /* [1026][512], [1026] */
+  const float* window;                                       /* hann [1024] */
+  const float* twiddle;                                      /* [512][2] cos/sin(2 pi k / 1024) */
+} ctts_codec_weights;
+
+int ctts_codec_create(ctts_codec** out, const ctts_codec_weights* w);
+void ctts_codec_destroy(ctts_codec* c);
+size_t ctts_codec_workspace_bytes(int32_t B, int32_t F); /* F = mel frames = 2T */
+int ctts_dvae_decode(ctts_codec* c, const float* hid, float* mel, int32_t B, int32_t T, void* workspace, size_t ws_bytes, void* stream);
+int ctts_vocos_decode(ctts_codec* c, const float* mel, float* wav, int32_t B, int32_t F, void* workspace, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Single-kernel entry points (unit parity tests call the kernels through these).
+ * ---------------------------------------------------------------------------------------------- */
+int ctts_k_gemm(int32_t tiled, const float* A, const void* W, float* C, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldc,
+                int32_t wt, int32_t epi, const float* norm_w, float eps, const float* res, int32_t ldr, const float* bias,
+                const float* gamma, int32_t taps, int32_t cin, int32_t frames, int32_t pad, int32_t dil, void* stream);
+int ctts_k_rope_append(float* qkv, void* kcache, void* vcache, int32_t kv_dtype, int32_t cmax, const float* cos_tab, const float* sin_tab,
+                       int32_t q_per_b, const int32_t* len, const int32_t* kv_start, int32_t M, void* stream);
+int ctts_k_attention(const float* qkv, const void* kcache, const void* vcache, int32_t kv_dtype, int32_t cmax, float* out,
+                     int32_t q_per_b, const int32_t* len, const int32_t* kv_start, int32_t M, void* stream);
+int ctts_k_embed_codes(const float* emb_code, const int64_t* ids_buf, int32_t tcap, const int32_t* len, float* x, int32_t B, void* stream);
+int ctts_k_final_norm(const float* x, int32_t q_per_b, const float* w, float eps, float* hfin, float* hiddens, int32_t max_new,
+                      const int32_t* len, int32_t T, int32_t B, void* stream);
+int ctts_k_sample(const ctts_gen_state* s, const float* logits, void* stream);
+int ctts_k_dwconv_ln(const float* x, const float* w, const float* b, const float* ln_w, const float* ln_b, float eps, int32_t dil,
+                     float* y, int32_t B, int32_t F, void* stream);
+int ctts_k_layernorm(const float* x, const float* w, const float* b, float eps, float* y, int32_t rows, void* stream);
+int ctts_k_istft(const float* head, const float* window, const float* twiddle, float* frames, float* wav, int32_t B, int32_t F, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

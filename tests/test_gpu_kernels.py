@@ -1,0 +1,385 @@
+"""Per-kernel parity: every HIP kernel, called through the C ABI, against the numpy oracle
+(oracle/*.py) or the reference-generated goldens.  Needs a real MI355X: `pytest -m gpu`."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from chattts_amd import _lib, rng  # noqa: E402
+from oracle import cases, codec_np, llama_np, sampling_np  # noqa: E402
+
+f32 = np.float32
+
+
+@pytest.fixture(scope="module")
+def G():
+    from tests import gpu_util
+    assert torch.cuda.is_available(), "-m gpu tests need a GPU"
+    return gpu_util
+
+
+# ------------------------------------------------------------------------------------------------
+# skinny GEMM (decode / prefill projections)
+# ------------------------------------------------------------------------------------------------
+SK_SHAPES = [  # (N, K, epi, rms)
+    (2304, 768, 0, True),    # RMSNorm + QKV
+    (768, 768, 1, False),    # o_proj + residual
+    (3072, 768, 2, True),    # RMSNorm + gate/up + SiLU*up
+    (768, 3072, 1, False),   # down_proj + residual
+    (2504, 768, 0, False),   # heads (N not a multiple of 16)
+]
+
+
+@pytest.mark.parametrize("wt", ["f32", "bf16"])
+@pytest.mark.parametrize("M", [1, 7, 16, 33, 64, 150])
+@pytest.mark.parametrize("shape", SK_SHAPES)
+def test_gemm_skinny(G, wt, M, shape):
+    N, K, epi, rms = shape
+    rs = np.random.RandomState(M * 131 + N + K)
+    A = rs.standard_normal((M, K)).astype(f32) * (2.0 if rms else 1.0)
+    nrows = 2 * N if epi == 2 else N
+    W = (rs.standard_normal((nrows, K)) * 0.03).astype(f32)
+    nw = (1.0 + 0.1 * rs.standard_normal(K)).astype(f32) if rms else None
+    res = rs.standard_normal((M, N)).astype(f32) if epi == 1 else None
+    got = G.gemm(A, W, wt=wt, epi=epi, norm_w=nw, res=res, n_out=N)
+    An = llama_np.rmsnorm(A, nw, f32(1e-6)) if rms else A
+    Wr = W
+    if wt == "bf16":
+        An, Wr = G.bf16_round(An), G.bf16_round(W)
+    acc = An.astype(np.float64) @ Wr.astype(np.float64).T
+    if epi == 2:
+        g, u = acc[:, :N], acc[:, N:]
+        ref = g / (1.0 + np.exp(-g)) * u
+    elif epi == 1:
+        ref = res + acc
+    else:
+        ref = acc
+    assert np.isfinite(got).all()
+    tol = 3e-6 if wt == "f32" else 2e-4   # bf16: inputs are rounded identically; only f32 accumulation order differs
+    assert G.relerr(got, ref) < tol, (wt, M, shape, G.relerr(got, ref))
+
+
+# asymmetric-B identity check: catches a row<->col swap in the C/D fragment mapping
+def test_gemm_skinny_identity(G):
+    K = 768
+    A = np.zeros((16, K), f32)
+    A[np.arange(16), np.arange(16)] = 1.0
+    W = (np.arange(32 * K, dtype=f32).reshape(32, K) % 97) * 0.25
+    for wt in ("f32", "bf16"):
+        got = G.gemm(A, W, wt=wt)
+        assert np.array_equal(got, W[:, :16].T), wt
+
+
+# ------------------------------------------------------------------------------------------------
+# tiled GEMM (codec dense layers incl. conv-as-GEMM)
+# ------------------------------------------------------------------------------------------------
+def _conv_ref(X, Wt, B, F, taps, pad):
+    """X [B*F, Cin], Wt [Cout, Cin, k] torch layout -> [B*F, Cout] float64"""
+    Cin = X.shape[1]
+    x = X.reshape(B, F, Cin)
+    y = codec_np.conv1d_cl(x, Wt.astype(f32), None, pad=pad).astype(np.float64)
+    return y.reshape(B * F, -1)
+
+
+@pytest.mark.parametrize("case", [
+    dict(B=3, F=50, cin=384, cout=128, taps=3, pad=1, epi=4),    # conv_in.0 + bias + GELU
+    dict(B=3, F=50, cin=128, cout=512, taps=3, pad=1, epi=3),    # conv_in.2 + bias
+    dict(B=2, F=37, cin=100, cout=512, taps=7, pad=3, epi=3),    # vocos embed (K = 700, ragged)
+    dict(B=2, F=37, cin=384, cout=100, taps=3, pad=1, epi=6),    # out_conv * coef (N = 100)
+    dict(B=1, F=5, cin=384, cout=128, taps=3, pad=1, epi=4),     # fewer frames than one tile
+])
+def test_gemm_tiled_conv(G, case):
+    c = case
+    rs = np.random.RandomState(c["cin"] + c["cout"])
+    X = rs.standard_normal((c["B"] * c["F"], c["cin"])).astype(f32)
+    Wt = (rs.standard_normal((c["cout"], c["cin"], c["taps"])) / np.sqrt(c["cin"] * c["taps"])).astype(f32)
+    Wp = np.ascontiguousarray(Wt.transpose(0, 2, 1)).reshape(c["cout"], c["taps"] * c["cin"])
+    bias = rs.standard_normal(c["cout"]).astype(f32) * 0.1
+    gam = (0.5 + rs.rand(c["cout"])).astype(f32)
+    got = G.gemm(X, Wp, tiled=True, epi=c["epi"], bias=bias, gamma=gam, taps=c["taps"], cin=c["cin"], frames=c["F"], pad=c["pad"])
+    acc = _conv_ref(X, Wt, c["B"], c["F"], c["taps"], c["pad"])
+    if c["epi"] == 4:
+        ref = codec_np.gelu((acc + bias).astype(f32))
+    elif c["epi"] == 3:
+        ref = acc + bias
+    else:
+        ref = acc * gam
+    assert G.relerr(got, ref) < 1e-5, G.relerr(got, ref)
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(200, 2048, 512, 4), (200, 512, 2048, 5), (130, 384, 512, 0), (70, 1026, 512, 3), (64, 1536, 512, 4)])
+def test_gemm_tiled_linear(G, M, N, K, epi):
+    rs = np.random.RandomState(M + N + K)
+    A = rs.standard_normal((M, K)).astype(f32)
+    W = (rs.standard_normal((N, K)) / np.sqrt(K)).astype(f32)
+    bias = rs.standard_normal(N).astype(f32) * 0.1
+    gam = (0.05 + 0.1 * rs.rand(N)).astype(f32)
+    res = rs.standard_normal((M, N)).astype(f32)
+    got = G.gemm(A, W, tiled=True, epi=epi, bias=bias, gamma=gam, res=res)
+    acc = A.astype(np.float64) @ W.astype(np.float64).T
+    ref = {0: acc, 3: acc + bias, 4: codec_np.gelu((acc + bias).astype(f32)), 5: res + gam * (acc + bias)}[epi]
+    assert G.relerr(got, ref) < 1e-5, G.relerr(got, ref)
+
+
+# ------------------------------------------------------------------------------------------------
+# RoPE + KV append + attention (prefill rows, then a decode row), both KV dtypes
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kv", ["f32", "bf16"])
+def test_rope_attention(G, kv):
+    from chattts_amd.engine import rope_tables
+    lib = _lib.lib()
+    B, T, nh, d, H = 3, 21, 12, 64, 768
+    cmax = T + 80
+    kv_start = np.array([0, 4, 13], np.int32)
+    rs = np.random.RandomState(5)
+    code = _lib.BF16 if kv == "bf16" else _lib.F32
+    tdt = torch.bfloat16 if kv == "bf16" else torch.float32
+    cos, sin = rope_tables(256)
+    cos_d, sin_d = G.dev(cos), G.dev(sin)
+    kc = torch.zeros((B, nh, cmax, d), dtype=tdt, device=G.DEV)
+    vc = torch.zeros_like(kc)
+    ks_d = G.dev(kv_start)
+    inv_freq = (1.0 / (10000.0 ** (np.arange(0, d, 2, dtype=np.float64) / d))).astype(f32)
+
+    def ref_rows(qkv, slots_b, Kc, Vc):
+        """numpy attention for query rows given as list of (b, slot); Kc/Vc [B,nh,cmax,d] f32 (already appended)"""
+        out = np.zeros((len(slots_b), H), f32)
+        for r, (b, slot) in enumerate(slots_b):
+            lo = min(kv_start[b], slot)
+            q = qkv[r, :H].reshape(nh, d)
+            Kb, Vb = Kc[b, :, lo: slot + 1], Vc[b, :, lo: slot + 1]
+            s = np.einsum("hd,hjd->hj", q.astype(np.float64), Kb.astype(np.float64)) * 0.125
+            p = np.exp(s - s.max(-1, keepdims=True))
+            p /= p.sum(-1, keepdims=True)
+            out[r] = np.einsum("hj,hjd->hd", p, Vb.astype(np.float64)).reshape(H)
+        return out
+
+    def rope_np(x, pos):  # x [nh, d]
+        c, s_ = llama_np.rope_tables(np.array([pos]), inv_freq)
+        rot = np.concatenate([-x[:, d // 2:], x[:, : d // 2]], -1)
+        return x * c[0] + rot * s_[0]
+
+    Kc = np.zeros((B, nh, cmax, d), f32)
+    Vc = np.zeros_like(Kc)
+    # ---- prefill: M = B*T rows
+    qkv = rs.standard_normal((B * T, 3 * H)).astype(f32)
+    qkv_d = G.dev(qkv)
+    _lib.check(lib.ctts_k_rope_append(qkv_d.data_ptr(), kc.data_ptr(), vc.data_ptr(), code, cmax, cos_d.data_ptr(), sin_d.data_ptr(),
+                                      T, None, ks_d.data_ptr(), B * T, None), "rope")
+    out_d = torch.full((B * T, H), float("nan"), dtype=torch.float32, device=G.DEV)
+    _lib.check(lib.ctts_k_attention(qkv_d.data_ptr(), kc.data_ptr(), vc.data_ptr(), code, cmax, out_d.data_ptr(), T, None,
+                                    ks_d.data_ptr(), B * T, None), "attn")
+    torch.cuda.synchronize()
+    qkv_r = qkv.copy()
+    rows = []
+    for b in range(B):
+        for t in range(T):
+            pos = t - kv_start[b]
+            pos = 1 if pos < 0 else pos
+            m = b * T + t
+            qkv_r[m, :H] = rope_np(qkv[m, :H].reshape(nh, d), pos).reshape(H)
+            Kc[b, :, t] = rope_np(qkv[m, H:2 * H].reshape(nh, d), pos)
+            Vc[b, :, t] = qkv[m, 2 * H:].reshape(nh, d)
+            rows.append((b, t))
+    if kv == "bf16":
+        Kc, Vc = G.bf16_round(Kc), G.bf16_round(Vc)
+    got_q = qkv_d.cpu().numpy()[:, :H]
+    assert np.abs(got_q - qkv_r[:, :H]).max() < 1e-5
+    assert np.abs(kc.float().cpu().numpy()[:, :, :T] - Kc[:, :, :T]).max() < (1e-5 if kv == "f32" else 1e-2)
+    ref = ref_rows(qkv_r, rows, Kc, Vc)
+    got = out_d.cpu().numpy()
+    valid = np.array([t >= kv_start[b] for b, t in rows])
+    assert np.isfinite(got).all()
+    assert np.abs(got[valid] - ref[valid]).max() < 2e-5, np.abs(got[valid] - ref[valid]).max()
+    # ---- decode rows at different context lengths (exercise multi-block / multi-wave paths)
+    for extra in (1, 37, 70):
+        # fill the cache with random K/V up to len-1, then append one row per b
+        lens = np.array([T + extra, T + extra, T + extra], np.int32)
+        fillK = rs.standard_normal((B, nh, cmax, d)).astype(f32)
+        fillV = rs.standard_normal((B, nh, cmax, d)).astype(f32)
+        if kv == "bf16":
+            fillK, fillV = G.bf16_round(fillK), G.bf16_round(fillV)
+        kc.copy_(G.dev(fillK).to(tdt))
+        vc.copy_(G.dev(fillV).to(tdt))
+        qkv1 = rs.standard_normal((B, 3 * H)).astype(f32)
+        q1_d = G.dev(qkv1)
+        len_d = G.dev(lens)
+        _lib.check(lib.ctts_k_rope_append(q1_d.data_ptr(), kc.data_ptr(), vc.data_ptr(), code, cmax, cos_d.data_ptr(), sin_d.data_ptr(),
+                                          1, len_d.data_ptr(), ks_d.data_ptr(), B, None), "rope1")
+        o1 = torch.full((B, H), float("nan"), dtype=torch.float32, device=G.DEV)
+        _lib.check(lib.ctts_k_attention(q1_d.data_ptr(), kc.data_ptr(), vc.data_ptr(), code, cmax, o1.data_ptr(), 1, len_d.data_ptr(),
+                                        ks_d.data_ptr(), B, None), "attn1")
+        torch.cuda.synchronize()
+        Kr, Vr = fillK.copy(), fillV.copy()
+        qr = qkv1.copy()
+        rows1 = []
+        for b in range(B):
+            slot = lens[b] - 1
+            pos = slot - kv_start[b]
+            qr[b, :H] = rope_np(qkv1[b, :H].reshape(nh, d), pos).reshape(H)
+            Kr[b, :, slot] = rope_np(qkv1[b, H:2 * H].reshape(nh, d), pos)
+            Vr[b, :, slot] = qkv1[b, 2 * H:].reshape(nh, d)
+            rows1.append((b, slot))
+        if kv == "bf16":
+            Kr, Vr = G.bf16_round(Kr), G.bf16_round(Vr)
+        ref1 = ref_rows(qr, rows1, Kr, Vr)
+        err = np.abs(o1.cpu().numpy() - ref1).max()
+        assert err < 2e-5, (extra, err)
+
+
+# ------------------------------------------------------------------------------------------------
+def test_embed_and_final_norm(G):
+    lib = _lib.lib()
+    rs = np.random.RandomState(3)
+    B, tcap, T, max_new = 5, 20, 6, 14
+    emb = rs.standard_normal((4, 626, 768)).astype(f32)
+    ids = rs.randint(0, 626, size=(B, tcap, 4)).astype(np.int64)
+    lens = np.array([7, 8, 9, 12, 20], np.int32)
+    x = torch.empty((B, 768), dtype=torch.float32, device=G.DEV)
+    e_d, i_d, l_d = G.dev(emb), G.dev(ids), G.dev(lens)
+    _lib.check(lib.ctts_k_embed_codes(e_d.data_ptr(), i_d.data_ptr(), tcap, l_d.data_ptr(), x.data_ptr(), B, None), "embed")
+    ref = np.stack([((emb[0][ids[b, lens[b] - 1, 0]] + emb[1][ids[b, lens[b] - 1, 1]]) + emb[2][ids[b, lens[b] - 1, 2]])
+                    + emb[3][ids[b, lens[b] - 1, 3]] for b in range(B)])
+    assert np.array_equal(x.cpu().numpy(), ref)  # same k-ordered f32 adds -> bit exact
+    # final norm, decode layout (q_per_b = 1) and prefill layout (q_per_b = T)
+    w = (1 + 0.1 * rs.standard_normal(768)).astype(f32)
+    for qpb in (1, T):
+        xin = rs.standard_normal((B * qpb, 768)).astype(f32) * 3
+        hfin = torch.empty((B, 768), dtype=torch.float32, device=G.DEV)
+        hid = torch.zeros((B, max_new, 768), dtype=torch.float32, device=G.DEV)
+        x_d, w_d = G.dev(xin), G.dev(w)
+        _lib.check(lib.ctts_k_final_norm(x_d.data_ptr(), qpb, w_d.data_ptr(), 1e-6, hfin.data_ptr(), hid.data_ptr(), max_new,
+                                         l_d.data_ptr(), T, B, None), "final_norm")
+        last = xin.reshape(B, qpb, 768)[:, -1]
+        refn = llama_np.rmsnorm(last, w, f32(1e-6))
+        assert np.abs(hfin.cpu().numpy() - refn).max() < 2e-6
+        h = hid.cpu().numpy()
+        for b in range(B):
+            g = lens[b] - T
+            assert np.array_equal(h[b, g], hfin.cpu().numpy()[b])
+
+
+# ------------------------------------------------------------------------------------------------
+# fused sampling kernel vs the reference's own outputs (goldens) and the oracle
+# ------------------------------------------------------------------------------------------------
+def run_sample_kernel(G, logits, hist, temp4, q, *, top_p, top_k, rep, mask_eos, row_offset=0, stop_at=None):
+    lib = _lib.lib()
+    rows, V = logits.shape
+    B = rows // 4
+    h = hist.shape[1]
+    T = 1
+    tcap = T + h + 2
+    ids = np.zeros((B, tcap, 4), np.int64)
+    if h:
+        ids[:, T: T + h, :] = hist.reshape(B, 4, h).transpose(0, 2, 1)
+    keep = []
+    d = lambda a: (keep.append(G.dev(a)), keep[-1])[1]
+    s = _lib.GenState()
+    s.B, s.T, s.max_new = B, T, h + 2
+    ids_d = d(ids)
+    len_d = d(np.full(B, T + h, np.int32))
+    fin_d = d(np.zeros(B, np.uint8))
+    end_d = d(np.zeros(B, np.int32))
+    s.ids_buf, s.len, s.finish, s.end_idx = ids_d.data_ptr(), len_d.data_ptr(), fin_d.data_ptr(), end_d.data_ptr()
+    s.q, s.nq = d(q.reshape(1, rows, V)).data_ptr(), 1
+    s.temperature = d(temp4.astype(f32)).data_ptr()
+    pt = rng.penalty_table(rep)
+    s.pow_table = None if pt is None else d(pt.numpy()).data_ptr()
+    s.top_p_thr = float(np.float32(1.0 - top_p)) if top_p is not None else 0.0
+    s.use_top_p, s.top_k, s.use_top_k = int(top_p is not None), int(top_k or 0), int(top_k is not None)
+    s.min_new = (h + 1) if mask_eos else 0
+    s.eos, s.row_offset = 625, row_offset
+    s.stop_at = None if stop_at is None else d(stop_at.astype(np.int32)).data_ptr()
+    lg = d(logits.reshape(B, 4 * V))
+    _lib.check(lib.ctts_k_sample(C.byref(s), lg.data_ptr(), None), "sample")
+    torch.cuda.synchronize()
+    out = ids_d.cpu().numpy()[:, T + h, :].reshape(-1)
+    return out, fin_d.cpu().numpy(), end_d.cpu().numpy(), len_d.cpu().numpy()
+
+
+@pytest.mark.parametrize("name", list(cases.SAMPLING_CASES))
+def test_sample_vs_reference_golden(G, golden, name):
+    c = cases.SAMPLING_CASES[name]
+    logits, hist, temp = cases.sampling_inputs(c)
+    rows, V = logits.shape
+    q = rng.ExpDraws(rows, V, c["seed"]).step(0).numpy()
+    got, fin, end, lens = run_sample_kernel(G, logits, hist, temp[:4], q, top_p=c["top_P"], top_k=c["top_K"], rep=c["rep"],
+                                            mask_eos=c["mask_eos"])
+    want = golden["sampling"][name + ".idx"]
+    assert np.array_equal(got, want), (name, int((got != want).sum()))
+    assert np.array_equal(fin, (want.reshape(-1, 4) == 625).any(1).astype(np.uint8))
+    assert np.array_equal(end, 1 - fin)
+    assert (lens == 1 + hist.shape[1] + 1).all()
+
+
+def test_sample_row_offset_and_stop(G):
+    """sharded rows keep the global rows>=625 quirk; stop_at forces / masks EOS like the oracle hook"""
+    c = cases.SAMPLING_CASES["rows640"]
+    logits, hist, temp = cases.sampling_inputs(c)
+    q = rng.ExpDraws(640, 626, c["seed"]).step(0).numpy()
+    pt = rng.penalty_table(c["rep"]).numpy()
+    sl = slice(600, 640)
+    got, *_ = run_sample_kernel(G, logits[sl], hist[sl], temp[:4], q[sl], top_p=c["top_P"], top_k=c["top_K"], rep=c["rep"],
+                                mask_eos=False, row_offset=600)
+    want = sampling_np.sample_step(logits[sl], hist[sl], q[sl], temperature=temp[sl], top_p=c["top_P"], top_k=c["top_K"],
+                                   pow_table=pt, max_input_ids=625, row_offset=600)
+    assert np.array_equal(got, want)
+    # stop_at: rows of batch element 0 forced (gen=12 >= 5), element 1 masked (gen < 50), element 2 free
+    stop = np.array([5, 50, -1] + [-1] * 7, np.int32)
+    sl = slice(0, 40)
+    got, fin, end, _ = run_sample_kernel(G, logits[sl], hist[sl], temp[:4], q[sl], top_p=c["top_P"], top_k=c["top_K"], rep=c["rep"],
+                                         mask_eos=False, stop_at=stop)
+    sa = np.repeat(stop, 4)
+    want = sampling_np.sample_step(logits[sl], hist[sl], q[sl], temperature=temp[sl], top_p=c["top_P"], top_k=c["top_K"],
+                                   pow_table=pt, max_input_ids=625, mask_eos=(sa >= 0) & (12 < sa), force_eos=(sa >= 0) & (12 >= sa))
+    assert np.array_equal(got, want)
+    assert (got[:4] == 625).all() and fin[0] == 1 and end[0] == 0
+
+
+# ------------------------------------------------------------------------------------------------
+# codec streaming kernels
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dil", [1, 2])
+def test_dwconv_ln(G, dil):
+    lib = _lib.lib()
+    rs = np.random.RandomState(dil)
+    B, F, Cc = 2, 29, 512
+    x = rs.standard_normal((B, F, Cc)).astype(f32)
+    w = rs.standard_normal((Cc, 1, 7)).astype(f32) * 0.4
+    b = rs.standard_normal(Cc).astype(f32) * 0.1
+    lw = (1 + 0.1 * rs.standard_normal(Cc)).astype(f32)
+    lb = rs.standard_normal(Cc).astype(f32) * 0.1
+    y = torch.empty((B, F, Cc), dtype=torch.float32, device=G.DEV)
+    keep = [G.dev(x), G.dev(np.ascontiguousarray(w[:, 0, :].T)), G.dev(b), G.dev(lw), G.dev(lb)]
+    _lib.check(lib.ctts_k_dwconv_ln(*[k.data_ptr() for k in keep], 1e-6, dil, y.data_ptr(), B, F, None), "dwconv_ln")
+    ref = codec_np.layer_norm(codec_np.dwconv1d_cl(x, w, b, pad=3 * dil, dil=dil), lw, lb, 1e-6)
+    assert np.abs(y.cpu().numpy() - ref).max() < 2e-5
+    y2 = torch.empty((B * F, Cc), dtype=torch.float32, device=G.DEV)
+    _lib.check(lib.ctts_k_layernorm(keep[0].data_ptr(), keep[3].data_ptr(), keep[4].data_ptr(), 1e-6, y2.data_ptr(), B * F, None), "ln")
+    assert np.abs(y2.cpu().numpy() - codec_np.layer_norm(x, lw, lb, 1e-6).reshape(B * F, Cc)).max() < 2e-5
+
+
+@pytest.mark.parametrize("B,F", [(1, 2), (2, 9), (3, 40)])
+def test_istft(G, B, F):
+    import math
+    lib = _lib.lib()
+    rs = np.random.RandomState(F)
+    head = rs.standard_normal((B, F, 1026)).astype(f32)
+    head[..., :513] = head[..., :513] * 0.7 + 0.5
+    head[0, 0, 3] = 9.0  # exercises the exp clip at 1e2
+    window = torch.hann_window(1024).numpy()
+    kk = np.arange(512, dtype=np.float64) * (2 * math.pi / 1024)
+    tw = np.stack([np.cos(kk), np.sin(kk)], 1).astype(f32)
+    frames = torch.empty((B, F, 1024), dtype=torch.float32, device=G.DEV)
+    wav = torch.empty((B, 256 * (F - 1)), dtype=torch.float32, device=G.DEV)
+    keep = [G.dev(head), G.dev(window), G.dev(tw)]
+    _lib.check(lib.ctts_k_istft(keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr(), frames.data_ptr(), wav.data_ptr(), B, F, None), "istft")
+    mag = np.minimum(np.exp(head[..., :513]), f32(1e2))
+    spec = mag * (np.cos(head[..., 513:]) + 1j * np.sin(head[..., 513:]))
+    ref = codec_np.istft_center(spec, window, 1024, 256)
+    got = wav.cpu().numpy()
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() < 5e-5 * max(1.0, np.abs(ref).max()), np.abs(got - ref).max()

@@ -1,0 +1,146 @@
+"""CPU-side tests: the C-ABI library loads and exports every declared symbol (no compute calls),
+host logic of the engine, sharding + weight broadcast over gloo (world_size 2)."""
+import os
+import re
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+from chattts_amd import _lib, dist as D, engine as E, rng, synth  # noqa: E402
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "chattts_amd.h")).read()
+    declared = set(re.findall(r"\b(ctts_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = _lib.lib()  # dlopen + getattr of every symbol
+    assert lib.ctts_version() == 1
+    assert lib.ctts_gpt_workspace_bytes(64, 48) > 64 * 48 * (768 + 2304 + 768 + 3072) * 4
+    assert lib.ctts_codec_workspace_bytes(2, 10) > 0
+
+
+def test_engine_fails_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(_lib.EngineError):
+        E.GptEngine({}, {}, torch.device("cpu"))
+    with pytest.raises(_lib.EngineError):
+        E.CodecEngine({}, {}, torch.device("cpu"))
+
+
+def test_plan_from_processors_accepts_reference_objects():
+    from transformers.generation import TopKLogitsWarper, TopPLogitsWarper
+    warpers, procs = E.gen_logits(625, 0.7, 20, 1.05)
+    p = E.plan_from_processors((*procs, *warpers))
+    assert (p.penalty, p.top_p, p.top_k) == (1.05, 0.7, 20)
+    p = E.plan_from_processors([TopPLogitsWarper(0.5, min_tokens_to_keep=3), TopKLogitsWarper(7, min_tokens_to_keep=3)])
+    assert (p.penalty, p.top_p, p.top_k) == (None, 0.5, 7)
+    assert E.plan_from_processors(E.gen_logits(625, None, None, 1.0)[0]) == E.SamplingPlan()
+    with pytest.raises(NotImplementedError):
+        E.plan_from_processors([lambda ids, scores: scores])
+    with pytest.raises(NotImplementedError):  # wrong order
+        E.plan_from_processors([E.TopK(5), E.TopP(0.5)])
+
+
+def test_left_pad_starts():
+    m = torch.tensor([[0, 0, 1, 1], [1, 1, 1, 1], [0, 1, 1, 1]])
+    assert E.left_pad_starts(m).tolist() == [2, 0, 1]
+    with pytest.raises(NotImplementedError):
+        E.left_pad_starts(torch.tensor([[1, 0, 1, 1]]))
+    with pytest.raises(ValueError):
+        E.left_pad_starts(torch.tensor([[0, 0, 0, 0]]))
+
+
+def test_shard_bounds_cover():
+    for n in (1, 7, 64, 512, 513):
+        for w in (1, 2, 3, 8):
+            b = [D.shard_bounds(n, w, r) for r in range(w)]
+            assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+            sizes = [hi - lo for lo, hi in b]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_exp_draws_shard_is_slice_of_full_batch():
+    full = rng.ExpDraws(64, 626, 42).step(0)
+    part = rng.ExpDraws(64, 626, 42, row_begin=24, row_end=40).step(0)
+    assert torch.equal(part, full[24:40])
+    assert torch.equal(rng.ExpDraws(64, 626, 42).step(5), full)  # re-seeded every step (gpt.py:504-507)
+    torch.manual_seed(3)
+    a = rng.ExpDraws(8, 626, None)
+    s0, s1 = a.step(0), a.step(1)
+    assert not torch.equal(s0, s1)
+    torch.manual_seed(3)
+    assert torch.equal(torch.empty(8, 626).exponential_(1), s0)
+
+
+def test_rope_table_matches_hf():
+    from transformers import LlamaConfig
+    from transformers.models.llama.modeling_llama import LlamaRotaryEmbedding
+    cfg = LlamaConfig(hidden_size=768, num_attention_heads=12, max_position_embeddings=4096)
+    rot = LlamaRotaryEmbedding(cfg)
+    pos = torch.arange(0, 300)[None]
+    cos, sin = rot(torch.zeros(1, 300, 768), pos)
+    c, s = E.rope_tables(300)
+    assert torch.equal(cos[0, :, :32], c) and torch.equal(sin[0, :, :32], s)
+    assert torch.equal(cos[0, :, 32:], c)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from chattts_amd import weights as W
+        sds = None
+        if rank == 0:
+            sds = {"gpt": W.synthetic_gpt(n_layers=1), "embed": {"emb_code.0.weight": torch.randn(626, 8)},
+                   "decoder": {"coef": torch.rand(1, 100, 1)}, "vocos": {"head.istft.window": torch.hann_window(1024)}}
+        meta = {"gpt": D.weights_meta(1)["gpt"], "embed": {"emb_code.0.weight": ((626, 8), torch.float32)},
+                "decoder": {"coef": ((1, 100, 1), torch.float32)}, "vocos": {"head.istft.window": ((1024,), torch.float32)}}
+        got = D.broadcast_state_dicts(sds, src=0, device=None, meta=meta)
+        fp = W.fingerprint(got["gpt"])
+        # sharded sampling == rows of the full batch (global row numbering for draws and the >=625 quirk)
+        from oracle import cases, sampling_np
+        c = cases.SAMPLING_CASES["rows640"]
+        logits, hist, temp = cases.sampling_inputs(c)
+        lo, hi = D.shard_bounds(160, world, rank)
+        r0, r1 = lo * 4, hi * 4
+        qd = rng.ExpDraws(640, 626, c["seed"], row_begin=r0, row_end=r1).step(0).numpy()
+        idx = sampling_np.sample_step(logits[r0:r1], hist[r0:r1], qd, temperature=temp[r0:r1], top_p=c["top_P"], top_k=c["top_K"],
+                                      pow_table=rng.penalty_table(c["rep"]).numpy(), max_input_ids=625, row_offset=r0)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (fp, r0, idx.tolist()))
+        if rank == 0:
+            q.put(gathered)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_broadcast_and_sharded_sampling(golden):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][0] == res[1][0]  # identical weights on both ranks after the broadcast
+    idx = np.array(res[0][2] + res[1][2])
+    assert np.array_equal(idx, golden["sampling"]["rows640.idx"])  # union of shards == the reference's full-batch run
