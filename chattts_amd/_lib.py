@@ -5,6 +5,9 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+import torch  # noqa: F401  -- MUST precede the dlopen below: torch bundles its own libamdhip64; loading ours first
+#                  would bind libchattts_amd.so to a second HIP runtime that cannot see torch's device context
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "libchattts_amd.so")
 
@@ -71,6 +74,8 @@ SIGNATURES = {
     "ctts_dvae_decode": (C.c_int, [P, P, P, I32, I32, P, SZ, P]),
     "ctts_vocos_decode": (C.c_int, [P, P, P, I32, I32, P, SZ, P]),
     "ctts_k_gemm": (C.c_int, [I32, P, P, P, I32, I32, I32, I32, I32, I32, I32, P, F, P, I32, P, P, I32, I32, I32, I32, I32, P]),
+    "ctts_k_gemm_fast": (C.c_int, [P, I32, P, I32, I32, I32, P, F, I32, P, I32, P, I32, P, P]),
+    "ctts_k_rows_prep": (C.c_int, [P, P, P, I32, P]),
     "ctts_k_rope_append": (C.c_int, [P, P, P, I32, I32, P, P, I32, P, P, I32, P]),
     "ctts_k_attention": (C.c_int, [P, P, P, I32, I32, P, I32, P, P, I32, P]),
     "ctts_k_embed_codes": (C.c_int, [P, P, I32, P, P, I32, P]),

@@ -45,7 +45,8 @@ struct ctts_gpt {
 static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct GptWs {
-  float *x, *qkv, *ao, *act, *hfin, *logits;
+  float *x, *qkv, *ao, *act, *hfin, *logits, *ssq;
+  uint16_t* xb;  // bf16 copy of the residual stream (perf mode); ao / act are reused as bf16 buffers there
   size_t bytes;
 };
 static GptWs carve(void* base, int B, int T) {
@@ -59,6 +60,8 @@ static GptWs carve(void* base, int B, int T) {
   w.act = (float*)(p + off); off += align_up(M * INTER * 4);
   w.hfin = (float*)(p + off); off += align_up((size_t)B * HID * 4);
   w.logits = (float*)(p + off); off += align_up((size_t)B * NVQ * NAUDIO * 4);
+  w.ssq = (float*)(p + off); off += align_up(M * SSQ_PARTS * 4);
+  w.xb = (uint16_t*)(p + off); off += align_up(M * HID * 2);
   w.bytes = off;
   return w;
 }
@@ -82,15 +85,15 @@ extern "C" int ctts_gpt_create(ctts_gpt** out, const ctts_gpt_weights* w) {
 
 extern "C" void ctts_gpt_graph_destroy(ctts_gpt* g) {
   if (!g) return;
-  if (g->exec) { hipGraphExecDestroy(g->exec); g->exec = nullptr; }
-  if (g->graph) { hipGraphDestroy(g->graph); g->graph = nullptr; }
+  if (g->exec) { (void)hipGraphExecDestroy(g->exec); g->exec = nullptr; }
+  if (g->graph) { (void)hipGraphDestroy(g->graph); g->graph = nullptr; }
 }
 
 extern "C" void ctts_gpt_destroy(ctts_gpt* g) {
   if (!g) return;
   ctts_gpt_graph_destroy(g);
-  for (auto e : g->ev0) hipEventDestroy(e);
-  for (auto e : g->ev1) hipEventDestroy(e);
+  for (auto e : g->ev0) (void)hipEventDestroy(e);
+  for (auto e : g->ev1) (void)hipEventDestroy(e);
   delete g;
 }
 
@@ -99,11 +102,11 @@ struct Prof {
   Prof(ctts_gpt* g_, int tag, hipStream_t st_, bool allow) : g(g_), st(st_), on(false), idx(0) {
     if (allow && g->prof_tag == tag && g->prof_n < g->prof_max) {
       on = true; idx = g->prof_n;
-      hipEventRecord(g->ev0[idx], st);
+      (void)hipEventRecord(g->ev0[idx], st);
     }
   }
   ~Prof() {
-    if (on) { hipEventRecord(g->ev1[idx], st); g->prof_n++; }
+    if (on) { (void)hipEventRecord(g->ev1[idx], st); g->prof_n++; }
   }
 };
 
@@ -133,7 +136,31 @@ static int run_step(ctts_gpt* g, const ctts_gen_state* s, int q_per_b, hipStream
   const int wt = g->w.weight_dtype, kt = g->w.kv_dtype;
   const size_t kv_layer = (size_t)B * NHEAD * cmax * HDIM * (kt == CTTS_BF16 ? 2 : 4);
   GptRowMap rm{q_per_b, s->len, s->kv_start};
-  for (int l = 0; l < g->w.n_layers; ++l) {
+  const bool fast = wt == CTTS_BF16;  // perf mode: bf16 activations, RMSNorm gain folded into wqkv / wgu by the loader
+  for (int l = 0; fast && l < g->w.n_layers; ++l) {
+    void* kc = (char*)s->kcache + kv_layer * l;
+    void* vc = (char*)s->vcache + kv_layer * l;
+    uint16_t* aob = (uint16_t*)ws.ao;
+    uint16_t* actb = (uint16_t*)ws.act;
+    FastGemmArgs f;
+    memset(&f, 0, sizeof(f));
+    f.M = M; f.eps = g->w.rms_eps;
+    f.A = ws.xb; f.lda = HID; f.W = (const uint16_t*)g->wqkv[l]; f.N = 3 * HID; f.K = HID; f.ssq_in = ws.ssq; f.epi = FEPI_STORE32;
+    f.C32 = ws.qkv; f.ldc = 3 * HID;
+    { Prof p(g, 1, st, prof_ok); CK(launch_gemm_fast(f, st)); }
+    { Prof p(g, 2, st, prof_ok); CK(launch_rope_append(ws.qkv, kc, vc, kt, cmax, g->w.rope_cos, g->w.rope_sin, rm, M, st)); }
+    { Prof p(g, 3, st, prof_ok); CK(launch_attention(ws.qkv, kc, vc, kt, cmax, aob, 1, rm, M, st)); }
+    f.A = aob; f.W = (const uint16_t*)g->wo[l]; f.N = HID; f.K = HID; f.ssq_in = nullptr; f.epi = FEPI_RES; f.C32 = ws.x; f.ldc = HID;
+    f.Cb = ws.xb; f.ldcb = HID; f.ssq_out = ws.ssq;
+    { Prof p(g, 4, st, prof_ok); CK(launch_gemm_fast(f, st)); }
+    f.A = ws.xb; f.W = (const uint16_t*)g->wgu[l]; f.N = INTER; f.K = HID; f.ssq_in = ws.ssq; f.epi = FEPI_SILU; f.C32 = nullptr;
+    f.Cb = actb; f.ldcb = INTER; f.ssq_out = nullptr;
+    { Prof p(g, 5, st, prof_ok); CK(launch_gemm_fast(f, st)); }
+    f.A = actb; f.lda = INTER; f.W = (const uint16_t*)g->wd[l]; f.N = HID; f.K = INTER; f.ssq_in = nullptr; f.epi = FEPI_RES;
+    f.C32 = ws.x; f.ldc = HID; f.Cb = ws.xb; f.ldcb = HID; f.ssq_out = ws.ssq;
+    { Prof p(g, 6, st, prof_ok); CK(launch_gemm_fast(f, st)); }
+  }
+  for (int l = 0; !fast && l < g->w.n_layers; ++l) {
     void* kc = (char*)s->kcache + kv_layer * l;
     void* vc = (char*)s->vcache + kv_layer * l;
     GemmArgs a;
@@ -144,7 +171,7 @@ static int run_step(ctts_gpt* g, const ctts_gen_state* s, int q_per_b, hipStream
     a.epi = EPI_STORE; a.norm_w = g->ln1[l]; a.eps = g->w.rms_eps;
     { Prof p(g, 1, st, prof_ok); CK(launch_gemm_skinny(a, st)); }
     { Prof p(g, 2, st, prof_ok); CK(launch_rope_append(ws.qkv, kc, vc, kt, cmax, g->w.rope_cos, g->w.rope_sin, rm, M, st)); }
-    { Prof p(g, 3, st, prof_ok); CK(launch_attention(ws.qkv, kc, vc, kt, cmax, ws.ao, rm, M, st)); }
+    { Prof p(g, 3, st, prof_ok); CK(launch_attention(ws.qkv, kc, vc, kt, cmax, ws.ao, 0, rm, M, st)); }
     // o_proj + residual
     a.A = ws.ao; a.lda = HID; a.W = g->wo[l]; a.C = ws.x; a.ldc = HID; a.N = HID; a.K = HID; a.epi = EPI_RES; a.norm_w = nullptr;
     a.res = ws.x; a.ldr = HID;
@@ -178,12 +205,14 @@ extern "C" int ctts_gpt_prefill(ctts_gpt* g, const ctts_gen_state* s, const floa
   hipStream_t st = (hipStream_t)stream;
   const GptWs ws = carve(s->workspace, s->B, s->T);
   CK(hipMemcpyAsync(ws.x, emb, (size_t)s->B * s->T * HID * 4, hipMemcpyDeviceToDevice, st));
+  if (g->w.weight_dtype == CTTS_BF16) CK(launch_rows_prep(ws.x, ws.xb, ws.ssq, s->B * s->T, st));
   return run_step(g, s, s->T, st, false);
 }
 
 static int decode_body(ctts_gpt* g, const ctts_gen_state* s, hipStream_t st, bool prof_ok) {
   const GptWs ws = carve(s->workspace, s->B, s->T);
-  { Prof p(g, 0, st, prof_ok); CK(launch_embed_codes(g->w.emb_code, s->ids_buf, s->T + s->max_new, s->len, ws.x, s->B, st)); }
+  { Prof p(g, 0, st, prof_ok); const bool fast = g->w.weight_dtype == CTTS_BF16;
+    CK(launch_embed_codes(g->w.emb_code, s->ids_buf, s->T + s->max_new, s->len, ws.x, fast ? ws.xb : nullptr, fast ? ws.ssq : nullptr, s->B, st)); }
   return run_step(g, s, 1, st, prof_ok);
 }
 
@@ -364,6 +393,19 @@ extern "C" int ctts_k_gemm(int32_t tiled, const float* A, const void* W, float* 
   CK(tiled ? launch_gemm_tiled(a, (hipStream_t)stream) : launch_gemm_skinny(a, (hipStream_t)stream));
   return 0;
 }
+extern "C" int ctts_k_gemm_fast(const uint16_t* A, int32_t lda, const uint16_t* W, int32_t M, int32_t N, int32_t K, const float* ssq_in,
+                                float eps, int32_t epi, float* C32, int32_t ldc, uint16_t* Cb, int32_t ldcb, float* ssq_out, void* stream) {
+  FastGemmArgs f;
+  memset(&f, 0, sizeof(f));
+  f.A = A; f.lda = lda; f.W = W; f.M = M; f.N = N; f.K = K; f.ssq_in = ssq_in; f.eps = eps; f.epi = epi; f.C32 = C32; f.ldc = ldc;
+  f.Cb = Cb; f.ldcb = ldcb; f.ssq_out = ssq_out;
+  CK(launch_gemm_fast(f, (hipStream_t)stream));
+  return 0;
+}
+extern "C" int ctts_k_rows_prep(const float* x32, uint16_t* xb, float* ssq, int32_t M, void* stream) {
+  CK(launch_rows_prep(x32, xb, ssq, M, (hipStream_t)stream));
+  return 0;
+}
 extern "C" int ctts_k_rope_append(float* qkv, void* kcache, void* vcache, int32_t kv_dtype, int32_t cmax, const float* cos_tab,
                                   const float* sin_tab, int32_t q_per_b, const int32_t* len, const int32_t* kv_start, int32_t M,
                                   void* stream) {
@@ -374,12 +416,12 @@ extern "C" int ctts_k_rope_append(float* qkv, void* kcache, void* vcache, int32_
 extern "C" int ctts_k_attention(const float* qkv, const void* kcache, const void* vcache, int32_t kv_dtype, int32_t cmax, float* out,
                                 int32_t q_per_b, const int32_t* len, const int32_t* kv_start, int32_t M, void* stream) {
   GptRowMap rm{q_per_b, len, kv_start};
-  CK(launch_attention(qkv, kcache, vcache, kv_dtype, cmax, out, rm, M, (hipStream_t)stream));
+  CK(launch_attention(qkv, kcache, vcache, kv_dtype, cmax, out, 0, rm, M, (hipStream_t)stream));
   return 0;
 }
 extern "C" int ctts_k_embed_codes(const float* emb_code, const int64_t* ids_buf, int32_t tcap, const int32_t* len, float* x, int32_t B,
                                   void* stream) {
-  CK(launch_embed_codes(emb_code, ids_buf, tcap, len, x, B, (hipStream_t)stream));
+  CK(launch_embed_codes(emb_code, ids_buf, tcap, len, x, nullptr, nullptr, B, (hipStream_t)stream));
   return 0;
 }
 extern "C" int ctts_k_final_norm(const float* x, int32_t q_per_b, const float* w, float eps, float* hfin, float* hiddens,

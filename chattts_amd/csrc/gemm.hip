@@ -286,3 +286,150 @@ hipError_t launch_gemm_tiled(const GemmArgs& a, hipStream_t st) {
   }
   return hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------------
+// fast bf16 path (perf mode): bf16 activations in, all loads of a round issued before the first MFMA
+// ------------------------------------------------------------------------------------------------
+template <int MB, int NW, bool SCALE, int EPI>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 2))) void gemm_fast_k(FastGemmArgs a) {
+  constexpr int NACC = (EPI == FEPI_SILU) ? 2 : 1;
+  constexpr int U = 6;    // k-chunks (of 32) per wave per round; every lane keeps U*(NACC+MB) 16-byte loads in flight
+  constexpr int KC = 32;
+  __shared__ float red[NW][NACC][MB][64][4];
+  __shared__ float rstd_s[16 * MB];
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 15, g = lane >> 4;
+  const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16 * MB;
+  const int M = a.M, N = a.N, K = a.K;
+
+  // per-row sum of squares: 4 threads x 12 partials per row, consumed only in the epilogue
+  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0;
+  const int srow = tid >> 2, spart = tid & 3;
+  if (SCALE && srow < 16 * MB) {
+    const float* sp = a.ssq_in + (size_t)min(m0 + srow, M - 1) * SSQ_PARTS + spart * 12;
+    s0 = *reinterpret_cast<const float4*>(sp);
+    s1 = *reinterpret_cast<const float4*>(sp + 4);
+    s2 = *reinterpret_cast<const float4*>(sp + 8);
+  }
+
+  const int n = min(n0 + li, N - 1);
+  const uint16_t* wrow = a.W + (size_t)n * K + g * 8;
+  const uint16_t* wrow2 = wrow + (size_t)N * K;
+  const uint16_t* arow[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) arow[mb] = a.A + (size_t)min(m0 + 16 * mb + li, M - 1) * a.lda + g * 8;
+
+  f32x4 acc[NACC][MB];
+#pragma unroll
+  for (int na = 0; na < NACC; ++na)
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) acc[na][mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nper = K / (KC * NW);
+  for (int i = 0; i < nper; i += U) {
+    u128 wf[NACC][U], af[MB][U];
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      const int k0 = ((i + j) * NW + wave) * KC;
+      wf[0][j] = *reinterpret_cast<const u128*>(wrow + k0);
+      if (NACC == 2) wf[1][j] = *reinterpret_cast<const u128*>(wrow2 + k0);
+    }
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      const int k0 = ((i + j) * NW + wave) * KC;
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) af[mb][j] = *reinterpret_cast<const u128*>(arow[mb] + k0);
+    }
+    // keep every load of the round in flight: hipcc otherwise sinks the loads next to their MFMA and
+    // waits vmcnt(1) per fragment (one L2/HBM round trip per MFMA pair)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < U; ++j)
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int na = 0; na < NACC; ++na)
+          acc[na][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&af[mb][j]),
+                                                                *reinterpret_cast<const bf16x8*>(&wf[na][j]), acc[na][mb], 0, 0, 0);
+  }
+
+  if (SCALE) {
+    float s = (((s0.x + s0.y) + (s0.z + s0.w)) + ((s1.x + s1.y) + (s1.z + s1.w))) + ((s2.x + s2.y) + (s2.z + s2.w));
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    if (spart == 0 && srow < 16 * MB) rstd_s[srow] = 1.0f / sqrtf(s / 768.0f + a.eps);
+  }
+#pragma unroll
+  for (int na = 0; na < NACC; ++na)
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[wave][na][mb][lane][r] = acc[na][mb][r];
+  __syncthreads();
+  if (wave < MB) {
+    const int mb = wave;
+    const int col = n0 + li;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = m0 + 16 * mb + 4 * g + r;
+      float v = 0.f, u = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) v += red[w][0][mb][lane][r];
+      if (EPI == FEPI_SILU) {
+#pragma unroll
+        for (int w = 0; w < NW; ++w) u += red[w][NACC - 1][mb][lane][r];
+      }
+      const bool ok = row < M && col < N;
+      if (SCALE) {
+        const float rs = rstd_s[16 * mb + 4 * g + r];
+        v *= rs;
+        u *= rs;
+      }
+      if (EPI == FEPI_STORE32) {
+        if (ok) a.C32[(size_t)row * a.ldc + col] = v;
+      } else if (EPI == FEPI_SILU) {
+        if (ok) a.Cb[(size_t)row * a.ldcb + col] = f32_to_bf16(silu_f(v) * u);
+      } else {  // FEPI_RES
+        float xn = 0.f;
+        if (ok) {
+          xn = a.C32[(size_t)row * a.ldc + col] + v;
+          a.C32[(size_t)row * a.ldc + col] = xn;
+          a.Cb[(size_t)row * a.ldcb + col] = f32_to_bf16(xn);
+        }
+        float sq = xn * xn;
+        sq += __shfl_xor(sq, 1, 64);
+        sq += __shfl_xor(sq, 2, 64);
+        sq += __shfl_xor(sq, 4, 64);
+        sq += __shfl_xor(sq, 8, 64);
+        if (li == 0 && row < M) a.ssq_out[(size_t)row * SSQ_PARTS + blockIdx.x] = sq;
+      }
+    }
+  }
+}
+
+template <int MB>
+static hipError_t fast_dispatch(const FastGemmArgs& a, hipStream_t st) {
+  dim3 grid((a.N + 15) / 16, (a.M + 16 * MB - 1) / (16 * MB));
+  const bool scale = a.ssq_in != nullptr;
+  if (a.K == 768) {
+    if (a.epi == FEPI_STORE32 && scale) hipLaunchKernelGGL((gemm_fast_k<MB, 4, true, FEPI_STORE32>), grid, dim3(256), 0, st, a);
+    else if (a.epi == FEPI_SILU && scale) hipLaunchKernelGGL((gemm_fast_k<MB, 4, true, FEPI_SILU>), grid, dim3(256), 0, st, a);
+    else if (a.epi == FEPI_RES && !scale) hipLaunchKernelGGL((gemm_fast_k<MB, 4, false, FEPI_RES>), grid, dim3(256), 0, st, a);
+    else return hipErrorInvalidValue;
+  } else if (a.K == 3072) {
+    if (a.epi == FEPI_RES && !scale) hipLaunchKernelGGL((gemm_fast_k<MB, 8, false, FEPI_RES>), grid, dim3(512), 0, st, a);
+    else return hipErrorInvalidValue;
+  } else {
+    return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_gemm_fast(const FastGemmArgs& a, hipStream_t st) {
+  if (a.M <= 0 || a.N <= 0 || (a.lda % 8) != 0) return hipErrorInvalidValue;
+  if (a.epi == FEPI_RES && a.N != 16 * SSQ_PARTS) return hipErrorInvalidValue;
+  if (a.M <= 16) return fast_dispatch<1>(a, st);
+  if (a.M <= 32) return fast_dispatch<2>(a, st);
+  return fast_dispatch<4>(a, st);
+}

@@ -20,8 +20,27 @@ __device__ __forceinline__ void row_to_b_slot(const GptRowMap& rm, int m, int& b
 // G1  x[b] = sum_k emb_code[k][ids_buf[b, len[b]-1, k]]     (gpt.py:403-415; k-ordered f32 adds
 //     like torch.stack(code_emb, 3).sum(3))
 // ------------------------------------------------------------------------------------------------
+// emit one residual-stream row: f32, optional bf16 copy, optional 48 partial sums of squares
+// (thread t owns columns 4t..4t+3; a partial covers 16 columns = 4 consecutive threads)
+__device__ __forceinline__ void emit_row(float4 s, int t, float* __restrict__ x_row, uint16_t* __restrict__ xb_row,
+                                         float* __restrict__ ssq_row) {
+  if (x_row) *reinterpret_cast<float4*>(x_row + t * 4) = s;
+  if (xb_row) {
+    ushort4 o;
+    o.x = f32_to_bf16(s.x); o.y = f32_to_bf16(s.y); o.z = f32_to_bf16(s.z); o.w = f32_to_bf16(s.w);
+    *reinterpret_cast<ushort4*>(xb_row + t * 4) = o;
+  }
+  if (ssq_row) {
+    float q = (s.x * s.x + s.y * s.y) + (s.z * s.z + s.w * s.w);
+    q += __shfl_xor(q, 1, 64);
+    q += __shfl_xor(q, 2, 64);
+    if ((t & 3) == 0) ssq_row[t >> 2] = q;
+  }
+}
+
 __global__ __launch_bounds__(192) void embed_codes_k(const float* __restrict__ emb, const int64_t* __restrict__ ids_buf,
-                                                     int tcap, const int32_t* __restrict__ len, float* __restrict__ x) {
+                                                     int tcap, const int32_t* __restrict__ len, float* __restrict__ x,
+                                                     uint16_t* __restrict__ xb, float* __restrict__ ssq) {
   const int b = blockIdx.x, t = threadIdx.x;
   const int64_t* tok = ids_buf + ((size_t)b * tcap + (len[b] - 1)) * NVQ;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -32,12 +51,23 @@ __global__ __launch_bounds__(192) void embed_codes_k(const float* __restrict__ e
     const float4 v = *reinterpret_cast<const float4*>(emb + ((size_t)k * NAUDIO + id) * HID + t * 4);
     if (k == 0) s = v; else { s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
   }
-  *reinterpret_cast<float4*>(x + (size_t)b * HID + t * 4) = s;
+  emit_row(s, t, x + (size_t)b * HID, xb ? xb + (size_t)b * HID : nullptr, ssq ? ssq + (size_t)b * SSQ_PARTS : nullptr);
 }
 
-hipError_t launch_embed_codes(const float* emb_code, const int64_t* ids_buf, int tcap, const int32_t* len, float* x, int B,
-                              hipStream_t st) {
-  hipLaunchKernelGGL(embed_codes_k, dim3(B), dim3(192), 0, st, emb_code, ids_buf, tcap, len, x);
+hipError_t launch_embed_codes(const float* emb_code, const int64_t* ids_buf, int tcap, const int32_t* len, float* x, uint16_t* xb,
+                              float* ssq, int B, hipStream_t st) {
+  hipLaunchKernelGGL(embed_codes_k, dim3(B), dim3(192), 0, st, emb_code, ids_buf, tcap, len, x, xb, ssq);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(192) void rows_prep_k(const float* __restrict__ x, uint16_t* __restrict__ xb, float* __restrict__ ssq) {
+  const int m = blockIdx.x, t = threadIdx.x;
+  const float4 s = *reinterpret_cast<const float4*>(x + (size_t)m * HID + t * 4);
+  emit_row(s, t, nullptr, xb + (size_t)m * HID, ssq + (size_t)m * SSQ_PARTS);
+}
+
+hipError_t launch_rows_prep(const float* x32, uint16_t* xb, float* ssq, int M, hipStream_t st) {
+  hipLaunchKernelGGL(rows_prep_k, dim3(M), dim3(192), 0, st, x32, xb, ssq);
   return hipGetLastError();
 }
 
@@ -119,9 +149,13 @@ template <> __device__ __forceinline__ void unpack16<bf16_t, 8>(const u128& r, f
   f[6] = __uint_as_float(r.w << 16); f[7] = __uint_as_float(r.w & 0xffff0000u);
 }
 
-template <typename KT, int NW>
+template <typename OT> __device__ __forceinline__ void store_out(OT* p, float v);
+template <> __device__ __forceinline__ void store_out<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void store_out<bf16_t>(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+
+template <typename KT, int NW, typename OT>
 __global__ __launch_bounds__(64 * NW) void attention_k(const float* __restrict__ qkv, const KT* __restrict__ kc,
-                                                       const KT* __restrict__ vc, int cmax, float* __restrict__ out, GptRowMap rm) {
+                                                       const KT* __restrict__ vc, int cmax, OT* __restrict__ out, GptRowMap rm) {
   constexpr int DPL = KTraits<KT>::DPL;
   constexpr int LPK = HDIM / DPL;   // lanes per key: 8 (bf16) / 16 (f32)
   constexpr int KPI = 64 / LPK;     // keys per load instruction: 8 / 4
@@ -212,9 +246,9 @@ __global__ __launch_bounds__(64 * NW) void attention_k(const float* __restrict__
   if (NW == 1) {
     if (kg == 0) {
       const float inv = 1.0f / lrun;
-      float* op = out + (size_t)m * HID + h * HDIM + dl * DPL;
+      OT* op = out + (size_t)m * HID + h * HDIM + dl * DPL;
 #pragma unroll
-      for (int e = 0; e < DPL; ++e) op[e] = acc[e] * inv;
+      for (int e = 0; e < DPL; ++e) store_out<OT>(op + e, acc[e] * inv);
     }
     return;
   }
@@ -235,21 +269,23 @@ __global__ __launch_bounds__(64 * NW) void attention_k(const float* __restrict__
       L += sm_l[w] * sc;
       o += sm_acc[w][tid] * sc;
     }
-    out[(size_t)m * HID + h * HDIM + tid] = o / L;
+    store_out<OT>(out + (size_t)m * HID + h * HDIM + tid, o / L);
   }
 }
 
-hipError_t launch_attention(const float* qkv, const void* kcache, const void* vcache, int kv_wt, int cmax, float* out,
+hipError_t launch_attention(const float* qkv, const void* kcache, const void* vcache, int kv_wt, int cmax, void* out, int out_bf16,
                             GptRowMap rm, int M, hipStream_t st) {
   dim3 grid(NHEAD, M);
   const bool decode = rm.q_per_b == 1;
+#define ATT(KT, NW, OT) hipLaunchKernelGGL((attention_k<KT, NW, OT>), grid, dim3(64 * NW), 0, st, qkv, (const KT*)kcache, (const KT*)vcache, cmax, (OT*)out, rm)
   if (kv_wt == WT_BF16) {
-    if (decode) hipLaunchKernelGGL((attention_k<bf16_t, 4>), grid, dim3(256), 0, st, qkv, (const bf16_t*)kcache, (const bf16_t*)vcache, cmax, out, rm);
-    else hipLaunchKernelGGL((attention_k<bf16_t, 1>), grid, dim3(64), 0, st, qkv, (const bf16_t*)kcache, (const bf16_t*)vcache, cmax, out, rm);
+    if (out_bf16) { if (decode) ATT(bf16_t, 4, bf16_t); else ATT(bf16_t, 1, bf16_t); }
+    else { if (decode) ATT(bf16_t, 4, float); else ATT(bf16_t, 1, float); }
   } else {
-    if (decode) hipLaunchKernelGGL((attention_k<float, 4>), grid, dim3(256), 0, st, qkv, (const float*)kcache, (const float*)vcache, cmax, out, rm);
-    else hipLaunchKernelGGL((attention_k<float, 1>), grid, dim3(64), 0, st, qkv, (const float*)kcache, (const float*)vcache, cmax, out, rm);
+    if (out_bf16) { if (decode) ATT(float, 4, bf16_t); else ATT(float, 1, bf16_t); }
+    else { if (decode) ATT(float, 4, float); else ATT(float, 1, float); }
   }
+#undef ATT
   return hipGetLastError();
 }
 

@@ -39,6 +39,28 @@ struct GemmArgs {
 };
 
 hipError_t launch_gemm_skinny(const GemmArgs& a, hipStream_t st);  // weight-streaming, M-tiles of <=64 rows
+
+// ---- bf16 fast path of the GPT projections (perf mode) ------------------------------------------
+// Activations travel between kernels as bf16 (the f32 residual stream is kept beside its bf16
+// copy), the RMSNorm gain is folded into the weights at load and the per-row 1/rms is applied in
+// the epilogue from 48 per-row partial sums of squares that the PRODUCER of the residual wrote,
+// so no consumer ever re-reads a full f32 row to normalise it.
+enum FastEpi { FEPI_STORE32 = 0, FEPI_RES = 1, FEPI_SILU = 2 };
+#define SSQ_PARTS 48  // 768 / 16: one partial per 16-column tile of the residual stream
+struct FastGemmArgs {
+  const uint16_t* A; int lda;   // [M,K] bf16
+  const uint16_t* W;            // [N (2N for SILU: gate rows then up rows), K] bf16
+  int M, N, K;
+  const float* ssq_in;          // [M,48] or null (no row scale)
+  float eps;
+  int epi;
+  float* C32; int ldc;          // STORE32: out; RES: f32 residual, updated in place
+  uint16_t* Cb; int ldcb;       // RES: bf16 copy of the new residual; SILU: activation
+  float* ssq_out;               // RES: [M,48] partial sums of squares of the new residual
+};
+hipError_t launch_gemm_fast(const FastGemmArgs& a, hipStream_t st);
+// x32 row -> bf16 copy + partial sums of squares (prefill entry); optional code-embedding gather
+hipError_t launch_rows_prep(const float* x32, uint16_t* xb, float* ssq, int M, hipStream_t st);
 hipError_t launch_gemm_tiled(const GemmArgs& a, hipStream_t st);   // 64x64 LDS-tiled f32 MFMA, large M
 
 // ---- GPT step kernels -------------------------------------------------------------------------
@@ -51,11 +73,11 @@ struct GptRowMap {
 };
 
 hipError_t launch_embed_codes(const float* emb_code /*[4,626,768]*/, const int64_t* ids_buf, int ids_row_stride /*Tcap*/,
-                              const int32_t* len, float* x, int B, hipStream_t st);
+                              const int32_t* len, float* x, uint16_t* xb /*null ok*/, float* ssq /*null ok*/, int B, hipStream_t st);
 hipError_t launch_rope_append(float* qkv /*[M,2304]*/, void* kcache, void* vcache, int kv_wt, int cmax,
                               const float* cos_tab, const float* sin_tab /*[max_pos,32]*/, GptRowMap rm, int M, hipStream_t st);
 hipError_t launch_attention(const float* qkv, const void* kcache, const void* vcache, int kv_wt, int cmax,
-                            float* out /*[M,768]*/, GptRowMap rm, int M, hipStream_t st);
+                            void* out /*[M,768] f32, or bf16 when out_bf16*/, int out_bf16, GptRowMap rm, int M, hipStream_t st);
 hipError_t launch_final_norm(const float* x, int q_per_b, const float* w, float eps, float* hfin /*[B,768]*/,
                              float* hiddens /*[B,max_new,768]*/, int max_new, const int32_t* len, int T, int B, hipStream_t st);
 

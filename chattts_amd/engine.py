@@ -165,12 +165,16 @@ class GptEngine:
         f = lambda t: t.to(torch.float32).contiguous().to(dev)
         wcast = lambda t: t.to(torch.float32).to(self.wdt).contiguous().to(dev)
         self.wqkv, self.wo, self.wgu, self.wd, self.ln1, self.ln2 = [], [], [], [], [], []
+        # perf mode folds the RMSNorm gains into the following projection (W' = W * gain[None, :], rounded to bf16
+        # once at load): the kernels then only need the per-row 1/rms, applied in the GEMM epilogue.
+        fold = (lambda w, g: w.float() * g.float()[None, :]) if dtype == "bf16" else (lambda w, g: w)
         for i in range(self.n_layers):
             p = f"layers.{i}."
-            self.wqkv.append(wcast(torch.cat([gpt_sd[p + "self_attn.q_proj.weight"], gpt_sd[p + "self_attn.k_proj.weight"],
-                                              gpt_sd[p + "self_attn.v_proj.weight"]], 0)))
+            ln1, ln2 = gpt_sd[p + "input_layernorm.weight"], gpt_sd[p + "post_attention_layernorm.weight"]
+            self.wqkv.append(wcast(fold(torch.cat([gpt_sd[p + "self_attn.q_proj.weight"], gpt_sd[p + "self_attn.k_proj.weight"],
+                                                   gpt_sd[p + "self_attn.v_proj.weight"]], 0), ln1)))
             self.wo.append(wcast(gpt_sd[p + "self_attn.o_proj.weight"]))
-            self.wgu.append(wcast(torch.cat([gpt_sd[p + "mlp.gate_proj.weight"], gpt_sd[p + "mlp.up_proj.weight"]], 0)))
+            self.wgu.append(wcast(fold(torch.cat([gpt_sd[p + "mlp.gate_proj.weight"], gpt_sd[p + "mlp.up_proj.weight"]], 0), ln2)))
             self.wd.append(wcast(gpt_sd[p + "mlp.down_proj.weight"]))
             self.ln1.append(f(gpt_sd[p + "input_layernorm.weight"]))
             self.ln2.append(f(gpt_sd[p + "post_attention_layernorm.weight"]))

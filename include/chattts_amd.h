@@ -154,6 +154,11 @@ int ctts_vocos_decode(ctts_codec* c, const float* mel, float* wav, int32_t B, in
 int ctts_k_gemm(int32_t tiled, const float* A, const void* W, float* C, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldc,
                 int32_t wt, int32_t epi, const float* norm_w, float eps, const float* res, int32_t ldr, const float* bias,
                 const float* gamma, int32_t taps, int32_t cin, int32_t frames, int32_t pad, int32_t dil, void* stream);
+/* perf-mode projection: bf16 activations/weights, optional per-row 1/rms from 48 partial sums of squares,
+ * epi 0 = f32 store, 1 = residual add (+ bf16 copy + new partial sums), 2 = SiLU(gate)*up -> bf16 */
+int ctts_k_gemm_fast(const uint16_t* A, int32_t lda, const uint16_t* W, int32_t M, int32_t N, int32_t K, const float* ssq_in, float eps,
+                     int32_t epi, float* C32, int32_t ldc, uint16_t* Cb, int32_t ldcb, float* ssq_out, void* stream);
+int ctts_k_rows_prep(const float* x32, uint16_t* xb, float* ssq, int32_t M, void* stream);
 int ctts_k_rope_append(float* qkv, void* kcache, void* vcache, int32_t kv_dtype, int32_t cmax, const float* cos_tab, const float* sin_tab,
                        int32_t q_per_b, const int32_t* len, const int32_t* kv_start, int32_t M, void* stream);
 int ctts_k_attention(const float* qkv, const void* kcache, const void* vcache, int32_t kv_dtype, int32_t cmax, float* out,

@@ -62,6 +62,60 @@ def test_gemm_skinny(G, wt, M, shape):
     assert G.relerr(got, ref) < tol, (wt, M, shape, G.relerr(got, ref))
 
 
+@pytest.mark.parametrize("M", [1, 9, 16, 31, 64, 200])
+def test_gemm_fast_bf16(G, M):
+    """perf-mode projections: bf16 activations, row scale from partial sums of squares, three epilogues"""
+    lib = _lib.lib()
+    rs = np.random.RandomState(M)
+    x32 = (rs.standard_normal((M, 768)) * 2).astype(f32)
+    x_d = G.dev(x32)
+    xb = torch.empty((M, 768), dtype=torch.bfloat16, device=G.DEV)
+    ssq = torch.empty((M, 48), dtype=torch.float32, device=G.DEV)
+    _lib.check(lib.ctts_k_rows_prep(x_d.data_ptr(), xb.data_ptr(), ssq.data_ptr(), M, None), "rows_prep")
+    xbr = G.bf16_round(x32)
+    assert np.array_equal(xb.float().cpu().numpy(), xbr)
+    assert np.abs(ssq.cpu().numpy().sum(1) - (x32.astype(np.float64) ** 2).sum(1)).max() < 1e-2
+    rstd = 1.0 / np.sqrt((x32.astype(np.float64) ** 2).mean(1, keepdims=True) + 1e-6)
+    # epi 0: (x_bf16 @ W^T) * rstd
+    W = G.bf16_round((rs.standard_normal((2304, 768)) * 0.03).astype(f32))
+    W_d = G.dev(W, torch.bfloat16)
+    C = torch.full((M, 2304), float("nan"), dtype=torch.float32, device=G.DEV)
+    _lib.check(lib.ctts_k_gemm_fast(xb.data_ptr(), 768, W_d.data_ptr(), M, 2304, 768, ssq.data_ptr(), 1e-6, 0, C.data_ptr(), 2304,
+                                    None, 0, None, None), "fast0")
+    ref = (xbr.astype(np.float64) @ W.astype(np.float64).T) * rstd
+    assert G.relerr(C.cpu().numpy(), ref) < 2e-4
+    # epi 2: silu(g) * u -> bf16
+    Wgu = G.bf16_round((rs.standard_normal((2 * 3072, 768)) * 0.03).astype(f32))
+    Wgu_d = G.dev(Wgu, torch.bfloat16)
+    act = torch.zeros((M, 3072), dtype=torch.bfloat16, device=G.DEV)
+    _lib.check(lib.ctts_k_gemm_fast(xb.data_ptr(), 768, Wgu_d.data_ptr(), M, 3072, 768, ssq.data_ptr(), 1e-6, 2, None, 0,
+                                    act.data_ptr(), 3072, None, None), "fast2")
+    gu = (xbr.astype(np.float64) @ Wgu.astype(np.float64).T) * rstd
+    g_, u_ = gu[:, :3072], gu[:, 3072:]
+    refa = g_ / (1 + np.exp(-g_)) * u_
+    assert G.relerr(act.float().cpu().numpy(), refa) < 1e-2  # bf16 output rounding
+    # epi 1 with K = 3072 (down_proj): residual update + bf16 copy + new partial sums
+    Wd = G.bf16_round((rs.standard_normal((768, 3072)) * 0.02).astype(f32))
+    Wd_d = G.dev(Wd, torch.bfloat16)
+    res = x_d.clone()
+    xb2 = torch.empty_like(xb)
+    ssq2 = torch.empty_like(ssq)
+    _lib.check(lib.ctts_k_gemm_fast(act.data_ptr(), 3072, Wd_d.data_ptr(), M, 768, 3072, None, 0.0, 1, res.data_ptr(), 768,
+                                    xb2.data_ptr(), 768, ssq2.data_ptr(), None), "fast1")
+    actf = act.float().cpu().numpy().astype(np.float64)
+    refx = x32 + actf @ Wd.astype(np.float64).T
+    got = res.cpu().numpy()
+    assert G.relerr(got, refx) < 2e-5
+    assert np.array_equal(xb2.float().cpu().numpy(), G.bf16_round(got))
+    assert np.abs(ssq2.cpu().numpy().sum(1) - (got.astype(np.float64) ** 2).sum(1)).max() < 1e-2
+    # epi 1 with K = 768 (o_proj)
+    Wo = G.bf16_round((rs.standard_normal((768, 768)) * 0.03).astype(f32))
+    res = x_d.clone()
+    _lib.check(lib.ctts_k_gemm_fast(xb.data_ptr(), 768, G.dev(Wo, torch.bfloat16).data_ptr(), M, 768, 768, None, 0.0, 1, res.data_ptr(),
+                                    768, xb2.data_ptr(), 768, ssq2.data_ptr(), None), "fast1o")
+    assert G.relerr(res.cpu().numpy(), x32 + xbr.astype(np.float64) @ Wo.astype(np.float64).T) < 2e-5
+
+
 # asymmetric-B identity check: catches a row<->col swap in the C/D fragment mapping
 def test_gemm_skinny_identity(G):
     K = 768
@@ -237,7 +291,7 @@ def test_embed_and_final_norm(G):
     B, tcap, T, max_new = 5, 20, 6, 14
     emb = rs.standard_normal((4, 626, 768)).astype(f32)
     ids = rs.randint(0, 626, size=(B, tcap, 4)).astype(np.int64)
-    lens = np.array([7, 8, 9, 12, 20], np.int32)
+    lens = np.array([7, 8, 9, 12, 19], np.int32)
     x = torch.empty((B, 768), dtype=torch.float32, device=G.DEV)
     e_d, i_d, l_d = G.dev(emb), G.dev(ids), G.dev(lens)
     _lib.check(lib.ctts_k_embed_codes(e_d.data_ptr(), i_d.data_ptr(), tcap, l_d.data_ptr(), x.data_ptr(), B, None), "embed")

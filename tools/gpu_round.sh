@@ -1,22 +1,42 @@
 #!/bin/bash
-# One GPU-box visit: parity tests, smoke, bench, rocprof kernel stats.  Everything lands in gpurun_out/.
+# One GPU-box visit.  usage: gpu_round.sh TAG "stage stage ..."   stages: tests smoke bench prof pmc
+# Everything lands in gpurun_out/ (merged back by gpurun).
 set +e
-cd "${GRAFT_REPO_ROOT:-/root/repo}"
+R="${GRAFT_REPO_ROOT:-/root/repo}"
+cd "$R"
 mkdir -p gpurun_out
 TAG=${1:-r1}
+STAGES=${2:-"tests smoke bench prof"}
+TESTSEL=${3:-tests}
 export TMPDIR=/tmp
-rocm-smi --showproductname 2>/dev/null | head -5 > gpurun_out/${TAG}_env.log
-lscpu | grep -E "Model name|^CPU\(s\)" >> gpurun_out/${TAG}_env.log
-timeout 1200 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/${TAG}_tests.log 2>&1
-echo "pytest exit $?" >> gpurun_out/${TAG}_tests.log
-timeout 300 python __graft_entry__.py smoke > gpurun_out/${TAG}_smoke.log 2>&1
-echo "smoke exit $?" >> gpurun_out/${TAG}_smoke.log
-timeout 900 python bench.py --steps 2 --warmup 1 > gpurun_out/${TAG}_bench.log 2>&1
-echo "bench exit $?" >> gpurun_out/${TAG}_bench.log
-cd /tmp
-timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_${TAG} -o ${TAG} -- python ${GRAFT_REPO_ROOT:-/root/repo}/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline > ${GRAFT_REPO_ROOT:-/root/repo}/gpurun_out/${TAG}_rocprof.log 2>&1
-echo "rocprof exit $?" >> ${GRAFT_REPO_ROOT:-/root/repo}/gpurun_out/${TAG}_rocprof.log
-find /tmp/prof_${TAG} -name "*stats*" -exec cp {} ${GRAFT_REPO_ROOT:-/root/repo}/gpurun_out/ \; 2>/dev/null
-ls -la /tmp/prof_${TAG} >> ${GRAFT_REPO_ROOT:-/root/repo}/gpurun_out/${TAG}_rocprof.log 2>&1
-tail -5 ${GRAFT_REPO_ROOT:-/root/repo}/gpurun_out/${TAG}_tests.log
-tail -3 ${GRAFT_REPO_ROOT:-/root/repo}/gpurun_out/${TAG}_bench.log
+lscpu | grep -E "Model name|^CPU\(s\)" > gpurun_out/${TAG}_env.log
+for S in $STAGES; do
+  case $S in
+    tests)
+      timeout 1500 python -m pytest $TESTSEL -m gpu -q --tb=short -p no:cacheprovider -s > gpurun_out/${TAG}_tests.log 2>&1
+      echo "pytest exit $?" >> gpurun_out/${TAG}_tests.log
+      tail -4 gpurun_out/${TAG}_tests.log ;;
+    smoke)
+      timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${TAG}_smoke.log 2>&1
+      echo "smoke exit $?" >> gpurun_out/${TAG}_smoke.log
+      tail -2 gpurun_out/${TAG}_smoke.log ;;
+    bench)
+      timeout 900 python bench.py --steps 3 --warmup 1 > gpurun_out/${TAG}_bench.log 2>&1
+      echo "bench exit $?" >> gpurun_out/${TAG}_bench.log
+      tail -3 gpurun_out/${TAG}_bench.log ;;
+    prof)
+      cd /tmp
+      timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${TAG} -o ${TAG} -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline > $R/gpurun_out/${TAG}_rocprof.log 2>&1
+      echo "rocprof exit $?" >> $R/gpurun_out/${TAG}_rocprof.log
+      find /tmp/prof_${TAG} -name "*stats*.csv" -exec cp {} $R/gpurun_out/ \;
+      find /tmp/prof_${TAG} -type f >> $R/gpurun_out/${TAG}_rocprof.log
+      cd "$R" ;;
+    pmc)
+      cd /tmp
+      for C in FETCH_SIZE WRITE_SIZE; do
+        timeout 900 rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/pmc_${TAG}_$C -o ${TAG}_$C -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --max-len 160 --min-len 128 > $R/gpurun_out/${TAG}_pmc_$C.log 2>&1
+        python $R/tools/pmc_summary.py /tmp/pmc_${TAG}_$C $C > $R/gpurun_out/${TAG}_pmc_${C}_summary.txt 2>&1
+      done
+      cd "$R" ;;
+  esac
+done
