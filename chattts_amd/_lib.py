@@ -75,6 +75,7 @@ SIGNATURES = {
     "ctts_vocos_decode": (C.c_int, [P, P, P, I32, I32, P, SZ, P]),
     "ctts_k_gemm": (C.c_int, [I32, P, P, P, I32, I32, I32, I32, I32, I32, I32, P, F, P, I32, P, P, I32, I32, I32, I32, I32, P]),
     "ctts_k_gemm_fast": (C.c_int, [P, I32, P, I32, I32, I32, P, F, I32, P, I32, P, I32, P, P]),
+    "ctts_k_qkv_rope": (C.c_int, [P, P, I32, P, F, P, P, P, I32, P, P, I32, P, P, I32, P]),
     "ctts_k_rows_prep": (C.c_int, [P, P, P, I32, P]),
     "ctts_k_rope_append": (C.c_int, [P, P, P, I32, I32, P, P, I32, P, P, I32, P]),
     "ctts_k_attention": (C.c_int, [P, P, P, I32, I32, P, I32, P, P, I32, P]),

@@ -126,6 +126,7 @@ static int check_state(const ctts_gpt* g, const ctts_gen_state* s) {
   if (s->T + s->max_new > g->w.max_pos) return fail("T + max_new (%d) exceeds the RoPE table (%d)", s->T + s->max_new, g->w.max_pos);
   if (s->workspace_bytes < ctts_gpt_workspace_bytes(s->B, s->T)) return fail("workspace too small");
   if (s->nq <= 0 || !s->q) return fail("q draws missing");
+  if (g->w.weight_dtype == CTTS_BF16 && g->w.kv_dtype != CTTS_BF16) return fail("perf mode needs a bf16 KV cache");
   return 0;
 }
 
@@ -145,10 +146,12 @@ static int run_step(ctts_gpt* g, const ctts_gen_state* s, int q_per_b, hipStream
     FastGemmArgs f;
     memset(&f, 0, sizeof(f));
     f.M = M; f.eps = g->w.rms_eps;
-    f.A = ws.xb; f.lda = HID; f.W = (const uint16_t*)g->wqkv[l]; f.N = 3 * HID; f.K = HID; f.ssq_in = ws.ssq; f.epi = FEPI_STORE32;
+    // RMSNorm + QKV + RoPE + KV append in one launch (q/k weight rows are permuted by the loader)
+    f.A = ws.xb; f.lda = HID; f.W = (const uint16_t*)g->wqkv[l]; f.N = 3 * HID; f.K = HID; f.ssq_in = ws.ssq; f.epi = FEPI_QKV_ROPE;
     f.C32 = ws.qkv; f.ldc = 3 * HID;
+    f.q_per_b = q_per_b; f.len = s->len; f.kv_start = s->kv_start; f.cos_t = g->w.rope_cos; f.sin_t = g->w.rope_sin;
+    f.kc = (uint16_t*)kc; f.vc = (uint16_t*)vc; f.cmax = cmax;
     { Prof p(g, 1, st, prof_ok); CK(launch_gemm_fast(f, st)); }
-    { Prof p(g, 2, st, prof_ok); CK(launch_rope_append(ws.qkv, kc, vc, kt, cmax, g->w.rope_cos, g->w.rope_sin, rm, M, st)); }
     { Prof p(g, 3, st, prof_ok); CK(launch_attention(ws.qkv, kc, vc, kt, cmax, aob, 1, rm, M, st)); }
     f.A = aob; f.W = (const uint16_t*)g->wo[l]; f.N = HID; f.K = HID; f.ssq_in = nullptr; f.epi = FEPI_RES; f.C32 = ws.x; f.ldc = HID;
     f.Cb = ws.xb; f.ldcb = HID; f.ssq_out = ws.ssq;
@@ -399,6 +402,17 @@ extern "C" int ctts_k_gemm_fast(const uint16_t* A, int32_t lda, const uint16_t* 
   memset(&f, 0, sizeof(f));
   f.A = A; f.lda = lda; f.W = W; f.M = M; f.N = N; f.K = K; f.ssq_in = ssq_in; f.eps = eps; f.epi = epi; f.C32 = C32; f.ldc = ldc;
   f.Cb = Cb; f.ldcb = ldcb; f.ssq_out = ssq_out;
+  CK(launch_gemm_fast(f, (hipStream_t)stream));
+  return 0;
+}
+extern "C" int ctts_k_qkv_rope(const uint16_t* A, const uint16_t* W, int32_t M, const float* ssq_in, float eps, float* qkv, uint16_t* kcache,
+                               uint16_t* vcache, int32_t cmax, const float* cos_tab, const float* sin_tab, int32_t q_per_b,
+                               const int32_t* len, const int32_t* kv_start, int32_t force_mb, void* stream) {
+  FastGemmArgs f;
+  memset(&f, 0, sizeof(f));
+  f.A = A; f.lda = HID; f.W = W; f.M = M; f.N = 3 * HID; f.K = HID; f.ssq_in = ssq_in; f.eps = eps; f.epi = FEPI_QKV_ROPE; f.C32 = qkv;
+  f.ldc = 3 * HID; f.q_per_b = q_per_b; f.len = len; f.kv_start = kv_start; f.cos_t = cos_tab; f.sin_t = sin_tab; f.kc = kcache;
+  f.vc = vcache; f.cmax = cmax; f.force_mb = force_mb;
   CK(launch_gemm_fast(f, (hipStream_t)stream));
   return 0;
 }

@@ -288,7 +288,9 @@ hipError_t launch_gemm_tiled(const GemmArgs& a, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// fast bf16 path (perf mode): bf16 activations in, all loads of a round issued before the first MFMA
+// fast bf16 path (perf mode): bf16 activations in, every load of a round issued before the first
+// MFMA, operands the epilogue needs (residual, RoPE position/cos/sin, row sums of squares) requested
+// at kernel entry so that no dependent memory round trip is left on the tail of the kernel.
 // ------------------------------------------------------------------------------------------------
 template <int MB, int NW, bool SCALE, int EPI>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 2))) void gemm_fast_k(FastGemmArgs a) {
@@ -311,6 +313,35 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 2)))
     s0 = *reinterpret_cast<const float4*>(sp);
     s1 = *reinterpret_cast<const float4*>(sp + 4);
     s2 = *reinterpret_cast<const float4*>(sp + 8);
+  }
+
+  // epilogue operands of the finishing waves (wave mb finishes m-block mb)
+  float pre0[4] = {0.f, 0.f, 0.f, 0.f}, pre1[4] = {0.f, 0.f, 0.f, 0.f};  // RES: residual | ROPE: cos, sin
+  int eb[4] = {0, 0, 0, 0}, eslot[4] = {0, 0, 0, 0};
+  // ROPE tiles (weights permuted by the loader): columns 0..7 of a q/k tile are dims d0..d0+7 of one
+  // head, columns 8..15 are dims d0+32..d0+39, so a rotate-half pair sits 8 lanes apart.
+  const int sect = n0 / 768, hcol = n0 % 768, head = hcol >> 6, t4 = (hcol & 63) >> 4;
+  const int dlo = 8 * t4 + (li & 7);
+  if (wave < MB) {
+    if (EPI == FEPI_RES) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = min(m0 + 16 * wave + 4 * g + r, M - 1);
+        pre0[r] = a.C32[(size_t)row * a.ldc + min(n0 + li, N - 1)];
+      }
+    } else if (EPI == FEPI_QKV_ROPE) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = min(m0 + 16 * wave + 4 * g + r, M - 1);
+        int b, slot;
+        if (a.q_per_b == 1) { b = row; slot = a.len[b] - 1; } else { b = row / a.q_per_b; slot = row - b * a.q_per_b; }
+        int pos = slot - a.kv_start[b];
+        if (pos < 0) pos = 1;
+        eb[r] = b; eslot[r] = slot;
+        pre0[r] = a.cos_t[pos * 32 + dlo];
+        pre1[r] = a.sin_t[pos * 32 + dlo];
+      }
+    }
   }
 
   const int n = min(n0 + li, N - 1);
@@ -390,10 +421,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 2)))
         if (ok) a.C32[(size_t)row * a.ldc + col] = v;
       } else if (EPI == FEPI_SILU) {
         if (ok) a.Cb[(size_t)row * a.ldcb + col] = f32_to_bf16(silu_f(v) * u);
-      } else {  // FEPI_RES
+      } else if (EPI == FEPI_RES) {
         float xn = 0.f;
         if (ok) {
-          xn = a.C32[(size_t)row * a.ldc + col] + v;
+          xn = pre0[r] + v;
           a.C32[(size_t)row * a.ldc + col] = xn;
           a.Cb[(size_t)row * a.ldcb + col] = f32_to_bf16(xn);
         }
@@ -403,6 +434,18 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 2)))
         sq += __shfl_xor(sq, 4, 64);
         sq += __shfl_xor(sq, 8, 64);
         if (li == 0 && row < M) a.ssq_out[(size_t)row * SSQ_PARTS + blockIdx.x] = sq;
+      } else {  // FEPI_QKV_ROPE: q -> roped, in the f32 qkv buffer; k -> roped, KV cache; v -> KV cache
+        const float other = __shfl_xor(v, 8, 64);
+        const bool hi = li >= 8;
+        // rotate-half: out[d] = x[d] c - x[d+32] s ; out[d+32] = x[d+32] c + x[d] s
+        const float roped = hi ? (v * pre0[r] + other * pre1[r]) : (v * pre0[r] - other * pre1[r]);
+        const int d = dlo + (hi ? 32 : 0);
+        if (ok) {
+          const size_t cbase = (((size_t)eb[r] * 12 + head) * a.cmax + eslot[r]) * 64;
+          if (sect == 0) a.C32[(size_t)row * a.ldc + head * 64 + d] = roped;
+          else if (sect == 1) a.kc[cbase + d] = f32_to_bf16(roped);
+          else a.vc[cbase + (hcol & 63) + li] = f32_to_bf16(v);
+        }
       }
     }
   }
@@ -414,6 +457,7 @@ static hipError_t fast_dispatch(const FastGemmArgs& a, hipStream_t st) {
   const bool scale = a.ssq_in != nullptr;
   if (a.K == 768) {
     if (a.epi == FEPI_STORE32 && scale) hipLaunchKernelGGL((gemm_fast_k<MB, 4, true, FEPI_STORE32>), grid, dim3(256), 0, st, a);
+    else if (a.epi == FEPI_QKV_ROPE && scale) hipLaunchKernelGGL((gemm_fast_k<MB, 4, true, FEPI_QKV_ROPE>), grid, dim3(256), 0, st, a);
     else if (a.epi == FEPI_SILU && scale) hipLaunchKernelGGL((gemm_fast_k<MB, 4, true, FEPI_SILU>), grid, dim3(256), 0, st, a);
     else if (a.epi == FEPI_RES && !scale) hipLaunchKernelGGL((gemm_fast_k<MB, 4, false, FEPI_RES>), grid, dim3(256), 0, st, a);
     else return hipErrorInvalidValue;
@@ -429,7 +473,15 @@ static hipError_t fast_dispatch(const FastGemmArgs& a, hipStream_t st) {
 hipError_t launch_gemm_fast(const FastGemmArgs& a, hipStream_t st) {
   if (a.M <= 0 || a.N <= 0 || (a.lda % 8) != 0) return hipErrorInvalidValue;
   if (a.epi == FEPI_RES && a.N != 16 * SSQ_PARTS) return hipErrorInvalidValue;
-  if (a.M <= 16) return fast_dispatch<1>(a, st);
-  if (a.M <= 32) return fast_dispatch<2>(a, st);
+  if (a.epi == FEPI_QKV_ROPE && (a.N != 2304 || a.K != 768)) return hipErrorInvalidValue;
+  // rows per workgroup: the per-workgroup latency is set by fixed round trips, not bytes, so prefer
+  // enough workgroups to cover the 256 CUs over big M tiles (decode: M <= 64)
+  const int ntiles = (a.N + 15) / 16;
+  int mb = 4;
+  while (mb > 1 && ntiles * ((a.M + 16 * mb - 1) / (16 * mb)) < 160) mb >>= 1;
+  if (a.M <= 16) mb = 1; else if (a.M <= 32 && mb > 2) mb = 2;
+  if (a.force_mb) mb = a.force_mb;
+  if (mb == 1) return fast_dispatch<1>(a, st);
+  if (mb == 2) return fast_dispatch<2>(a, st);
   return fast_dispatch<4>(a, st);
 }

@@ -184,13 +184,19 @@ __global__ __launch_bounds__(64 * NW) void attention_k(const float* __restrict__
 #pragma unroll
   for (int i = 0; i < DPL; ++i) acc[i] = 0.f;
 
-  for (int j0 = jlo + wave * KB; j0 <= slot; j0 += KB * NW) {
+  // each wave owns one contiguous, KPI-aligned share of the visible keys (balanced: a context of n
+  // keys costs every wave ceil(n / NW / KB) rounds instead of giving wave 0 the remainder blocks)
+  const int nkeys = slot - jlo + 1;
+  const int per = ((nkeys + NW - 1) / NW + KPI - 1) / KPI * KPI;
+  const int jbeg = jlo + wave * per;
+  const int jend = min(jbeg + per, slot + 1);  // exclusive
+  for (int j0 = jbeg; j0 < jend; j0 += KB) {
     u128 kr[NI], vr[NI];
     bool ok[NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int j = j0 + i * KPI + kg;
-      ok[i] = j <= slot;
+      ok[i] = j < jend;
       if (ok[i]) kr[i] = *reinterpret_cast<const u128*>(kbase + (size_t)j * HDIM);
     }
 #pragma unroll
@@ -216,7 +222,7 @@ __global__ __launch_bounds__(64 * NW) void attention_k(const float* __restrict__
     }
 #pragma unroll
     for (int o = LPK; o < 64; o <<= 1) bmax = fmaxf(bmax, __shfl_xor(bmax, o, 64));
-    // bmax is finite: key j0 (i = 0, kg = 0) is always <= slot inside this loop
+    // bmax is finite: key j0 (i = 0, kg = 0) is always < jend inside this loop
     const float mnew = fmaxf(mrun, bmax);
     const float alpha = expf(mrun - mnew);  // exp(-inf) = 0 on the first block
     lrun *= alpha;
@@ -279,11 +285,11 @@ hipError_t launch_attention(const float* qkv, const void* kcache, const void* vc
   const bool decode = rm.q_per_b == 1;
 #define ATT(KT, NW, OT) hipLaunchKernelGGL((attention_k<KT, NW, OT>), grid, dim3(64 * NW), 0, st, qkv, (const KT*)kcache, (const KT*)vcache, cmax, (OT*)out, rm)
   if (kv_wt == WT_BF16) {
-    if (out_bf16) { if (decode) ATT(bf16_t, 4, bf16_t); else ATT(bf16_t, 1, bf16_t); }
-    else { if (decode) ATT(bf16_t, 4, float); else ATT(bf16_t, 1, float); }
+    if (out_bf16) { if (decode) ATT(bf16_t, 8, bf16_t); else ATT(bf16_t, 1, bf16_t); }
+    else { if (decode) ATT(bf16_t, 8, float); else ATT(bf16_t, 1, float); }
   } else {
-    if (out_bf16) { if (decode) ATT(float, 4, bf16_t); else ATT(float, 1, bf16_t); }
-    else { if (decode) ATT(float, 4, float); else ATT(float, 1, float); }
+    if (out_bf16) { if (decode) ATT(float, 8, bf16_t); else ATT(float, 1, bf16_t); }
+    else { if (decode) ATT(float, 8, float); else ATT(float, 1, float); }
   }
 #undef ATT
   return hipGetLastError();

@@ -45,7 +45,7 @@ hipError_t launch_gemm_skinny(const GemmArgs& a, hipStream_t st);  // weight-str
 // copy), the RMSNorm gain is folded into the weights at load and the per-row 1/rms is applied in
 // the epilogue from 48 per-row partial sums of squares that the PRODUCER of the residual wrote,
 // so no consumer ever re-reads a full f32 row to normalise it.
-enum FastEpi { FEPI_STORE32 = 0, FEPI_RES = 1, FEPI_SILU = 2 };
+enum FastEpi { FEPI_STORE32 = 0, FEPI_RES = 1, FEPI_SILU = 2, FEPI_QKV_ROPE = 3 };
 #define SSQ_PARTS 48  // 768 / 16: one partial per 16-column tile of the residual stream
 struct FastGemmArgs {
   const uint16_t* A; int lda;   // [M,K] bf16
@@ -57,6 +57,11 @@ struct FastGemmArgs {
   float* C32; int ldc;          // STORE32: out; RES: f32 residual, updated in place
   uint16_t* Cb; int ldcb;       // RES: bf16 copy of the new residual; SILU: activation
   float* ssq_out;               // RES: [M,48] partial sums of squares of the new residual
+  // QKV_ROPE: RoPE + KV append fused into the epilogue (weights row-permuted by the loader, see engine.py)
+  int q_per_b; const int32_t* len; const int32_t* kv_start;   // row -> (b, slot) map, as GptRowMap
+  const float* cos_t; const float* sin_t;                     // [max_pos, 32]
+  uint16_t* kc; uint16_t* vc; int cmax;                       // this layer's bf16 K / V cache [B,12,cmax,64]
+  int force_mb;                 // tests only: 0 = heuristic
 };
 hipError_t launch_gemm_fast(const FastGemmArgs& a, hipStream_t st);
 // x32 row -> bf16 copy + partial sums of squares (prefill entry); optional code-embedding gather

@@ -131,6 +131,17 @@ def left_pad_starts(attention_mask: torch.Tensor) -> torch.Tensor:
     return start.to(torch.int32)
 
 
+def rope_row_perm() -> torch.Tensor:
+    """Row order of q_proj / k_proj inside wqkv in perf mode: within every head the 16-row tiles hold
+    dims [8t..8t+7] followed by [32+8t..32+8t+7], so that the two halves of a rotate-half pair land in
+    the same 16-column MFMA tile of the QKV kernel and RoPE + KV append run in its epilogue."""
+    idx = []
+    for h in range(GPT.n_heads):
+        for t in range(4):
+            idx += [h * 64 + 8 * t + i for i in range(8)] + [h * 64 + 32 + 8 * t + i for i in range(8)]
+    return torch.tensor(idx, dtype=torch.long)
+
+
 def rope_tables(max_pos: int, head_dim: int = GPT.head_dim, theta: float = GPT.rope_theta):
     """cos/sin [max_pos, head_dim/2] float32, evaluated with the same torch f32 ops HF's
     LlamaRotaryEmbedding uses (inv_freq = 1/theta^(arange(0,d,2)/d); freqs = pos * inv_freq)."""
@@ -168,10 +179,11 @@ class GptEngine:
         # perf mode folds the RMSNorm gains into the following projection (W' = W * gain[None, :], rounded to bf16
         # once at load): the kernels then only need the per-row 1/rms, applied in the GEMM epilogue.
         fold = (lambda w, g: w.float() * g.float()[None, :]) if dtype == "bf16" else (lambda w, g: w)
+        perm = rope_row_perm() if dtype == "bf16" else torch.arange(GPT.hidden)
         for i in range(self.n_layers):
             p = f"layers.{i}."
             ln1, ln2 = gpt_sd[p + "input_layernorm.weight"], gpt_sd[p + "post_attention_layernorm.weight"]
-            self.wqkv.append(wcast(fold(torch.cat([gpt_sd[p + "self_attn.q_proj.weight"], gpt_sd[p + "self_attn.k_proj.weight"],
+            self.wqkv.append(wcast(fold(torch.cat([gpt_sd[p + "self_attn.q_proj.weight"][perm], gpt_sd[p + "self_attn.k_proj.weight"][perm],
                                                    gpt_sd[p + "self_attn.v_proj.weight"]], 0), ln1)))
             self.wo.append(wcast(gpt_sd[p + "self_attn.o_proj.weight"]))
             self.wgu.append(wcast(fold(torch.cat([gpt_sd[p + "mlp.gate_proj.weight"], gpt_sd[p + "mlp.up_proj.weight"]], 0), ln2)))

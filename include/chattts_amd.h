@@ -158,6 +158,10 @@ int ctts_k_gemm(int32_t tiled, const float* A, const void* W, float* C, int32_t 
  * epi 0 = f32 store, 1 = residual add (+ bf16 copy + new partial sums), 2 = SiLU(gate)*up -> bf16 */
 int ctts_k_gemm_fast(const uint16_t* A, int32_t lda, const uint16_t* W, int32_t M, int32_t N, int32_t K, const float* ssq_in, float eps,
                      int32_t epi, float* C32, int32_t ldc, uint16_t* Cb, int32_t ldcb, float* ssq_out, void* stream);
+/* perf-mode fused RMSNorm-scale + QKV + RoPE + KV append (W rows permuted as engine.py `rope_row_perm` does) */
+int ctts_k_qkv_rope(const uint16_t* A, const uint16_t* W, int32_t M, const float* ssq_in, float eps, float* qkv, uint16_t* kcache,
+                    uint16_t* vcache, int32_t cmax, const float* cos_tab, const float* sin_tab, int32_t q_per_b, const int32_t* len,
+                    const int32_t* kv_start, int32_t force_mb, void* stream);
 int ctts_k_rows_prep(const float* x32, uint16_t* xb, float* ssq, int32_t M, void* stream);
 int ctts_k_rope_append(float* qkv, void* kcache, void* vcache, int32_t kv_dtype, int32_t cmax, const float* cos_tab, const float* sin_tab,
                        int32_t q_per_b, const int32_t* len, const int32_t* kv_start, int32_t M, void* stream);

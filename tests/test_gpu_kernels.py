@@ -116,6 +116,55 @@ def test_gemm_fast_bf16(G, M):
     assert G.relerr(res.cpu().numpy(), x32 + xbr.astype(np.float64) @ Wo.astype(np.float64).T) < 2e-5
 
 
+@pytest.mark.parametrize("force_mb", [0, 1, 2, 4])
+@pytest.mark.parametrize("decode", [False, True])
+def test_qkv_rope_fused(G, force_mb, decode):
+    """perf-mode fused RMSNorm-scale + QKV + RoPE + KV append vs numpy (natural weight order)"""
+    from chattts_amd.engine import rope_row_perm, rope_tables
+    lib = _lib.lib()
+    rs = np.random.RandomState(17 + force_mb)
+    B, T, cmax, nh, d = (37, 1, 90, 12, 64) if decode else (3, 23, 60, 12, 64)
+    M = B * T
+    kv_start = rs.randint(0, 6, size=B).astype(np.int32)
+    lens = (rs.randint(20, 60, size=B)).astype(np.int32)
+    x32 = (rs.standard_normal((M, 768)) * 1.5).astype(f32)
+    x_d = G.dev(x32)
+    xb = torch.empty((M, 768), dtype=torch.bfloat16, device=G.DEV)
+    ssq = torch.empty((M, 48), dtype=torch.float32, device=G.DEV)
+    _lib.check(lib.ctts_k_rows_prep(x_d.data_ptr(), xb.data_ptr(), ssq.data_ptr(), M, None), "rows_prep")
+    W = G.bf16_round((rs.standard_normal((2304, 768)) * 0.05).astype(f32))
+    perm = rope_row_perm().numpy()
+    Wp = np.concatenate([W[:768][perm], W[768:1536][perm], W[1536:]], 0)
+    cos, sin = rope_tables(128)
+    keep = [G.dev(Wp, torch.bfloat16), G.dev(cos), G.dev(sin), G.dev(lens), G.dev(kv_start)]
+    qkv = torch.zeros((M, 2304), dtype=torch.float32, device=G.DEV)
+    kc = torch.zeros((B, nh, cmax, d), dtype=torch.bfloat16, device=G.DEV)
+    vc = torch.zeros_like(kc)
+    _lib.check(lib.ctts_k_qkv_rope(xb.data_ptr(), keep[0].data_ptr(), M, ssq.data_ptr(), 1e-6, qkv.data_ptr(), kc.data_ptr(), vc.data_ptr(),
+                                   cmax, keep[1].data_ptr(), keep[2].data_ptr(), 1 if decode else T, keep[3].data_ptr(), keep[4].data_ptr(),
+                                   force_mb, None), "qkv_rope")
+    torch.cuda.synchronize()
+    rstd = 1.0 / np.sqrt((x32.astype(np.float64) ** 2).mean(1, keepdims=True) + 1e-6)
+    y = (G.bf16_round(x32).astype(np.float64) @ W.astype(np.float64).T) * rstd
+    inv_freq = (1.0 / (10000.0 ** (np.arange(0, d, 2, dtype=np.float64) / d))).astype(f32)
+    got_q = qkv.cpu().numpy()[:, :768]
+    kcn, vcn = kc.float().cpu().numpy(), vc.float().cpu().numpy()
+    for m in range(M):
+        b, slot = (m, lens[m] - 1) if decode else (m // T, m % T)
+        pos = slot - kv_start[b]
+        pos = 1 if pos < 0 else pos
+        c, s_ = llama_np.rope_tables(np.array([pos]), inv_freq)
+
+        def rope(v):
+            v = v.reshape(nh, d)
+            rot = np.concatenate([-v[:, d // 2:], v[:, : d // 2]], -1)
+            return v * c[0] + rot * s_[0]
+        rq, rk, rv = rope(y[m, :768]), rope(y[m, 768:1536]), y[m, 1536:].reshape(nh, d)
+        assert np.abs(got_q[m].reshape(nh, d) - rq).max() < 2e-4 * max(1.0, np.abs(rq).max()), m
+        assert np.abs(kcn[b, :, slot] - rk).max() < 1e-2 * max(1.0, np.abs(rk).max()), m
+        assert np.abs(vcn[b, :, slot] - rv).max() < 1e-2 * max(1.0, np.abs(rv).max()), m
+
+
 # asymmetric-B identity check: catches a row<->col swap in the C/D fragment mapping
 def test_gemm_skinny_identity(G):
     K = 768
