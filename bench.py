@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--lanes", type=int, default=1, help="concurrent decode lanes (HIP streams) the batch is cut into")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -95,7 +96,7 @@ def main():
         out = None
         for out in gpt.generate(emb, ids_d, temp, 625, mask_d, max_new_override or max_new, 0, (*procs, *warpers), return_hidden=True,
                                 manual_seed=42, use_graph=use_graph, stop_at=stop_t, row_offset=lo * 4, total_rows=Bg * 4,
-                                profile_tag=profile_tag):
+                                profile_tag=profile_tag, lanes=args.lanes):
             pass
         lens = [int(t.shape[0]) for t in out.ids]
         wav = codec.decode_to_wavs(out.hiddens) if decode_audio else None
@@ -131,7 +132,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "C3: batch=64/GPU mixed-length (prompts 16-48 tok, outputs U{%d..%d} tok), top-p .7/top-k 20/rep 1.05/"
                                "temp .3, manual_seed 42, hipGraph decode + DVAE + Vocos" % (args.min_len, args.max_len),
-                   "global_batch": Bg, "decode_steps_per_pass": gpt_steps, "parallelism": f"dp{world}",
+                   "global_batch": Bg, "decode_steps_per_pass": gpt_steps, "parallelism": f"dp{world}", "lanes_per_gpu": args.lanes,
                    "tokens_per_pass": int(stop.sum()), "audio_s_per_pass": round(audio_seconds(stop), 2)},
     }
 

@@ -478,7 +478,7 @@ hipError_t launch_gemm_fast(const FastGemmArgs& a, hipStream_t st) {
   // enough workgroups to cover the 256 CUs over big M tiles (decode: M <= 64)
   const int ntiles = (a.N + 15) / 16;
   int mb = 4;
-  while (mb > 1 && ntiles * ((a.M + 16 * mb - 1) / (16 * mb)) < 160) mb >>= 1;
+  while (mb > 1 && ntiles * ((a.M + 16 * mb - 1) / (16 * mb)) < 256) mb >>= 1;
   if (a.M <= 16) mb = 1; else if (a.M <= 32 && mb > 2) mb = 2;
   if (a.force_mb) mb = a.force_mb;
   if (mb == 1) return fast_dispatch<1>(a, st);

@@ -285,11 +285,11 @@ hipError_t launch_attention(const float* qkv, const void* kcache, const void* vc
   const bool decode = rm.q_per_b == 1;
 #define ATT(KT, NW, OT) hipLaunchKernelGGL((attention_k<KT, NW, OT>), grid, dim3(64 * NW), 0, st, qkv, (const KT*)kcache, (const KT*)vcache, cmax, (OT*)out, rm)
   if (kv_wt == WT_BF16) {
-    if (out_bf16) { if (decode) ATT(bf16_t, 8, bf16_t); else ATT(bf16_t, 1, bf16_t); }
-    else { if (decode) ATT(bf16_t, 8, float); else ATT(bf16_t, 1, float); }
+    if (out_bf16) { if (decode) ATT(bf16_t, 4, bf16_t); else ATT(bf16_t, 1, bf16_t); }
+    else { if (decode) ATT(bf16_t, 4, float); else ATT(bf16_t, 1, float); }
   } else {
-    if (out_bf16) { if (decode) ATT(float, 8, bf16_t); else ATT(float, 1, bf16_t); }
-    else { if (decode) ATT(float, 8, float); else ATT(float, 1, float); }
+    if (out_bf16) { if (decode) ATT(float, 4, bf16_t); else ATT(float, 1, bf16_t); }
+    else { if (decode) ATT(float, 4, float); else ATT(float, 1, float); }
   }
 #undef ATT
   return hipGetLastError();

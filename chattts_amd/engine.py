@@ -210,13 +210,16 @@ class GptEngine:
         _lib.check(self.lib.ctts_gpt_create(C.byref(h), C.byref(w)), "ctts_gpt_create")
         self.handle = h
         self.stream = torch.cuda.Stream(device=dev)
+        self._lane_res = [(self.handle, self.stream)]
+        self.default_lanes = 1
         self.last_stats = {}
 
     def __del__(self):
         try:
-            if getattr(self, "handle", None):
-                self.lib.ctts_gpt_destroy(self.handle)
-                self.handle = None
+            for h, _ in getattr(self, "_lane_res", []):
+                self.lib.ctts_gpt_destroy(h)
+            self._lane_res = []
+            self.handle = None
         except Exception:
             pass
 
@@ -238,17 +241,29 @@ class GptEngine:
         return torch.where(tm[..., None], et, ec).contiguous()
 
     # -- a3: GPT.generate
+    def _lane_resources(self, n: int):
+        """(handle, stream) pairs for n concurrent lanes; lane 0 is the engine's own handle/stream."""
+        while len(self._lane_res) < n:
+            h = C.c_void_p()
+            _lib.check(self.lib.ctts_gpt_create(C.byref(h), C.byref(self._w)), "ctts_gpt_create")
+            self._lane_res.append((h, torch.cuda.Stream(device=self.device)))
+        return self._lane_res[:n]
+
     def generate(self, emb: torch.Tensor, inputs_ids: torch.Tensor, temperature: torch.Tensor, eos_token: int = GPT.n_audio - 1,
                  attention_mask: Optional[torch.Tensor] = None, max_new_token: int = 2048, min_new_token: int = 0,
                  logits_processors: Sequence = (), infer_text: bool = False, return_attn: bool = False,
                  return_hidden: bool = False, stream: bool = False, show_tqdm: bool = False, ensure_non_empty: bool = True,
                  stream_batch: int = 24, manual_seed: Optional[int] = None, context: Optional[Context] = None,
                  *, use_graph: bool = True, stop_at: Optional[torch.Tensor] = None, row_offset: int = 0,
-                 total_rows: Optional[int] = None, profile_tag: Optional[int] = None) -> Iterator[GenerationOutputs]:
+                 total_rows: Optional[int] = None, profile_tag: Optional[int] = None,
+                 lanes: Optional[int] = None) -> Iterator[GenerationOutputs]:
         """Drop-in for `GPT.generate` (gpt.py:316-337), code mode.  Extra keyword-only arguments:
         `use_graph` (hipGraph replay of the decode step), `stop_at` ([B] int32 forced output lengths,
         benchmark hook), `row_offset`/`total_rows` (this shard's position inside a data-parallel batch:
-        keeps the CPU draw and the rows>=625 penalty quirk keyed on the global row index)."""
+        keeps the CPU draw and the rows>=625 penalty quirk keyed on the global row index), `lanes`
+        (the batch is cut into that many contiguous row groups, each decoding on its own HIP stream
+        with its own captured graph; utterances never interact, so the result is identical, while the
+        per-kernel launch / dependent-load latency of one lane overlaps the others' kernels)."""
         if infer_text:
             raise NotImplementedError("refine-text generation (infer_text=True) is a 'next' row (SURVEY 8f-1)")
         if return_attn:
@@ -259,138 +274,153 @@ class GptEngine:
         B, T, nvq = inputs_ids.shape
         assert nvq == GPT.n_vq and emb.shape == (B, T, GPT.hidden)
         max_new = int(max_new_token)
-        tcap = T + max_new
-        if tcap > self.max_pos:
-            raise ValueError(f"T + max_new_token = {tcap} exceeds max_position_embeddings {self.max_pos}")
+        if T + max_new > self.max_pos:
+            raise ValueError(f"T + max_new_token = {T + max_new} exceeds max_position_embeddings {self.max_pos}")
         if attention_mask is None:
             attention_mask = torch.ones((B, T), dtype=torch.bool)
-        kv_start = left_pad_starts(attention_mask).to(dev)
-
-        st = self.stream
+        kv_start_all = left_pad_starts(attention_mask)
+        n_lanes = self.default_lanes if lanes is None else int(lanes)
+        n_lanes = max(1, min(n_lanes, B))
+        if profile_tag is not None or not use_graph:
+            n_lanes = 1
+        from .dist import shard_bounds
+        bounds = [shard_bounds(B, n_lanes, i) for i in range(n_lanes)]
+        res = self._lane_resources(n_lanes)
         caller = torch.cuda.current_stream(dev)
-        st.wait_stream(caller)
-        ctx = [torch.cuda.stream(st)]
-        ctx[0].__enter__()   # entered/left by hand so the side stream is never current while suspended in a yield
+        draws = ExpDraws(total_rows if total_rows is not None else B * nvq, GPT.n_audio, manual_seed,
+                         row_begin=row_offset, row_end=row_offset + B * nvq)
+        ptab = penalty_table(plan.penalty)
+        nq = 1 if draws.constant else self.NQ_RING
+        emb_all = emb.to(torch.float32).contiguous().to(dev)
+        ids_all = inputs_ids.to(dev)
+        temp_d = temperature.to(torch.float32).reshape(-1).to(dev)
+        assert temp_d.numel() == nvq
+        ptab_d = None if ptab is None else ptab.to(dev)
+        caller.synchronize()  # inputs above were produced on the caller's stream
 
-        def hand_over(o):
-            """leave the side stream before control returns to the consumer"""
-            ctx[0].__exit__(None, None, None)
-            caller.wait_stream(st)
-            return o
+        class Lane:
+            pass
 
-        def resume():
-            st.wait_stream(caller)
-            ctx[0] = torch.cuda.stream(st)
-            ctx[0].__enter__()
-
-        try:
-            ids_buf = torch.zeros((B, tcap, nvq), dtype=torch.int64, device=dev)  # gpt.py:372-379
-            ids_buf[:, :T] = inputs_ids.to(dev)
-            len_d = torch.full((B,), T, dtype=torch.int32, device=dev)
-            finish = torch.zeros((B,), dtype=torch.uint8, device=dev)             # gpt.py:346
-            end_idx = torch.zeros((B,), dtype=torch.int32, device=dev)            # gpt.py:343
-            hiddens = torch.empty((B, max_new, GPT.hidden), dtype=torch.float32, device=dev)
-            kv_shape = (self.n_layers, B, GPT.n_heads, tcap, GPT.head_dim)
-            kcache = torch.empty(kv_shape, dtype=self.wdt, device=dev)
-            vcache = torch.empty(kv_shape, dtype=self.wdt, device=dev)
-            ws_bytes = lib.ctts_gpt_workspace_bytes(B, T)
-            workspace = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
-            temp_d = temperature.to(torch.float32).reshape(-1).to(dev)
-            assert temp_d.numel() == nvq
-            ptab = penalty_table(plan.penalty)
-            ptab_d = None if ptab is None else ptab.to(dev)
-            stop_d = None if stop_at is None else stop_at.to(torch.int32).to(dev)
-            emb_d = emb.to(torch.float32).contiguous().to(dev)
-
-            draws = ExpDraws(total_rows if total_rows is not None else B * nvq, GPT.n_audio, manual_seed,
-                             row_begin=row_offset, row_end=row_offset + B * nvq)
-            if draws.constant:
-                nq = 1
-                q_d = draws.step(0).to(dev).reshape(1, B * nvq, GPT.n_audio).contiguous()
-                q_host = None
-            else:
-                nq = self.NQ_RING
-                q_d = torch.empty((nq, B * nvq, GPT.n_audio), dtype=torch.float32, device=dev)
-                q_host = torch.empty((nq // 2, B * nvq, GPT.n_audio), dtype=torch.float32).pin_memory()
-
+        L = []
+        for (lo, hi), (handle, st) in zip(bounds, res):
+            ln = Lane()
+            ln.lo, ln.hi, ln.handle, ln.st, ln.done = lo, hi, handle, st, False
+            Bl = hi - lo
+            with torch.cuda.stream(st):
+                ln.ids_buf = torch.zeros((Bl, T + max_new, nvq), dtype=torch.int64, device=dev)  # gpt.py:372-379
+                ln.ids_buf[:, :T] = ids_all[lo:hi]
+                ln.len_d = torch.full((Bl,), T, dtype=torch.int32, device=dev)
+                ln.finish = torch.zeros((Bl,), dtype=torch.uint8, device=dev)             # gpt.py:346
+                ln.end_idx = torch.zeros((Bl,), dtype=torch.int32, device=dev)            # gpt.py:343
+                ln.hiddens = torch.empty((Bl, max_new, GPT.hidden), dtype=torch.float32, device=dev)
+                kv_shape = (self.n_layers, Bl, GPT.n_heads, T + max_new, GPT.head_dim)
+                ln.kcache = torch.empty(kv_shape, dtype=self.wdt, device=dev)
+                ln.vcache = torch.empty(kv_shape, dtype=self.wdt, device=dev)
+                ws_bytes = lib.ctts_gpt_workspace_bytes(Bl, T)
+                ln.workspace = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+                ln.kv_start = kv_start_all[lo:hi].contiguous().to(dev)
+                ln.stop_d = None if stop_at is None else stop_at[lo:hi].to(torch.int32).contiguous().to(dev)
+                ln.emb = emb_all[lo:hi].contiguous()
+                if draws.constant:
+                    ln.q_d = draws.step(0)[lo * nvq: hi * nvq].to(dev).reshape(1, Bl * nvq, GPT.n_audio).contiguous()
+                else:
+                    ln.q_d = torch.empty((nq, Bl * nvq, GPT.n_audio), dtype=torch.float32, device=dev)
             s = _lib.GenState()
-            s.B, s.T, s.max_new = B, T, max_new
-            s.ids_buf, s.len, s.kv_start = ids_buf.data_ptr(), len_d.data_ptr(), kv_start.data_ptr()
-            s.finish, s.end_idx, s.hiddens = finish.data_ptr(), end_idx.data_ptr(), hiddens.data_ptr()
-            s.kcache, s.vcache, s.q, s.nq = kcache.data_ptr(), vcache.data_ptr(), q_d.data_ptr(), nq
+            s.B, s.T, s.max_new = Bl, T, max_new
+            s.ids_buf, s.len, s.kv_start = ln.ids_buf.data_ptr(), ln.len_d.data_ptr(), ln.kv_start.data_ptr()
+            s.finish, s.end_idx, s.hiddens = ln.finish.data_ptr(), ln.end_idx.data_ptr(), ln.hiddens.data_ptr()
+            s.kcache, s.vcache, s.q, s.nq = ln.kcache.data_ptr(), ln.vcache.data_ptr(), ln.q_d.data_ptr(), nq
             s.temperature = temp_d.data_ptr()
             s.pow_table = _lib.ptr(ptab_d)
             s.top_p_thr = float(np.float32(1.0 - plan.top_p)) if plan.top_p is not None else 0.0
             s.use_top_p = int(plan.top_p is not None)
             s.top_k = int(plan.top_k or 0)
             s.use_top_k = int(plan.top_k is not None)
-            s.min_new, s.eos, s.row_offset = int(min_new_token), int(eos_token), int(row_offset)
-            s.stop_at = _lib.ptr(stop_d)
-            s.workspace, s.workspace_bytes = workspace.data_ptr(), ws_bytes
-            sp = st.cuda_stream
+            s.min_new, s.eos = int(min_new_token), int(eos_token)
+            s.row_offset = int(row_offset + lo * nvq)
+            s.stop_at = _lib.ptr(ln.stop_d)
+            s.workspace, s.workspace_bytes = ln.workspace.data_ptr(), ws_bytes
+            ln.s = s
+            L.append(ln)
 
-            uploaded = 0  # number of steps whose q draws are on the device (unseeded mode)
+        q_host = None if draws.constant else torch.empty((nq // 2, B * nvq, GPT.n_audio), dtype=torch.float32).pin_memory()
+        uploaded = 0  # steps whose Exp(1) draws are on the device (unseeded mode only)
 
-            def ensure_q(upto: int):
-                nonlocal uploaded
-                if q_host is None:
-                    return
-                half = nq // 2
-                while uploaded < upto:
-                    st.synchronize()  # staging buffer reuse; unseeded mode is host-RNG bound anyway
-                    n = min(half, max_new - uploaded)
-                    for j in range(n):
-                        q_host[j].copy_(draws.step(uploaded + j))
-                    slab = uploaded % nq
-                    q_d[slab: slab + n].copy_(q_host[:n], non_blocking=True)
-                    uploaded += n
+        def ensure_q(upto: int):
+            nonlocal uploaded
+            if q_host is None:
+                return
+            half = nq // 2
+            while uploaded < upto:
+                for ln in L:
+                    ln.st.synchronize()  # ring slab + staging reuse; unseeded sampling is host-RNG bound anyway
+                n = min(half, max_new - uploaded)
+                for j in range(n):
+                    q_host[j].copy_(draws.step(uploaded + j))
+                slab = uploaded % nq
+                for ln in L:
+                    with torch.cuda.stream(ln.st):
+                        ln.q_d[slab: slab + n].copy_(q_host[:n, ln.lo * nvq: ln.hi * nvq], non_blocking=True)
+                uploaded += n
 
-            ensure_q(1)
-            _lib.check(lib.ctts_gpt_prefill(self.handle, C.byref(s), emb_d.data_ptr(), sp), "ctts_gpt_prefill")
-            steps_done = 1
-            fin_host = finish.cpu()  # syncs: the step-0 rule needs it (gpt.py:527)
-            if bool(fin_host.any()):
-                self.logger.warning("unexpected end at index %s", str(fin_host.nonzero().flatten().tolist()))
-                if ensure_non_empty and manual_seed is None:
-                    self.logger.warning("regenerate in order to ensure non-empty")
-                    hand_over(None)
-                    yield from self.generate(emb, inputs_ids, temperature, eos_token, attention_mask, max_new_token,
-                                             min_new_token, logits_processors, infer_text, return_attn, return_hidden,
-                                             stream, show_tqdm, ensure_non_empty, stream_batch, manual_seed, context,
-                                             use_graph=use_graph, stop_at=stop_at, row_offset=row_offset, total_rows=total_rows)
-                    resume()
-                return  # gpt.py:570: the seeded case yields nothing
+        def outputs() -> GenerationOutputs:
+            ids, hid = [], []
+            for ln in L:
+                with torch.cuda.stream(ln.st):
+                    e = ln.end_idx.cpu().tolist()
+                ids += [ln.ids_buf[b, T: T + e[b]] for b in range(ln.hi - ln.lo)]                      # gpt.py:297-299
+                if return_hidden:
+                    hid += [ln.hiddens[b, : e[b]] for b in range(ln.hi - ln.lo)]                       # gpt.py:303-307
+            for ln in L:
+                caller.wait_stream(ln.st)
+            return GenerationOutputs(ids=ids, attentions=[], hiddens=hid)
 
-            graph_ok = False
-            if use_graph and max_new > 1:
-                _lib.check(lib.ctts_gpt_graph_build(self.handle, C.byref(s), sp), "ctts_gpt_graph_build")
-                graph_ok = True
-            if profile_tag is not None:
-                _lib.check(lib.ctts_gpt_profile_begin(self.handle, int(profile_tag), 4096), "profile_begin")
+        # ---- step 0: prefill ----
+        ensure_q(1)
+        for ln in L:
+            _lib.check(lib.ctts_gpt_prefill(ln.handle, C.byref(ln.s), ln.emb.data_ptr(), ln.st.cuda_stream), "ctts_gpt_prefill")
+        steps_done = 1
+        fin0 = torch.cat([ln.finish.cpu() for ln in L])  # syncs: the step-0 rule needs it (gpt.py:527)
+        if bool(fin0.any()):
+            self.logger.warning("unexpected end at index %s", str(fin0.nonzero().flatten().tolist()))
+            if ensure_non_empty and manual_seed is None:
+                self.logger.warning("regenerate in order to ensure non-empty")
+                yield from self.generate(emb, inputs_ids, temperature, eos_token, attention_mask, max_new_token,
+                                         min_new_token, logits_processors, infer_text, return_attn, return_hidden,
+                                         stream, show_tqdm, ensure_non_empty, stream_batch, manual_seed, context,
+                                         use_graph=use_graph, stop_at=stop_at, row_offset=row_offset, total_rows=total_rows,
+                                         lanes=lanes)
+            return  # gpt.py:570: the seeded case yields nothing
 
-            def outputs() -> GenerationOutputs:
-                e = end_idx.cpu().tolist()
-                return GenerationOutputs(
-                    ids=[ids_buf[b, T: T + e[b]] for b in range(B)],                      # gpt.py:297-299
-                    attentions=[],
-                    hiddens=[hiddens[b, : e[b]] for b in range(B)] if return_hidden else [],  # gpt.py:303-307
-                )
+        graph_ok = use_graph and max_new > 1
+        if graph_ok:
+            for ln in L:
+                _lib.check(lib.ctts_gpt_graph_build(ln.handle, C.byref(ln.s), ln.st.cuda_stream), "ctts_gpt_graph_build")
+        if profile_tag is not None:
+            _lib.check(lib.ctts_gpt_profile_begin(L[0].handle, int(profile_tag), 4096), "profile_begin")
 
-            chunk = stream_batch if stream else self.POLL
-            all_done = False
-            interrupted = False
+        chunk = stream_batch if stream else self.POLL
+        all_done = False
+        interrupted = False
+        try:
             while steps_done < max_new and not all_done:
-                # reference yields when (i+1) % stream_batch == 0: keep chunk ends on those steps
+                # the reference yields when (i+1) % stream_batch == 0: keep chunk ends on those steps
                 n = min(chunk - (steps_done % chunk), max_new - steps_done)
                 ensure_q(steps_done + n)
-                if graph_ok:
-                    _lib.check(lib.ctts_gpt_graph_launch(self.handle, n, sp), "ctts_gpt_graph_launch")
-                else:
-                    for _ in range(n):
-                        _lib.check(lib.ctts_gpt_decode_step(self.handle, C.byref(s), sp), "ctts_gpt_decode_step")
+                for ln in L:
+                    if ln.done:
+                        continue
+                    if graph_ok:
+                        _lib.check(lib.ctts_gpt_graph_launch(ln.handle, n, ln.st.cuda_stream), "ctts_gpt_graph_launch")
+                    else:
+                        for _ in range(n):
+                            _lib.check(lib.ctts_gpt_decode_step(ln.handle, C.byref(ln.s), ln.st.cuda_stream), "ctts_gpt_decode_step")
                 steps_done += n
-                fin_host = finish.cpu()  # stream-ordered D2H + sync
-                all_done = bool(fin_host.all())
+                for ln in L:
+                    if not ln.done:
+                        with torch.cuda.stream(ln.st):
+                            ln.done = bool(ln.finish.cpu().all())  # stream-ordered D2H + sync of that lane
+                all_done = all(ln.done for ln in L)
                 if context.get():  # gpt.py:592
                     interrupted = True
                     break
@@ -399,32 +429,26 @@ class GptEngine:
                     if not all_done and steps_done % stream_batch == 0:
                         emit = True                                      # gpt.py:579-589
                     elif all_done:
-                        i_star = int(end_idx.max().item())               # step at which the last row hit EOS
+                        i_star = max(int(ln.end_idx.max().item()) for ln in L)   # step at which the last row hit EOS
                         emit = i_star > 0 and i_star % stream_batch == 0  # the reference's duplicate yield (stream_iter quirk)
                     if emit:
-                        yield hand_over(outputs())
-                        resume()
+                        yield outputs()
             if profile_tag is not None:
                 n_s, tot = C.c_int32(0), C.c_double(0.0)
-                _lib.check(lib.ctts_gpt_profile_end(self.handle, C.byref(n_s), C.byref(tot)), "profile_end")
+                _lib.check(lib.ctts_gpt_profile_end(L[0].handle, C.byref(n_s), C.byref(tot)), "profile_end")
                 self.last_stats["profile"] = (int(n_s.value), float(tot.value))
-            if graph_ok:
-                st.synchronize()
-                lib.ctts_gpt_graph_destroy(self.handle)
-            if not all_done:
-                if interrupted:
-                    self.logger.warning("generation is interrupted")
-                else:
-                    self.logger.warning(f"incomplete result. hit max_new_token: {max_new_token}")   # gpt.py:601-607
-            self.last_stats.update(steps=steps_done, B=B, T=T)
-            out = outputs()
         finally:
-            try:
-                ctx[0].__exit__(None, None, None)
-            except Exception:
-                pass
-        caller.wait_stream(st)
-        yield out
+            if graph_ok:
+                for ln in L:
+                    ln.st.synchronize()
+                    lib.ctts_gpt_graph_destroy(ln.handle)
+        if not all_done:
+            if interrupted:
+                self.logger.warning("generation is interrupted")
+            else:
+                self.logger.warning(f"incomplete result. hit max_new_token: {max_new_token}")   # gpt.py:601-607
+        self.last_stats.update(steps=steps_done, B=B, T=T, lanes=n_lanes)
+        yield outputs()
 
 
 # ---------------------------------------------------------------------------------------------
