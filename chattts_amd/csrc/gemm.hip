@@ -293,17 +293,46 @@ hipError_t launch_gemm_tiled(const GemmArgs& a, hipStream_t st) {
 // at kernel entry so that no dependent memory round trip is left on the tail of the kernel.
 // ------------------------------------------------------------------------------------------------
 template <int MB, int NW, bool SCALE, int EPI>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 2))) void gemm_fast_k(FastGemmArgs a) {
+__global__ __launch_bounds__(64 * (NW + (EPI == FEPI_QKV_ROPE ? 1 : 0)))
+void gemm_fast_k(FastGemmArgs a) {
   constexpr int NACC = (EPI == FEPI_SILU) ? 2 : 1;
   constexpr int U = 6;    // k-chunks (of 32) per wave per round; every lane keeps U*(NACC+MB) 16-byte loads in flight
   constexpr int KC = 32;
   __shared__ float red[NW][NACC][MB][64][4];
   __shared__ float rstd_s[16 * MB];
+  __shared__ float cs_s[(EPI == FEPI_QKV_ROPE) ? 16 * MB : 1][16];   // per row: cos[8], sin[8] of this tile's dims
+  __shared__ int meta_s[(EPI == FEPI_QKV_ROPE) ? 16 * MB : 1][2];    // per row: b, slot
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int li = lane & 15, g = lane >> 4;
   const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16 * MB;
   const int M = a.M, N = a.N, K = a.K;
+  // ROPE tiles (weights permuted by the loader): columns 0..7 of a q/k tile are dims d0..d0+7 of one
+  // head, columns 8..15 are dims d0+32..d0+39, so a rotate-half pair sits 8 lanes apart.
+  const int sect = n0 / 768, hcol = n0 % 768, head = hcol >> 6, t4 = (hcol & 63) >> 4;
+  const int dlo = 8 * t4 + (li & 7);
+
+  if (EPI == FEPI_QKV_ROPE && wave == NW) {
+    // helper wave: the dependent chain len -> position -> cos/sin runs here, beside the main waves' load
+    // phase (a vector-memory wait in a main wave would sit behind its 30+ operand loads: vmcnt is in-order)
+    if (lane < 16 * MB) {
+      const int row = min(m0 + lane, M - 1);
+      int b, slot;
+      if (a.q_per_b == 1) { b = row; slot = a.len[b] - 1; } else { b = row / a.q_per_b; slot = row - b * a.q_per_b; }
+      int pos = slot - a.kv_start[b];
+      if (pos < 0) pos = 1;
+      const float4 c0 = *reinterpret_cast<const float4*>(a.cos_t + pos * 32 + 8 * t4);
+      const float4 c1 = *reinterpret_cast<const float4*>(a.cos_t + pos * 32 + 8 * t4 + 4);
+      const float4 s0 = *reinterpret_cast<const float4*>(a.sin_t + pos * 32 + 8 * t4);
+      const float4 s1 = *reinterpret_cast<const float4*>(a.sin_t + pos * 32 + 8 * t4 + 4);
+      float* o = cs_s[lane];
+      o[0] = c0.x; o[1] = c0.y; o[2] = c0.z; o[3] = c0.w; o[4] = c1.x; o[5] = c1.y; o[6] = c1.z; o[7] = c1.w;
+      o[8] = s0.x; o[9] = s0.y; o[10] = s0.z; o[11] = s0.w; o[12] = s1.x; o[13] = s1.y; o[14] = s1.z; o[15] = s1.w;
+      meta_s[lane][0] = b; meta_s[lane][1] = slot;
+    }
+    __syncthreads();
+    return;
+  }
 
   // per-row sum of squares: 4 threads x 12 partials per row, consumed only in the epilogue
   float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0;
@@ -316,31 +345,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 2)))
   }
 
   // epilogue operands of the finishing waves (wave mb finishes m-block mb)
-  float pre0[4] = {0.f, 0.f, 0.f, 0.f}, pre1[4] = {0.f, 0.f, 0.f, 0.f};  // RES: residual | ROPE: cos, sin
-  int eb[4] = {0, 0, 0, 0}, eslot[4] = {0, 0, 0, 0};
-  // ROPE tiles (weights permuted by the loader): columns 0..7 of a q/k tile are dims d0..d0+7 of one
-  // head, columns 8..15 are dims d0+32..d0+39, so a rotate-half pair sits 8 lanes apart.
-  const int sect = n0 / 768, hcol = n0 % 768, head = hcol >> 6, t4 = (hcol & 63) >> 4;
-  const int dlo = 8 * t4 + (li & 7);
-  if (wave < MB) {
-    if (EPI == FEPI_RES) {
+  float pre0[4] = {0.f, 0.f, 0.f, 0.f};  // RES: residual, requested before the operand loads
+  if (EPI == FEPI_RES && wave < MB) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = min(m0 + 16 * wave + 4 * g + r, M - 1);
-        pre0[r] = a.C32[(size_t)row * a.ldc + min(n0 + li, N - 1)];
-      }
-    } else if (EPI == FEPI_QKV_ROPE) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = min(m0 + 16 * wave + 4 * g + r, M - 1);
-        int b, slot;
-        if (a.q_per_b == 1) { b = row; slot = a.len[b] - 1; } else { b = row / a.q_per_b; slot = row - b * a.q_per_b; }
-        int pos = slot - a.kv_start[b];
-        if (pos < 0) pos = 1;
-        eb[r] = b; eslot[r] = slot;
-        pre0[r] = a.cos_t[pos * 32 + dlo];
-        pre1[r] = a.sin_t[pos * 32 + dlo];
-      }
+    for (int r = 0; r < 4; ++r) {
+      const int row = min(m0 + 16 * wave + 4 * g + r, M - 1);
+      pre0[r] = a.C32[(size_t)row * a.ldc + min(n0 + li, N - 1)];
     }
   }
 
@@ -437,11 +447,13 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 2)))
       } else {  // FEPI_QKV_ROPE: q -> roped, in the f32 qkv buffer; k -> roped, KV cache; v -> KV cache
         const float other = __shfl_xor(v, 8, 64);
         const bool hi = li >= 8;
+        const int lr = 16 * mb + 4 * g + r;
+        const float cc = cs_s[lr][li & 7], ss = cs_s[lr][8 + (li & 7)];
         // rotate-half: out[d] = x[d] c - x[d+32] s ; out[d+32] = x[d+32] c + x[d] s
-        const float roped = hi ? (v * pre0[r] + other * pre1[r]) : (v * pre0[r] - other * pre1[r]);
+        const float roped = hi ? (v * cc + other * ss) : (v * cc - other * ss);
         const int d = dlo + (hi ? 32 : 0);
         if (ok) {
-          const size_t cbase = (((size_t)eb[r] * 12 + head) * a.cmax + eslot[r]) * 64;
+          const size_t cbase = (((size_t)meta_s[lr][0] * 12 + head) * a.cmax + meta_s[lr][1]) * 64;
           if (sect == 0) a.C32[(size_t)row * a.ldc + head * 64 + d] = roped;
           else if (sect == 1) a.kc[cbase + d] = f32_to_bf16(roped);
           else a.vc[cbase + (hcol & 63) + li] = f32_to_bf16(v);
@@ -457,13 +469,16 @@ static hipError_t fast_dispatch(const FastGemmArgs& a, hipStream_t st) {
   const bool scale = a.ssq_in != nullptr;
   if (a.K == 768) {
     if (a.epi == FEPI_STORE32 && scale) hipLaunchKernelGGL((gemm_fast_k<MB, 4, true, FEPI_STORE32>), grid, dim3(256), 0, st, a);
-    else if (a.epi == FEPI_QKV_ROPE && scale) hipLaunchKernelGGL((gemm_fast_k<MB, 4, true, FEPI_QKV_ROPE>), grid, dim3(256), 0, st, a);
+    else if (a.epi == FEPI_QKV_ROPE && scale) hipLaunchKernelGGL((gemm_fast_k<MB, 4, true, FEPI_QKV_ROPE>), grid, dim3(320), 0, st, a);
     else if (a.epi == FEPI_SILU && scale) hipLaunchKernelGGL((gemm_fast_k<MB, 4, true, FEPI_SILU>), grid, dim3(256), 0, st, a);
     else if (a.epi == FEPI_RES && !scale) hipLaunchKernelGGL((gemm_fast_k<MB, 4, false, FEPI_RES>), grid, dim3(256), 0, st, a);
     else return hipErrorInvalidValue;
   } else if (a.K == 3072) {
-    if (a.epi == FEPI_RES && !scale) hipLaunchKernelGGL((gemm_fast_k<MB, 8, false, FEPI_RES>), grid, dim3(512), 0, st, a);
-    else return hipErrorInvalidValue;
+    if (a.epi == FEPI_RES && !scale) {
+      // one load round per wave when the tile is a single m-block (decode): 16 waves x 6 chunks = K
+      if (MB == 1) hipLaunchKernelGGL((gemm_fast_k<1, 16, false, FEPI_RES>), grid, dim3(1024), 0, st, a);
+      else hipLaunchKernelGGL((gemm_fast_k<MB, 8, false, FEPI_RES>), grid, dim3(512), 0, st, a);
+    } else return hipErrorInvalidValue;
   } else {
     return hipErrorInvalidValue;
   }
