@@ -372,13 +372,13 @@ void gemm_fast_k(FastGemmArgs a) {
     u128 wf[NACC][U], af[MB][U];
 #pragma unroll
     for (int j = 0; j < U; ++j) {
-      const int k0 = ((i + j) * NW + wave) * KC;
+      const int k0 = (wave * nper + i + j) * KC;  // contiguous K range per wave: whole 128-B lines of a row stay in one wave
       wf[0][j] = *reinterpret_cast<const u128*>(wrow + k0);
       if (NACC == 2) wf[1][j] = *reinterpret_cast<const u128*>(wrow2 + k0);
     }
 #pragma unroll
     for (int j = 0; j < U; ++j) {
-      const int k0 = ((i + j) * NW + wave) * KC;
+      const int k0 = (wave * nper + i + j) * KC;  // contiguous K range per wave: whole 128-B lines of a row stay in one wave
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) af[mb][j] = *reinterpret_cast<const u128*>(arow[mb] + k0);
     }
