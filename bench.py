@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-ttfs", action="store_true")
     ap.add_argument("--lanes", type=int, default=1, help="concurrent decode lanes (HIP streams) the batch is cut into")
     args = ap.parse_args()
 
@@ -92,11 +93,11 @@ def main():
     emb = gpt.embed_prompt(ids_t, tm_t)
     ids_d, mask_d = ids_t.to(dev), mask_t
 
-    def one_pass(use_graph=True, profile_tag=None, decode_audio=True, max_new_override=None):
+    def one_pass(use_graph=True, profile_tag=None, decode_audio=True, max_new_override=None, profile_stride=1):
         out = None
         for out in gpt.generate(emb, ids_d, temp, 625, mask_d, max_new_override or max_new, 0, (*procs, *warpers), return_hidden=True,
                                 manual_seed=42, use_graph=use_graph, stop_at=stop_t, row_offset=lo * 4, total_rows=Bg * 4,
-                                profile_tag=profile_tag, lanes=args.lanes):
+                                profile_tag=profile_tag, profile_stride=profile_stride, lanes=args.lanes):
             pass
         lens = [int(t.shape[0]) for t in out.ids]
         wav = codec.decode_to_wavs(out.hiddens) if decode_audio else None
@@ -136,14 +137,15 @@ def main():
                    "tokens_per_pass": int(stop.sum()), "audio_s_per_pass": round(audio_seconds(stop), 2)},
     }
 
-    # ---- roofline of the dominant decode kernel: HIP events around each launch on the launch stream ----
+    # ---- roofline of the dominant decode kernel: HIP events around sampled launches, on the launch stream,
+    #      in an eager pass of the SAME workload (every 5th launch of the tag over all decode steps) ----
     if rank == 0 and not args.no_roofline:
-        prof_steps = 97  # eager pass length (prefill + 96 decode steps): 96*20 = 1920 attention launches sampled
         per_tag = {}
-        for tag in (1, 3, 4, 5, 6, 8, 9, 2):
-            one_pass(use_graph=False, profile_tag=tag, decode_audio=False, max_new_override=prof_steps)
-            n, tot = gpt.last_stats.get("profile", (0, 0.0))
-            per_tag[tag] = (n, tot)
+        for tag in (1, 3, 4, 5, 6, 8, 9):
+            calls = 1 if tag in (8, 9) else GPT.n_layers
+            stride = 1 if calls == 1 else 5
+            one_pass(use_graph=False, profile_tag=tag, profile_stride=stride, decode_audio=False)
+            per_tag[tag] = gpt.last_stats.get("profile", (0, 0.0))
         calls_per_step = {t: (1 if t in (8, 9) else GPT.n_layers) for t in per_tag}
         step_ms = {TAGS[t]: round(per_tag[t][1] / max(1, per_tag[t][0]) * calls_per_step[t], 4) for t in per_tag}
         dom = max(per_tag, key=lambda t: per_tag[t][1] / max(1, per_tag[t][0]) * calls_per_step[t])
@@ -152,21 +154,37 @@ def main():
         es = 2 if args.dtype == "bf16" else 4
         B = hi - lo
         valid_prompt = mask[lo:hi].sum(1).astype(np.int64)
-        n_steps_sampled = max(1, n // calls_per_step[dom])
         if dom == 3:
-            # KV read 2*768*s*c_b per row per layer + KV write is done by rope_append; q read + out write
-            ctx = [(valid_prompt + i).sum() for i in range(1, n_steps_sampled + 1)]  # context incl. the current token
-            alg = float(np.mean(ctx)) * 2 * 768 * es + B * (768 * 4 * 2)
+            # SURVEY 8d per-unit figure: KV read 2*768*s bytes per visible key per row per layer, + q read / out write.
+            # All rows stay in the lock-step loop until the last one finishes, so at decode step i row b sees
+            # valid_prompt[b] + i keys; launches are sampled uniformly over the decode steps 1..steps-1.
+            ctx = [(valid_prompt + i).sum() for i in range(1, gpt_steps)]
+            alg = float(np.mean(ctx)) * 2 * 768 * es + B * 768 * (4 + es)
         else:
-            wbytes = {1: 3 * 768 * 768, 4: 768 * 768, 5: 2 * 3072 * 768, 6: 768 * 3072, 8: 2504 * 768 * (4 // es)}.get(dom, 0) * es
-            act = {1: B * (768 + 2304) * 4, 4: B * 768 * 3 * 4, 5: B * (768 + 3072) * 4, 6: B * (3072 + 2 * 768) * 4,
-                   8: B * (768 + 2504) * 4, 9: B * 4 * 626 * 8, 2: B * 2304 * 4 * 2}.get(dom, 0)
+            wbytes = {1: 3 * 768 * 768 * es, 4: 768 * 768 * es, 5: 2 * 3072 * 768 * es, 6: 768 * 3072 * es, 8: 2504 * 768 * 4}.get(dom, 0)
+            act = {1: B * (768 * es + 2304 * 4), 4: B * 768 * (es + 8 + es), 5: B * (768 + 3072) * es, 6: B * (3072 * es + 768 * (8 + es)),
+                   8: B * (768 + 2504) * 4, 9: B * 4 * 626 * 8}.get(dom, 0)
             alg = float(wbytes + act)
         achieved = alg / (avg_ms * 1e-3) / 1e9
         result["roofline"] = {"kernel": TAGS[dom], "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "avg_launch_us": round(avg_ms * 1e3, 2),
                               "launches_timed": n, "alg_bytes_per_launch": int(alg)}
         result["decode_kernel_ms_per_step"] = step_ms
+
+    # ---- time to first sample: stream=True with the reference's yield schedule (first audio after 3 x 24 tokens) ----
+    if rank == 0 and not args.no_ttfs:
+        from chattts_amd.core import Chat, InferCodeParams
+        chat = Chat()
+        chat.gpt, chat.codec = gpt, codec
+        params = InferCodeParams(max_new_token=max_new, manual_seed=42, show_tqdm=False)
+        ttfs = []
+        for _ in range(5):
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for chunk in chat.infer_ids_stream(ids_t, mask_t, tm_t, params, stop_at=stop_t, row_offset=lo * 4, total_rows=Bg * 4):
+                ttfs.append(time.perf_counter() - t1)   # chunk is a host numpy array: audio is on the host here
+                break
+        result["ttfs_ms_p50"] = round(1000.0 * float(np.median(ttfs)), 2)
 
     # ---- same-box CPU baseline: the numpy port of the reference path, bounded sample ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -97,3 +97,29 @@ class Chat:
         if last is None:
             return np.zeros((0,), np.float32)
         return self.decode_to_wavs(last.hiddens)
+
+    def infer_ids_stream(self, input_ids, attention_mask, text_mask, params: InferCodeParams = InferCodeParams(), **kw):
+        """stream=True body of `Chat._infer` for one batch (core.py:455-503): every `stream_batch` live steps the
+        generator yields the cumulative result, the prefix is decoded again (the reference's O(n^2) schedule,
+        App. D-10) and the next `stream_speed` samples are emitted; the first `pass_first_n_batches` yields are
+        dropped (their decode is skipped here: its output is discarded by the reference, core.py:488-490);
+        the tail is emitted with all-silent columns removed (core.py:500-503)."""
+        length = 0
+        pass_batch_count = 0
+        wavs = None
+        for result in self.infer_code(input_ids, attention_mask, text_mask, params, stream=True, **kw):
+            pass_batch_count += 1
+            if pass_batch_count <= params.pass_first_n_batches:
+                wavs = None
+                continue
+            wavs = self.decode_to_wavs(result.hiddens)
+            a = length
+            b = min(a + params.stream_speed, wavs.shape[1])
+            length = b
+            yield wavs[:, a:b]
+        if wavs is None and pass_batch_count > 0:
+            wavs = self.decode_to_wavs(result.hiddens)
+        if wavs is not None:
+            new_wavs = wavs[:, length:]
+            keep_cols = np.sum(np.abs(new_wavs) > 1e-5, axis=0) > 0
+            yield new_wavs[:, keep_cols]

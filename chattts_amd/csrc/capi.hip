@@ -38,6 +38,8 @@ struct ctts_gpt {
   // profiling (eager decode only)
   int prof_tag = -1;
   int prof_max = 0;
+  int prof_stride = 1;   // time every prof_stride-th launch of the tag
+  int prof_seen = 0;
   std::vector<hipEvent_t> ev0, ev1;
   int prof_n = 0;
 };
@@ -100,7 +102,7 @@ extern "C" void ctts_gpt_destroy(ctts_gpt* g) {
 struct Prof {
   ctts_gpt* g; hipStream_t st; bool on; int idx;
   Prof(ctts_gpt* g_, int tag, hipStream_t st_, bool allow) : g(g_), st(st_), on(false), idx(0) {
-    if (allow && g->prof_tag == tag && g->prof_n < g->prof_max) {
+    if (allow && g->prof_tag == tag && g->prof_n < g->prof_max && (g->prof_seen++ % g->prof_stride) == 0) {
       on = true; idx = g->prof_n;
       (void)hipEventRecord(g->ev0[idx], st);
     }
@@ -246,8 +248,8 @@ extern "C" int ctts_gpt_graph_launch(ctts_gpt* g, int32_t n_steps, void* stream)
   return 0;
 }
 
-extern "C" int ctts_gpt_profile_begin(ctts_gpt* g, int32_t tag, int32_t max_samples) {
-  if (!g || max_samples <= 0) return fail("bad profile args");
+extern "C" int ctts_gpt_profile_begin(ctts_gpt* g, int32_t tag, int32_t max_samples, int32_t stride) {
+  if (!g || max_samples <= 0 || stride <= 0) return fail("bad profile args");
   while ((int)g->ev0.size() < max_samples) {
     hipEvent_t a, b;
     CK(hipEventCreate(&a));
@@ -255,7 +257,7 @@ extern "C" int ctts_gpt_profile_begin(ctts_gpt* g, int32_t tag, int32_t max_samp
     g->ev0.push_back(a);
     g->ev1.push_back(b);
   }
-  g->prof_tag = tag; g->prof_max = max_samples; g->prof_n = 0;
+  g->prof_tag = tag; g->prof_max = max_samples; g->prof_n = 0; g->prof_stride = stride; g->prof_seen = 0;
   return 0;
 }
 

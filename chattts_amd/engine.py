@@ -256,7 +256,7 @@ class GptEngine:
                  stream_batch: int = 24, manual_seed: Optional[int] = None, context: Optional[Context] = None,
                  *, use_graph: bool = True, stop_at: Optional[torch.Tensor] = None, row_offset: int = 0,
                  total_rows: Optional[int] = None, profile_tag: Optional[int] = None,
-                 lanes: Optional[int] = None) -> Iterator[GenerationOutputs]:
+                 profile_stride: int = 1, lanes: Optional[int] = None) -> Iterator[GenerationOutputs]:
         """Drop-in for `GPT.generate` (gpt.py:316-337), code mode.  Extra keyword-only arguments:
         `use_graph` (hipGraph replay of the decode step), `stop_at` ([B] int32 forced output lengths,
         benchmark hook), `row_offset`/`total_rows` (this shard's position inside a data-parallel batch:
@@ -397,7 +397,7 @@ class GptEngine:
             for ln in L:
                 _lib.check(lib.ctts_gpt_graph_build(ln.handle, C.byref(ln.s), ln.st.cuda_stream), "ctts_gpt_graph_build")
         if profile_tag is not None:
-            _lib.check(lib.ctts_gpt_profile_begin(L[0].handle, int(profile_tag), 4096), "profile_begin")
+            _lib.check(lib.ctts_gpt_profile_begin(L[0].handle, int(profile_tag), 4096, int(profile_stride)), "profile_begin")
 
         chunk = stream_batch if stream else self.POLL
         all_done = False

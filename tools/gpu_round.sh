@@ -26,7 +26,7 @@ for S in $STAGES; do
       tail -3 gpurun_out/${TAG}_bench.log ;;
     prof)
       cd /tmp
-      timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${TAG} -o ${TAG} -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline > $R/gpurun_out/${TAG}_rocprof.log 2>&1
+      timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${TAG} -o ${TAG} -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-ttfs > $R/gpurun_out/${TAG}_rocprof.log 2>&1
       echo "rocprof exit $?" >> $R/gpurun_out/${TAG}_rocprof.log
       find /tmp/prof_${TAG} -name "*stats*.csv" -exec cp {} $R/gpurun_out/ \;
       find /tmp/prof_${TAG} -type f >> $R/gpurun_out/${TAG}_rocprof.log
@@ -34,7 +34,7 @@ for S in $STAGES; do
     pmc)
       cd /tmp
       for C in FETCH_SIZE WRITE_SIZE; do
-        timeout 900 rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/pmc_${TAG}_$C -o ${TAG}_$C -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --max-len 160 --min-len 128 > $R/gpurun_out/${TAG}_pmc_$C.log 2>&1
+        timeout 900 rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/pmc_${TAG}_$C -o ${TAG}_$C -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-ttfs --max-len 160 --min-len 128 > $R/gpurun_out/${TAG}_pmc_$C.log 2>&1
         python $R/tools/pmc_summary.py /tmp/pmc_${TAG}_$C $C > $R/gpurun_out/${TAG}_pmc_${C}_summary.txt 2>&1
       done
       cd "$R" ;;
