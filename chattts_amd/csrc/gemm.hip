@@ -15,6 +15,8 @@
 //
 // f32-input MFMA is an exact k-ordered fmaf chain on gfx950 (MI355X guide), which is what the f32
 // "parity" mode relies on.
+#include <stdlib.h>
+
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -496,6 +498,16 @@ hipError_t launch_gemm_fast(const FastGemmArgs& a, hipStream_t st) {
   while (mb > 1 && ntiles * ((a.M + 16 * mb - 1) / (16 * mb)) < 256) mb >>= 1;
   if (a.M <= 16) mb = 1; else if (a.M <= 32 && mb > 2) mb = 2;
   if (a.force_mb) mb = a.force_mb;
+  {  // tuning hook: CTTS_MB_<epi> = 1|2|4 overrides the heuristic for that epilogue kind (read once)
+    static int env_mb[4] = {-1, -1, -1, -1};
+    if (env_mb[0] < 0) {
+      const char* names[4] = {"CTTS_MB_STORE", "CTTS_MB_RES", "CTTS_MB_SILU", "CTTS_MB_QKV"};
+      for (int i = 0; i < 4; ++i) { const char* e = getenv(names[i]); env_mb[i] = e ? atoi(e) : 0; }
+    }
+    int e = env_mb[a.epi & 3];
+    if (a.epi == FEPI_RES && a.K == 3072) { static int dn = -1; if (dn < 0) { const char* v = getenv("CTTS_MB_DOWN"); dn = v ? atoi(v) : 0; } e = dn; }
+    if ((e == 1 || e == 2 || e == 4) && a.M > 16 * (e / 2)) mb = e;
+  }
   if (mb == 1) return fast_dispatch<1>(a, st);
   if (mb == 2) return fast_dispatch<2>(a, st);
   return fast_dispatch<4>(a, st);

@@ -159,8 +159,9 @@ __global__ __launch_bounds__(64 * NW) void attention_k(const float* __restrict__
   constexpr int DPL = KTraits<KT>::DPL;
   constexpr int LPK = HDIM / DPL;   // lanes per key: 8 (bf16) / 16 (f32)
   constexpr int KPI = 64 / LPK;     // keys per load instruction: 8 / 4
-  constexpr int NI = 8;             // load instructions per block
-  constexpr int KB = KPI * NI;      // keys per wave-block: 64 / 32
+  constexpr int NI = 4;             // load instructions per block and operand (K and V): 8 loads per block in flight,
+                                    // and the NEXT block's 8 are issued before the current block is consumed
+  constexpr int KB = KPI * NI;      // keys per wave-block: 32 / 16
   __shared__ float sm_m[NW], sm_l[NW], sm_acc[NW][HDIM];
 
   const int h = blockIdx.x, m = blockIdx.y;
@@ -185,36 +186,35 @@ __global__ __launch_bounds__(64 * NW) void attention_k(const float* __restrict__
   for (int i = 0; i < DPL; ++i) acc[i] = 0.f;
 
   // each wave owns one contiguous, KPI-aligned share of the visible keys (balanced: a context of n
-  // keys costs every wave ceil(n / NW / KB) rounds instead of giving wave 0 the remainder blocks)
+  // keys costs every wave ceil(n / NW / KB) blocks instead of giving wave 0 the remainder blocks)
   const int nkeys = slot - jlo + 1;
   const int per = ((nkeys + NW - 1) / NW + KPI - 1) / KPI * KPI;
   const int jbeg = jlo + wave * per;
   const int jend = min(jbeg + per, slot + 1);  // exclusive
-  for (int j0 = jbeg; j0 < jend; j0 += KB) {
-    u128 kr[NI], vr[NI];
-    bool ok[NI];
+
+  u128 kA[NI], vA[NI], kB[NI], vB[NI];
+  // Loads are UNCONDITIONAL with the key index clamped into the wave's range: a per-lane `if (j < jend) load`
+  // makes hipcc branch around every load and wait vmcnt(0) in between (one memory round trip per load).
+  // Clamped lanes re-read the last key (an L1 hit) and are masked where they are consumed.
+  const int jlast = max(jend - 1, jlo);
+  auto load_blk = [&](u128* kr, u128* vr, int j0) {
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const int j = j0 + i * KPI + kg;
-      ok[i] = j < jend;
-      if (ok[i]) kr[i] = *reinterpret_cast<const u128*>(kbase + (size_t)j * HDIM);
-    }
+    for (int i = 0; i < NI; ++i) kr[i] = *reinterpret_cast<const u128*>(kbase + (size_t)min(j0 + i * KPI + kg, jlast) * HDIM);
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const int j = j0 + i * KPI + kg;
-      if (ok[i]) vr[i] = *reinterpret_cast<const u128*>(vbase + (size_t)j * HDIM);
-    }
+    for (int i = 0; i < NI; ++i) vr[i] = *reinterpret_cast<const u128*>(vbase + (size_t)min(j0 + i * KPI + kg, jlast) * HDIM);
+  };
+  auto use_blk = [&](const u128* kr, const u128* vr, int j0) {
     float s[NI];
+    bool ok[NI];
     float bmax = -INFINITY;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
+      ok[i] = (j0 + i * KPI + kg) < jend;
       float kf[DPL];
       float d = 0.f;
-      if (ok[i]) {
-        unpack16<KT, DPL>(kr[i], kf);
+      unpack16<KT, DPL>(kr[i], kf);
 #pragma unroll
-        for (int e = 0; e < DPL; ++e) d = fmaf(q[e], kf[e], d);
-      }
+      for (int e = 0; e < DPL; ++e) d = fmaf(q[e], kf[e], d);
 #pragma unroll
       for (int o = 1; o < LPK; o <<= 1) d += __shfl_xor(d, o, 64);
       s[i] = ok[i] ? d : -INFINITY;
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(64 * NW) void attention_k(const float* __restrict__
     }
 #pragma unroll
     for (int o = LPK; o < 64; o <<= 1) bmax = fmaxf(bmax, __shfl_xor(bmax, o, 64));
-    // bmax is finite: key j0 (i = 0, kg = 0) is always < jend inside this loop
+    // bmax is finite: key j0 (i = 0, kg = 0) is always < jend for a block that is consumed
     const float mnew = fmaxf(mrun, bmax);
     const float alpha = expf(mrun - mnew);  // exp(-inf) = 0 on the first block
     lrun *= alpha;
@@ -230,17 +230,30 @@ __global__ __launch_bounds__(64 * NW) void attention_k(const float* __restrict__
     for (int e = 0; e < DPL; ++e) acc[e] *= alpha;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      if (ok[i]) {
-        const float p = expf(s[i] - mnew);
-        lrun += p;
-        float vf[DPL];
-        unpack16<KT, DPL>(vr[i], vf);
+      const float p = expf(s[i] - mnew);  // masked lanes: s = -inf -> p = 0 (their V is a finite, clamped re-read)
+      lrun += p;
+      float vf[DPL];
+      unpack16<KT, DPL>(vr[i], vf);
 #pragma unroll
-        for (int e = 0; e < DPL; ++e) acc[e] = fmaf(p, vf[e], acc[e]);
-      }
+      for (int e = 0; e < DPL; ++e) acc[e] = fmaf(p, vf[e], acc[e]);
     }
     mrun = mnew;
+  };
+
+  int j = jbeg;
+  load_blk(kA, vA, j);
+  while (j < jend) {
+    load_blk(kB, vB, j + KB);   // prefetch (clamped, so harmless past the end)
+    __builtin_amdgcn_sched_barrier(0);  // keep the 8 prefetch loads ahead of the consumer (hipcc sinks them otherwise)
+    use_blk(kA, vA, j);
+    j += KB;
+    if (!(j < jend)) break;
+    load_blk(kA, vA, j + KB);
+    __builtin_amdgcn_sched_barrier(0);
+    use_blk(kB, vB, j);
+    j += KB;
   }
+
   // merge the key groups of this wave (same running max in every lane)
 #pragma unroll
   for (int o = LPK; o < 64; o <<= 1) {
@@ -248,7 +261,6 @@ __global__ __launch_bounds__(64 * NW) void attention_k(const float* __restrict__
 #pragma unroll
     for (int e = 0; e < DPL; ++e) acc[e] += __shfl_xor(acc[e], o, 64);
   }
-  // lrun was accumulated identically by the LPK lanes of a key group -> it already is the per-wave sum
   if (NW == 1) {
     if (kg == 0) {
       const float inv = 1.0f / lrun;
@@ -375,8 +387,12 @@ __global__ __launch_bounds__(256) void sample_k(SampleArgs a) {
   const int grow = a.row_offset + b * NVQ + k;
   if (a.pow_table != nullptr && grow < a.max_input_ids) {
     const int nh = min(gen, 16);
-    for (int j = 0; j < nh; ++j) {
-      const int t = (int)a.ids_buf[((size_t)b * a.tcap + (len - 1 - j)) * NVQ + k];
+    // the <=16 history tokens are fetched by 16 lanes in ONE load round and broadcast (a serial loop of
+    // dependent global loads costs one L2 round trip per token)
+    const int mine = (lane < nh) ? (int)a.ids_buf[((size_t)b * a.tcap + (len - 1 - lane)) * NVQ + k] : -1;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int t = __shfl(mine, j, 64);  // -1 beyond the history: matches no vocabulary slot
 #pragma unroll
       for (int s = 0; s < SLOTS; ++s) cnt[s] += (t == s * 64 + lane) ? 1 : 0;
     }
