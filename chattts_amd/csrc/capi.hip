@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 
@@ -404,6 +405,7 @@ extern "C" int ctts_k_gemm_fast(const uint16_t* A, int32_t lda, const uint16_t* 
   memset(&f, 0, sizeof(f));
   f.A = A; f.lda = lda; f.W = W; f.M = M; f.N = N; f.K = K; f.ssq_in = ssq_in; f.eps = eps; f.epi = epi; f.C32 = C32; f.ldc = ldc;
   f.Cb = Cb; f.ldcb = ldcb; f.ssq_out = ssq_out;
+  { const char* e = getenv("CTTS_GEMM_DBG_PTR"); if (e) f.dbg = (long long*)strtoull(e, nullptr, 0); }
   CK(launch_gemm_fast(f, (hipStream_t)stream));
   return 0;
 }

@@ -309,6 +309,10 @@ void gemm_fast_k(FastGemmArgs a) {
   const int li = lane & 15, g = lane >> 4;
   const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16 * MB;
   const int M = a.M, N = a.N, K = a.K;
+  // optional phase stamps (tools/gemm_phase_probe.py): 100 MHz s_memrealtime, wave 0 lane 0 of every workgroup
+  long long* dbg = a.dbg ? a.dbg + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 : nullptr;
+#define STAMP(i) do { if (dbg && tid == 0) dbg[i] = wall_clock64(); } while (0)
+  STAMP(0);
   // ROPE tiles (weights permuted by the loader): columns 0..7 of a q/k tile are dims d0..d0+7 of one
   // head, columns 8..15 are dims d0+32..d0+39, so a rotate-half pair sits 8 lanes apart.
   const int sect = n0 / 768, hcol = n0 % 768, head = hcol >> 6, t4 = (hcol & 63) >> 4;
@@ -347,12 +351,20 @@ void gemm_fast_k(FastGemmArgs a) {
   }
 
   // epilogue operands of the finishing waves (wave mb finishes m-block mb)
-  float pre0[4] = {0.f, 0.f, 0.f, 0.f};  // RES: residual, requested before the operand loads
-  if (EPI == FEPI_RES && wave < MB) {
+  // Finishing work = 4*MB (m-block, accumulator register) pairs of 64 outputs each, dealt round-robin to the
+  // first NF waves, so the LDS reduction + epilogue of a tile is spread over up to 4 waves instead of MB.
+  constexpr int NPAIR = 4 * MB;
+  constexpr int NF = NW < 4 ? NW : 4;
+  constexpr int PPW = NPAIR / NF;        // pairs per finishing wave
+  float pre0[PPW];                        // RES: residual, requested before the operand loads
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = min(m0 + 16 * wave + 4 * g + r, M - 1);
-      pre0[r] = a.C32[(size_t)row * a.ldc + min(n0 + li, N - 1)];
+  for (int q = 0; q < PPW; ++q) pre0[q] = 0.f;
+  if (EPI == FEPI_RES && wave < NF) {
+#pragma unroll
+    for (int q = 0; q < PPW; ++q) {
+      const int p = wave + q * NF, mb = p >> 2, r = p & 3;
+      const int row = min(m0 + 16 * mb + 4 * g + r, M - 1);
+      pre0[q] = a.C32[(size_t)row * a.ldc + min(n0 + li, N - 1)];
     }
   }
 
@@ -387,6 +399,7 @@ void gemm_fast_k(FastGemmArgs a) {
     // keep every load of the round in flight: hipcc otherwise sinks the loads next to their MFMA and
     // waits vmcnt(1) per fragment (one L2/HBM round trip per MFMA pair)
     __builtin_amdgcn_sched_barrier(0);
+    if (i == 0) STAMP(1);
 #pragma unroll
     for (int j = 0; j < U; ++j)
 #pragma unroll
@@ -397,6 +410,7 @@ void gemm_fast_k(FastGemmArgs a) {
                                                                 *reinterpret_cast<const bf16x8*>(&wf[na][j]), acc[na][mb], 0, 0, 0);
   }
 
+  STAMP(2);
   if (SCALE) {
     float s = (((s0.x + s0.y) + (s0.z + s0.w)) + ((s1.x + s1.y) + (s1.z + s1.w))) + ((s2.x + s2.y) + (s2.z + s2.w));
     s += __shfl_xor(s, 1, 64);
@@ -410,11 +424,12 @@ void gemm_fast_k(FastGemmArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) red[wave][na][mb][lane][r] = acc[na][mb][r];
   __syncthreads();
-  if (wave < MB) {
-    const int mb = wave;
+  STAMP(3);
+  if (wave < NF) {
     const int col = n0 + li;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int q = 0; q < PPW; ++q) {
+      const int p = wave + q * NF, mb = p >> 2, r = p & 3;
       const int row = m0 + 16 * mb + 4 * g + r;
       float v = 0.f, u = 0.f;
 #pragma unroll
@@ -436,7 +451,7 @@ void gemm_fast_k(FastGemmArgs a) {
       } else if (EPI == FEPI_RES) {
         float xn = 0.f;
         if (ok) {
-          xn = pre0[r] + v;
+          xn = pre0[q] + v;
           a.C32[(size_t)row * a.ldc + col] = xn;
           a.Cb[(size_t)row * a.ldcb + col] = f32_to_bf16(xn);
         }
@@ -463,6 +478,8 @@ void gemm_fast_k(FastGemmArgs a) {
       }
     }
   }
+  STAMP(4);
+#undef STAMP
 }
 
 template <int MB>
@@ -493,10 +510,19 @@ hipError_t launch_gemm_fast(const FastGemmArgs& a, hipStream_t st) {
   if (a.epi == FEPI_QKV_ROPE && (a.N != 2304 || a.K != 768)) return hipErrorInvalidValue;
   // rows per workgroup: the per-workgroup latency is set by fixed round trips, not bytes, so prefer
   // enough workgroups to cover the 256 CUs over big M tiles (decode: M <= 64)
+  // measured (tools/gemm_phase_probe.py): these kernels are bound by each CU's vector-memory path, so pick
+  // the M tile that minimises  ceil(workgroups / 256 CUs) x (W tile + A tile bytes)  of the busiest CU
   const int ntiles = (a.N + 15) / 16;
-  int mb = 4;
-  while (mb > 1 && ntiles * ((a.M + 16 * mb - 1) / (16 * mb)) < 256) mb >>= 1;
-  if (a.M <= 16) mb = 1; else if (a.M <= 32 && mb > 2) mb = 2;
+  const int nacc = a.epi == FEPI_SILU ? 2 : 1;
+  int mb = 1;
+  long best = -1;
+  for (int c = 1; c <= 4; c <<= 1) {
+    if (c > 1 && a.M <= 16 * (c / 2)) break;
+    const long wgs = (long)ntiles * ((a.M + 16 * c - 1) / (16 * c));
+    const long per = (long)(16 * nacc + 16 * c) * a.K * 2;
+    const long cost = ((wgs + 255) / 256) * per;
+    if (best < 0 || cost < best) { best = cost; mb = c; }
+  }
   if (a.force_mb) mb = a.force_mb;
   {  // tuning hook: CTTS_MB_<epi> = 1|2|4 overrides the heuristic for that epilogue kind (read once)
     static int env_mb[4] = {-1, -1, -1, -1};

@@ -62,6 +62,7 @@ struct FastGemmArgs {
   const float* cos_t; const float* sin_t;                     // [max_pos, 32]
   uint16_t* kc; uint16_t* vc; int cmax;                       // this layer's bf16 K / V cache [B,12,cmax,64]
   int force_mb;                 // tests only: 0 = heuristic
+  long long* dbg;               // probes only: [n_workgroups][8] phase stamps, or null
 };
 hipError_t launch_gemm_fast(const FastGemmArgs& a, hipStream_t st);
 // x32 row -> bf16 copy + partial sums of squares (prefill entry); optional code-embedding gather
