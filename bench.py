@@ -166,8 +166,16 @@ def main():
                    8: B * (768 + 2504) * 4, 9: B * 4 * 626 * 8}.get(dom, 0)
             alg = float(wbytes + act)
         achieved = alg / (avg_ms * 1e-3) / 1e9
+        # HBM traffic per launch from the PMC counters: collected by `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`
+        # passes of THIS command (tools/gpu_round.sh pmc -> profiles/pmc_traffic.json, gfx950 FETCH x2 correction applied)
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+                traffic = json.load(fh).get(TAGS[dom], {}).get("hbm_bytes_per_launch")
+        except OSError:
+            pass
         result["roofline"] = {"kernel": TAGS[dom], "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "avg_launch_us": round(avg_ms * 1e3, 2),
+                              "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "avg_launch_us": round(avg_ms * 1e3, 2),
                               "launches_timed": n, "alg_bytes_per_launch": int(alg)}
         result["decode_kernel_ms_per_step"] = step_ms
 

@@ -34,9 +34,9 @@ for S in $STAGES; do
     pmc)
       cd /tmp
       for C in FETCH_SIZE WRITE_SIZE; do
-        timeout 900 rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/pmc_${TAG}_$C -o ${TAG}_$C -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-ttfs --max-len 160 --min-len 128 > $R/gpurun_out/${TAG}_pmc_$C.log 2>&1
-        python $R/tools/pmc_summary.py /tmp/pmc_${TAG}_$C $C > $R/gpurun_out/${TAG}_pmc_${C}_summary.txt 2>&1
+        timeout 900 rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/pmc_${TAG}_$C -o ${TAG}_$C -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-ttfs > $R/gpurun_out/${TAG}_pmc_$C.log 2>&1
       done
+      python $R/tools/pmc_summary.py /tmp/pmc_${TAG}_FETCH_SIZE /tmp/pmc_${TAG}_WRITE_SIZE $R/gpurun_out/${TAG}_pmc_traffic.json > $R/gpurun_out/${TAG}_pmc_summary.txt 2>&1
       cd "$R" ;;
   esac
 done

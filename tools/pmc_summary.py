@@ -1,30 +1,53 @@
-"""Summarise a rocprofv3 --pmc CSV run: per kernel name, dispatch count and mean counter value."""
+"""Summarise rocprofv3 --pmc CSV runs: per kernel name, dispatch count and mean counter value.
+usage: pmc_summary.py <dir_FETCH_SIZE> <dir_WRITE_SIZE> <out.json>
+FETCH_SIZE / WRITE_SIZE are reported in KiB; on gfx950 FETCH_SIZE reads exactly half of the bytes a
+wide coalesced stream fetches (MI355X_MICROARCH.md, HBM section), so read bytes = 2 * FETCH_SIZE * 1024."""
 import csv
 import glob
+import json
 import os
 import sys
 from collections import defaultdict
 
 
-def main(root, counter):
-    files = glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True)
-    if not files:
-        print("no counter_collection.csv under", root)
-        return
+def collect(root, counter):
     acc = defaultdict(lambda: [0, 0.0])
-    for f in files:
+    for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
         with open(f) as fh:
             for row in csv.DictReader(fh):
                 if row.get("Counter_Name") != counter:
                     continue
-                k = row.get("Kernel_Name", "?")[:90]
-                a = acc[k]
+                a = acc[row.get("Kernel_Name", "?")]
                 a[0] += 1
                 a[1] += float(row.get("Counter_Value", 0) or 0)
-    print(f"{counter}: kernel, dispatches, mean value per dispatch (FETCH_SIZE/WRITE_SIZE are in KiB; gfx950: double FETCH_SIZE)")
-    for k, (n, tot) in sorted(acc.items(), key=lambda kv: -kv[1][1]):
-        print(f"{k:90s} {n:8d} {tot / max(n, 1):14.2f}")
+    return acc
+
+
+def short(name):
+    for key, tag in (("attention_k", "attention"), ("gemm_fast_k<2, 4, true, 3>", "qkv_gemm"), ("gemm_fast_k<4, 4, true, 3>", "qkv_gemm"),
+                     ("gemm_fast_k<1, 4, false, 1>", "o_proj_gemm"), ("true, 2>", "gate_up_gemm"), ("gemm_fast_k<1, 16, false, 1>", "down_gemm"),
+                     ("gemm_skinny_k<float", "heads_gemm"), ("sample_k", "sample")):
+        if key in name:
+            return tag
+    return None
+
+
+def main(d_fetch, d_write, out):
+    fe, wr = collect(d_fetch, "FETCH_SIZE"), collect(d_write, "WRITE_SIZE")
+    res = {}
+    print("kernel, dispatches, mean FETCH_SIZE KiB, mean WRITE_SIZE KiB, HBM bytes/launch (2*FETCH+WRITE)")
+    for k, (n, tot) in sorted(fe.items(), key=lambda kv: -kv[1][1]):
+        f = tot / max(n, 1)
+        w = wr.get(k, [0, 0.0])
+        wv = w[1] / max(w[0], 1)
+        hbm = int((2 * f + wv) * 1024)
+        print(f"{k[:80]:80s} {n:7d} {f:12.1f} {wv:12.1f} {hbm:14d}")
+        tag = short(k)
+        if tag and (tag not in res or n > res[tag]["dispatches"]):
+            res[tag] = {"dispatches": n, "fetch_kib_mean": round(f, 2), "write_kib_mean": round(wv, 2), "hbm_bytes_per_launch": hbm}
+    with open(out, "w") as fh:
+        json.dump(res, fh, indent=1)
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(*sys.argv[1:4])
