@@ -103,7 +103,8 @@ int ctts_gpt_graph_launch(ctts_gpt* g, int32_t n_steps, void* stream);
 void ctts_gpt_graph_destroy(ctts_gpt* g);
 
 /* HIP-event timing of one launch site (tag) of the eager decode step, for bench.py's roofline leg.
- * tags: 0 embed, 1 qkv, 2 rope_append, 3 attention, 4 o_proj, 5 gate_up, 6 down, 7 final_norm, 8 heads, 9 sample */
+ * tags: 0 embed, 1 qkv, 2 rope_append, 3 attention, 4 o_proj, 5 gate_up, 6 down, 7 final_norm, 8 heads, 9 sample,
+ * 99 = an empty event pair once per step (the measurement overhead itself) */
 int ctts_gpt_profile_begin(ctts_gpt* g, int32_t tag, int32_t max_samples, int32_t stride /* time every stride-th launch */);
 int ctts_gpt_profile_end(ctts_gpt* g, int32_t* n_samples, double* total_ms);
 

@@ -187,3 +187,27 @@ def test_full_size_properties(gpt_bf16, codec):
                                   total_rows=B * 4))[-1]
     same = sum(int(torch.equal(out.ids[8 + i], out2.ids[i])) for i in range(8))
     assert same == 8, same
+
+
+def test_chat_facade_stream_and_batch(weights):
+    """`Chat.infer_ids` / `infer_ids_stream` (mirrors of core.py:469-503): chunk schedule and shapes"""
+    from chattts_amd.core import Chat, InferCodeParams
+    chat = Chat()
+    assert chat.load(state_dicts=weights, device=DEV, dtype="bf16") and chat.has_loaded()
+    ids, mask, tmask = synth.make_prompts(4, 8, 12, seed=3)
+    stop = torch.tensor([100, 60, 30, 100], dtype=torch.int32)
+    p = InferCodeParams(max_new_token=128, manual_seed=5, show_tqdm=False)
+    args = (torch.from_numpy(ids), torch.from_numpy(mask), torch.from_numpy(tmask), p)
+    wav = chat.infer_ids(*args, stop_at=stop)
+    assert wav.dtype == np.float32 and wav.shape == (4, 256 * (2 * 100 - 1)) and np.isfinite(wav).all()
+    chunks = list(chat.infer_ids_stream(*args, stop_at=stop))
+    # yields at 24, 48, 72, 96 tokens: the first two are dropped (pass_first_n_batches=2), then 12000 samples
+    # per yield (stream_speed), then the remainder with silent columns removed (core.py:488-503)
+    assert [c.shape[1] for c in chunks[:2]] == [12000, 12000]
+    assert len(chunks) == 3 and chunks[2].shape[1] <= wav.shape[1] - 24000
+    assert all(c.shape[0] == 4 and np.isfinite(c).all() for c in chunks)
+    chat.interrupt()
+    out = list(chat.infer_code(*args[:3], p, stop_at=stop))  # interrupted before the first poll completes a chunk
+    assert len(out) == 1 and max(int(t.shape[0]) for t in out[0].ids) <= 16
+    chat.unload()
+    assert not chat.has_loaded()
