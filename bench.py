@@ -145,7 +145,10 @@ def main():
         per_tag = {}
         one_pass(use_graph=False, profile_tag=99, profile_stride=1, decode_audio=False)
         n0, t0_ = gpt.last_stats.get("profile", (0, 0.0))
-        pair_overhead_ms = t0_ / max(1, n0)   # an event pair around nothing: subtracted from every timed launch
+        # An event pair around a no-op kernel costs (marker overhead + one kernel boundary); a kernel boundary inside
+        # the graph-replayed timed region is 1.6 us (tools/launch_floor.hip, profiles/r1_launch_floor.log), so
+        # marker overhead = pair(noop) - 1.6 us, subtracted from every event-timed launch.
+        pair_overhead_ms = max(0.0, t0_ / max(1, n0) - 1.6e-3)
         for tag in (1, 3, 4, 5, 6, 8, 9):
             calls = 1 if tag in (8, 9) else GPT.n_layers
             stride = 1 if calls == 1 else 5

@@ -514,3 +514,9 @@ hipError_t launch_sample(const SampleArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(sample_k, dim3(a.B), dim3(256), 0, st, a);
   return hipGetLastError();
 }
+
+__global__ void noop_k() {}
+hipError_t launch_noop(hipStream_t st) {
+  hipLaunchKernelGGL(noop_k, dim3(1), dim3(64), 0, st);
+  return hipGetLastError();
+}

@@ -108,6 +108,7 @@ struct SampleArgs {
   int B;
 };
 hipError_t launch_sample(const SampleArgs& a, hipStream_t st);
+hipError_t launch_noop(hipStream_t st);  // empty kernel (timing calibration)
 
 // ---- codec kernels (channels-last [B, F, C]) ---------------------------------------------------
 hipError_t launch_dwconv_ln(const float* x, const float* w /*[C,7]*/, const float* b, const float* ln_w, const float* ln_b,

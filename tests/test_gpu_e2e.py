@@ -201,10 +201,11 @@ def test_chat_facade_stream_and_batch(weights):
     wav = chat.infer_ids(*args, stop_at=stop)
     assert wav.dtype == np.float32 and wav.shape == (4, 256 * (2 * 100 - 1)) and np.isfinite(wav).all()
     chunks = list(chat.infer_ids_stream(*args, stop_at=stop))
-    # yields at 24, 48, 72, 96 tokens: the first two are dropped (pass_first_n_batches=2), then 12000 samples
-    # per yield (stream_speed), then the remainder with silent columns removed (core.py:488-503)
-    assert [c.shape[1] for c in chunks[:2]] == [12000, 12000]
-    assert len(chunks) == 3 and chunks[2].shape[1] <= wav.shape[1] - 24000
+    # generator yields at 24, 48, 72, 96 tokens + the final result: the first two are dropped
+    # (pass_first_n_batches=2), each later one emits the next 12000 samples (stream_speed), then the remainder
+    # with silent columns removed (core.py:488-503)
+    assert [c.shape[1] for c in chunks[:3]] == [12000, 12000, 12000]
+    assert len(chunks) == 4 and chunks[3].shape[1] <= wav.shape[1] - 36000
     assert all(c.shape[0] == 4 and np.isfinite(c).all() for c in chunks)
     chat.interrupt()
     out = list(chat.infer_code(*args[:3], p, stop_at=stop))  # interrupted before the first poll completes a chunk
