@@ -139,22 +139,15 @@ def main():
                    "tokens_per_pass": int(stop.sum()), "audio_s_per_pass": round(audio_seconds(stop), 2)},
     }
 
-    # ---- roofline of the dominant decode kernel: HIP events around sampled launches, on the launch stream,
+    # ---- roofline of the dominant decode kernel: HIP start/stop events of sampled launches (hipExtLaunchKernel, on the launch stream),
     #      in an eager pass of the SAME workload (every 5th launch of the tag over all decode steps) ----
     if rank == 0 and not args.no_roofline:
         per_tag = {}
-        one_pass(use_graph=False, profile_tag=99, profile_stride=1, decode_audio=False)
-        n0, t0_ = gpt.last_stats.get("profile", (0, 0.0))
-        # An event pair around a no-op kernel costs (marker overhead + one kernel boundary); a kernel boundary inside
-        # the graph-replayed timed region is 1.6 us (tools/launch_floor.hip, profiles/r1_launch_floor.log), so
-        # marker overhead = pair(noop) - 1.6 us, subtracted from every event-timed launch.
-        pair_overhead_ms = max(0.0, t0_ / max(1, n0) - 1.6e-3)
         for tag in (1, 3, 4, 5, 6, 8, 9):
             calls = 1 if tag in (8, 9) else GPT.n_layers
             stride = 1 if calls == 1 else 5
             one_pass(use_graph=False, profile_tag=tag, profile_stride=stride, decode_audio=False)
-            n_, t_ = gpt.last_stats.get("profile", (0, 0.0))
-            per_tag[tag] = (n_, max(0.0, t_ - n_ * pair_overhead_ms))
+            per_tag[tag] = gpt.last_stats.get("profile", (0, 0.0))
         calls_per_step = {t: (1 if t in (8, 9) else GPT.n_layers) for t in per_tag}
         step_ms = {TAGS[t]: round(per_tag[t][1] / max(1, per_tag[t][0]) * calls_per_step[t], 4) for t in per_tag}
         dom = max(per_tag, key=lambda t: per_tag[t][1] / max(1, per_tag[t][0]) * calls_per_step[t])
@@ -185,8 +178,7 @@ def main():
             pass
         result["roofline"] = {"kernel": TAGS[dom], "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "avg_launch_us": round(avg_ms * 1e3, 2),
-                              "launches_timed": n, "alg_bytes_per_launch": int(alg),
-                              "event_pair_overhead_us": round(pair_overhead_ms * 1e3, 2)}
+                              "launches_timed": n, "alg_bytes_per_launch": int(alg)}
         result["decode_kernel_ms_per_step"] = step_ms
 
     # ---- time to first sample: stream=True with the reference's yield schedule (first audio after 3 x 24 tokens) ----

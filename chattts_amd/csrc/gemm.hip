@@ -168,10 +168,10 @@ template <typename WT, int MB>
 static hipError_t skinny_dispatch(const GemmArgs& a, hipStream_t st) {
   dim3 grid((a.N + 15) / 16, (a.M + 16 * MB - 1) / (16 * MB)), block(256);
   const bool rms = a.norm_w != nullptr;
-  if (a.epi == EPI_STORE && rms) hipLaunchKernelGGL((gemm_skinny_k<WT, MB, true, EPI_STORE>), grid, block, 0, st, a);
-  else if (a.epi == EPI_STORE) hipLaunchKernelGGL((gemm_skinny_k<WT, MB, false, EPI_STORE>), grid, block, 0, st, a);
-  else if (a.epi == EPI_RES && !rms) hipLaunchKernelGGL((gemm_skinny_k<WT, MB, false, EPI_RES>), grid, block, 0, st, a);
-  else if (a.epi == EPI_SILU_MUL && rms) hipLaunchKernelGGL((gemm_skinny_k<WT, MB, true, EPI_SILU_MUL>), grid, block, 0, st, a);
+  if (a.epi == EPI_STORE && rms) CTTS_LAUNCH((gemm_skinny_k<WT, MB, true, EPI_STORE>), grid, block, st, a);
+  else if (a.epi == EPI_STORE) CTTS_LAUNCH((gemm_skinny_k<WT, MB, false, EPI_STORE>), grid, block, st, a);
+  else if (a.epi == EPI_RES && !rms) CTTS_LAUNCH((gemm_skinny_k<WT, MB, false, EPI_RES>), grid, block, st, a);
+  else if (a.epi == EPI_SILU_MUL && rms) CTTS_LAUNCH((gemm_skinny_k<WT, MB, true, EPI_SILU_MUL>), grid, block, st, a);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }
@@ -278,12 +278,12 @@ hipError_t launch_gemm_tiled(const GemmArgs& a, hipStream_t st) {
   if (a.taps > 1 && (a.cin % 4 != 0 || a.K != a.taps * a.cin)) return hipErrorInvalidValue;
   dim3 grid((a.N + 63) / 64, (a.M + 63) / 64), block(256);
   switch (a.epi) {
-    case EPI_STORE: hipLaunchKernelGGL((gemm_tiled_f32_k<EPI_STORE>), grid, block, 0, st, a); break;
-    case EPI_RES: hipLaunchKernelGGL((gemm_tiled_f32_k<EPI_RES>), grid, block, 0, st, a); break;
-    case EPI_BIAS: hipLaunchKernelGGL((gemm_tiled_f32_k<EPI_BIAS>), grid, block, 0, st, a); break;
-    case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm_tiled_f32_k<EPI_BIAS_GELU>), grid, block, 0, st, a); break;
-    case EPI_BIAS_SCALE_RES: hipLaunchKernelGGL((gemm_tiled_f32_k<EPI_BIAS_SCALE_RES>), grid, block, 0, st, a); break;
-    case EPI_SCALE: hipLaunchKernelGGL((gemm_tiled_f32_k<EPI_SCALE>), grid, block, 0, st, a); break;
+    case EPI_STORE: CTTS_LAUNCH((gemm_tiled_f32_k<EPI_STORE>), grid, block, st, a); break;
+    case EPI_RES: CTTS_LAUNCH((gemm_tiled_f32_k<EPI_RES>), grid, block, st, a); break;
+    case EPI_BIAS: CTTS_LAUNCH((gemm_tiled_f32_k<EPI_BIAS>), grid, block, st, a); break;
+    case EPI_BIAS_GELU: CTTS_LAUNCH((gemm_tiled_f32_k<EPI_BIAS_GELU>), grid, block, st, a); break;
+    case EPI_BIAS_SCALE_RES: CTTS_LAUNCH((gemm_tiled_f32_k<EPI_BIAS_SCALE_RES>), grid, block, st, a); break;
+    case EPI_SCALE: CTTS_LAUNCH((gemm_tiled_f32_k<EPI_SCALE>), grid, block, st, a); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -487,16 +487,16 @@ static hipError_t fast_dispatch(const FastGemmArgs& a, hipStream_t st) {
   dim3 grid((a.N + 15) / 16, (a.M + 16 * MB - 1) / (16 * MB));
   const bool scale = a.ssq_in != nullptr;
   if (a.K == 768) {
-    if (a.epi == FEPI_STORE32 && scale) hipLaunchKernelGGL((gemm_fast_k<MB, 4, true, FEPI_STORE32>), grid, dim3(256), 0, st, a);
-    else if (a.epi == FEPI_QKV_ROPE && scale) hipLaunchKernelGGL((gemm_fast_k<MB, 4, true, FEPI_QKV_ROPE>), grid, dim3(320), 0, st, a);
-    else if (a.epi == FEPI_SILU && scale) hipLaunchKernelGGL((gemm_fast_k<MB, 4, true, FEPI_SILU>), grid, dim3(256), 0, st, a);
-    else if (a.epi == FEPI_RES && !scale) hipLaunchKernelGGL((gemm_fast_k<MB, 4, false, FEPI_RES>), grid, dim3(256), 0, st, a);
+    if (a.epi == FEPI_STORE32 && scale) CTTS_LAUNCH((gemm_fast_k<MB, 4, true, FEPI_STORE32>), grid, dim3(256), st, a);
+    else if (a.epi == FEPI_QKV_ROPE && scale) CTTS_LAUNCH((gemm_fast_k<MB, 4, true, FEPI_QKV_ROPE>), grid, dim3(320), st, a);
+    else if (a.epi == FEPI_SILU && scale) CTTS_LAUNCH((gemm_fast_k<MB, 4, true, FEPI_SILU>), grid, dim3(256), st, a);
+    else if (a.epi == FEPI_RES && !scale) CTTS_LAUNCH((gemm_fast_k<MB, 4, false, FEPI_RES>), grid, dim3(256), st, a);
     else return hipErrorInvalidValue;
   } else if (a.K == 3072) {
     if (a.epi == FEPI_RES && !scale) {
       // one load round per wave when the tile is a single m-block (decode): 16 waves x 6 chunks = K
-      if (MB == 1) hipLaunchKernelGGL((gemm_fast_k<1, 16, false, FEPI_RES>), grid, dim3(1024), 0, st, a);
-      else hipLaunchKernelGGL((gemm_fast_k<MB, 8, false, FEPI_RES>), grid, dim3(512), 0, st, a);
+      if (MB == 1) CTTS_LAUNCH((gemm_fast_k<1, 16, false, FEPI_RES>), grid, dim3(1024), st, a);
+      else CTTS_LAUNCH((gemm_fast_k<MB, 8, false, FEPI_RES>), grid, dim3(512), st, a);
     } else return hipErrorInvalidValue;
   } else {
     return hipErrorInvalidValue;

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(192) void embed_codes_k(const float* __restrict__ e
 
 hipError_t launch_embed_codes(const float* emb_code, const int64_t* ids_buf, int tcap, const int32_t* len, float* x, uint16_t* xb,
                               float* ssq, int B, hipStream_t st) {
-  hipLaunchKernelGGL(embed_codes_k, dim3(B), dim3(192), 0, st, emb_code, ids_buf, tcap, len, x, xb, ssq);
+  CTTS_LAUNCH(embed_codes_k, dim3(B), dim3(192), st, emb_code, ids_buf, tcap, len, x, xb, ssq);
   return hipGetLastError();
 }
 
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(192) void rows_prep_k(const float* __restrict__ x, 
 }
 
 hipError_t launch_rows_prep(const float* x32, uint16_t* xb, float* ssq, int M, hipStream_t st) {
-  hipLaunchKernelGGL(rows_prep_k, dim3(M), dim3(192), 0, st, x32, xb, ssq);
+  CTTS_LAUNCH(rows_prep_k, dim3(M), dim3(192), st, x32, xb, ssq);
   return hipGetLastError();
 }
 
@@ -117,10 +117,10 @@ __global__ __launch_bounds__(384) void rope_append_k(float* __restrict__ qkv, KT
 hipError_t launch_rope_append(float* qkv, void* kcache, void* vcache, int kv_wt, int cmax, const float* cos_tab,
                               const float* sin_tab, GptRowMap rm, int M, hipStream_t st) {
   if (kv_wt == WT_BF16)
-    hipLaunchKernelGGL((rope_append_k<bf16_t>), dim3(M), dim3(384), 0, st, qkv, (bf16_t*)kcache, (bf16_t*)vcache, cmax, cos_tab,
+    CTTS_LAUNCH((rope_append_k<bf16_t>), dim3(M), dim3(384), st, qkv, (bf16_t*)kcache, (bf16_t*)vcache, cmax, cos_tab,
                        sin_tab, rm);
   else
-    hipLaunchKernelGGL((rope_append_k<float>), dim3(M), dim3(384), 0, st, qkv, (float*)kcache, (float*)vcache, cmax, cos_tab,
+    CTTS_LAUNCH((rope_append_k<float>), dim3(M), dim3(384), st, qkv, (float*)kcache, (float*)vcache, cmax, cos_tab,
                        sin_tab, rm);
   return hipGetLastError();
 }
@@ -295,7 +295,7 @@ hipError_t launch_attention(const float* qkv, const void* kcache, const void* vc
                             GptRowMap rm, int M, hipStream_t st) {
   dim3 grid(NHEAD, M);
   const bool decode = rm.q_per_b == 1;
-#define ATT(KT, NW, OT) hipLaunchKernelGGL((attention_k<KT, NW, OT>), grid, dim3(64 * NW), 0, st, qkv, (const KT*)kcache, (const KT*)vcache, cmax, (OT*)out, rm)
+#define ATT(KT, NW, OT) CTTS_LAUNCH((attention_k<KT, NW, OT>), grid, dim3(64 * NW), st, qkv, (const KT*)kcache, (const KT*)vcache, cmax, (OT*)out, rm)
   if (kv_wt == WT_BF16) {
     if (out_bf16) { if (decode) ATT(bf16_t, 4, bf16_t); else ATT(bf16_t, 1, bf16_t); }
     else { if (decode) ATT(bf16_t, 4, float); else ATT(bf16_t, 1, float); }
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(192) void final_norm_k(const float* __restrict__ x,
 
 hipError_t launch_final_norm(const float* x, int q_per_b, const float* w, float eps, float* hfin, float* hiddens, int max_new,
                              const int32_t* len, int T, int B, hipStream_t st) {
-  hipLaunchKernelGGL(final_norm_k, dim3(B), dim3(192), 0, st, x, q_per_b, w, eps, hfin, hiddens, max_new, len, T);
+  CTTS_LAUNCH(final_norm_k, dim3(B), dim3(192), st, x, q_per_b, w, eps, hfin, hiddens, max_new, len, T);
   return hipGetLastError();
 }
 
@@ -511,12 +511,7 @@ __global__ __launch_bounds__(256) void sample_k(SampleArgs a) {
 }
 
 hipError_t launch_sample(const SampleArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL(sample_k, dim3(a.B), dim3(256), 0, st, a);
+  CTTS_LAUNCH(sample_k, dim3(a.B), dim3(256), st, a);
   return hipGetLastError();
 }
 
-__global__ void noop_k() {}
-hipError_t launch_noop(hipStream_t st) {
-  hipLaunchKernelGGL(noop_k, dim3(1), dim3(64), 0, st);
-  return hipGetLastError();
-}

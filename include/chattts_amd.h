@@ -102,9 +102,9 @@ int ctts_gpt_graph_build(ctts_gpt* g, const ctts_gen_state* s, void* stream);
 int ctts_gpt_graph_launch(ctts_gpt* g, int32_t n_steps, void* stream);
 void ctts_gpt_graph_destroy(ctts_gpt* g);
 
-/* HIP-event timing of one launch site (tag) of the eager decode step, for bench.py's roofline leg.
- * tags: 0 embed, 1 qkv, 2 rope_append, 3 attention, 4 o_proj, 5 gate_up, 6 down, 7 final_norm, 8 heads, 9 sample,
- * 99 = an empty event pair once per step (the measurement overhead itself) */
+/* Per-kernel timing of one launch site (tag) of the eager decode step, for bench.py's roofline leg: the
+ * launch goes through hipExtLaunchKernel with start/stop events (dispatch timestamps, as rocprofv3 reads them).
+ * tags: 0 embed, 1 qkv, 2 rope_append, 3 attention, 4 o_proj, 5 gate_up, 6 down, 7 final_norm, 8 heads, 9 sample */
 int ctts_gpt_profile_begin(ctts_gpt* g, int32_t tag, int32_t max_samples, int32_t stride /* time every stride-th launch */);
 int ctts_gpt_profile_end(ctts_gpt* g, int32_t* n_samples, double* total_ms);
 
