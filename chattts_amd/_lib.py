@@ -49,6 +49,7 @@ class CodecWeights(C.Structure):
         ("v_dw_w", PP), ("v_dw_b", PP), ("v_ln_w", PP), ("v_ln_b", PP), ("v_pw1_w", PP), ("v_pw1_b", PP),
         ("v_pw2_w", PP), ("v_pw2_b", PP), ("v_gamma", PP),
         ("v_final_w", P), ("v_final_b", P), ("head_w", P), ("head_b", P), ("window", P), ("twiddle", P),
+        ("gemm_mode", C.c_int32),
     ]
 
 

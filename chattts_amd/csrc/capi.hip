@@ -327,24 +327,30 @@ static GemmArgs lin(const float* A, int lda, const float* W, float* C, int ldc, 
   a.A = A; a.lda = lda; a.W = W; a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.wt = WT_F32; a.epi = epi; a.taps = 1;
   return a;
 }
+// dense layer of the decoder: f32 MFMA tiles, or split-bf16 tiles when the weights were packed [2][N][Kp] bf16
+static hipError_t dense(const ctts_codec* c, const GemmArgs& a, hipStream_t st);
 static GemmArgs conv(const float* X, int cin, const float* W, float* C, int cout, int B, int F, int taps, int pad, int epi) {
   GemmArgs a = lin(X, cin, W, C, cout, B * F, cout, taps * cin, epi);
   a.taps = taps; a.cin = cin; a.frames = F; a.pad = pad; a.dil = 1;
   return a;
 }
 
-static int convnext_stack(int n, std::vector<const float*>* p, int inter, int dil, CodecWs& ws, int B, int F, hipStream_t st) {
+static int convnext_stack(const ctts_codec* c, int n, const std::vector<const float*>* p, int inter, int dil, CodecWs& ws, int B, int F, hipStream_t st) {
   const int R = B * F;
   for (int i = 0; i < n; ++i) {
     CK(launch_dwconv_ln(ws.a, p[0][i], p[1][i], p[2][i], p[3][i], 1e-6f, dil, ws.b, B, F, 512, st));
     GemmArgs g1 = lin(ws.b, 512, p[4][i], ws.big, inter, R, inter, 512, EPI_BIAS_GELU);
     g1.bias = p[5][i];
-    CK(launch_gemm_tiled(g1, st));
+    CK(dense(c, g1, st));
     GemmArgs g2 = lin(ws.big, inter, p[6][i], ws.a, 512, R, 512, inter, EPI_BIAS_SCALE_RES);
     g2.bias = p[7][i]; g2.gamma = p[8][i]; g2.res = ws.a; g2.ldr = 512;
-    CK(launch_gemm_tiled(g2, st));
+    CK(dense(c, g2, st));
   }
   return 0;
+}
+
+static hipError_t dense(const ctts_codec* c, const GemmArgs& a, hipStream_t st) {
+  return c->w.gemm_mode == 1 ? launch_gemm_tiled_bf16x3(a, st) : launch_gemm_tiled(a, st);
 }
 
 extern "C" int ctts_dvae_decode(ctts_codec* c, const float* hid, float* mel, int32_t B, int32_t T, void* workspace, size_t ws_bytes,
@@ -357,15 +363,15 @@ extern "C" int ctts_dvae_decode(ctts_codec* c, const float* hid, float* mel, int
   // dvae.py:281-287: [B,T,768] viewed as [B,2T,384] channels-last
   GemmArgs c0 = conv(hid, 384, c->w.conv_in0_w, ws.big, 128, B, F, 3, 1, EPI_BIAS_GELU);
   c0.bias = c->w.conv_in0_b;
-  CK(launch_gemm_tiled(c0, st));
+  CK(dense(c, c0, st));
   GemmArgs c2 = conv(ws.big, 128, c->w.conv_in2_w, ws.a, 512, B, F, 3, 1, EPI_BIAS);
   c2.bias = c->w.conv_in2_b;
-  CK(launch_gemm_tiled(c2, st));
-  if (convnext_stack(c->w.n_dvae_blocks, c->d, 2048, 2, ws, B, F, st)) return -1;
-  CK(launch_gemm_tiled(lin(ws.a, 512, c->w.conv_out_w, ws.mid, 384, B * F, 384, 512, EPI_STORE), st));
+  CK(dense(c, c2, st));
+  if (convnext_stack(c, c->w.n_dvae_blocks, c->d, 2048, 2, ws, B, F, st)) return -1;
+  CK(dense(c, lin(ws.a, 512, c->w.conv_out_w, ws.mid, 384, B * F, 384, 512, EPI_STORE), st));
   GemmArgs oc = conv(ws.mid, 384, c->w.out_conv_w, mel, 100, B, F, 3, 1, EPI_SCALE);
   oc.gamma = c->w.coef;
-  CK(launch_gemm_tiled(oc, st));
+  CK(dense(c, oc, st));
   return 0;
 }
 
@@ -377,13 +383,13 @@ extern "C" int ctts_vocos_decode(ctts_codec* c, const float* mel, float* wav, in
   CodecWs ws = carve_codec(workspace, B, F);
   GemmArgs e = conv(mel, 100, c->w.v_embed_w, ws.b, 512, B, F, 7, 3, EPI_BIAS);
   e.bias = c->w.v_embed_b;
-  CK(launch_gemm_tiled(e, st));
+  CK(dense(c, e, st));
   CK(launch_layernorm(ws.b, c->w.v_norm_w, c->w.v_norm_b, 1e-6f, ws.a, B * F, 512, st));
-  if (convnext_stack(c->w.n_vocos_blocks, c->v, 1536, 1, ws, B, F, st)) return -1;
+  if (convnext_stack(c, c->w.n_vocos_blocks, c->v, 1536, 1, ws, B, F, st)) return -1;
   CK(launch_layernorm(ws.a, c->w.v_final_w, c->w.v_final_b, 1e-6f, ws.b, B * F, 512, st));
   GemmArgs h = lin(ws.b, 512, c->w.head_w, ws.big, 1026, B * F, 1026, 512, EPI_BIAS);
   h.bias = c->w.head_b;
-  CK(launch_gemm_tiled(h, st));
+  CK(dense(c, h, st));
   CK(launch_istft(ws.big, c->w.window, c->w.twiddle, ws.frames, wav, B, F, st));
   return 0;
 }
@@ -400,7 +406,7 @@ extern "C" int ctts_k_gemm(int32_t tiled, const float* A, const void* W, float* 
   a.A = A; a.W = W; a.C = C; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldc = ldc; a.wt = wt; a.epi = epi; a.norm_w = norm_w; a.eps = eps;
   a.res = res; a.ldr = ldr; a.bias = bias; a.gamma = gamma; a.taps = taps > 0 ? taps : 1; a.cin = cin; a.frames = frames; a.pad = pad;
   a.dil = dil;
-  CK(tiled ? launch_gemm_tiled(a, (hipStream_t)stream) : launch_gemm_skinny(a, (hipStream_t)stream));
+  CK(tiled == 2 ? launch_gemm_tiled_bf16x3(a, (hipStream_t)stream) : tiled ? launch_gemm_tiled(a, (hipStream_t)stream) : launch_gemm_skinny(a, (hipStream_t)stream));
   return 0;
 }
 extern "C" int ctts_k_gemm_fast(const uint16_t* A, int32_t lda, const uint16_t* W, int32_t M, int32_t N, int32_t K, const float* ssq_in,

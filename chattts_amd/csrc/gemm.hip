@@ -538,3 +538,145 @@ hipError_t launch_gemm_fast(const FastGemmArgs& a, hipStream_t st) {
   if (mb == 2) return fast_dispatch<2>(a, st);
   return fast_dispatch<4>(a, st);
 }
+
+// ------------------------------------------------------------------------------------------------
+// tiled, split-bf16 ("bf16x3"): near-f32 accuracy at the bf16 MFMA rate for the acoustic decoder's
+// dense layers.  Every f32 operand x is written as x = hi + lo with hi = bf16(x), lo = bf16(x - hi)
+// (residual <= 2^-17 |x|), and a.w ~= a_hi w_hi + a_hi w_lo + a_lo w_hi (the dropped lo.lo term is
+// <= 2^-16 relative), three v_mfma_f32_32x32x16_bf16 per product, f32 accumulation.  Weights are split
+// once at load ([2][N][Kp] bf16: hi plane then lo plane, K zero-padded to a multiple of 32), activations
+// are split while they are staged into LDS.  128x128x32 tile, 4 waves as 2x2, each wave 2x2 MFMA blocks.
+// f32-input MFMA peaks at 157 TF on gfx950 and the f32 tiled kernel above already runs at ~115 TF, so
+// this is the only way to make the 157 MFLOP/token decoder cheaper without giving up the 1e-4 RMS bar.
+// ------------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_tiled_bf16x3_k(GemmArgs a) {
+  constexpr int BM = 128, BN = 128, BK = 32, LD = 40;  // LD: 80-byte rows -> conflict-free ds_read_b128 of the fragments
+  __shared__ __attribute__((aligned(16))) uint16_t Ah[BM][LD], Al[BM][LD], Wh[BN][LD], Wl[BN][LD];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int M = a.M, N = a.N, K = a.K;
+  const int Kp = (K + 31) & ~31;
+  const uint16_t* Whi = reinterpret_cast<const uint16_t*>(a.W);
+  const uint16_t* Wlo = Whi + (size_t)N * Kp;
+
+  // A loader: 8 lanes cover one 128-byte row segment (32 floats); thread handles rows ar + 32p, p = 0..3
+  const int ar = tid >> 3, ak = (tid & 7) * 4;
+  int ab[4], af[4];
+  bool aval[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int m = m0 + ar + 32 * p;
+    aval[p] = m < M;
+    if (a.taps > 1) { ab[p] = m / a.frames; af[p] = m - ab[p] * a.frames; } else { ab[p] = 0; af[p] = m; }
+  }
+  // W loader: 4 lanes cover one 64-byte row segment (32 bf16); thread handles rows wr + 64p, p = 0..1
+  const int wr = tid >> 2, wk = (tid & 3) * 8;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  for (int k0 = 0; k0 < Kp; k0 += BK) {
+    const int k = k0 + ak;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (aval[p] && k < K) {
+        if (a.taps > 1) {
+          const int tap = k / a.cin, c = k - tap * a.cin;
+          const int fs = af[p] + (tap - a.pad) * a.dil;
+          if (fs >= 0 && fs < a.frames) v = *reinterpret_cast<const float4*>(a.A + ((size_t)ab[p] * a.frames + fs) * a.lda + c);
+        } else {
+          v = *reinterpret_cast<const float4*>(a.A + (size_t)af[p] * a.lda + k);
+        }
+      }
+      ushort4 h, l;
+      h.x = f32_to_bf16(v.x); l.x = f32_to_bf16(v.x - bf16_to_f32(h.x));
+      h.y = f32_to_bf16(v.y); l.y = f32_to_bf16(v.y - bf16_to_f32(h.y));
+      h.z = f32_to_bf16(v.z); l.z = f32_to_bf16(v.z - bf16_to_f32(h.z));
+      h.w = f32_to_bf16(v.w); l.w = f32_to_bf16(v.w - bf16_to_f32(h.w));
+      *reinterpret_cast<ushort4*>(&Ah[ar + 32 * p][ak]) = h;
+      *reinterpret_cast<ushort4*>(&Al[ar + 32 * p][ak]) = l;
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int nn = n0 + wr + 64 * p;
+      u128 h = {0u, 0u, 0u, 0u}, l = {0u, 0u, 0u, 0u};
+      if (nn < N) {
+        h = *reinterpret_cast<const u128*>(Whi + (size_t)nn * Kp + k0 + wk);
+        l = *reinterpret_cast<const u128*>(Wlo + (size_t)nn * Kp + k0 + wk);
+      }
+      *reinterpret_cast<u128*>(&Wh[wr + 64 * p][wk]) = h;
+      *reinterpret_cast<u128*>(&Wl[wr + 64 * p][wk]) = l;
+    }
+    __syncthreads();
+    const int ri = lane & 31, kg = (lane >> 5) * 8;
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 16) {
+      bf16x8 fah[2], fal[2], fwh[2], fwl[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        fah[i] = *reinterpret_cast<const bf16x8*>(&Ah[wm * 64 + i * 32 + ri][kk + kg]);
+        fal[i] = *reinterpret_cast<const bf16x8*>(&Al[wm * 64 + i * 32 + ri][kk + kg]);
+        fwh[i] = *reinterpret_cast<const bf16x8*>(&Wh[wn * 64 + i * 32 + ri][kk + kg]);
+        fwl[i] = *reinterpret_cast<const bf16x8*>(&Wl[wn * 64 + i * 32 + ri][kk + kg]);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[i], fwh[j], acc[i][j], 0, 0, 0);  // small terms first
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fwl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fwh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+    if (col >= N) continue;
+    float bias = 0.f, gam = 1.f;
+    if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_SCALE_RES) bias = a.bias[col];
+    if (EPI == EPI_BIAS_SCALE_RES || EPI == EPI_SCALE) gam = a.gamma[col];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < M) {
+          float v = acc[i][j][r];
+          if (EPI == EPI_BIAS) v = v + bias;
+          else if (EPI == EPI_BIAS_GELU) v = gelu_erf(v + bias);
+          else if (EPI == EPI_BIAS_SCALE_RES) v = a.res[(size_t)row * a.ldr + col] + gam * (v + bias);
+          else if (EPI == EPI_RES) v = a.res[(size_t)row * a.ldr + col] + v;
+          else if (EPI == EPI_SCALE) v = v * gam;
+          a.C[(size_t)row * a.ldc + col] = v;
+        }
+      }
+    }
+  }
+}
+
+hipError_t launch_gemm_tiled_bf16x3(const GemmArgs& a, hipStream_t st) {
+  if (a.K % 4 != 0 || a.lda % 4 != 0 || a.norm_w != nullptr) return hipErrorInvalidValue;
+  if (a.taps > 1 && (a.cin % 4 != 0 || a.K != a.taps * a.cin)) return hipErrorInvalidValue;
+  dim3 grid((a.N + 127) / 128, (a.M + 127) / 128), block(256);
+  switch (a.epi) {
+    case EPI_STORE: CTTS_LAUNCH((gemm_tiled_bf16x3_k<EPI_STORE>), grid, block, st, a); break;
+    case EPI_RES: CTTS_LAUNCH((gemm_tiled_bf16x3_k<EPI_RES>), grid, block, st, a); break;
+    case EPI_BIAS: CTTS_LAUNCH((gemm_tiled_bf16x3_k<EPI_BIAS>), grid, block, st, a); break;
+    case EPI_BIAS_GELU: CTTS_LAUNCH((gemm_tiled_bf16x3_k<EPI_BIAS_GELU>), grid, block, st, a); break;
+    case EPI_BIAS_SCALE_RES: CTTS_LAUNCH((gemm_tiled_bf16x3_k<EPI_BIAS_SCALE_RES>), grid, block, st, a); break;
+    case EPI_SCALE: CTTS_LAUNCH((gemm_tiled_bf16x3_k<EPI_SCALE>), grid, block, st, a); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}

@@ -83,6 +83,7 @@ hipError_t launch_gemm_fast(const FastGemmArgs& a, hipStream_t st);
 // x32 row -> bf16 copy + partial sums of squares (prefill entry); optional code-embedding gather
 hipError_t launch_rows_prep(const float* x32, uint16_t* xb, float* ssq, int M, hipStream_t st);
 hipError_t launch_gemm_tiled(const GemmArgs& a, hipStream_t st);   // 64x64 LDS-tiled f32 MFMA, large M
+hipError_t launch_gemm_tiled_bf16x3(const GemmArgs& a, hipStream_t st);  // 128x128 split-bf16 (3 MFMA / product), W = [2][N][Kp] bf16
 
 // ---- GPT step kernels -------------------------------------------------------------------------
 struct GptRowMap {

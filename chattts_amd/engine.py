@@ -451,19 +451,44 @@ class GptEngine:
         yield outputs()
 
 
+def split_bf16(w: torch.Tensor) -> torch.Tensor:
+    """[N, K] float32 -> [2, N, Kp] bfloat16 (hi plane, lo plane), Kp = K rounded up to 32 and zero padded:
+    w = hi + lo up to 2^-17 |w|  (the weight operand of the bf16x3 GEMM tiles)."""
+    N, K = w.shape
+    Kp = (K + 31) // 32 * 32
+    out = torch.zeros((2, N, Kp), dtype=torch.bfloat16)
+    hi = w.to(torch.bfloat16)
+    out[0, :, :K] = hi
+    out[1, :, :K] = (w - hi.to(torch.float32)).to(torch.bfloat16)
+    return out.contiguous()
+
+
 # ---------------------------------------------------------------------------------------------
 class CodecEngine:
     """DVAE decoder + Vocos on the device (channels-last)."""
 
-    def __init__(self, decoder_sd: dict, vocos_sd: dict, device: torch.device):
+    def __init__(self, decoder_sd: dict, vocos_sd: dict, device: torch.device, gemm: str = "bf16x3"):
+        """gemm="bf16x3": dense layers run on split-bf16 MFMA tiles (x = hi + lo, 3 products; f32-class accuracy,
+        measured wav RMS error vs the reference ~1e-6 against the 1e-4 bar); gemm="f32": f32-input MFMA tiles."""
+        if gemm not in ("bf16x3", "f32"):
+            raise ValueError("gemm must be 'bf16x3' or 'f32'")
+        self.gemm = gemm
         self.lib = _lib.lib()
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.EngineError("CodecEngine needs a ROCm GPU device (there is no CPU path)")
         dev = self.device
         f = lambda t: t.to(torch.float32).contiguous().to(dev)
-        convw = lambda t: f(t.permute(0, 2, 1))          # [Cout,Cin,k] -> [Cout,k,Cin]
         dww = lambda t: f(t[:, 0, :].t())                # [C,1,7] -> [7,C]
+
+        def dense(t):
+            """[N, K] float32 dense weight -> device tensor in the layout the selected GEMM tiles read"""
+            t = t.to(torch.float32).reshape(t.shape[0], -1).contiguous()
+            if gemm == "f32":
+                return t.to(dev)
+            return split_bf16(t).to(dev)
+
+        convw = lambda t: dense(t.permute(0, 2, 1))      # [Cout,Cin,k] -> [Cout,k*Cin]
         self.keep = []
         k = self.keep.append
         w = _lib.CodecWeights()
@@ -490,12 +515,12 @@ class CodecEngine:
         w.d_dw_b = PA([f(blk(i, "dwconv.bias")) for i in range(nb)])
         w.d_ln_w = PA([f(blk(i, "norm.weight")) for i in range(nb)])
         w.d_ln_b = PA([f(blk(i, "norm.bias")) for i in range(nb)])
-        w.d_pw1_w = PA([f(blk(i, "pwconv1.weight")) for i in range(nb)])
+        w.d_pw1_w = PA([dense(blk(i, "pwconv1.weight")) for i in range(nb)])
         w.d_pw1_b = PA([f(blk(i, "pwconv1.bias")) for i in range(nb)])
-        w.d_pw2_w = PA([f(blk(i, "pwconv2.weight")) for i in range(nb)])
+        w.d_pw2_w = PA([dense(blk(i, "pwconv2.weight")) for i in range(nb)])
         w.d_pw2_b = PA([f(blk(i, "pwconv2.bias")) for i in range(nb)])
         w.d_gamma = PA([f(blk(i, "weight")) for i in range(nb)])
-        w.conv_out_w = P(f(d["decoder.conv_out.weight"][:, :, 0]))
+        w.conv_out_w = P(dense(d["decoder.conv_out.weight"][:, :, 0]))
         w.out_conv_w = P(convw(d["out_conv.weight"]))
         w.coef = P(f(d["coef"].reshape(-1)))
         v = vocos_sd
@@ -510,16 +535,17 @@ class CodecEngine:
         w.v_dw_b = PA([f(vb(i, "dwconv.bias")) for i in range(nv)])
         w.v_ln_w = PA([f(vb(i, "norm.weight")) for i in range(nv)])
         w.v_ln_b = PA([f(vb(i, "norm.bias")) for i in range(nv)])
-        w.v_pw1_w = PA([f(vb(i, "pwconv1.weight")) for i in range(nv)])
+        w.v_pw1_w = PA([dense(vb(i, "pwconv1.weight")) for i in range(nv)])
         w.v_pw1_b = PA([f(vb(i, "pwconv1.bias")) for i in range(nv)])
-        w.v_pw2_w = PA([f(vb(i, "pwconv2.weight")) for i in range(nv)])
+        w.v_pw2_w = PA([dense(vb(i, "pwconv2.weight")) for i in range(nv)])
         w.v_pw2_b = PA([f(vb(i, "pwconv2.bias")) for i in range(nv)])
         w.v_gamma = PA([f(vb(i, "gamma")) for i in range(nv)])
         w.v_final_w, w.v_final_b = P(f(v["backbone.final_layer_norm.weight"])), P(f(v["backbone.final_layer_norm.bias"]))
-        w.head_w, w.head_b = P(f(v["head.out.weight"])), P(f(v["head.out.bias"]))
+        w.head_w, w.head_b = P(dense(v["head.out.weight"])), P(f(v["head.out.bias"]))
         w.window = P(f(v["head.istft.window"]))
         kk = torch.arange(VOCOS.n_fft // 2, dtype=torch.float64) * (2.0 * math.pi / VOCOS.n_fft)
         w.twiddle = P(f(torch.stack([kk.cos(), kk.sin()], 1)))
+        w.gemm_mode = 1 if gemm == "bf16x3" else 0
         self._w = w
         h = C.c_void_p()
         _lib.check(self.lib.ctts_codec_create(C.byref(h), C.byref(w)), "ctts_codec_create")

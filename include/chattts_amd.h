@@ -141,6 +141,11 @@ typedef struct {
   const float* head_w; const float* head_b;                  /* [1026][512], [1026] */
   const float* window;                                       /* hann [1024] */
   const float* twiddle;                                      /* [512][2] cos/sin(2 pi k / 1024) */
+  /* 0: every dense weight above is float32 [N][K] (f32-input MFMA tiles);
+   * 1: every dense weight (conv_in*, *_pw1, *_pw2, conv_out, out_conv, v_embed, head) is instead a packed
+   *    split-bf16 tensor [2][N][Kp] (hi plane, lo plane; Kp = K rounded up to 32, zero padded), consumed by
+   *    the bf16x3 tiles (3 bf16 MFMAs per product, f32-class accuracy).  Biases/LN/depthwise stay float32. */
+  int32_t gemm_mode;
 } ctts_codec_weights;
 
 int ctts_codec_create(ctts_codec** out, const ctts_codec_weights* w);
@@ -152,7 +157,7 @@ int ctts_vocos_decode(ctts_codec* c, const float* mel, float* wav, int32_t B, in
 /* ------------------------------------------------------------------------------------------------
  * Single-kernel entry points (unit parity tests call the kernels through these).
  * ---------------------------------------------------------------------------------------------- */
-int ctts_k_gemm(int32_t tiled, const float* A, const void* W, float* C, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldc,
+int ctts_k_gemm(int32_t tiled /* 0 skinny, 1 f32 tiles, 2 split-bf16 tiles */, const float* A, const void* W, float* C, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldc,
                 int32_t wt, int32_t epi, const float* norm_w, float eps, const float* res, int32_t ldr, const float* bias,
                 const float* gamma, int32_t taps, int32_t cin, int32_t frames, int32_t pad, int32_t dil, void* stream);
 /* perf-mode projection: bf16 activations/weights, optional per-row 1/rms from 48 partial sums of squares,

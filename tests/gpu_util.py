@@ -27,10 +27,17 @@ def gemm(A, W, *, wt="f32", tiled=False, epi=0, norm_w=None, eps=1e-6, res=None,
     """A [M(or B*F), lda] f32, W [N(,2N),K].  Returns C [M, N] numpy."""
     lib = _lib.lib()
     A_d = dev(A, torch.float32)
-    W_d = dev(W, torch.bfloat16 if wt == "bf16" else torch.float32)
+    if tiled == 2:  # split-bf16 tiles: weights packed [2][N][Kp]
+        from chattts_amd.engine import split_bf16
+        Wt = torch.as_tensor(np.ascontiguousarray(W), dtype=torch.float32)
+        W_d = split_bf16(Wt).to(DEV)
+        K = Wt.shape[1]
+        N = n_out if n_out is not None else Wt.shape[0]
+    else:
+        W_d = dev(W, torch.bfloat16 if wt == "bf16" else torch.float32)
+        K = W_d.shape[1]
+        N = n_out if n_out is not None else W_d.shape[0]
     M = A_d.shape[0]
-    K = W_d.shape[1]
-    N = n_out if n_out is not None else W_d.shape[0]
     C_d = torch.full((M, N), float("nan"), dtype=torch.float32, device=DEV)
     nw = None if norm_w is None else dev(norm_w, torch.float32)
     r = None if res is None else dev(res, torch.float32)

@@ -194,7 +194,8 @@ def _conv_ref(X, Wt, B, F, taps, pad):
     dict(B=2, F=37, cin=384, cout=100, taps=3, pad=1, epi=6),    # out_conv * coef (N = 100)
     dict(B=1, F=5, cin=384, cout=128, taps=3, pad=1, epi=4),     # fewer frames than one tile
 ])
-def test_gemm_tiled_conv(G, case):
+@pytest.mark.parametrize("tiled", [1, 2])
+def test_gemm_tiled_conv(G, case, tiled):
     c = case
     rs = np.random.RandomState(c["cin"] + c["cout"])
     X = rs.standard_normal((c["B"] * c["F"], c["cin"])).astype(f32)
@@ -202,7 +203,7 @@ def test_gemm_tiled_conv(G, case):
     Wp = np.ascontiguousarray(Wt.transpose(0, 2, 1)).reshape(c["cout"], c["taps"] * c["cin"])
     bias = rs.standard_normal(c["cout"]).astype(f32) * 0.1
     gam = (0.5 + rs.rand(c["cout"])).astype(f32)
-    got = G.gemm(X, Wp, tiled=True, epi=c["epi"], bias=bias, gamma=gam, taps=c["taps"], cin=c["cin"], frames=c["F"], pad=c["pad"])
+    got = G.gemm(X, Wp, tiled=tiled, epi=c["epi"], bias=bias, gamma=gam, taps=c["taps"], cin=c["cin"], frames=c["F"], pad=c["pad"])
     acc = _conv_ref(X, Wt, c["B"], c["F"], c["taps"], c["pad"])
     if c["epi"] == 4:
         ref = codec_np.gelu((acc + bias).astype(f32))
@@ -210,21 +211,23 @@ def test_gemm_tiled_conv(G, case):
         ref = acc + bias
     else:
         ref = acc * gam
-    assert G.relerr(got, ref) < 1e-5, G.relerr(got, ref)
+    assert G.relerr(got, ref) < (1e-5 if tiled == 1 else 3e-5), G.relerr(got, ref)  # split-bf16: 2^-16-class products
 
 
-@pytest.mark.parametrize("M,N,K,epi", [(200, 2048, 512, 4), (200, 512, 2048, 5), (130, 384, 512, 0), (70, 1026, 512, 3), (64, 1536, 512, 4)])
-def test_gemm_tiled_linear(G, M, N, K, epi):
+@pytest.mark.parametrize("tiled", [1, 2])
+@pytest.mark.parametrize("M,N,K,epi", [(200, 2048, 512, 4), (200, 512, 2048, 5), (130, 384, 512, 0), (70, 1026, 512, 3), (64, 1536, 512, 4),
+                                       (300, 100, 1152, 6)])
+def test_gemm_tiled_linear(G, M, N, K, epi, tiled):
     rs = np.random.RandomState(M + N + K)
     A = rs.standard_normal((M, K)).astype(f32)
     W = (rs.standard_normal((N, K)) / np.sqrt(K)).astype(f32)
     bias = rs.standard_normal(N).astype(f32) * 0.1
     gam = (0.05 + 0.1 * rs.rand(N)).astype(f32)
     res = rs.standard_normal((M, N)).astype(f32)
-    got = G.gemm(A, W, tiled=True, epi=epi, bias=bias, gamma=gam, res=res)
+    got = G.gemm(A, W, tiled=tiled, epi=epi, bias=bias, gamma=gam, res=res)
     acc = A.astype(np.float64) @ W.astype(np.float64).T
-    ref = {0: acc, 3: acc + bias, 4: codec_np.gelu((acc + bias).astype(f32)), 5: res + gam * (acc + bias)}[epi]
-    assert G.relerr(got, ref) < 1e-5, G.relerr(got, ref)
+    ref = {0: acc, 3: acc + bias, 4: codec_np.gelu((acc + bias).astype(f32)), 5: res + gam * (acc + bias), 6: acc * gam}[epi]
+    assert G.relerr(got, ref) < (1e-5 if tiled == 1 else 3e-5), G.relerr(got, ref)
 
 
 # ------------------------------------------------------------------------------------------------
