@@ -550,13 +550,18 @@ hipError_t launch_gemm_fast(const FastGemmArgs& a, hipStream_t st) {
 // this is the only way to make the 157 MFLOP/token decoder cheaper without giving up the 1e-4 RMS bar.
 // ------------------------------------------------------------------------------------------------
 template <int EPI>
-__global__ __launch_bounds__(256) void gemm_tiled_bf16x3_k(GemmArgs a) {
+__global__ __launch_bounds__(256, 2) void gemm_tiled_bf16x3_k(GemmArgs a) {
   constexpr int BM = 128, BN = 128, BK = 32, LD = 40;  // LD: 80-byte rows -> conflict-free ds_read_b128 of the fragments
   __shared__ __attribute__((aligned(16))) uint16_t Ah[BM][LD], Al[BM][LD], Wh[BN][LD], Wl[BN][LD];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int wm = wave & 1, wn = wave >> 1;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const int M = a.M, N = a.N, K = a.K;
+  // XCD-aware tile order: the dispatcher places workgroup L on XCD L % 8 (each XCD has its own L2), so give
+  // every XCD a contiguous run of tiles; the N-tiles that share one A row-panel then hit the same L2.
+  const int nx = (N + BN - 1) / BN, ny = (M + BM - 1) / BM, T = nx * ny, per = (T + 7) / 8;
+  const int t = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= per || t >= T) return;
+  const int m0 = (t / nx) * BM, n0 = (t % nx) * BN;
   const int Kp = (K + 31) & ~31;
   const uint16_t* Whi = reinterpret_cast<const uint16_t*>(a.W);
   const uint16_t* Wlo = Whi + (size_t)N * Kp;
@@ -582,41 +587,61 @@ __global__ __launch_bounds__(256) void gemm_tiled_bf16x3_k(GemmArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // register staging (one tile ahead): the global loads of tile k+1 are in flight while tile k is multiplied
+  float4 ra0, ra1, ra2, ra3;
+  u128 rh0, rl0, rh1, rl1;
+#define X3_FETCH(K0)                                                                                        \
+  do {                                                                                                      \
+    const int k0_ = (K0);                                                                                   \
+    const int k = k0_ + ak;                                                                                 \
+    _Pragma("unroll") for (int p = 0; p < 4; ++p) {                                                         \
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                                                           \
+      if (aval[p] && k < K) {                                                                               \
+        if (a.taps > 1) {                                                                                   \
+          const int tap = k / a.cin, c = k - tap * a.cin;                                                   \
+          const int fs = af[p] + (tap - a.pad) * a.dil;                                                     \
+          if (fs >= 0 && fs < a.frames)                                                                     \
+            v = *reinterpret_cast<const float4*>(a.A + ((size_t)ab[p] * a.frames + fs) * a.lda + c);        \
+        } else {                                                                                            \
+          v = *reinterpret_cast<const float4*>(a.A + (size_t)af[p] * a.lda + k);                            \
+        }                                                                                                   \
+      }                                                                                                     \
+      if (p == 0) ra0 = v; else if (p == 1) ra1 = v; else if (p == 2) ra2 = v; else ra3 = v;                \
+    }                                                                                                       \
+    {                                                                                                       \
+      const int nA = min(n0 + wr, N - 1), nB = min(n0 + wr + 64, N - 1);                                    \
+      rh0 = *reinterpret_cast<const u128*>(Whi + (size_t)nA * Kp + k0_ + wk);                               \
+      rl0 = *reinterpret_cast<const u128*>(Wlo + (size_t)nA * Kp + k0_ + wk);                               \
+      rh1 = *reinterpret_cast<const u128*>(Whi + (size_t)nB * Kp + k0_ + wk);                               \
+      rl1 = *reinterpret_cast<const u128*>(Wlo + (size_t)nB * Kp + k0_ + wk);                               \
+    }                                                                                                       \
+  } while (0)
+
+#define X3_SPLIT_STORE(V, R)                                                                               \
+  do {                                                                                                      \
+    const float4 v = (V);                                                                                   \
+    ushort4 h, l;                                                                                           \
+    h.x = f32_to_bf16(v.x); l.x = f32_to_bf16(v.x - bf16_to_f32(h.x));                                      \
+    h.y = f32_to_bf16(v.y); l.y = f32_to_bf16(v.y - bf16_to_f32(h.y));                                      \
+    h.z = f32_to_bf16(v.z); l.z = f32_to_bf16(v.z - bf16_to_f32(h.z));                                      \
+    h.w = f32_to_bf16(v.w); l.w = f32_to_bf16(v.w - bf16_to_f32(h.w));                                      \
+    *reinterpret_cast<ushort4*>(&Ah[(R)][ak]) = h;                                                          \
+    *reinterpret_cast<ushort4*>(&Al[(R)][ak]) = l;                                                          \
+  } while (0)
+#define X3_STAGE()                                                                                          \
+  do {                                                                                                      \
+    X3_SPLIT_STORE(ra0, ar); X3_SPLIT_STORE(ra1, ar + 32); X3_SPLIT_STORE(ra2, ar + 64); X3_SPLIT_STORE(ra3, ar + 96); \
+    *reinterpret_cast<u128*>(&Wh[wr][wk]) = rh0; *reinterpret_cast<u128*>(&Wl[wr][wk]) = rl0;              \
+    *reinterpret_cast<u128*>(&Wh[wr + 64][wk]) = rh1; *reinterpret_cast<u128*>(&Wl[wr + 64][wk]) = rl1;    \
+  } while (0)
+
+  X3_FETCH(0);
+  X3_STAGE();
+  __syncthreads();
+  const int ri = lane & 31, kg = (lane >> 5) * 8;
   for (int k0 = 0; k0 < Kp; k0 += BK) {
-    const int k = k0 + ak;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (aval[p] && k < K) {
-        if (a.taps > 1) {
-          const int tap = k / a.cin, c = k - tap * a.cin;
-          const int fs = af[p] + (tap - a.pad) * a.dil;
-          if (fs >= 0 && fs < a.frames) v = *reinterpret_cast<const float4*>(a.A + ((size_t)ab[p] * a.frames + fs) * a.lda + c);
-        } else {
-          v = *reinterpret_cast<const float4*>(a.A + (size_t)af[p] * a.lda + k);
-        }
-      }
-      ushort4 h, l;
-      h.x = f32_to_bf16(v.x); l.x = f32_to_bf16(v.x - bf16_to_f32(h.x));
-      h.y = f32_to_bf16(v.y); l.y = f32_to_bf16(v.y - bf16_to_f32(h.y));
-      h.z = f32_to_bf16(v.z); l.z = f32_to_bf16(v.z - bf16_to_f32(h.z));
-      h.w = f32_to_bf16(v.w); l.w = f32_to_bf16(v.w - bf16_to_f32(h.w));
-      *reinterpret_cast<ushort4*>(&Ah[ar + 32 * p][ak]) = h;
-      *reinterpret_cast<ushort4*>(&Al[ar + 32 * p][ak]) = l;
-    }
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      const int nn = n0 + wr + 64 * p;
-      u128 h = {0u, 0u, 0u, 0u}, l = {0u, 0u, 0u, 0u};
-      if (nn < N) {
-        h = *reinterpret_cast<const u128*>(Whi + (size_t)nn * Kp + k0 + wk);
-        l = *reinterpret_cast<const u128*>(Wlo + (size_t)nn * Kp + k0 + wk);
-      }
-      *reinterpret_cast<u128*>(&Wh[wr + 64 * p][wk]) = h;
-      *reinterpret_cast<u128*>(&Wl[wr + 64 * p][wk]) = l;
-    }
-    __syncthreads();
-    const int ri = lane & 31, kg = (lane >> 5) * 8;
+    const bool more = k0 + BK < Kp;
+    if (more) X3_FETCH(k0 + BK);
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 16) {
       bf16x8 fah[2], fal[2], fwh[2], fwl[2];
@@ -637,6 +662,10 @@ __global__ __launch_bounds__(256) void gemm_tiled_bf16x3_k(GemmArgs a) {
         }
     }
     __syncthreads();
+    if (more) {
+      X3_STAGE();
+      __syncthreads();
+    }
   }
 
 #pragma unroll
@@ -665,10 +694,15 @@ __global__ __launch_bounds__(256) void gemm_tiled_bf16x3_k(GemmArgs a) {
   }
 }
 
+#undef X3_FETCH
+#undef X3_STAGE
+#undef X3_SPLIT_STORE
+
 hipError_t launch_gemm_tiled_bf16x3(const GemmArgs& a, hipStream_t st) {
   if (a.K % 4 != 0 || a.lda % 4 != 0 || a.norm_w != nullptr) return hipErrorInvalidValue;
   if (a.taps > 1 && (a.cin % 4 != 0 || a.K != a.taps * a.cin)) return hipErrorInvalidValue;
-  dim3 grid((a.N + 127) / 128, (a.M + 127) / 128), block(256);
+  const int tiles = ((a.N + 127) / 128) * ((a.M + 127) / 128);
+  dim3 grid(((tiles + 7) / 8) * 8), block(256);  // 1-D grid, remapped XCD-aware inside the kernel
   switch (a.epi) {
     case EPI_STORE: CTTS_LAUNCH((gemm_tiled_bf16x3_k<EPI_STORE>), grid, block, st, a); break;
     case EPI_RES: CTTS_LAUNCH((gemm_tiled_bf16x3_k<EPI_RES>), grid, block, st, a); break;
