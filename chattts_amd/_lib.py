@@ -22,6 +22,7 @@ class GptWeights(C.Structure):
         ("wqkv", PP), ("wo", PP), ("wgu", PP), ("wd", PP), ("ln1", PP), ("ln2", PP),
         ("norm", P), ("emb_code", P), ("heads", P), ("rope_cos", P), ("rope_sin", P),
         ("rms_eps", C.c_float),
+        ("emb_text", P), ("head_text", P), ("n_text", C.c_int32),
     ]
 
 
@@ -33,7 +34,7 @@ class GenState(C.Structure):
         ("temperature", P), ("pow_table", P),
         ("top_p_thr", C.c_float), ("use_top_p", C.c_int32), ("top_k", C.c_int32), ("use_top_k", C.c_int32),
         ("min_new", C.c_int32), ("eos", C.c_int32), ("row_offset", C.c_int32),
-        ("stop_at", P), ("workspace", P), ("workspace_bytes", C.c_size_t),
+        ("stop_at", P), ("workspace", P), ("workspace_bytes", C.c_size_t), ("infer_text", C.c_int32),
     ]
 
 

@@ -23,6 +23,20 @@ from .engine import CodecEngine, Context, GenerationOutputs, GptEngine, gen_logi
 
 
 @dataclass(repr=False, eq=False)
+class RefineTextParams:           # core.py:182-193
+    prompt: str = ""
+    top_P: float = 0.7
+    top_K: int = 20
+    temperature: float = 0.7
+    repetition_penalty: float = 1.0
+    max_new_token: int = 384
+    min_new_token: int = 0
+    show_tqdm: bool = True
+    ensure_non_empty: bool = True
+    manual_seed: Optional[int] = None
+
+
+@dataclass(repr=False, eq=False)
 class InferCodeParams:            # core.py:195-206 (+ the RefineTextParams fields it inherits, :182-193)
     prompt: str = ""
     top_P: float = 0.7
@@ -82,6 +96,19 @@ class Chat:
             emb, input_ids, temperature, GPT.n_audio - 1, attention_mask, params.max_new_token, params.min_new_token,
             (*procs, *warpers), False, False, return_hidden, stream, params.show_tqdm, params.ensure_non_empty,
             params.stream_batch, params.manual_seed, self.context, **shard_kw)
+
+    def refine_text_ids(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, text_mask: torch.Tensor, eos_token: int,
+                        params: RefineTextParams = RefineTextParams(), **kw) -> GenerationOutputs:
+        """`Chat._refine_text` from `gen_logits` on (core.py:682-751): the same generator in text mode
+        (`infer_text=True`: text embedding, 21178-way text head, tokens replicated over the 4 slots); `eos_token`
+        is `tokenizer.eos_token` ([Ebreak]).  Returns `GenerationOutputs` whose `ids[b]` is the 1-D refined token row."""
+        assert self.has_loaded()
+        warpers, procs = gen_logits(GPT.n_text, params.top_P, params.top_K, params.repetition_penalty)
+        emb = self.gpt.embed_prompt(input_ids, text_mask)
+        return next(self.gpt.generate(
+            emb, input_ids, torch.tensor([params.temperature]), eos_token, attention_mask, params.max_new_token,
+            params.min_new_token, (*procs, *warpers), True, False, False, False, params.show_tqdm, params.ensure_non_empty,
+            24, params.manual_seed, self.context, **kw))
 
     def decode_to_wavs(self, hiddens: List[torch.Tensor]) -> np.ndarray:
         """`Chat._decode_to_wavs(result.hiddens, use_decoder=True)` (core.py:513-539) -> np.float32 [B, n]."""

@@ -27,7 +27,7 @@ static int fail(const char* fmt, ...) {
 extern "C" const char* ctts_last_error(void) { return g_err; }
 extern "C" int ctts_version(void) { return 1; }
 
-static const int HID = 768, INTER = 3072, NHEAD = 12, HDIM = 64, NVQ = 4, NAUDIO = 626;
+static const int HID = 768, INTER = 3072, NHEAD = 12, HDIM = 64, NVQ = 4, NAUDIO = 626, NTEXT_MAX = 21248;
 
 // ------------------------------------------------------------------------------------------------
 struct ctts_gpt {
@@ -62,7 +62,7 @@ static GptWs carve(void* base, int B, int T) {
   w.ao = (float*)(p + off); off += align_up(M * HID * 4);
   w.act = (float*)(p + off); off += align_up(M * INTER * 4);
   w.hfin = (float*)(p + off); off += align_up((size_t)B * HID * 4);
-  w.logits = (float*)(p + off); off += align_up((size_t)B * NVQ * NAUDIO * 4);
+  w.logits = (float*)(p + off); off += align_up((size_t)B * NTEXT_MAX * 4);  // >= B*4*626; refine-text mode needs B*n_text
   w.ssq = (float*)(p + off); off += align_up(M * SSQ_PARTS * 4);
   w.xb = (uint16_t*)(p + off); off += align_up(M * HID * 2);
   w.bytes = off;
@@ -134,6 +134,11 @@ static int check_state(const ctts_gpt* g, const ctts_gen_state* s) {
   if (s->workspace_bytes < ctts_gpt_workspace_bytes(s->B, s->T)) return fail("workspace too small");
   if (s->nq <= 0 || !s->q) return fail("q draws missing");
   if (g->w.weight_dtype == CTTS_BF16 && g->w.kv_dtype != CTTS_BF16) return fail("perf mode needs a bf16 KV cache");
+  if (s->infer_text) {
+    if (!g->w.emb_text || !g->w.head_text || g->w.n_text <= 0 || g->w.n_text > NTEXT_MAX) return fail("text head/embedding not loaded");
+    if (s->pow_table) return fail("refine-text mode does not support a repetition penalty (the reference's own processor mis-broadcasts there)");
+    if (s->eos < 0 || s->eos >= g->w.n_text) return fail("bad eos for text mode");
+  }
   return 0;
 }
 
@@ -198,15 +203,20 @@ static int run_step(ctts_gpt* g, const ctts_gen_state* s, int q_per_b, hipStream
   { Prof p(g, 7, st, prof_ok);
     CK(launch_final_norm(ws.x, q_per_b, g->w.norm, g->w.rms_eps, ws.hfin, s->hiddens, s->max_new, s->len, s->T, B, st)); }
   {
+    const int nlog = s->infer_text ? g->w.n_text : NVQ * NAUDIO;   // gpt.py:439-440 text head | :441-454 four code heads
     GemmArgs a;
     memset(&a, 0, sizeof(a));
     a.taps = 1;
-    a.A = ws.hfin; a.lda = HID; a.W = g->w.heads; a.C = ws.logits; a.ldc = NVQ * NAUDIO; a.M = B; a.N = NVQ * NAUDIO; a.K = HID;
-    a.wt = WT_F32; a.epi = EPI_STORE;
+    a.A = ws.hfin; a.lda = HID; a.W = s->infer_text ? g->w.head_text : g->w.heads; a.C = ws.logits; a.ldc = nlog; a.M = B; a.N = nlog;
+    a.K = HID; a.wt = WT_F32; a.epi = EPI_STORE;
     Prof p(g, 8, st, prof_ok);
     CK(launch_gemm_skinny(a, st));
   }
-  { Prof p(g, 9, st, prof_ok); CK(launch_sample(make_sample_args(s, ws.logits), st)); }
+  {
+    Prof p(g, 9, st, prof_ok);
+    if (s->infer_text) CK(launch_sample_text(make_sample_args(s, ws.logits), g->w.n_text, st));
+    else CK(launch_sample(make_sample_args(s, ws.logits), st));
+  }
   return 0;
 }
 
@@ -222,7 +232,11 @@ extern "C" int ctts_gpt_prefill(ctts_gpt* g, const ctts_gen_state* s, const floa
 static int decode_body(ctts_gpt* g, const ctts_gen_state* s, hipStream_t st, bool prof_ok) {
   const GptWs ws = carve(s->workspace, s->B, s->T);
   { Prof p(g, 0, st, prof_ok); const bool fast = g->w.weight_dtype == CTTS_BF16;
-    CK(launch_embed_codes(g->w.emb_code, s->ids_buf, s->T + s->max_new, s->len, ws.x, fast ? ws.xb : nullptr, fast ? ws.ssq : nullptr, s->B, st)); }
+    if (s->infer_text)
+      CK(launch_embed_text(g->w.emb_text, g->w.n_text, s->ids_buf, s->T + s->max_new, s->len, ws.x, fast ? ws.xb : nullptr,
+                           fast ? ws.ssq : nullptr, s->B, st));
+    else
+      CK(launch_embed_codes(g->w.emb_code, s->ids_buf, s->T + s->max_new, s->len, ws.x, fast ? ws.xb : nullptr, fast ? ws.ssq : nullptr, s->B, st)); }
   return run_step(g, s, 1, st, prof_ok);
 }
 

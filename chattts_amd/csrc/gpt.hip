@@ -515,3 +515,166 @@ hipError_t launch_sample(const SampleArgs& a, hipStream_t st) {
   return hipGetLastError();
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// refine-text mode (infer_text=True, gpt.py:406-407,439-440,477-485,519-525): the decode input is
+// emb_text[last token], the head is the 21178-way text head, one sampling row per utterance.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(192) void embed_text_k(const float* __restrict__ emb_text, int n_text, const int64_t* __restrict__ ids_buf,
+                                                    int tcap, const int32_t* __restrict__ len, float* __restrict__ x,
+                                                    uint16_t* __restrict__ xb, float* __restrict__ ssq) {
+  const int b = blockIdx.x, t = threadIdx.x;
+  int id = (int)ids_buf[((size_t)b * tcap + (len[b] - 1)) * NVQ];  // slot 0 (gpt.py:407)
+  id = min(max(id, 0), n_text - 1);
+  const float4 s = *reinterpret_cast<const float4*>(emb_text + (size_t)id * HID + t * 4);
+  emit_row(s, t, x + (size_t)b * HID, xb ? xb + (size_t)b * HID : nullptr, ssq ? ssq + (size_t)b * SSQ_PARTS : nullptr);
+}
+
+hipError_t launch_embed_text(const float* emb_text, int n_text, const int64_t* ids_buf, int tcap, const int32_t* len, float* x,
+                             uint16_t* xb, float* ssq, int B, hipStream_t st) {
+  CTTS_LAUNCH(embed_text_k, dim3(B), dim3(192), st, emb_text, n_text, ids_buf, tcap, len, x, xb, ssq);
+  return hipGetLastError();
+}
+
+#define TEXT_VMAX 21248  // >= num_text_tokens (21178), multiple of 256
+
+struct BlockRed {
+  float f[4]; int i[4]; double d[4];
+};
+__device__ __forceinline__ float block_max4(float v, BlockRed& r, int wave, int lane) {
+  v = wave_max(v);
+  __syncthreads();
+  if (lane == 0) r.f[wave] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(r.f[0], r.f[1]), fmaxf(r.f[2], r.f[3]));
+}
+__device__ __forceinline__ float block_sum4(float v, BlockRed& r, int wave, int lane) {
+  v = wave_sum(v);
+  __syncthreads();
+  if (lane == 0) r.f[wave] = v;
+  __syncthreads();
+  return (r.f[0] + r.f[1]) + (r.f[2] + r.f[3]);
+}
+__device__ __forceinline__ double block_sum4d(double v, BlockRed& r, int wave, int lane) {
+  v = wave_sum_d(v);
+  __syncthreads();
+  if (lane == 0) r.d[wave] = v;
+  __syncthreads();
+  return (r.d[0] + r.d[1]) + (r.d[2] + r.d[3]);
+}
+// max value, ties -> lowest index, uniform over the 256-thread block
+__device__ __forceinline__ void block_argmax4(float v, int idx, BlockRed& r, int wave, int lane, float& bv, int& bi) {
+  float wv; int wi;
+  wave_argmax(v, idx, wv, wi);
+  __syncthreads();
+  if (lane == 0) { r.f[wave] = wv; r.i[wave] = wi; }
+  __syncthreads();
+  bv = r.f[0]; bi = r.i[0];
+#pragma unroll
+  for (int w = 1; w < 4; ++w)
+    if (r.f[w] > bv || (r.f[w] == bv && r.i[w] < bi)) { bv = r.f[w]; bi = r.i[w]; }
+}
+
+// One 256-thread workgroup per utterance; the tempered logits live in LDS, the kept set is a bitmask.
+// Same sort-free prefix extraction as sample_k (see there), block-wide instead of wave-wide.
+__global__ __launch_bounds__(256) void sample_text_k(SampleArgs a, int V) {
+  __shared__ float xs[TEXT_VMAX];
+  __shared__ unsigned keptbits[TEXT_VMAX / 32];
+  __shared__ BlockRed red;
+  const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int len = a.len[b];
+  const int gen = len - a.T;
+  const float* lrow = a.logits + (size_t)b * V;
+  const float temp = a.temperature[0];
+
+  float mx = -INFINITY;
+  for (int v = tid; v < TEXT_VMAX; v += 256) {
+    const float x = (v < V) ? lrow[v] / temp : -INFINITY;   // gpt.py:487 (repetition penalty is not supported in this mode)
+    xs[v] = x;
+    mx = fmaxf(mx, x);
+  }
+  for (int w = tid; w < TEXT_VMAX / 32; w += 256) keptbits[w] = 0u;
+  mx = block_max4(mx, red, wave, lane);
+  float zs = 0.f;
+  for (int v = tid; v < V; v += 256) zs += expf(xs[v] - mx);
+  zs = block_sum4(zs, red, wave, lane);
+  const float rz = 1.0f / zs;
+  double sall = 0.0;
+  for (int v = tid; v < V; v += 256) sall += (double)(expf(xs[v] - mx) * rz);
+  sall = block_sum4d(sall, red, wave, lane);
+
+  const int kk = a.use_top_k ? min(max(a.top_k, 3), V) : V;
+  const float thr = a.top_p_thr;
+  const bool any_filter = a.use_top_p || a.use_top_k;
+  double mass_above = 0.0;
+  float kth_val = 0.f;
+  int n = 0;
+  while (any_filter && n < V) {
+    float bv = -INFINITY; int bi = 0x7fffffff;
+    for (int v = tid; v < V; v += 256) {
+      const bool avail = !((keptbits[v >> 5] >> (v & 31)) & 1u);
+      const float x = xs[v];
+      if (avail && x > bv) { bv = x; bi = v; }   // ascending v => lowest index on ties
+    }
+    float wv; int wi;
+    block_argmax4(bv, bi, red, wave, lane, wv, wi);
+    bool keep = true;
+    if (a.use_top_p && n >= 3) {
+      const float cum = (float)(sall - mass_above);
+      keep = !(cum <= thr);
+    }
+    if (!keep) break;
+    if (a.use_top_k && n >= kk) {
+      if (!(wv == kth_val)) break;
+    }
+    mass_above += (double)(expf(wv - mx) * rz);
+    if (tid == 0) keptbits[wi >> 5] |= 1u << (wi & 31);
+    if (n == kk - 1) kth_val = wv;
+    ++n;
+    __syncthreads();
+  }
+  __syncthreads();
+
+  bool mask_eos = gen < a.min_new;
+  bool force_eos = false;
+  if (a.stop_at != nullptr) {
+    const int sa = a.stop_at[b];
+    if (sa >= 0) { mask_eos = mask_eos || (gen < sa); force_eos = gen >= sa; }
+  }
+  const float* qrow = a.q + ((size_t)(gen % a.nq) * a.B + b) * V;
+  float m2 = -INFINITY;
+  for (int v = tid; v < V; v += 256) {
+    const bool live = (!any_filter || ((keptbits[v >> 5] >> (v & 31)) & 1u)) && !(mask_eos && v == a.eos);
+    if (live) m2 = fmaxf(m2, xs[v]);
+  }
+  m2 = block_max4(m2, red, wave, lane);
+  float z2 = 0.f;
+  for (int v = tid; v < V; v += 256) {
+    const bool live = (!any_filter || ((keptbits[v >> 5] >> (v & 31)) & 1u)) && !(mask_eos && v == a.eos);
+    if (live) z2 += expf(xs[v] - m2);
+  }
+  z2 = block_sum4(z2, red, wave, lane);
+  const float rz2 = 1.0f / z2;
+  float bv = -1.f; int bi = 0x7fffffff;
+  for (int v = tid; v < V; v += 256) {
+    const bool live = (!any_filter || ((keptbits[v >> 5] >> (v & 31)) & 1u)) && !(mask_eos && v == a.eos);
+    const float r = (live ? expf(xs[v] - m2) * rz2 : 0.f) / qrow[v];
+    if (r > bv) { bv = r; bi = v; }
+  }
+  float wv; int wi;
+  block_argmax4(bv, bi, red, wave, lane, wv, wi);
+  if (force_eos) wi = a.eos;
+  if (tid < NVQ) a.ids_buf[((size_t)b * a.tcap + len) * NVQ + tid] = (int64_t)wi;   // gpt.py:522-525: replicated over the 4 slots
+  if (tid == 0) {
+    const bool fin = (a.finish[b] != 0) || (wi == a.eos);
+    a.finish[b] = fin ? 1 : 0;
+    if (!fin) a.end_idx[b] += 1;
+    a.len[b] = len + 1;
+  }
+}
+
+hipError_t launch_sample_text(const SampleArgs& a, int V, hipStream_t st) {
+  if (V > TEXT_VMAX || a.pow_table != nullptr) return hipErrorInvalidValue;
+  CTTS_LAUNCH(sample_text_k, dim3(a.B), dim3(256), st, a, V);
+  return hipGetLastError();
+}

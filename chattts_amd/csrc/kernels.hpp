@@ -124,6 +124,10 @@ struct SampleArgs {
   int B;
 };
 hipError_t launch_sample(const SampleArgs& a, hipStream_t st);
+// refine-text mode: logits [B, V], q [nq, B, V], temperature[0]; no repetition penalty (see gpt.hip)
+hipError_t launch_sample_text(const SampleArgs& a, int V, hipStream_t st);
+hipError_t launch_embed_text(const float* emb_text, int n_text, const int64_t* ids_buf, int tcap, const int32_t* len, float* x,
+                             uint16_t* xb, float* ssq, int B, hipStream_t st);
 
 // ---- codec kernels (channels-last [B, F, C]) ---------------------------------------------------
 hipError_t launch_dwconv_ln(const float* x, const float* w /*[C,7]*/, const float* b, const float* ln_w, const float* ln_b,

@@ -67,7 +67,7 @@ class SamplingPlan:
     penalty: Optional[float] = None
 
 
-def plan_from_processors(processors: Sequence) -> SamplingPlan:
+def plan_from_processors(processors: Sequence, infer_text: bool = False) -> SamplingPlan:
     """Accepts this module's descriptors AND the reference's own objects (duck-typed on the attribute
     names of transformers' warpers / the reference's penalty class).  Anything else cannot be fused
     into the kernel and is rejected loudly.  Order must be penalty -> top-p -> top-k (core.py:649)."""
@@ -75,6 +75,11 @@ def plan_from_processors(processors: Sequence) -> SamplingPlan:
     stage = 0
     for p in processors:
         if hasattr(p, "penalty") and hasattr(p, "past_window"):
+            if infer_text:
+                # the reference's processor receives [B, n, 1] histories in text mode (gpt.py:477-485) and its
+                # one_hot(...).sum(1) then broadcasts [B,V] against [B,1,V]: it only works because refine-text
+                # defaults to repetition_penalty = 1.0, which creates no processor (processors.py:52)
+                raise NotImplementedError("refine-text mode supports repetition_penalty = 1.0 only (reference default)")
             if stage > 0 or p.past_window != 16 or p.max_input_ids != GPT.n_audio - 1:
                 raise NotImplementedError("repetition penalty must come first with past_window=16, max_input_ids=625")
             plan.penalty = float(p.penalty)
@@ -196,6 +201,8 @@ class GptEngine:
         self.heads = f(torch.cat([fold_weight_norm(embed_sd[f"head_code.{k}.parametrizations.weight.original0"].float(),
                                                    embed_sd[f"head_code.{k}.parametrizations.weight.original1"].float())
                                   for k in range(GPT.n_vq)], 0))
+        self.head_text = f(fold_weight_norm(embed_sd["head_text.parametrizations.weight.original0"].float(),
+                                            embed_sd["head_text.parametrizations.weight.original1"].float()))
         cos, sin = rope_tables(max_pos)
         self.rope_cos, self.rope_sin = cos.to(dev), sin.to(dev)
         self._arrs = [_lib.ptr_array(x) for x in (self.wqkv, self.wo, self.wgu, self.wd, self.ln1, self.ln2)]
@@ -205,6 +212,7 @@ class GptEngine:
         w.norm, w.emb_code, w.heads = self.norm.data_ptr(), self.emb_code.data_ptr(), self.heads.data_ptr()
         w.rope_cos, w.rope_sin = self.rope_cos.data_ptr(), self.rope_sin.data_ptr()
         w.rms_eps = GPT.rms_eps
+        w.emb_text, w.head_text, w.n_text = self.emb_text.data_ptr(), self.head_text.data_ptr(), GPT.n_text
         self._w = w
         h = C.c_void_p()
         _lib.check(self.lib.ctts_gpt_create(C.byref(h), C.byref(w)), "ctts_gpt_create")
@@ -264,15 +272,15 @@ class GptEngine:
         (the batch is cut into that many contiguous row groups, each decoding on its own HIP stream
         with its own captured graph; utterances never interact, so the result is identical, while the
         per-kernel launch / dependent-load latency of one lane overlaps the others' kernels)."""
-        if infer_text:
-            raise NotImplementedError("refine-text generation (infer_text=True) is a 'next' row (SURVEY 8f-1)")
         if return_attn:
             raise NotImplementedError("return_attn is not supported by the fused attention kernel")
         context = context or Context()
-        plan = plan_from_processors(logits_processors)
+        plan = plan_from_processors(logits_processors, infer_text)
         lib, dev = self.lib, self.device
         B, T, nvq = inputs_ids.shape
         assert nvq == GPT.n_vq and emb.shape == (B, T, GPT.hidden)
+        nrow = 1 if infer_text else nvq                   # sampling rows per utterance (gpt.py:459-464 vs :439-440)
+        V = GPT.n_text if infer_text else GPT.n_audio
         max_new = int(max_new_token)
         if T + max_new > self.max_pos:
             raise ValueError(f"T + max_new_token = {T + max_new} exceeds max_position_embeddings {self.max_pos}")
@@ -287,14 +295,14 @@ class GptEngine:
         bounds = [shard_bounds(B, n_lanes, i) for i in range(n_lanes)]
         res = self._lane_resources(n_lanes)
         caller = torch.cuda.current_stream(dev)
-        draws = ExpDraws(total_rows if total_rows is not None else B * nvq, GPT.n_audio, manual_seed,
-                         row_begin=row_offset, row_end=row_offset + B * nvq)
+        draws = ExpDraws(total_rows if total_rows is not None else B * nrow, V, manual_seed,
+                         row_begin=row_offset, row_end=row_offset + B * nrow)
         ptab = penalty_table(plan.penalty)
         nq = 1 if draws.constant else self.NQ_RING
         emb_all = emb.to(torch.float32).contiguous().to(dev)
         ids_all = inputs_ids.to(dev)
         temp_d = temperature.to(torch.float32).reshape(-1).to(dev)
-        assert temp_d.numel() == nvq
+        assert temp_d.numel() == nrow, "temperature must have one entry per sampling row of an utterance"
         ptab_d = None if ptab is None else ptab.to(dev)
         caller.synchronize()  # inputs above were produced on the caller's stream
 
@@ -322,9 +330,9 @@ class GptEngine:
                 ln.stop_d = None if stop_at is None else stop_at[lo:hi].to(torch.int32).contiguous().to(dev)
                 ln.emb = emb_all[lo:hi].contiguous()
                 if draws.constant:
-                    ln.q_d = draws.step(0)[lo * nvq: hi * nvq].to(dev).reshape(1, Bl * nvq, GPT.n_audio).contiguous()
+                    ln.q_d = draws.step(0)[lo * nrow: hi * nrow].to(dev).reshape(1, Bl * nrow, V).contiguous()
                 else:
-                    ln.q_d = torch.empty((nq, Bl * nvq, GPT.n_audio), dtype=torch.float32, device=dev)
+                    ln.q_d = torch.empty((nq, Bl * nrow, V), dtype=torch.float32, device=dev)
             s = _lib.GenState()
             s.B, s.T, s.max_new = Bl, T, max_new
             s.ids_buf, s.len, s.kv_start = ln.ids_buf.data_ptr(), ln.len_d.data_ptr(), ln.kv_start.data_ptr()
@@ -337,13 +345,14 @@ class GptEngine:
             s.top_k = int(plan.top_k or 0)
             s.use_top_k = int(plan.top_k is not None)
             s.min_new, s.eos = int(min_new_token), int(eos_token)
-            s.row_offset = int(row_offset + lo * nvq)
+            s.row_offset = int(row_offset + lo * nrow)
+            s.infer_text = int(infer_text)
             s.stop_at = _lib.ptr(ln.stop_d)
             s.workspace, s.workspace_bytes = ln.workspace.data_ptr(), ws_bytes
             ln.s = s
             L.append(ln)
 
-        q_host = None if draws.constant else torch.empty((nq // 2, B * nvq, GPT.n_audio), dtype=torch.float32).pin_memory()
+        q_host = None if draws.constant else torch.empty((nq // 2, B * nrow, V), dtype=torch.float32).pin_memory()
         uploaded = 0  # steps whose Exp(1) draws are on the device (unseeded mode only)
 
         def ensure_q(upto: int):
@@ -360,7 +369,7 @@ class GptEngine:
                 slab = uploaded % nq
                 for ln in L:
                     with torch.cuda.stream(ln.st):
-                        ln.q_d[slab: slab + n].copy_(q_host[:n, ln.lo * nvq: ln.hi * nvq], non_blocking=True)
+                        ln.q_d[slab: slab + n].copy_(q_host[:n, ln.lo * nrow: ln.hi * nrow], non_blocking=True)
                 uploaded += n
 
         def outputs() -> GenerationOutputs:
@@ -368,7 +377,10 @@ class GptEngine:
             for ln in L:
                 with torch.cuda.stream(ln.st):
                     e = ln.end_idx.cpu().tolist()
-                ids += [ln.ids_buf[b, T: T + e[b]] for b in range(ln.hi - ln.lo)]                      # gpt.py:297-299
+                if infer_text:
+                    ids += [ln.ids_buf[b, T: T + e[b], 0] for b in range(ln.hi - ln.lo)]               # gpt.py:300-301
+                else:
+                    ids += [ln.ids_buf[b, T: T + e[b]] for b in range(ln.hi - ln.lo)]                  # gpt.py:297-299
                 if return_hidden:
                     hid += [ln.hiddens[b, : e[b]] for b in range(ln.hi - ln.lo)]                       # gpt.py:303-307
             for ln in L:

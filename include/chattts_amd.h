@@ -58,6 +58,10 @@ typedef struct {
   const float* rope_cos;           /* [max_pos,32] float32, built by the host with the reference's own ops */
   const float* rope_sin;
   float rms_eps;
+  /* refine-text mode (infer_text=True, gpt.py:406-407,439-440): optional, may be NULL / 0 */
+  const float* emb_text;           /* [n_text,768] */
+  const float* head_text;          /* [n_text,768] folded weight-norm text head */
+  int32_t n_text;                  /* 21178 */
 } ctts_gpt_weights;
 
 /* One generate() call's device state (every array is caller-allocated, device memory). */
@@ -85,6 +89,9 @@ typedef struct {
   const int32_t* stop_at;          /* [B] or NULL: benchmark length forcing, not a reference feature */
   void* workspace;                 /* >= ctts_gpt_workspace_bytes(B, T) */
   size_t workspace_bytes;
+  int32_t infer_text;              /* 1: refine-text mode -- text embedding/head, ONE sampling row per utterance (q is
+                                      [nq, B, n_text], temperature[0]), the sampled id is written to all 4 slots
+                                      (gpt.py:519-525); repetition penalty must be off */
 } ctts_gen_state;
 
 int ctts_gpt_create(ctts_gpt** out, const ctts_gpt_weights* w);

@@ -56,6 +56,16 @@ GEN_CASES = {
 }
 
 
+# refine-text mode (core.py:665-751 defaults: temperature 0.7, top_P 0.7, top_K 20, repetition_penalty 1.0)
+TEXT_EOS = 21000  # stands in for tokenizer.eos_token ([Ebreak]); any id works with synthetic weights
+TEXT_CASES = {
+    "text3": dict(B=3, t_min=9, t_max=15, pseed=4, temperature=[0.7], top_P=0.7, top_K=20, rep=1.0, max_new=24, min_new=2,
+                  manual_seed=12345, keep_hidden_rows=[2], keep_logit_steps=[0, 5]),
+    "text1_greedyish": dict(B=1, t_min=12, t_max=12, pseed=5, temperature=[0.3], top_P=0.1, top_K=3, rep=1.0, max_new=16, min_new=0,
+                            manual_seed=7, keep_hidden_rows=[0], keep_logit_steps=[0]),
+}
+
+
 def gen_inputs(c):
     return synth.make_prompts(c["B"], c["t_min"], c["t_max"], seed=c["pseed"])
 

@@ -71,6 +71,26 @@ def golden_generate(sds):
     np.savez_compressed(os.path.join(OUT, "generate.npz"), **out)
 
 
+def golden_text(sds):
+    embed, gpt = ref_harness.build_gpt(sds)
+    out = {}
+    for name, c in cases.TEXT_CASES.items():
+        ids, mask, tmask = cases.gen_inputs(c)
+        res, emb, cap = ref_harness.run_generate(
+            embed, gpt, ids, mask, tmask, temperature=c["temperature"], top_P=c["top_P"], top_K=c["top_K"],
+            repetition_penalty=c["rep"], max_new_token=c["max_new"], min_new_token=c["min_new"],
+            manual_seed=c["manual_seed"], capture_logits=True, infer_text=True, eos_token=cases.TEXT_EOS)
+        out[name + ".lens"] = np.array([r.shape[0] for r in res.ids], dtype=np.int64)
+        out[name + ".ids"] = np.concatenate([r.numpy().reshape(-1) for r in res.ids], 0)
+        for b in c["keep_hidden_rows"]:
+            out[name + f".hid{b}"] = res.hiddens[b].numpy()
+        for s in c["keep_logit_steps"]:
+            if s < len(cap):
+                out[name + f".tlogits{s}"] = cap[s].astype(np.float16)  # [B, 21178] logits / temperature (f16: size)
+        print(name, "steps", len(cap), "lens", out[name + ".lens"].tolist())
+    np.savez_compressed(os.path.join(OUT, "text.npz"), **out)
+
+
 def golden_codec(sds):
     dec = ref_harness.build_decoder(sds)
     out = {}
@@ -95,13 +115,15 @@ def main():
         for k in sorted(fp):
             f.write(f"{k} {fp[k]}\n")
         f.write(f"torch {torch.__version__}\n")
-    which = sys.argv[1:] or ["sampling", "generate", "codec"]
+    which = sys.argv[1:] or ["sampling", "generate", "codec", "text"]
     if "sampling" in which:
         golden_sampling()
     if "generate" in which:
         golden_generate(sds)
     if "codec" in which:
         golden_codec(sds)
+    if "text" in which:
+        golden_text(sds)
 
 
 if __name__ == "__main__":

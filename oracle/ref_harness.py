@@ -90,13 +90,15 @@ def build_gpt(sds: dict):
 
 def run_generate(embed, gpt, input_ids, attention_mask, text_mask, *, temperature, top_P, top_K,
                  repetition_penalty, max_new_token, min_new_token, manual_seed, extra_processors=(),
-                 capture_logits=False):
+                 capture_logits=False, infer_text=False, eos_token=None):
     """`Chat._infer_code` from `gen_logits` on (core.py:580-658), minus tokenizer/speaker."""
     m = ref_modules()
     ids = torch.from_numpy(input_ids)
     am = torch.from_numpy(attention_mask)
     tm = torch.from_numpy(text_mask)
-    num_code = gpt.num_audio_tokens - 1
+    num_code = (gpt.num_audio_tokens - 1) if not infer_text else gpt.num_text_tokens  # core.py:580 / :682-687
+    if eos_token is None:
+        eos_token = num_code
     warpers, procs = m["processors"].gen_logits(num_code=num_code, top_P=top_P, top_K=top_K,
                                                 repetition_penalty=repetition_penalty)
     emb = embed(ids, tm)
@@ -109,9 +111,9 @@ def run_generate(embed, gpt, input_ids, attention_mask, text_mask, *, temperatur
         plist = [spy] + plist
     out = None
     for out in gpt.generate(
-        emb, ids, temperature=torch.tensor(temperature), eos_token=num_code, attention_mask=am,
+        emb, ids, temperature=torch.tensor(temperature), eos_token=eos_token, attention_mask=am,
         max_new_token=max_new_token, min_new_token=min_new_token, logits_processors=tuple(plist),
-        infer_text=False, return_hidden=True, stream=False, show_tqdm=False, ensure_non_empty=True,
+        infer_text=infer_text, return_hidden=True, stream=False, show_tqdm=False, ensure_non_empty=True,
         manual_seed=manual_seed,
     ):
         pass

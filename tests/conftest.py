@@ -34,4 +34,4 @@ def weights():
 
 @pytest.fixture(scope="session")
 def golden():
-    return {n: np.load(os.path.join(GOLDEN, n + ".npz")) for n in ("sampling", "generate", "codec")}
+    return {n: np.load(os.path.join(GOLDEN, n + ".npz")) for n in ("sampling", "generate", "codec", "text")}

@@ -214,3 +214,38 @@ def test_chat_facade_stream_and_batch(weights):
     assert len(out) == 1 and max(int(t.shape[0]) for t in out[0].ids) <= 16
     chat.unload()
     assert not chat.has_loaded()
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+@pytest.mark.parametrize("name", list(cases.TEXT_CASES))
+def test_refine_text_mode_bit_exact(gpt_f32, golden, name, use_graph):
+    """infer_text=True: text embedding, 21178-way head, block-wide sampling kernel; token ids
+    bit-exact vs the reference run (tests/golden/text.npz)"""
+    c = cases.TEXT_CASES[name]
+    Gd = golden["text"]
+    ids, mask, tmask = cases.gen_inputs(c)
+    ids_t, mask_t = torch.from_numpy(ids), torch.from_numpy(mask)
+    emb = gpt_f32.embed_prompt(ids_t, torch.from_numpy(tmask))
+    warpers, procs = E.gen_logits(21178, c["top_P"], c["top_K"], c["rep"])
+    out = list(gpt_f32.generate(emb, ids_t, torch.tensor(c["temperature"]), cases.TEXT_EOS, mask_t, c["max_new"], c["min_new"],
+                                (*procs, *warpers), infer_text=True, return_hidden=True, manual_seed=c["manual_seed"],
+                                use_graph=use_graph))[-1]
+    assert all(t.dim() == 1 for t in out.ids)
+    assert np.array_equal(np.array([int(t.shape[0]) for t in out.ids]), Gd[name + ".lens"])
+    assert np.array_equal(np.concatenate([t.cpu().numpy() for t in out.ids]), Gd[name + ".ids"])
+    for b in c["keep_hidden_rows"]:
+        assert np.abs(out.hiddens[b].cpu().numpy() - Gd[name + f".hid{b}"]).max() < 2e-4
+
+
+def test_refine_text_facade_and_rejections(weights):
+    from chattts_amd.core import Chat, RefineTextParams
+    chat = Chat()
+    chat.load(state_dicts=weights, device=DEV, dtype="bf16")
+    ids, mask, tmask = synth.make_prompts(5, 6, 14, seed=8)
+    a = (torch.from_numpy(ids), torch.from_numpy(mask), torch.from_numpy(tmask))
+    out = chat.refine_text_ids(*a, cases.TEXT_EOS, RefineTextParams(max_new_token=20, manual_seed=1, show_tqdm=False),
+                               stop_at=torch.tensor([3, 20, 7, 1, 12], dtype=torch.int32))
+    assert [int(t.shape[0]) for t in out.ids] == [3, 20, 7, 1, 12]
+    assert all(int(t.max()) < 21178 and int(t.min()) >= 0 and (t != cases.TEXT_EOS).all() for t in out.ids)
+    with pytest.raises(NotImplementedError):   # the reference's penalty processor mis-broadcasts in text mode
+        chat.refine_text_ids(*a, cases.TEXT_EOS, RefineTextParams(repetition_penalty=1.2, max_new_token=4, manual_seed=1))

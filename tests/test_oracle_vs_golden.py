@@ -63,6 +63,28 @@ def test_generate(golden, np_model, name):
             assert np.abs(got - G[key]).max() < 2e-3, s
 
 
+@pytest.mark.parametrize("name", list(cases.TEXT_CASES))
+def test_generate_refine_text_mode(golden, np_model, name):
+    """infer_text=True (refine-text): text head, one row per utterance, ids replicated over the 4 slots"""
+    llama, esd, _ = np_model
+    c = cases.TEXT_CASES[name]
+    G = golden["text"]
+    ids, mask, tmask = cases.gen_inputs(c)
+    B = ids.shape[0]
+    draws = rng.ExpDraws(B, 21178, c["manual_seed"])
+    res = generate_np.generate(
+        llama, esd, generate_np.fold_head_text(esd), generate_np.embed_prompt(esd, ids, tmask), ids, mask,
+        temperature=np.array(c["temperature"], np.float32), draw_q=lambda i: draws.step(i).numpy(), top_p=c["top_P"], top_k=c["top_K"],
+        pow_table=None, max_new_token=c["max_new"], min_new_token=c["min_new"], eos=cases.TEXT_EOS, infer_text=True, keep_logits=True)
+    assert np.array_equal(np.array([r.shape[0] for r in res.ids]), G[name + ".lens"])
+    assert np.array_equal(np.concatenate(res.ids, 0), G[name + ".ids"])
+    for b in c["keep_hidden_rows"]:
+        assert np.abs(res.hiddens[b] - G[name + f".hid{b}"]).max() < 2e-4
+    for s in c["keep_logit_steps"]:
+        got = res.logits[s] / np.float32(c["temperature"][0])
+        assert np.abs(got - G[name + f".tlogits{s}"].astype(np.float32)).max() < 3e-2  # golden stored as float16
+
+
 @pytest.mark.parametrize("name", list(cases.CODEC_CASES))
 def test_codec(golden, weights, name):
     c = cases.CODEC_CASES[name]
