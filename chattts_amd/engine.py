@@ -312,7 +312,7 @@ class GptEngine:
         L = []
         for (lo, hi), (handle, st) in zip(bounds, res):
             ln = Lane()
-            ln.lo, ln.hi, ln.handle, ln.st, ln.done = lo, hi, handle, st, False
+            ln.lo, ln.hi, ln.handle, ln.st, ln.done, ln.end_snap = lo, hi, handle, st, False, None
             Bl = hi - lo
             with torch.cuda.stream(st):
                 ln.ids_buf = torch.zeros((Bl, T + max_new, nvq), dtype=torch.int64, device=dev)  # gpt.py:372-379
@@ -373,26 +373,51 @@ class GptEngine:
                 uploaded += n
 
         def outputs() -> GenerationOutputs:
+            """Snapshot of the result so far.  Uses each lane's `end_snap` (host copy of end_idx taken by the last
+            poll) and makes the caller's stream wait for the poll-time event only, so a chunk that was already
+            enqueued behind the poll keeps running while the consumer (e.g. the DVAE/Vocos decode of a streamed
+            prefix) works on the caller's stream -- the two overlap on the GPU."""
             ids, hid = [], []
             for ln in L:
-                with torch.cuda.stream(ln.st):
-                    e = ln.end_idx.cpu().tolist()
+                e = ln.end_snap
                 if infer_text:
                     ids += [ln.ids_buf[b, T: T + e[b], 0] for b in range(ln.hi - ln.lo)]               # gpt.py:300-301
                 else:
                     ids += [ln.ids_buf[b, T: T + e[b]] for b in range(ln.hi - ln.lo)]                  # gpt.py:297-299
                 if return_hidden:
                     hid += [ln.hiddens[b, : e[b]] for b in range(ln.hi - ln.lo)]                       # gpt.py:303-307
-            for ln in L:
-                caller.wait_stream(ln.st)
+                caller.wait_event(ln.ev)
             return GenerationOutputs(ids=ids, attentions=[], hiddens=hid)
+
+        def poll(ln):
+            """stream-ordered D2H of the lane's finish flags and end_idx (+ sync), and the event outputs() waits on"""
+            with torch.cuda.stream(ln.st):
+                fin = ln.finish.cpu()
+                ln.end_snap = ln.end_idx.cpu().tolist()
+                ln.ev.record(ln.st)
+            ln.done = bool(fin.all())
+            return fin
+
+        def enqueue(n):
+            ensure_q(steps_done + n)
+            for ln in L:
+                if ln.done:
+                    continue
+                if graph_ok:
+                    _lib.check(lib.ctts_gpt_graph_launch(ln.handle, n, ln.st.cuda_stream), "ctts_gpt_graph_launch")
+                else:
+                    for _ in range(n):
+                        _lib.check(lib.ctts_gpt_decode_step(ln.handle, C.byref(ln.s), ln.st.cuda_stream), "ctts_gpt_decode_step")
 
         # ---- step 0: prefill ----
         ensure_q(1)
         for ln in L:
             _lib.check(lib.ctts_gpt_prefill(ln.handle, C.byref(ln.s), ln.emb.data_ptr(), ln.st.cuda_stream), "ctts_gpt_prefill")
         steps_done = 1
-        fin0 = torch.cat([ln.finish.cpu() for ln in L])  # syncs: the step-0 rule needs it (gpt.py:527)
+        graph_ok = False
+        for ln in L:
+            ln.ev = torch.cuda.Event()
+        fin0 = torch.cat([poll(ln) for ln in L])  # syncs: the step-0 rule needs it (gpt.py:527)
         if bool(fin0.any()):
             self.logger.warning("unexpected end at index %s", str(fin0.nonzero().flatten().tolist()))
             if ensure_non_empty and manual_seed is None:
@@ -412,36 +437,35 @@ class GptEngine:
             _lib.check(lib.ctts_gpt_profile_begin(L[0].handle, int(profile_tag), 4096, int(profile_stride)), "profile_begin")
 
         chunk = stream_batch if stream else self.POLL
-        all_done = False
+        all_done = all(ln.done for ln in L)
         interrupted = False
+        # the reference yields when (i+1) % stream_batch == 0: keep chunk ends on those steps
+        next_n = lambda done: min(chunk - (done % chunk), max_new - done)
         try:
-            while steps_done < max_new and not all_done:
-                # the reference yields when (i+1) % stream_batch == 0: keep chunk ends on those steps
-                n = min(chunk - (steps_done % chunk), max_new - steps_done)
-                ensure_q(steps_done + n)
-                for ln in L:
-                    if ln.done:
-                        continue
-                    if graph_ok:
-                        _lib.check(lib.ctts_gpt_graph_launch(ln.handle, n, ln.st.cuda_stream), "ctts_gpt_graph_launch")
-                    else:
-                        for _ in range(n):
-                            _lib.check(lib.ctts_gpt_decode_step(ln.handle, C.byref(ln.s), ln.st.cuda_stream), "ctts_gpt_decode_step")
-                steps_done += n
+            pending = 0
+            if steps_done < max_new and not all_done:
+                pending = next_n(steps_done)
+                enqueue(pending)
+            while pending:
                 for ln in L:
                     if not ln.done:
-                        with torch.cuda.stream(ln.st):
-                            ln.done = bool(ln.finish.cpu().all())  # stream-ordered D2H + sync of that lane
+                        poll(ln)
+                steps_done += pending
+                pending = 0
                 all_done = all(ln.done for ln in L)
                 if context.get():  # gpt.py:592
                     interrupted = True
                     break
+                if steps_done < max_new and not all_done:
+                    # run ahead: the next chunk is enqueued BEFORE the consumer gets this one
+                    pending = next_n(steps_done)
+                    enqueue(pending)
                 if stream:
                     emit = False
                     if not all_done and steps_done % stream_batch == 0:
                         emit = True                                      # gpt.py:579-589
                     elif all_done:
-                        i_star = max(int(ln.end_idx.max().item()) for ln in L)   # step at which the last row hit EOS
+                        i_star = max(max(ln.end_snap) for ln in L)       # step at which the last row hit EOS
                         emit = i_star > 0 and i_star % stream_batch == 0  # the reference's duplicate yield (stream_iter quirk)
                     if emit:
                         yield outputs()
@@ -460,6 +484,9 @@ class GptEngine:
             else:
                 self.logger.warning(f"incomplete result. hit max_new_token: {max_new_token}")   # gpt.py:601-607
         self.last_stats.update(steps=steps_done, B=B, T=T, lanes=n_lanes)
+        for ln in L:
+            if not ln.done or ln.end_snap is None:
+                poll(ln)
         yield outputs()
 
 
