@@ -45,6 +45,26 @@ def test_plan_from_processors_accepts_reference_objects():
         E.plan_from_processors([lambda ids, scores: scores])
     with pytest.raises(NotImplementedError):  # wrong order
         E.plan_from_processors([E.TopK(5), E.TopP(0.5)])
+    # refine-text mode: warpers are fine, a repetition penalty is rejected (the reference's processor mis-broadcasts there)
+    assert E.plan_from_processors(E.gen_logits(21178, 0.7, 20, 1.0)[0], infer_text=True).top_k == 20
+    with pytest.raises(NotImplementedError):
+        E.plan_from_processors(E.gen_logits(21178, 0.7, 20, 1.2)[1], infer_text=True)
+
+
+def test_split_bf16_reconstructs_f32():
+    w = torch.randn(37, 100) * 3
+    p = E.split_bf16(w)
+    assert p.shape == (2, 37, 128) and p.dtype == torch.bfloat16
+    rec = p[0, :, :100].float() + p[1, :, :100].float()
+    assert float((rec - w).abs().max() / w.abs().max()) < 2 ** -15
+    assert float(p[:, :, 100:].abs().max()) == 0.0
+
+
+def test_rope_row_perm_is_a_permutation_pairing_halves():
+    perm = E.rope_row_perm()
+    assert sorted(perm.tolist()) == list(range(768))
+    t = perm.view(12, 4, 16)
+    assert torch.equal(t[:, :, 8:] - t[:, :, :8], torch.full((12, 4, 8), 32))
 
 
 def test_left_pad_starts():
