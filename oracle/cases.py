@@ -50,6 +50,10 @@ GEN_CASES = {
     # mixed-length left-padded batch, default sampling
     "b8": dict(B=8, t_min=12, t_max=28, pseed=1, temperature=[0.3] * 4, top_P=0.7, top_K=20, rep=1.05,
                max_new=64, min_new=8, manual_seed=42, keep_hidden_rows=[0, 5], keep_logit_steps=[0, 1, 30, 63]),
+    # long run: 320 autoregressive steps (context up to ~350 keys: several attention blocks per wave); any argmax flip
+    # anywhere would diverge the whole suffix
+    "long": dict(B=2, t_min=20, t_max=30, pseed=3, temperature=[0.3] * 4, top_P=0.7, top_K=20, rep=1.05,
+                 max_new=320, min_new=320, manual_seed=1234, keep_hidden_rows=[], keep_logit_steps=[]),
     # per-codebook temperatures, no seed => torch global CPU generator advances per step
     "unseeded": dict(B=2, t_min=10, t_max=14, pseed=2, temperature=[0.3, 0.5, 0.7, 1.0], top_P=0.7, top_K=20, rep=1.05,
                      max_new=24, min_new=0, manual_seed=None, global_seed=7, keep_hidden_rows=[1], keep_logit_steps=[0, 23]),
