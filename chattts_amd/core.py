@@ -150,3 +150,31 @@ class Chat:
             new_wavs = wavs[:, length:]
             keep_cols = np.sum(np.abs(new_wavs) > 1e-5, axis=0) > 0
             yield new_wavs[:, keep_cols]
+
+    def infer_tokens(self, input_ids, attention_mask, text_mask, params: InferCodeParams = InferCodeParams(),
+                     stream: bool = False, split_text: bool = False, max_split_batch: int = 4, **kw):
+        """`Chat.infer(..., skip_refine_text=True)` from the point where text has become tokens
+        (core.py:208-270 + `_infer` :455-503): batches of `max_split_batch` rows when `split_text` (else one
+        batch), then the sample-level silence strip of :258-268 (`wav[|wav| > 1e-5]`, also mid-utterance) and,
+        with `split_text`, one concatenated waveform.  `stream=True` returns the chunk generator instead.
+        `interrupt()` state is cleared first, like core.py:223."""
+        self.context.set(False)
+        B = int(input_ids.shape[0])
+        if B == 0:
+            return []
+        if stream:
+            return self.infer_ids_stream(input_ids, attention_mask, text_mask, params, **kw)
+        step = max_split_batch if split_text else B
+        thr = np.float32(1e-5)
+        stripped = []
+        for lo in range(0, B, step):
+            sl = slice(lo, min(lo + step, B))
+            kw_b = dict(kw)
+            if "stop_at" in kw_b and kw_b["stop_at"] is not None:
+                kw_b["stop_at"] = kw_b["stop_at"][sl]
+            wavs = self.infer_ids(input_ids[sl], attention_mask[sl], text_mask[sl], params, **kw_b)
+            for wav in wavs:
+                stripped.append(wav[np.abs(wav) > thr])
+        if split_text:
+            return [np.concatenate(stripped)]
+        return stripped

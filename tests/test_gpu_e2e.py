@@ -209,6 +209,11 @@ def test_chat_facade_stream_and_batch(weights):
     assert [c.shape[1] for c in chunks[:3]] == [12000, 12000, 12000]
     assert len(chunks) == 4 and chunks[3].shape[1] <= wav.shape[1] - 36000
     assert all(c.shape[0] == 4 and np.isfinite(c).all() for c in chunks)
+    # Chat.infer-level post-processing: silence strip per row, concatenation with split_text (core.py:258-270)
+    rows = chat.infer_tokens(*args, stop_at=stop)
+    assert len(rows) == 4 and all(r.ndim == 1 and (np.abs(r) > 1e-5).all() for r in rows)
+    one = chat.infer_tokens(*args, split_text=True, max_split_batch=2, stop_at=stop)
+    assert len(one) == 1 and one[0].ndim == 1 and one[0].size > 0
     chat.interrupt()
     out = list(chat.infer_code(*args[:3], p, stop_at=stop))  # interrupted before the first poll completes a chunk
     assert len(out) == 1 and max(int(t.shape[0]) for t in out[0].ids) <= 16
