@@ -382,13 +382,21 @@ void gemm_fast_k(FastGemmArgs a) {
     for (int mb = 0; mb < MB; ++mb) acc[na][mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int nper = K / (KC * NW);
+  const bool w_once = gridDim.y == 1 && a.w_nt;
   for (int i = 0; i < nper; i += U) {
     u128 wf[NACC][U], af[MB][U];
+    // W is streamed once when a single M tile covers all rows (decode): non-temporal then; when several M
+    // tiles re-read it (o/down at 16-row tiles, prefill) the normal policy keeps it in L2 for the others
 #pragma unroll
     for (int j = 0; j < U; ++j) {
       const int k0 = (wave * nper + i + j) * KC;  // contiguous K range per wave: whole 128-B lines of a row stay in one wave
-      wf[0][j] = *reinterpret_cast<const u128*>(wrow + k0);
-      if (NACC == 2) wf[1][j] = *reinterpret_cast<const u128*>(wrow2 + k0);
+      if (w_once) {
+        wf[0][j] = load16_nt(wrow + k0);
+        if (NACC == 2) wf[1][j] = load16_nt(wrow2 + k0);
+      } else {
+        wf[0][j] = load16(wrow + k0);
+        if (NACC == 2) wf[1][j] = load16(wrow2 + k0);
+      }
     }
 #pragma unroll
     for (int j = 0; j < U; ++j) {
@@ -504,7 +512,13 @@ static hipError_t fast_dispatch(const FastGemmArgs& a, hipStream_t st) {
   return hipGetLastError();
 }
 
-hipError_t launch_gemm_fast(const FastGemmArgs& a, hipStream_t st) {
+hipError_t launch_gemm_fast(const FastGemmArgs& a_in, hipStream_t st) {
+  FastGemmArgs a = a_in;
+  {
+    static int nt = -1;
+    if (nt < 0) { const char* e = getenv("CTTS_W_NT"); nt = e ? atoi(e) : 1; }
+    a.w_nt = nt;
+  }
   if (a.M <= 0 || a.N <= 0 || (a.lda % 8) != 0) return hipErrorInvalidValue;
   if (a.epi == FEPI_RES && a.N != 16 * SSQ_PARTS) return hipErrorInvalidValue;
   if (a.epi == FEPI_QKV_ROPE && (a.N != 2304 || a.K != 768)) return hipErrorInvalidValue;

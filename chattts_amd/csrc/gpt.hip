@@ -162,6 +162,7 @@ __global__ __launch_bounds__(64 * NW) void attention_k(const float* __restrict__
   constexpr int NI = 4;             // load instructions per block and operand (K and V): 8 loads per block in flight,
                                     // and the NEXT block's 8 are issued before the current block is consumed
   constexpr int KB = KPI * NI;      // keys per wave-block: 32 / 16
+  constexpr bool KV_NT = NW > 1;    // decode: every KV byte is read once per step by exactly one workgroup -> non-temporal
   __shared__ float sm_m[NW], sm_l[NW], sm_acc[NW][HDIM];
 
   const int h = blockIdx.x, m = blockIdx.y;
@@ -199,9 +200,11 @@ __global__ __launch_bounds__(64 * NW) void attention_k(const float* __restrict__
   const int jlast = max(jend - 1, jlo);
   auto load_blk = [&](u128* kr, u128* vr, int j0) {
 #pragma unroll
-    for (int i = 0; i < NI; ++i) kr[i] = *reinterpret_cast<const u128*>(kbase + (size_t)min(j0 + i * KPI + kg, jlast) * HDIM);
+    for (int i = 0; i < NI; ++i) kr[i] = KV_NT ? load16_nt(kbase + (size_t)min(j0 + i * KPI + kg, jlast) * HDIM)
+                                               : load16(kbase + (size_t)min(j0 + i * KPI + kg, jlast) * HDIM);
 #pragma unroll
-    for (int i = 0; i < NI; ++i) vr[i] = *reinterpret_cast<const u128*>(vbase + (size_t)min(j0 + i * KPI + kg, jlast) * HDIM);
+    for (int i = 0; i < NI; ++i) vr[i] = KV_NT ? load16_nt(vbase + (size_t)min(j0 + i * KPI + kg, jlast) * HDIM)
+                                               : load16(vbase + (size_t)min(j0 + i * KPI + kg, jlast) * HDIM);
   };
   auto use_blk = [&](const u128* kr, const u128* vr, int j0) {
     float s[NI];

@@ -77,6 +77,7 @@ struct FastGemmArgs {
   const float* cos_t; const float* sin_t;                     // [max_pos, 32]
   uint16_t* kc; uint16_t* vc; int cmax;                       // this layer's bf16 K / V cache [B,12,cmax,64]
   int force_mb;                 // tests only: 0 = heuristic
+  int w_nt;                     // 1: non-temporal W loads when a single M tile reads W (set by the launcher, env CTTS_W_NT=0 disables)
   long long* dbg;               // probes only: [n_workgroups][8] phase stamps, or null
 };
 hipError_t launch_gemm_fast(const FastGemmArgs& a, hipStream_t st);
