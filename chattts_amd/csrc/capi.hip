@@ -39,6 +39,7 @@ struct ctts_gpt {
   // profiling (eager decode only)
   int prof_tag = -1;
   int prof_max = 0;
+  bool skip_finished = true;  // env CTTS_SKIP_FINISHED=0 restores the reference's "finished rows keep stepping"
   int prof_stride = 1;   // time every prof_stride-th launch of the tag
   int prof_seen = 0;
   std::vector<hipEvent_t> ev0, ev1;
@@ -82,6 +83,7 @@ extern "C" int ctts_gpt_create(ctts_gpt** out, const ctts_gpt_weights* w) {
   g->wd.assign(w->wd, w->wd + L);
   g->ln1.assign(w->ln1, w->ln1 + L);
   g->ln2.assign(w->ln2, w->ln2 + L);
+  { const char* e = getenv("CTTS_SKIP_FINISHED"); if (e && atoi(e) == 0) g->skip_finished = false; }
   *out = g;
   return 0;
 }
@@ -148,7 +150,7 @@ static int run_step(ctts_gpt* g, const ctts_gen_state* s, int q_per_b, hipStream
   const int B = s->B, M = B * q_per_b, cmax = s->T + s->max_new;
   const int wt = g->w.weight_dtype, kt = g->w.kv_dtype;
   const size_t kv_layer = (size_t)B * NHEAD * cmax * HDIM * (kt == CTTS_BF16 ? 2 : 4);
-  GptRowMap rm{q_per_b, s->len, s->kv_start};
+  GptRowMap rm{q_per_b, s->len, s->kv_start, (q_per_b == 1 && g->skip_finished) ? s->finish : nullptr};
   const bool fast = wt == CTTS_BF16;  // perf mode: bf16 activations, RMSNorm gain folded into wqkv / wgu by the loader
   for (int l = 0; fast && l < g->w.n_layers; ++l) {
     void* kc = (char*)s->kcache + kv_layer * l;
@@ -451,13 +453,13 @@ extern "C" int ctts_k_rows_prep(const float* x32, uint16_t* xb, float* ssq, int3
 extern "C" int ctts_k_rope_append(float* qkv, void* kcache, void* vcache, int32_t kv_dtype, int32_t cmax, const float* cos_tab,
                                   const float* sin_tab, int32_t q_per_b, const int32_t* len, const int32_t* kv_start, int32_t M,
                                   void* stream) {
-  GptRowMap rm{q_per_b, len, kv_start};
+  GptRowMap rm{q_per_b, len, kv_start, nullptr};
   CK(launch_rope_append(qkv, kcache, vcache, kv_dtype, cmax, cos_tab, sin_tab, rm, M, (hipStream_t)stream));
   return 0;
 }
 extern "C" int ctts_k_attention(const float* qkv, const void* kcache, const void* vcache, int32_t kv_dtype, int32_t cmax, float* out,
                                 int32_t q_per_b, const int32_t* len, const int32_t* kv_start, int32_t M, void* stream) {
-  GptRowMap rm{q_per_b, len, kv_start};
+  GptRowMap rm{q_per_b, len, kv_start, nullptr};
   CK(launch_attention(qkv, kcache, vcache, kv_dtype, cmax, out, 0, rm, M, (hipStream_t)stream));
   return 0;
 }

@@ -170,6 +170,7 @@ __global__ __launch_bounds__(64 * NW) void attention_k(const float* __restrict__
   const int kg = lane / LPK, dl = lane % LPK;
   int b, slot;
   row_to_b_slot(rm, m, b, slot);
+  if (rm.finish != nullptr && rm.finish[b]) return;  // finished row: nothing downstream of it is ever read
   int jlo = rm.kv_start[b];
   if (jlo > slot) jlo = slot;  // pad query row: sees only itself (its output is never consumed)
 

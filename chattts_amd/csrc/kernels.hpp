@@ -93,6 +93,9 @@ struct GptRowMap {
   int q_per_b;
   const int32_t* len;       // [B] tokens present in ids_buf (prompt + generated)   (decode)
   const int32_t* kv_start;  // [B] left-pad slots (attention_mask == 0 there)
+  const uint8_t* finish;    // [B] or null (decode): rows that already sampled EOS.  The reference keeps stepping them
+                            // until every row is done (gpt.py:512-518,592) but truncates their output at end_idx, so
+                            // their per-step work is unobservable: the attention kernel skips their KV read.
 };
 
 hipError_t launch_embed_codes(const float* emb_code /*[4,626,768]*/, const int64_t* ids_buf, int ids_row_stride /*Tcap*/,
