@@ -125,7 +125,7 @@ static SampleArgs make_sample_args(const ctts_gen_state* s, const float* logits)
   a.end_idx = s->end_idx; a.q = s->q; a.nq = s->nq; a.temperature = s->temperature; a.pow_table = s->pow_table;
   a.top_p_thr = s->top_p_thr; a.use_top_p = s->use_top_p; a.top_k = s->top_k; a.use_top_k = s->use_top_k;
   a.min_new = s->min_new; a.eos = s->eos; a.row_offset = s->row_offset; a.max_input_ids = NAUDIO - 1; a.stop_at = s->stop_at;
-  a.B = s->B;
+  a.B = s->B; a.row_map = nullptr; a.n_active = nullptr;
   return a;
 }
 
@@ -150,7 +150,10 @@ static int run_step(ctts_gpt* g, const ctts_gen_state* s, int q_per_b, hipStream
   const int B = s->B, M = B * q_per_b, cmax = s->T + s->max_new;
   const int wt = g->w.weight_dtype, kt = g->w.kv_dtype;
   const size_t kv_layer = (size_t)B * NHEAD * cmax * HDIM * (kt == CTTS_BF16 ? 2 : 4);
-  GptRowMap rm{q_per_b, s->len, s->kv_start, (q_per_b == 1 && g->skip_finished) ? s->finish : nullptr};
+  const bool dec = q_per_b == 1;
+  const int32_t* rmap = dec ? s->row_map : nullptr;      // decode rows are compact (see GptRowMap); prefill is 1:1
+  const int32_t* nact = dec ? s->n_active : nullptr;
+  GptRowMap rm{q_per_b, s->len, s->kv_start, rmap, nact, (dec && g->skip_finished) ? s->finish : nullptr};
   const bool fast = wt == CTTS_BF16;  // perf mode: bf16 activations, RMSNorm gain folded into wqkv / wgu by the loader
   for (int l = 0; fast && l < g->w.n_layers; ++l) {
     void* kc = (char*)s->kcache + kv_layer * l;
@@ -159,7 +162,7 @@ static int run_step(ctts_gpt* g, const ctts_gen_state* s, int q_per_b, hipStream
     uint16_t* actb = (uint16_t*)ws.act;
     FastGemmArgs f;
     memset(&f, 0, sizeof(f));
-    f.M = M; f.eps = g->w.rms_eps;
+    f.M = M; f.eps = g->w.rms_eps; f.n_active = nact; f.row_map = rmap;
     // RMSNorm + QKV + RoPE + KV append in one launch (q/k weight rows are permuted by the loader)
     f.A = ws.xb; f.lda = HID; f.W = (const uint16_t*)g->wqkv[l]; f.N = 3 * HID; f.K = HID; f.ssq_in = ws.ssq; f.epi = FEPI_QKV_ROPE;
     f.C32 = ws.qkv; f.ldc = 3 * HID;
@@ -183,6 +186,7 @@ static int run_step(ctts_gpt* g, const ctts_gen_state* s, int q_per_b, hipStream
     GemmArgs a;
     memset(&a, 0, sizeof(a));
     a.taps = 1;
+    a.n_active = nact;
     // RMSNorm + QKV
     a.A = ws.x; a.lda = HID; a.W = g->wqkv[l]; a.C = ws.qkv; a.ldc = 3 * HID; a.M = M; a.N = 3 * HID; a.K = HID; a.wt = wt;
     a.epi = EPI_STORE; a.norm_w = g->ln1[l]; a.eps = g->w.rms_eps;
@@ -203,21 +207,23 @@ static int run_step(ctts_gpt* g, const ctts_gen_state* s, int q_per_b, hipStream
     { Prof p(g, 6, st, prof_ok); CK(launch_gemm_skinny(a, st)); }
   }
   { Prof p(g, 7, st, prof_ok);
-    CK(launch_final_norm(ws.x, q_per_b, g->w.norm, g->w.rms_eps, ws.hfin, s->hiddens, s->max_new, s->len, s->T, B, st)); }
+    CK(launch_final_norm(ws.x, q_per_b, g->w.norm, g->w.rms_eps, ws.hfin, s->hiddens, s->max_new, s->len, s->T, B, rmap, nact, st)); }
   {
     const int nlog = s->infer_text ? g->w.n_text : NVQ * NAUDIO;   // gpt.py:439-440 text head | :441-454 four code heads
     GemmArgs a;
     memset(&a, 0, sizeof(a));
     a.taps = 1;
     a.A = ws.hfin; a.lda = HID; a.W = s->infer_text ? g->w.head_text : g->w.heads; a.C = ws.logits; a.ldc = nlog; a.M = B; a.N = nlog;
-    a.K = HID; a.wt = WT_F32; a.epi = EPI_STORE;
+    a.K = HID; a.wt = WT_F32; a.epi = EPI_STORE; a.n_active = nact;
     Prof p(g, 8, st, prof_ok);
     CK(launch_gemm_skinny(a, st));
   }
   {
     Prof p(g, 9, st, prof_ok);
-    if (s->infer_text) CK(launch_sample_text(make_sample_args(s, ws.logits), g->w.n_text, st));
-    else CK(launch_sample(make_sample_args(s, ws.logits), st));
+    SampleArgs sa = make_sample_args(s, ws.logits);
+    sa.row_map = rmap; sa.n_active = nact;
+    if (s->infer_text) CK(launch_sample_text(sa, g->w.n_text, st));
+    else CK(launch_sample(sa, st));
   }
   return 0;
 }
@@ -236,9 +242,10 @@ static int decode_body(ctts_gpt* g, const ctts_gen_state* s, hipStream_t st, boo
   { Prof p(g, 0, st, prof_ok); const bool fast = g->w.weight_dtype == CTTS_BF16;
     if (s->infer_text)
       CK(launch_embed_text(g->w.emb_text, g->w.n_text, s->ids_buf, s->T + s->max_new, s->len, ws.x, fast ? ws.xb : nullptr,
-                           fast ? ws.ssq : nullptr, s->B, st));
+                           fast ? ws.ssq : nullptr, s->B, s->row_map, s->n_active, st));
     else
-      CK(launch_embed_codes(g->w.emb_code, s->ids_buf, s->T + s->max_new, s->len, ws.x, fast ? ws.xb : nullptr, fast ? ws.ssq : nullptr, s->B, st)); }
+      CK(launch_embed_codes(g->w.emb_code, s->ids_buf, s->T + s->max_new, s->len, ws.x, fast ? ws.xb : nullptr, fast ? ws.ssq : nullptr, s->B,
+                            s->row_map, s->n_active, st)); }
   return run_step(g, s, 1, st, prof_ok);
 }
 
@@ -453,24 +460,24 @@ extern "C" int ctts_k_rows_prep(const float* x32, uint16_t* xb, float* ssq, int3
 extern "C" int ctts_k_rope_append(float* qkv, void* kcache, void* vcache, int32_t kv_dtype, int32_t cmax, const float* cos_tab,
                                   const float* sin_tab, int32_t q_per_b, const int32_t* len, const int32_t* kv_start, int32_t M,
                                   void* stream) {
-  GptRowMap rm{q_per_b, len, kv_start, nullptr};
+  GptRowMap rm{q_per_b, len, kv_start, nullptr, nullptr, nullptr};
   CK(launch_rope_append(qkv, kcache, vcache, kv_dtype, cmax, cos_tab, sin_tab, rm, M, (hipStream_t)stream));
   return 0;
 }
 extern "C" int ctts_k_attention(const float* qkv, const void* kcache, const void* vcache, int32_t kv_dtype, int32_t cmax, float* out,
                                 int32_t q_per_b, const int32_t* len, const int32_t* kv_start, int32_t M, void* stream) {
-  GptRowMap rm{q_per_b, len, kv_start, nullptr};
+  GptRowMap rm{q_per_b, len, kv_start, nullptr, nullptr, nullptr};
   CK(launch_attention(qkv, kcache, vcache, kv_dtype, cmax, out, 0, rm, M, (hipStream_t)stream));
   return 0;
 }
 extern "C" int ctts_k_embed_codes(const float* emb_code, const int64_t* ids_buf, int32_t tcap, const int32_t* len, float* x, int32_t B,
                                   void* stream) {
-  CK(launch_embed_codes(emb_code, ids_buf, tcap, len, x, nullptr, nullptr, B, (hipStream_t)stream));
+  CK(launch_embed_codes(emb_code, ids_buf, tcap, len, x, nullptr, nullptr, B, nullptr, nullptr, (hipStream_t)stream));
   return 0;
 }
 extern "C" int ctts_k_final_norm(const float* x, int32_t q_per_b, const float* w, float eps, float* hfin, float* hiddens,
                                  int32_t max_new, const int32_t* len, int32_t T, int32_t B, void* stream) {
-  CK(launch_final_norm(x, q_per_b, w, eps, hfin, hiddens, max_new, len, T, B, (hipStream_t)stream));
+  CK(launch_final_norm(x, q_per_b, w, eps, hfin, hiddens, max_new, len, T, B, nullptr, nullptr, (hipStream_t)stream));
   return 0;
 }
 extern "C" int ctts_k_sample(const ctts_gen_state* s, const float* logits, void* stream) {

@@ -39,7 +39,10 @@ __global__ __launch_bounds__(256) void gemm_skinny_k(GemmArgs a) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int li = lane & 15, g = lane >> 4;
   const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16 * MB;
-  const int M = a.M, N = a.N, K = a.K;
+  const int N = a.N, K = a.K;
+  // decode: only the first *n_active rows exist (compact active utterances); rows beyond are neither read nor written
+  const int M = a.n_active ? min(*a.n_active, a.M) : a.M;
+  if (m0 >= M) return;
 
   if (RMS) {
     for (int r = wave; r < 16 * MB; r += 4) {
@@ -308,7 +311,11 @@ void gemm_fast_k(FastGemmArgs a) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int li = lane & 15, g = lane >> 4;
   const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16 * MB;
-  const int M = a.M, N = a.N, K = a.K;
+  const int N = a.N, K = a.K;
+  // decode: only the first *n_active rows exist (compact active utterances, see GptRowMap); rows beyond are neither
+  // loaded (their A fragments clamp onto the last live row: L1 hits) nor stored, and whole M tiles beyond exit
+  const int M = a.n_active ? min(*a.n_active, a.M) : a.M;
+  if (m0 >= M) return;
   // optional phase stamps (tools/gemm_phase_probe.py): 100 MHz s_memrealtime, wave 0 lane 0 of every workgroup
   long long* dbg = a.dbg ? a.dbg + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 : nullptr;
 #define STAMP(i) do { if (dbg && tid == 0) dbg[i] = wall_clock64(); } while (0)
@@ -324,7 +331,8 @@ void gemm_fast_k(FastGemmArgs a) {
     if (lane < 16 * MB) {
       const int row = min(m0 + lane, M - 1);
       int b, slot;
-      if (a.q_per_b == 1) { b = row; slot = a.len[b] - 1; } else { b = row / a.q_per_b; slot = row - b * a.q_per_b; }
+      if (a.q_per_b == 1) { b = a.row_map ? a.row_map[row] : row; slot = a.len[b] - 1; }
+      else { b = row / a.q_per_b; slot = row - b * a.q_per_b; }
       int pos = slot - a.kv_start[b];
       if (pos < 0) pos = 1;
       const float4 c0 = *reinterpret_cast<const float4*>(a.cos_t + pos * 32 + 8 * t4);

@@ -12,9 +12,11 @@
 #define NAUDIO 626
 
 __device__ __forceinline__ void row_to_b_slot(const GptRowMap& rm, int m, int& b, int& slot) {
-  if (rm.q_per_b == 1) { b = m; slot = rm.len[b] - 1; }
+  if (rm.q_per_b == 1) { b = rm.row_map ? rm.row_map[m] : m; slot = rm.len[b] - 1; }
   else { b = m / rm.q_per_b; slot = m - b * rm.q_per_b; }
 }
+// decode launches keep the captured grid (B rows); rows beyond the compact active count do nothing
+__device__ __forceinline__ bool row_absent(const int32_t* n_active, int m) { return n_active != nullptr && m >= *n_active; }
 
 // ------------------------------------------------------------------------------------------------
 // G1  x[b] = sum_k emb_code[k][ids_buf[b, len[b]-1, k]]     (gpt.py:403-415; k-ordered f32 adds
@@ -40,8 +42,11 @@ __device__ __forceinline__ void emit_row(float4 s, int t, float* __restrict__ x_
 
 __global__ __launch_bounds__(192) void embed_codes_k(const float* __restrict__ emb, const int64_t* __restrict__ ids_buf,
                                                      int tcap, const int32_t* __restrict__ len, float* __restrict__ x,
-                                                     uint16_t* __restrict__ xb, float* __restrict__ ssq) {
-  const int b = blockIdx.x, t = threadIdx.x;
+                                                     uint16_t* __restrict__ xb, float* __restrict__ ssq,
+                                                     const int32_t* __restrict__ row_map, const int32_t* __restrict__ n_active) {
+  const int m = blockIdx.x, t = threadIdx.x;
+  if (row_absent(n_active, m)) return;
+  const int b = row_map ? row_map[m] : m;
   const int64_t* tok = ids_buf + ((size_t)b * tcap + (len[b] - 1)) * NVQ;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -51,12 +56,12 @@ __global__ __launch_bounds__(192) void embed_codes_k(const float* __restrict__ e
     const float4 v = *reinterpret_cast<const float4*>(emb + ((size_t)k * NAUDIO + id) * HID + t * 4);
     if (k == 0) s = v; else { s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
   }
-  emit_row(s, t, x + (size_t)b * HID, xb ? xb + (size_t)b * HID : nullptr, ssq ? ssq + (size_t)b * SSQ_PARTS : nullptr);
+  emit_row(s, t, x + (size_t)m * HID, xb ? xb + (size_t)m * HID : nullptr, ssq ? ssq + (size_t)m * SSQ_PARTS : nullptr);
 }
 
 hipError_t launch_embed_codes(const float* emb_code, const int64_t* ids_buf, int tcap, const int32_t* len, float* x, uint16_t* xb,
-                              float* ssq, int B, hipStream_t st) {
-  CTTS_LAUNCH(embed_codes_k, dim3(B), dim3(192), st, emb_code, ids_buf, tcap, len, x, xb, ssq);
+                              float* ssq, int B, const int32_t* row_map, const int32_t* n_active, hipStream_t st) {
+  CTTS_LAUNCH(embed_codes_k, dim3(B), dim3(192), st, emb_code, ids_buf, tcap, len, x, xb, ssq, row_map, n_active);
   return hipGetLastError();
 }
 
@@ -86,6 +91,7 @@ __global__ __launch_bounds__(384) void rope_append_k(float* __restrict__ qkv, KT
                                                      const float* __restrict__ cos_t, const float* __restrict__ sin_t,
                                                      GptRowMap rm) {
   const int m = blockIdx.x, t = threadIdx.x;  // t: head = t / 32, pair d = t % 32
+  if (rm.q_per_b == 1 && row_absent(rm.n_active, m)) return;
   int b, slot;
   row_to_b_slot(rm, m, b, slot);
   int pos = slot - rm.kv_start[b];
@@ -168,9 +174,10 @@ __global__ __launch_bounds__(64 * NW) void attention_k(const float* __restrict__
   const int h = blockIdx.x, m = blockIdx.y;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int kg = lane / LPK, dl = lane % LPK;
+  if (rm.q_per_b == 1 && row_absent(rm.n_active, m)) return;
   int b, slot;
   row_to_b_slot(rm, m, b, slot);
-  if (rm.finish != nullptr && rm.finish[b]) return;  // finished row: nothing downstream of it is ever read
+  if (rm.finish != nullptr && rm.finish[b]) return;  // finished since the last compaction: nothing downstream is ever read
   int jlo = rm.kv_start[b];
   if (jlo > slot) jlo = slot;  // pad query row: sees only itself (its output is never consumed)
 
@@ -317,10 +324,13 @@ hipError_t launch_attention(const float* qkv, const void* kcache, const void* vc
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(192) void final_norm_k(const float* __restrict__ x, int q_per_b, const float* __restrict__ w, float eps,
                                                     float* __restrict__ hfin, float* __restrict__ hiddens, int max_new,
-                                                    const int32_t* __restrict__ len, int T) {
+                                                    const int32_t* __restrict__ len, int T, const int32_t* __restrict__ row_map,
+                                                    const int32_t* __restrict__ n_active) {
   __shared__ float part[3];
-  const int b = blockIdx.x, t = threadIdx.x;
-  const float* row = x + ((size_t)b * q_per_b + (q_per_b - 1)) * HID;
+  const int m = blockIdx.x, t = threadIdx.x;
+  if (row_absent(n_active, m)) return;
+  const int b = row_map ? row_map[m] : m;   // compact activation row m belongs to utterance b
+  const float* row = x + ((size_t)m * q_per_b + (q_per_b - 1)) * HID;
   const float4 v = *reinterpret_cast<const float4*>(row + t * 4);
   float ss = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
   ss = wave_sum(ss);
@@ -330,15 +340,15 @@ __global__ __launch_bounds__(192) void final_norm_k(const float* __restrict__ x,
   const float4 g = *reinterpret_cast<const float4*>(w + t * 4);
   float4 o;
   o.x = g.x * (v.x * rstd); o.y = g.y * (v.y * rstd); o.z = g.z * (v.z * rstd); o.w = g.w * (v.w * rstd);
-  *reinterpret_cast<float4*>(hfin + (size_t)b * HID + t * 4) = o;
+  *reinterpret_cast<float4*>(hfin + (size_t)m * HID + t * 4) = o;
   const int gen = len[b] - T;
   if (hiddens != nullptr && gen >= 0 && gen < max_new)
     *reinterpret_cast<float4*>(hiddens + ((size_t)b * max_new + gen) * HID + t * 4) = o;
 }
 
 hipError_t launch_final_norm(const float* x, int q_per_b, const float* w, float eps, float* hfin, float* hiddens, int max_new,
-                             const int32_t* len, int T, int B, hipStream_t st) {
-  CTTS_LAUNCH(final_norm_k, dim3(B), dim3(192), st, x, q_per_b, w, eps, hfin, hiddens, max_new, len, T);
+                             const int32_t* len, int T, int B, const int32_t* row_map, const int32_t* n_active, hipStream_t st) {
+  CTTS_LAUNCH(final_norm_k, dim3(B), dim3(192), st, x, q_per_b, w, eps, hfin, hiddens, max_new, len, T, row_map, n_active);
   return hipGetLastError();
 }
 
@@ -372,11 +382,13 @@ __device__ __forceinline__ void wave_argmax(float v, int idx, float& bv, int& bi
 
 __global__ __launch_bounds__(256) void sample_k(SampleArgs a) {
   __shared__ int tok_s[NVQ];
-  const int b = blockIdx.x;
+  const int m = blockIdx.x;                       // compact logits row
+  if (row_absent(a.n_active, m)) return;
+  const int b = a.row_map ? a.row_map[m] : m;     // utterance (batch slot)
   const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int len = a.len[b];
   const int gen = len - a.T;  // tokens generated so far == step index i of gpt.py:394
-  const float* lrow = a.logits + ((size_t)b * NVQ + k) * NAUDIO;
+  const float* lrow = a.logits + ((size_t)m * NVQ + k) * NAUDIO;
   const float temp = a.temperature[k];
 
   float x[SLOTS];
@@ -526,17 +538,20 @@ hipError_t launch_sample(const SampleArgs& a, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(192) void embed_text_k(const float* __restrict__ emb_text, int n_text, const int64_t* __restrict__ ids_buf,
                                                     int tcap, const int32_t* __restrict__ len, float* __restrict__ x,
-                                                    uint16_t* __restrict__ xb, float* __restrict__ ssq) {
-  const int b = blockIdx.x, t = threadIdx.x;
+                                                    uint16_t* __restrict__ xb, float* __restrict__ ssq,
+                                                    const int32_t* __restrict__ row_map, const int32_t* __restrict__ n_active) {
+  const int m = blockIdx.x, t = threadIdx.x;
+  if (row_absent(n_active, m)) return;
+  const int b = row_map ? row_map[m] : m;
   int id = (int)ids_buf[((size_t)b * tcap + (len[b] - 1)) * NVQ];  // slot 0 (gpt.py:407)
   id = min(max(id, 0), n_text - 1);
   const float4 s = *reinterpret_cast<const float4*>(emb_text + (size_t)id * HID + t * 4);
-  emit_row(s, t, x + (size_t)b * HID, xb ? xb + (size_t)b * HID : nullptr, ssq ? ssq + (size_t)b * SSQ_PARTS : nullptr);
+  emit_row(s, t, x + (size_t)m * HID, xb ? xb + (size_t)m * HID : nullptr, ssq ? ssq + (size_t)m * SSQ_PARTS : nullptr);
 }
 
 hipError_t launch_embed_text(const float* emb_text, int n_text, const int64_t* ids_buf, int tcap, const int32_t* len, float* x,
-                             uint16_t* xb, float* ssq, int B, hipStream_t st) {
-  CTTS_LAUNCH(embed_text_k, dim3(B), dim3(192), st, emb_text, n_text, ids_buf, tcap, len, x, xb, ssq);
+                             uint16_t* xb, float* ssq, int B, const int32_t* row_map, const int32_t* n_active, hipStream_t st) {
+  CTTS_LAUNCH(embed_text_k, dim3(B), dim3(192), st, emb_text, n_text, ids_buf, tcap, len, x, xb, ssq, row_map, n_active);
   return hipGetLastError();
 }
 
@@ -585,10 +600,12 @@ __global__ __launch_bounds__(256) void sample_text_k(SampleArgs a, int V) {
   __shared__ float xs[TEXT_VMAX];
   __shared__ unsigned keptbits[TEXT_VMAX / 32];
   __shared__ BlockRed red;
-  const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int m = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  if (row_absent(a.n_active, m)) return;
+  const int b = a.row_map ? a.row_map[m] : m;
   const int len = a.len[b];
   const int gen = len - a.T;
-  const float* lrow = a.logits + (size_t)b * V;
+  const float* lrow = a.logits + (size_t)m * V;
   const float temp = a.temperature[0];
 
   float mx = -INFINITY;

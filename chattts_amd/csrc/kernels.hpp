@@ -48,6 +48,7 @@ struct GemmArgs {
   const float* res; int ldr;
   const float* bias;   // [N]
   const float* gamma;  // [N] (EPI_BIAS_SCALE_RES) or scale (EPI_SCALE)
+  const int32_t* n_active;  // skinny kernel, decode: device scalar, rows >= *n_active are not computed; null = M
   // conv-as-GEMM gather (tiled kernel only): logical row m = b*F + f, k = tap*Cin + c reads
   // X[b, f + (tap - pad)*dil, c] (zero outside [0,F)); taps == 1 -> plain GEMM.
   int taps, cin, frames, pad, dil;
@@ -74,6 +75,8 @@ struct FastGemmArgs {
   float* ssq_out;               // RES: [M,48] partial sums of squares of the new residual
   // QKV_ROPE: RoPE + KV append fused into the epilogue (weights row-permuted by the loader, see engine.py)
   int q_per_b; const int32_t* len; const int32_t* kv_start;   // row -> (b, slot) map, as GptRowMap
+  const int32_t* row_map;       // decode: compact row -> batch slot (QKV_ROPE epilogue), or null
+  const int32_t* n_active;      // decode: device scalar, rows >= *n_active are not computed; null = M
   const float* cos_t; const float* sin_t;                     // [max_pos, 32]
   uint16_t* kc; uint16_t* vc; int cmax;                       // this layer's bf16 K / V cache [B,12,cmax,64]
   int force_mb;                 // tests only: 0 = heuristic
@@ -89,23 +92,31 @@ hipError_t launch_gemm_tiled_bf16x3(const GemmArgs& a, hipStream_t st);  // 128x
 // ---- GPT step kernels -------------------------------------------------------------------------
 struct GptRowMap {
   // query row m of a launch maps to (b, slot): prefill (q_per_b = T): b = m / T, slot = m % T;
-  // decode (q_per_b = 1): b = m, slot = len[b] - 1.
+  // decode (q_per_b = 1): b = row_map ? row_map[m] : m, slot = len[b] - 1, and rows m >= *n_active do not exist.
+  // Decode activations are COMPACT: the host packs the still-running utterances to the front (row_map, n_active;
+  // refreshed at every finish poll), every per-utterance array (ids_buf, len, KV cache, hiddens, q ...) stays
+  // indexed by the batch slot b.  Finished utterances thus cost nothing (the reference keeps stepping them until
+  // the last one is done, gpt.py:512-518,592, but truncates their output at end_idx, so that work is unobservable).
   int q_per_b;
   const int32_t* len;       // [B] tokens present in ids_buf (prompt + generated)   (decode)
   const int32_t* kv_start;  // [B] left-pad slots (attention_mask == 0 there)
+  const int32_t* row_map;   // [B] compact row -> batch slot, or null (identity)
+  const int32_t* n_active;  // device scalar, or null (all rows)
   const uint8_t* finish;    // [B] or null (decode): rows that already sampled EOS.  The reference keeps stepping them
                             // until every row is done (gpt.py:512-518,592) but truncates their output at end_idx, so
                             // their per-step work is unobservable: the attention kernel skips their KV read.
 };
 
 hipError_t launch_embed_codes(const float* emb_code /*[4,626,768]*/, const int64_t* ids_buf, int ids_row_stride /*Tcap*/,
-                              const int32_t* len, float* x, uint16_t* xb /*null ok*/, float* ssq /*null ok*/, int B, hipStream_t st);
+                              const int32_t* len, float* x, uint16_t* xb /*null ok*/, float* ssq /*null ok*/, int B,
+                              const int32_t* row_map, const int32_t* n_active, hipStream_t st);
 hipError_t launch_rope_append(float* qkv /*[M,2304]*/, void* kcache, void* vcache, int kv_wt, int cmax,
                               const float* cos_tab, const float* sin_tab /*[max_pos,32]*/, GptRowMap rm, int M, hipStream_t st);
 hipError_t launch_attention(const float* qkv, const void* kcache, const void* vcache, int kv_wt, int cmax,
                             void* out /*[M,768] f32, or bf16 when out_bf16*/, int out_bf16, GptRowMap rm, int M, hipStream_t st);
 hipError_t launch_final_norm(const float* x, int q_per_b, const float* w, float eps, float* hfin /*[B,768]*/,
-                             float* hiddens /*[B,max_new,768]*/, int max_new, const int32_t* len, int T, int B, hipStream_t st);
+                             float* hiddens /*[B,max_new,768]*/, int max_new, const int32_t* len, int T, int B,
+                             const int32_t* row_map, const int32_t* n_active, hipStream_t st);
 
 struct SampleArgs {
   const float* logits;      // [B, 4*626]
@@ -126,12 +137,14 @@ struct SampleArgs {
   int max_input_ids;        // 625
   const int32_t* stop_at;   // [B] or null: bench harness length forcing
   int B;
+  const int32_t* row_map;   // decode: workgroup m samples utterance row_map[m] from logits row m; null = identity
+  const int32_t* n_active;  // decode: device scalar; null = B
 };
 hipError_t launch_sample(const SampleArgs& a, hipStream_t st);
 // refine-text mode: logits [B, V], q [nq, B, V], temperature[0]; no repetition penalty (see gpt.hip)
 hipError_t launch_sample_text(const SampleArgs& a, int V, hipStream_t st);
 hipError_t launch_embed_text(const float* emb_text, int n_text, const int64_t* ids_buf, int tcap, const int32_t* len, float* x,
-                             uint16_t* xb, float* ssq, int B, hipStream_t st);
+                             uint16_t* xb, float* ssq, int B, const int32_t* row_map, const int32_t* n_active, hipStream_t st);
 
 // ---- codec kernels (channels-last [B, F, C]) ---------------------------------------------------
 hipError_t launch_dwconv_ln(const float* x, const float* w /*[C,7]*/, const float* b, const float* ln_w, const float* ln_b,

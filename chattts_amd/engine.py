@@ -319,6 +319,9 @@ class GptEngine:
                 ln.ids_buf[:, :T] = ids_all[lo:hi]
                 ln.len_d = torch.full((Bl,), T, dtype=torch.int32, device=dev)
                 ln.finish = torch.zeros((Bl,), dtype=torch.uint8, device=dev)             # gpt.py:346
+                ln.row_map = torch.arange(Bl, dtype=torch.int32, device=dev)              # compact decode row -> batch slot
+                ln.n_active = torch.full((1,), Bl, dtype=torch.int32, device=dev)
+                ln.n_act_host = Bl
                 ln.end_idx = torch.zeros((Bl,), dtype=torch.int32, device=dev)            # gpt.py:343
                 ln.hiddens = torch.empty((Bl, max_new, GPT.hidden), dtype=torch.float32, device=dev)
                 kv_shape = (self.n_layers, Bl, GPT.n_heads, T + max_new, GPT.head_dim)
@@ -349,6 +352,7 @@ class GptEngine:
             s.infer_text = int(infer_text)
             s.stop_at = _lib.ptr(ln.stop_d)
             s.workspace, s.workspace_bytes = ln.workspace.data_ptr(), ws_bytes
+            s.row_map, s.n_active = ln.row_map.data_ptr(), ln.n_active.data_ptr()
             ln.s = s
             L.append(ln)
 
@@ -395,7 +399,15 @@ class GptEngine:
                 fin = ln.finish.cpu()
                 ln.end_snap = ln.end_idx.cpu().tolist()
                 ln.ev.record(ln.st)
-            ln.done = bool(fin.all())
+                ln.done = bool(fin.all())
+                # compaction: the utterances still running move to the front of the decode batch (stable order).  The
+                # reference keeps stepping finished rows until the last one is done (gpt.py:512-518,592) but cuts their
+                # output at end_idx, so dropping them from the step changes nothing observable.
+                active = (fin == 0).nonzero().flatten().to(torch.int32)
+                if not ln.done and int(active.numel()) != ln.n_act_host:
+                    ln.n_act_host = int(active.numel())
+                    ln.row_map[: ln.n_act_host].copy_(active, non_blocking=False)
+                    ln.n_active.fill_(ln.n_act_host)
             return fin
 
         def enqueue(n):

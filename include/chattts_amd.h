@@ -89,6 +89,10 @@ typedef struct {
   const int32_t* stop_at;          /* [B] or NULL: benchmark length forcing, not a reference feature */
   void* workspace;                 /* >= ctts_gpt_workspace_bytes(B, T) */
   size_t workspace_bytes;
+  const int32_t* row_map;          /* [B] or NULL: compact decode row -> batch slot.  The host packs the utterances that are still
+                                      running to the front and refreshes this (and n_active) whenever it polls `finish`; every
+                                      array above stays indexed by the batch slot.  NULL = identity / all rows. */
+  const int32_t* n_active;         /* device scalar or NULL: number of compact rows the decode step computes */
   int32_t infer_text;              /* 1: refine-text mode -- text embedding/head, ONE sampling row per utterance (q is
                                       [nq, B, n_text], temperature[0]), the sampled id is written to all 4 slots
                                       (gpt.py:519-525); repetition penalty must be off */
