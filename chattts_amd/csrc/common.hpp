@@ -37,6 +37,36 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// ---- DPP wave reductions (no LDS crossbar): __shfl_xor lowers to ds_bpermute_b32 (~50+ cycles each, 12 in a
+// dependent chain per argmax); the DPP forms below are plain VALU ops.  Pattern: xor-1, xor-2 (quad_perm),
+// row_half_mirror, row_mirror reduce each 16-lane row; row_bcast15 / row_bcast31 fold the 4 rows into lane 63.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i(int v) {
+  return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xf, false);  // unwritten lanes keep v
+}
+__device__ __forceinline__ float wave_max_dpp(float v) {
+#define CTTS_FMAX_DPP(C, M) v = fmaxf(v, __int_as_float(dpp_i<C, M>(__float_as_int(v))))
+  CTTS_FMAX_DPP(0xB1, 0xf);   // quad_perm [1,0,3,2]
+  CTTS_FMAX_DPP(0x4E, 0xf);   // quad_perm [2,3,0,1]
+  CTTS_FMAX_DPP(0x141, 0xf);  // row_half_mirror
+  CTTS_FMAX_DPP(0x140, 0xf);  // row_mirror
+  CTTS_FMAX_DPP(0x142, 0xa);  // row_bcast15 -> rows 1, 3
+  CTTS_FMAX_DPP(0x143, 0xc);  // row_bcast31 -> rows 2, 3
+#undef CTTS_FMAX_DPP
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ int wave_min_dpp(int v) {
+#define CTTS_IMIN_DPP(C, M) v = min(v, dpp_i<C, M>(v))
+  CTTS_IMIN_DPP(0xB1, 0xf);
+  CTTS_IMIN_DPP(0x4E, 0xf);
+  CTTS_IMIN_DPP(0x141, 0xf);
+  CTTS_IMIN_DPP(0x140, 0xf);
+  CTTS_IMIN_DPP(0x142, 0xa);
+  CTTS_IMIN_DPP(0x143, 0xc);
+#undef CTTS_IMIN_DPP
+  return __builtin_amdgcn_readlane(v, 63);
+}
+
 // erf-based GELU (nn.GELU default, approximate='none')
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }

@@ -370,14 +370,10 @@ hipError_t launch_final_norm(const float* x, int q_per_b, const float* w, float 
 #define SLOTS 10  // ceil(626 / 64)
 
 __device__ __forceinline__ void wave_argmax(float v, int idx, float& bv, int& bi) {
-  // max value, ties -> lowest index; result uniform across the wave
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const float ov = __shfl_xor(v, o, 64);
-    const int oi = __shfl_xor(idx, o, 64);
-    if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
-  }
-  bv = v; bi = idx;
+  // max value, ties -> lowest index; result uniform across the wave.  Two DPP reductions (max of the values,
+  // then min of the indices that hold it) instead of a 6-step (value, index) butterfly on ds_bpermute.
+  bv = wave_max_dpp(v);
+  bi = wave_min_dpp(v == bv ? idx : 0x7fffffff);
 }
 
 __global__ __launch_bounds__(256) void sample_k(SampleArgs a) {
@@ -468,7 +464,7 @@ __global__ __launch_bounds__(256) void sample_k(SampleArgs a) {
     float pe = 0.f;
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) if (s == ws) pe = e[s];
-    pe = __shfl(pe, wl, 64);
+    pe = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pe), wl));  // wl is wave-uniform
     mass_above += (double)pe;
     if (lane == wl) { taken |= 1u << ws; kept |= 1u << ws; }
     if (n == kk - 1) kth_val = wv;
