@@ -445,6 +445,36 @@ def test_sample_row_offset_and_stop(G):
     assert (got[:4] == 625).all() and fin[0] == 1 and end[0] == 0
 
 
+@pytest.mark.parametrize("trial", range(24))
+def test_sample_randomised_vs_oracle(G, trial):
+    """seeded sweep over the sampling parameters (temperature per codebook, top-p, top-k incl. None / > V, penalty,
+    history length, EOS masking, tied logits): fused kernel == numpy oracle of the reference chain"""
+    rs = np.random.RandomState(1000 + trial)
+    B = int(rs.choice([1, 3, 8]))
+    rows = B * 4
+    scale = float(rs.choice([0.3, 1.0, 4.0, 8.0]))
+    logits = (rs.standard_normal((rows, 626)) * scale).astype(f32)
+    if trial % 5 == 0:
+        logits = (np.round(logits * 2) / 2).astype(f32)  # many exact ties
+    h = int(rs.choice([0, 1, 7, 16, 23]))
+    hist = rs.randint(0, 626, size=(rows, h)).astype(np.int64)
+    if h:
+        hist[:, : h // 2] = np.argsort(-logits, axis=1)[:, : h // 2]  # penalise likely tokens too
+    temp4 = rs.choice([0.1, 0.3, 0.7, 1.0, 1.5], size=4).astype(f32)
+    top_p = [None, 0.05, 0.5, 0.7, 0.95, 0.999][int(rs.randint(6))]
+    top_k = [None, 1, 3, 20, 100, 1000][int(rs.randint(6))]
+    rep = [None, 1.05, 1.3, 2.0][int(rs.randint(4))]
+    if trial % 5 == 0 and top_p is not None:
+        top_p = None   # tie order inside the top-p cut is unspecified in the reference (unstable sort); ties are tested with top-k only
+    mask_eos = bool(rs.randint(2))
+    q = rng.ExpDraws(rows, 626, int(rs.randint(1 << 30))).step(0).numpy()
+    got, *_ = run_sample_kernel(G, logits, hist, temp4, q, top_p=top_p, top_k=top_k, rep=rep, mask_eos=mask_eos)
+    pt = rng.penalty_table(rep)
+    want = sampling_np.sample_step(logits, hist, q, temperature=np.tile(temp4, B), top_p=top_p, top_k=top_k,
+                                   pow_table=None if pt is None else pt.numpy(), max_input_ids=625, mask_eos=mask_eos)
+    assert np.array_equal(got, want), (trial, top_p, top_k, rep, h, int((got != want).sum()))
+
+
 # ------------------------------------------------------------------------------------------------
 # codec streaming kernels
 # ------------------------------------------------------------------------------------------------
