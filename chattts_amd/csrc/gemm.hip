@@ -571,12 +571,18 @@ hipError_t launch_gemm_fast(const FastGemmArgs& a_in, hipStream_t st) {
 // f32-input MFMA peaks at 157 TF on gfx950 and the f32 tiled kernel above already runs at ~115 TF, so
 // this is the only way to make the 157 MFLOP/token decoder cheaper without giving up the 1e-4 RMS bar.
 // ------------------------------------------------------------------------------------------------
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_tiled_bf16x3_k(GemmArgs a) {
-  constexpr int BM = 128, BN = 128, BK = 32, LD = 40;  // LD: 80-byte rows -> conflict-free ds_read_b128 of the fragments
+// WM x WN waves, each wave MBLK x NBLK MFMA blocks of 32x32: tile = (WM*MBLK*32) x (WN*NBLK*32).
+//   <2,2,2,2>: 128x128, 256 threads (narrow layers);  <4,2,2,4>: 256x256, 512 threads, one workgroup per CU --
+//   the kernel is bound by each CU's L1 fill, and a 256x256x32 step moves 64 KB for 4x the flops of a 128x128 one.
+template <int EPI, int WM, int WN, int MBLK, int NBLK>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) void gemm_tiled_bf16x3_k(GemmArgs a) {
+  constexpr int NT = 64 * WM * WN;
+  constexpr int BM = WM * MBLK * 32, BN = WN * NBLK * 32, BK = 32, LD = 40;  // LD: 80-byte rows -> conflict-free ds_read_b128
+  constexpr int PA = BM / (NT / 8);   // A loader passes: NT/8 rows per pass (8 lanes = one 128-byte row segment)
+  constexpr int PW = BN / (NT / 4);   // W loader passes: NT/4 rows per pass (4 lanes = one 64-byte row segment)
   __shared__ __attribute__((aligned(16))) uint16_t Ah[BM][LD], Al[BM][LD], Wh[BN][LD], Wl[BN][LD];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int wm = wave & 1, wn = wave >> 1;
+  const int wm = wave % WM, wn = wave / WM;
   const int M = a.M, N = a.N, K = a.K;
   // XCD-aware tile order: the dispatcher places workgroup L on XCD L % 8 (each XCD has its own L2), so give
   // every XCD a contiguous run of tiles; the N-tiles that share one A row-panel then hit the same L2.
@@ -588,35 +594,33 @@ __global__ __launch_bounds__(256, 2) void gemm_tiled_bf16x3_k(GemmArgs a) {
   const uint16_t* Whi = reinterpret_cast<const uint16_t*>(a.W);
   const uint16_t* Wlo = Whi + (size_t)N * Kp;
 
-  // A loader: 8 lanes cover one 128-byte row segment (32 floats); thread handles rows ar + 32p, p = 0..3
   const int ar = tid >> 3, ak = (tid & 7) * 4;
-  int ab[4], af[4];
-  bool aval[4];
+  int ab[PA], af[PA];
+  bool aval[PA];
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    const int m = m0 + ar + 32 * p;
+  for (int p = 0; p < PA; ++p) {
+    const int m = m0 + ar + (NT / 8) * p;
     aval[p] = m < M;
     if (a.taps > 1) { ab[p] = m / a.frames; af[p] = m - ab[p] * a.frames; } else { ab[p] = 0; af[p] = m; }
   }
-  // W loader: 4 lanes cover one 64-byte row segment (32 bf16); thread handles rows wr + 64p, p = 0..1
   const int wr = tid >> 2, wk = (tid & 3) * 8;
 
-  f32x16 acc[2][2];
+  f32x16 acc[MBLK][NBLK];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MBLK; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NBLK; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   // register staging (one tile ahead): the global loads of tile k+1 are in flight while tile k is multiplied
-  float4 ra0, ra1, ra2, ra3;
-  u128 rh0, rl0, rh1, rl1;
+  float4 ra[PA];
+  u128 rh[PW], rl[PW];
 #define X3_FETCH(K0)                                                                                        \
   do {                                                                                                      \
     const int k0_ = (K0);                                                                                   \
     const int k = k0_ + ak;                                                                                 \
-    _Pragma("unroll") for (int p = 0; p < 4; ++p) {                                                         \
+    _Pragma("unroll") for (int p = 0; p < PA; ++p) {                                                        \
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                                                           \
       if (aval[p] && k < K) {                                                                               \
         if (a.taps > 1) {                                                                                   \
@@ -628,33 +632,31 @@ __global__ __launch_bounds__(256, 2) void gemm_tiled_bf16x3_k(GemmArgs a) {
           v = *reinterpret_cast<const float4*>(a.A + (size_t)af[p] * a.lda + k);                            \
         }                                                                                                   \
       }                                                                                                     \
-      if (p == 0) ra0 = v; else if (p == 1) ra1 = v; else if (p == 2) ra2 = v; else ra3 = v;                \
+      ra[p] = v;                                                                                            \
     }                                                                                                       \
-    {                                                                                                       \
-      const int nA = min(n0 + wr, N - 1), nB = min(n0 + wr + 64, N - 1);                                    \
-      rh0 = *reinterpret_cast<const u128*>(Whi + (size_t)nA * Kp + k0_ + wk);                               \
-      rl0 = *reinterpret_cast<const u128*>(Wlo + (size_t)nA * Kp + k0_ + wk);                               \
-      rh1 = *reinterpret_cast<const u128*>(Whi + (size_t)nB * Kp + k0_ + wk);                               \
-      rl1 = *reinterpret_cast<const u128*>(Wlo + (size_t)nB * Kp + k0_ + wk);                               \
+    _Pragma("unroll") for (int p = 0; p < PW; ++p) {                                                        \
+      const int nn = min(n0 + wr + (NT / 4) * p, N - 1); /* clamped: rows >= N are never stored */          \
+      rh[p] = *reinterpret_cast<const u128*>(Whi + (size_t)nn * Kp + k0_ + wk);                             \
+      rl[p] = *reinterpret_cast<const u128*>(Wlo + (size_t)nn * Kp + k0_ + wk);                             \
     }                                                                                                       \
   } while (0)
 
-#define X3_SPLIT_STORE(V, R)                                                                               \
-  do {                                                                                                      \
-    const float4 v = (V);                                                                                   \
-    ushort4 h, l;                                                                                           \
-    h.x = f32_to_bf16(v.x); l.x = f32_to_bf16(v.x - bf16_to_f32(h.x));                                      \
-    h.y = f32_to_bf16(v.y); l.y = f32_to_bf16(v.y - bf16_to_f32(h.y));                                      \
-    h.z = f32_to_bf16(v.z); l.z = f32_to_bf16(v.z - bf16_to_f32(h.z));                                      \
-    h.w = f32_to_bf16(v.w); l.w = f32_to_bf16(v.w - bf16_to_f32(h.w));                                      \
-    *reinterpret_cast<ushort4*>(&Ah[(R)][ak]) = h;                                                          \
-    *reinterpret_cast<ushort4*>(&Al[(R)][ak]) = l;                                                          \
-  } while (0)
 #define X3_STAGE()                                                                                          \
   do {                                                                                                      \
-    X3_SPLIT_STORE(ra0, ar); X3_SPLIT_STORE(ra1, ar + 32); X3_SPLIT_STORE(ra2, ar + 64); X3_SPLIT_STORE(ra3, ar + 96); \
-    *reinterpret_cast<u128*>(&Wh[wr][wk]) = rh0; *reinterpret_cast<u128*>(&Wl[wr][wk]) = rl0;              \
-    *reinterpret_cast<u128*>(&Wh[wr + 64][wk]) = rh1; *reinterpret_cast<u128*>(&Wl[wr + 64][wk]) = rl1;    \
+    _Pragma("unroll") for (int p = 0; p < PA; ++p) {                                                        \
+      const float4 v = ra[p];                                                                               \
+      ushort4 h, l;                                                                                         \
+      h.x = f32_to_bf16(v.x); l.x = f32_to_bf16(v.x - bf16_to_f32(h.x));                                    \
+      h.y = f32_to_bf16(v.y); l.y = f32_to_bf16(v.y - bf16_to_f32(h.y));                                    \
+      h.z = f32_to_bf16(v.z); l.z = f32_to_bf16(v.z - bf16_to_f32(h.z));                                    \
+      h.w = f32_to_bf16(v.w); l.w = f32_to_bf16(v.w - bf16_to_f32(h.w));                                    \
+      *reinterpret_cast<ushort4*>(&Ah[ar + (NT / 8) * p][ak]) = h;                                          \
+      *reinterpret_cast<ushort4*>(&Al[ar + (NT / 8) * p][ak]) = l;                                          \
+    }                                                                                                       \
+    _Pragma("unroll") for (int p = 0; p < PW; ++p) {                                                        \
+      *reinterpret_cast<u128*>(&Wh[wr + (NT / 4) * p][wk]) = rh[p];                                         \
+      *reinterpret_cast<u128*>(&Wl[wr + (NT / 4) * p][wk]) = rl[p];                                         \
+    }                                                                                                       \
   } while (0)
 
   X3_FETCH(0);
@@ -666,18 +668,21 @@ __global__ __launch_bounds__(256, 2) void gemm_tiled_bf16x3_k(GemmArgs a) {
     if (more) X3_FETCH(k0 + BK);
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 16) {
-      bf16x8 fah[2], fal[2], fwh[2], fwl[2];
+      bf16x8 fah[MBLK], fal[MBLK], fwh[NBLK], fwl[NBLK];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        fah[i] = *reinterpret_cast<const bf16x8*>(&Ah[wm * 64 + i * 32 + ri][kk + kg]);
-        fal[i] = *reinterpret_cast<const bf16x8*>(&Al[wm * 64 + i * 32 + ri][kk + kg]);
-        fwh[i] = *reinterpret_cast<const bf16x8*>(&Wh[wn * 64 + i * 32 + ri][kk + kg]);
-        fwl[i] = *reinterpret_cast<const bf16x8*>(&Wl[wn * 64 + i * 32 + ri][kk + kg]);
+      for (int i = 0; i < MBLK; ++i) {
+        fah[i] = *reinterpret_cast<const bf16x8*>(&Ah[(wm * MBLK + i) * 32 + ri][kk + kg]);
+        fal[i] = *reinterpret_cast<const bf16x8*>(&Al[(wm * MBLK + i) * 32 + ri][kk + kg]);
       }
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int j = 0; j < NBLK; ++j) {
+        fwh[j] = *reinterpret_cast<const bf16x8*>(&Wh[(wn * NBLK + j) * 32 + ri][kk + kg]);
+        fwl[j] = *reinterpret_cast<const bf16x8*>(&Wl[(wn * NBLK + j) * 32 + ri][kk + kg]);
+      }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+      for (int i = 0; i < MBLK; ++i)
+#pragma unroll
+        for (int j = 0; j < NBLK; ++j) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[i], fwh[j], acc[i][j], 0, 0, 0);  // small terms first
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fwl[j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fwh[j], acc[i][j], 0, 0, 0);
@@ -691,17 +696,17 @@ __global__ __launch_bounds__(256, 2) void gemm_tiled_bf16x3_k(GemmArgs a) {
   }
 
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+  for (int j = 0; j < NBLK; ++j) {
+    const int col = n0 + (wn * NBLK + j) * 32 + (lane & 31);
     if (col >= N) continue;
     float bias = 0.f, gam = 1.f;
     if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_SCALE_RES) bias = a.bias[col];
     if (EPI == EPI_BIAS_SCALE_RES || EPI == EPI_SCALE) gam = a.gamma[col];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < MBLK; ++i) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int row = m0 + (wm * MBLK + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (row < M) {
           float v = acc[i][j][r];
           if (EPI == EPI_BIAS) v = v + bias;
@@ -718,21 +723,29 @@ __global__ __launch_bounds__(256, 2) void gemm_tiled_bf16x3_k(GemmArgs a) {
 
 #undef X3_FETCH
 #undef X3_STAGE
-#undef X3_SPLIT_STORE
+
+template <int WM, int WN, int MBLK, int NBLK>
+static hipError_t x3_dispatch(const GemmArgs& a, hipStream_t st) {
+  constexpr int BM = WM * MBLK * 32, BN = WN * NBLK * 32;
+  const int tiles = ((a.N + BN - 1) / BN) * ((a.M + BM - 1) / BM);
+  dim3 grid(((tiles + 7) / 8) * 8), block(64 * WM * WN);  // 1-D grid, remapped XCD-aware inside the kernel
+  switch (a.epi) {
+    case EPI_STORE: CTTS_LAUNCH((gemm_tiled_bf16x3_k<EPI_STORE, WM, WN, MBLK, NBLK>), grid, block, st, a); break;
+    case EPI_RES: CTTS_LAUNCH((gemm_tiled_bf16x3_k<EPI_RES, WM, WN, MBLK, NBLK>), grid, block, st, a); break;
+    case EPI_BIAS: CTTS_LAUNCH((gemm_tiled_bf16x3_k<EPI_BIAS, WM, WN, MBLK, NBLK>), grid, block, st, a); break;
+    case EPI_BIAS_GELU: CTTS_LAUNCH((gemm_tiled_bf16x3_k<EPI_BIAS_GELU, WM, WN, MBLK, NBLK>), grid, block, st, a); break;
+    case EPI_BIAS_SCALE_RES: CTTS_LAUNCH((gemm_tiled_bf16x3_k<EPI_BIAS_SCALE_RES, WM, WN, MBLK, NBLK>), grid, block, st, a); break;
+    case EPI_SCALE: CTTS_LAUNCH((gemm_tiled_bf16x3_k<EPI_SCALE, WM, WN, MBLK, NBLK>), grid, block, st, a); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
 
 hipError_t launch_gemm_tiled_bf16x3(const GemmArgs& a, hipStream_t st) {
   if (a.K % 4 != 0 || a.lda % 4 != 0 || a.norm_w != nullptr) return hipErrorInvalidValue;
   if (a.taps > 1 && (a.cin % 4 != 0 || a.K != a.taps * a.cin)) return hipErrorInvalidValue;
-  const int tiles = ((a.N + 127) / 128) * ((a.M + 127) / 128);
-  dim3 grid(((tiles + 7) / 8) * 8), block(256);  // 1-D grid, remapped XCD-aware inside the kernel
-  switch (a.epi) {
-    case EPI_STORE: CTTS_LAUNCH((gemm_tiled_bf16x3_k<EPI_STORE>), grid, block, st, a); break;
-    case EPI_RES: CTTS_LAUNCH((gemm_tiled_bf16x3_k<EPI_RES>), grid, block, st, a); break;
-    case EPI_BIAS: CTTS_LAUNCH((gemm_tiled_bf16x3_k<EPI_BIAS>), grid, block, st, a); break;
-    case EPI_BIAS_GELU: CTTS_LAUNCH((gemm_tiled_bf16x3_k<EPI_BIAS_GELU>), grid, block, st, a); break;
-    case EPI_BIAS_SCALE_RES: CTTS_LAUNCH((gemm_tiled_bf16x3_k<EPI_BIAS_SCALE_RES>), grid, block, st, a); break;
-    case EPI_SCALE: CTTS_LAUNCH((gemm_tiled_bf16x3_k<EPI_SCALE>), grid, block, st, a); break;
-    default: return hipErrorInvalidValue;
-  }
-  return hipGetLastError();
+  static int big = -1;  // CTTS_X3_TILE=128 forces the small tile (A/B experiments)
+  if (big < 0) { const char* e = getenv("CTTS_X3_TILE"); big = (e && atoi(e) == 128) ? 0 : 1; }
+  if (big && a.N >= 512 && a.M >= 2048) return x3_dispatch<4, 2, 2, 4>(a, st);   // 256x256 tile, 512 threads
+  return x3_dispatch<2, 2, 2, 2>(a, st);                                          // 128x128 tile, 256 threads
 }

@@ -216,7 +216,7 @@ def test_gemm_tiled_conv(G, case, tiled):
 
 @pytest.mark.parametrize("tiled", [1, 2])
 @pytest.mark.parametrize("M,N,K,epi", [(200, 2048, 512, 4), (200, 512, 2048, 5), (130, 384, 512, 0), (70, 1026, 512, 3), (64, 1536, 512, 4),
-                                       (300, 100, 1152, 6)])
+                                       (300, 100, 1152, 6), (2304, 512, 2048, 5), (2100, 1536, 512, 4)])
 def test_gemm_tiled_linear(G, M, N, K, epi, tiled):
     rs = np.random.RandomState(M + N + K)
     A = rs.standard_normal((M, K)).astype(f32)
