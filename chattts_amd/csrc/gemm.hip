@@ -744,8 +744,9 @@ static hipError_t x3_dispatch(const GemmArgs& a, hipStream_t st) {
 hipError_t launch_gemm_tiled_bf16x3(const GemmArgs& a, hipStream_t st) {
   if (a.K % 4 != 0 || a.lda % 4 != 0 || a.norm_w != nullptr) return hipErrorInvalidValue;
   if (a.taps > 1 && (a.cin % 4 != 0 || a.K != a.taps * a.cin)) return hipErrorInvalidValue;
-  static int big = -1;  // CTTS_X3_TILE=128 forces the small tile (A/B experiments)
-  if (big < 0) { const char* e = getenv("CTTS_X3_TILE"); big = (e && atoi(e) == 128) ? 0 : 1; }
+  static int big = -1;  // CTTS_X3_TILE=128 forces the small tile, =2 the 256x128 tile (A/B experiments)
+  if (big < 0) { const char* e = getenv("CTTS_X3_TILE"); big = e ? (atoi(e) == 128 ? 0 : atoi(e)) : 1; }
+  if (big == 2 && a.N >= 512 && a.M >= 2048) return x3_dispatch<2, 2, 4, 2>(a, st);  // 256x128 tile, 256 threads, 2 per CU
   if (big && a.N >= 512 && a.M >= 2048) return x3_dispatch<4, 2, 2, 4>(a, st);   // 256x256 tile, 512 threads
   return x3_dispatch<2, 2, 2, 2>(a, st);                                          // 128x128 tile, 256 threads
 }
