@@ -254,3 +254,24 @@ def test_refine_text_facade_and_rejections(weights):
     assert all(int(t.max()) < 21178 and int(t.min()) >= 0 and (t != cases.TEXT_EOS).all() for t in out.ids)
     with pytest.raises(NotImplementedError):   # the reference's penalty processor mis-broadcasts in text mode
         chat.refine_text_ids(*a, cases.TEXT_EOS, RefineTextParams(repetition_penalty=1.2, max_new_token=4, manual_seed=1))
+
+
+def test_long_context_prefix_consistency(gpt_bf16):
+    """2000 decode steps (context > 2000 keys, KV cache near max_position_embeddings): the run is finite, honours the
+    forced lengths, and -- generation being causal -- its first 150 tokens equal those of a 160-step run."""
+    ids, mask, tmask = synth.make_prompts(3, 20, 40, seed=11)
+    ids_t, mask_t = torch.from_numpy(ids), torch.from_numpy(mask)
+    warpers, procs = E.gen_logits(625, 0.7, 20, 1.05)
+    emb = gpt_bf16.embed_prompt(ids_t, torch.from_numpy(tmask))
+
+    def run(max_new, stop):
+        return list(gpt_bf16.generate(emb, ids_t, torch.tensor([0.3] * 4), 625, mask_t, max_new, 0, (*procs, *warpers), return_hidden=True,
+                                      manual_seed=9, stop_at=torch.tensor(stop, dtype=torch.int32)))[-1]
+    long = run(2001, [2000, 700, 1500])
+    short = run(161, [160, 160, 160])
+    assert [int(t.shape[0]) for t in long.ids] == [2000, 700, 1500]
+    for b in range(3):
+        assert torch.equal(long.ids[b][:150], short.ids[b][:150])
+        assert torch.isfinite(long.hiddens[b]).all()
+    with pytest.raises(ValueError):   # T + max_new_token beyond the RoPE table / max_position_embeddings (config.py:57)
+        run(4096, [10, 10, 10])
