@@ -157,11 +157,14 @@ def main():
         B = hi - lo
         valid_prompt = mask[lo:hi].sum(1).astype(np.int64)
         if dom == 3:
-            # SURVEY 8d per-unit figure: KV read 2*768*s bytes per visible key per row per layer, + q read / out write.
-            # All rows stay in the lock-step loop until the last one finishes, so at decode step i row b sees
-            # valid_prompt[b] + i keys; launches are sampled uniformly over the decode steps 1..steps-1.
-            ctx = [(valid_prompt + i).sum() for i in range(1, gpt_steps)]
-            alg = float(np.mean(ctx)) * 2 * 768 * es + B * 768 * (4 + es)
+            # SURVEY 8d per-unit figure: KV read 2*768*s bytes per visible key per LIVE row per layer, + q read / out write.
+            # At decode step i row b sees valid_prompt[b] + i keys and is live while i <= stop[b] (after its EOS the
+            # engine drops it from the step -- the reference would keep reading its KV, but no output depends on it, so
+            # those bytes are not counted as useful work).  Launches are sampled uniformly over decode steps 1..steps-1.
+            st_ = stop[lo:hi].astype(np.int64)
+            ctx = [((valid_prompt + i) * (st_ >= i)).sum() for i in range(1, gpt_steps)]
+            live = [int((st_ >= i).sum()) for i in range(1, gpt_steps)]
+            alg = float(np.mean(ctx)) * 2 * 768 * es + float(np.mean(live)) * 768 * (4 + es)
         else:
             wbytes = {1: 3 * 768 * 768 * es, 4: 768 * 768 * es, 5: 2 * 3072 * 768 * es, 6: 768 * 3072 * es, 8: 2504 * 768 * 4}.get(dom, 0)
             act = {1: B * (768 * es + 2304 * 4), 4: B * 768 * (es + 8 + es), 5: B * (768 + 3072) * es, 6: B * (3072 * es + 768 * (8 + es)),
