@@ -2,6 +2,8 @@
 // decode/prefill attention, final RMSNorm + hidden capture, and the fused sampling chain.
 // Reference call sites are cited per kernel; all of them live in the per-step body of
 // /root/reference/ChatTTS/model/gpt.py:396-577 or in the HF LlamaModel forward it calls.
+#include <stdlib.h>
+
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -306,6 +308,12 @@ hipError_t launch_attention(const float* qkv, const void* kcache, const void* vc
                             GptRowMap rm, int M, hipStream_t st) {
   dim3 grid(NHEAD, M);
   const bool decode = rm.q_per_b == 1;
+  static int nw8 = -1;  // CTTS_ATT_NW=8: 8 waves per (utterance, head) in decode (A/B knob)
+  if (nw8 < 0) { const char* e = getenv("CTTS_ATT_NW"); nw8 = (e && atoi(e) == 8) ? 1 : 0; }
+  if (decode && nw8 && kv_wt == WT_BF16 && out_bf16) {
+    CTTS_LAUNCH((attention_k<bf16_t, 8, bf16_t>), grid, dim3(512), st, qkv, (const bf16_t*)kcache, (const bf16_t*)vcache, cmax, (bf16_t*)out, rm);
+    return hipGetLastError();
+  }
 #define ATT(KT, NW, OT) CTTS_LAUNCH((attention_k<KT, NW, OT>), grid, dim3(64 * NW), st, qkv, (const KT*)kcache, (const KT*)vcache, cmax, (OT*)out, rm)
   if (kv_wt == WT_BF16) {
     if (out_bf16) { if (decode) ATT(bf16_t, 4, bf16_t); else ATT(bf16_t, 1, bf16_t); }
