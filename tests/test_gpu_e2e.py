@@ -81,6 +81,21 @@ def test_sharded_rows_equal_full_batch(gpt_f32, golden):
         assert np.array_equal(got, want), b
 
 
+def test_lanes_do_not_change_results(gpt_f32, golden):
+    """the batch cut into 3 concurrently decoding lanes (own stream, graph, compaction state each) == reference run"""
+    c = cases.GEN_CASES["b8"]
+    ids, mask, tmask = cases.gen_inputs(c)
+    ids_t, mask_t = torch.from_numpy(ids), torch.from_numpy(mask)
+    emb = gpt_f32.embed_prompt(ids_t, torch.from_numpy(tmask))
+    warpers, procs = E.gen_logits(625, c["top_P"], c["top_K"], c["rep"])
+    out = list(gpt_f32.generate(emb, ids_t, torch.tensor(c["temperature"]), 625, mask_t, c["max_new"], c["min_new"], (*procs, *warpers),
+                                return_hidden=True, manual_seed=c["manual_seed"], lanes=3))[-1]
+    got = np.concatenate([t.cpu().numpy() for t in out.ids], 0)
+    assert np.array_equal(np.array([int(t.shape[0]) for t in out.ids]), golden["generate"]["b8.lens"])
+    assert np.array_equal(got, golden["generate"]["b8.ids"])
+    assert gpt_f32.last_stats["lanes"] == 3
+
+
 def test_stream_yield_schedule(gpt_f32):
     c = dict(cases.GEN_CASES["c1"])
     outs, _ = run_case(gpt_f32, c, use_graph=True, stream=True)

@@ -67,6 +67,26 @@ def test_rope_row_perm_is_a_permutation_pairing_halves():
     assert torch.equal(t[:, :, 8:] - t[:, :, :8], torch.full((12, 4, 8), 32))
 
 
+def test_asset_layout_round_trip(tmp_path):
+    """the four hot-path safetensors files in the reference's asset layout (config.py:4-11): save -> load is lossless,
+    HF's `model.` prefix and the unused embed_tokens (gpt.py:78) are handled"""
+    from chattts_amd import weights as W
+    from safetensors.torch import save_file
+    sds = {"gpt": W.synthetic_gpt(n_layers=1), "embed": {"emb_code.0.weight": torch.randn(626, 8)},
+           "decoder": {"coef": torch.rand(1, 100, 1)}, "vocos": {"head.istft.window": torch.hann_window(1024)}}
+    W.save_assets(str(tmp_path), sds)
+    got = W.load_assets(str(tmp_path))
+    for name in sds:
+        assert set(got[name]) == set(sds[name])
+        assert all(torch.equal(got[name][k], sds[name][k]) for k in sds[name])
+    # a checkpoint saved from LlamaForCausalLM-style naming: keys prefixed with "model." + an embed_tokens table
+    pref = {"model." + k: v for k, v in sds["gpt"].items()}
+    pref["model.embed_tokens.weight"] = torch.zeros(4, 768)
+    save_file(pref, os.path.join(str(tmp_path), "gpt", "model.safetensors"))
+    got = W.load_assets(str(tmp_path))["gpt"]
+    assert set(got) == set(sds["gpt"]) and W.gpt_layer_count(got) == 1
+
+
 def test_left_pad_starts():
     m = torch.tensor([[0, 0, 1, 1], [1, 1, 1, 1], [0, 1, 1, 1]])
     assert E.left_pad_starts(m).tolist() == [2, 0, 1]
