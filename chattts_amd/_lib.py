@@ -34,7 +34,9 @@ class GenState(C.Structure):
         ("temperature", P), ("pow_table", P),
         ("top_p_thr", C.c_float), ("use_top_p", C.c_int32), ("top_k", C.c_int32), ("use_top_k", C.c_int32),
         ("min_new", C.c_int32), ("eos", C.c_int32), ("row_offset", C.c_int32),
-        ("stop_at", P), ("workspace", P), ("workspace_bytes", C.c_size_t), ("row_map", P), ("n_active", P), ("infer_text", C.c_int32),
+        ("stop_at", P), ("workspace", P), ("workspace_bytes", C.c_size_t), ("row_map", P), ("n_active", P),
+        ("cap", C.c_int32), ("hid_cap", C.c_int32), ("kv_batch", C.c_int32), ("q_batch", C.c_int32), ("prompt_len", P),
+        ("infer_text", C.c_int32),
     ]
 
 

@@ -121,18 +121,20 @@ struct Prof {
 
 static SampleArgs make_sample_args(const ctts_gen_state* s, const float* logits) {
   SampleArgs a;
-  a.logits = logits; a.ids_buf = s->ids_buf; a.tcap = s->T + s->max_new; a.T = s->T; a.len = s->len; a.finish = s->finish;
+  a.logits = logits; a.ids_buf = s->ids_buf; a.tcap = s->cap ? s->cap : s->T + s->max_new; a.T = s->T; a.len = s->len; a.finish = s->finish;
   a.end_idx = s->end_idx; a.q = s->q; a.nq = s->nq; a.temperature = s->temperature; a.pow_table = s->pow_table;
   a.top_p_thr = s->top_p_thr; a.use_top_p = s->use_top_p; a.top_k = s->top_k; a.use_top_k = s->use_top_k;
   a.min_new = s->min_new; a.eos = s->eos; a.row_offset = s->row_offset; a.max_input_ids = NAUDIO - 1; a.stop_at = s->stop_at;
-  a.B = s->B; a.row_map = nullptr; a.n_active = nullptr;
+  a.B = s->B; a.row_map = nullptr; a.n_active = nullptr; a.prompt_len = s->prompt_len; a.q_rows = s->q_batch ? s->q_batch : s->B;
   return a;
 }
 
 static int check_state(const ctts_gpt* g, const ctts_gen_state* s) {
   if (!g || !s) return fail("null engine/state");
   if (s->B <= 0 || s->T <= 0 || s->max_new <= 0) return fail("bad B/T/max_new");
-  if (s->T + s->max_new > g->w.max_pos) return fail("T + max_new (%d) exceeds the RoPE table (%d)", s->T + s->max_new, g->w.max_pos);
+  const int cap_ = s->cap ? s->cap : s->T + s->max_new;
+  if (cap_ > g->w.max_pos) return fail("slot capacity T + max_new (%d) exceeds the RoPE table (%d)", cap_, g->w.max_pos);
+  if (s->cap && s->T + 1 > s->cap) return fail("prompt does not fit the slot capacity");
   if (s->workspace_bytes < ctts_gpt_workspace_bytes(s->B, s->T)) return fail("workspace too small");
   if (s->nq <= 0 || !s->q) return fail("q draws missing");
   if (g->w.weight_dtype == CTTS_BF16 && g->w.kv_dtype != CTTS_BF16) return fail("perf mode needs a bf16 KV cache");
@@ -147,11 +149,11 @@ static int check_state(const ctts_gpt* g, const ctts_gen_state* s) {
 // the 20-layer body + heads + sampling over M = B * q_per_b rows
 static int run_step(ctts_gpt* g, const ctts_gen_state* s, int q_per_b, hipStream_t st, bool prof_ok) {
   const GptWs ws = carve(s->workspace, s->B, s->T);
-  const int B = s->B, M = B * q_per_b, cmax = s->T + s->max_new;
+  const int B = s->B, M = B * q_per_b, cmax = s->cap ? s->cap : s->T + s->max_new;
   const int wt = g->w.weight_dtype, kt = g->w.kv_dtype;
-  const size_t kv_layer = (size_t)B * NHEAD * cmax * HDIM * (kt == CTTS_BF16 ? 2 : 4);
+  const size_t kv_layer = (size_t)(s->kv_batch ? s->kv_batch : B) * NHEAD * cmax * HDIM * (kt == CTTS_BF16 ? 2 : 4);
   const bool dec = q_per_b == 1;
-  const int32_t* rmap = dec ? s->row_map : nullptr;      // decode rows are compact (see GptRowMap); prefill is 1:1
+  const int32_t* rmap = s->row_map;   // decode: compact row -> slot (see GptRowMap); prefill: row group -> slot of a pool (or null)
   const int32_t* nact = dec ? s->n_active : nullptr;
   GptRowMap rm{q_per_b, s->len, s->kv_start, rmap, nact, (dec && g->skip_finished) ? s->finish : nullptr};
   const bool fast = wt == CTTS_BF16;  // perf mode: bf16 activations, RMSNorm gain folded into wqkv / wgu by the loader
@@ -207,7 +209,8 @@ static int run_step(ctts_gpt* g, const ctts_gen_state* s, int q_per_b, hipStream
     { Prof p(g, 6, st, prof_ok); CK(launch_gemm_skinny(a, st)); }
   }
   { Prof p(g, 7, st, prof_ok);
-    CK(launch_final_norm(ws.x, q_per_b, g->w.norm, g->w.rms_eps, ws.hfin, s->hiddens, s->max_new, s->len, s->T, B, rmap, nact, st)); }
+    CK(launch_final_norm(ws.x, q_per_b, g->w.norm, g->w.rms_eps, ws.hfin, s->hiddens, s->hid_cap ? s->hid_cap : s->max_new, s->len, s->T, B, rmap,
+                         nact, s->prompt_len, st)); }
   {
     const int nlog = s->infer_text ? g->w.n_text : NVQ * NAUDIO;   // gpt.py:439-440 text head | :441-454 four code heads
     GemmArgs a;
@@ -241,10 +244,10 @@ static int decode_body(ctts_gpt* g, const ctts_gen_state* s, hipStream_t st, boo
   const GptWs ws = carve(s->workspace, s->B, s->T);
   { Prof p(g, 0, st, prof_ok); const bool fast = g->w.weight_dtype == CTTS_BF16;
     if (s->infer_text)
-      CK(launch_embed_text(g->w.emb_text, g->w.n_text, s->ids_buf, s->T + s->max_new, s->len, ws.x, fast ? ws.xb : nullptr,
+      CK(launch_embed_text(g->w.emb_text, g->w.n_text, s->ids_buf, s->cap ? s->cap : s->T + s->max_new, s->len, ws.x, fast ? ws.xb : nullptr,
                            fast ? ws.ssq : nullptr, s->B, s->row_map, s->n_active, st));
     else
-      CK(launch_embed_codes(g->w.emb_code, s->ids_buf, s->T + s->max_new, s->len, ws.x, fast ? ws.xb : nullptr, fast ? ws.ssq : nullptr, s->B,
+      CK(launch_embed_codes(g->w.emb_code, s->ids_buf, s->cap ? s->cap : s->T + s->max_new, s->len, ws.x, fast ? ws.xb : nullptr, fast ? ws.ssq : nullptr, s->B,
                             s->row_map, s->n_active, st)); }
   return run_step(g, s, 1, st, prof_ok);
 }
@@ -477,7 +480,7 @@ extern "C" int ctts_k_embed_codes(const float* emb_code, const int64_t* ids_buf,
 }
 extern "C" int ctts_k_final_norm(const float* x, int32_t q_per_b, const float* w, float eps, float* hfin, float* hiddens,
                                  int32_t max_new, const int32_t* len, int32_t T, int32_t B, void* stream) {
-  CK(launch_final_norm(x, q_per_b, w, eps, hfin, hiddens, max_new, len, T, B, nullptr, nullptr, (hipStream_t)stream));
+  CK(launch_final_norm(x, q_per_b, w, eps, hfin, hiddens, max_new, len, T, B, nullptr, nullptr, nullptr, (hipStream_t)stream));
   return 0;
 }
 extern "C" int ctts_k_sample(const ctts_gen_state* s, const float* logits, void* stream) {

@@ -15,7 +15,7 @@
 
 __device__ __forceinline__ void row_to_b_slot(const GptRowMap& rm, int m, int& b, int& slot) {
   if (rm.q_per_b == 1) { b = rm.row_map ? rm.row_map[m] : m; slot = rm.len[b] - 1; }
-  else { b = m / rm.q_per_b; slot = m - b * rm.q_per_b; }
+  else { b = m / rm.q_per_b; slot = m - b * rm.q_per_b; if (rm.row_map) b = rm.row_map[b]; }  // prefill into a slot pool
 }
 // decode launches keep the captured grid (B rows); rows beyond the compact active count do nothing
 __device__ __forceinline__ bool row_absent(const int32_t* n_active, int m) { return n_active != nullptr && m >= *n_active; }
@@ -333,7 +333,7 @@ hipError_t launch_attention(const float* qkv, const void* kcache, const void* vc
 __global__ __launch_bounds__(192) void final_norm_k(const float* __restrict__ x, int q_per_b, const float* __restrict__ w, float eps,
                                                     float* __restrict__ hfin, float* __restrict__ hiddens, int max_new,
                                                     const int32_t* __restrict__ len, int T, const int32_t* __restrict__ row_map,
-                                                    const int32_t* __restrict__ n_active) {
+                                                    const int32_t* __restrict__ n_active, const int32_t* __restrict__ prompt_len) {
   __shared__ float part[3];
   const int m = blockIdx.x, t = threadIdx.x;
   if (row_absent(n_active, m)) return;
@@ -349,14 +349,15 @@ __global__ __launch_bounds__(192) void final_norm_k(const float* __restrict__ x,
   float4 o;
   o.x = g.x * (v.x * rstd); o.y = g.y * (v.y * rstd); o.z = g.z * (v.z * rstd); o.w = g.w * (v.w * rstd);
   *reinterpret_cast<float4*>(hfin + (size_t)m * HID + t * 4) = o;
-  const int gen = len[b] - T;
+  const int gen = len[b] - (prompt_len ? prompt_len[b] : T);
   if (hiddens != nullptr && gen >= 0 && gen < max_new)
     *reinterpret_cast<float4*>(hiddens + ((size_t)b * max_new + gen) * HID + t * 4) = o;
 }
 
 hipError_t launch_final_norm(const float* x, int q_per_b, const float* w, float eps, float* hfin, float* hiddens, int max_new,
-                             const int32_t* len, int T, int B, const int32_t* row_map, const int32_t* n_active, hipStream_t st) {
-  CTTS_LAUNCH(final_norm_k, dim3(B), dim3(192), st, x, q_per_b, w, eps, hfin, hiddens, max_new, len, T, row_map, n_active);
+                             const int32_t* len, int T, int B, const int32_t* row_map, const int32_t* n_active,
+                             const int32_t* prompt_len, hipStream_t st) {
+  CTTS_LAUNCH(final_norm_k, dim3(B), dim3(192), st, x, q_per_b, w, eps, hfin, hiddens, max_new, len, T, row_map, n_active, prompt_len);
   return hipGetLastError();
 }
 
@@ -391,7 +392,11 @@ __global__ __launch_bounds__(256) void sample_k(SampleArgs a) {
   const int b = a.row_map ? a.row_map[m] : m;     // utterance (batch slot)
   const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int len = a.len[b];
-  const int gen = len - a.T;  // tokens generated so far == step index i of gpt.py:394
+  if (len >= a.tcap) {  // slot full (slot pools only; generate() never steps past max_new_token): stop, write nothing
+    if (threadIdx.x == 0) a.finish[b] = 1;
+    return;
+  }
+  const int gen = len - (a.prompt_len ? a.prompt_len[b] : a.T);  // tokens generated so far == step index i of gpt.py:394
   const float* lrow = a.logits + ((size_t)m * NVQ + k) * NAUDIO;
   const float temp = a.temperature[k];
 
@@ -488,7 +493,7 @@ __global__ __launch_bounds__(256) void sample_k(SampleArgs a) {
     if (sa >= 0) { mask_eos = mask_eos || (gen < sa); force_eos = gen >= sa; }
   }
   // final softmax over the kept set and argmax(p / q)
-  const float* qrow = a.q + ((size_t)(gen % a.nq) * a.B * NVQ + (size_t)b * NVQ + k) * NAUDIO;
+  const float* qrow = a.q + ((size_t)(gen % a.nq) * a.q_rows * NVQ + (size_t)b * NVQ + k) * NAUDIO;
   float m2 = -INFINITY;
   bool live[SLOTS];
 #pragma unroll
@@ -608,7 +613,11 @@ __global__ __launch_bounds__(256) void sample_text_k(SampleArgs a, int V) {
   if (row_absent(a.n_active, m)) return;
   const int b = a.row_map ? a.row_map[m] : m;
   const int len = a.len[b];
-  const int gen = len - a.T;
+  if (len >= a.tcap) {
+    if (tid == 0) a.finish[b] = 1;
+    return;
+  }
+  const int gen = len - (a.prompt_len ? a.prompt_len[b] : a.T);
   const float* lrow = a.logits + (size_t)m * V;
   const float temp = a.temperature[0];
 
@@ -666,7 +675,7 @@ __global__ __launch_bounds__(256) void sample_text_k(SampleArgs a, int V) {
     const int sa = a.stop_at[b];
     if (sa >= 0) { mask_eos = mask_eos || (gen < sa); force_eos = gen >= sa; }
   }
-  const float* qrow = a.q + ((size_t)(gen % a.nq) * a.B + b) * V;
+  const float* qrow = a.q + ((size_t)(gen % a.nq) * a.q_rows + b) * V;
   float m2 = -INFINITY;
   for (int v = tid; v < V; v += 256) {
     const bool live = (!any_filter || ((keptbits[v >> 5] >> (v & 31)) & 1u)) && !(mask_eos && v == a.eos);

@@ -115,8 +115,8 @@ hipError_t launch_rope_append(float* qkv /*[M,2304]*/, void* kcache, void* vcach
 hipError_t launch_attention(const float* qkv, const void* kcache, const void* vcache, int kv_wt, int cmax,
                             void* out /*[M,768] f32, or bf16 when out_bf16*/, int out_bf16, GptRowMap rm, int M, hipStream_t st);
 hipError_t launch_final_norm(const float* x, int q_per_b, const float* w, float eps, float* hfin /*[B,768]*/,
-                             float* hiddens /*[B,max_new,768]*/, int max_new, const int32_t* len, int T, int B,
-                             const int32_t* row_map, const int32_t* n_active, hipStream_t st);
+                             float* hiddens /*[slots,max_new,768]*/, int max_new, const int32_t* len, int T, int B,
+                             const int32_t* row_map, const int32_t* n_active, const int32_t* prompt_len, hipStream_t st);
 
 struct SampleArgs {
   const float* logits;      // [B, 4*626]
@@ -139,6 +139,8 @@ struct SampleArgs {
   int B;
   const int32_t* row_map;   // decode: workgroup m samples utterance row_map[m] from logits row m; null = identity
   const int32_t* n_active;  // decode: device scalar; null = B
+  const int32_t* prompt_len;  // [slots] per-utterance prompt length, or null (T for all)
+  int q_rows;               // utterance slots in q (>= B)
 };
 hipError_t launch_sample(const SampleArgs& a, hipStream_t st);
 // refine-text mode: logits [B, V], q [nq, B, V], temperature[0]; no repetition penalty (see gpt.hip)

@@ -1,0 +1,197 @@
+"""Continuous batching over a pool of utterance slots.
+
+The reference's default path generates one fixed batch to completion (`GPT.generate`, gpt.py:316-618; rows that
+finish early idle until the last one is done, :592); only its optional vLLM fork schedules requests continuously
+(/root/reference/ChatTTS/model/velocity/scheduler.py:130-293, block_manager.py:73-296).  `SlotPool` is the
+MI355X-native equivalent for this engine: a fixed pool of S utterance slots with a dense KV cache per slot
+(288 GB of HBM make paging unnecessary: 64 slots x 2560 positions x 61 KB = 10 GB), ONE captured decode graph
+for the whole session, and three device-side arrays that make admission / retirement free of re-capture:
+`row_map` + `n_active` (which slots the decode step computes) and `prompt_len` (where each slot's generated part
+starts).  Newly admitted requests are prefilled as a group straight into their slots' KV cache.
+
+Parity contract: a request produces exactly the tokens `GptEngine.generate` produces for it alone with
+`row_offset = 4*slot, total_rows = 4*S` (the Exp(1) draw of a sampling row is the pool row's), because nothing
+in the step mixes utterances.  Seeded sampling only (`manual_seed`): the reference re-seeds its CPU generator every
+step, so the draw is one constant tensor for the whole session.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from collections import deque
+from dataclasses import dataclass
+from typing import Deque, Iterator, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config import GPT
+from .engine import GptEngine, gen_logits, plan_from_processors
+from .rng import ExpDraws, penalty_table
+
+
+@dataclass
+class _Req:
+    rid: object
+    ids: torch.Tensor        # [T, 4] int64
+    tmask: torch.Tensor      # [T] bool
+    max_new: int
+    stop_at: int             # -1: none (benchmark hook, see engine.generate)
+
+
+class SlotPool:
+    POLL = 16
+
+    def __init__(self, engine: GptEngine, slots: int = 64, cap: int = 1536, hid_cap: int = 1024, *, temperature=(0.3,) * 4,
+                 top_P: Optional[float] = 0.7, top_K: Optional[int] = 20, repetition_penalty: float = 1.05, manual_seed: int = 42,
+                 min_new_token: int = 0, eos_token: int = GPT.n_audio - 1):
+        if manual_seed is None:
+            raise NotImplementedError("SlotPool needs manual_seed (one constant Exp(1) draw per session)")
+        if cap > engine.max_pos:
+            raise ValueError("slot capacity exceeds max_position_embeddings")
+        self.eng, self.S, self.cap, self.hid_cap = engine, slots, cap, hid_cap
+        self.lib = engine.lib
+        dev = self.dev = engine.device
+        warpers, procs = gen_logits(GPT.n_audio - 1, top_P, top_K, repetition_penalty)
+        plan = plan_from_processors((*procs, *warpers))
+        h = C.c_void_p()
+        _lib.check(self.lib.ctts_gpt_create(C.byref(h), C.byref(engine._w)), "ctts_gpt_create")
+        self.handle = h
+        self.st = torch.cuda.Stream(device=dev)
+        nvq = GPT.n_vq
+        with torch.cuda.stream(self.st):
+            self.ids_buf = torch.zeros((slots, cap, nvq), dtype=torch.int64, device=dev)
+            self.len = torch.ones((slots,), dtype=torch.int32, device=dev)
+            self.kv_start = torch.zeros((slots,), dtype=torch.int32, device=dev)
+            self.finish = torch.ones((slots,), dtype=torch.uint8, device=dev)      # free slots look finished
+            self.end_idx = torch.zeros((slots,), dtype=torch.int32, device=dev)
+            self.prompt_len = torch.ones((slots,), dtype=torch.int32, device=dev)
+            self.stop_at = torch.full((slots,), -1, dtype=torch.int32, device=dev)
+            self.hiddens = torch.empty((slots, hid_cap, GPT.hidden), dtype=torch.float32, device=dev)
+            kv_shape = (engine.n_layers, slots, GPT.n_heads, cap, GPT.head_dim)
+            self.kcache = torch.zeros(kv_shape, dtype=engine.wdt, device=dev)
+            self.vcache = torch.zeros(kv_shape, dtype=engine.wdt, device=dev)
+            self.row_map = torch.zeros((slots,), dtype=torch.int32, device=dev)
+            self.n_active = torch.zeros((1,), dtype=torch.int32, device=dev)
+            self.q = ExpDraws(slots * nvq, GPT.n_audio, manual_seed).step(0).to(dev).reshape(1, slots * nvq, GPT.n_audio).contiguous()
+            self.temp = torch.tensor(list(temperature), dtype=torch.float32, device=dev)
+            ptab = penalty_table(plan.penalty)
+            self.ptab = None if ptab is None else ptab.to(dev)
+            ws_bytes = self.lib.ctts_gpt_workspace_bytes(slots, 1)
+            self.ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+        self.plan, self.min_new, self.eos = plan, int(min_new_token), int(eos_token)
+        self.dec = self._state(B=slots, T=1, workspace=self.ws, row_map=self.row_map, n_active=self.n_active)
+        self.st.synchronize()
+        _lib.check(self.lib.ctts_gpt_graph_build(self.handle, C.byref(self.dec), self.st.cuda_stream), "ctts_gpt_graph_build")
+        self.free: List[int] = list(range(slots))
+        self.active: dict = {}                 # slot -> (_Req, Tg)
+        self.queue: Deque[_Req] = deque()
+        self.steps = 0
+        self.slot_of: dict = {}               # request id -> slot it ran in (parity tests / tracing)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.st.synchronize()
+            self.lib.ctts_gpt_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _state(self, B, T, workspace, row_map, n_active) -> _lib.GenState:
+        s = _lib.GenState()
+        s.B, s.T, s.max_new = B, T, self.cap - T
+        s.ids_buf, s.len, s.kv_start = self.ids_buf.data_ptr(), self.len.data_ptr(), self.kv_start.data_ptr()
+        s.finish, s.end_idx, s.hiddens = self.finish.data_ptr(), self.end_idx.data_ptr(), self.hiddens.data_ptr()
+        s.kcache, s.vcache, s.q, s.nq = self.kcache.data_ptr(), self.vcache.data_ptr(), self.q.data_ptr(), 1
+        s.temperature, s.pow_table = self.temp.data_ptr(), _lib.ptr(self.ptab)
+        p = self.plan
+        s.top_p_thr = float(np.float32(1.0 - p.top_p)) if p.top_p is not None else 0.0
+        s.use_top_p, s.top_k, s.use_top_k = int(p.top_p is not None), int(p.top_k or 0), int(p.top_k is not None)
+        s.min_new, s.eos, s.row_offset = self.min_new, self.eos, 0
+        s.stop_at = self.stop_at.data_ptr()
+        s.workspace, s.workspace_bytes = workspace.data_ptr(), workspace.numel()
+        s.row_map, s.n_active = _lib.ptr(row_map), _lib.ptr(n_active)
+        s.cap, s.hid_cap, s.kv_batch, s.q_batch = self.cap, self.hid_cap, self.S, self.S
+        s.prompt_len = self.prompt_len.data_ptr()
+        s.infer_text = 0
+        return s
+
+    # -- request intake ---------------------------------------------------------------------------------------
+    def submit(self, rid, input_ids, text_mask=None, max_new_token: int = 512, stop_at: int = -1) -> None:
+        ids = torch.as_tensor(input_ids).to(torch.int64)
+        assert ids.dim() == 2 and ids.shape[1] == GPT.n_vq
+        tm = torch.ones(ids.shape[0], dtype=torch.bool) if text_mask is None else torch.as_tensor(text_mask).bool()
+        if ids.shape[0] + max_new_token + 1 > self.cap or max_new_token > self.hid_cap:
+            raise ValueError("request does not fit a slot (prompt + max_new_token vs cap / hid_cap)")
+        self.queue.append(_Req(rid, ids, tm, int(max_new_token), int(stop_at)))
+
+    def _admit(self) -> None:
+        n = min(len(self.free), len(self.queue))
+        if n == 0:
+            return
+        reqs = [self.queue.popleft() for _ in range(n)]
+        slots = [self.free.pop(0) for _ in range(n)]              # lowest free slots first (deterministic)
+        Tg = max(int(r.ids.shape[0]) for r in reqs)
+        ids = torch.zeros((n, Tg, GPT.n_vq), dtype=torch.int64)
+        mask = torch.zeros((n, Tg), dtype=torch.bool)
+        tmask = torch.zeros((n, Tg), dtype=torch.bool)
+        for i, r in enumerate(reqs):                               # left padding, like Tokenizer.encode (tokenizer.py:73-110)
+            t = int(r.ids.shape[0])
+            ids[i, Tg - t:], mask[i, Tg - t:], tmask[i, Tg - t:] = r.ids, True, r.tmask
+        dev = self.dev
+        with torch.cuda.stream(self.st):
+            sl = torch.tensor(slots, dtype=torch.long, device=dev)
+            emb = self.eng.embed_prompt(ids, tmask)
+            self.ids_buf[sl, :Tg] = ids.to(dev)
+            self.len[sl] = Tg
+            self.prompt_len[sl] = Tg
+            self.kv_start[sl] = (Tg - mask.sum(1)).to(torch.int32).to(dev)
+            self.finish[sl] = 0
+            self.end_idx[sl] = 0
+            self.stop_at[sl] = torch.tensor([r.stop_at for r in reqs], dtype=torch.int32, device=dev)
+            rmap = sl.to(torch.int32)
+            ws = torch.empty((self.lib.ctts_gpt_workspace_bytes(n, Tg),), dtype=torch.uint8, device=dev)
+            pre = self._state(B=n, T=Tg, workspace=ws, row_map=rmap, n_active=None)
+            _lib.check(self.lib.ctts_gpt_prefill(self.handle, C.byref(pre), emb.data_ptr(), self.st.cuda_stream), "ctts_gpt_prefill")
+            self.st.synchronize()  # ws / emb / rmap are freed when this scope ends
+        for s_, r in zip(slots, reqs):
+            self.active[s_] = (r, Tg)
+            self.slot_of[r.rid] = s_
+
+    def _publish_active(self) -> None:
+        act = sorted(self.active)
+        with torch.cuda.stream(self.st):
+            if act:
+                self.row_map[: len(act)].copy_(torch.tensor(act, dtype=torch.int32))
+            self.n_active.fill_(len(act))
+
+    # -- main loop --------------------------------------------------------------------------------------------
+    def run(self) -> Iterator[Tuple[object, torch.Tensor, torch.Tensor]]:
+        """Yields (request id, ids [n,4] int64, hiddens [n,768] float32) as requests complete, admitting queued
+        requests into freed slots between decode chunks."""
+        while self.queue or self.active:
+            self._admit()
+            # requests can already be over after the prefill's sample (EOS at step 0) -> handled by the poll below
+            self._publish_active()
+            if self.active:
+                _lib.check(self.lib.ctts_gpt_graph_launch(self.handle, self.POLL, self.st.cuda_stream), "ctts_gpt_graph_launch")
+                self.steps += self.POLL
+            with torch.cuda.stream(self.st):
+                fin = self.finish.cpu()
+                end = self.end_idx.cpu()
+            done = [s for s, (r, _) in self.active.items() if bool(fin[s]) or int(end[s]) >= r.max_new]
+            for s in done:
+                r, Tg = self.active.pop(s)
+                n = min(int(end[s]), r.max_new)
+                with torch.cuda.stream(self.st):
+                    ids = self.ids_buf[s, Tg: Tg + n].clone()
+                    hid = self.hiddens[s, :n].clone()
+                    self.finish[s] = 1      # a request cut at max_new_token stops costing attention bandwidth
+                self.st.synchronize()
+                self.free.append(s)
+                self.free.sort()
+                yield r.rid, ids, hid

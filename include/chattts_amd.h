@@ -93,6 +93,15 @@ typedef struct {
                                       running to the front and refreshes this (and n_active) whenever it polls `finish`; every
                                       array above stays indexed by the batch slot.  NULL = identity / all rows. */
   const int32_t* n_active;         /* device scalar or NULL: number of compact rows the decode step computes */
+  /* Slot-pool (continuous batching) extensions -- all optional, 0 / NULL = the plain generate() layout.  They let a
+   * prefill of B freshly admitted utterances write into a larger pool of `kv_batch` utterance slots (row_map[m] = slot
+   * of prefill row-group m), with every per-utterance array (ids_buf, len, kv_start, finish, end_idx, hiddens, q,
+   * stop_at, prompt_len) allocated for the pool and indexed by slot. */
+  int32_t cap;                     /* rows per slot in ids_buf and in the KV cache (0: T + max_new) */
+  int32_t hid_cap;                 /* rows per slot in hiddens (0: max_new) */
+  int32_t kv_batch;                /* utterance slots in kcache/vcache (0: B) */
+  int32_t q_batch;                 /* utterance slots in q (0: B) */
+  const int32_t* prompt_len;       /* [slots] padded prompt length of each slot (NULL: T for every row) */
   int32_t infer_text;              /* 1: refine-text mode -- text embedding/head, ONE sampling row per utterance (q is
                                       [nq, B, n_text], temperature[0]), the sampled id is written to all 4 slots
                                       (gpt.py:519-525); repetition penalty must be off */

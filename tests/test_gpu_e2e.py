@@ -290,3 +290,34 @@ def test_long_context_prefix_consistency(gpt_bf16):
         assert torch.isfinite(long.hiddens[b]).all()
     with pytest.raises(ValueError):   # T + max_new_token beyond the RoPE table / max_position_embeddings (config.py:57)
         run(4096, [10, 10, 10])
+
+
+def test_continuous_batching_equals_isolated_generation(gpt_f32):
+    """SlotPool: 9 requests through 4 slots, admitted as slots free up; every request's tokens are
+    bit-identical to generating it alone at its pool row (row_offset = 4*slot, total_rows = 4*slots), whatever group it
+    was left-padded into and whatever ran beside it."""
+    from chattts_amd.serving import SlotPool
+    S = 4
+    pool = SlotPool(gpt_f32, slots=S, cap=160, hid_cap=64, manual_seed=21)
+    rs = np.random.RandomState(6)
+    reqs = {}
+    lens = [5, 40, 17, 33, 9, 21, 3, 48, 12]
+    for i, n in enumerate(lens):
+        T = int(rs.randint(6, 30))
+        ids = np.repeat(rs.randint(1, 21178, size=(T, 1)), 4, axis=1).astype(np.int64)
+        reqs[i] = (ids, n)
+        pool.submit(i, ids, max_new_token=48, stop_at=n)
+    got = {rid: (ids.cpu().numpy(), hid.cpu().numpy()) for rid, ids, hid in pool.run()}
+    assert sorted(got) == list(range(len(lens)))
+    assert len(set(pool.slot_of.values())) <= S and not pool.active and len(pool.free) == S
+    warpers, procs = E.gen_logits(625, 0.7, 20, 1.05)
+    for rid, (ids, n) in reqs.items():
+        assert got[rid][0].shape == (n, 4), (rid, got[rid][0].shape)
+        ids_t = torch.from_numpy(ids)[None]
+        emb = gpt_f32.embed_prompt(ids_t, torch.ones((1, ids.shape[0]), dtype=torch.bool))
+        ref = list(gpt_f32.generate(emb, ids_t, torch.tensor([0.3] * 4), 625, None, 64, 0, (*procs, *warpers), return_hidden=True,
+                                    manual_seed=21, stop_at=torch.tensor([n], dtype=torch.int32), row_offset=4 * pool.slot_of[rid],
+                                    total_rows=4 * S))[-1]
+        assert np.array_equal(got[rid][0], ref.ids[0].cpu().numpy()), rid
+        assert np.abs(got[rid][1] - ref.hiddens[0].cpu().numpy()).max() < 1e-5, rid
+    pool.close()
