@@ -40,7 +40,7 @@ class _Req:
 
 
 class SlotPool:
-    POLL = 16
+    POLL = 8   # decode steps between two looks at the finish flags (= admission / retirement granularity)
 
     def __init__(self, engine: GptEngine, slots: int = 64, cap: int = 1536, hid_cap: int = 1024, *, temperature=(0.3,) * 4,
                  top_P: Optional[float] = 0.7, top_K: Optional[int] = 20, repetition_penalty: float = 1.05, manual_seed: int = 42,
@@ -87,6 +87,7 @@ class SlotPool:
         self.active: dict = {}                 # slot -> (_Req, Tg)
         self.queue: Deque[_Req] = deque()
         self.steps = 0
+        self._keep = None
         self.slot_of: dict = {}               # request id -> slot it ran in (parity tests / tracing)
 
     def close(self):
@@ -157,7 +158,7 @@ class SlotPool:
             ws = torch.empty((self.lib.ctts_gpt_workspace_bytes(n, Tg),), dtype=torch.uint8, device=dev)
             pre = self._state(B=n, T=Tg, workspace=ws, row_map=rmap, n_active=None)
             _lib.check(self.lib.ctts_gpt_prefill(self.handle, C.byref(pre), emb.data_ptr(), self.st.cuda_stream), "ctts_gpt_prefill")
-            self.st.synchronize()  # ws / emb / rmap are freed when this scope ends
+            self._keep = (ws, emb, rmap, sl)  # stream-ordered: stay alive until the next poll's sync, no extra sync here
         for s_, r in zip(slots, reqs):
             self.active[s_] = (r, Tg)
             self.slot_of[r.rid] = s_
