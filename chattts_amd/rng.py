@@ -48,6 +48,16 @@ class ExpDraws:
             return self._const
         return self._draw(None)
 
+    def step_into(self, i: int, dst: torch.Tensor) -> None:
+        """Writes step i's draw into `dst` ([rows, vocab] float32, e.g. a pinned staging row).  When this object covers
+        the whole batch the draw goes straight into `dst` (same generator call, no temporary, no copy)."""
+        if self._const is not None:
+            dst.copy_(self._const)
+        elif self.r0 == 0 and self.r1 == self.total_rows and dst.is_contiguous():
+            dst.exponential_(1)
+        else:
+            dst.copy_(self._draw(None))
+
     def block(self, i0: int, n: int) -> torch.Tensor:
         """[n, rows, vocab] for steps i0 .. i0+n-1 (n == 1 when seeded)."""
         if self._const is not None:
