@@ -122,6 +122,17 @@ class Context:                    # gpt.py:103-111
         return self._interrupt
 
 
+class _EventGroup:
+    """several CUDA events waited on as one"""
+
+    def __init__(self, evs):
+        self.evs = evs
+
+    def synchronize(self):
+        for e in self.evs:
+            e.synchronize()
+
+
 def left_pad_starts(attention_mask: torch.Tensor) -> torch.Tensor:
     """kv_start[b] = number of leading zeros; raises unless the mask is left padding (tokenizer.py:73-110)."""
     m = attention_mask.to(torch.bool).cpu()
@@ -356,32 +367,72 @@ class GptEngine:
             ln.s = s
             L.append(ln)
 
-        q_host = None if draws.constant else torch.empty((nq // 2, B * nrow, V), dtype=torch.float32).pin_memory()
+        # ---- Exp(1) draws of the unseeded mode: the reference draws one [rows, V] tensor per step from torch's global
+        # CPU generator (gpt.py:498-500).  That stream is serial (~2 ms per step at B=64, more than a decode step), so
+        # a worker thread draws 32-step blocks ahead into two pinned buffers while the GPU consumes the previous block;
+        # uploads are stream-ordered behind the launches that still read the ring half they overwrite (no host sync).
+        half = nq // 2
+        feeder = None
+        if not draws.constant:
+            from concurrent.futures import ThreadPoolExecutor
+            feeder = dict(pool=ThreadPoolExecutor(max_workers=1), bufs=[torch.empty((half, B * nrow, V), dtype=torch.float32).pin_memory()
+                                                                           for _ in range(2)],
+                          evs=[None, None], fut=None, next_block=0, states=[])
+
+            def draw_block(blk):
+                buf = feeder["bufs"][blk % 2]
+                if feeder["evs"][blk % 2] is not None:
+                    feeder["evs"][blk % 2].synchronize()       # the H2D copy that last read this buffer is done
+                feeder["states"].append((blk, torch.get_rng_state()))
+                nthr = torch.get_num_threads()
+                torch.set_num_threads(1)   # exponential_ is a serial stream; a 100+-thread OpenMP wake-up costs ~10 ms per call
+                try:
+                    n = min(half, max_new - blk * half)
+                    for j in range(max(n, 0)):
+                        draws.step_into(blk * half + j, buf[j])
+                finally:
+                    torch.set_num_threads(nthr)
+                return blk
+
+            feeder["fut"] = feeder["pool"].submit(draw_block, 0)
         uploaded = 0  # steps whose Exp(1) draws are on the device (unseeded mode only)
 
         def ensure_q(upto: int):
             nonlocal uploaded
-            if q_host is None:
+            if feeder is None:
                 return
-            half = nq // 2
             while uploaded < upto:
-                for ln in L:
-                    ln.st.synchronize()  # ring slab + staging reuse; unseeded sampling is host-RNG bound anyway
+                blk = feeder["fut"].result()
                 n = min(half, max_new - uploaded)
-                # one intra-op thread: exponential_ is a serial stream anyway, and waking a 100+-thread OpenMP pool for a
-                # 640 KB tensor costs ~10 ms per call on a big host (measured 12 ms vs 2 ms per step)
-                nthr = torch.get_num_threads()
-                torch.set_num_threads(1)
-                try:
-                    for j in range(n):
-                        draws.step_into(uploaded + j, q_host[j])
-                finally:
-                    torch.set_num_threads(nthr)
+                buf = feeder["bufs"][blk % 2]
                 slab = uploaded % nq
+                evs = []
                 for ln in L:
                     with torch.cuda.stream(ln.st):
-                        ln.q_d[slab: slab + n].copy_(q_host[:n, ln.lo * nrow: ln.hi * nrow], non_blocking=True)
+                        ln.q_d[slab: slab + n].copy_(buf[:n, ln.lo * nrow: ln.hi * nrow], non_blocking=True)
+                        ev = torch.cuda.Event()
+                        ev.record(ln.st)
+                        evs.append(ev)
+                feeder["evs"][blk % 2] = evs[-1] if len(evs) == 1 else _EventGroup(evs)
                 uploaded += n
+                if uploaded < max_new:
+                    feeder["fut"] = feeder["pool"].submit(draw_block, blk + 1)
+                else:
+                    feeder["fut"] = None
+
+        def finish_rng(steps_reference: int):
+            """Leave torch's global CPU generator exactly where the reference would: it draws once per executed step
+            (the loop of gpt.py:394 stops at the step where the last row hits EOS), while the feeder ran ahead."""
+            if feeder is None:
+                return
+            if feeder["fut"] is not None:
+                feeder["fut"].result()
+            feeder["pool"].shutdown(wait=True)
+            blk = min(steps_reference // half, len(feeder["states"]) - 1)
+            torch.set_rng_state(feeder["states"][blk][1])
+            tmp = torch.empty((draws.total_rows, V), dtype=torch.float32)
+            for _ in range(steps_reference - blk * half):
+                tmp.exponential_(1)
 
         def outputs() -> GenerationOutputs:
             """Snapshot of the result so far.  Uses each lane's `end_snap` (host copy of end_idx taken by the last
@@ -439,6 +490,7 @@ class GptEngine:
         fin0 = torch.cat([poll(ln) for ln in L])  # syncs: the step-0 rule needs it (gpt.py:527)
         if bool(fin0.any()):
             self.logger.warning("unexpected end at index %s", str(fin0.nonzero().flatten().tolist()))
+            finish_rng(1)   # the reference drew exactly one tensor (step 0) before it got here
             if ensure_non_empty and manual_seed is None:
                 self.logger.warning("regenerate in order to ensure non-empty")
                 yield from self.generate(emb, inputs_ids, temperature, eos_token, attention_mask, max_new_token,
@@ -493,6 +545,8 @@ class GptEngine:
                 _lib.check(lib.ctts_gpt_profile_end(L[0].handle, C.byref(n_s), C.byref(tot)), "profile_end")
                 self.last_stats["profile"] = (int(n_s.value), float(tot.value))
         finally:
+            if feeder is not None:
+                feeder["pool"].shutdown(wait=True)   # idempotent; the generator-state rewind happens in finish_rng
             if graph_ok:
                 for ln in L:
                     ln.st.synchronize()
@@ -506,6 +560,9 @@ class GptEngine:
         for ln in L:
             if not ln.done or ln.end_snap is None:
                 poll(ln)
+        # steps the reference loop would have executed: up to and including the step at which the last row hit EOS
+        steps_ref = (max(max(ln.end_snap) for ln in L) + 1) if all_done else min(steps_done, max_new)
+        finish_rng(min(steps_ref, max_new))
         yield outputs()
 
 

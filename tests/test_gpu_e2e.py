@@ -321,3 +321,16 @@ def test_continuous_batching_equals_isolated_generation(gpt_f32):
         assert np.array_equal(got[rid][0], ref.ids[0].cpu().numpy()), rid
         assert np.abs(got[rid][1] - ref.hiddens[0].cpu().numpy()).max() < 1e-5, rid
     pool.close()
+
+
+def test_unseeded_leaves_global_generator_where_the_reference_would(gpt_f32, golden):
+    """manual_seed=None: the host draws run ahead of the GPU in a worker thread, but afterwards torch's global CPU
+    generator must sit exactly after one [rows, 626] draw per executed step, like the reference's (gpt.py:498-500)"""
+    c = cases.GEN_CASES["unseeded"]
+    outs, _ = run_case(gpt_f32, c, use_graph=True)
+    after = torch.rand(3)
+    torch.manual_seed(c["global_seed"])
+    steps = int(max(t.shape[0] for t in outs[0].ids))     # never finished: max_new_token steps were executed
+    for _ in range(steps):
+        torch.empty(2 * 4, 626).exponential_(1)
+    assert torch.equal(after, torch.rand(3))
