@@ -1,18 +1,23 @@
-"""`Chat`-level seam of the hot path: mirror of `Chat._infer_code` / `Chat._decode_to_wavs`
-(/root/reference/ChatTTS/core.py:513-662) over token ids.
+"""`Chat`-level seam of the hot path: mirror of `Chat.infer` / `_infer` / `_infer_code` / `_refine_text` /
+`_decode_to_wavs` (/root/reference/ChatTTS/core.py:208-270, 395-503, 513-751).
 
-The reference's text front end (normalizer, tokenizer, speaker prompt decoration -- SURVEY 2.1 rows
-7-9) is host string work outside the accelerated path and needs assets that are not reachable
-offline; this facade therefore starts where `_infer_code` has tokens: `input_ids [B,T,4]`,
-`attention_mask [B,T]`, `text_mask [B,T]` exactly as `Tokenizer.encode` returns them
-(tokenizer.py:36-126).  INTEGRATION.md shows the ~10-line patch that routes the reference's own
-`Chat` through these two calls.
+Two entry levels:
+  * text level  -- `Chat.infer(text, ...)` with the reference's argument list.  Needs a tokenizer directory
+    (`asset/tokenizer`, config.py:10) and, for speaker sampling, the `Config.spk_stat` string (config.py:132); the host
+    front end lives in `chattts_amd.frontend`.
+  * token level -- `infer_code` / `refine_text_ids` / `infer_ids` / `infer_ids_stream` / `infer_tokens` start where
+    `_infer_code` has tensors: `input_ids [B,T,4]`, `attention_mask [B,T]`, `text_mask [B,T]` exactly as
+    `Tokenizer.encode` returns them (tokenizer.py:36-126).  bench.py and the parity tests use this level (synthetic
+    prompts; the trained tokenizer is not reachable offline).
+INTEGRATION.md shows the ~10-line patch that routes the reference's own `Chat` through the engine instead.
 """
 from __future__ import annotations
 
 import logging
+import os
+import re
 from dataclasses import dataclass
-from typing import Iterator, List, Optional
+from typing import Iterator, List, Optional, Union
 
 import numpy as np
 import torch
@@ -20,6 +25,7 @@ import torch
 from . import weights as W
 from .config import GPT
 from .engine import CodecEngine, Context, GenerationOutputs, GptEngine, gen_logits
+from .frontend import Normalizer, Speaker, Tokenizer, apply_speaker
 
 
 @dataclass(repr=False, eq=False)
@@ -38,7 +44,7 @@ class RefineTextParams:           # core.py:182-193
 
 @dataclass(repr=False, eq=False)
 class InferCodeParams:            # core.py:195-206 (+ the RefineTextParams fields it inherits, :182-193)
-    prompt: str = ""
+    prompt: str = "[speed_5]"
     top_P: float = 0.7
     top_K: int = 20
     temperature: float = 0.3
@@ -57,41 +63,82 @@ class InferCodeParams:            # core.py:195-206 (+ the RefineTextParams fiel
 
 
 class Chat:
-    def __init__(self, logger=logging.getLogger("chattts_amd")):
+    RefineTextParams = RefineTextParams      # the reference nests the two dataclasses in `Chat` (core.py:182-206)
+    InferCodeParams = InferCodeParams
+
+    def __init__(self, logger=logging.getLogger("chattts_amd"), homophones_map: Optional[str] = None):
+        """`homophones_map`: path of the reference package's `res/homophones_map.json` (core.py:39-42); without it the
+        normalizer skips homophone replacement."""
         self.logger = logger
         self.context = Context()
         self.gpt: Optional[GptEngine] = None
         self.codec: Optional[CodecEngine] = None
+        self.tokenizer: Optional[Tokenizer] = None
+        self.speaker: Optional[Speaker] = None
+        self.normalizer = Normalizer(homophones_map, logger)
 
-    def has_loaded(self) -> bool:
+    def has_loaded(self, use_decoder: bool = True) -> bool:
         return self.gpt is not None and self.codec is not None
 
     def load(self, custom_path: Optional[str] = None, device: Optional[torch.device] = None, dtype: str = "bf16",
-             state_dicts: Optional[dict] = None) -> bool:
-        """`Chat.load(source="custom", custom_path=...)` (core.py:137-163) for the four hot-path asset
-        files; `state_dicts` short-circuits disk I/O (synthetic weights)."""
+             state_dicts: Optional[dict] = None, tokenizer: Union[None, str, Tokenizer] = None, spk_stat: Optional[str] = None,
+             source: str = "custom", force_redownload: bool = False, compile: bool = False, coef=None,
+             use_flash_attn: bool = False, use_vllm: bool = False, experimental: bool = False) -> bool:
+        """`Chat.load` (core.py:137-163) for `source="custom"` / `"local"` (assets already on disk; there is no
+        network path here): the four hot-path safetensors files of `custom_path` and `asset/tokenizer`.
+        `state_dicts` short-circuits disk I/O (synthetic weights); `tokenizer` is a directory or a `Tokenizer`;
+        `spk_stat` is the reference's `Config.spk_stat` string (needed by `sample_random_speaker` only).
+        `compile`, `use_flash_attn`, `use_vllm`, `experimental` select between the reference's torch back ends and
+        have no meaning for this engine (accepted, ignored); `coef` is not supported (the file's `coef` tensor is used)."""
+        if source not in ("custom", "local"):
+            self.logger.error("chattts_amd loads local assets only (source=%s)", source)
+            return False
+        if coef is not None:
+            raise NotImplementedError("coef override: the Decoder.safetensors `coef` tensor is used")
         device = device or torch.device("cuda:0")
-        sds = state_dicts if state_dicts is not None else W.load_assets(custom_path)
+        root = custom_path if custom_path is not None else os.getcwd()
+        sds = state_dicts if state_dicts is not None else W.load_assets(root)
         self.gpt = GptEngine(sds["gpt"], sds["embed"], device, dtype=dtype, logger=self.logger)
         self.codec = CodecEngine(sds["decoder"], sds["vocos"], device)
+        self.device = device
+        if tokenizer is None and state_dicts is None and os.path.isdir(os.path.join(root, "asset", "tokenizer")):
+            tokenizer = os.path.join(root, "asset", "tokenizer")
+        if tokenizer is not None:
+            self.tokenizer = tokenizer if isinstance(tokenizer, Tokenizer) else Tokenizer(tokenizer)
+        if spk_stat is not None:
+            self.speaker = Speaker(GPT.hidden, spk_stat, torch.device("cpu"))
         return True
 
     def unload(self):               # core.py:165-174
         self.gpt = None
         self.codec = None
+        self.tokenizer = None
+        self.speaker = None
+
+    # -- speakers (core.py:176-180) ---------------------------------------------------------------------------
+    def sample_random_speaker(self) -> str:
+        if self.speaker is None:
+            raise RuntimeError("speaker statistics not loaded: pass spk_stat= to Chat.load")
+        return self.speaker.sample_random()
+
+    def sample_audio_speaker(self, wav) -> str:
+        raise NotImplementedError("sample_audio_speaker needs the DVAE encoder + GFSQ (SURVEY.md 8f-2): not built yet")
 
     def interrupt(self):            # core.py:272-273
         self.context.set(True)
 
     def infer_code(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, text_mask: torch.Tensor,
                    params: InferCodeParams = InferCodeParams(), stream: bool = False, return_hidden: bool = True,
-                   **shard_kw) -> Iterator[GenerationOutputs]:
-        """`Chat._infer_code` from `gen_logits` on (core.py:580-658)."""
+                   spk_emb_ids: Optional[int] = None, **shard_kw) -> Iterator[GenerationOutputs]:
+        """`Chat._infer_code` from `gen_logits` on (core.py:580-658).  With `params.spk_emb` and `spk_emb_ids` (the
+        tokenizer's id of `[spk_emb]`) the prompt embedding gets the speaker vector at those positions (:630-637)."""
         assert self.has_loaded()
         # core.py:558-561: a scalar temperature is replicated over the 4 codebooks, a list is used as is
         temperature = torch.tensor(params.temperature if isinstance(params.temperature, list) else [params.temperature] * GPT.n_vq)
         warpers, procs = gen_logits(GPT.n_audio - 1, params.top_P, params.top_K, params.repetition_penalty)
         emb = self.gpt.embed_prompt(input_ids, text_mask)
+        if params.spk_emb is not None and spk_emb_ids is not None:
+            apply_speaker(emb, params.spk_emb, input_ids, spk_emb_ids)
         return self.gpt.generate(
             emb, input_ids, temperature, GPT.n_audio - 1, attention_mask, params.max_new_token, params.min_new_token,
             (*procs, *warpers), False, False, return_hidden, stream, params.show_tqdm, params.ensure_non_empty,
@@ -178,3 +225,112 @@ class Chat:
         if split_text:
             return [np.concatenate(stripped)]
         return stripped
+
+    # ---------------------------------------------------------------------------------------------------------
+    # text level: the reference's public call (core.py:208-270) and its private helpers
+    # ---------------------------------------------------------------------------------------------------------
+    def _need_tokenizer(self):
+        if self.tokenizer is None:
+            raise RuntimeError("no tokenizer loaded: Chat.load(custom_path=<dir holding asset/tokenizer>) or tokenizer=<dir>")
+
+    def _infer_code(self, text, stream: bool, device, return_hidden: bool, params: InferCodeParams) -> Iterator[GenerationOutputs]:
+        """core.py:542-662: decorate -> tokenise (+ audio-code prompt `spk_smp`) -> embed -> speaker -> generate."""
+        self._need_tokenizer()
+        if not isinstance(text, list):
+            text = [text]
+        assert len(text), "text should not be empty"
+        prompt = Speaker.decode_prompt(params.spk_smp) if params.spk_smp is not None else None
+        ids, attn, tmask = self.tokenizer.encode(
+            Speaker.decorate_code_prompts(text, params.prompt, params.txt_smp, params.spk_emb), GPT.n_vq, prompt=prompt)
+        return self.infer_code(ids, attn, tmask, params, stream=stream, return_hidden=return_hidden,
+                               spk_emb_ids=self.tokenizer.spk_emb_ids)
+
+    def _refine_text(self, text, device, params: RefineTextParams) -> GenerationOutputs:
+        """core.py:665-751"""
+        self._need_tokenizer()
+        if not isinstance(text, list):
+            text = [text]
+        ids, attn, tmask = self.tokenizer.encode(Speaker.decorate_text_prompts(text, params.prompt), GPT.n_vq)
+        return self.refine_text_ids(ids, attn, tmask, self.tokenizer.eos_token, params)
+
+    def infer(self, text, stream=False, lang=None, skip_refine_text=False, refine_text_only=False, use_decoder=True,
+              do_text_normalization=True, do_homophone_replacement=True, split_text=True, max_split_batch=4,
+              params_refine_text: RefineTextParams = RefineTextParams(), params_infer_code: InferCodeParams = InferCodeParams()):
+        """core.py:208-270: `List[np.ndarray]` (one stripped waveform per text, or ONE concatenated waveform when
+        `split_text`), a generator of `np.ndarray [B, n]` chunks when `stream`, the refined text when `refine_text_only`."""
+        self.context.set(False)
+        if split_text and isinstance(text, str):
+            if "\n" in text:
+                text = text.split("\n")
+            else:                                  # sentence ends: after a CJK full stop, or after ". "
+                text = [t for t in re.split(r"(?<=\u3002)|(?<=\.\s)", text) if t]
+            self.logger.info("split text into %d parts", len(text))
+        if len(text) == 0:
+            return []
+        res_gen = self._infer(text, stream, lang, skip_refine_text, refine_text_only, use_decoder, do_text_normalization,
+                              do_homophone_replacement, split_text, max_split_batch, params_refine_text, params_infer_code)
+        if stream:
+            return res_gen
+        if refine_text_only:
+            return next(res_gen)
+        thr = np.float32(1e-5)
+        stripped = [wav[np.abs(wav) > thr] for wavs in res_gen for wav in wavs]   # sample-level strip, also mid-utterance
+        return [np.concatenate(stripped)] if split_text else stripped
+
+    def _infer(self, text, stream, lang, skip_refine_text, refine_text_only, use_decoder, do_text_normalization,
+               do_homophone_replacement, split_text, max_split_batch, params_refine_text, params_infer_code):
+        """core.py:395-503 (generator)."""
+        assert self.has_loaded(use_decoder=use_decoder)
+        if not use_decoder:
+            raise NotImplementedError("use_decoder=False decodes token ids through the DVAE's GFSQ (SURVEY.md 8f-2): not built yet")
+        if not isinstance(text, list):
+            text = [text]
+        text = [self.normalizer(t, do_text_normalization, do_homophone_replacement, lang) for t in text]
+        if not skip_refine_text:
+            refined = self._refine_text(text, self.device, params_refine_text)
+            tokens = [row[row.less(self.tokenizer.break_0_ids)] for row in refined.ids]   # control tokens >= [break_0] dropped
+            text = self.tokenizer.decode(tokens)
+            refined.destroy()
+            if refine_text_only:
+                yield "\n".join(text) if (split_text and isinstance(text, list)) else text
+                return
+        if split_text and len(text) > 1 and params_infer_code.spk_smp is None:
+            # core.py:435-453: the first sentence is synthesised alone and its audio becomes the speaker prompt of the rest
+            refer_text = text[0]
+            result = next(self._infer_code(refer_text, False, self.device, use_decoder, params_infer_code))
+            wavs = self.decode_to_wavs(result.hiddens)
+            result.destroy()
+            params_infer_code.spk_smp = self.sample_audio_speaker(wavs[0])
+            params_infer_code.txt_smp = refer_text
+        length = 0
+        pass_batch_count = 0
+        step = max_split_batch if split_text else len(text)
+        for lo in range(0, len(text), step):
+            batch = text[lo: lo + step]
+            if split_text:
+                self.logger.info("infer split %d~%d", lo, lo + len(batch))
+            wavs, skipped = None, None
+            for result in self._infer_code(batch, stream, self.device, use_decoder, params_infer_code):
+                if stream:
+                    pass_batch_count += 1
+                    if pass_batch_count <= params_infer_code.pass_first_n_batches:
+                        # the reference decodes these yields and drops the audio (core.py:482-490); the decode is only
+                        # needed if this turns out to be the LAST yield (the tail below reads `wavs`)
+                        wavs, skipped = None, result
+                        continue
+                wavs, skipped = self.decode_to_wavs(result.hiddens), None
+                result.destroy()
+                if stream:
+                    a, b = length, min(length + params_infer_code.stream_speed, wavs.shape[1])
+                    length = b
+                    yield wavs[:, a:b]
+                else:
+                    yield wavs
+            if stream:
+                if wavs is None and skipped is not None:
+                    wavs = self.decode_to_wavs(skipped.hiddens)
+                if wavs is None:
+                    continue
+                new_wavs = wavs[:, length:]
+                keep_cols = np.sum(np.abs(new_wavs) > 1e-5, axis=0) > 0
+                yield new_wavs[:, keep_cols]

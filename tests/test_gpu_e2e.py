@@ -334,3 +334,62 @@ def test_unseeded_leaves_global_generator_where_the_reference_would(gpt_f32, gol
     for _ in range(steps):
         torch.empty(2 * 4, 626).exponential_(1)
     assert torch.equal(after, torch.rand(3))
+
+
+def test_chat_infer_text_level_matches_oracle(weights):
+    """`Chat.infer(text, ...)` (core.py:208-270) end to end in f32 parity mode: normalise -> decorate -> tokenise ->
+    embed -> speaker vector at [spk_emb] -> generate, and the refine-text leg; token ids and refined strings equal the
+    numpy oracle driven by the same host front end (the front end itself is pinned in tests/test_frontend.py)."""
+    import os
+    from chattts_amd import frontend as F, rng
+    from chattts_amd.core import Chat
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    with open(os.path.join(gold, "spk_stat.txt"), encoding="utf-8") as f:
+        spk_stat = f.read()
+    chat = Chat()
+    assert chat.load(state_dicts=weights, device=DEV, dtype="f32", tokenizer=os.path.join(gold, "tokenizer"), spk_stat=spk_stat)
+    tok = chat.tokenizer
+    torch.manual_seed(11)
+    spk = chat.sample_random_speaker()
+    texts = ["What is [uv_break]your favorite english food?[laugh][lbreak]", "hello world"]
+    p = Chat.InferCodeParams(spk_emb=spk, max_new_token=20, manual_seed=7, show_tqdm=False)
+    out = next(chat._infer_code(list(texts), False, DEV, True, p))
+    wavs = chat.infer(list(texts), skip_refine_text=True, split_text=False, params_infer_code=p)
+    full = chat.decode_to_wavs(out.hiddens)
+    assert len(wavs) == 2 and all(np.array_equal(w, r[np.abs(r) > 1e-5]) for w, r in zip(wavs, full))
+
+    # oracle leg: same normaliser + decoration + tokenizer, numpy embedding with the unit speaker vector substituted
+    normed = [chat.normalizer(t, True, True, None) for t in texts]
+    assert normed[0] == "What is [uv_break]your favorite english food[laugh][lbreak]"   # '?' is outside the model's alphabet
+    ids, mask, tmask = tok.encode(F.Speaker.decorate_code_prompts(normed, p.prompt, None, spk), 4)
+    ids, mask, tmask = ids.numpy(), mask.numpy(), tmask.numpy()
+    assert (ids[..., 0] == tok.spk_emb_ids).sum() == 2
+    llama = llama_np.LlamaWeights({k: v.numpy() for k, v in weights["gpt"].items()})
+    esd = {k: v.numpy() for k, v in weights["embed"].items()}
+    emb = generate_np.embed_prompt(esd, ids, tmask)
+    unit = torch.nn.functional.normalize(torch.from_numpy(F.Speaker.decode_vector(spk)), p=2.0, dim=0, eps=1e-12).float().numpy()
+    emb[ids[..., 0] == tok.spk_emb_ids] = unit
+    draws = rng.ExpDraws(2 * 4, 626, 7)
+    ref = generate_np.generate(llama, esd, generate_np.fold_heads(esd), emb, ids, mask, temperature=np.array([0.3] * 4, np.float32),
+                               draw_q=lambda i: draws.step(i).numpy(), pow_table=rng.penalty_table(1.05).numpy(), max_new_token=20)
+    for b in range(2):
+        assert np.array_equal(out.ids[b].cpu().numpy(), ref.ids[b])
+        assert np.abs(out.hiddens[b].cpu().numpy() - ref.hiddens[b]).max() < 2e-4
+
+    # refine-text leg (the shape of /root/reference/tests/#655.py:34-48): strings out
+    rp = Chat.RefineTextParams(prompt="[oral_2][laugh_0][break_6]", manual_seed=12345, max_new_token=10, show_tqdm=False)
+    refined = chat.infer(list(texts), refine_text_only=True, split_text=False, params_refine_text=rp)
+    ids, mask, tmask = tok.encode(F.Speaker.decorate_text_prompts(normed, rp.prompt), 4)
+    ids, mask, tmask = ids.numpy(), mask.numpy(), tmask.numpy()
+    draws = rng.ExpDraws(2, 21178, 12345)
+    rt = generate_np.generate(llama, esd, generate_np.fold_head_text(esd), generate_np.embed_prompt(esd, ids, tmask), ids, mask,
+                              temperature=np.array([0.7], np.float32), draw_q=lambda i: draws.step(i).numpy(), pow_table=None,
+                              max_new_token=10, eos=tok.eos_token, infer_text=True)
+    want = tok.decode([torch.from_numpy(r)[torch.from_numpy(r) < tok.break_0_ids] for r in rt.ids])
+    assert isinstance(refined, list) and refined == want
+    joined = chat.infer("hello world\nthe time of day", refine_text_only=True, split_text=True, params_refine_text=rp)
+    assert isinstance(joined, str) and joined.count("\n") == 1
+    with pytest.raises(NotImplementedError):
+        chat.infer(list(texts), skip_refine_text=True, split_text=True, params_infer_code=Chat.InferCodeParams(max_new_token=4, manual_seed=1))
+    with pytest.raises(NotImplementedError):
+        chat.infer(texts[0], skip_refine_text=True, split_text=False, use_decoder=False)
