@@ -56,6 +56,25 @@ class CodecWeights(C.Structure):
     ]
 
 
+class TrunkWeights(C.Structure):
+    _fields_ = [
+        ("idim", C.c_int32), ("odim", C.c_int32), ("hidden", C.c_int32), ("bn_dim", C.c_int32), ("n_blocks", C.c_int32),
+        ("conv_in0_w", P), ("conv_in0_b", P), ("conv_in2_w", P), ("conv_in2_b", P),
+        ("dw_w", PP), ("dw_b", PP), ("ln_w", PP), ("ln_b", PP), ("pw1_w", PP), ("pw1_b", PP), ("pw2_w", PP), ("pw2_b", PP),
+        ("gamma", PP), ("conv_out_w", P),
+    ]
+
+
+class DvaeWeights(C.Structure):
+    _fields_ = [
+        ("encoder", TrunkWeights), ("decoder", TrunkWeights),
+        ("ds0_w", P), ("ds0_b", P), ("ds1_w", P), ("ds1_b", P), ("out_conv_w", P), ("coef", P),
+        ("q_in_w", P), ("q_in_b", P), ("q_out_w", P), ("q_out_b", P),
+        ("levels", C.c_int32 * 4), ("G", C.c_int32), ("R", C.c_int32), ("D", C.c_int32), ("bound_first", C.c_int32),
+        ("mel_window", P), ("mel_fb", P), ("twiddle", P),
+    ]
+
+
 I32, F, SZ = C.c_int32, C.c_float, C.c_size_t
 
 # name -> (restype, argtypes): every symbol include/chattts_amd.h declares
@@ -77,6 +96,13 @@ SIGNATURES = {
     "ctts_codec_workspace_bytes": (SZ, [I32, I32]),
     "ctts_dvae_decode": (C.c_int, [P, P, P, I32, I32, P, SZ, P]),
     "ctts_vocos_decode": (C.c_int, [P, P, P, I32, I32, P, SZ, P]),
+    "ctts_dvae_create": (C.c_int, [PP, C.POINTER(DvaeWeights)]),
+    "ctts_dvae_destroy": (None, [P]),
+    "ctts_dvae_code_frames": (I32, [I32]),
+    "ctts_dvae_encode_workspace_bytes": (SZ, [I32]),
+    "ctts_dvae_decode_workspace_bytes": (SZ, [I32, I32]),
+    "ctts_dvae_encode": (C.c_int, [P, P, I32, P, P, SZ, P]),
+    "ctts_dvae_decode_codes": (C.c_int, [P, P, P, I32, I32, P, SZ, P]),
     "ctts_k_gemm": (C.c_int, [I32, P, P, P, I32, I32, I32, I32, I32, I32, I32, P, F, P, I32, P, P, I32, I32, I32, I32, I32, P]),
     "ctts_k_gemm_fast": (C.c_int, [P, I32, P, I32, I32, I32, P, F, I32, P, I32, P, I32, P, P]),
     "ctts_k_qkv_rope": (C.c_int, [P, P, I32, P, F, P, P, P, I32, P, P, I32, P, P, I32, P]),

@@ -24,6 +24,7 @@ import torch
 
 from . import weights as W
 from .config import GPT
+from .dvae import DvaeEngine
 from .engine import CodecEngine, Context, GenerationOutputs, GptEngine, gen_logits
 from .frontend import Normalizer, Speaker, Tokenizer, apply_speaker
 
@@ -73,12 +74,14 @@ class Chat:
         self.context = Context()
         self.gpt: Optional[GptEngine] = None
         self.codec: Optional[CodecEngine] = None
+        self.dvae: Optional[DvaeEngine] = None
         self.tokenizer: Optional[Tokenizer] = None
         self.speaker: Optional[Speaker] = None
         self.normalizer = Normalizer(homophones_map, logger)
 
     def has_loaded(self, use_decoder: bool = True) -> bool:
-        return self.gpt is not None and self.codec is not None
+        """core.py:50-66: the decoder path needs `Decoder.safetensors`, the `use_decoder=False` path the full DVAE"""
+        return self.gpt is not None and self.codec is not None and (use_decoder or self.dvae is not None)
 
     def load(self, custom_path: Optional[str] = None, device: Optional[torch.device] = None, dtype: str = "bf16",
              state_dicts: Optional[dict] = None, tokenizer: Union[None, str, Tokenizer] = None, spk_stat: Optional[str] = None,
@@ -100,6 +103,7 @@ class Chat:
         sds = state_dicts if state_dicts is not None else W.load_assets(root)
         self.gpt = GptEngine(sds["gpt"], sds["embed"], device, dtype=dtype, logger=self.logger)
         self.codec = CodecEngine(sds["decoder"], sds["vocos"], device)
+        self.dvae = DvaeEngine(sds["dvae"], device) if "dvae" in sds else None
         self.device = device
         if tokenizer is None and state_dicts is None and os.path.isdir(os.path.join(root, "asset", "tokenizer")):
             tokenizer = os.path.join(root, "asset", "tokenizer")
@@ -112,6 +116,7 @@ class Chat:
     def unload(self):               # core.py:165-174
         self.gpt = None
         self.codec = None
+        self.dvae = None
         self.tokenizer = None
         self.speaker = None
 
@@ -122,7 +127,10 @@ class Chat:
         return self.speaker.sample_random()
 
     def sample_audio_speaker(self, wav) -> str:
-        raise NotImplementedError("sample_audio_speaker needs the DVAE encoder + GFSQ (SURVEY.md 8f-2): not built yet")
+        """24 kHz waveform -> `spk_smp` string: DVAE encode to [4,T] codes, packed like `Speaker.encode_prompt`"""
+        if self.dvae is None:
+            raise RuntimeError("full DVAE not loaded (asset/DVAE.safetensors, or state_dicts['dvae'])")
+        return Speaker.encode_prompt(self.dvae.sample_audio(wav))
 
     def interrupt(self):            # core.py:272-273
         self.context.set(True)
@@ -157,10 +165,15 @@ class Chat:
             params.min_new_token, (*procs, *warpers), True, False, False, False, params.show_tqdm, params.ensure_non_empty,
             24, params.manual_seed, self.context, **kw))
 
-    def decode_to_wavs(self, hiddens: List[torch.Tensor]) -> np.ndarray:
-        """`Chat._decode_to_wavs(result.hiddens, use_decoder=True)` (core.py:513-539) -> np.float32 [B, n]."""
-        assert self.has_loaded()
-        return self.codec.decode_to_wavs(hiddens).cpu().numpy()
+    def decode_to_wavs(self, result_list: List[torch.Tensor], use_decoder: bool = True) -> np.ndarray:
+        """`Chat._decode_to_wavs` (core.py:513-539) -> np.float32 [B, n]: per-row hidden states [T_b,768] through the
+        decoder, or (use_decoder=False) per-row token ids [T_b,4] through the full DVAE's codebook; then Vocos."""
+        assert self.has_loaded(use_decoder)
+        if len(result_list) == 0:
+            return np.array([], dtype=np.float32)
+        if use_decoder:
+            return self.codec.decode_to_wavs(result_list).cpu().numpy()
+        return self.codec.vocos_decode(self.dvae.decode_codes(result_list)).cpu().numpy()
 
     def infer_ids(self, input_ids, attention_mask, text_mask, params: InferCodeParams = InferCodeParams(), **kw) -> np.ndarray:
         """non-stream `Chat._infer` body for one batch (core.py:469-481, split_text=False, skip_refine_text=True),
@@ -281,8 +294,6 @@ class Chat:
                do_homophone_replacement, split_text, max_split_batch, params_refine_text, params_infer_code):
         """core.py:395-503 (generator)."""
         assert self.has_loaded(use_decoder=use_decoder)
-        if not use_decoder:
-            raise NotImplementedError("use_decoder=False decodes token ids through the DVAE's GFSQ (SURVEY.md 8f-2): not built yet")
         if not isinstance(text, list):
             text = [text]
         text = [self.normalizer(t, do_text_normalization, do_homophone_replacement, lang) for t in text]
@@ -298,7 +309,7 @@ class Chat:
             # core.py:435-453: the first sentence is synthesised alone and its audio becomes the speaker prompt of the rest
             refer_text = text[0]
             result = next(self._infer_code(refer_text, False, self.device, use_decoder, params_infer_code))
-            wavs = self.decode_to_wavs(result.hiddens)
+            wavs = self.decode_to_wavs(result.hiddens if use_decoder else result.ids, use_decoder)
             result.destroy()
             params_infer_code.spk_smp = self.sample_audio_speaker(wavs[0])
             params_infer_code.txt_smp = refer_text
@@ -318,7 +329,7 @@ class Chat:
                         # needed if this turns out to be the LAST yield (the tail below reads `wavs`)
                         wavs, skipped = None, result
                         continue
-                wavs, skipped = self.decode_to_wavs(result.hiddens), None
+                wavs, skipped = self.decode_to_wavs(result.hiddens if use_decoder else result.ids, use_decoder), None
                 result.destroy()
                 if stream:
                     a, b = length, min(length + params_infer_code.stream_speed, wavs.shape[1])
@@ -328,7 +339,7 @@ class Chat:
                     yield wavs
             if stream:
                 if wavs is None and skipped is not None:
-                    wavs = self.decode_to_wavs(skipped.hiddens)
+                    wavs = self.decode_to_wavs(skipped.hiddens if use_decoder else skipped.ids, use_decoder)
                 if wavs is None:
                     continue
                 new_wavs = wavs[:, length:]

@@ -11,13 +11,14 @@
 #include "kernels.hpp"
 
 static thread_local char g_err[512] = "";
-static int fail(const char* fmt, ...) {
+int ctts_fail(const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
   return -1;
 }
+#define fail ctts_fail
 #define CK(expr)                                                                                   \
   do {                                                                                             \
     hipError_t _e = (expr);                                                                        \

@@ -1,5 +1,5 @@
 // Acoustic-decoder kernels for gfx950 that are not GEMMs (channels-last [B, F, C] layout):
-//   dwconv_ln : ConvNeXt depthwise Conv1d(k7, dilation d, zero pad 3d) + LayerNorm(512, eps 1e-6)
+//   dwconv_ln : ConvNeXt depthwise Conv1d(k7, dilation d, zero pad 3d) + LayerNorm(C = 512 | 256, eps 1e-6)
 //               (/root/reference/ChatTTS/model/dvae.py:26-35,49-52 and vocos.modules.ConvNeXtBlock)
 //   layernorm : LayerNorm(512) (VocosBackbone.norm / final_layer_norm)
 //   istft     : ISTFTHead tail -- mag = min(exp(.), 1e2), S = mag (cos p + i sin p), per-frame
@@ -10,61 +10,68 @@
 #include "common.hpp"
 #include "kernels.hpp"
 
-#define CCH 512  // channel count of both ConvNeXt stacks
-
+// channels = 64 lanes x CPL: 512 (CPL 8: both ConvNeXt stacks of the decoder path) or 256 (CPL 4: the full DVAE's trunks)
+template <int CPL>
 __device__ __forceinline__ void ln_finish(float* y, const float* __restrict__ lw, const float* __restrict__ lb, float eps, int c0,
                                           float* __restrict__ dst) {
+  constexpr int C = 64 * CPL;
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) s += y[i];
-  const float mean = wave_sum(s) * (1.0f / CCH);
+  for (int i = 0; i < CPL; ++i) s += y[i];
+  const float mean = wave_sum(s) * (1.0f / C);
   float v = 0.f;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) { const float d = y[i] - mean; v += d * d; }
-  const float rstd = 1.0f / sqrtf(wave_sum(v) * (1.0f / CCH) + eps);
-  const float4 w0 = *reinterpret_cast<const float4*>(lw + c0), w1 = *reinterpret_cast<const float4*>(lw + c0 + 4);
-  const float4 b0 = *reinterpret_cast<const float4*>(lb + c0), b1 = *reinterpret_cast<const float4*>(lb + c0 + 4);
-  float4 o0, o1;
-  o0.x = (y[0] - mean) * rstd * w0.x + b0.x; o0.y = (y[1] - mean) * rstd * w0.y + b0.y;
-  o0.z = (y[2] - mean) * rstd * w0.z + b0.z; o0.w = (y[3] - mean) * rstd * w0.w + b0.w;
-  o1.x = (y[4] - mean) * rstd * w1.x + b1.x; o1.y = (y[5] - mean) * rstd * w1.y + b1.y;
-  o1.z = (y[6] - mean) * rstd * w1.z + b1.z; o1.w = (y[7] - mean) * rstd * w1.w + b1.w;
-  *reinterpret_cast<float4*>(dst + c0) = o0;
-  *reinterpret_cast<float4*>(dst + c0 + 4) = o1;
+  for (int i = 0; i < CPL; ++i) { const float d = y[i] - mean; v += d * d; }
+  const float rstd = 1.0f / sqrtf(wave_sum(v) * (1.0f / C) + eps);
+#pragma unroll
+  for (int q = 0; q < CPL / 4; ++q) {
+    const float4 w = *reinterpret_cast<const float4*>(lw + c0 + 4 * q), b = *reinterpret_cast<const float4*>(lb + c0 + 4 * q);
+    float4 o;
+    o.x = (y[4 * q + 0] - mean) * rstd * w.x + b.x; o.y = (y[4 * q + 1] - mean) * rstd * w.y + b.y;
+    o.z = (y[4 * q + 2] - mean) * rstd * w.z + b.z; o.w = (y[4 * q + 3] - mean) * rstd * w.w + b.w;
+    *reinterpret_cast<float4*>(dst + c0 + 4 * q) = o;
+  }
 }
 
-// w is the depthwise kernel transposed on the host to [7][C] so that a lane's 8 channels are contiguous
+// w is the depthwise kernel transposed on the host to [7][C] so that a lane's CPL channels are contiguous
+template <int CPL>
 __global__ __launch_bounds__(256) void dwconv_ln_k(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
                                                    const float* __restrict__ lw, const float* __restrict__ lb, float eps, int dil,
                                                    float* __restrict__ y, int F, int rows) {
+  constexpr int C = 64 * CPL;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
-  const int lane = threadIdx.x & 63, c0 = lane * 8;
+  const int lane = threadIdx.x & 63, c0 = lane * CPL;
   const int bi = row / F, f = row - bi * F;
-  float acc[8];
-  {
-    const float4 b0 = *reinterpret_cast<const float4*>(b + c0), b1 = *reinterpret_cast<const float4*>(b + c0 + 4);
-    acc[0] = b0.x; acc[1] = b0.y; acc[2] = b0.z; acc[3] = b0.w; acc[4] = b1.x; acc[5] = b1.y; acc[6] = b1.z; acc[7] = b1.w;
+  float acc[CPL];
+#pragma unroll
+  for (int q = 0; q < CPL / 4; ++q) {
+    const float4 b0 = *reinterpret_cast<const float4*>(b + c0 + 4 * q);
+    acc[4 * q] = b0.x; acc[4 * q + 1] = b0.y; acc[4 * q + 2] = b0.z; acc[4 * q + 3] = b0.w;
   }
 #pragma unroll
   for (int j = 0; j < 7; ++j) {
     const int fs = f + (j - 3) * dil;
     if (fs >= 0 && fs < F) {
-      const float* xp = x + ((size_t)bi * F + fs) * CCH + c0;
-      const float4 x0 = *reinterpret_cast<const float4*>(xp), x1 = *reinterpret_cast<const float4*>(xp + 4);
-      const float4 w0 = *reinterpret_cast<const float4*>(w + j * CCH + c0), w1 = *reinterpret_cast<const float4*>(w + j * CCH + c0 + 4);
-      acc[0] = fmaf(w0.x, x0.x, acc[0]); acc[1] = fmaf(w0.y, x0.y, acc[1]); acc[2] = fmaf(w0.z, x0.z, acc[2]); acc[3] = fmaf(w0.w, x0.w, acc[3]);
-      acc[4] = fmaf(w1.x, x1.x, acc[4]); acc[5] = fmaf(w1.y, x1.y, acc[5]); acc[6] = fmaf(w1.z, x1.z, acc[6]); acc[7] = fmaf(w1.w, x1.w, acc[7]);
+      const float* xp = x + ((size_t)bi * F + fs) * C + c0;
+#pragma unroll
+      for (int q = 0; q < CPL / 4; ++q) {
+        const float4 x0 = *reinterpret_cast<const float4*>(xp + 4 * q);
+        const float4 w0 = *reinterpret_cast<const float4*>(w + j * C + c0 + 4 * q);
+        acc[4 * q] = fmaf(w0.x, x0.x, acc[4 * q]); acc[4 * q + 1] = fmaf(w0.y, x0.y, acc[4 * q + 1]);
+        acc[4 * q + 2] = fmaf(w0.z, x0.z, acc[4 * q + 2]); acc[4 * q + 3] = fmaf(w0.w, x0.w, acc[4 * q + 3]);
+      }
     }
   }
-  ln_finish(acc, lw, lb, eps, c0, y + (size_t)row * CCH);
+  ln_finish<CPL>(acc, lw, lb, eps, c0, y + (size_t)row * C);
 }
 
 hipError_t launch_dwconv_ln(const float* x, const float* w, const float* b, const float* ln_w, const float* ln_b, float eps, int dil,
                             float* y, int B, int F, int C, hipStream_t st) {
-  if (C != CCH) return hipErrorInvalidValue;
   const int rows = B * F;
-  hipLaunchKernelGGL(dwconv_ln_k, dim3((rows + 3) / 4), dim3(256), 0, st, x, w, b, ln_w, ln_b, eps, dil, y, F, rows);
+  if (C == 512) hipLaunchKernelGGL(dwconv_ln_k<8>, dim3((rows + 3) / 4), dim3(256), 0, st, x, w, b, ln_w, ln_b, eps, dil, y, F, rows);
+  else if (C == 256) hipLaunchKernelGGL(dwconv_ln_k<4>, dim3((rows + 3) / 4), dim3(256), 0, st, x, w, b, ln_w, ln_b, eps, dil, y, F, rows);
+  else return hipErrorInvalidValue;
   return hipGetLastError();
 }
 
@@ -73,14 +80,14 @@ __global__ __launch_bounds__(256) void layernorm_k(const float* __restrict__ x, 
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int lane = threadIdx.x & 63, c0 = lane * 8;
-  const float* xp = x + (size_t)row * CCH + c0;
+  const float* xp = x + (size_t)row * 512 + c0;
   const float4 x0 = *reinterpret_cast<const float4*>(xp), x1 = *reinterpret_cast<const float4*>(xp + 4);
   float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-  ln_finish(v, lw, lb, eps, c0, y + (size_t)row * CCH);
+  ln_finish<8>(v, lw, lb, eps, c0, y + (size_t)row * 512);
 }
 
 hipError_t launch_layernorm(const float* x, const float* w, const float* b, float eps, float* y, int rows, int C, hipStream_t st) {
-  if (C != CCH) return hipErrorInvalidValue;
+  if (C != 512) return hipErrorInvalidValue;
   hipLaunchKernelGGL(layernorm_k, dim3((rows + 3) / 4), dim3(256), 0, st, x, w, b, eps, y, rows);
   return hipGetLastError();
 }

@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256) void gemm_tiled_f32_k(GemmArgs a) {
   if (col < N) {
     float bias = 0.f, gam = 1.f;
     if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_SCALE_RES) bias = a.bias[col];
-    if (EPI == EPI_BIAS_SCALE_RES || EPI == EPI_SCALE) gam = a.gamma[col];
+    if (EPI == EPI_BIAS_SCALE_RES || EPI == EPI_SCALE || EPI == EPI_LOG_DIV) gam = a.gamma[col];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);  // C/D map of 32x32 MFMA
@@ -270,6 +270,7 @@ __global__ __launch_bounds__(256) void gemm_tiled_f32_k(GemmArgs a) {
         else if (EPI == EPI_BIAS_SCALE_RES) v = a.res[(size_t)row * a.ldr + col] + gam * (v + bias);
         else if (EPI == EPI_RES) v = a.res[(size_t)row * a.ldr + col] + v;
         else if (EPI == EPI_SCALE) v = v * gam;
+        else if (EPI == EPI_LOG_DIV) v = logf(fmaxf(v, 1e-5f)) / gam;
         a.C[(size_t)row * a.ldc + col] = v;
       }
     }
@@ -287,6 +288,7 @@ hipError_t launch_gemm_tiled(const GemmArgs& a, hipStream_t st) {
     case EPI_BIAS_GELU: CTTS_LAUNCH((gemm_tiled_f32_k<EPI_BIAS_GELU>), grid, block, st, a); break;
     case EPI_BIAS_SCALE_RES: CTTS_LAUNCH((gemm_tiled_f32_k<EPI_BIAS_SCALE_RES>), grid, block, st, a); break;
     case EPI_SCALE: CTTS_LAUNCH((gemm_tiled_f32_k<EPI_SCALE>), grid, block, st, a); break;
+    case EPI_LOG_DIV: CTTS_LAUNCH((gemm_tiled_f32_k<EPI_LOG_DIV>), grid, block, st, a); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

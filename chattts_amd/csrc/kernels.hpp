@@ -31,6 +31,7 @@ enum GemmEpi {
   EPI_BIAS_GELU = 4,   // C = gelu(acc + bias[n])
   EPI_BIAS_SCALE_RES = 5,  // C = res + gamma[n] * (acc + bias[n])    (ConvNeXt pwconv2)
   EPI_SCALE = 6,       // C = acc * scale[n]                          (DVAE out_conv * coef)
+  EPI_LOG_DIV = 7,     // C = log(max(acc, 1e-5)) / gamma[n]          (log-mel / coef, DVAE encode; f32 tiles only)
 };
 
 struct GemmArgs {
@@ -154,3 +155,21 @@ hipError_t launch_dwconv_ln(const float* x, const float* w /*[C,7]*/, const floa
 hipError_t launch_layernorm(const float* x, const float* w, const float* b, float eps, float* y, int rows, int C, hipStream_t st);
 hipError_t launch_istft(const float* head /*[B,F,1026]*/, const float* window /*[1024]*/, const float* twiddle /*[512,2]*/,
                         float* frames /*[B,F,1024] scratch*/, float* wav /*[B,256(F-1)]*/, int B, int F, hipStream_t st);
+
+// ---- full DVAE: mel front end + GFSQ (dvae.hip) ------------------------------------------------
+// |STFT| of one waveform: center=True reflect padding, frame f = padded[256 f, 256 f + 1024) * window, 1024-point FFT,
+// mag [F][516] (bins 0..512, then 3 zeros so that the mel projection's K is a multiple of 4)
+hipError_t launch_stft_mag(const float* wav, int n, const float* window, const float* twiddle, float* mag, int F, hipStream_t st);
+struct GfsqArgs {
+  const float* in_w;   // [G][4][D]   project_in
+  const float* in_b;   // [G][4]
+  const float* out_w;  // [G][D][4]   project_out
+  const float* out_b;  // [G][D]
+  int levels[4];
+  int G, R, D;         // D = 512 channels per group
+  int bound_first;
+};
+hipError_t launch_gfsq_encode(const GfsqArgs& q, const float* feat /*[rows][G*D]*/, int32_t* codes /*[rows][G*R]*/, int rows, hipStream_t st);
+hipError_t launch_gfsq_embed(const GfsqArgs& q, const int64_t* codes /*[rows][G*R]*/, float* feat /*[rows][G*D]*/, int rows, hipStream_t st);
+
+int ctts_fail(const char* fmt, ...);   // sets the thread's last-error string, returns -1 (capi.hip)

@@ -16,6 +16,7 @@ It is generated with torch's CPU generator, which is bit-reproducible for a fixe
 from __future__ import annotations
 
 import hashlib
+import math
 import os
 from typing import Dict
 
@@ -124,6 +125,64 @@ def synthetic_vocos(seed: int = 1237) -> StateDict:
     return sd
 
 
+def _trunk(g: torch.Generator, sd: StateDict, prefix: str, idim: int, odim: int, hidden: int, bn: int, n_layers: int) -> None:
+    """`DVAEDecoder(idim, odim, n_layer, bn_dim, hidden)` (dvae.py:131-161), same init style as `synthetic_decoder`."""
+    sd[prefix + "conv_in.0.weight"] = _normal(g, (bn, idim, 3), (1.0 / (idim * 3)) ** 0.5)
+    sd[prefix + "conv_in.0.bias"] = _normal(g, (bn,), 0.1)
+    sd[prefix + "conv_in.2.weight"] = _normal(g, (hidden, bn, 3), (1.0 / (bn * 3)) ** 0.5)
+    sd[prefix + "conv_in.2.bias"] = _normal(g, (hidden,), 0.1)
+    for i in range(n_layers):
+        p = f"{prefix}decoder_block.{i}."
+        sd[p + "weight"] = torch.full((hidden,), 1.0 / n_layers) * (1.0 + _normal(g, (hidden,), 0.1))
+        sd[p + "dwconv.weight"] = _normal(g, (hidden, 1, 7), (1.0 / 7) ** 0.5)
+        sd[p + "dwconv.bias"] = _normal(g, (hidden,), 0.1)
+        sd[p + "norm.weight"] = 1.0 + _normal(g, (hidden,), 0.05)
+        sd[p + "norm.bias"] = _normal(g, (hidden,), 0.05)
+        sd[p + "pwconv1.weight"] = _normal(g, (hidden * 4, hidden), (1.0 / hidden) ** 0.5)
+        sd[p + "pwconv1.bias"] = _normal(g, (hidden * 4,), 0.1)
+        sd[p + "pwconv2.weight"] = _normal(g, (hidden, hidden * 4), (1.0 / (hidden * 4)) ** 0.5)
+        sd[p + "pwconv2.bias"] = _normal(g, (hidden,), 0.1)
+    sd[prefix + "conv_out.weight"] = _normal(g, (odim, hidden, 1), (1.0 / hidden) ** 0.5)
+
+
+def mel_filterbank(n_freqs: int = 513, n_mels: int = 100, sample_rate: int = 24000) -> torch.Tensor:
+    """torchaudio.functional.melscale_fbanks(n_freqs, 0, sr/2, n_mels, sr, norm=None, mel_scale="htk") -> [n_freqs, n_mels]:
+    the `mel_scale.fb` buffer of the MelSpectrogram inside DVAE.preprocessor_mel (dvae.py:189-196)."""
+    all_freqs = torch.linspace(0, sample_rate // 2, n_freqs)
+    to_mel = lambda f: 2595.0 * math.log10(1.0 + f / 700.0)
+    m_pts = torch.linspace(to_mel(0.0), to_mel(sample_rate / 2.0), n_mels + 2)
+    f_pts = 700.0 * (10.0 ** (m_pts / 2595.0) - 1.0)
+    f_diff = f_pts[1:] - f_pts[:-1]
+    slopes = f_pts.unsqueeze(0) - all_freqs.unsqueeze(1)
+    down = -slopes[:, :-2] / f_diff[:-1]
+    up = slopes[:, 2:] / f_diff[1:]
+    return torch.clamp(torch.min(down, up), min=0.0)
+
+
+def synthetic_dvae(seed: int = 1238, n_layers: int = 12) -> StateDict:
+    """The full DVAE of `asset/DVAE.safetensors` (dvae.py:209-244 with config.py:31-47: encoder 512->1024 and decoder
+    512->512 trunks of hidden 256 / bn 128, GroupedResidualFSQ(1024, levels 5^4, G=2, R=2), mel front end buffers).
+    Quantiser keys follow vector_quantize_pytorch's module tree (`rvqs.{g}.project_in/out`)."""
+    g = torch.Generator().manual_seed(seed)
+    sd: StateDict = {"coef": 0.5 + torch.rand((1, 100, 1), generator=g)}
+    sd["downsample_conv.0.weight"] = _normal(g, (512, 100, 3), (1.0 / 300) ** 0.5)
+    sd["downsample_conv.0.bias"] = _normal(g, (512,), 0.1)
+    sd["downsample_conv.2.weight"] = _normal(g, (512, 512, 4), (1.0 / 2048) ** 0.5)
+    sd["downsample_conv.2.bias"] = _normal(g, (512,), 0.1)
+    _trunk(g, sd, "encoder.", 512, 1024, 256, 128, n_layers)
+    _trunk(g, sd, "decoder.", 512, 512, 256, 128, n_layers)
+    sd["out_conv.weight"] = _normal(g, (100, 512, 3), (1.0 / 1536) ** 0.5)
+    for grp in range(2):
+        p = f"vq_layer.quantizer.rvqs.{grp}."
+        sd[p + "project_in.weight"] = _normal(g, (4, 512), 2.0 * (1.0 / 512) ** 0.5)   # z std ~ 2-3: all 5 levels get used
+        sd[p + "project_in.bias"] = _normal(g, (4,), 0.2)
+        sd[p + "project_out.weight"] = _normal(g, (512, 4), 0.5)
+        sd[p + "project_out.bias"] = _normal(g, (512,), 0.1)
+    sd["preprocessor_mel.mel_spec.spectrogram.window"] = torch.hann_window(1024)
+    sd["preprocessor_mel.mel_spec.mel_scale.fb"] = mel_filterbank()
+    return sd
+
+
 def synthetic_all(n_layers: int = GPT.n_layers) -> Dict[str, StateDict]:
     return {
         "gpt": synthetic_gpt(n_layers=n_layers),
@@ -151,12 +210,15 @@ ASSET_FILES = {
     "decoder": "Decoder.safetensors",
     "vocos": "Vocos.safetensors",
 }
+OPTIONAL_ASSET_FILES = {"dvae": "DVAE.safetensors"}   # full DVAE (encoder + GFSQ): speaker prompts and use_decoder=False only
 
 
 def save_assets(root: str, sds: Dict[str, StateDict]) -> None:
     from safetensors.torch import save_file
 
-    for name, rel in ASSET_FILES.items():
+    for name, rel in {**ASSET_FILES, **OPTIONAL_ASSET_FILES}.items():
+        if name not in sds:
+            continue
         path = os.path.join(root, rel)
         os.makedirs(os.path.dirname(path), exist_ok=True)
         save_file({k: v.contiguous() for k, v in sds[name].items()}, path)
@@ -167,7 +229,9 @@ def load_assets(root: str) -> Dict[str, StateDict]:
     from safetensors import safe_open
 
     out: Dict[str, StateDict] = {}
-    for name, rel in ASSET_FILES.items():
+    for name, rel in {**ASSET_FILES, **OPTIONAL_ASSET_FILES}.items():
+        if name in OPTIONAL_ASSET_FILES and not os.path.exists(os.path.join(root, rel)):
+            continue
         sd: StateDict = {}
         with safe_open(os.path.join(root, rel), framework="pt") as f:
             for k in f.keys():

@@ -175,6 +175,60 @@ int ctts_dvae_decode(ctts_codec* c, const float* hid, float* mel, int32_t B, int
 int ctts_vocos_decode(ctts_codec* c, const float* mel, float* wav, int32_t B, int32_t F, void* workspace, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Full DVAE (asset/DVAE.safetensors): audio -> 4 x T codes and codes -> mel through the GFSQ codebook.
+ * Replaces `self.dvae(wav, "encode")` of `Chat.sample_audio_speaker` (ChatTTS/core.py:179-180 ->
+ * DVAE.sample_audio, dvae.py:299-303, encode branch :265-274) and `self.dvae(batch_ids)` of
+ * `Chat._decode_to_wavs(result.ids, use_decoder=False)` (core.py:518,535; decode branch dvae.py:276-297
+ * with GFSQ._embed :87-97).  Dense weights are float32 [N][K] (f32-input MFMA tiles); convs repacked
+ * [Cout][tap][Cin]; depthwise kernels [7][hidden].
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ctts_dvae ctts_dvae;
+
+typedef struct {            /* DVAEDecoder(idim, odim, n_layer, bn_dim, hidden)  dvae.py:131-172 */
+  int32_t idim, odim, hidden /* 256 | 512 */, bn_dim, n_blocks;
+  const float* conv_in0_w; const float* conv_in0_b;   /* [bn][3][idim], [bn] */
+  const float* conv_in2_w; const float* conv_in2_b;   /* [hidden][3][bn], [hidden] */
+  const float* const* dw_w; const float* const* dw_b;
+  const float* const* ln_w; const float* const* ln_b;
+  const float* const* pw1_w; const float* const* pw1_b;   /* [4 hidden][hidden] */
+  const float* const* pw2_w; const float* const* pw2_b;   /* [hidden][4 hidden] */
+  const float* const* gamma;
+  const float* conv_out_w;                                 /* [odim][hidden] */
+} ctts_trunk_weights;
+
+typedef struct {
+  ctts_trunk_weights encoder;   /* 512 -> 1024, hidden 256 (config.py:33-39) */
+  ctts_trunk_weights decoder;   /* 512 -> 512,  hidden 256 (config.py:40-46) */
+  const float* ds0_w; const float* ds0_b;   /* downsample_conv.0: [512][3][100] */
+  const float* ds1_w; const float* ds1_b;   /* downsample_conv.2 (k4, stride 2, pad 1) repacked as a k3 conv over frame
+                                             * pairs: [512][3][1024] = {[0, W0], [W1, W2], [W3, 0]} */
+  const float* out_conv_w;                  /* [100][3][512] */
+  const float* coef;                        /* [100] */
+  /* GroupedResidualFSQ(dim 1024, levels, num_quantizers R, groups G): per group project_in / project_out */
+  const float* q_in_w; const float* q_in_b;     /* [G][4][D], [G][4] */
+  const float* q_out_w; const float* q_out_b;   /* [G][D][4], [G][D] */
+  int32_t levels[4];
+  int32_t G, R, D;                          /* 2, 2, 512 */
+  int32_t bound_first;                      /* 1: residual loop starts from bound(project_in(x)) (current library) */
+  /* MelSpectrogram(n_fft 1024, hop 256, n_mels 100, center, power 1) buffers */
+  const float* mel_window;                  /* [1024] */
+  const float* mel_fb;                      /* [100][516]: fb^T, K padded 513 -> 516 with zeros */
+  const float* twiddle;                     /* [512][2] cos/sin(2 pi k / 1024) */
+} ctts_dvae_weights;
+
+int ctts_dvae_create(ctts_dvae** out, const ctts_dvae_weights* w);
+void ctts_dvae_destroy(ctts_dvae* c);
+int32_t ctts_dvae_code_frames(int32_t n_samples);            /* T for a clip: F = 1 + n/256 mel frames, T = (F-2)/2 + 1 */
+size_t ctts_dvae_encode_workspace_bytes(int32_t n_samples);
+size_t ctts_dvae_decode_workspace_bytes(int32_t B, int32_t T);
+/* wav [n_samples] f32 (24 kHz) -> codes [T][4] int32 (row t = the 4 code slots of frame t; DVAE.sample_audio
+ * returns the transpose [4][T]) */
+int ctts_dvae_encode(ctts_dvae* c, const float* wav, int32_t n_samples, int32_t* codes, void* workspace, size_t ws_bytes, void* stream);
+/* codes [B][T][4] int64 (zero padded rows, core.py:525-533) -> mel [B][2T][100] */
+int ctts_dvae_decode_codes(ctts_dvae* c, const int64_t* codes, float* mel, int32_t B, int32_t T, void* workspace, size_t ws_bytes,
+                           void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Single-kernel entry points (unit parity tests call the kernels through these).
  * ---------------------------------------------------------------------------------------------- */
 int ctts_k_gemm(int32_t tiled /* 0 skinny, 1 f32 tiles, 2 split-bf16 tiles */, const float* A, const void* W, float* C, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldc,

@@ -1,0 +1,123 @@
+"""Full DVAE on the GPU: audio -> codes and codes -> mel through `ctts_dvae_*`, against
+tests/golden/dvae.npz (conv trunks evaluated by the reference's own `DVAEDecoder` class; mel framing by torch.stft; the
+GFSQ quantiser by the restated algorithm -- parity unpinned for that piece, see oracle/dvae_np.py) and the numpy oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from chattts_amd import weights as W  # noqa: E402
+from chattts_amd.dvae import DvaeEngine  # noqa: E402
+from oracle import codec_np, dvae_np  # noqa: E402
+
+DEV = torch.device("cuda:0")
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = ["half_second", "odd_frames", "short"]
+
+
+@pytest.fixture(scope="module")
+def dvae_sd():
+    sd = W.synthetic_dvae()
+    with open(os.path.join(GOLD, "weights_fingerprint.txt")) as f:
+        want = dict(line.split() for line in f if line.strip())
+    assert W.fingerprint(sd) == want["dvae"]
+    return sd
+
+
+@pytest.fixture(scope="module")
+def eng(dvae_sd):
+    return DvaeEngine(dvae_sd, DEV)
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(os.path.join(GOLD, "dvae.npz"))
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_encode_codes_match_golden(eng, gold, dvae_sd, name):
+    wav, want = gold[name + ".wav"], gold[name + ".codes"]          # want [T, 4]
+    codes = eng.sample_audio(wav)
+    assert codes.dtype == torch.int32 and tuple(codes.shape) == (4, want.shape[0])
+    got = codes.numpy().T
+    assert got.min() >= 0 and got.max() < 625
+    same = (got == want)
+    # a code flips only where a pre-rounding FSQ coordinate sits within float noise of a .5 boundary; on these clips none does
+    if not same.all():
+        nsd = {k: v.numpy() for k, v in dvae_sd.items()}
+        near = np.abs(dvae_np.gfsq_embed(nsd, got) - dvae_np.gfsq_embed(nsd, want)).max()
+        print(f"{name}: {int((~same).sum())} of {same.size} codes differ (max feature distance {near:.3f})")
+    assert same.mean() >= 0.98
+    assert same.all() or name != "short"
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_decode_codes_match_golden(eng, gold, name):
+    codes, want = gold[name + ".codes"], gold[name + ".mel_out"]    # [T,4], [2T,100]
+    mel = eng.decode_codes(torch.from_numpy(codes.astype(np.int64))[None]).cpu().numpy()[0]
+    assert mel.shape == want.shape
+    err = np.abs(mel - want).max()
+    print(f"dvae decode {name}: max err {err:.2e} (|mel| max {np.abs(want).max():.2f})")
+    assert err < 1e-4 * max(1.0, np.abs(want).max())
+
+
+def test_decode_ragged_batch_and_round_trip(eng, dvae_sd):
+    """rows of different length are zero padded with code 0 (core.py:525-533); batch vs oracle; and encode(decode) runs"""
+    rs = np.random.RandomState(1)
+    rows = [rs.randint(0, 625, size=(n, 4)).astype(np.int64) for n in (30, 7, 19)]
+    mel = eng.decode_codes([torch.from_numpy(r) for r in rows]).cpu().numpy()
+    nsd = {k: v.numpy() for k, v in dvae_sd.items()}
+    pad = np.zeros((3, 30, 4), np.int64)
+    for i, r in enumerate(rows):
+        pad[i, : len(r)] = r
+    ref = dvae_np.dvae_decode_codes(nsd, pad)
+    assert mel.shape == ref.shape == (3, 60, 100)
+    assert np.abs(mel - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
+
+
+def test_encode_rejects_short_clip(eng):
+    from chattts_amd import _lib
+    with pytest.raises(_lib.EngineError):
+        eng.sample_audio(np.zeros(400, np.float32))
+
+
+def test_chat_split_text_and_use_decoder_false(weights, dvae_sd):
+    """`Chat.infer` paths that need the full DVAE: (a) split_text with several sentences synthesises the first one,
+    encodes its audio into the `spk_smp` prompt of the rest (core.py:435-453); (b) use_decoder=False decodes token ids
+    through the GFSQ codebook (core.py:518,535) -- waveform vs the numpy oracle on the same ids."""
+    from chattts_amd import frontend as F
+    from chattts_amd.core import Chat
+    chat = Chat()
+    assert chat.load(state_dicts={**weights, "dvae": dvae_sd}, device=DEV, dtype="f32", tokenizer=os.path.join(GOLD, "tokenizer"))
+    assert chat.has_loaded(use_decoder=False)
+    p = Chat.InferCodeParams(max_new_token=24, manual_seed=3, show_tqdm=False)
+    # (b)
+    texts = ["hello world", "the time of day"]
+    out = next(chat._infer_code(list(texts), False, DEV, False, p))
+    lens = [int(t.shape[0]) for t in out.ids]     # random weights may sample EOS before max_new_token: rows are ragged
+    assert out.hiddens == [] and max(lens) <= 24 and all(t.shape[1] == 4 for t in out.ids)
+    wavs = chat.infer(list(texts), skip_refine_text=True, split_text=False, use_decoder=False, params_infer_code=p)
+    nsd = {k: v.numpy() for k, v in dvae_sd.items()}
+    vsd = {k: v.numpy() for k, v in weights["vocos"].items()}
+    ids = np.zeros((2, max(lens), 4), np.int64)      # zero padding with code 0 (core.py:525-533)
+    for i, t in enumerate(out.ids):
+        ids[i, : lens[i]] = t.cpu().numpy()
+    ref = codec_np.vocos_decode(vsd, dvae_np.dvae_decode_codes(nsd, ids))
+    for w, r in zip(wavs, ref):
+        r = r[np.abs(r) > 1e-5]
+        assert w.shape == r.shape and float(np.sqrt(np.mean((w - r) ** 2))) < 1e-4
+    # (a)
+    p2 = Chat.InferCodeParams(max_new_token=24, manual_seed=3, show_tqdm=False)
+    one = chat.infer("hello world. the time of day. chat tts test string", skip_refine_text=True, split_text=True, max_split_batch=2,
+                     params_infer_code=p2)
+    assert len(one) == 1 and one[0].ndim == 1 and one[0].size > 256 * 40 and np.isfinite(one[0]).all()
+    assert p2.txt_smp in ("hello world. ", "hello world.")                      # the reference mutates the params object too
+    prompt = F.Speaker.decode_prompt(p2.spk_smp)                                # [4, T] codes of the first sentence's audio
+    first = next(chat._infer_code(p2.txt_smp, False, DEV, True, Chat.InferCodeParams(max_new_token=24, manual_seed=3, show_tqdm=False)))
+    n_tok = int(first.ids[0].shape[0])
+    assert prompt.shape[0] == 4 and prompt.shape[1] == ((2 * n_tok - 1) + 1 - 2) // 2 + 1     # F = 2 n_tok mel frames
+    assert torch.equal(prompt, chat.dvae.sample_audio(chat.decode_to_wavs(first.hiddens)[0]))
+    assert int(prompt.min()) >= 0 and int(prompt.max()) < 625

@@ -353,14 +353,14 @@ def test_chat_infer_text_level_matches_oracle(weights):
     spk = chat.sample_random_speaker()
     texts = ["What is [uv_break]your favorite english food?[laugh][lbreak]", "hello world"]
     p = Chat.InferCodeParams(spk_emb=spk, max_new_token=20, manual_seed=7, show_tqdm=False)
-    out = next(chat._infer_code(list(texts), False, DEV, True, p))
+    normed = [chat.normalizer(t, True, True, None) for t in texts]
+    assert normed[0] == "What is [uv_break]your favorite english food[laugh][lbreak]"   # '?' is outside the model's alphabet
+    out = next(chat._infer_code(list(normed), False, DEV, True, p))
     wavs = chat.infer(list(texts), skip_refine_text=True, split_text=False, params_infer_code=p)
     full = chat.decode_to_wavs(out.hiddens)
     assert len(wavs) == 2 and all(np.array_equal(w, r[np.abs(r) > 1e-5]) for w, r in zip(wavs, full))
 
     # oracle leg: same normaliser + decoration + tokenizer, numpy embedding with the unit speaker vector substituted
-    normed = [chat.normalizer(t, True, True, None) for t in texts]
-    assert normed[0] == "What is [uv_break]your favorite english food[laugh][lbreak]"   # '?' is outside the model's alphabet
     ids, mask, tmask = tok.encode(F.Speaker.decorate_code_prompts(normed, p.prompt, None, spk), 4)
     ids, mask, tmask = ids.numpy(), mask.numpy(), tmask.numpy()
     assert (ids[..., 0] == tok.spk_emb_ids).sum() == 2
@@ -389,7 +389,7 @@ def test_chat_infer_text_level_matches_oracle(weights):
     assert isinstance(refined, list) and refined == want
     joined = chat.infer("hello world\nthe time of day", refine_text_only=True, split_text=True, params_refine_text=rp)
     assert isinstance(joined, str) and joined.count("\n") == 1
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError):      # several sentences need the full DVAE for the speaker prompt (tests/test_gpu_dvae.py)
         chat.infer(list(texts), skip_refine_text=True, split_text=True, params_infer_code=Chat.InferCodeParams(max_new_token=4, manual_seed=1))
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(AssertionError):    # has_loaded(use_decoder=False) is False without it (core.py:404)
         chat.infer(texts[0], skip_refine_text=True, split_text=False, use_decoder=False)
