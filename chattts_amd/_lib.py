@@ -9,7 +9,7 @@ import torch  # noqa: F401  -- MUST precede the dlopen below: torch bundles its 
 #                  would bind libchattts_amd.so to a second HIP runtime that cannot see torch's device context
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "libchattts_amd.so")
+LIB_PATH = os.environ.get("CTTS_LIB") or os.path.join(HERE, "csrc", "libchattts_amd.so")   # CTTS_LIB: A/B builds of the same ABI
 
 F32, BF16 = 0, 1
 P = C.c_void_p
