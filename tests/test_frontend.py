@@ -142,3 +142,20 @@ def test_chat_text_level_needs_tokenizer():
         c.sample_random_speaker()
     assert Chat.InferCodeParams().prompt == "[speed_5]" and Chat.RefineTextParams().temperature == 0.7
     assert c.infer([], split_text=False) == []
+
+
+def test_audio_back_end():
+    """float_to_int16 / WAV container (tools/audio/np.py:7-12, pcm.py:8-33): values restated here as literals computed
+    by the reference's formula: am = 32767*32768 // (ceil(max|x|)*32768), int16(x*am) truncating toward zero"""
+    import io
+    import wave
+    from chattts_amd import audio as A
+    x = np.array([0.0, 0.5, -0.5, 0.999, -1.0, 0.25001], np.float32)
+    assert A.float_to_int16(x).tolist() == [0, 16383, -16383, 32734, -32767, 8192]
+    y = np.array([1.5, -0.75], np.float32)              # peak above 1 -> ceil = 2 -> scale 16383
+    assert A.float_to_int16(y).tolist() == [24574, -12287]
+    assert A.float_to_int16(np.zeros(4, np.float32)).tolist() == [0, 0, 0, 0]
+    b = A.pcm_to_wav_bytes(x)
+    with wave.open(io.BytesIO(b), "rb") as wf:
+        assert (wf.getnchannels(), wf.getsampwidth(), wf.getframerate(), wf.getnframes()) == (1, 2, 24000, 6)
+        assert np.frombuffer(wf.readframes(6), dtype="<i2").tolist() == A.float_to_int16(x).tolist()

@@ -393,3 +393,25 @@ def test_chat_infer_text_level_matches_oracle(weights):
         chat.infer(list(texts), skip_refine_text=True, split_text=True, params_infer_code=Chat.InferCodeParams(max_new_token=4, manual_seed=1))
     with pytest.raises(AssertionError):    # has_loaded(use_decoder=False) is False without it (core.py:404)
         chat.infer(texts[0], skip_refine_text=True, split_text=False, use_decoder=False)
+
+
+def test_chat_infer_stream_text_level_equals_token_level(weights):
+    """`Chat.infer(..., stream=True)` (core.py:455-503 through the text front end) yields exactly the chunks of the
+    token-level `infer_ids_stream` for the same prompts, and the non-stream result is their source waveform."""
+    import os
+    from chattts_amd import frontend as F
+    from chattts_amd.core import Chat
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    chat = Chat()
+    chat.load(state_dicts=weights, device=DEV, dtype="bf16", tokenizer=os.path.join(gold, "tokenizer"))
+    texts = ["hello world the time of day", "chat tts test string"]
+    mk = lambda: Chat.InferCodeParams(max_new_token=100, manual_seed=9, show_tqdm=False, stream_speed=6000)
+    chunks = list(chat.infer(list(texts), stream=True, skip_refine_text=True, split_text=False, params_infer_code=mk()))
+    ids, mask, tmask = chat.tokenizer.encode(F.Speaker.decorate_code_prompts(list(texts), "[speed_5]", None, None), 4)
+    want = list(chat.infer_ids_stream(ids, mask, tmask, mk()))
+    assert len(chunks) == len(want) >= 2
+    assert all(a.shape == b.shape and np.array_equal(a, b) for a, b in zip(chunks, want))
+    assert all(c.shape[1] == 6000 for c in chunks[:-1])
+    whole = chat.infer(list(texts), skip_refine_text=True, split_text=False, params_infer_code=mk())
+    full = chat.infer_ids(ids, mask, tmask, mk())
+    assert all(np.array_equal(w, r[np.abs(r) > 1e-5]) for w, r in zip(whole, full))
