@@ -92,12 +92,12 @@ class Chat:
         `state_dicts` short-circuits disk I/O (synthetic weights); `tokenizer` is a directory or a `Tokenizer`;
         `spk_stat` is the reference's `Config.spk_stat` string (needed by `sample_random_speaker` only).
         `compile`, `use_flash_attn`, `use_vllm`, `experimental` select between the reference's torch back ends and
-        have no meaning for this engine (accepted, ignored); `coef` is not supported (the file's `coef` tensor is used)."""
+        have no meaning for this engine (accepted, ignored).  `coef` is accepted and has no effect, as in the reference:
+        `DVAE.__init__` installs it (dvae.py:219-226) and `load_pretrained` then overwrites the buffer with the
+        checkpoint's `coef` tensor (dvae.py:254-259)."""
         if source not in ("custom", "local"):
             self.logger.error("chattts_amd loads local assets only (source=%s)", source)
             return False
-        if coef is not None:
-            raise NotImplementedError("coef override: the Decoder.safetensors `coef` tensor is used")
         device = device or torch.device("cuda:0")
         root = custom_path if custom_path is not None else os.getcwd()
         sds = state_dicts if state_dicts is not None else W.load_assets(root)
