@@ -354,7 +354,7 @@ static GemmArgs lin(const float* A, int lda, const float* W, float* C, int ldc, 
   a.A = A; a.lda = lda; a.W = W; a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.wt = WT_F32; a.epi = epi; a.taps = 1;
   return a;
 }
-// dense layer of the decoder: f32 MFMA tiles, or split-bf16 tiles when the weights were packed [2][N][Kp] bf16
+// dense layer of the decoder: f32 MFMA tiles, or split-bf16 tiles when the weights were packed [N][Kp/32][2][32] bf16
 static hipError_t dense(const ctts_codec* c, const GemmArgs& a, hipStream_t st);
 static GemmArgs conv(const float* X, int cin, const float* W, float* C, int cout, int B, int F, int taps, int pad, int epi) {
   GemmArgs a = lin(X, cin, W, C, cout, B * F, cout, taps * cin, epi);
@@ -433,6 +433,7 @@ extern "C" int ctts_k_gemm(int32_t tiled, const float* A, const void* W, float* 
   a.A = A; a.W = W; a.C = C; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldc = ldc; a.wt = wt; a.epi = epi; a.norm_w = norm_w; a.eps = eps;
   a.res = res; a.ldr = ldr; a.bias = bias; a.gamma = gamma; a.taps = taps > 0 ? taps : 1; a.cin = cin; a.frames = frames; a.pad = pad;
   a.dil = dil;
+  { const char* e = getenv("CTTS_X3_DBG_PTR"); if (e) a.dbg = (long long*)strtoull(e, nullptr, 0); }   // probe builds only
   CK(tiled == 2 ? launch_gemm_tiled_bf16x3(a, (hipStream_t)stream) : tiled ? launch_gemm_tiled(a, (hipStream_t)stream) : launch_gemm_skinny(a, (hipStream_t)stream));
   return 0;
 }

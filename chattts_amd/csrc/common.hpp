@@ -21,6 +21,14 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
   return (bf16_t)(u >> 16);
 }
 
+// two floats -> packed bf16 pair (first value in the low half) with gfx950's v_cvt_pk_bf16_f32 (round-to-nearest-even)
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
+  const bf16x2_t r = __builtin_convertvector((f32x2_t){a, b}, bf16x2_t);
+  return __builtin_bit_cast(uint32_t, r);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

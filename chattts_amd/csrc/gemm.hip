@@ -568,7 +568,8 @@ hipError_t launch_gemm_fast(const FastGemmArgs& a_in, hipStream_t st) {
 // dense layers.  Every f32 operand x is written as x = hi + lo with hi = bf16(x), lo = bf16(x - hi)
 // (residual <= 2^-17 |x|), and a.w ~= a_hi w_hi + a_hi w_lo + a_lo w_hi (the dropped lo.lo term is
 // <= 2^-16 relative), three v_mfma_f32_32x32x16_bf16 per product, f32 accumulation.  Weights are split
-// once at load ([2][N][Kp] bf16: hi plane then lo plane, K zero-padded to a multiple of 32), activations
+// once at load ([N][Kp/32][2][32] bf16: per row and 32-wide k block the hi values then the lo values -- one k-step of
+// a row is one 128-byte line --, K zero-padded to a multiple of 32), activations
 // are split while they are staged into LDS.  128x128x32 tile, 4 waves as 2x2, each wave 2x2 MFMA blocks.
 // f32-input MFMA peaks at 157 TF on gfx950 and the f32 tiled kernel above already runs at ~115 TF, so
 // this is the only way to make the 157 MFLOP/token decoder cheaper without giving up the 1e-4 RMS bar.
@@ -576,13 +577,16 @@ hipError_t launch_gemm_fast(const FastGemmArgs& a_in, hipStream_t st) {
 // WM x WN waves, each wave MBLK x NBLK MFMA blocks of 32x32: tile = (WM*MBLK*32) x (WN*NBLK*32).
 //   <2,2,2,2>: 128x128, 256 threads (narrow layers);  <4,2,2,4>: 256x256, 512 threads, one workgroup per CU --
 //   the kernel is bound by each CU's L1 fill, and a 256x256x32 step moves 64 KB for 4x the flops of a 128x128 one.
-template <int EPI, int WM, int WN, int MBLK, int NBLK>
+// NBUF = 2 (256x256 tile only: 2 x 80 KB = the CU's whole 160 KB LDS): the staged tile k+1 goes to the other LDS buffer
+// while tile k is multiplied, so a k-step has ONE barrier and the waves drift apart -- one wave of a SIMD converts /
+// writes LDS / sits blocked on its load issue while the other one feeds the MFMA pipe.
+template <int EPI, int WM, int WN, int MBLK, int NBLK, int NBUF = 1>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) void gemm_tiled_bf16x3_k(GemmArgs a) {
   constexpr int NT = 64 * WM * WN;
   constexpr int BM = WM * MBLK * 32, BN = WN * NBLK * 32, BK = 32, LD = 40;  // LD: 80-byte rows -> conflict-free ds_read_b128
   constexpr int PA = BM / (NT / 8);   // A loader passes: NT/8 rows per pass (8 lanes = one 128-byte row segment)
-  constexpr int PW = BN / (NT / 4);   // W loader passes: NT/4 rows per pass (4 lanes = one 64-byte row segment)
-  __shared__ __attribute__((aligned(16))) uint16_t Ah[BM][LD], Al[BM][LD], Wh[BN][LD], Wl[BN][LD];
+  constexpr int PW = BN / (NT / 8);   // W loader passes: NT/8 rows per pass (8 lanes = one 128-byte line: hi 64 B | lo 64 B)
+  __shared__ __attribute__((aligned(16))) uint16_t Ah[NBUF][BM][LD], Al[NBUF][BM][LD], Wh[NBUF][BN][LD], Wl[NBUF][BN][LD];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int wm = wave % WM, wn = wave / WM;
   const int M = a.M, N = a.N, K = a.K;
@@ -593,8 +597,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) void gemm_til
   if ((int)(blockIdx.x >> 3) >= per || t >= T) return;
   const int m0 = (t / nx) * BM, n0 = (t % nx) * BN;
   const int Kp = (K + 31) & ~31;
-  const uint16_t* Whi = reinterpret_cast<const uint16_t*>(a.W);
-  const uint16_t* Wlo = Whi + (size_t)N * Kp;
+  const uint16_t* Wb = reinterpret_cast<const uint16_t*>(a.W);   // [N][Kp/32][2][32]: per row and k block, hi then lo
 
   const int ar = tid >> 3, ak = (tid & 7) * 4;
   int ab[PA], af[PA];
@@ -605,7 +608,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) void gemm_til
     aval[p] = m < M;
     if (a.taps > 1) { ab[p] = m / a.frames; af[p] = m - ab[p] * a.frames; } else { ab[p] = 0; af[p] = m; }
   }
-  const int wr = tid >> 2, wk = (tid & 3) * 8;
+  const int wr = tid >> 3, wk = (tid & 3) * 8, wlo = (tid >> 2) & 1;   // lanes 0-3 of a row: hi chunks, lanes 4-7: lo chunks
 
   f32x16 acc[MBLK][NBLK];
 #pragma unroll
@@ -617,85 +620,116 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) void gemm_til
 
   // register staging (one tile ahead): the global loads of tile k+1 are in flight while tile k is multiplied
   float4 ra[PA];
-  u128 rh[PW], rl[PW];
+  u128 rw[PW];
+#define X3_FETCH_A(P, K0)                                                                                   \
+  do {                                                                                                      \
+    const int p_ = (P), k = (K0) + ak;                                                                      \
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                                                             \
+    if (aval[p_] && k < K) {                                                                                \
+      if (a.taps > 1) {                                                                                     \
+        const int tap = k / a.cin, c = k - tap * a.cin;                                                     \
+        const int fs = af[p_] + (tap - a.pad) * a.dil;                                                      \
+        if (fs >= 0 && fs < a.frames)                                                                       \
+          v = *reinterpret_cast<const float4*>(a.A + ((size_t)ab[p_] * a.frames + fs) * a.lda + c);         \
+      } else {                                                                                              \
+        v = *reinterpret_cast<const float4*>(a.A + (size_t)af[p_] * a.lda + k);                             \
+      }                                                                                                     \
+    }                                                                                                       \
+    ra[p_] = v;                                                                                             \
+  } while (0)
+#define X3_FETCH_W(P, K0)                                                                                   \
+  do {                                                                                                      \
+    const int p_ = (P);                                                                                     \
+    const int nn = min(n0 + wr + (NT / 8) * p_, N - 1); /* clamped: rows >= N are never stored */           \
+    rw[p_] = *reinterpret_cast<const u128*>(Wb + ((size_t)nn * Kp + (K0)) * 2 + wlo * 32 + wk);             \
+  } while (0)
 #define X3_FETCH(K0)                                                                                        \
   do {                                                                                                      \
-    const int k0_ = (K0);                                                                                   \
-    const int k = k0_ + ak;                                                                                 \
-    _Pragma("unroll") for (int p = 0; p < PA; ++p) {                                                        \
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                                                           \
-      if (aval[p] && k < K) {                                                                               \
-        if (a.taps > 1) {                                                                                   \
-          const int tap = k / a.cin, c = k - tap * a.cin;                                                   \
-          const int fs = af[p] + (tap - a.pad) * a.dil;                                                     \
-          if (fs >= 0 && fs < a.frames)                                                                     \
-            v = *reinterpret_cast<const float4*>(a.A + ((size_t)ab[p] * a.frames + fs) * a.lda + c);        \
-        } else {                                                                                            \
-          v = *reinterpret_cast<const float4*>(a.A + (size_t)af[p] * a.lda + k);                            \
-        }                                                                                                   \
-      }                                                                                                     \
-      ra[p] = v;                                                                                            \
-    }                                                                                                       \
-    _Pragma("unroll") for (int p = 0; p < PW; ++p) {                                                        \
-      const int nn = min(n0 + wr + (NT / 4) * p, N - 1); /* clamped: rows >= N are never stored */          \
-      rh[p] = *reinterpret_cast<const u128*>(Whi + (size_t)nn * Kp + k0_ + wk);                             \
-      rl[p] = *reinterpret_cast<const u128*>(Wlo + (size_t)nn * Kp + k0_ + wk);                             \
-    }                                                                                                       \
+    _Pragma("unroll") for (int p = 0; p < PA; ++p) X3_FETCH_A(p, (K0));                                     \
+    _Pragma("unroll") for (int p = 0; p < PW; ++p) X3_FETCH_W(p, (K0));                                     \
   } while (0)
 
-#define X3_STAGE()                                                                                          \
+#define X3_STAGE(SB)                                                                                        \
   do {                                                                                                      \
+    const int sb_ = (SB);                                                                                   \
     _Pragma("unroll") for (int p = 0; p < PA; ++p) {                                                        \
       const float4 v = ra[p];                                                                               \
-      ushort4 h, l;                                                                                         \
-      h.x = f32_to_bf16(v.x); l.x = f32_to_bf16(v.x - bf16_to_f32(h.x));                                    \
-      h.y = f32_to_bf16(v.y); l.y = f32_to_bf16(v.y - bf16_to_f32(h.y));                                    \
-      h.z = f32_to_bf16(v.z); l.z = f32_to_bf16(v.z - bf16_to_f32(h.z));                                    \
-      h.w = f32_to_bf16(v.w); l.w = f32_to_bf16(v.w - bf16_to_f32(h.w));                                    \
-      *reinterpret_cast<ushort4*>(&Ah[ar + (NT / 8) * p][ak]) = h;                                          \
-      *reinterpret_cast<ushort4*>(&Al[ar + (NT / 8) * p][ak]) = l;                                          \
+      /* x = hi + lo: hi = bf16(x), lo = bf16(x - hi), two values per v_cvt_pk_bf16_f32 */                  \
+      const uint32_t h01 = pack_bf16x2(v.x, v.y), h23 = pack_bf16x2(v.z, v.w);                              \
+      const uint32_t l01 = pack_bf16x2(v.x - __uint_as_float(h01 << 16), v.y - __uint_as_float(h01 & 0xffff0000u)); \
+      const uint32_t l23 = pack_bf16x2(v.z - __uint_as_float(h23 << 16), v.w - __uint_as_float(h23 & 0xffff0000u)); \
+      *reinterpret_cast<uint2*>(&Ah[sb_][ar + (NT / 8) * p][ak]) = make_uint2(h01, h23);                    \
+      *reinterpret_cast<uint2*>(&Al[sb_][ar + (NT / 8) * p][ak]) = make_uint2(l01, l23);                    \
     }                                                                                                       \
     _Pragma("unroll") for (int p = 0; p < PW; ++p) {                                                        \
-      *reinterpret_cast<u128*>(&Wh[wr + (NT / 4) * p][wk]) = rh[p];                                         \
-      *reinterpret_cast<u128*>(&Wl[wr + (NT / 4) * p][wk]) = rl[p];                                         \
+      *reinterpret_cast<u128*>(wlo ? &Wl[sb_][wr + (NT / 8) * p][wk] : &Wh[sb_][wr + (NT / 8) * p][wk]) = rw[p]; \
     }                                                                                                       \
   } while (0)
 
+#ifdef CTTS_X3_PROBE
+  // phase probe (tools/x3_phase_probe.py): wave 0 accumulates s_memrealtime deltas: fetch issue, MFMA, barrier, stage, barrier
+  long long tacc[5] = {0, 0, 0, 0, 0}, tprev = wall_clock64();
+#define X3_MARK(i) do { if (a.dbg && wave == 0) { const long long tn = wall_clock64(); tacc[i] += tn - tprev; tprev = tn; } } while (0)
+#else
+#define X3_MARK(i) do { } while (0)
+#endif
   X3_FETCH(0);
-  X3_STAGE();
+  X3_STAGE(0);
+  if (NBUF == 2 && BK < Kp) X3_FETCH(BK);
   __syncthreads();
+  X3_MARK(3);
   const int ri = lane & 31, kg = (lane >> 5) * 8;
+  int sb = 0;
   for (int k0 = 0; k0 < Kp; k0 += BK) {
     const bool more = k0 + BK < Kp;
-    if (more) X3_FETCH(k0 + BK);
+    const bool more2 = k0 + 2 * BK < Kp;
+    if (NBUF == 2) {
+      // registers hold tile k+1 (requested one whole step ago): park it in the other buffer, then request tile k+2
+      if (more) X3_STAGE(sb ^ 1);
+      X3_MARK(3);
+      if (more2) X3_FETCH(k0 + 2 * BK);   // in bulk: spreading these loads over the MFMA phase measured 12 % slower
+    } else {
+      if (more) X3_FETCH(k0 + BK);
+    }
+    X3_MARK(0);
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 16) {
-      bf16x8 fah[MBLK], fal[MBLK], fwh[NBLK], fwl[NBLK];
-#pragma unroll
-      for (int i = 0; i < MBLK; ++i) {
-        fah[i] = *reinterpret_cast<const bf16x8*>(&Ah[(wm * MBLK + i) * 32 + ri][kk + kg]);
-        fal[i] = *reinterpret_cast<const bf16x8*>(&Al[(wm * MBLK + i) * 32 + ri][kk + kg]);
-      }
+      bf16x8 fwh[NBLK], fwl[NBLK];
 #pragma unroll
       for (int j = 0; j < NBLK; ++j) {
-        fwh[j] = *reinterpret_cast<const bf16x8*>(&Wh[(wn * NBLK + j) * 32 + ri][kk + kg]);
-        fwl[j] = *reinterpret_cast<const bf16x8*>(&Wl[(wn * NBLK + j) * 32 + ri][kk + kg]);
+        fwh[j] = *reinterpret_cast<const bf16x8*>(&Wh[sb][(wn * NBLK + j) * 32 + ri][kk + kg]);
+        fwl[j] = *reinterpret_cast<const bf16x8*>(&Wl[sb][(wn * NBLK + j) * 32 + ri][kk + kg]);
       }
 #pragma unroll
-      for (int i = 0; i < MBLK; ++i)
+      for (int i = 0; i < MBLK; ++i) {
+        const bf16x8 fah = *reinterpret_cast<const bf16x8*>(&Ah[sb][(wm * MBLK + i) * 32 + ri][kk + kg]);
+        const bf16x8 fal = *reinterpret_cast<const bf16x8*>(&Al[sb][(wm * MBLK + i) * 32 + ri][kk + kg]);
 #pragma unroll
         for (int j = 0; j < NBLK; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[i], fwh[j], acc[i][j], 0, 0, 0);  // small terms first
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fwl[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fwh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal, fwh[j], acc[i][j], 0, 0, 0);  // small terms first
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah, fwl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah, fwh[j], acc[i][j], 0, 0, 0);
         }
+      }
     }
+    X3_MARK(1);
     __syncthreads();
-    if (more) {
-      X3_STAGE();
+    X3_MARK(2);
+    if (NBUF == 2) {
+      sb ^= 1;
+    } else if (more) {
+      X3_STAGE(0);
+      X3_MARK(3);
       __syncthreads();
+      X3_MARK(4);
     }
   }
+#ifdef CTTS_X3_PROBE
+  if (a.dbg && tid == 0) {
+    long long* d = a.dbg + (size_t)blockIdx.x * 8;
+    for (int i = 0; i < 5; ++i) d[i] = tacc[i];
+  }
+#endif
 
 #pragma unroll
   for (int j = 0; j < NBLK; ++j) {
@@ -724,20 +758,23 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) void gemm_til
 }
 
 #undef X3_FETCH
+#undef X3_FETCH_A
+#undef X3_FETCH_W
 #undef X3_STAGE
+#undef X3_MARK
 
-template <int WM, int WN, int MBLK, int NBLK>
+template <int WM, int WN, int MBLK, int NBLK, int NBUF = 1>
 static hipError_t x3_dispatch(const GemmArgs& a, hipStream_t st) {
   constexpr int BM = WM * MBLK * 32, BN = WN * NBLK * 32;
   const int tiles = ((a.N + BN - 1) / BN) * ((a.M + BM - 1) / BM);
   dim3 grid(((tiles + 7) / 8) * 8), block(64 * WM * WN);  // 1-D grid, remapped XCD-aware inside the kernel
   switch (a.epi) {
-    case EPI_STORE: CTTS_LAUNCH((gemm_tiled_bf16x3_k<EPI_STORE, WM, WN, MBLK, NBLK>), grid, block, st, a); break;
-    case EPI_RES: CTTS_LAUNCH((gemm_tiled_bf16x3_k<EPI_RES, WM, WN, MBLK, NBLK>), grid, block, st, a); break;
-    case EPI_BIAS: CTTS_LAUNCH((gemm_tiled_bf16x3_k<EPI_BIAS, WM, WN, MBLK, NBLK>), grid, block, st, a); break;
-    case EPI_BIAS_GELU: CTTS_LAUNCH((gemm_tiled_bf16x3_k<EPI_BIAS_GELU, WM, WN, MBLK, NBLK>), grid, block, st, a); break;
-    case EPI_BIAS_SCALE_RES: CTTS_LAUNCH((gemm_tiled_bf16x3_k<EPI_BIAS_SCALE_RES, WM, WN, MBLK, NBLK>), grid, block, st, a); break;
-    case EPI_SCALE: CTTS_LAUNCH((gemm_tiled_bf16x3_k<EPI_SCALE, WM, WN, MBLK, NBLK>), grid, block, st, a); break;
+    case EPI_STORE: CTTS_LAUNCH((gemm_tiled_bf16x3_k<EPI_STORE, WM, WN, MBLK, NBLK, NBUF>), grid, block, st, a); break;
+    case EPI_RES: CTTS_LAUNCH((gemm_tiled_bf16x3_k<EPI_RES, WM, WN, MBLK, NBLK, NBUF>), grid, block, st, a); break;
+    case EPI_BIAS: CTTS_LAUNCH((gemm_tiled_bf16x3_k<EPI_BIAS, WM, WN, MBLK, NBLK, NBUF>), grid, block, st, a); break;
+    case EPI_BIAS_GELU: CTTS_LAUNCH((gemm_tiled_bf16x3_k<EPI_BIAS_GELU, WM, WN, MBLK, NBLK, NBUF>), grid, block, st, a); break;
+    case EPI_BIAS_SCALE_RES: CTTS_LAUNCH((gemm_tiled_bf16x3_k<EPI_BIAS_SCALE_RES, WM, WN, MBLK, NBLK, NBUF>), grid, block, st, a); break;
+    case EPI_SCALE: CTTS_LAUNCH((gemm_tiled_bf16x3_k<EPI_SCALE, WM, WN, MBLK, NBLK, NBUF>), grid, block, st, a); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -749,6 +786,7 @@ hipError_t launch_gemm_tiled_bf16x3(const GemmArgs& a, hipStream_t st) {
   static int big = -1;  // CTTS_X3_TILE=128 forces the small tile, =2 the 256x128 tile (A/B experiments)
   if (big < 0) { const char* e = getenv("CTTS_X3_TILE"); big = e ? (atoi(e) == 128 ? 0 : atoi(e)) : 1; }
   if (big == 2 && a.N >= 512 && a.M >= 2048) return x3_dispatch<2, 2, 4, 2>(a, st);  // 256x128 tile, 256 threads, 2 per CU
-  if (big && a.N >= 512 && a.M >= 2048) return x3_dispatch<4, 2, 2, 4>(a, st);   // 256x256 tile, 512 threads
+  if (big == 1 && a.N >= 512 && a.M >= 2048) return x3_dispatch<4, 2, 2, 4, 2>(a, st);   // 256x256 tile, 512 threads, 2 LDS buffers
+  if (big && a.N >= 512 && a.M >= 2048) return x3_dispatch<4, 2, 2, 4>(a, st);   // CTTS_X3_TILE=256: single LDS buffer (A/B)
   return x3_dispatch<2, 2, 2, 2>(a, st);                                          // 128x128 tile, 256 threads
 }

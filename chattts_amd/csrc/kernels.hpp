@@ -53,6 +53,7 @@ struct GemmArgs {
   // conv-as-GEMM gather (tiled kernel only): logical row m = b*F + f, k = tap*Cin + c reads
   // X[b, f + (tap - pad)*dil, c] (zero outside [0,F)); taps == 1 -> plain GEMM.
   int taps, cin, frames, pad, dil;
+  long long* dbg;      // -DCTTS_X3_PROBE builds only: [n_workgroups][8] accumulated phase times of the split-bf16 tiles, or null
 };
 
 hipError_t launch_gemm_skinny(const GemmArgs& a, hipStream_t st);  // weight-streaming, M-tiles of <=64 rows
@@ -88,7 +89,7 @@ hipError_t launch_gemm_fast(const FastGemmArgs& a, hipStream_t st);
 // x32 row -> bf16 copy + partial sums of squares (prefill entry); optional code-embedding gather
 hipError_t launch_rows_prep(const float* x32, uint16_t* xb, float* ssq, int M, hipStream_t st);
 hipError_t launch_gemm_tiled(const GemmArgs& a, hipStream_t st);   // 64x64 LDS-tiled f32 MFMA, large M
-hipError_t launch_gemm_tiled_bf16x3(const GemmArgs& a, hipStream_t st);  // 128x128 split-bf16 (3 MFMA / product), W = [2][N][Kp] bf16
+hipError_t launch_gemm_tiled_bf16x3(const GemmArgs& a, hipStream_t st);  // 128x128 split-bf16 (3 MFMA / product), W = [N][Kp/32][2][32] bf16
 
 // ---- GPT step kernels -------------------------------------------------------------------------
 struct GptRowMap {

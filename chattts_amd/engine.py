@@ -567,15 +567,17 @@ class GptEngine:
 
 
 def split_bf16(w: torch.Tensor) -> torch.Tensor:
-    """[N, K] float32 -> [2, N, Kp] bfloat16 (hi plane, lo plane), Kp = K rounded up to 32 and zero padded:
-    w = hi + lo up to 2^-17 |w|  (the weight operand of the bf16x3 GEMM tiles)."""
+    """[N, K] float32 -> [N, Kp/32, 2, 32] bfloat16, Kp = K rounded up to 32 and zero padded: for every row and every
+    32-wide k block the hi values then the lo values, w = hi + lo up to 2^-17 |w| (the weight operand of the bf16x3
+    GEMM tiles).  One k-step of one row is ONE 128-byte line (hi 64 B + lo 64 B), so a tile step never fetches a
+    half-used cache line."""
     N, K = w.shape
     Kp = (K + 31) // 32 * 32
-    out = torch.zeros((2, N, Kp), dtype=torch.bfloat16)
-    hi = w.to(torch.bfloat16)
-    out[0, :, :K] = hi
-    out[1, :, :K] = (w - hi.to(torch.float32)).to(torch.bfloat16)
-    return out.contiguous()
+    wp = torch.zeros((N, Kp), dtype=torch.float32)
+    wp[:, :K] = w
+    hi = wp.to(torch.bfloat16)
+    lo = (wp - hi.to(torch.float32)).to(torch.bfloat16)
+    return torch.stack([hi.view(N, Kp // 32, 32), lo.view(N, Kp // 32, 32)], 2).contiguous()
 
 
 # ---------------------------------------------------------------------------------------------

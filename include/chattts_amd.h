@@ -163,7 +163,7 @@ typedef struct {
   const float* twiddle;                                      /* [512][2] cos/sin(2 pi k / 1024) */
   /* 0: every dense weight above is float32 [N][K] (f32-input MFMA tiles);
    * 1: every dense weight (conv_in*, *_pw1, *_pw2, conv_out, out_conv, v_embed, head) is instead a packed
-   *    split-bf16 tensor [2][N][Kp] (hi plane, lo plane; Kp = K rounded up to 32, zero padded), consumed by
+   *    split-bf16 tensor [N][Kp/32][2][32] (per row and 32-wide k block: hi values, lo values; Kp = K rounded up to 32, zero padded), consumed by
    *    the bf16x3 tiles (3 bf16 MFMAs per product, f32-class accuracy).  Biases/LN/depthwise stay float32. */
   int32_t gemm_mode;
 } ctts_codec_weights;

@@ -54,10 +54,10 @@ def test_plan_from_processors_accepts_reference_objects():
 def test_split_bf16_reconstructs_f32():
     w = torch.randn(37, 100) * 3
     p = E.split_bf16(w)
-    assert p.shape == (2, 37, 128) and p.dtype == torch.bfloat16
-    rec = p[0, :, :100].float() + p[1, :, :100].float()
-    assert float((rec - w).abs().max() / w.abs().max()) < 2 ** -15
-    assert float(p[:, :, 100:].abs().max()) == 0.0
+    assert p.shape == (37, 4, 2, 32) and p.dtype == torch.bfloat16 and p.is_contiguous()   # [N][k block][hi|lo][32]
+    rec = (p[:, :, 0].float() + p[:, :, 1].float()).reshape(37, 128)
+    assert float((rec[:, :100] - w).abs().max() / w.abs().max()) < 2 ** -15
+    assert float(rec[:, 100:].abs().max()) == 0.0
 
 
 def test_rope_row_perm_is_a_permutation_pairing_halves():
