@@ -232,6 +232,7 @@ class GptEngine:
         self._lane_res = [(self.handle, self.stream)]
         self.default_lanes = 1
         self.last_stats = {}
+        self._session = None      # buffers + instantiated graph of the last generate() geometry (see generate)
 
     def __del__(self):
         try:
@@ -320,52 +321,92 @@ class GptEngine:
         class Lane:
             pass
 
-        L = []
-        for (lo, hi), (handle, st) in zip(bounds, res):
-            ln = Lane()
-            ln.lo, ln.hi, ln.handle, ln.st, ln.done, ln.end_snap = lo, hi, handle, st, False, None
-            Bl = hi - lo
-            with torch.cuda.stream(st):
-                ln.ids_buf = torch.zeros((Bl, T + max_new, nvq), dtype=torch.int64, device=dev)  # gpt.py:372-379
-                ln.ids_buf[:, :T] = ids_all[lo:hi]
-                ln.len_d = torch.full((Bl,), T, dtype=torch.int32, device=dev)
-                ln.finish = torch.zeros((Bl,), dtype=torch.uint8, device=dev)             # gpt.py:346
-                ln.row_map = torch.arange(Bl, dtype=torch.int32, device=dev)              # compact decode row -> batch slot
-                ln.n_active = torch.full((1,), Bl, dtype=torch.int32, device=dev)
-                ln.n_act_host = Bl
-                ln.end_idx = torch.zeros((Bl,), dtype=torch.int32, device=dev)            # gpt.py:343
-                ln.hiddens = torch.empty((Bl, max_new, GPT.hidden), dtype=torch.float32, device=dev)
-                kv_shape = (self.n_layers, Bl, GPT.n_heads, T + max_new, GPT.head_dim)
-                ln.kcache = torch.empty(kv_shape, dtype=self.wdt, device=dev)
-                ln.vcache = torch.empty(kv_shape, dtype=self.wdt, device=dev)
-                ws_bytes = lib.ctts_gpt_workspace_bytes(Bl, T)
-                ln.workspace = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
-                ln.kv_start = kv_start_all[lo:hi].contiguous().to(dev)
-                ln.stop_d = None if stop_at is None else stop_at[lo:hi].to(torch.int32).contiguous().to(dev)
-                ln.emb = emb_all[lo:hi].contiguous()
-                if draws.constant:
-                    ln.q_d = draws.step(0)[lo * nrow: hi * nrow].to(dev).reshape(1, Bl * nrow, V).contiguous()
-                else:
+        # ---- session reuse: a call with the same geometry and sampling constants as the previous one keeps that call's
+        # device buffers AND its instantiated decode graph (every pointer and by-value field the captured kernels hold is
+        # then unchanged); only buffer contents are re-initialised, stream-ordered on the lane's stream.  The first
+        # replays of a freshly instantiated graph cost ~17 ms at B = 64 (tools/ttfs_probe.py), which a serving loop or a
+        # second batch of the same shape should not pay again.  Results are handed out as copies (see outputs()).
+        top_p_thr = float(np.float32(1.0 - plan.top_p)) if plan.top_p is not None else 0.0
+        key = (tuple(bounds), T, max_new, nrow, V, nq, self.dtype, top_p_thr, plan.top_p is not None, int(plan.top_k or 0),
+               plan.top_k is not None, int(min_new_token), int(eos_token), int(row_offset), bool(infer_text), stop_at is not None,
+               ptab is not None)
+        sess = self._session if (self._session is not None and self._session["key"] == key) else None
+        if sess is None:
+            self._session = None     # drop the previous session's buffers before allocating new ones
+            sess = dict(key=key, lanes=[], graph=False, temp=torch.empty((nrow,), dtype=torch.float32, device=dev),
+                        ptab=None if ptab is None else torch.empty_like(ptab, device=dev), q_sig=None)
+            for (lo, hi), (handle, st) in zip(bounds, res):
+                ln = Lane()
+                ln.lo, ln.hi, ln.handle, ln.st = lo, hi, handle, st
+                Bl = hi - lo
+                with torch.cuda.stream(st):
+                    ln.ids_buf = torch.empty((Bl, T + max_new, nvq), dtype=torch.int64, device=dev)  # gpt.py:372-379
+                    ln.len_d = torch.empty((Bl,), dtype=torch.int32, device=dev)
+                    ln.finish = torch.empty((Bl,), dtype=torch.uint8, device=dev)             # gpt.py:346
+                    ln.row_map = torch.empty((Bl,), dtype=torch.int32, device=dev)            # compact decode row -> batch slot
+                    ln.n_active = torch.empty((1,), dtype=torch.int32, device=dev)
+                    ln.end_idx = torch.empty((Bl,), dtype=torch.int32, device=dev)            # gpt.py:343
+                    ln.hiddens = torch.empty((Bl, max_new, GPT.hidden), dtype=torch.float32, device=dev)
+                    kv_shape = (self.n_layers, Bl, GPT.n_heads, T + max_new, GPT.head_dim)
+                    ln.kcache = torch.empty(kv_shape, dtype=self.wdt, device=dev)
+                    ln.vcache = torch.empty(kv_shape, dtype=self.wdt, device=dev)
+                    ln.ws_bytes = lib.ctts_gpt_workspace_bytes(Bl, T)
+                    ln.workspace = torch.empty((ln.ws_bytes,), dtype=torch.uint8, device=dev)
+                    ln.kv_start = torch.empty((Bl,), dtype=kv_start_all.dtype, device=dev)
+                    ln.stop_d = None if stop_at is None else torch.empty((Bl,), dtype=torch.int32, device=dev)
                     ln.q_d = torch.empty((nq, Bl * nrow, V), dtype=torch.float32, device=dev)
-            s = _lib.GenState()
-            s.B, s.T, s.max_new = Bl, T, max_new
-            s.ids_buf, s.len, s.kv_start = ln.ids_buf.data_ptr(), ln.len_d.data_ptr(), ln.kv_start.data_ptr()
-            s.finish, s.end_idx, s.hiddens = ln.finish.data_ptr(), ln.end_idx.data_ptr(), ln.hiddens.data_ptr()
-            s.kcache, s.vcache, s.q, s.nq = ln.kcache.data_ptr(), ln.vcache.data_ptr(), ln.q_d.data_ptr(), nq
-            s.temperature = temp_d.data_ptr()
-            s.pow_table = _lib.ptr(ptab_d)
-            s.top_p_thr = float(np.float32(1.0 - plan.top_p)) if plan.top_p is not None else 0.0
-            s.use_top_p = int(plan.top_p is not None)
-            s.top_k = int(plan.top_k or 0)
-            s.use_top_k = int(plan.top_k is not None)
-            s.min_new, s.eos = int(min_new_token), int(eos_token)
-            s.row_offset = int(row_offset + lo * nrow)
-            s.infer_text = int(infer_text)
-            s.stop_at = _lib.ptr(ln.stop_d)
-            s.workspace, s.workspace_bytes = ln.workspace.data_ptr(), ws_bytes
-            s.row_map, s.n_active = ln.row_map.data_ptr(), ln.n_active.data_ptr()
-            ln.s = s
-            L.append(ln)
+                s = _lib.GenState()
+                s.B, s.T, s.max_new = Bl, T, max_new
+                s.ids_buf, s.len, s.kv_start = ln.ids_buf.data_ptr(), ln.len_d.data_ptr(), ln.kv_start.data_ptr()
+                s.finish, s.end_idx, s.hiddens = ln.finish.data_ptr(), ln.end_idx.data_ptr(), ln.hiddens.data_ptr()
+                s.kcache, s.vcache, s.q, s.nq = ln.kcache.data_ptr(), ln.vcache.data_ptr(), ln.q_d.data_ptr(), nq
+                s.temperature = sess["temp"].data_ptr()
+                s.pow_table = _lib.ptr(sess["ptab"])
+                s.top_p_thr = top_p_thr
+                s.use_top_p = int(plan.top_p is not None)
+                s.top_k = int(plan.top_k or 0)
+                s.use_top_k = int(plan.top_k is not None)
+                s.min_new, s.eos = int(min_new_token), int(eos_token)
+                s.row_offset = int(row_offset + lo * nrow)
+                s.infer_text = int(infer_text)
+                s.stop_at = _lib.ptr(ln.stop_d)
+                s.workspace, s.workspace_bytes = ln.workspace.data_ptr(), ln.ws_bytes
+                s.row_map, s.n_active = ln.row_map.data_ptr(), ln.n_active.data_ptr()
+                ln.s = s
+                sess["lanes"].append(ln)
+            self._session = sess
+        L = sess["lanes"]
+        q_sig = (draws.total_rows, V, manual_seed, row_offset, B * nrow) if draws.constant else None
+        for ln in L:
+            lo, hi = ln.lo, ln.hi
+            Bl = hi - lo
+            ln.done, ln.end_snap, ln.n_act_host = False, None, Bl
+            with torch.cuda.stream(ln.st):
+                if sess.get("out_ev") is not None:
+                    ln.st.wait_event(sess["out_ev"])   # the previous call's result copies have read these buffers
+                ln.ids_buf.zero_()
+                ln.ids_buf[:, :T] = ids_all[lo:hi]
+                ln.len_d.fill_(T)
+                ln.finish.zero_()
+                ln.row_map.copy_(torch.arange(Bl, dtype=torch.int32))
+                ln.n_active.fill_(Bl)
+                ln.end_idx.zero_()
+                ln.kv_start.copy_(kv_start_all[lo:hi])
+                if ln.stop_d is not None:
+                    ln.stop_d.copy_(stop_at[lo:hi].to(torch.int32))
+                ln.emb = emb_all[lo:hi].contiguous()
+                if draws.constant and sess["q_sig"] != q_sig:
+                    ln.q_d[0].copy_(draws.step(0)[lo * nrow: hi * nrow])
+                if ln is L[0]:
+                    sess["temp"].copy_(temp_d)
+                    if ptab is not None:
+                        sess["ptab"].copy_(ptab)
+        sess["q_sig"] = q_sig
+        if n_lanes > 1:   # temp / ptab were written on lane 0's stream
+            ev0 = torch.cuda.Event()
+            ev0.record(L[0].st)
+            for ln in L[1:]:
+                ln.st.wait_event(ev0)
 
         # ---- Exp(1) draws of the unseeded mode: the reference draws one [rows, V] tensor per step from torch's global
         # CPU generator (gpt.py:498-500).  That stream is serial (~2 ms per step at B=64, more than a decode step), so
@@ -440,15 +481,20 @@ class GptEngine:
             enqueued behind the poll keeps running while the consumer (e.g. the DVAE/Vocos decode of a streamed
             prefix) works on the caller's stream -- the two overlap on the GPU."""
             ids, hid = [], []
-            for ln in L:
-                e = ln.end_snap
-                if infer_text:
-                    ids += [ln.ids_buf[b, T: T + e[b], 0] for b in range(ln.hi - ln.lo)]               # gpt.py:300-301
-                else:
-                    ids += [ln.ids_buf[b, T: T + e[b]] for b in range(ln.hi - ln.lo)]                  # gpt.py:297-299
-                if return_hidden:
-                    hid += [ln.hiddens[b, : e[b]] for b in range(ln.hi - ln.lo)]                       # gpt.py:303-307
-                caller.wait_event(ln.ev)
+            # copies, on the caller's stream behind the poll-time event: the session's buffers are reused by the next
+            # call of the same geometry, results must not alias them
+            with torch.cuda.stream(caller):
+                for ln in L:
+                    e = ln.end_snap
+                    caller.wait_event(ln.ev)
+                    if infer_text:
+                        ids += [ln.ids_buf[b, T: T + e[b], 0].clone() for b in range(ln.hi - ln.lo)]   # gpt.py:300-301
+                    else:
+                        ids += [ln.ids_buf[b, T: T + e[b]].clone() for b in range(ln.hi - ln.lo)]      # gpt.py:297-299
+                    if return_hidden:
+                        hid += [ln.hiddens[b, : e[b]].clone() for b in range(ln.hi - ln.lo)]           # gpt.py:303-307
+                sess["out_ev"] = torch.cuda.Event()
+                sess["out_ev"].record(caller)
             return GenerationOutputs(ids=ids, attentions=[], hiddens=hid)
 
         def poll(ln):
@@ -501,9 +547,10 @@ class GptEngine:
             return  # gpt.py:570: the seeded case yields nothing
 
         graph_ok = use_graph and max_new > 1
-        if graph_ok:
+        if graph_ok and not sess["graph"]:
             for ln in L:
                 _lib.check(lib.ctts_gpt_graph_build(ln.handle, C.byref(ln.s), ln.st.cuda_stream), "ctts_gpt_graph_build")
+            sess["graph"] = True
         if profile_tag is not None:
             _lib.check(lib.ctts_gpt_profile_begin(L[0].handle, int(profile_tag), 4096, int(profile_stride)), "profile_begin")
 
@@ -547,10 +594,8 @@ class GptEngine:
         finally:
             if feeder is not None:
                 feeder["pool"].shutdown(wait=True)   # idempotent; the generator-state rewind happens in finish_rng
-            if graph_ok:
-                for ln in L:
-                    ln.st.synchronize()
-                    lib.ctts_gpt_graph_destroy(ln.handle)
+            for ln in L:
+                ln.st.synchronize()   # nothing of this call is still running when its buffers are handed to the next one
         if not all_done:
             if interrupted:
                 self.logger.warning("generation is interrupted")
