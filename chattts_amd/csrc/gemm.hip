@@ -299,10 +299,7 @@ hipError_t launch_gemm_tiled(const GemmArgs& a, hipStream_t st) {
 // MFMA, operands the epilogue needs (residual, RoPE position/cos/sin, row sums of squares) requested
 // at kernel entry so that no dependent memory round trip is left on the tail of the kernel.
 // ------------------------------------------------------------------------------------------------
-// NT > 1 (prefill, many M tiles): the workgroup keeps its A fragments in registers and walks NT consecutive N tiles
-// (A-stationary): per 16 output columns it then fetches only the 24 KB weight tile instead of weight tile + 98 KB
-// of activations, 3.4x less L2 -> L1 traffic at NT = 8.  Needs the whole K range of a wave in one load round.
-template <int MB, int NW, bool SCALE, int EPI, int NT = 1>
+template <int MB, int NW, bool SCALE, int EPI>
 __global__ __launch_bounds__(64 * (NW + (EPI == FEPI_QKV_ROPE ? 1 : 0)))
 void gemm_fast_k(FastGemmArgs a) {
   constexpr int NACC = (EPI == FEPI_SILU) ? 2 : 1;
@@ -310,13 +307,12 @@ void gemm_fast_k(FastGemmArgs a) {
   constexpr int KC = 32;
   __shared__ float red[NW][NACC][MB][64][4];
   __shared__ float rstd_s[16 * MB];
-  // per row: cos[32], sin[32] of the row's position (NT == 1 fills only the 8 + 8 entries of this tile's dims)
-  __shared__ float cs_s[(EPI == FEPI_QKV_ROPE) ? 16 * MB : 1][(EPI == FEPI_QKV_ROPE) ? 64 : 1];
+  __shared__ float cs_s[(EPI == FEPI_QKV_ROPE) ? 16 * MB : 1][16];   // per row: cos[8], sin[8] of this tile's dims
   __shared__ int meta_s[(EPI == FEPI_QKV_ROPE) ? 16 * MB : 1][2];    // per row: b, slot
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int li = lane & 15, g = lane >> 4;
-  const int nb0 = blockIdx.x * NT, m0 = blockIdx.y * 16 * MB;   // first N tile (of 16 columns) of this workgroup
+  const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16 * MB;
   const int N = a.N, K = a.K;
   // decode: only the first *n_active rows exist (compact active utterances, see GptRowMap); rows beyond are neither
   // loaded (their A fragments clamp onto the last live row: L1 hits) nor stored, and whole M tiles beyond exit
@@ -326,6 +322,10 @@ void gemm_fast_k(FastGemmArgs a) {
   long long* dbg = a.dbg ? a.dbg + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 : nullptr;
 #define STAMP(i) do { if (dbg && tid == 0) dbg[i] = wall_clock64(); } while (0)
   STAMP(0);
+  // ROPE tiles (weights permuted by the loader): columns 0..7 of a q/k tile are dims d0..d0+7 of one
+  // head, columns 8..15 are dims d0+32..d0+39, so a rotate-half pair sits 8 lanes apart.
+  const int sect = n0 / 768, hcol = n0 % 768, head = hcol >> 6, t4 = (hcol & 63) >> 4;
+  const int dlo = 8 * t4 + (li & 7);
 
   if (EPI == FEPI_QKV_ROPE && wave == NW) {
     // helper wave: the dependent chain len -> position -> cos/sin runs here, beside the main waves' load
@@ -337,19 +337,13 @@ void gemm_fast_k(FastGemmArgs a) {
       else { b = row / a.q_per_b; slot = row - b * a.q_per_b; if (a.row_map) b = a.row_map[b]; }
       int pos = slot - a.kv_start[b];
       if (pos < 0) pos = 1;
-      // NT == 1: only the 8 rotary dims of this tile (which quarter of the head it covers); NT > 1: all 32
-      const int q_lo = NT == 1 ? (((nb0 * 16) % 768) & 63) >> 4 : 0, q_hi = NT == 1 ? q_lo + 1 : 4;
+      const float4 c0 = *reinterpret_cast<const float4*>(a.cos_t + pos * 32 + 8 * t4);
+      const float4 c1 = *reinterpret_cast<const float4*>(a.cos_t + pos * 32 + 8 * t4 + 4);
+      const float4 s0 = *reinterpret_cast<const float4*>(a.sin_t + pos * 32 + 8 * t4);
+      const float4 s1 = *reinterpret_cast<const float4*>(a.sin_t + pos * 32 + 8 * t4 + 4);
       float* o = cs_s[lane];
-      for (int qq = q_lo; qq < q_hi; ++qq) {
-        const float4 c0 = *reinterpret_cast<const float4*>(a.cos_t + pos * 32 + 8 * qq);
-        const float4 c1 = *reinterpret_cast<const float4*>(a.cos_t + pos * 32 + 8 * qq + 4);
-        const float4 s0 = *reinterpret_cast<const float4*>(a.sin_t + pos * 32 + 8 * qq);
-        const float4 s1 = *reinterpret_cast<const float4*>(a.sin_t + pos * 32 + 8 * qq + 4);
-        float* oc = o + 8 * qq;
-        float* os = o + 32 + 8 * qq;
-        oc[0] = c0.x; oc[1] = c0.y; oc[2] = c0.z; oc[3] = c0.w; oc[4] = c1.x; oc[5] = c1.y; oc[6] = c1.z; oc[7] = c1.w;
-        os[0] = s0.x; os[1] = s0.y; os[2] = s0.z; os[3] = s0.w; os[4] = s1.x; os[5] = s1.y; os[6] = s1.z; os[7] = s1.w;
-      }
+      o[0] = c0.x; o[1] = c0.y; o[2] = c0.z; o[3] = c0.w; o[4] = c1.x; o[5] = c1.y; o[6] = c1.z; o[7] = c1.w;
+      o[8] = s0.x; o[9] = s0.y; o[10] = s0.z; o[11] = s0.w; o[12] = s1.x; o[13] = s1.y; o[14] = s1.z; o[15] = s1.w;
       meta_s[lane][0] = b; meta_s[lane][1] = slot;
     }
     __syncthreads();
@@ -372,175 +366,135 @@ void gemm_fast_k(FastGemmArgs a) {
   constexpr int NPAIR = 4 * MB;
   constexpr int NF = NW < 4 ? NW : 4;
   constexpr int PPW = NPAIR / NF;        // pairs per finishing wave
+  float pre0[PPW];                        // RES: residual, requested before the operand loads
+#pragma unroll
+  for (int q = 0; q < PPW; ++q) pre0[q] = 0.f;
+  if (EPI == FEPI_RES && wave < NF) {
+#pragma unroll
+    for (int q = 0; q < PPW; ++q) {
+      const int p = wave + q * NF, mb = p >> 2, r = p & 3;
+      const int row = min(m0 + 16 * mb + 4 * g + r, M - 1);
+      pre0[q] = a.C32[(size_t)row * a.ldc + min(n0 + li, N - 1)];
+    }
+  }
 
+  const int n = min(n0 + li, N - 1);
+  const uint16_t* wrow = a.W + (size_t)n * K + g * 8;
+  const uint16_t* wrow2 = wrow + (size_t)N * K;
   const uint16_t* arow[MB];
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) arow[mb] = a.A + (size_t)min(m0 + 16 * mb + li, M - 1) * a.lda + g * 8;
 
-  const int nper = K / (KC * NW);        // NT > 1: == U (one load round; the launcher guarantees it)
+  f32x4 acc[NACC][MB];
+#pragma unroll
+  for (int na = 0; na < NACC; ++na)
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) acc[na][mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nper = K / (KC * NW);
   const bool w_once = gridDim.y == 1 && a.w_nt;
-  u128 af1[MB][U];                       // NT > 1: the A fragments, loaded once and kept for all N tiles
-  u128 wnext[NACC][U];                   // NT > 1: the next N tile's weight fragments (one tile of prefetch)
-
-#pragma unroll 1
-  for (int nt = 0; nt < NT; ++nt) {
-    const int n0 = (nb0 + nt) * 16;
-    if (NT > 1 && n0 >= N) break;
-    // ROPE tiles (weights permuted by the loader): columns 0..7 of a q/k tile are dims d0..d0+7 of one
-    // head, columns 8..15 are dims d0+32..d0+39, so a rotate-half pair sits 8 lanes apart.
-    const int sect = n0 / 768, hcol = n0 % 768, head = hcol >> 6, t4 = (hcol & 63) >> 4;
-    const int dlo = 8 * t4 + (li & 7);
-
-    float pre0[PPW];                        // RES: residual, requested before the operand loads
+  for (int i = 0; i < nper; i += U) {
+    u128 wf[NACC][U], af[MB][U];
+    // W is streamed once when a single M tile covers all rows (decode): non-temporal then; when several M
+    // tiles re-read it (o/down at 16-row tiles, prefill) the normal policy keeps it in L2 for the others
 #pragma unroll
-    for (int q = 0; q < PPW; ++q) pre0[q] = 0.f;
-    if (EPI == FEPI_RES && wave < NF) {
-#pragma unroll
-      for (int q = 0; q < PPW; ++q) {
-        const int p = wave + q * NF, mb = p >> 2, r = p & 3;
-        const int row = min(m0 + 16 * mb + 4 * g + r, M - 1);
-        pre0[q] = a.C32[(size_t)row * a.ldc + min(n0 + li, N - 1)];
-      }
-    }
-
-    const int n = min(n0 + li, N - 1);
-    const uint16_t* wrow = a.W + (size_t)n * K + g * 8;
-    const uint16_t* wrow2 = wrow + (size_t)N * K;
-
-    f32x4 acc[NACC][MB];
-#pragma unroll
-    for (int na = 0; na < NACC; ++na)
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb) acc[na][mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    for (int i = 0; i < (NT > 1 ? U : nper); i += U) {
-      u128 wf[NACC][U], afr[MB][U];
-      // W is streamed once when a single M tile covers all rows (decode): non-temporal then; when several M
-      // tiles re-read it (o/down at 16-row tiles, prefill) the normal policy keeps it in L2 for the others
-      if (NT == 1 || nt == 0) {
-#pragma unroll
-        for (int j = 0; j < U; ++j) {
-          const int k0 = (wave * nper + i + j) * KC;  // contiguous K range per wave: whole 128-B lines of a row stay in one wave
-          if (w_once) {
-            wf[0][j] = load16_nt(wrow + k0);
-            if (NACC == 2) wf[1][j] = load16_nt(wrow2 + k0);
-          } else {
-            wf[0][j] = load16(wrow + k0);
-            if (NACC == 2) wf[1][j] = load16(wrow2 + k0);
-          }
-        }
+    for (int j = 0; j < U; ++j) {
+      const int k0 = (wave * nper + i + j) * KC;  // contiguous K range per wave: whole 128-B lines of a row stay in one wave
+      if (w_once) {
+        wf[0][j] = load16_nt(wrow + k0);
+        if (NACC == 2) wf[1][j] = load16_nt(wrow2 + k0);
       } else {
-        // NT > 1: this tile's weights were requested during the previous tile (see below)
-#pragma unroll
-        for (int j = 0; j < U; ++j) {
-          wf[0][j] = wnext[0][j];
-          if (NACC == 2) wf[1][j] = wnext[1][j];
-        }
+        wf[0][j] = load16(wrow + k0);
+        if (NACC == 2) wf[1][j] = load16(wrow2 + k0);
       }
-      if (NT > 1 && nt + 1 < NT && n0 + 16 < N) {
-        // request the NEXT N tile's weights now: they land while this tile is multiplied, reduced and finished
-        const uint16_t* wn_ = a.W + (size_t)min(n0 + 16 + li, N - 1) * K + g * 8;
-#pragma unroll
-        for (int j = 0; j < U; ++j) {
-          const int k0 = (wave * nper + j) * KC;
-          wnext[0][j] = load16(wn_ + k0);
-          if (NACC == 2) wnext[1][j] = load16(wn_ + (size_t)N * K + k0);
-        }
-      }
-      if (NT == 1 || nt == 0) {
-#pragma unroll
-        for (int j = 0; j < U; ++j) {
-          const int k0 = (wave * nper + i + j) * KC;
-#pragma unroll
-          for (int mb = 0; mb < MB; ++mb) {
-            const u128 v = *reinterpret_cast<const u128*>(arow[mb] + k0);
-            if (NT == 1) afr[mb][j] = v; else af1[mb][j] = v;
-          }
-        }
-      }
-      // keep every load of the round in flight: hipcc otherwise sinks the loads next to their MFMA and
-      // waits vmcnt(1) per fragment (one L2/HBM round trip per MFMA pair)
-      __builtin_amdgcn_sched_barrier(0);
-      if (i == 0 && nt == 0) STAMP(1);
-#pragma unroll
-      for (int j = 0; j < U; ++j)
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-          for (int na = 0; na < NACC; ++na)
-            acc[na][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(NT == 1 ? &afr[mb][j] : &af1[mb][j]),
-                                                                  *reinterpret_cast<const bf16x8*>(&wf[na][j]), acc[na][mb], 0, 0, 0);
-    }
-
-    if (nt == 0) STAMP(2);
-    if (SCALE && nt == 0) {
-      float s = (((s0.x + s0.y) + (s0.z + s0.w)) + ((s1.x + s1.y) + (s1.z + s1.w))) + ((s2.x + s2.y) + (s2.z + s2.w));
-      s += __shfl_xor(s, 1, 64);
-      s += __shfl_xor(s, 2, 64);
-      if (spart == 0 && srow < 16 * MB) rstd_s[srow] = 1.0f / sqrtf(s / 768.0f + a.eps);
     }
 #pragma unroll
-    for (int na = 0; na < NACC; ++na)
+    for (int j = 0; j < U; ++j) {
+      const int k0 = (wave * nper + i + j) * KC;  // contiguous K range per wave: whole 128-B lines of a row stay in one wave
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) af[mb][j] = *reinterpret_cast<const u128*>(arow[mb] + k0);
+    }
+    // keep every load of the round in flight: hipcc otherwise sinks the loads next to their MFMA and
+    // waits vmcnt(1) per fragment (one L2/HBM round trip per MFMA pair)
+    __builtin_amdgcn_sched_barrier(0);
+    if (i == 0) STAMP(1);
+#pragma unroll
+    for (int j = 0; j < U; ++j)
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) red[wave][na][mb][lane][r] = acc[na][mb][r];
-    __syncthreads();
-    if (nt == 0) STAMP(3);
-    if (wave < NF) {
-      const int col = n0 + li;
+        for (int na = 0; na < NACC; ++na)
+          acc[na][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&af[mb][j]),
+                                                                *reinterpret_cast<const bf16x8*>(&wf[na][j]), acc[na][mb], 0, 0, 0);
+  }
+
+  STAMP(2);
+  if (SCALE) {
+    float s = (((s0.x + s0.y) + (s0.z + s0.w)) + ((s1.x + s1.y) + (s1.z + s1.w))) + ((s2.x + s2.y) + (s2.z + s2.w));
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    if (spart == 0 && srow < 16 * MB) rstd_s[srow] = 1.0f / sqrtf(s / 768.0f + a.eps);
+  }
 #pragma unroll
-      for (int q = 0; q < PPW; ++q) {
-        const int p = wave + q * NF, mb = p >> 2, r = p & 3;
-        const int row = m0 + 16 * mb + 4 * g + r;
-        float v = 0.f, u = 0.f;
+  for (int na = 0; na < NACC; ++na)
 #pragma unroll
-        for (int w = 0; w < NW; ++w) v += red[w][0][mb][lane][r];
-        if (EPI == FEPI_SILU) {
+    for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-          for (int w = 0; w < NW; ++w) u += red[w][NACC - 1][mb][lane][r];
+      for (int r = 0; r < 4; ++r) red[wave][na][mb][lane][r] = acc[na][mb][r];
+  __syncthreads();
+  STAMP(3);
+  if (wave < NF) {
+    const int col = n0 + li;
+#pragma unroll
+    for (int q = 0; q < PPW; ++q) {
+      const int p = wave + q * NF, mb = p >> 2, r = p & 3;
+      const int row = m0 + 16 * mb + 4 * g + r;
+      float v = 0.f, u = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) v += red[w][0][mb][lane][r];
+      if (EPI == FEPI_SILU) {
+#pragma unroll
+        for (int w = 0; w < NW; ++w) u += red[w][NACC - 1][mb][lane][r];
+      }
+      const bool ok = row < M && col < N;
+      if (SCALE) {
+        const float rs = rstd_s[16 * mb + 4 * g + r];
+        v *= rs;
+        u *= rs;
+      }
+      if (EPI == FEPI_STORE32) {
+        if (ok) a.C32[(size_t)row * a.ldc + col] = v;
+      } else if (EPI == FEPI_SILU) {
+        if (ok) a.Cb[(size_t)row * a.ldcb + col] = f32_to_bf16(silu_f(v) * u);
+      } else if (EPI == FEPI_RES) {
+        float xn = 0.f;
+        if (ok) {
+          xn = pre0[q] + v;
+          a.C32[(size_t)row * a.ldc + col] = xn;
+          a.Cb[(size_t)row * a.ldcb + col] = f32_to_bf16(xn);
         }
-        const bool ok = row < M && col < N;
-        if (SCALE) {
-          const float rs = rstd_s[16 * mb + 4 * g + r];
-          v *= rs;
-          u *= rs;
-        }
-        if (EPI == FEPI_STORE32) {
-          if (ok) a.C32[(size_t)row * a.ldc + col] = v;
-        } else if (EPI == FEPI_SILU) {
-          if (ok) a.Cb[(size_t)row * a.ldcb + col] = f32_to_bf16(silu_f(v) * u);
-        } else if (EPI == FEPI_RES) {
-          float xn = 0.f;
-          if (ok) {
-            xn = pre0[q] + v;
-            a.C32[(size_t)row * a.ldc + col] = xn;
-            a.Cb[(size_t)row * a.ldcb + col] = f32_to_bf16(xn);
-          }
-          float sq = xn * xn;
-          sq += __shfl_xor(sq, 1, 64);
-          sq += __shfl_xor(sq, 2, 64);
-          sq += __shfl_xor(sq, 4, 64);
-          sq += __shfl_xor(sq, 8, 64);
-          if (li == 0 && row < M) a.ssq_out[(size_t)row * SSQ_PARTS + nb0 + nt] = sq;
-        } else {  // FEPI_QKV_ROPE: q -> roped, in the f32 qkv buffer; k -> roped, KV cache; v -> KV cache
-          const float other = __shfl_xor(v, 8, 64);
-          const bool hi = li >= 8;
-          const int lr = 16 * mb + 4 * g + r;
-          const float cc = cs_s[lr][8 * t4 + (li & 7)], ss = cs_s[lr][32 + 8 * t4 + (li & 7)];
-          // rotate-half: out[d] = x[d] c - x[d+32] s ; out[d+32] = x[d+32] c + x[d] s
-          const float roped = hi ? (v * cc + other * ss) : (v * cc - other * ss);
-          const int d = dlo + (hi ? 32 : 0);
-          if (ok) {
-            const size_t cbase = (((size_t)meta_s[lr][0] * 12 + head) * a.cmax + meta_s[lr][1]) * 64;
-            if (sect == 0) a.C32[(size_t)row * a.ldc + head * 64 + d] = roped;
-            else if (sect == 1) a.kc[cbase + d] = f32_to_bf16(roped);
-            else a.vc[cbase + (hcol & 63) + li] = f32_to_bf16(v);
-          }
+        float sq = xn * xn;
+        sq += __shfl_xor(sq, 1, 64);
+        sq += __shfl_xor(sq, 2, 64);
+        sq += __shfl_xor(sq, 4, 64);
+        sq += __shfl_xor(sq, 8, 64);
+        if (li == 0 && row < M) a.ssq_out[(size_t)row * SSQ_PARTS + blockIdx.x] = sq;
+      } else {  // FEPI_QKV_ROPE: q -> roped, in the f32 qkv buffer; k -> roped, KV cache; v -> KV cache
+        const float other = __shfl_xor(v, 8, 64);
+        const bool hi = li >= 8;
+        const int lr = 16 * mb + 4 * g + r;
+        const float cc = cs_s[lr][li & 7], ss = cs_s[lr][8 + (li & 7)];
+        // rotate-half: out[d] = x[d] c - x[d+32] s ; out[d+32] = x[d+32] c + x[d] s
+        const float roped = hi ? (v * cc + other * ss) : (v * cc - other * ss);
+        const int d = dlo + (hi ? 32 : 0);
+        if (ok) {
+          const size_t cbase = (((size_t)meta_s[lr][0] * 12 + head) * a.cmax + meta_s[lr][1]) * 64;
+          if (sect == 0) a.C32[(size_t)row * a.ldc + head * 64 + d] = roped;
+          else if (sect == 1) a.kc[cbase + d] = f32_to_bf16(roped);
+          else a.vc[cbase + (hcol & 63) + li] = f32_to_bf16(v);
         }
       }
     }
-    if (NT > 1 && nt + 1 < NT) __syncthreads();   // `red` is rewritten by the next N tile
   }
   STAMP(4);
 #undef STAMP
@@ -550,19 +504,6 @@ template <int MB>
 static hipError_t fast_dispatch(const FastGemmArgs& a, hipStream_t st) {
   dim3 grid((a.N + 15) / 16, (a.M + 16 * MB - 1) / (16 * MB));
   const bool scale = a.ssq_in != nullptr;
-  // prefill (many M tiles): A-stationary walk over 8 N tiles per workgroup (K = 768 kernels: one load round per wave)
-  constexpr int NTP = 8;
-  static int ntp = -1;   // CTTS_PREFILL_NT=1 restores one N tile per workgroup (A/B)
-  if (ntp < 0) { const char* e = getenv("CTTS_PREFILL_NT"); ntp = e ? atoi(e) : NTP; }
-  if (MB == 4 && a.K == 768 && a.M >= 256 && grid.x % NTP == 0 && ntp == NTP) {
-    dim3 g8(grid.x / NTP, grid.y);
-    if (a.epi == FEPI_STORE32 && scale) CTTS_LAUNCH((gemm_fast_k<4, 4, true, FEPI_STORE32, NTP>), g8, dim3(256), st, a);
-    else if (a.epi == FEPI_QKV_ROPE && scale) CTTS_LAUNCH((gemm_fast_k<4, 4, true, FEPI_QKV_ROPE, NTP>), g8, dim3(320), st, a);
-    else if (a.epi == FEPI_SILU && scale) CTTS_LAUNCH((gemm_fast_k<4, 4, true, FEPI_SILU, NTP>), g8, dim3(256), st, a);
-    else if (a.epi == FEPI_RES && !scale) CTTS_LAUNCH((gemm_fast_k<4, 4, false, FEPI_RES, NTP>), g8, dim3(256), st, a);
-    else return hipErrorInvalidValue;
-    return hipGetLastError();
-  }
   if (a.K == 768) {
     if (a.epi == FEPI_STORE32 && scale) CTTS_LAUNCH((gemm_fast_k<MB, 4, true, FEPI_STORE32>), grid, dim3(256), st, a);
     else if (a.epi == FEPI_QKV_ROPE && scale) CTTS_LAUNCH((gemm_fast_k<MB, 4, true, FEPI_QKV_ROPE>), grid, dim3(320), st, a);
@@ -591,6 +532,13 @@ hipError_t launch_gemm_fast(const FastGemmArgs& a_in, hipStream_t st) {
   if (a.M <= 0 || a.N <= 0 || (a.lda % 8) != 0) return hipErrorInvalidValue;
   if (a.epi == FEPI_RES && a.N != 16 * SSQ_PARTS) return hipErrorInvalidValue;
   if (a.epi == FEPI_QKV_ROPE && (a.N != 2304 || a.K != 768)) return hipErrorInvalidValue;
+  {
+    // prompt-sized M: the LDS-tiled kernel of prefill.hip (this one is a weight-streaming shape for M <= 64 and
+    // re-reads its operands from L2 for every 16 output columns when there are many M tiles)
+    static int tiled = -1;   // CTTS_PREFILL_TILED=0: keep gemm_fast_k for every M (A/B)
+    if (tiled < 0) { const char* e = getenv("CTTS_PREFILL_TILED"); tiled = e ? atoi(e) : 1; }
+    if (tiled && a.M >= 256 && !a.force_mb && gemm_prefill_supported(a)) return launch_gemm_prefill(a, st);
+  }
   // rows per workgroup: the per-workgroup latency is set by fixed round trips, not bytes, so prefer
   // enough workgroups to cover the 256 CUs over big M tiles (decode: M <= 64)
   // measured (tools/gemm_phase_probe.py): these kernels are bound by each CU's vector-memory path, so pick

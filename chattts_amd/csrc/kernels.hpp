@@ -86,6 +86,10 @@ struct FastGemmArgs {
   long long* dbg;               // probes only: [n_workgroups][8] phase stamps, or null
 };
 hipError_t launch_gemm_fast(const FastGemmArgs& a, hipStream_t st);
+// prefill.hip: 128x128x64 LDS-tiled bf16 GEMM with the RES / SILU / QKV_ROPE epilogues, for M = B*T prompt rows
+// (launch_gemm_fast routes M >= 256 here; CTTS_PREFILL_TILED=0 keeps the A-stationary gemm_fast_k variant)
+bool gemm_prefill_supported(const FastGemmArgs& a);
+hipError_t launch_gemm_prefill(const FastGemmArgs& a, hipStream_t st);
 // x32 row -> bf16 copy + partial sums of squares (prefill entry); optional code-embedding gather
 hipError_t launch_rows_prep(const float* x32, uint16_t* xb, float* ssq, int M, hipStream_t st);
 hipError_t launch_gemm_tiled(const GemmArgs& a, hipStream_t st);   // 64x64 LDS-tiled f32 MFMA, large M

@@ -62,7 +62,7 @@ def test_gemm_skinny(G, wt, M, shape):
     assert G.relerr(got, ref) < tol, (wt, M, shape, G.relerr(got, ref))
 
 
-@pytest.mark.parametrize("M", [1, 9, 16, 31, 64, 200])
+@pytest.mark.parametrize("M", [1, 9, 16, 31, 64, 200, 300, 1111, 1500, 11008])   # >= 256 rows: the LDS-tiled prefill kernel (64- and 128-row tiles)
 def test_gemm_fast_bf16(G, M):
     """perf-mode projections: bf16 activations, row scale from partial sums of squares, three epilogues"""
     lib = _lib.lib()
@@ -117,13 +117,20 @@ def test_gemm_fast_bf16(G, M):
 
 
 @pytest.mark.parametrize("force_mb", [0, 1, 2, 4])
-@pytest.mark.parametrize("decode", [False, True])
+@pytest.mark.parametrize("decode", [False, True, "tiled", "tiled128"])
 def test_qkv_rope_fused(G, force_mb, decode):
-    """perf-mode fused RMSNorm-scale + QKV + RoPE + KV append vs numpy (natural weight order)"""
+    """perf-mode fused RMSNorm-scale + QKV + RoPE + KV append vs numpy (natural weight order); "tiled": a prompt-sized
+    launch (M = 333 rows >= 256) goes to the LDS-tiled prefill kernel (prefill.hip) unless an M tile is forced"""
     from chattts_amd.engine import rope_row_perm, rope_tables
     lib = _lib.lib()
     rs = np.random.RandomState(17 + force_mb)
-    B, T, cmax, nh, d = (37, 1, 90, 12, 64) if decode else (3, 23, 60, 12, 64)
+    if decode in ("tiled", "tiled128"):
+        if force_mb not in (0, 4) or (decode == "tiled128" and force_mb):
+            pytest.skip("one forced variant is enough at this size")
+        B, T, cmax, nh, d = (9, 37, 60, 12, 64) if decode == "tiled" else (100, 37, 40, 12, 64)   # 333 / 3700 rows
+        decode = False
+    else:
+        B, T, cmax, nh, d = (37, 1, 90, 12, 64) if decode else (3, 23, 60, 12, 64)
     M = B * T
     kv_start = rs.randint(0, 6, size=B).astype(np.int32)
     lens = (rs.randint(20, 60, size=B)).astype(np.int32)

@@ -24,10 +24,8 @@ def collect(root, counter):
 
 
 def short(name):
-    # decode kernels only (the last template argument 1 = one N tile per workgroup; the 8-tile variants are prefill)
-    for key, tag in (("attention_k<unsigned short, 4", "attention"), ("gemm_fast_k<2, 4, true, 3, 1>", "qkv_gemm"),
-                     ("gemm_fast_k<4, 4, true, 3, 1>", "qkv_gemm"), ("gemm_fast_k<1, 4, false, 1, 1>", "o_proj_gemm"),
-                     ("true, 2, 1>", "gate_up_gemm"), ("gemm_fast_k<1, 16, false, 1, 1>", "down_gemm"),
+    for key, tag in (("attention_k", "attention"), ("gemm_fast_k<2, 4, true, 3>", "qkv_gemm"), ("gemm_fast_k<4, 4, true, 3>", "qkv_gemm"),
+                     ("gemm_fast_k<1, 4, false, 1>", "o_proj_gemm"), ("true, 2>", "gate_up_gemm"), ("gemm_fast_k<1, 16, false, 1>", "down_gemm"),
                      ("gemm_skinny_k<float", "heads_gemm"), ("sample_k", "sample")):
         if key in name:
             return tag
