@@ -415,3 +415,37 @@ def test_chat_infer_stream_text_level_equals_token_level(weights):
     whole = chat.infer(list(texts), skip_refine_text=True, split_text=False, params_infer_code=mk())
     full = chat.infer_ids(ids, mask, tmask, mk())
     assert all(np.array_equal(w, r[np.abs(r) > 1e-5]) for w, r in zip(whole, full))
+
+
+def test_session_reuse_has_no_stale_state(gpt_f32, weights):
+    """Two calls of identical geometry and sampling constants share device buffers and the captured graph (session
+    reuse): the second call, with different prompts / padding / forced lengths, must equal the oracle exactly as if it
+    ran on a fresh engine, and the first call's returned tensors must not change under it."""
+    from chattts_amd import rng
+    llama = llama_np.LlamaWeights({k: v.numpy() for k, v in weights["gpt"].items()})
+    esd = {k: v.numpy() for k, v in weights["embed"].items()}
+    warpers, procs = E.gen_logits(625, 0.7, 20, 1.05)
+    kept = None
+    for seed, stop in ((21, [6, 11, 3]), (22, [9, 2, 12])):
+        ids, mask, tmask = synth.make_prompts(3, 12, 12, seed=seed)     # same T for both calls
+        if seed == 22:
+            mask[1, :4] = 0                                               # different left padding the second time
+            ids[1, :4] = 0
+            tmask[1, :4] = False
+        stop = np.array(stop, np.int32)
+        ids_t, mask_t = torch.from_numpy(ids), torch.from_numpy(mask)
+        emb = gpt_f32.embed_prompt(ids_t, torch.from_numpy(tmask))
+        out = list(gpt_f32.generate(emb, ids_t, torch.tensor([0.3] * 4), 625, mask_t, 16, 0, (*procs, *warpers), return_hidden=True,
+                                    manual_seed=5, stop_at=torch.from_numpy(stop)))[-1]
+        draws = rng.ExpDraws(3 * 4, 626, 5)
+        ref = generate_np.generate(llama, esd, generate_np.fold_heads(esd), generate_np.embed_prompt(esd, ids, tmask), ids, mask,
+                                   temperature=np.array([0.3] * 4, np.float32), draw_q=lambda i: draws.step(i).numpy(),
+                                   pow_table=rng.penalty_table(1.05).numpy(), max_new_token=16, stop_at=stop)
+        for b in range(3):
+            assert np.array_equal(out.ids[b].cpu().numpy(), ref.ids[b]), (seed, b)
+            assert np.abs(out.hiddens[b].cpu().numpy() - ref.hiddens[b]).max() < 2e-4
+        if kept is None:
+            kept = (out, [t.clone() for t in out.ids], [t.clone() for t in out.hiddens])
+    first, ids0, hid0 = kept
+    assert all(torch.equal(a, b) for a, b in zip(first.ids, ids0)) and all(torch.equal(a, b) for a, b in zip(first.hiddens, hid0))
+    assert gpt_f32._session is not None and gpt_f32._session["graph"]
