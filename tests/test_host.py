@@ -184,3 +184,21 @@ def test_two_rank_broadcast_and_sharded_sampling(golden):
     assert res[0][0] == res[1][0]  # identical weights on both ranks after the broadcast
     idx = np.array(res[0][2] + res[1][2])
     assert np.array_equal(idx, golden["sampling"]["rows640.idx"])  # union of shards == the reference's full-batch run
+
+
+def test_pmc_summary_maps_the_profiled_kernel_names():
+    """tools/pmc_summary.py maps rocprofv3 kernel names to bench.py's tags by substring; the committed kernel-stat CSV of the
+    round must still resolve to every tag bench.py's roofline leg can ask for (catches template-argument drift)."""
+    import csv
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("pmc_summary", os.path.join(ROOT, "tools", "pmc_summary.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    with open(os.path.join(ROOT, "profiles", "r1z_kernel_stats.csv")) as f:
+        names = [r["Name"] for r in csv.DictReader(f)]
+    tags = {mod.short(n) for n in names} - {None}
+    assert {"attention", "qkv_gemm", "o_proj_gemm", "gate_up_gemm", "down_gemm", "heads_gemm", "sample"} <= tags
+    import json
+    with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+        traffic = json.load(f)
+    assert traffic["attention"]["hbm_bytes_per_launch"] > 1e7 and traffic["attention"]["dispatches"] > 1000
