@@ -793,7 +793,10 @@ hipError_t launch_gemm_tiled_bf16x3(const GemmArgs& a, hipStream_t st) {
   static int big = -1;  // CTTS_X3_TILE=128 forces the small tile, =2 the 256x128 tile (A/B experiments)
   if (big < 0) { const char* e = getenv("CTTS_X3_TILE"); big = e ? (atoi(e) == 128 ? 0 : atoi(e)) : 1; }
   if (big == 2 && a.N >= 512 && a.M >= 2048) return x3_dispatch<2, 2, 4, 2>(a, st);  // 256x128 tile, 256 threads, 2 per CU
-  if (big == 1 && a.N >= 512 && a.M >= 2048) return x3_dispatch<4, 2, 2, 4, 2>(a, st);   // 256x256 tile, 512 threads, 2 LDS buffers
+  // 256x256 tiles pay off once they fill the chip about twice over; below that the one-workgroup-per-CU rounds quantise badly
+  // (tools/codec_small_probe.py, whole decoder: 2304 frames 6.8 -> 4.1 ms, 9216 frames 8.2 -> 7.2 ms with 128x128 tiles;
+  // 18432 frames 10.5 vs 12.2 ms and 65536 frames in favour of 256x256)
+  if (big == 1 && a.N >= 512 && a.M >= 12288) return x3_dispatch<4, 2, 2, 4, 2>(a, st);   // 256x256 tile, 512 threads, 2 LDS buffers
   if (big && a.N >= 512 && a.M >= 2048) return x3_dispatch<4, 2, 2, 4>(a, st);   // CTTS_X3_TILE=256: single LDS buffer (A/B)
   return x3_dispatch<2, 2, 2, 2>(a, st);                                          // 128x128 tile, 256 threads
 }
