@@ -159,3 +159,12 @@ def test_audio_back_end():
     with wave.open(io.BytesIO(b), "rb") as wf:
         assert (wf.getnchannels(), wf.getsampwidth(), wf.getframerate(), wf.getnframes()) == (1, 2, 24000, 6)
         assert np.frombuffer(wf.readframes(6), dtype="<i2").tolist() == A.float_to_int16(x).tolist()
+
+
+def test_chat_load_rejects_remote_sources_before_touching_the_gpu():
+    """the reference's `load` returns False on a failed download (core.py:149-151); this engine has no network path"""
+    from chattts_amd.core import Chat
+    c = Chat()
+    assert c.load(source="huggingface") is False and not c.has_loaded()
+    # sentence splitting of `infer` (core.py:225-238) happens before anything is loaded: an empty text yields []
+    assert c.infer("", split_text=True) == []
