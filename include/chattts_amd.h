@@ -112,7 +112,8 @@ void ctts_gpt_destroy(ctts_gpt* g);
 size_t ctts_gpt_workspace_bytes(int32_t B, int32_t T);
 
 /* step 0 of gpt.py:394: consumes emb[B,T,768] f32 (Embed.forward output, embed.py:52-79), fills the KV
- * cache, writes hiddens[:,0], samples token 0 into ids_buf[:,T], sets len = T+1. */
+ * cache, writes hiddens[:,0], samples token 0 into ids_buf[:,T], sets len = T+1.  In bf16 mode the four projections of
+ * a layer run on LDS-tiled 128x128x64 MFMA tiles when B*T >= 256 rows (csrc/prefill.hip), on the decode kernels below that. */
 int ctts_gpt_prefill(ctts_gpt* g, const ctts_gen_state* s, const float* emb, void* stream);
 /* one iteration i > 0 of gpt.py:394-577, eager launches */
 int ctts_gpt_decode_step(ctts_gpt* g, const ctts_gen_state* s, void* stream);
