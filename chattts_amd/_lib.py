@@ -23,6 +23,7 @@ class GptWeights(C.Structure):
         ("norm", P), ("emb_code", P), ("heads", P), ("rope_cos", P), ("rope_sin", P),
         ("rms_eps", C.c_float),
         ("emb_text", P), ("head_text", P), ("n_text", C.c_int32),
+        ("wqkv_pk", PP), ("wo_pk", PP), ("wgu_pk", PP), ("wd_pk", PP),
     ]
 
 
@@ -36,7 +37,7 @@ class GenState(C.Structure):
         ("min_new", C.c_int32), ("eos", C.c_int32), ("row_offset", C.c_int32),
         ("stop_at", P), ("workspace", P), ("workspace_bytes", C.c_size_t), ("row_map", P), ("n_active", P),
         ("cap", C.c_int32), ("hid_cap", C.c_int32), ("kv_batch", C.c_int32), ("q_batch", C.c_int32), ("prompt_len", P),
-        ("infer_text", C.c_int32),
+        ("infer_text", C.c_int32), ("teacher_ids", P),
     ]
 
 
@@ -106,6 +107,7 @@ SIGNATURES = {
     "ctts_k_gemm": (C.c_int, [I32, P, P, P, I32, I32, I32, I32, I32, I32, I32, P, F, P, I32, P, P, I32, I32, I32, I32, I32, P]),
     "ctts_k_gemm_fast": (C.c_int, [P, I32, P, I32, I32, I32, P, F, I32, P, I32, P, I32, P, P]),
     "ctts_k_qkv_rope": (C.c_int, [P, P, I32, P, F, P, P, P, I32, P, P, I32, P, P, I32, P]),
+    "ctts_k_gemm_dec": (C.c_int, [P, P, I32, I32, I32, P, P, F, I32, P, I32, P, I32, P, I32, P]),
     "ctts_k_rows_prep": (C.c_int, [P, P, P, I32, P]),
     "ctts_k_rope_append": (C.c_int, [P, P, P, I32, I32, P, P, I32, P, P, I32, P]),
     "ctts_k_attention": (C.c_int, [P, P, P, I32, I32, P, I32, P, P, I32, P]),

@@ -34,6 +34,8 @@ static const int HID = 768, INTER = 3072, NHEAD = 12, HDIM = 64, NVQ = 4, NAUDIO
 struct ctts_gpt {
   ctts_gpt_weights w;
   std::vector<const void*> wqkv, wo, wgu, wd;
+  std::vector<const void*> wqkv_pk, wo_pk, wgu_pk, wd_pk;   // fragment-packed copies for the decode step (perf mode), or empty
+  bool dec_packed = false;
   std::vector<const float*> ln1, ln2;
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
@@ -52,6 +54,9 @@ static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 struct GptWs {
   float *x, *qkv, *ao, *act, *hfin, *logits, *ssq;
   uint16_t* xb;  // bf16 copy of the residual stream (perf mode); ao / act are reused as bf16 buffers there
+  // decode step on fragment-packed operands (decode.hip): row tiles of 16 utterances
+  uint16_t *xp, *aop, *actp;
+  RowDesc* desc;
   size_t bytes;
 };
 static GptWs carve(void* base, int B, int T) {
@@ -67,6 +72,11 @@ static GptWs carve(void* base, int B, int T) {
   w.logits = (float*)(p + off); off += align_up((size_t)B * NTEXT_MAX * 4);  // >= B*4*626; refine-text mode needs B*n_text
   w.ssq = (float*)(p + off); off += align_up(M * SSQ_PARTS * 4);
   w.xb = (uint16_t*)(p + off); off += align_up(M * HID * 2);
+  const size_t Bp = ((size_t)B + 15) / 16 * 16;
+  w.xp = (uint16_t*)(p + off); off += align_up(Bp * HID * 2);
+  w.aop = (uint16_t*)(p + off); off += align_up(Bp * HID * 2);
+  w.actp = (uint16_t*)(p + off); off += align_up(Bp * INTER * 2);
+  w.desc = (RowDesc*)(p + off); off += align_up(Bp * sizeof(RowDesc));
   w.bytes = off;
   return w;
 }
@@ -84,6 +94,15 @@ extern "C" int ctts_gpt_create(ctts_gpt** out, const ctts_gpt_weights* w) {
   g->wd.assign(w->wd, w->wd + L);
   g->ln1.assign(w->ln1, w->ln1 + L);
   g->ln2.assign(w->ln2, w->ln2 + L);
+  if (w->weight_dtype == CTTS_BF16 && w->wqkv_pk && w->wo_pk && w->wgu_pk && w->wd_pk) {
+    g->wqkv_pk.assign(w->wqkv_pk, w->wqkv_pk + L);
+    g->wo_pk.assign(w->wo_pk, w->wo_pk + L);
+    g->wgu_pk.assign(w->wgu_pk, w->wgu_pk + L);
+    g->wd_pk.assign(w->wd_pk, w->wd_pk + L);
+    g->dec_packed = true;
+    const char* e = getenv("CTTS_DEC_PACKED");   // =0: decode on the row-major kernels (A/B)
+    if (e && atoi(e) == 0) g->dec_packed = false;
+  }
   { const char* e = getenv("CTTS_SKIP_FINISHED"); if (e && atoi(e) == 0) g->skip_finished = false; }
   *out = g;
   return 0;
@@ -127,6 +146,7 @@ static SampleArgs make_sample_args(const ctts_gen_state* s, const float* logits)
   a.top_p_thr = s->top_p_thr; a.use_top_p = s->use_top_p; a.top_k = s->top_k; a.use_top_k = s->use_top_k;
   a.min_new = s->min_new; a.eos = s->eos; a.row_offset = s->row_offset; a.max_input_ids = NAUDIO - 1; a.stop_at = s->stop_at;
   a.B = s->B; a.row_map = nullptr; a.n_active = nullptr; a.prompt_len = s->prompt_len; a.q_rows = s->q_batch ? s->q_batch : s->B;
+  a.teacher = s->teacher_ids; a.teacher_stride = s->hid_cap ? s->hid_cap : s->max_new;
   return a;
 }
 
@@ -156,9 +176,33 @@ static int run_step(ctts_gpt* g, const ctts_gen_state* s, int q_per_b, hipStream
   const bool dec = q_per_b == 1;
   const int32_t* rmap = s->row_map;   // decode: compact row -> slot (see GptRowMap); prefill: row group -> slot of a pool (or null)
   const int32_t* nact = dec ? s->n_active : nullptr;
-  GptRowMap rm{q_per_b, s->len, s->kv_start, rmap, nact, (dec && g->skip_finished) ? s->finish : nullptr};
+  GptRowMap rm{q_per_b, s->len, s->kv_start, rmap, nact, (dec && g->skip_finished) ? s->finish : nullptr, nullptr};
   const bool fast = wt == CTTS_BF16;  // perf mode: bf16 activations, RMSNorm gain folded into wqkv / wgu by the loader
-  for (int l = 0; fast && l < g->w.n_layers; ++l) {
+  const bool packed = fast && dec && g->dec_packed;   // decode step on fragment-packed operands (decode.hip)
+  if (dec) rm.desc = ws.desc;                          // written by the embedding kernel at the head of the step
+  for (int l = 0; packed && l < g->w.n_layers; ++l) {
+    void* kc = (char*)s->kcache + kv_layer * l;
+    void* vc = (char*)s->vcache + kv_layer * l;
+    DecGemmArgs d;
+    memset(&d, 0, sizeof(d));
+    d.M = M; d.eps = g->w.rms_eps; d.n_active = nact;
+    // RMSNorm scale + QKV + RoPE + KV append
+    d.Ap = ws.xp; d.Wp = (const uint16_t*)g->wqkv_pk[l]; d.N = 3 * HID; d.K = HID; d.ssq_in = ws.ssq; d.epi = FEPI_QKV_ROPE;
+    d.C32 = ws.qkv; d.ldc = 3 * HID; d.desc = ws.desc; d.cos_t = g->w.rope_cos; d.sin_t = g->w.rope_sin;
+    d.kc = (uint16_t*)kc; d.vc = (uint16_t*)vc; d.cmax = cmax;
+    { Prof p(g, 1, st, prof_ok); CK(launch_gemm_dec(d, st)); }
+    { Prof p(g, 3, st, prof_ok); CK(launch_attention(ws.qkv, kc, vc, kt, cmax, ws.aop, 2, rm, M, st)); }
+    d.Ap = ws.aop; d.Wp = (const uint16_t*)g->wo_pk[l]; d.N = HID; d.ssq_in = nullptr; d.epi = FEPI_RES; d.C32 = ws.x; d.ldc = HID;
+    d.Cp = ws.xp; d.kch_out = HID / 32; d.ssq_out = ws.ssq;
+    { Prof p(g, 4, st, prof_ok); CK(launch_gemm_dec(d, st)); }
+    d.Ap = ws.xp; d.Wp = (const uint16_t*)g->wgu_pk[l]; d.N = INTER; d.ssq_in = ws.ssq; d.epi = FEPI_SILU; d.C32 = nullptr;
+    d.Cp = ws.actp; d.kch_out = INTER / 32; d.ssq_out = nullptr;
+    { Prof p(g, 5, st, prof_ok); CK(launch_gemm_dec(d, st)); }
+    d.Ap = ws.actp; d.Wp = (const uint16_t*)g->wd_pk[l]; d.N = HID; d.K = INTER; d.ssq_in = nullptr; d.epi = FEPI_RES; d.C32 = ws.x;
+    d.ldc = HID; d.Cp = ws.xp; d.kch_out = HID / 32; d.ssq_out = ws.ssq;
+    { Prof p(g, 6, st, prof_ok); CK(launch_gemm_dec(d, st)); }
+  }
+  for (int l = 0; fast && !packed && l < g->w.n_layers; ++l) {
     void* kc = (char*)s->kcache + kv_layer * l;
     void* vc = (char*)s->vcache + kv_layer * l;
     uint16_t* aob = (uint16_t*)ws.ao;
@@ -244,12 +288,15 @@ extern "C" int ctts_gpt_prefill(ctts_gpt* g, const ctts_gen_state* s, const floa
 static int decode_body(ctts_gpt* g, const ctts_gen_state* s, hipStream_t st, bool prof_ok) {
   const GptWs ws = carve(s->workspace, s->B, s->T);
   { Prof p(g, 0, st, prof_ok); const bool fast = g->w.weight_dtype == CTTS_BF16;
+    const bool packed = fast && g->dec_packed;
+    StepPrep sp{ws.desc, s->kv_start, g->skip_finished ? s->finish : nullptr, packed ? 1 : 0};
+    uint16_t* xb = fast ? (packed ? ws.xp : ws.xb) : nullptr;
     if (s->infer_text)
-      CK(launch_embed_text(g->w.emb_text, g->w.n_text, s->ids_buf, s->cap ? s->cap : s->T + s->max_new, s->len, ws.x, fast ? ws.xb : nullptr,
-                           fast ? ws.ssq : nullptr, s->B, s->row_map, s->n_active, st));
+      CK(launch_embed_text(g->w.emb_text, g->w.n_text, s->ids_buf, s->cap ? s->cap : s->T + s->max_new, s->len, ws.x, xb,
+                           fast ? ws.ssq : nullptr, s->B, s->row_map, s->n_active, st, &sp));
     else
-      CK(launch_embed_codes(g->w.emb_code, s->ids_buf, s->cap ? s->cap : s->T + s->max_new, s->len, ws.x, fast ? ws.xb : nullptr, fast ? ws.ssq : nullptr, s->B,
-                            s->row_map, s->n_active, st)); }
+      CK(launch_embed_codes(g->w.emb_code, s->ids_buf, s->cap ? s->cap : s->T + s->max_new, s->len, ws.x, xb, fast ? ws.ssq : nullptr, s->B,
+                            s->row_map, s->n_active, st, &sp)); }
   return run_step(g, s, 1, st, prof_ok);
 }
 
@@ -458,6 +505,17 @@ extern "C" int ctts_k_qkv_rope(const uint16_t* A, const uint16_t* W, int32_t M, 
   CK(launch_gemm_fast(f, (hipStream_t)stream));
   return 0;
 }
+extern "C" int ctts_k_gemm_dec(const uint16_t* Ap, const uint16_t* Wp, int32_t M, int32_t N, int32_t K, const int32_t* n_active,
+                               const float* ssq_in, float eps, int32_t epi, float* C32, int32_t ldc, uint16_t* Cp, int32_t kch_out,
+                               float* ssq_out, int32_t force_mb, void* stream) {
+  if (epi == FEPI_QKV_ROPE) return fail("ctts_k_gemm_dec: the fused QKV epilogue is reached through the decode step only");
+  DecGemmArgs d;
+  memset(&d, 0, sizeof(d));
+  d.Ap = Ap; d.Wp = Wp; d.M = M; d.N = N; d.K = K; d.n_active = n_active; d.ssq_in = ssq_in; d.eps = eps; d.epi = epi; d.C32 = C32;
+  d.ldc = ldc; d.Cp = Cp; d.kch_out = kch_out; d.ssq_out = ssq_out; d.force_mb = force_mb;
+  CK(launch_gemm_dec(d, (hipStream_t)stream));
+  return 0;
+}
 extern "C" int ctts_k_rows_prep(const float* x32, uint16_t* xb, float* ssq, int32_t M, void* stream) {
   CK(launch_rows_prep(x32, xb, ssq, M, (hipStream_t)stream));
   return 0;
@@ -465,13 +523,13 @@ extern "C" int ctts_k_rows_prep(const float* x32, uint16_t* xb, float* ssq, int3
 extern "C" int ctts_k_rope_append(float* qkv, void* kcache, void* vcache, int32_t kv_dtype, int32_t cmax, const float* cos_tab,
                                   const float* sin_tab, int32_t q_per_b, const int32_t* len, const int32_t* kv_start, int32_t M,
                                   void* stream) {
-  GptRowMap rm{q_per_b, len, kv_start, nullptr, nullptr, nullptr};
+  GptRowMap rm{q_per_b, len, kv_start, nullptr, nullptr, nullptr, nullptr};
   CK(launch_rope_append(qkv, kcache, vcache, kv_dtype, cmax, cos_tab, sin_tab, rm, M, (hipStream_t)stream));
   return 0;
 }
 extern "C" int ctts_k_attention(const float* qkv, const void* kcache, const void* vcache, int32_t kv_dtype, int32_t cmax, float* out,
                                 int32_t q_per_b, const int32_t* len, const int32_t* kv_start, int32_t M, void* stream) {
-  GptRowMap rm{q_per_b, len, kv_start, nullptr, nullptr, nullptr};
+  GptRowMap rm{q_per_b, len, kv_start, nullptr, nullptr, nullptr, nullptr};
   CK(launch_attention(qkv, kcache, vcache, kv_dtype, cmax, out, 0, rm, M, (hipStream_t)stream));
   return 0;
 }

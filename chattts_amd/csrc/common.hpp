@@ -93,3 +93,10 @@ __device__ __forceinline__ u128 load16_nt(const void* p) {
   return r;
 }
 __device__ __forceinline__ u128 load16(const void* p) { return *reinterpret_cast<const u128*>(p); }
+
+// Fragment-packed bf16 operand order of the decode projections (decode.hip): a [rows][C] matrix is stored as
+// [rows/16][C/32][lane = (c%32)/8 * 16 + row%16][c%8], i.e. every (16-row tile, 32-column chunk) is one contiguous KiB in
+// exactly the lane order v_mfma_f32_16x16x32_bf16 wants its A / B operand.  kch = C / 32.
+__device__ __forceinline__ size_t pk_off(int m, int c, int kch) {
+  return ((size_t)((m >> 4) * kch + (c >> 5)) * 64 + (((c & 31) >> 3) << 4) + (m & 15)) * 8 + (c & 7);
+}

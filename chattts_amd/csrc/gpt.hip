@@ -32,7 +32,7 @@ __device__ __forceinline__ void emit_row(float4 s, int t, float* __restrict__ x_
   if (xb_row) {
     ushort4 o;
     o.x = f32_to_bf16(s.x); o.y = f32_to_bf16(s.y); o.z = f32_to_bf16(s.z); o.w = f32_to_bf16(s.w);
-    *reinterpret_cast<ushort4*>(xb_row + t * 4) = o;
+    *reinterpret_cast<ushort4*>(xb_row + t * 4) = o;   // columns 4t..4t+3 share one 8-column group in either layout
   }
   if (ssq_row) {
     float q = (s.x * s.x + s.y * s.y) + (s.z * s.z + s.w * s.w);
@@ -42,14 +42,34 @@ __device__ __forceinline__ void emit_row(float4 s, int t, float* __restrict__ x_
   }
 }
 
+// The first kernel of a decode step also writes the step's row descriptors (kernels.hpp RowDesc): it walks
+// row_map -> len -> kv_start -> finish once, the 20 QKV epilogues and 20 attention launches behind it start from desc[m].
+__device__ __forceinline__ void write_desc(const StepPrep& sp, int m, int b, int slot) {
+  RowDesc d;
+  const int ks = sp.kv_start[b];
+  d.b = (sp.finish != nullptr && sp.finish[b]) ? -1 : b;
+  d.slot = slot;
+  d.pos = slot - ks < 0 ? 1 : slot - ks;   // pad slots get position 1 (gpt.py:234-241)
+  d.jlo = ks > slot ? slot : ks;
+  sp.desc[m] = d;
+}
+__device__ __forceinline__ uint16_t* xb_row_ptr(uint16_t* xb, int m, int t, int packed) {
+  // emit_row adds 4t itself: hand it a base such that base + 4t is where columns 4t..4t+3 of row m live
+  if (!xb) return nullptr;
+  return packed ? xb + pk_off(m, 4 * t, HID / 32) - 4 * t : xb + (size_t)m * HID;
+}
+
 __global__ __launch_bounds__(192) void embed_codes_k(const float* __restrict__ emb, const int64_t* __restrict__ ids_buf,
                                                      int tcap, const int32_t* __restrict__ len, float* __restrict__ x,
                                                      uint16_t* __restrict__ xb, float* __restrict__ ssq,
-                                                     const int32_t* __restrict__ row_map, const int32_t* __restrict__ n_active) {
+                                                     const int32_t* __restrict__ row_map, const int32_t* __restrict__ n_active,
+                                                     StepPrep sp) {
   const int m = blockIdx.x, t = threadIdx.x;
   if (row_absent(n_active, m)) return;
   const int b = row_map ? row_map[m] : m;
-  const int64_t* tok = ids_buf + ((size_t)b * tcap + (len[b] - 1)) * NVQ;
+  const int slot = len[b] - 1;
+  if (sp.desc != nullptr && t == 0) write_desc(sp, m, b, slot);
+  const int64_t* tok = ids_buf + ((size_t)b * tcap + slot) * NVQ;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int k = 0; k < NVQ; ++k) {
@@ -58,12 +78,18 @@ __global__ __launch_bounds__(192) void embed_codes_k(const float* __restrict__ e
     const float4 v = *reinterpret_cast<const float4*>(emb + ((size_t)k * NAUDIO + id) * HID + t * 4);
     if (k == 0) s = v; else { s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
   }
-  emit_row(s, t, x + (size_t)m * HID, xb ? xb + (size_t)m * HID : nullptr, ssq ? ssq + (size_t)m * SSQ_PARTS : nullptr);
+  emit_row(s, t, x + (size_t)m * HID, xb_row_ptr(xb, m, t, sp.xb_packed), ssq ? ssq + (size_t)m * SSQ_PARTS : nullptr);
+}
+
+static StepPrep prep_or_none(const StepPrep* p) {
+  StepPrep sp{nullptr, nullptr, nullptr, 0};
+  if (p) sp = *p;
+  return sp;
 }
 
 hipError_t launch_embed_codes(const float* emb_code, const int64_t* ids_buf, int tcap, const int32_t* len, float* x, uint16_t* xb,
-                              float* ssq, int B, const int32_t* row_map, const int32_t* n_active, hipStream_t st) {
-  CTTS_LAUNCH(embed_codes_k, dim3(B), dim3(192), st, emb_code, ids_buf, tcap, len, x, xb, ssq, row_map, n_active);
+                              float* ssq, int B, const int32_t* row_map, const int32_t* n_active, hipStream_t st, const StepPrep* prep) {
+  CTTS_LAUNCH(embed_codes_k, dim3(B), dim3(192), st, emb_code, ids_buf, tcap, len, x, xb, ssq, row_map, n_active, prep_or_none(prep));
   return hipGetLastError();
 }
 
@@ -161,7 +187,7 @@ template <typename OT> __device__ __forceinline__ void store_out(OT* p, float v)
 template <> __device__ __forceinline__ void store_out<float>(float* p, float v) { *p = v; }
 template <> __device__ __forceinline__ void store_out<bf16_t>(bf16_t* p, float v) { *p = f32_to_bf16(v); }
 
-template <typename KT, int NW, typename OT>
+template <typename KT, int NW, typename OT, bool PKO = false>
 __global__ __launch_bounds__(64 * NW) void attention_k(const float* __restrict__ qkv, const KT* __restrict__ kc,
                                                        const KT* __restrict__ vc, int cmax, OT* __restrict__ out, GptRowMap rm) {
   constexpr int DPL = KTraits<KT>::DPL;
@@ -177,11 +203,17 @@ __global__ __launch_bounds__(64 * NW) void attention_k(const float* __restrict__
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int kg = lane / LPK, dl = lane % LPK;
   if (rm.q_per_b == 1 && row_absent(rm.n_active, m)) return;
-  int b, slot;
-  row_to_b_slot(rm, m, b, slot);
-  if (rm.finish != nullptr && rm.finish[b]) return;  // finished since the last compaction: nothing downstream is ever read
-  int jlo = rm.kv_start[b];
-  if (jlo > slot) jlo = slot;  // pad query row: sees only itself (its output is never consumed)
+  int b, slot, jlo;
+  if (rm.desc != nullptr) {   // decode: one 16-byte load instead of the row_map -> len -> kv_start / finish chain
+    const RowDesc d = rm.desc[m];
+    if (d.b < 0) return;      // finished since the last compaction: nothing downstream is ever read
+    b = d.b; slot = d.slot; jlo = d.jlo;
+  } else {
+    row_to_b_slot(rm, m, b, slot);
+    if (rm.finish != nullptr && rm.finish[b]) return;
+    jlo = rm.kv_start[b];
+    if (jlo > slot) jlo = slot;  // pad query row: sees only itself (its output is never consumed)
+  }
 
   float q[DPL];
   {
@@ -277,7 +309,7 @@ __global__ __launch_bounds__(64 * NW) void attention_k(const float* __restrict__
   if (NW == 1) {
     if (kg == 0) {
       const float inv = 1.0f / lrun;
-      OT* op = out + (size_t)m * HID + h * HDIM + dl * DPL;
+      OT* op = PKO ? out + pk_off(m, h * HDIM + dl * DPL, HID / 32) : out + (size_t)m * HID + h * HDIM + dl * DPL;
 #pragma unroll
       for (int e = 0; e < DPL; ++e) store_out<OT>(op + e, acc[e] * inv);
     }
@@ -300,7 +332,7 @@ __global__ __launch_bounds__(64 * NW) void attention_k(const float* __restrict__
       L += sm_l[w] * sc;
       o += sm_acc[w][tid] * sc;
     }
-    store_out<OT>(out + (size_t)m * HID + h * HDIM + tid, o / L);
+    store_out<OT>(PKO ? out + pk_off(m, h * HDIM + tid, HID / 32) : out + (size_t)m * HID + h * HDIM + tid, o / L);
   }
 }
 
@@ -310,6 +342,11 @@ hipError_t launch_attention(const float* qkv, const void* kcache, const void* vc
   const bool decode = rm.q_per_b == 1;
   static int nw8 = -1;  // CTTS_ATT_NW=8: 8 waves per (utterance, head) in decode (A/B knob)
   if (nw8 < 0) { const char* e = getenv("CTTS_ATT_NW"); nw8 = (e && atoi(e) == 8) ? 1 : 0; }
+  if (out_bf16 == 2) {   // decode, perf mode: bf16 output in the fragment-packed order the o_proj kernel of decode.hip reads
+    if (!decode || kv_wt != WT_BF16) return hipErrorInvalidValue;
+    CTTS_LAUNCH((attention_k<bf16_t, 4, bf16_t, true>), grid, dim3(256), st, qkv, (const bf16_t*)kcache, (const bf16_t*)vcache, cmax, (bf16_t*)out, rm);
+    return hipGetLastError();
+  }
   if (decode && nw8 && kv_wt == WT_BF16 && out_bf16) {
     CTTS_LAUNCH((attention_k<bf16_t, 8, bf16_t>), grid, dim3(512), st, qkv, (const bf16_t*)kcache, (const bf16_t*)vcache, cmax, (bf16_t*)out, rm);
     return hipGetLastError();
@@ -520,6 +557,7 @@ __global__ __launch_bounds__(256) void sample_k(SampleArgs a) {
   float wv; int wi;
   wave_argmax(bv, bi, wv, wi);
   if (force_eos) wi = a.eos;
+  if (a.teacher != nullptr && gen < a.teacher_stride) wi = (int)a.teacher[((size_t)b * a.teacher_stride + gen) * NVQ + k];
   if (lane == 0) {
     a.ids_buf[((size_t)b * a.tcap + len) * NVQ + k] = (int64_t)wi;
     tok_s[k] = wi;
@@ -548,19 +586,23 @@ hipError_t launch_sample(const SampleArgs& a, hipStream_t st) {
 __global__ __launch_bounds__(192) void embed_text_k(const float* __restrict__ emb_text, int n_text, const int64_t* __restrict__ ids_buf,
                                                     int tcap, const int32_t* __restrict__ len, float* __restrict__ x,
                                                     uint16_t* __restrict__ xb, float* __restrict__ ssq,
-                                                    const int32_t* __restrict__ row_map, const int32_t* __restrict__ n_active) {
+                                                    const int32_t* __restrict__ row_map, const int32_t* __restrict__ n_active,
+                                                    StepPrep sp) {
   const int m = blockIdx.x, t = threadIdx.x;
   if (row_absent(n_active, m)) return;
   const int b = row_map ? row_map[m] : m;
-  int id = (int)ids_buf[((size_t)b * tcap + (len[b] - 1)) * NVQ];  // slot 0 (gpt.py:407)
+  const int slot = len[b] - 1;
+  if (sp.desc != nullptr && t == 0) write_desc(sp, m, b, slot);
+  int id = (int)ids_buf[((size_t)b * tcap + slot) * NVQ];  // slot 0 (gpt.py:407)
   id = min(max(id, 0), n_text - 1);
   const float4 s = *reinterpret_cast<const float4*>(emb_text + (size_t)id * HID + t * 4);
-  emit_row(s, t, x + (size_t)m * HID, xb ? xb + (size_t)m * HID : nullptr, ssq ? ssq + (size_t)m * SSQ_PARTS : nullptr);
+  emit_row(s, t, x + (size_t)m * HID, xb_row_ptr(xb, m, t, sp.xb_packed), ssq ? ssq + (size_t)m * SSQ_PARTS : nullptr);
 }
 
 hipError_t launch_embed_text(const float* emb_text, int n_text, const int64_t* ids_buf, int tcap, const int32_t* len, float* x,
-                             uint16_t* xb, float* ssq, int B, const int32_t* row_map, const int32_t* n_active, hipStream_t st) {
-  CTTS_LAUNCH(embed_text_k, dim3(B), dim3(192), st, emb_text, n_text, ids_buf, tcap, len, x, xb, ssq, row_map, n_active);
+                             uint16_t* xb, float* ssq, int B, const int32_t* row_map, const int32_t* n_active, hipStream_t st,
+                             const StepPrep* prep) {
+  CTTS_LAUNCH(embed_text_k, dim3(B), dim3(192), st, emb_text, n_text, ids_buf, tcap, len, x, xb, ssq, row_map, n_active, prep_or_none(prep));
   return hipGetLastError();
 }
 

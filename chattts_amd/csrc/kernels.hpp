@@ -95,6 +95,35 @@ hipError_t launch_rows_prep(const float* x32, uint16_t* xb, float* ssq, int M, h
 hipError_t launch_gemm_tiled(const GemmArgs& a, hipStream_t st);   // 64x64 LDS-tiled f32 MFMA, large M
 hipError_t launch_gemm_tiled_bf16x3(const GemmArgs& a, hipStream_t st);  // 128x128 split-bf16 (3 MFMA / product), W = [N][Kp/32][2][32] bf16
 
+// ---- decode-step projections on fragment-packed operands (decode.hip) --------------------------
+// Compact decode row m -> everything the layer kernels need about it, written ONCE per step by the embedding kernel
+// (which walks row_map -> len -> kv_start anyway), so that the QKV epilogue and the attention kernel of each of the 20
+// layers start from one 16-byte load instead of a 3-hop dependent chain.
+struct alignas(16) RowDesc {
+  int32_t b;     // utterance (batch slot), or -1: already finished (sampled EOS) -- nothing downstream is ever read
+  int32_t slot;  // KV slot of this step's token = len[b] - 1
+  int32_t pos;   // RoPE position = slot - kv_start[b]
+  int32_t jlo;   // first visible key = kv_start[b]
+};
+struct DecGemmArgs {
+  const uint16_t* Ap;           // activations, packed [ceil(M/16)][K/32][64][8] bf16
+  const uint16_t* Wp;           // weights, packed [N/16 (SILU: gate tiles then up tiles)][K/32][64][8] bf16
+  int M, N, K;                  // M = rows the buffers hold (utterances); live rows = *n_active
+  const int32_t* n_active;      // device scalar or null (M)
+  const float* ssq_in;          // [M,48] or null (no row scale)
+  float eps;
+  int epi;                      // FastEpi
+  float* C32; int ldc;          // QKV_ROPE: f32 qkv buffer; RES: f32 residual, updated in place
+  uint16_t* Cp; int kch_out;    // packed bf16 output (RES: new residual, SILU: activation) with kch_out = columns / 32
+  float* ssq_out;               // RES: [M,48]
+  const RowDesc* desc;          // QKV_ROPE
+  const float* cos_t; const float* sin_t;
+  uint16_t* kc; uint16_t* vc; int cmax;
+  int force_mb;                 // tests only
+  int w_nt;                     // set by the launcher
+};
+hipError_t launch_gemm_dec(const DecGemmArgs& a, hipStream_t st);
+
 // ---- GPT step kernels -------------------------------------------------------------------------
 struct GptRowMap {
   // query row m of a launch maps to (b, slot): prefill (q_per_b = T): b = m / T, slot = m % T;
@@ -111,15 +140,25 @@ struct GptRowMap {
   const uint8_t* finish;    // [B] or null (decode): rows that already sampled EOS.  The reference keeps stepping them
                             // until every row is done (gpt.py:512-518,592) but truncates their output at end_idx, so
                             // their per-step work is unobservable: the attention kernel skips their KV read.
+  const RowDesc* desc;      // decode, optional: this step's row descriptors (replaces the row_map/len/kv_start/finish chain)
 };
 
+// what the first kernel of a decode step additionally produces: the row descriptors, and (xb_packed) the bf16 copy of
+// the embedding in the fragment-packed order of decode.hip instead of row-major
+struct StepPrep {
+  RowDesc* desc;            // [B] out, or null
+  const int32_t* kv_start;  // [slots]
+  const uint8_t* finish;    // [slots] or null
+  int xb_packed;
+};
 hipError_t launch_embed_codes(const float* emb_code /*[4,626,768]*/, const int64_t* ids_buf, int ids_row_stride /*Tcap*/,
                               const int32_t* len, float* x, uint16_t* xb /*null ok*/, float* ssq /*null ok*/, int B,
-                              const int32_t* row_map, const int32_t* n_active, hipStream_t st);
+                              const int32_t* row_map, const int32_t* n_active, hipStream_t st, const StepPrep* prep = nullptr);
 hipError_t launch_rope_append(float* qkv /*[M,2304]*/, void* kcache, void* vcache, int kv_wt, int cmax,
                               const float* cos_tab, const float* sin_tab /*[max_pos,32]*/, GptRowMap rm, int M, hipStream_t st);
 hipError_t launch_attention(const float* qkv, const void* kcache, const void* vcache, int kv_wt, int cmax,
-                            void* out /*[M,768] f32, or bf16 when out_bf16*/, int out_bf16, GptRowMap rm, int M, hipStream_t st);
+                            void* out /*[M,768] f32, or bf16 when out_bf16 (2: bf16 in the packed order of decode.hip)*/, int out_bf16,
+                            GptRowMap rm, int M, hipStream_t st);
 hipError_t launch_final_norm(const float* x, int q_per_b, const float* w, float eps, float* hfin /*[B,768]*/,
                              float* hiddens /*[slots,max_new,768]*/, int max_new, const int32_t* len, int T, int B,
                              const int32_t* row_map, const int32_t* n_active, const int32_t* prompt_len, hipStream_t st);
@@ -147,12 +186,15 @@ struct SampleArgs {
   const int32_t* n_active;  // decode: device scalar; null = B
   const int32_t* prompt_len;  // [slots] per-utterance prompt length, or null (T for all)
   int q_rows;               // utterance slots in q (>= B)
+  const int64_t* teacher;   // [slots, teacher_stride, 4] or null: teacher forcing (evaluation hook)
+  int teacher_stride;
 };
 hipError_t launch_sample(const SampleArgs& a, hipStream_t st);
 // refine-text mode: logits [B, V], q [nq, B, V], temperature[0]; no repetition penalty (see gpt.hip)
 hipError_t launch_sample_text(const SampleArgs& a, int V, hipStream_t st);
 hipError_t launch_embed_text(const float* emb_text, int n_text, const int64_t* ids_buf, int tcap, const int32_t* len, float* x,
-                             uint16_t* xb, float* ssq, int B, const int32_t* row_map, const int32_t* n_active, hipStream_t st);
+                             uint16_t* xb, float* ssq, int B, const int32_t* row_map, const int32_t* n_active, hipStream_t st,
+                             const StepPrep* prep = nullptr);
 
 // ---- codec kernels (channels-last [B, F, C]) ---------------------------------------------------
 hipError_t launch_dwconv_ln(const float* x, const float* w /*[C,7]*/, const float* b, const float* ln_w, const float* ln_b,

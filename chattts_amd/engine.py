@@ -158,6 +158,21 @@ def rope_row_perm() -> torch.Tensor:
     return torch.tensor(idx, dtype=torch.long)
 
 
+def pack_frag(w: torch.Tensor) -> torch.Tensor:
+    """[R, C] (R % 16 == 0, C % 32 == 0) -> the fragment-packed order of csrc/decode.hip,
+    [R/16][C/32][lane = (c%32)/8 * 16 + r%16][c%8]: every (16-row tile, 32-column chunk) becomes one contiguous KiB (bf16)
+    in exactly the lane order v_mfma_f32_16x16x32_bf16 reads its operand, so a wave's fragment load is ONE coalesced KiB
+    instead of 64 scattered 16-byte pieces."""
+    R, Cc = w.shape
+    assert R % 16 == 0 and Cc % 32 == 0
+    return w.reshape(R // 16, 16, Cc // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous()
+
+
+def unpack_frag(p: torch.Tensor, R: int, Cc: int) -> torch.Tensor:
+    """inverse of pack_frag (tests / debugging)"""
+    return p.reshape(R // 16, Cc // 32, 4, 16, 8).permute(0, 3, 1, 2, 4).reshape(R, Cc).contiguous()
+
+
 def rope_tables(max_pos: int, head_dim: int = GPT.head_dim, theta: float = GPT.rope_theta):
     """cos/sin [max_pos, head_dim/2] float32, evaluated with the same torch f32 ops HF's
     LlamaRotaryEmbedding uses (inv_freq = 1/theta^(arange(0,d,2)/d); freqs = pos * inv_freq)."""
@@ -217,6 +232,10 @@ class GptEngine:
         cos, sin = rope_tables(max_pos)
         self.rope_cos, self.rope_sin = cos.to(dev), sin.to(dev)
         self._arrs = [_lib.ptr_array(x) for x in (self.wqkv, self.wo, self.wgu, self.wd, self.ln1, self.ln2)]
+        # perf mode: a second copy of the four matrices in the fragment-packed order the DECODE kernels read (decode.hip);
+        # the row-major copy stays for the LDS-tiled prefill kernels (+0.38 GB of the 288 GB)
+        self.packed = [[pack_frag(t) for t in ws] for ws in (self.wqkv, self.wo, self.wgu, self.wd)] if dtype == "bf16" else None
+        self._pk_arrs = None if self.packed is None else [_lib.ptr_array(x) for x in self.packed]
         w = _lib.GptWeights()
         w.n_layers, w.weight_dtype, w.kv_dtype, w.max_pos = self.n_layers, self.code, self.code, max_pos
         w.wqkv, w.wo, w.wgu, w.wd, w.ln1, w.ln2 = [C.cast(a, _lib.PP) for a in self._arrs]
@@ -224,6 +243,8 @@ class GptEngine:
         w.rope_cos, w.rope_sin = self.rope_cos.data_ptr(), self.rope_sin.data_ptr()
         w.rms_eps = GPT.rms_eps
         w.emb_text, w.head_text, w.n_text = self.emb_text.data_ptr(), self.head_text.data_ptr(), GPT.n_text
+        if self._pk_arrs is not None:
+            w.wqkv_pk, w.wo_pk, w.wgu_pk, w.wd_pk = [C.cast(a, _lib.PP) for a in self._pk_arrs]
         self._w = w
         h = C.c_void_p()
         _lib.check(self.lib.ctts_gpt_create(C.byref(h), C.byref(w)), "ctts_gpt_create")
@@ -277,14 +298,17 @@ class GptEngine:
                  stream_batch: int = 24, manual_seed: Optional[int] = None, context: Optional[Context] = None,
                  *, use_graph: bool = True, stop_at: Optional[torch.Tensor] = None, row_offset: int = 0,
                  total_rows: Optional[int] = None, profile_tag: Optional[int] = None,
-                 profile_stride: int = 1, lanes: Optional[int] = None) -> Iterator[GenerationOutputs]:
+                 profile_stride: int = 1, lanes: Optional[int] = None,
+                 teacher_ids: Optional[torch.Tensor] = None) -> Iterator[GenerationOutputs]:
         """Drop-in for `GPT.generate` (gpt.py:316-337), code mode.  Extra keyword-only arguments:
         `use_graph` (hipGraph replay of the decode step), `stop_at` ([B] int32 forced output lengths,
         benchmark hook), `row_offset`/`total_rows` (this shard's position inside a data-parallel batch:
         keeps the CPU draw and the rows>=625 penalty quirk keyed on the global row index), `lanes`
         (the batch is cut into that many contiguous row groups, each decoding on its own HIP stream
         with its own captured graph; utterances never interact, so the result is identical, while the
-        per-kernel launch / dependent-load latency of one lane overlaps the others' kernels)."""
+        per-kernel launch / dependent-load latency of one lane overlaps the others' kernels), `teacher_ids`
+        ([B, max_new_token, 4] int64: teacher forcing -- the token written at step i is teacher_ids[:, i] instead of
+        the sampled one; evaluation hook used to bound the bf16 mode's drift on the reference's token stream)."""
         if return_attn:
             raise NotImplementedError("return_attn is not supported by the fused attention kernel")
         context = context or Context()
@@ -337,7 +361,7 @@ class GptEngine:
         top_p_thr = float(np.float32(1.0 - plan.top_p)) if plan.top_p is not None else 0.0
         key = (tuple(bounds), T, max_new, nrow, V, nq, self.dtype, top_p_thr, plan.top_p is not None, int(plan.top_k or 0),
                plan.top_k is not None, int(min_new_token), int(eos_token), int(row_offset), bool(infer_text), stop_at is not None,
-               ptab is not None)
+               ptab is not None, teacher_ids is not None)
         sess = self._session if (self._session is not None and self._session["key"] == key) else None
         if sess is None:
             self._session = None     # drop the previous session's buffers before allocating new ones
@@ -363,6 +387,7 @@ class GptEngine:
                     ln.kv_start = torch.empty((Bl,), dtype=kv_start_all.dtype, device=dev)
                     ln.stop_d = None if stop_at is None else torch.empty((Bl,), dtype=torch.int32, device=dev)
                     ln.q_d = torch.empty((nq, Bl * nrow, V), dtype=torch.float32, device=dev)
+                    ln.teacher = None if teacher_ids is None else torch.empty((Bl, max_new, nvq), dtype=torch.int64, device=dev)
                 s = _lib.GenState()
                 s.B, s.T, s.max_new = Bl, T, max_new
                 s.ids_buf, s.len, s.kv_start = ln.ids_buf.data_ptr(), ln.len_d.data_ptr(), ln.kv_start.data_ptr()
@@ -378,6 +403,7 @@ class GptEngine:
                 s.row_offset = int(row_offset + lo * nrow)
                 s.infer_text = int(infer_text)
                 s.stop_at = _lib.ptr(ln.stop_d)
+                s.teacher_ids = _lib.ptr(ln.teacher)
                 s.workspace, s.workspace_bytes = ln.workspace.data_ptr(), ln.ws_bytes
                 s.row_map, s.n_active = ln.row_map.data_ptr(), ln.n_active.data_ptr()
                 ln.s = s
@@ -402,6 +428,9 @@ class GptEngine:
                 ln.kv_start.copy_(kv_start_all[lo:hi])
                 if ln.stop_d is not None:
                     ln.stop_d.copy_(stop_at[lo:hi].to(torch.int32))
+                if ln.teacher is not None:
+                    assert tuple(teacher_ids.shape) == (B, max_new, nvq)
+                    ln.teacher.copy_(teacher_ids[lo:hi].to(torch.int64))
                 ln.emb = emb_all[lo:hi].contiguous()
                 if draws.constant and sess["q_sig"] != q_sig:
                     ln.q_d[0].copy_(draws.step(0)[lo * nrow: hi * nrow])

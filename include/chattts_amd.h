@@ -62,6 +62,13 @@ typedef struct {
   const float* emb_text;           /* [n_text,768] */
   const float* head_text;          /* [n_text,768] folded weight-norm text head */
   int32_t n_text;                  /* 21178 */
+  /* perf mode, optional (NULL: the decode step uses the row-major kernels): the same four matrices per layer in the
+   * fragment-packed order of csrc/decode.hip -- [rows/16][K/32][lane = (k%32)/8*16 + row%16][k%8] bf16, one contiguous KiB per
+   * (16-row tile, 32-wide k chunk); wqkv with the RoPE row permutation and the folded RMSNorm gain like `wqkv` */
+  const void* const* wqkv_pk;
+  const void* const* wo_pk;
+  const void* const* wgu_pk;
+  const void* const* wd_pk;
 } ctts_gpt_weights;
 
 /* One generate() call's device state (every array is caller-allocated, device memory). */
@@ -105,6 +112,10 @@ typedef struct {
   int32_t infer_text;              /* 1: refine-text mode -- text embedding/head, ONE sampling row per utterance (q is
                                       [nq, B, n_text], temperature[0]), the sampled id is written to all 4 slots
                                       (gpt.py:519-525); repetition penalty must be off */
+  const int64_t* teacher_ids;      /* [slots, max_new, 4] or NULL: teacher forcing (evaluation hook, not a reference feature) -- the
+                                      token WRITTEN at generation step i of utterance b is teacher_ids[b, i, :] instead of the
+                                      sampled one; everything else (finish on EOS, lengths, hidden capture) is unchanged.  Used
+                                      to bound the bf16 mode's drift against the reference's golden token stream. */
 } ctts_gen_state;
 
 int ctts_gpt_create(ctts_gpt** out, const ctts_gpt_weights* w);
@@ -243,6 +254,12 @@ int ctts_k_gemm_fast(const uint16_t* A, int32_t lda, const uint16_t* W, int32_t 
 int ctts_k_qkv_rope(const uint16_t* A, const uint16_t* W, int32_t M, const float* ssq_in, float eps, float* qkv, uint16_t* kcache,
                     uint16_t* vcache, int32_t cmax, const float* cos_tab, const float* sin_tab, int32_t q_per_b, const int32_t* len,
                     const int32_t* kv_start, int32_t force_mb, void* stream);
+/* decode-step projection on fragment-packed operands (csrc/decode.hip): Ap [ceil(M/16)][K/32][64][8] bf16, Wp packed likewise
+ * (epi 2: gate tiles then up tiles); epi 1 = residual add (C32 in place, Cp packed bf16 copy with kch_out = N/32, ssq_out),
+ * 2 = SiLU(gate)*up -> Cp packed (kch_out = N/32).  n_active: device scalar or NULL.  force_mb: rows/16 per workgroup (0 = default) */
+int ctts_k_gemm_dec(const uint16_t* Ap, const uint16_t* Wp, int32_t M, int32_t N, int32_t K, const int32_t* n_active, const float* ssq_in,
+                    float eps, int32_t epi, float* C32, int32_t ldc, uint16_t* Cp, int32_t kch_out, float* ssq_out, int32_t force_mb,
+                    void* stream);
 int ctts_k_rows_prep(const float* x32, uint16_t* xb, float* ssq, int32_t M, void* stream);
 int ctts_k_rope_append(float* qkv, void* kcache, void* vcache, int32_t kv_dtype, int32_t cmax, const float* cos_tab, const float* sin_tab,
                        int32_t q_per_b, const int32_t* len, const int32_t* kv_start, int32_t M, void* stream);

@@ -60,6 +60,19 @@ GEN_CASES = {
 }
 
 
+# ---- BASELINE-size cases (tests/golden/generate_big.npz): the widths / lengths BASELINE.json's configs name --------
+BIG_CASES = {
+    # C3 at full width: 64 utterances, the bench's own mixed-length left-padded prompts (synth seed 0, 16..48 tokens),
+    # default sampling; rows hit EOS naturally at different steps after min_new (compaction across 64 rows, the
+    # M = 64 projection tiles, 4-row groups up to global sampling row 255)
+    "c3w": dict(B=64, t_min=16, t_max=48, pseed=0, temperature=[0.3] * 4, top_P=0.7, top_K=20, rep=1.05,
+                max_new=40, min_new=6, manual_seed=42, keep_hidden_rows=[0, 37, 63], keep_logit_steps=[0, 39]),
+    # C2: batch 1, 512 speech tokens (context up to 544 keys), nothing may flip over 512 autoregressive steps
+    "c2": dict(B=1, t_min=32, t_max=32, pseed=7, temperature=[0.3] * 4, top_P=0.7, top_K=20, rep=1.05,
+               max_new=512, min_new=512, manual_seed=42, keep_hidden_rows=[0], keep_logit_steps=[0, 511]),
+}
+
+
 # refine-text mode (core.py:665-751 defaults: temperature 0.7, top_P 0.7, top_K 20, repetition_penalty 1.0)
 TEXT_EOS = 21000  # stands in for tokenizer.eos_token ([Ebreak]); any id works with synthetic weights
 TEXT_CASES = {

@@ -45,10 +45,10 @@ def golden_sampling():
     print("sampling.npz", {k: v.shape for k, v in out.items()})
 
 
-def golden_generate(sds):
+def golden_generate(sds, which=None, fname="generate.npz"):
     embed, gpt = ref_harness.build_gpt(sds)
     out = {}
-    for name, c in cases.GEN_CASES.items():
+    for name, c in (which or cases.GEN_CASES).items():
         t0 = time.time()
         ids, mask, tmask = cases.gen_inputs(c)
         if c["manual_seed"] is None:
@@ -68,7 +68,7 @@ def golden_generate(sds):
             if s < len(cap):
                 out[name + f".tlogits{s}"] = cap[s]  # logits / temperature at step s, [B*4, 626]
         print(name, "steps", len(cap), "lens", out[name + ".lens"].tolist(), f"{time.time() - t0:.1f}s")
-    np.savez_compressed(os.path.join(OUT, "generate.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, fname), **out)
 
 
 def golden_text(sds):
@@ -120,6 +120,8 @@ def main():
         golden_sampling()
     if "generate" in which:
         golden_generate(sds)
+    if "big" in which:   # BASELINE-size cases (C3 at B = 64, C2 at 512 steps): separate file, ~2 min of reference CPU time
+        golden_generate(sds, cases.BIG_CASES, "generate_big.npz")
     if "codec" in which:
         golden_codec(sds)
     if "text" in which:

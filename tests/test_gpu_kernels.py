@@ -117,6 +117,67 @@ def test_gemm_fast_bf16(G, M):
 
 
 @pytest.mark.parametrize("force_mb", [0, 1, 2, 4])
+@pytest.mark.parametrize("M,n_act", [(1, None), (9, None), (16, 16), (40, 33), (64, None), (64, 45), (100, 70), (130, None)])
+def test_gemm_dec_packed(G, M, n_act, force_mb):
+    """decode projections on fragment-packed operands (csrc/decode.hip): SiLU and residual epilogues, both K, partial row
+    tiles, the live-row count read from the device (rows >= n_active are neither computed nor written)"""
+    from chattts_amd.engine import pack_frag, unpack_frag
+    lib = _lib.lib()
+    rs = np.random.RandomState(M * 7 + (n_act or 0))
+    Mp = (M + 15) // 16 * 16
+    live = M if n_act is None else n_act
+    na_d = None if n_act is None else G.dev(np.array([n_act], np.int32))
+    x32 = (rs.standard_normal((M, 768)) * 2).astype(f32)
+    xbr = G.bf16_round(x32)
+    xpad = np.zeros((Mp, 768), f32)
+    xpad[:M] = xbr
+    xp = pack_frag(torch.from_numpy(xpad).to(torch.bfloat16)).to(G.DEV)
+    ssq_np = (x32.astype(np.float64) ** 2).reshape(M, 48, 16).sum(2).astype(f32)
+    ssq = G.dev(ssq_np)
+    rstd = 1.0 / np.sqrt((x32.astype(np.float64) ** 2).mean(1, keepdims=True) + 1e-6)
+    # epi 2: silu(g) * u -> packed bf16 [Mp][3072]
+    Wgu = G.bf16_round((rs.standard_normal((2 * 3072, 768)) * 0.03).astype(f32))
+    Wgu_p = pack_frag(torch.from_numpy(Wgu).to(torch.bfloat16)).to(G.DEV)
+    actp = torch.full((Mp * 3072,), float("nan"), dtype=torch.bfloat16, device=G.DEV)
+    _lib.check(lib.ctts_k_gemm_dec(xp.data_ptr(), Wgu_p.data_ptr(), M, 3072, 768, _lib.ptr(na_d), ssq.data_ptr(), 1e-6, 2, None, 0,
+                                   actp.data_ptr(), 96, None, force_mb, None), "dec silu")
+    torch.cuda.synchronize()
+    gu = (xbr.astype(np.float64) @ Wgu.astype(np.float64).T) * rstd
+    g_, u_ = gu[:, :3072], gu[:, 3072:]
+    refa = g_ / (1 + np.exp(-g_)) * u_
+    act = unpack_frag(actp.float().cpu(), Mp, 3072).numpy()
+    assert G.relerr(act[:live], refa[:live]) < 1e-2  # bf16 output rounding
+    assert np.isnan(act[live:M]).all()                # rows beyond the live count are not written
+    # epi 1, K = 3072 (down_proj): residual update in place + packed bf16 copy + partial sums of squares
+    actc = np.where(np.isnan(act), 0, act).astype(f32)
+    actp2 = pack_frag(torch.from_numpy(actc).to(torch.bfloat16)).to(G.DEV)
+    Wd = G.bf16_round((rs.standard_normal((768, 3072)) * 0.02).astype(f32))
+    Wd_p = pack_frag(torch.from_numpy(Wd).to(torch.bfloat16)).to(G.DEV)
+    res = G.dev(x32).clone()
+    xp2 = torch.full((Mp * 768,), float("nan"), dtype=torch.bfloat16, device=G.DEV)
+    ssq2 = torch.full((M, 48), float("nan"), dtype=torch.float32, device=G.DEV)
+    _lib.check(lib.ctts_k_gemm_dec(actp2.data_ptr(), Wd_p.data_ptr(), M, 768, 3072, _lib.ptr(na_d), None, 0.0, 1, res.data_ptr(), 768,
+                                   xp2.data_ptr(), 24, ssq2.data_ptr(), force_mb, None), "dec down")
+    torch.cuda.synchronize()
+    refx = x32 + actc[:M].astype(np.float64) @ Wd.astype(np.float64).T
+    got = res.cpu().numpy()
+    assert G.relerr(got[:live], refx[:live]) < 2e-5
+    assert np.array_equal(got[live:], x32[live:])
+    xb2 = unpack_frag(xp2.float().cpu(), Mp, 768).numpy()
+    assert np.array_equal(xb2[:live], G.bf16_round(got[:live])) and np.isnan(xb2[live:M]).all()
+    assert np.abs(ssq2.cpu().numpy()[:live].sum(1) - (got[:live].astype(np.float64) ** 2).sum(1)).max() < 1e-2
+    # epi 1, K = 768 (o_proj)
+    Wo = G.bf16_round((rs.standard_normal((768, 768)) * 0.03).astype(f32))
+    Wo_p = pack_frag(torch.from_numpy(Wo).to(torch.bfloat16)).to(G.DEV)
+    res = G.dev(x32).clone()
+    _lib.check(lib.ctts_k_gemm_dec(xp.data_ptr(), Wo_p.data_ptr(), M, 768, 768, _lib.ptr(na_d), None, 0.0, 1, res.data_ptr(), 768,
+                                   xp2.data_ptr(), 24, ssq2.data_ptr(), force_mb, None), "dec o")
+    torch.cuda.synchronize()
+    refo = x32 + xbr.astype(np.float64) @ Wo.astype(np.float64).T
+    assert G.relerr(res.cpu().numpy()[:live], refo[:live]) < 2e-5
+
+
+@pytest.mark.parametrize("force_mb", [0, 1, 2, 4])
 @pytest.mark.parametrize("decode", [False, True, "tiled", "tiled128"])
 def test_qkv_rope_fused(G, force_mb, decode):
     """perf-mode fused RMSNorm-scale + QKV + RoPE + KV append vs numpy (natural weight order); "tiled": a prompt-sized
@@ -235,6 +296,41 @@ def test_gemm_tiled_linear(G, M, N, K, epi, tiled):
     acc = A.astype(np.float64) @ W.astype(np.float64).T
     ref = {0: acc, 3: acc + bias, 4: codec_np.gelu((acc + bias).astype(f32)), 5: res + gam * (acc + bias), 6: acc * gam}[epi]
     assert G.relerr(got, ref) < (1e-5 if tiled == 1 else 3e-5), G.relerr(got, ref)
+
+
+# the 256x256 split-bf16 tile with two LDS buffers is what the acoustic decoder of a BASELINE-size batch runs (selected from
+# M >= 12288 rows, gemm.hip launch_gemm_tiled_bf16x3): every layer shape of DVAE / Vocos at that size, vs float64
+@pytest.mark.parametrize("M", [12288, 16400])
+@pytest.mark.parametrize("N,K,epi", [(2048, 512, 4), (512, 2048, 5), (1536, 512, 4), (512, 1536, 5), (1026, 512, 3)])
+def test_gemm_tiled_bf16x3_big_tile_linear(G, M, N, K, epi):
+    rs = np.random.RandomState(M + N + K)
+    A = rs.standard_normal((M, K)).astype(f32)
+    W = (rs.standard_normal((N, K)) / np.sqrt(K)).astype(f32)
+    bias = rs.standard_normal(N).astype(f32) * 0.1
+    gam = (0.05 + 0.1 * rs.rand(N)).astype(f32)
+    res = rs.standard_normal((M, N)).astype(f32)
+    got = G.gemm(A, W, tiled=2, epi=epi, bias=bias, gamma=gam, res=res)
+    acc = A.astype(np.float64) @ W.astype(np.float64).T
+    ref = {3: acc + bias, 4: codec_np.gelu((acc + bias).astype(f32)), 5: res + gam * (acc + bias)}[epi]
+    assert np.isfinite(got).all()
+    assert G.relerr(got, ref) < 3e-5, G.relerr(got, ref)
+
+
+def test_gemm_tiled_bf16x3_big_tile_conv(G):
+    """conv-as-GEMM gather (taps 3, zero padding at both utterance ends) on the two-buffer 256x256 tile: conv_in.2 of the
+    DVAE decoder at 4 x 3100 frames (M = 12400 >= 12288)"""
+    B, F, cin, cout, taps, pad = 4, 3100, 128, 512, 3, 1
+    rs = np.random.RandomState(17)
+    X = rs.standard_normal((B * F, cin)).astype(f32)
+    Wt = (rs.standard_normal((cout, cin, taps)) / np.sqrt(cin * taps)).astype(f32)
+    Wp = np.ascontiguousarray(Wt.transpose(0, 2, 1)).reshape(cout, taps * cin)
+    bias = rs.standard_normal(cout).astype(f32) * 0.1
+    got = G.gemm(X, Wp, tiled=2, epi=3, bias=bias, taps=taps, cin=cin, frames=F, pad=pad)
+    x = X.reshape(B, F, cin).astype(np.float64)
+    xp = np.zeros((B, F + 2 * pad, cin))
+    xp[:, pad: pad + F] = x
+    ref = sum(xp[:, j: j + F] @ Wt[:, :, j].astype(np.float64).T for j in range(taps)).reshape(B * F, cout) + bias
+    assert G.relerr(got, ref) < 3e-5, G.relerr(got, ref)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -63,6 +63,37 @@ def test_generate(golden, np_model, name):
             assert np.abs(got - G[key]).max() < 2e-3, s
 
 
+@pytest.mark.parametrize("name,k", [("c3w", 9), ("c2", 40)])
+def test_generate_baseline_sizes_prefix(golden, np_model, name, k):
+    """BASELINE-size goldens (generate_big.npz: C3 at B = 64, C2 at 512 steps): the oracle reproduces their first k
+    steps bit-exactly (generation is causal, so a k-step run equals the k-step prefix; the full runs take minutes of
+    numpy time and are checked on the GPU side, tests/test_gpu_e2e.py)."""
+    llama, esd, heads = np_model
+    c = cases.BIG_CASES[name]
+    G = golden["generate_big"]
+    ids, mask, tmask = cases.gen_inputs(c)
+    emb = generate_np.embed_prompt(esd, ids, tmask)
+    assert np.array_equal(emb[0], G[name + ".emb_row0"])
+    B = ids.shape[0]
+    draws = rng.ExpDraws(B * 4, 626, c["manual_seed"])
+    res = generate_np.generate(
+        llama, esd, heads, emb, ids, mask, temperature=np.array(c["temperature"], np.float32),
+        draw_q=lambda i: draws.step(i).numpy(), top_p=c["top_P"], top_k=c["top_K"],
+        pow_table=rng.penalty_table(c["rep"]).numpy(), max_new_token=k, min_new_token=min(c["min_new"], k), keep_logits=True)
+    lens = G[name + ".lens"]
+    off = np.concatenate([[0], np.cumsum(lens)])
+    for b in range(B):
+        want = G[name + ".ids"][off[b]: off[b + 1]][:k]
+        assert np.array_equal(res.ids[b][: len(want)], want), b
+        assert len(res.ids[b]) == min(lens[b], k), (b, len(res.ids[b]), lens[b])
+    key = name + ".tlogits0"
+    got = res.logits[0] / np.tile(np.array(c["temperature"], np.float32), B)[:, None]
+    assert np.abs(got - G[key]).max() < 2e-3
+    for b in c["keep_hidden_rows"]:
+        n = min(k, lens[b])
+        assert np.abs(res.hiddens[b][:n] - G[name + f".hid{b}"][:n]).max() < 2e-4
+
+
 @pytest.mark.parametrize("name", list(cases.TEXT_CASES))
 def test_generate_refine_text_mode(golden, np_model, name):
     """infer_text=True (refine-text): text head, one row per utterance, ids replicated over the 4 slots"""
