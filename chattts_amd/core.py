@@ -83,12 +83,14 @@ class Chat:
         """core.py:50-66: the decoder path needs `Decoder.safetensors`, the `use_decoder=False` path the full DVAE"""
         return self.gpt is not None and self.codec is not None and (use_decoder or self.dvae is not None)
 
-    def load(self, custom_path: Optional[str] = None, device: Optional[torch.device] = None, dtype: str = "bf16",
-             state_dicts: Optional[dict] = None, tokenizer: Union[None, str, Tokenizer] = None, spk_stat: Optional[str] = None,
-             source: str = "custom", force_redownload: bool = False, compile: bool = False, coef=None,
-             use_flash_attn: bool = False, use_vllm: bool = False, experimental: bool = False) -> bool:
-        """`Chat.load` (core.py:137-163) for `source="custom"` / `"local"` (assets already on disk; there is no
-        network path here): the four hot-path safetensors files of `custom_path` and `asset/tokenizer`.
+    def load(self, source: str = "local", force_redownload: bool = False, compile: bool = False, custom_path: Optional[str] = None,
+             device: Optional[torch.device] = None, coef=None, use_flash_attn: bool = False, use_vllm: bool = False,
+             experimental: bool = False, *, dtype: str = "bf16", state_dicts: Optional[dict] = None,
+             tokenizer: Union[None, str, Tokenizer] = None, spk_stat: Optional[str] = None) -> bool:
+        """`Chat.load` with the reference's positional parameters and defaults (core.py:137-148), for `source="local"` /
+        `"custom"` (assets already on disk; there is no network path here, `"huggingface"` returns False): the four
+        hot-path safetensors files under `custom_path` (default: the working directory, like the reference's "local"
+        source) and `asset/tokenizer`.  Keyword-only extras of this engine: `dtype` ("bf16" perf mode | "f32" parity mode),
         `state_dicts` short-circuits disk I/O (synthetic weights); `tokenizer` is a directory or a `Tokenizer`;
         `spk_stat` is the reference's `Config.spk_stat` string (needed by `sample_random_speaker` only).
         `compile`, `use_flash_attn`, `use_vllm`, `experimental` select between the reference's torch back ends and

@@ -57,6 +57,7 @@ struct GptWs {
   // decode step on fragment-packed operands (decode.hip): row tiles of 16 utterances
   uint16_t *xp, *aop, *actp;
   RowDesc* desc;
+  int32_t* row_map;   // device-side compaction: this step's compact row -> utterance map (written by the step's first kernel)
   size_t bytes;
 };
 static GptWs carve(void* base, int B, int T) {
@@ -77,6 +78,7 @@ static GptWs carve(void* base, int B, int T) {
   w.aop = (uint16_t*)(p + off); off += align_up(Bp * HID * 2);
   w.actp = (uint16_t*)(p + off); off += align_up(Bp * INTER * 2);
   w.desc = (RowDesc*)(p + off); off += align_up(Bp * sizeof(RowDesc));
+  w.row_map = (int32_t*)(p + off); off += align_up(Bp * sizeof(int32_t));
   w.bytes = off;
   return w;
 }
@@ -167,6 +169,13 @@ static int check_state(const ctts_gpt* g, const ctts_gen_state* s) {
   return 0;
 }
 
+// Device-side compaction of the decode batch: the caller passes a writable `n_active` scalar and NO row_map; the first kernel
+// of every step then ranks the utterances whose finish flag is 0 (ascending slot), writes the map and the live count, and the
+// step computes exactly those rows.  (With a host row_map -- slot pools -- the host stays in charge of both.)
+static bool dev_compact(const ctts_gpt* g, const ctts_gen_state* s) {
+  return s->row_map == nullptr && s->n_active != nullptr && g->skip_finished;
+}
+
 // the 20-layer body + heads + sampling over M = B * q_per_b rows
 static int run_step(ctts_gpt* g, const ctts_gen_state* s, int q_per_b, hipStream_t st, bool prof_ok) {
   const GptWs ws = carve(s->workspace, s->B, s->T);
@@ -174,7 +183,9 @@ static int run_step(ctts_gpt* g, const ctts_gen_state* s, int q_per_b, hipStream
   const int wt = g->w.weight_dtype, kt = g->w.kv_dtype;
   const size_t kv_layer = (size_t)(s->kv_batch ? s->kv_batch : B) * NHEAD * cmax * HDIM * (kt == CTTS_BF16 ? 2 : 4);
   const bool dec = q_per_b == 1;
-  const int32_t* rmap = s->row_map;   // decode: compact row -> slot (see GptRowMap); prefill: row group -> slot of a pool (or null)
+  // decode: compact row -> slot (see GptRowMap) -- the host's map, or the one the step's first kernel derives from the finish
+  // flags (device-side compaction); prefill: row group -> slot of a pool (or null)
+  const int32_t* rmap = (dec && dev_compact(g, s)) ? ws.row_map : s->row_map;
   const int32_t* nact = dec ? s->n_active : nullptr;
   GptRowMap rm{q_per_b, s->len, s->kv_start, rmap, nact, (dec && g->skip_finished) ? s->finish : nullptr, nullptr};
   const bool fast = wt == CTTS_BF16;  // perf mode: bf16 activations, RMSNorm gain folded into wqkv / wgu by the loader
@@ -278,6 +289,7 @@ static int run_step(ctts_gpt* g, const ctts_gen_state* s, int q_per_b, hipStream
 
 extern "C" int ctts_gpt_prefill(ctts_gpt* g, const ctts_gen_state* s, const float* emb, void* stream) {
   if (check_state(g, s)) return -1;
+  CttsDeviceGuard dg(stream);
   hipStream_t st = (hipStream_t)stream;
   const GptWs ws = carve(s->workspace, s->B, s->T);
   CK(hipMemcpyAsync(ws.x, emb, (size_t)s->B * s->T * HID * 4, hipMemcpyDeviceToDevice, st));
@@ -289,7 +301,9 @@ static int decode_body(ctts_gpt* g, const ctts_gen_state* s, hipStream_t st, boo
   const GptWs ws = carve(s->workspace, s->B, s->T);
   { Prof p(g, 0, st, prof_ok); const bool fast = g->w.weight_dtype == CTTS_BF16;
     const bool packed = fast && g->dec_packed;
-    StepPrep sp{ws.desc, s->kv_start, g->skip_finished ? s->finish : nullptr, packed ? 1 : 0};
+    const bool dc = dev_compact(g, s);
+    StepPrep sp{ws.desc, s->kv_start, g->skip_finished ? s->finish : nullptr, packed ? 1 : 0, dc ? ws.row_map : nullptr,
+                dc ? const_cast<int32_t*>(s->n_active) : nullptr};
     uint16_t* xb = fast ? (packed ? ws.xp : ws.xb) : nullptr;
     if (s->infer_text)
       CK(launch_embed_text(g->w.emb_text, g->w.n_text, s->ids_buf, s->cap ? s->cap : s->T + s->max_new, s->len, ws.x, xb,
@@ -302,11 +316,13 @@ static int decode_body(ctts_gpt* g, const ctts_gen_state* s, hipStream_t st, boo
 
 extern "C" int ctts_gpt_decode_step(ctts_gpt* g, const ctts_gen_state* s, void* stream) {
   if (check_state(g, s)) return -1;
+  CttsDeviceGuard dg(stream);
   return decode_body(g, s, (hipStream_t)stream, true);
 }
 
 extern "C" int ctts_gpt_graph_build(ctts_gpt* g, const ctts_gen_state* s, void* stream) {
   if (check_state(g, s)) return -1;
+  CttsDeviceGuard dg(stream);
   ctts_gpt_graph_destroy(g);
   hipStream_t st = (hipStream_t)stream;
   if (st == nullptr) return fail("graph capture needs a non-default stream");
@@ -323,6 +339,7 @@ extern "C" int ctts_gpt_graph_build(ctts_gpt* g, const ctts_gen_state* s, void* 
 
 extern "C" int ctts_gpt_graph_launch(ctts_gpt* g, int32_t n_steps, void* stream) {
   if (!g || !g->exec) return fail("no captured graph");
+  CttsDeviceGuard dg(stream);
   for (int i = 0; i < n_steps; ++i) CK(hipGraphLaunch(g->exec, (hipStream_t)stream));
   return 0;
 }
@@ -430,6 +447,7 @@ static hipError_t dense(const ctts_codec* c, const GemmArgs& a, hipStream_t st) 
 extern "C" int ctts_dvae_decode(ctts_codec* c, const float* hid, float* mel, int32_t B, int32_t T, void* workspace, size_t ws_bytes,
                                 void* stream) {
   if (!c || B <= 0 || T <= 0) return fail("ctts_dvae_decode: bad arguments");
+  CttsDeviceGuard dg(stream);
   const int F = 2 * T;
   if (ws_bytes < ctts_codec_workspace_bytes(B, F)) return fail("codec workspace too small");
   hipStream_t st = (hipStream_t)stream;
@@ -452,6 +470,7 @@ extern "C" int ctts_dvae_decode(ctts_codec* c, const float* hid, float* mel, int
 extern "C" int ctts_vocos_decode(ctts_codec* c, const float* mel, float* wav, int32_t B, int32_t F, void* workspace, size_t ws_bytes,
                                  void* stream) {
   if (!c || B <= 0 || F < 2) return fail("ctts_vocos_decode: bad arguments");
+  CttsDeviceGuard dg(stream);
   if (ws_bytes < ctts_codec_workspace_bytes(B, F)) return fail("codec workspace too small");
   hipStream_t st = (hipStream_t)stream;
   CodecWs ws = carve_codec(workspace, B, F);
@@ -513,6 +532,7 @@ extern "C" int ctts_k_gemm_dec(const uint16_t* Ap, const uint16_t* Wp, int32_t M
   memset(&d, 0, sizeof(d));
   d.Ap = Ap; d.Wp = Wp; d.M = M; d.N = N; d.K = K; d.n_active = n_active; d.ssq_in = ssq_in; d.eps = eps; d.epi = epi; d.C32 = C32;
   d.ldc = ldc; d.Cp = Cp; d.kch_out = kch_out; d.ssq_out = ssq_out; d.force_mb = force_mb;
+  { const char* e = getenv("CTTS_GEMM_DBG_PTR"); if (e) d.dbg = (long long*)strtoull(e, nullptr, 0); }   // probes only
   CK(launch_gemm_dec(d, (hipStream_t)stream));
   return 0;
 }

@@ -25,22 +25,29 @@
 #include "common.hpp"
 #include "kernels.hpp"
 
+constexpr int DEC_U = 6;  // k-chunks of 32 per wave and round: DEC_U * (NACC + NMB) 16-byte loads in flight per lane
+
 template <int NMB, int MBT, int NW, bool SCALE, int EPI>
 __device__ __forceinline__ void dec_body(const DecGemmArgs& a, const int M, const int tile, const int mt0,
+                                         u128 (&wf)[(EPI == FEPI_SILU) ? 2 : 1][DEC_U],
                                          float (*red)[(EPI == FEPI_SILU) ? 2 : 1][MBT][64][4], float* rstd_s,
                                          float (*cs_s)[16], int (*meta_s)[2]) {
   constexpr int NACC = (EPI == FEPI_SILU) ? 2 : 1;
-  constexpr int U = 6;  // k-chunks of 32 per wave and round: U * (NACC + NMB) 16-byte loads in flight per lane
+  constexpr int U = DEC_U;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int li = lane & 15, g = lane >> 4;
   const int n0 = tile * 16, m0 = mt0 * 16;
   const int N = a.N, KCH = a.K >> 5;
+  // optional phase stamps (tools/dec_phase_probe.py): 100 MHz realtime counter, thread 0 of every workgroup
+  long long* dbg = a.dbg ? a.dbg + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 : nullptr;
+#define STAMP(i) do { if (dbg && tid == 0) dbg[i] = wall_clock64(); } while (0)
+  STAMP(1);
 
   // per-row sum of squares: 4 threads x 12 partials per row, consumed only in the epilogue
   float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0;
   const int srow = tid >> 2, spart = tid & 3;
   if (SCALE && srow < 16 * NMB) {
-    const float* sp = a.ssq_in + (size_t)min(m0 + srow, M - 1) * SSQ_PARTS + spart * 12;
+    const float* sp = a.ssq_in + (size_t)min(m0 + srow, a.M - 1) * SSQ_PARTS + spart * 12;   // a.M: no wait on *n_active
     s0 = *reinterpret_cast<const float4*>(sp);
     s1 = *reinterpret_cast<const float4*>(sp + 4);
     s2 = *reinterpret_cast<const float4*>(sp + 8);
@@ -58,7 +65,7 @@ __device__ __forceinline__ void dec_body(const DecGemmArgs& a, const int M, cons
     for (int q = 0; q < PPW; ++q) {
       const int p = wave + q * NF, mb = p >> 2, r = p & 3;
       if (p < NPAIR) {
-        const int row = min(m0 + 16 * mb + 4 * g + r, M - 1);
+        const int row = min(m0 + 16 * mb + 4 * g + r, a.M - 1);
         pre0[q] = a.C32[(size_t)row * a.ldc + n0 + li];
       }
     }
@@ -68,7 +75,7 @@ __device__ __forceinline__ void dec_body(const DecGemmArgs& a, const int M, cons
   const u128* wp = reinterpret_cast<const u128*>(a.Wp) + ((size_t)tile * KCH + wave * nper) * 64 + lane;
   const u128* wp2 = wp + (size_t)(N >> 4) * KCH * 64;  // SILU: the "up" tile of the same columns
   const u128* ap = reinterpret_cast<const u128*>(a.Ap) + ((size_t)mt0 * KCH + wave * nper) * 64 + lane;
-  const bool w_once = a.w_nt && M <= 16 * MBT;  // a single row group reads W: stream it past the caches
+  const bool w_once = a.w_nt && gridDim.y == 1;  // a single row group reads W: stream it past the caches
 
   f32x4 acc[NACC][NMB];
 #pragma unroll
@@ -77,15 +84,21 @@ __device__ __forceinline__ void dec_body(const DecGemmArgs& a, const int M, cons
     for (int mb = 0; mb < NMB; ++mb) acc[na][mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   for (int i = 0; i < nper; i += U) {
-    u128 wf[NACC][U], af[NMB][U];
-#pragma unroll
-    for (int j = 0; j < U; ++j) {
+    u128 af[NMB][U];
+    if (i > 0) {   // the first round's weight fragments were requested at kernel entry (before *n_active was known)
+      // (the policy test is hoisted out of the unrolled loads: a per-load select makes hipcc branch around every load)
       if (w_once) {
-        wf[0][j] = load16_nt(wp + (size_t)(i + j) * 64);
-        if (NACC == 2) wf[1][j] = load16_nt(wp2 + (size_t)(i + j) * 64);
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+          wf[0][j] = load16_nt(wp + (size_t)(i + j) * 64);
+          if (NACC == 2) wf[1][j] = load16_nt(wp2 + (size_t)(i + j) * 64);
+        }
       } else {
-        wf[0][j] = load16(wp + (size_t)(i + j) * 64);
-        if (NACC == 2) wf[1][j] = load16(wp2 + (size_t)(i + j) * 64);
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+          wf[0][j] = load16(wp + (size_t)(i + j) * 64);
+          if (NACC == 2) wf[1][j] = load16(wp2 + (size_t)(i + j) * 64);
+        }
       }
     }
 #pragma unroll
@@ -94,6 +107,7 @@ __device__ __forceinline__ void dec_body(const DecGemmArgs& a, const int M, cons
       for (int j = 0; j < U; ++j) af[mb][j] = load16(ap + ((size_t)mb * KCH + i + j) * 64);
     // every load of the round in flight before the first MFMA (hipcc otherwise sinks each load next to its use)
     __builtin_amdgcn_sched_barrier(0);
+    if (i == 0) STAMP(2);
 #pragma unroll
     for (int j = 0; j < U; ++j)
 #pragma unroll
@@ -104,6 +118,7 @@ __device__ __forceinline__ void dec_body(const DecGemmArgs& a, const int M, cons
                                                                 *reinterpret_cast<const bf16x8*>(&wf[na][j]), acc[na][mb], 0, 0, 0);
   }
 
+  STAMP(3);
   if (SCALE) {
     float s = (((s0.x + s0.y) + (s0.z + s0.w)) + ((s1.x + s1.y) + (s1.z + s1.w))) + ((s2.x + s2.y) + (s2.z + s2.w));
     s += __shfl_xor(s, 1, 64);
@@ -117,6 +132,7 @@ __device__ __forceinline__ void dec_body(const DecGemmArgs& a, const int M, cons
 #pragma unroll
       for (int r = 0; r < 4; ++r) red[wave][na][mb][lane][r] = acc[na][mb][r];
   __syncthreads();
+  STAMP(4);
   if (wave >= NF) return;
 
   const int col = n0 + li;
@@ -175,6 +191,8 @@ __device__ __forceinline__ void dec_body(const DecGemmArgs& a, const int M, cons
       }
     }
   }
+  STAMP(5);
+#undef STAMP
 }
 
 template <int MBT, int NW, bool SCALE, int EPI>
@@ -187,11 +205,36 @@ void gemm_dec_k(DecGemmArgs a) {
   __shared__ int meta_s[(EPI == FEPI_QKV_ROPE) ? 16 * MBT : 1][2];    // per row: utterance b (-1: finished), KV slot
 
   const int tile = blockIdx.x, mt0 = blockIdx.y * MBT;
+  if (a.dbg && threadIdx.x == 0) a.dbg[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8] = wall_clock64();
+  // The weight fragments of the first round do not depend on anything but the kernel arguments: request them before
+  // the live-row count (a dependent scalar load) is known.  Decode weights are read by one row group (<= 64 live
+  // rows with MBT = 4; the 16-row workgroups of o/down re-read them from L2), streamed non-temporal when so.
+  u128 wf[NACC][DEC_U];
+  const bool is_helper = EPI == FEPI_QKV_ROPE && (threadIdx.x >> 6) == NW;
+  if (!is_helper) {
+    const int KCH = a.K >> 5, nper = KCH / NW, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const u128* wp = reinterpret_cast<const u128*>(a.Wp) + ((size_t)tile * KCH + wave * nper) * 64 + lane;
+    const u128* wp2 = wp + (size_t)(a.N >> 4) * KCH * 64;
+    const bool w_once = a.w_nt && gridDim.y == 1;
+    if (w_once) {
+#pragma unroll
+      for (int j = 0; j < DEC_U; ++j) {
+        wf[0][j] = load16_nt(wp + (size_t)j * 64);
+        if (NACC == 2) wf[1][j] = load16_nt(wp2 + (size_t)j * 64);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < DEC_U; ++j) {
+        wf[0][j] = load16(wp + (size_t)j * 64);
+        if (NACC == 2) wf[1][j] = load16(wp2 + (size_t)j * 64);
+      }
+    }
+  }
   const int M = a.n_active ? min(*a.n_active, a.M) : a.M;   // live (compact) rows
   if (mt0 * 16 >= M) return;
   const int nmb = min(MBT, (M - mt0 * 16 + 15) >> 4);
 
-  if (EPI == FEPI_QKV_ROPE && (threadIdx.x >> 6) == NW) {
+  if (is_helper) {
     // helper wave: row descriptor -> cos/sin of the row's position, beside the main waves' load phase
     const int lane = threadIdx.x & 63;
     if (lane < 16 * nmb) {
@@ -212,15 +255,15 @@ void gemm_dec_k(DecGemmArgs a) {
   }
 
   if constexpr (MBT == 1) {
-    dec_body<1, MBT, NW, SCALE, EPI>(a, M, tile, mt0, red, rstd_s, cs_s, meta_s);
+    dec_body<1, MBT, NW, SCALE, EPI>(a, M, tile, mt0, wf, red, rstd_s, cs_s, meta_s);
   } else if constexpr (MBT == 2) {
-    if (nmb == 1) dec_body<1, MBT, NW, SCALE, EPI>(a, M, tile, mt0, red, rstd_s, cs_s, meta_s);
-    else dec_body<2, MBT, NW, SCALE, EPI>(a, M, tile, mt0, red, rstd_s, cs_s, meta_s);
+    if (nmb == 1) dec_body<1, MBT, NW, SCALE, EPI>(a, M, tile, mt0, wf, red, rstd_s, cs_s, meta_s);
+    else dec_body<2, MBT, NW, SCALE, EPI>(a, M, tile, mt0, wf, red, rstd_s, cs_s, meta_s);
   } else {
-    if (nmb == 1) dec_body<1, MBT, NW, SCALE, EPI>(a, M, tile, mt0, red, rstd_s, cs_s, meta_s);
-    else if (nmb == 2) dec_body<2, MBT, NW, SCALE, EPI>(a, M, tile, mt0, red, rstd_s, cs_s, meta_s);
-    else if (nmb == 3) dec_body<3, MBT, NW, SCALE, EPI>(a, M, tile, mt0, red, rstd_s, cs_s, meta_s);
-    else dec_body<4, MBT, NW, SCALE, EPI>(a, M, tile, mt0, red, rstd_s, cs_s, meta_s);
+    if (nmb == 1) dec_body<1, MBT, NW, SCALE, EPI>(a, M, tile, mt0, wf, red, rstd_s, cs_s, meta_s);
+    else if (nmb == 2) dec_body<2, MBT, NW, SCALE, EPI>(a, M, tile, mt0, wf, red, rstd_s, cs_s, meta_s);
+    else if (nmb == 3) dec_body<3, MBT, NW, SCALE, EPI>(a, M, tile, mt0, wf, red, rstd_s, cs_s, meta_s);
+    else dec_body<4, MBT, NW, SCALE, EPI>(a, M, tile, mt0, wf, red, rstd_s, cs_s, meta_s);
   }
 }
 

@@ -260,6 +260,7 @@ extern "C" int ctts_dvae_encode(ctts_dvae* c, const float* wav, int32_t n_sample
   const int F = 1 + n_samples / HOP, T = ctts_dvae_code_frames(n_samples);
   if (T < 1) return ctts_fail("ctts_dvae_encode: clip too short");
   if (ws_bytes < ctts_dvae_encode_workspace_bytes(n_samples)) return ctts_fail("dvae workspace too small");
+  CttsDeviceGuard dg(stream);
   hipStream_t st = (hipStream_t)stream;
   DvaeWs ws = carve_dvae(workspace, F / 2 + 1, F);
   const ctts_dvae_weights& w = c->w;
@@ -287,6 +288,7 @@ extern "C" int ctts_dvae_decode_codes(ctts_dvae* c, const int64_t* codes, float*
                                       size_t ws_bytes, void* stream) {
   if (!c || !codes || !mel || B <= 0 || T <= 0) return ctts_fail("ctts_dvae_decode_codes: bad arguments");
   if (ws_bytes < ctts_dvae_decode_workspace_bytes(B, T)) return ctts_fail("dvae workspace too small");
+  CttsDeviceGuard dg(stream);
   hipStream_t st = (hipStream_t)stream;
   DvaeWs ws = carve_dvae(workspace, (size_t)B * 2 * T, 0);
   // feat [B*T][1024] IS [B*2T][512] in channels-last (dvae.py:281-287, see oracle/dvae_np.py)

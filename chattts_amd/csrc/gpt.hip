@@ -53,6 +53,28 @@ __device__ __forceinline__ void write_desc(const StepPrep& sp, int m, int b, int
   d.jlo = ks > slot ? slot : ks;
   sp.desc[m] = d;
 }
+// Device-side compaction: which utterance is compact row m, and how many rows are live.  Every wave of the workgroup
+// evaluates this itself (the finish bytes are one load for B <= 64; no barrier).  Returns -1 when row m does not exist.
+__device__ __forceinline__ int nth_unfinished(const uint8_t* __restrict__ finish, int B, int m, int& total) {
+  const int lane = threadIdx.x & 63;
+  int cnt = 0, found = -1;
+  for (int base = 0; base < B; base += 64) {
+    const int idx = base + lane;
+    const bool alive = idx < B && finish[idx] == 0;
+    const unsigned long long mask = __ballot(alive);
+    const int c = __popcll(mask);
+    if (found < 0 && m < cnt + c) {
+      const int r = m - cnt;   // the r-th set bit of mask
+      const bool mine = alive && __popcll(mask & ((1ull << lane) - 1ull)) == r;
+      const unsigned long long pick = __ballot(mine);
+      found = base + (int)__ffsll((long long)pick) - 1;
+    }
+    cnt += c;
+  }
+  total = cnt;
+  return found;
+}
+
 __device__ __forceinline__ uint16_t* xb_row_ptr(uint16_t* xb, int m, int t, int packed) {
   // emit_row adds 4t itself: hand it a base such that base + 4t is where columns 4t..4t+3 of row m live
   if (!xb) return nullptr;
@@ -65,8 +87,17 @@ __global__ __launch_bounds__(192) void embed_codes_k(const float* __restrict__ e
                                                      const int32_t* __restrict__ row_map, const int32_t* __restrict__ n_active,
                                                      StepPrep sp) {
   const int m = blockIdx.x, t = threadIdx.x;
-  if (row_absent(n_active, m)) return;
-  const int b = row_map ? row_map[m] : m;
+  int b;
+  if (sp.row_map_out != nullptr) {   // device-side compaction: this step's row order comes from the finish flags
+    int total;
+    b = nth_unfinished(sp.finish, gridDim.x, m, total);
+    if (m == 0 && t == 0) *sp.n_active_out = total;
+    if (b < 0) return;
+    if (t == 0) sp.row_map_out[m] = b;
+  } else {
+    if (row_absent(n_active, m)) return;
+    b = row_map ? row_map[m] : m;
+  }
   const int slot = len[b] - 1;
   if (sp.desc != nullptr && t == 0) write_desc(sp, m, b, slot);
   const int64_t* tok = ids_buf + ((size_t)b * tcap + slot) * NVQ;
@@ -82,7 +113,7 @@ __global__ __launch_bounds__(192) void embed_codes_k(const float* __restrict__ e
 }
 
 static StepPrep prep_or_none(const StepPrep* p) {
-  StepPrep sp{nullptr, nullptr, nullptr, 0};
+  StepPrep sp{nullptr, nullptr, nullptr, 0, nullptr, nullptr};
   if (p) sp = *p;
   return sp;
 }
@@ -589,8 +620,17 @@ __global__ __launch_bounds__(192) void embed_text_k(const float* __restrict__ em
                                                     const int32_t* __restrict__ row_map, const int32_t* __restrict__ n_active,
                                                     StepPrep sp) {
   const int m = blockIdx.x, t = threadIdx.x;
-  if (row_absent(n_active, m)) return;
-  const int b = row_map ? row_map[m] : m;
+  int b;
+  if (sp.row_map_out != nullptr) {   // device-side compaction (see embed_codes_k)
+    int total;
+    b = nth_unfinished(sp.finish, gridDim.x, m, total);
+    if (m == 0 && t == 0) *sp.n_active_out = total;
+    if (b < 0) return;
+    if (t == 0) sp.row_map_out[m] = b;
+  } else {
+    if (row_absent(n_active, m)) return;
+    b = row_map ? row_map[m] : m;
+  }
   const int slot = len[b] - 1;
   if (sp.desc != nullptr && t == 0) write_desc(sp, m, b, slot);
   int id = (int)ids_buf[((size_t)b * tcap + slot) * NVQ];  // slot 0 (gpt.py:407)

@@ -121,6 +121,7 @@ struct DecGemmArgs {
   uint16_t* kc; uint16_t* vc; int cmax;
   int force_mb;                 // tests only
   int w_nt;                     // set by the launcher
+  long long* dbg;               // probes only (tools/dec_phase_probe.py): [n_workgroups][8] phase stamps, or null
 };
 hipError_t launch_gemm_dec(const DecGemmArgs& a, hipStream_t st);
 
@@ -150,6 +151,11 @@ struct StepPrep {
   const int32_t* kv_start;  // [slots]
   const uint8_t* finish;    // [slots] or null
   int xb_packed;
+  // device-side compaction (optional): compact row m becomes the m-th utterance (ascending slot) whose finish flag is 0;
+  // the kernel writes row_map_out[m] for the rows that exist and the live count to *n_active_out, which every later
+  // kernel of the step reads -- finished utterances leave the step at once, without the host
+  int32_t* row_map_out;     // [B] or null
+  int32_t* n_active_out;    // device scalar or null
 };
 hipError_t launch_embed_codes(const float* emb_code /*[4,626,768]*/, const int64_t* ids_buf, int ids_row_stride /*Tcap*/,
                               const int32_t* len, float* x, uint16_t* xb /*null ok*/, float* ssq /*null ok*/, int B,
@@ -218,5 +224,19 @@ struct GfsqArgs {
 };
 hipError_t launch_gfsq_encode(const GfsqArgs& q, const float* feat /*[rows][G*D]*/, int32_t* codes /*[rows][G*R]*/, int rows, hipStream_t st);
 hipError_t launch_gfsq_embed(const GfsqArgs& q, const int64_t* codes /*[rows][G*R]*/, float* feat /*[rows][G*D]*/, int rows, hipStream_t st);
+
+// Makes the device that owns `stream` current for the calling thread while an entry point enqueues on it (and restores the
+// previous one): kernels / graph capture / hipExtLaunch are issued against the CURRENT device, which need not be the engine's
+// (Chat.load(device=cuda:1) without a torch.cuda.set_device).  The null stream carries no device: nothing is changed then.
+struct CttsDeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  explicit CttsDeviceGuard(void* stream) {
+    hipDevice_t d;
+    if (stream != nullptr && hipStreamGetDevice((hipStream_t)stream, &d) == hipSuccess && hipGetDevice(&prev) == hipSuccess && prev != (int)d)
+      switched = hipSetDevice((int)d) == hipSuccess;
+  }
+  ~CttsDeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+};
 
 int ctts_fail(const char* fmt, ...);   // sets the thread's last-error string, returns -1 (capi.hip)

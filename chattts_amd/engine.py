@@ -405,7 +405,10 @@ class GptEngine:
                 s.stop_at = _lib.ptr(ln.stop_d)
                 s.teacher_ids = _lib.ptr(ln.teacher)
                 s.workspace, s.workspace_bytes = ln.workspace.data_ptr(), ln.ws_bytes
-                s.row_map, s.n_active = ln.row_map.data_ptr(), ln.n_active.data_ptr()
+                # no row_map: the library compacts on the device -- the first kernel of every decode step ranks the utterances
+                # whose finish flag is 0 and writes n_active (include/chattts_amd.h), so finished utterances leave the step
+                # at once and the host only ever READS finish / end_idx
+                s.row_map, s.n_active = None, ln.n_active.data_ptr()
                 ln.s = s
                 sess["lanes"].append(ln)
             self._session = sess
@@ -534,39 +537,57 @@ class GptEngine:
                 sess["out_ev"].record(caller)
             return GenerationOutputs(ids=ids, attentions=[], hiddens=hid)
 
-        def poll(ln):
-            """stream-ordered D2H of the lane's finish flags and end_idx (+ sync), and the event outputs() waits on"""
+        def snapshot(ln):
+            """stream-ordered, ASYNCHRONOUS D2H of the lane's finish flags and end_idx into pinned host buffers, plus the event
+            that marks the copy (and everything enqueued before it) done.  Two buffer sets: up to two chunks are in flight."""
+            k = ln.snap_i = (getattr(ln, "snap_i", 0) + 1) % 2
+            if not hasattr(ln, "snap_buf"):
+                ln.snap_buf = [(torch.empty((ln.hi - ln.lo,), dtype=torch.uint8).pin_memory(),
+                                torch.empty((ln.hi - ln.lo,), dtype=torch.int32).pin_memory(), torch.cuda.Event()) for _ in range(2)]
+            fin_h, end_h, ev = ln.snap_buf[k]
             with torch.cuda.stream(ln.st):
-                fin = ln.finish.cpu()
-                ln.end_snap = ln.end_idx.cpu().tolist()
-                ln.ev.record(ln.st)
-                ln.done = bool(fin.all())
-                # compaction: the utterances still running move to the front of the decode batch (stable order).  The
-                # reference keeps stepping finished rows until the last one is done (gpt.py:512-518,592) but cuts their
-                # output at end_idx, so dropping them from the step changes nothing observable.
-                active = (fin == 0).nonzero().flatten().to(torch.int32)
-                if not ln.done and int(active.numel()) != ln.n_act_host:
-                    ln.n_act_host = int(active.numel())
-                    ln.row_map[: ln.n_act_host].copy_(active, non_blocking=False)
-                    ln.n_active.fill_(ln.n_act_host)
-            return fin
+                fin_h.copy_(ln.finish, non_blocking=True)
+                end_h.copy_(ln.end_idx, non_blocking=True)
+                ev.record(ln.st)
+            return k
+
+        def collect(ln, k):
+            """wait for snapshot k; the reference keeps stepping finished rows until the last one is done (gpt.py:512-518,592)
+            but cuts their output at end_idx -- here they left the step on the device the moment they finished"""
+            fin_h, end_h, ev = ln.snap_buf[k]
+            ev.synchronize()
+            ln.ev = ev
+            ln.end_snap = end_h.tolist()
+            ln.done = bool(fin_h.all())
+            return fin_h.clone()
+
+        def poll(ln):
+            return collect(ln, snapshot(ln))
 
         def enqueue(n):
-            ensure_q(steps_done + n)
-            for ln in L:
-                if ln.done:
-                    continue
-                if graph_ok:
-                    _lib.check(lib.ctts_gpt_graph_launch(ln.handle, n, ln.st.cuda_stream), "ctts_gpt_graph_launch")
-                else:
-                    for _ in range(n):
-                        _lib.check(lib.ctts_gpt_decode_step(ln.handle, C.byref(ln.s), ln.st.cuda_stream), "ctts_gpt_decode_step")
+            """n decode steps on every unfinished lane; unseeded mode: in pieces that stay inside one block of the Exp(1) ring,
+            so a block is uploaded only after every step that still reads the half it overwrites has been enqueued"""
+            nonlocal steps_enq
+            while n > 0:
+                k = n if feeder is None else min(n, half - (steps_enq % half))
+                ensure_q(steps_enq + k)
+                for ln in L:
+                    if ln.done:
+                        continue
+                    if graph_ok:
+                        _lib.check(lib.ctts_gpt_graph_launch(ln.handle, k, ln.st.cuda_stream), "ctts_gpt_graph_launch")
+                    else:
+                        for _ in range(k):
+                            _lib.check(lib.ctts_gpt_decode_step(ln.handle, C.byref(ln.s), ln.st.cuda_stream), "ctts_gpt_decode_step")
+                steps_enq += k
+                n -= k
 
         # ---- step 0: prefill ----
         ensure_q(1)
         for ln in L:
             _lib.check(lib.ctts_gpt_prefill(ln.handle, C.byref(ln.s), ln.emb.data_ptr(), ln.st.cuda_stream), "ctts_gpt_prefill")
         steps_done = 1
+        steps_enq = 1     # steps enqueued so far (>= steps_done: chunks run ahead of the host's finish polls)
         graph_ok = False
         for ln in L:
             ln.ev = torch.cuda.Event()
@@ -596,25 +617,32 @@ class GptEngine:
         interrupted = False
         # the reference yields when (i+1) % stream_batch == 0: keep chunk ends on those steps
         next_n = lambda done: min(chunk - (done % chunk), max_new - done)
+        # Run-ahead: chunk k+1 is enqueued BEFORE the host looks at chunk k's finish flags (asynchronous snapshots), so the
+        # GPU never idles on the host between chunks; a streamed chunk's consumer (DVAE/Vocos of the prefix) overlaps the
+        # generation of the next one.  If everything turns out finished, the surplus chunk is ~100 empty launches per step.
+        import time as _time
+        t_dec0 = _time.perf_counter()
+        inflight = []   # [(steps, [snapshot index per lane])], oldest first
+
+        def launch_chunk():
+            n = next_n(steps_enq)
+            enqueue(n)
+            inflight.append((n, [None if ln.done else snapshot(ln) for ln in L]))
+
         try:
-            pending = 0
-            if steps_done < max_new and not all_done:
-                pending = next_n(steps_done)
-                enqueue(pending)
-            while pending:
-                for ln in L:
-                    if not ln.done:
-                        poll(ln)
-                steps_done += pending
-                pending = 0
+            if steps_enq < max_new and not all_done:
+                launch_chunk()
+            while inflight:
+                if len(inflight) < 2 and steps_enq < max_new and not context.get():
+                    launch_chunk()
+                n, snaps = inflight.pop(0)
+                for ln, k in zip(L, snaps):
+                    if k is not None and not ln.done:
+                        collect(ln, k)
+                steps_done += n
                 all_done = all(ln.done for ln in L)
-                if context.get():  # gpt.py:592
-                    interrupted = True
-                    break
-                if steps_done < max_new and not all_done:
-                    # run ahead: the next chunk is enqueued BEFORE the consumer gets this one
-                    pending = next_n(steps_done)
-                    enqueue(pending)
+                if all_done:
+                    inflight.clear()   # a surplus chunk computes nothing (no live rows); its launches drain in `finally`
                 if stream:
                     emit = False
                     if not all_done and steps_done % stream_batch == 0:
@@ -624,6 +652,11 @@ class GptEngine:
                         emit = i_star > 0 and i_star % stream_batch == 0  # the reference's duplicate yield (stream_iter quirk)
                     if emit:
                         yield outputs()
+                # the reference tests the interrupt flag after the step's stream yield (gpt.py:579-592): a chunk that ends on a
+                # yield boundary is still handed out.  Granularity here is one chunk (POLL / stream_batch steps), not one step.
+                if context.get():
+                    interrupted = True
+                    break
             if profile_tag is not None:
                 n_s, tot = C.c_int32(0), C.c_double(0.0)
                 _lib.check(lib.ctts_gpt_profile_end(L[0].handle, C.byref(n_s), C.byref(tot)), "profile_end")
@@ -633,6 +666,7 @@ class GptEngine:
                 feeder["pool"].shutdown(wait=True)   # idempotent; the generator-state rewind happens in finish_rng
             for ln in L:
                 ln.st.synchronize()   # nothing of this call is still running when its buffers are handed to the next one
+            self.last_stats["decode_ms"] = 1e3 * (_time.perf_counter() - t_dec0)   # host wall of the decode loop (streaming: incl. consumer time)
         if not all_done:
             if interrupted:
                 self.logger.warning("generation is interrupted")

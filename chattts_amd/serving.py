@@ -131,12 +131,22 @@ class SlotPool:
         self.queue.append(_Req(rid, ids, tm, int(max_new_token), int(stop_at)))
 
     def _admit(self) -> None:
-        n = min(len(self.free), len(self.queue))
+        # A group is left-padded to its longest prompt Tg, and every member then needs Tg + max_new_token + 1 <= cap (not just
+        # its own prompt length, which is all submit() can check): take queued requests in FIFO order while that holds for the
+        # whole group; the first one that does not fit waits for the next round (alone it always fits).  Nothing is popped
+        # from the queue / the free list before the group is known to be valid.
+        n, Tg, need = 0, 0, 0
+        for r in list(self.queue)[: len(self.free)]:
+            t_new = max(Tg, int(r.ids.shape[0]))
+            need_new = max(need, r.max_new)
+            if n > 0 and t_new + need_new + 1 > self.cap:
+                break
+            n, Tg, need = n + 1, t_new, need_new
         if n == 0:
             return
+        assert Tg + need + 1 <= self.cap
         reqs = [self.queue.popleft() for _ in range(n)]
         slots = [self.free.pop(0) for _ in range(n)]              # lowest free slots first (deterministic)
-        Tg = max(int(r.ids.shape[0]) for r in reqs)
         ids = torch.zeros((n, Tg, GPT.n_vq), dtype=torch.int64)
         mask = torch.zeros((n, Tg), dtype=torch.bool)
         tmask = torch.zeros((n, Tg), dtype=torch.bool)

@@ -99,7 +99,10 @@ typedef struct {
   const int32_t* row_map;          /* [B] or NULL: compact decode row -> batch slot.  The host packs the utterances that are still
                                       running to the front and refreshes this (and n_active) whenever it polls `finish`; every
                                       array above stays indexed by the batch slot.  NULL = identity / all rows. */
-  const int32_t* n_active;         /* device scalar or NULL: number of compact rows the decode step computes */
+  const int32_t* n_active;         /* device scalar or NULL: number of compact rows the decode step computes.  With row_map == NULL and
+                                      n_active != NULL the library compacts ON THE DEVICE: the first kernel of every decode step ranks
+                                      the utterances whose finish flag is 0 (ascending slot) and WRITES this scalar (it must be
+                                      writable device memory), so finished utterances leave the step at once, without the host. */
   /* Slot-pool (continuous batching) extensions -- all optional, 0 / NULL = the plain generate() layout.  They let a
    * prefill of B freshly admitted utterances write into a larger pool of `kv_batch` utterance slots (row_map[m] = slot
    * of prefill row-group m), with every per-utterance array (ids_buf, len, kv_start, finish, end_idx, hiddens, q,

@@ -111,10 +111,16 @@ def main():
     torch.set_num_threads(os.cpu_count())
     sds = W.synthetic_all()
     fp = {k: W.fingerprint(v) for k, v in sds.items()}
-    with open(os.path.join(OUT, "weights_fingerprint.txt"), "w") as f:
-        for k in sorted(fp):
-            f.write(f"{k} {fp[k]}\n")
-        f.write(f"torch {torch.__version__}\n")
+    fpath = os.path.join(OUT, "weights_fingerprint.txt")
+    keep = {}
+    if os.path.exists(fpath):     # lines other generators own (make_dvae_goldens.py: "dvae") stay
+        with open(fpath) as f:
+            keep = dict(line.split(None, 1) for line in f if line.strip())
+    keep.update({k: fp[k] + "\n" for k in fp})
+    keep["torch"] = torch.__version__ + "\n"
+    with open(fpath, "w") as f:
+        for k in sorted(keep):
+            f.write(f"{k} {keep[k]}")
     which = sys.argv[1:] or ["sampling", "generate", "codec", "text"]
     if "sampling" in which:
         golden_sampling()

@@ -132,23 +132,7 @@ def build_decoder(sds: dict):
 
 def torch_vocos_decode(sd: dict, mel_bcf: torch.Tensor) -> torch.Tensor:
     """Vocos.decode restated with torch ops (the `vocos` package is not installed): the pin for
-    oracle/codec_np.vocos_decode.  mel [B,100,F] (reference layout) -> wav [B, 256(F-1)]."""
-    F = torch.nn.functional
-    x = F.conv1d(mel_bcf, sd["backbone.embed.weight"], sd["backbone.embed.bias"], padding=3)
-    x = F.layer_norm(x.transpose(1, 2), (512,), sd["backbone.norm.weight"], sd["backbone.norm.bias"], 1e-6).transpose(1, 2)
-    i = 0
-    while f"backbone.convnext.{i}.gamma" in sd:
-        p = f"backbone.convnext.{i}."
-        r = x
-        y = F.conv1d(x, sd[p + "dwconv.weight"], sd[p + "dwconv.bias"], padding=3, groups=512).transpose(1, 2)
-        y = F.layer_norm(y, (512,), sd[p + "norm.weight"], sd[p + "norm.bias"], 1e-6)
-        y = F.gelu(F.linear(y, sd[p + "pwconv1.weight"], sd[p + "pwconv1.bias"]))
-        y = F.linear(y, sd[p + "pwconv2.weight"], sd[p + "pwconv2.bias"]) * sd[p + "gamma"]
-        x = r + y.transpose(1, 2)
-        i += 1
-    x = F.layer_norm(x.transpose(1, 2), (512,), sd["backbone.final_layer_norm.weight"], sd["backbone.final_layer_norm.bias"], 1e-6)
-    y = F.linear(x, sd["head.out.weight"], sd["head.out.bias"]).transpose(1, 2)
-    mag, p = y.chunk(2, dim=1)
-    mag = torch.clip(torch.exp(mag), max=1e2)
-    S = mag * (torch.cos(p) + 1j * torch.sin(p))
-    return torch.istft(S, 1024, 256, 1024, sd["head.istft.window"], center=True)
+    oracle/codec_np.vocos_decode.  mel [B,100,F] (reference layout) -> wav [B, 256(F-1)].  Lives in oracle/torch_port.py
+    (which also travels to the GPU box for bench.py's CPU baseline)."""
+    from . import torch_port
+    return torch_port.vocos_decode(sd, mel_bcf)

@@ -168,3 +168,14 @@ def test_chat_load_rejects_remote_sources_before_touching_the_gpu():
     assert c.load(source="huggingface") is False and not c.has_loaded()
     # sentence splitting of `infer` (core.py:225-238) happens before anything is loaded: an empty text yields []
     assert c.infer("", split_text=True) == []
+
+
+def test_chat_load_signature_matches_reference():
+    """the reference's positional parameters and defaults of Chat.load (core.py:137-148), extras keyword-only"""
+    import inspect
+    from chattts_amd.core import Chat
+    ps = list(inspect.signature(Chat.load).parameters.values())[1:]
+    pos = [(p.name, p.default) for p in ps if p.kind == p.POSITIONAL_OR_KEYWORD]
+    assert pos == [("source", "local"), ("force_redownload", False), ("compile", False), ("custom_path", None), ("device", None),
+                   ("coef", None), ("use_flash_attn", False), ("use_vllm", False), ("experimental", False)]
+    assert all(p.kind == p.KEYWORD_ONLY for p in ps[len(pos):])

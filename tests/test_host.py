@@ -186,6 +186,63 @@ def test_two_rank_broadcast_and_sharded_sampling(golden):
     assert np.array_equal(idx, golden["sampling"]["rows640.idx"])  # union of shards == the reference's full-batch run
 
 
+def _bench_shard_worker(rank, world, port, q):
+    """one rank of bench.py's data-parallel path on CPU: bench.shard_workload -> this shard's prompts / forced lengths /
+    global row numbering -> generation (numpy oracle standing in for the HIP engine) -> gather in rank order"""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import bench
+        from chattts_amd import weights as W
+        from oracle import generate_np, llama_np
+        wl = bench.shard_workload(3, world, rank, 4, 9)      # 3 utterances per rank
+        llama = llama_np.LlamaWeights({k: v.numpy() for k, v in W.synthetic_gpt(n_layers=2).items()})
+        esd = {k: v.numpy() for k, v in W.synthetic_embed().items()}
+        draws = rng.ExpDraws(wl["total_rows"], 626, 42, row_begin=wl["row_offset"], row_end=wl["row_offset"] + 4 * (wl["hi"] - wl["lo"]))
+        res = generate_np.generate(llama, esd, generate_np.fold_heads(esd), generate_np.embed_prompt(esd, wl["ids"], wl["tmask"]),
+                                   wl["ids"], wl["mask"], temperature=np.array([0.3] * 4, np.float32), draw_q=lambda i: draws.step(i).numpy(),
+                                   pow_table=rng.penalty_table(1.05).numpy(), max_new_token=int(wl["stop_all"].max()) + 1,
+                                   stop_at=wl["stop"], row_offset=wl["row_offset"])
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (wl["lo"], wl["hi"], [r.tolist() for r in res.ids]))
+        if rank == 0:
+            q.put(gathered)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_bench_sharding_path_equals_the_unsharded_batch():
+    """bench.py --gpus 2 on CPU/gloo: the union of the two ranks' shards, in rank order, is the single-process run of the
+    global batch row for row (contiguous blocks, draws and the rows>=625 quirk keyed on the global row index)"""
+    import torch.multiprocessing as mp
+    import bench
+    from chattts_amd import weights as W
+    from oracle import generate_np, llama_np
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_shard_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [(lo, hi) for lo, hi, _ in res] == [(0, 3), (3, 6)]
+    sharded = [np.array(r, dtype=np.int64).reshape(-1, 4) for _, _, rows in res for r in rows]
+    wl = bench.shard_workload(6, 1, 0, 4, 9)                 # the same 6 utterances as ONE batch
+    llama = llama_np.LlamaWeights({k: v.numpy() for k, v in W.synthetic_gpt(n_layers=2).items()})
+    esd = {k: v.numpy() for k, v in W.synthetic_embed().items()}
+    draws = rng.ExpDraws(24, 626, 42)
+    full = generate_np.generate(llama, esd, generate_np.fold_heads(esd), generate_np.embed_prompt(esd, wl["ids"], wl["tmask"]), wl["ids"],
+                                wl["mask"], temperature=np.array([0.3] * 4, np.float32), draw_q=lambda i: draws.step(i).numpy(),
+                                pow_table=rng.penalty_table(1.05).numpy(), max_new_token=int(wl["stop_all"].max()) + 1, stop_at=wl["stop"])
+    assert [len(r) for r in sharded] == wl["stop"].tolist()
+    for a, b in zip(sharded, full.ids):
+        assert np.array_equal(a, b)
+
+
 def test_pmc_summary_maps_the_profiled_kernel_names():
     """tools/pmc_summary.py maps rocprofv3 kernel names to bench.py's tags by substring; the committed kernel-stat CSV of the
     round must still resolve to every tag bench.py's roofline leg can ask for (catches template-argument drift)."""
@@ -194,7 +251,7 @@ def test_pmc_summary_maps_the_profiled_kernel_names():
     spec = importlib.util.spec_from_file_location("pmc_summary", os.path.join(ROOT, "tools", "pmc_summary.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    with open(os.path.join(ROOT, "profiles", "r1z_kernel_stats.csv")) as f:
+    with open(os.path.join(ROOT, "profiles", "r2a_kernel_stats.csv")) as f:
         names = [r["Name"] for r in csv.DictReader(f)]
     tags = {mod.short(n) for n in names} - {None}
     assert {"attention", "qkv_gemm", "o_proj_gemm", "gate_up_gemm", "down_gemm", "heads_gemm", "sample"} <= tags

@@ -129,3 +129,32 @@ def test_codec(golden, weights, name):
     ref = golden["codec"][name + ".wav"]
     rms = np.sqrt(np.mean((wav - ref) ** 2))
     assert wav.shape == ref.shape and rms < 1e-4, rms  # north_star bar: float32 waveform within 1e-4 RMS
+
+
+def test_torch_port_matches_goldens(golden, weights):
+    """oracle/torch_port.py (bench.py's CPU baseline: HF LlamaModel + DynamicCache + transformers' warpers under
+    torch/MKL) reproduces the reference's golden token ids, and its DVAE / Vocos restatements the reference-class mel
+    and the wav golden"""
+    from oracle import torch_port
+    c = cases.GEN_CASES["b8"]
+    ids, mask, tmask = cases.gen_inputs(c)
+    esd = weights["embed"]
+    emb = torch.from_numpy(generate_np.embed_prompt({k: v.numpy() for k, v in esd.items()}, ids, tmask))
+    llama = torch_port.build_llama(weights["gpt"])
+    n = 24
+    got, hid, end_idx = torch_port.generate(llama, esd, emb, torch.from_numpy(ids), torch.from_numpy(mask), temperature=c["temperature"],
+                                            top_P=c["top_P"], top_K=c["top_K"], repetition_penalty=c["rep"], max_new_token=n,
+                                            min_new_token=min(n, c["min_new"]), manual_seed=c["manual_seed"])
+    G = golden["generate"]
+    lens = G["b8.lens"]
+    off = np.concatenate([[0], np.cumsum(lens)])
+    for b in range(ids.shape[0]):
+        want = G["b8.ids"][off[b]: off[b + 1]][:n]
+        assert np.array_equal(got[b, : len(want)].numpy(), want), b
+        assert int(end_idx[b]) == min(lens[b], n)
+    cc = cases.CODEC_CASES["c24"]
+    hidc = torch.from_numpy(cases.codec_inputs(cc))
+    mel = torch_port.dvae_decode(weights["decoder"], hidc)
+    assert float((mel - torch.from_numpy(golden["codec"]["c24.mel"])).abs().max()) < 1e-4
+    wav = torch_port.vocos_decode(weights["vocos"], mel)
+    assert float((wav - torch.from_numpy(golden["codec"]["c24.wav"])).pow(2).mean().sqrt()) < 1e-5

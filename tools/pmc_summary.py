@@ -24,11 +24,25 @@ def collect(root, counter):
 
 
 def short(name):
-    for key, tag in (("attention_k", "attention"), ("gemm_fast_k<2, 4, true, 3>", "qkv_gemm"), ("gemm_fast_k<4, 4, true, 3>", "qkv_gemm"),
-                     ("gemm_fast_k<1, 4, false, 1>", "o_proj_gemm"), ("true, 2>", "gate_up_gemm"), ("gemm_fast_k<1, 16, false, 1>", "down_gemm"),
-                     ("gemm_skinny_k<float", "heads_gemm"), ("sample_k", "sample")):
-        if key in name:
-            return tag
+    """rocprofv3 kernel name -> bench.py tag.  gemm_dec_k<MBT, NW, SCALE, EPI> (decode.hip, the packed decode projections):
+    EPI 3 = QKV+RoPE, 2 = SiLU gate/up, 1 = residual (NW 4: o_proj, K = 768; NW 8/16: down_proj, K = 3072);
+    gemm_fast_k<MB, NW, SCALE, EPI> are the row-major kernels (prefill below 256 rows, CTTS_DEC_PACKED=0)."""
+    import re
+    if "attention_k" in name:
+        return "attention"
+    m = re.search(r"gemm_(dec|fast)_k<(\d+), (\d+), (true|false), (\d+)>", name)
+    if m:
+        nw, epi = int(m.group(3)), int(m.group(5))
+        if epi == 3:
+            return "qkv_gemm"
+        if epi == 2:
+            return "gate_up_gemm"
+        if epi == 1:
+            return "o_proj_gemm" if nw == 4 else "down_gemm"
+    if "gemm_skinny_k<float" in name:
+        return "heads_gemm"
+    if "sample_k" in name:
+        return "sample"
     return None
 
 
