@@ -328,8 +328,8 @@ def cpu_baseline(sds, ids, mask, tmask, stop, n_steps: int = 33, codec_rows: int
     workload is  prefill + (max(stop)) decode steps  -- taken at the sampled per-step time, i.e. at contexts <= 48 + n_steps
     keys although the bench's contexts reach 560 (this favours the CPU) -- plus DVAE + Vocos per generated token, measured
     on a [codec_rows, codec_T]-token slice.  value = audio seconds of the workload / that wall time.
-    Thread count: a 3-step calibration at {32, 64, all hardware threads} (BASELINE.md asks for all; on a 256-thread host
-    the small decode matmuls may run slower with all of them), the one with the fastest decode step runs the sample.  Every
+    Thread count: a 3-step calibration at {32, 64, all hardware threads if <= 96} (BASELINE.md asks for all; measured on this
+    pool's 256-thread host, all threads are 40x SLOWER than 32), the one with the fastest decode step runs the sample.  Every
     leg carries a wall-clock deadline so that a slow host shortens the sample instead of stalling the bench."""
     from oracle import generate_np, torch_port
 
@@ -344,7 +344,10 @@ def cpu_baseline(sds, ids, mask, tmask, stop, n_steps: int = 33, codec_rows: int
     kw = dict(temperature=[0.3] * 4, top_P=0.7, top_K=20, repetition_penalty=1.05, manual_seed=42)
     t_start = time.perf_counter()   # the budget covers the timed legs, not building the model
     try:
-        for nthr in sorted({min(cores, 32), min(cores, 64), cores}):
+        # all hardware threads only on hosts where that is sane: on the 256-thread EPYC 9575F box of this pool the batch-64
+        # prefill alone took 115 s at 256 torch threads against 2.6 s at 32 (profiles/r2c_bench.log)
+        cands = {min(cores, 32), min(cores, 64)} | ({cores} if cores <= 96 else set())
+        for nthr in sorted(cands):
             if calib and time.perf_counter() - t_start > 0.35 * budget_s:
                 break
             torch.set_num_threads(nthr)

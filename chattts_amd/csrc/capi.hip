@@ -43,6 +43,7 @@ struct ctts_gpt {
   int prof_tag = -1;
   int prof_max = 0;
   bool skip_finished = true;  // env CTTS_SKIP_FINISHED=0 restores the reference's "finished rows keep stepping"
+  int n_cu = 0;               // compute units of the device when attention remainder splitting is on (env CTTS_ATT_SPLIT=1); 0 = off
   int prof_stride = 1;   // time every prof_stride-th launch of the tag
   int prof_seen = 0;
   std::vector<hipEvent_t> ev0, ev1;
@@ -50,6 +51,7 @@ struct ctts_gpt {
 };
 
 static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
+#define ATT_CUS_MAX 512   // upper bound of compute units the attention split state is sized for
 
 struct GptWs {
   float *x, *qkv, *ao, *act, *hfin, *logits, *ssq;
@@ -57,6 +59,8 @@ struct GptWs {
   // decode step on fragment-packed operands (decode.hip): row tiles of 16 utterances
   uint16_t *xp, *aop, *actp;
   RowDesc* desc;
+  float* att_part;    // attention remainder splitting: partials of the split units' pieces, and their arrival counters
+  int32_t* att_cnt;
   int32_t* row_map;   // device-side compaction: this step's compact row -> utterance map (written by the step's first kernel)
   size_t bytes;
 };
@@ -79,6 +83,8 @@ static GptWs carve(void* base, int B, int T) {
   w.actp = (uint16_t*)(p + off); off += align_up(Bp * INTER * 2);
   w.desc = (RowDesc*)(p + off); off += align_up(Bp * sizeof(RowDesc));
   w.row_map = (int32_t*)(p + off); off += align_up(Bp * sizeof(int32_t));
+  w.att_part = (float*)(p + off); off += align_up((size_t)ATT_CUS_MAX * ATT_SPLIT_MAX * 66 * sizeof(float));
+  w.att_cnt = (int32_t*)(p + off); off += align_up((size_t)ATT_CUS_MAX * sizeof(int32_t));
   w.bytes = off;
   return w;
 }
@@ -106,6 +112,15 @@ extern "C" int ctts_gpt_create(ctts_gpt** out, const ctts_gpt_weights* w) {
     if (e && atoi(e) == 0) g->dec_packed = false;
   }
   { const char* e = getenv("CTTS_SKIP_FINISHED"); if (e && atoi(e) == 0) g->skip_finished = false; }
+  {
+    int dev = 0, cus = 0;
+    // OFF by default: measured on the C3 bench it does not pay (attention 9.3 -> 9.8 us per launch, 1296 -> 1280 audio-s/s,
+    // profiles/r2e_ab_split.log) and it makes a row's bf16 result depend on how many rows share the step
+    const char* e = getenv("CTTS_ATT_SPLIT");
+    if (e && atoi(e) == 1 && hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0 && cus <= ATT_CUS_MAX)
+      g->n_cu = cus;
+  }
   *out = g;
   return 0;
 }
@@ -187,10 +202,11 @@ static int run_step(ctts_gpt* g, const ctts_gen_state* s, int q_per_b, hipStream
   // flags (device-side compaction); prefill: row group -> slot of a pool (or null)
   const int32_t* rmap = (dec && dev_compact(g, s)) ? ws.row_map : s->row_map;
   const int32_t* nact = dec ? s->n_active : nullptr;
-  GptRowMap rm{q_per_b, s->len, s->kv_start, rmap, nact, (dec && g->skip_finished) ? s->finish : nullptr, nullptr};
+  GptRowMap rm{q_per_b, s->len, s->kv_start, rmap, nact, (dec && g->skip_finished) ? s->finish : nullptr, nullptr, nullptr, nullptr, 0};
   const bool fast = wt == CTTS_BF16;  // perf mode: bf16 activations, RMSNorm gain folded into wqkv / wgu by the loader
   const bool packed = fast && dec && g->dec_packed;   // decode step on fragment-packed operands (decode.hip)
   if (dec) rm.desc = ws.desc;                          // written by the embedding kernel at the head of the step
+  if (packed && g->n_cu > 0) { rm.sp_part = ws.att_part; rm.sp_cnt = ws.att_cnt; rm.sp_cus = g->n_cu; }
   for (int l = 0; packed && l < g->w.n_layers; ++l) {
     void* kc = (char*)s->kcache + kv_layer * l;
     void* vc = (char*)s->vcache + kv_layer * l;
@@ -292,6 +308,7 @@ extern "C" int ctts_gpt_prefill(ctts_gpt* g, const ctts_gen_state* s, const floa
   CttsDeviceGuard dg(stream);
   hipStream_t st = (hipStream_t)stream;
   const GptWs ws = carve(s->workspace, s->B, s->T);
+  CK(hipMemsetAsync(ws.att_cnt, 0, (size_t)ATT_CUS_MAX * sizeof(int32_t), st));   // arrival counters of the attention split
   CK(hipMemcpyAsync(ws.x, emb, (size_t)s->B * s->T * HID * 4, hipMemcpyDeviceToDevice, st));
   if (g->w.weight_dtype == CTTS_BF16) CK(launch_rows_prep(ws.x, ws.xb, ws.ssq, s->B * s->T, st));
   return run_step(g, s, s->T, st, false);
@@ -326,6 +343,11 @@ extern "C" int ctts_gpt_graph_build(ctts_gpt* g, const ctts_gen_state* s, void* 
   ctts_gpt_graph_destroy(g);
   hipStream_t st = (hipStream_t)stream;
   if (st == nullptr) return fail("graph capture needs a non-default stream");
+  {  // the decode workspace may never have seen a prefill (slot pools prefill into their own): zero the arrival counters of the
+     // attention split once, stream-ordered before anything the graph will run
+    const GptWs ws = carve(s->workspace, s->B, s->T);
+    CK(hipMemsetAsync(ws.att_cnt, 0, (size_t)ATT_CUS_MAX * sizeof(int32_t), st));
+  }
   CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
   const int rc = decode_body(g, s, st, false);
   hipGraph_t graph = nullptr;
@@ -543,14 +565,22 @@ extern "C" int ctts_k_rows_prep(const float* x32, uint16_t* xb, float* ssq, int3
 extern "C" int ctts_k_rope_append(float* qkv, void* kcache, void* vcache, int32_t kv_dtype, int32_t cmax, const float* cos_tab,
                                   const float* sin_tab, int32_t q_per_b, const int32_t* len, const int32_t* kv_start, int32_t M,
                                   void* stream) {
-  GptRowMap rm{q_per_b, len, kv_start, nullptr, nullptr, nullptr, nullptr};
+  GptRowMap rm{q_per_b, len, kv_start, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
   CK(launch_rope_append(qkv, kcache, vcache, kv_dtype, cmax, cos_tab, sin_tab, rm, M, (hipStream_t)stream));
   return 0;
 }
 extern "C" int ctts_k_attention(const float* qkv, const void* kcache, const void* vcache, int32_t kv_dtype, int32_t cmax, float* out,
                                 int32_t q_per_b, const int32_t* len, const int32_t* kv_start, int32_t M, void* stream) {
-  GptRowMap rm{q_per_b, len, kv_start, nullptr, nullptr, nullptr, nullptr};
+  GptRowMap rm{q_per_b, len, kv_start, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
   CK(launch_attention(qkv, kcache, vcache, kv_dtype, cmax, out, 0, rm, M, (hipStream_t)stream));
+  return 0;
+}
+extern "C" int ctts_k_attention_dec(const float* qkv, const uint16_t* kcache, const uint16_t* vcache, int32_t cmax, uint16_t* out_packed,
+                                    const int32_t* desc, const int32_t* n_active, int32_t M, float* part, int32_t* cnt, int32_t n_cu,
+                                    void* stream) {
+  if (n_cu < 0 || n_cu > ATT_CUS_MAX) return fail("ctts_k_attention_dec: bad n_cu");
+  GptRowMap rm{1, nullptr, nullptr, nullptr, n_active, nullptr, reinterpret_cast<const RowDesc*>(desc), part, cnt, n_cu};
+  CK(launch_attention(qkv, kcache, vcache, WT_BF16, cmax, out_packed, 2, rm, M, (hipStream_t)stream));
   return 0;
 }
 extern "C" int ctts_k_embed_codes(const float* emb_code, const int64_t* ids_buf, int32_t tcap, const int32_t* len, float* x, int32_t B,

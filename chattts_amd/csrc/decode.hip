@@ -53,21 +53,21 @@ __device__ __forceinline__ void dec_body(const DecGemmArgs& a, const int M, cons
     s2 = *reinterpret_cast<const float4*>(sp + 8);
   }
 
-  // finishing work = 4*NMB (row tile, accumulator register) pairs of 64 outputs, dealt round-robin to NF waves
-  constexpr int NPAIR = 4 * NMB;
-  constexpr int NF = NW < 4 ? NW : 4;
-  constexpr int PPW = (NPAIR + NF - 1) / NF;
+  // finishing work = 4*NMB (row tile, accumulator register) pairs of 64 outputs.  Finishing wave w owns PPW CONSECUTIVE pairs, so
+  // its LDS reads below are whole 16- / 8-byte vectors (reading one float of every lane's float4 is an 8-way bank conflict):
+  // NMB >= 3: wave w finishes row tile w (all 4 registers); NMB = 2: tile w/2, registers 2(w&1)..+1; NMB = 1: register w
+  constexpr int PPW = NMB >= 3 ? 4 : NMB;
+  constexpr int NF = NMB >= 3 ? NMB : 4;
+  static_assert(NW >= 4, "needs at least 4 waves");
+  const int fmb = (wave * PPW) >> 2, fr0 = (wave * PPW) & 3;   // meaningful for wave < NF
   float pre0[PPW];  // RES: residual, requested before the operand loads
 #pragma unroll
   for (int q = 0; q < PPW; ++q) pre0[q] = 0.f;
   if (EPI == FEPI_RES && wave < NF) {
 #pragma unroll
     for (int q = 0; q < PPW; ++q) {
-      const int p = wave + q * NF, mb = p >> 2, r = p & 3;
-      if (p < NPAIR) {
-        const int row = min(m0 + 16 * mb + 4 * g + r, a.M - 1);
-        pre0[q] = a.C32[(size_t)row * a.ldc + n0 + li];
-      }
+      const int row = min(m0 + 16 * fmb + 4 * g + fr0 + q, a.M - 1);
+      pre0[q] = a.C32[(size_t)row * a.ldc + n0 + li];
     }
   }
 
@@ -128,12 +128,30 @@ __device__ __forceinline__ void dec_body(const DecGemmArgs& a, const int M, cons
 #pragma unroll
   for (int na = 0; na < NACC; ++na)
 #pragma unroll
-    for (int mb = 0; mb < NMB; ++mb)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) red[wave][na][mb][lane][r] = acc[na][mb][r];
+    for (int mb = 0; mb < NMB; ++mb) *reinterpret_cast<f32x4*>(&red[wave][na][mb][lane][0]) = acc[na][mb];
   __syncthreads();
   STAMP(4);
   if (wave >= NF) return;
+
+  float vsum[PPW], usum[PPW];
+#pragma unroll
+  for (int q = 0; q < PPW; ++q) { vsum[q] = 0.f; usum[q] = 0.f; }
+#pragma unroll
+  for (int w = 0; w < NW; ++w) {      // fixed order: deterministic
+    float tv[4], tu[4];
+    if constexpr (PPW == 4) {
+      *reinterpret_cast<f32x4*>(tv) = *reinterpret_cast<const f32x4*>(&red[w][0][fmb][lane][0]);
+      if (EPI == FEPI_SILU) *reinterpret_cast<f32x4*>(tu) = *reinterpret_cast<const f32x4*>(&red[w][NACC - 1][fmb][lane][0]);
+    } else if constexpr (PPW == 2) {
+      *reinterpret_cast<float2*>(tv) = *reinterpret_cast<const float2*>(&red[w][0][fmb][lane][fr0]);
+      if (EPI == FEPI_SILU) *reinterpret_cast<float2*>(tu) = *reinterpret_cast<const float2*>(&red[w][NACC - 1][fmb][lane][fr0]);
+    } else {
+      tv[0] = red[w][0][fmb][lane][fr0];
+      if (EPI == FEPI_SILU) tu[0] = red[w][NACC - 1][fmb][lane][fr0];
+    }
+#pragma unroll
+    for (int q = 0; q < PPW; ++q) { vsum[q] += tv[q]; if (EPI == FEPI_SILU) usum[q] += tu[q]; }
+  }
 
   const int col = n0 + li;
   // ROPE tiles (weights permuted by the loader): columns 0..7 of a q/k tile are dims d0..d0+7 of one head, columns
@@ -142,16 +160,9 @@ __device__ __forceinline__ void dec_body(const DecGemmArgs& a, const int M, cons
   const int dlo = 8 * t4 + (li & 7);
 #pragma unroll
   for (int q = 0; q < PPW; ++q) {
-    const int p = wave + q * NF, mb = p >> 2, r = p & 3;
-    if (p >= NPAIR) break;
+    const int mb = fmb, r = fr0 + q;
     const int row = m0 + 16 * mb + 4 * g + r;
-    float v = 0.f, u = 0.f;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) v += red[w][0][mb][lane][r];
-    if (EPI == FEPI_SILU) {
-#pragma unroll
-      for (int w = 0; w < NW; ++w) u += red[w][NACC - 1][mb][lane][r];
-    }
+    float v = vsum[q], u = usum[q];
     const bool ok = row < M;
     if (SCALE) {
       const float rs = rstd_s[16 * mb + 4 * g + r];
@@ -199,7 +210,7 @@ template <int MBT, int NW, bool SCALE, int EPI>
 __global__ __launch_bounds__(64 * (NW + (EPI == FEPI_QKV_ROPE ? 1 : 0)))
 void gemm_dec_k(DecGemmArgs a) {
   constexpr int NACC = (EPI == FEPI_SILU) ? 2 : 1;
-  __shared__ float red[NW][NACC][MBT][64][4];
+  __shared__ __attribute__((aligned(16))) float red[NW][NACC][MBT][64][4];
   __shared__ float rstd_s[16 * MBT];
   __shared__ float cs_s[(EPI == FEPI_QKV_ROPE) ? 16 * MBT : 1][16];   // per row: cos[8], sin[8] of this tile's dims
   __shared__ int meta_s[(EPI == FEPI_QKV_ROPE) ? 16 * MBT : 1][2];    // per row: utterance b (-1: finished), KV slot

@@ -218,7 +218,19 @@ template <typename OT> __device__ __forceinline__ void store_out(OT* p, float v)
 template <> __device__ __forceinline__ void store_out<float>(float* p, float v) { *p = v; }
 template <> __device__ __forceinline__ void store_out<bf16_t>(bf16_t* p, float v) { *p = f32_to_bf16(v); }
 
-template <typename KT, int NW, typename OT, bool PKO = false>
+// SPLIT (decode, perf mode): "remainder splitting".  A (utterance, head) unit streams ctx * 256 bytes of KV and a CU ingests
+// only ~25 GB/s of that, so the kernel lasts as long as the CU with the most units: U = 12 * n_active units on C CUs cost
+// ceil(U / C) units of time although the average CU holds U / C (540 units on 256 CUs: 3 instead of 2.1; below 256 units whole
+// CUs idle).  Here the first floor(U / C) * C units stay whole (one workgroup each, merged through LDS as before) and each
+// of the R = U mod C remainder units is cut into S = min(8, C / R) key ranges handled by S workgroups -- R * S <= C small
+// workgroups, about one per CU -- that meet through memory: every piece writes its partial (o[64], m, l) write-through, draws
+// a ticket from the unit's counter, and the LAST arriver reads the S partials (L1-bypassing loads), merges them and writes the
+// output (MI355X guide, Guideline 16 hand-off in its counter form: sc1 payload -> vmcnt(0) -> relaxed agent atomic; placement
+// independent).  grid = 12 * rows + C workgroups.  MEASURED (profiles/r2e_*): correct (tests/test_gpu_kernels.py), but on the C3
+// bench the launch gets 0.5 us SLOWER (9.3 -> 9.8 us) -- the pieces' hand-off latency is not hidden behind the whole units --
+// and the split geometry depends on the live-row count, which costs bf16 mode its batch invariance.  Kept behind
+// CTTS_ATT_SPLIT=1 (default off) as a recorded negative result.
+template <typename KT, int NW, typename OT, bool PKO = false, bool SPLIT = false>
 __global__ __launch_bounds__(64 * NW) void attention_k(const float* __restrict__ qkv, const KT* __restrict__ kc,
                                                        const KT* __restrict__ vc, int cmax, OT* __restrict__ out, GptRowMap rm) {
   constexpr int DPL = KTraits<KT>::DPL;
@@ -230,10 +242,29 @@ __global__ __launch_bounds__(64 * NW) void attention_k(const float* __restrict__
   constexpr bool KV_NT = NW > 1;    // decode: every KV byte is read once per step by exactly one workgroup -> non-temporal
   __shared__ float sm_m[NW], sm_l[NW], sm_acc[NW][HDIM];
 
-  const int h = blockIdx.x, m = blockIdx.y;
+  int h = blockIdx.x, m = blockIdx.y;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int kg = lane / LPK, dl = lane % LPK;
-  if (rm.q_per_b == 1 && row_absent(rm.n_active, m)) return;
+  int n_piece = 1, piece = 0, su = 0;   // SPLIT: pieces of this unit, this workgroup's piece, index among the split units
+  if (SPLIT) {
+    const int nact = rm.n_active ? *rm.n_active : (int)(gridDim.x - rm.sp_cus) / NHEAD;
+    const int U = nact * NHEAD, C = rm.sp_cus;
+    const int k = U / C, R = U - k * C;
+    const int full = R == 0 ? U : k * C;                 // units [0, full) stay whole
+    const int S = R == 0 ? 1 : min(ATT_SPLIT_MAX, C / R);
+    const int w = blockIdx.x;
+    int unit = w;
+    if (w >= full) {
+      const int idx = w - full;
+      su = idx / S;
+      unit = full + su;
+      piece = idx - su * S;
+      n_piece = S;
+      if (unit >= U) return;
+    }
+    m = unit / NHEAD;
+    h = unit - m * NHEAD;
+  } else if (rm.q_per_b == 1 && row_absent(rm.n_active, m)) return;
   int b, slot, jlo;
   if (rm.desc != nullptr) {   // decode: one 16-byte load instead of the row_map -> len -> kv_start / finish chain
     const RowDesc d = rm.desc[m];
@@ -259,12 +290,19 @@ __global__ __launch_bounds__(64 * NW) void attention_k(const float* __restrict__
 #pragma unroll
   for (int i = 0; i < DPL; ++i) acc[i] = 0.f;
 
-  // each wave owns one contiguous, KPI-aligned share of the visible keys (balanced: a context of n
+  // this workgroup's key range [rbeg, rend): all visible keys, or one of n_piece KPI-aligned pieces of them
+  int rbeg = jlo, rend = slot + 1;
+  if (SPLIT && n_piece > 1) {
+    const int pper = ((slot + 1 - jlo + n_piece - 1) / n_piece + KPI - 1) / KPI * KPI;
+    rbeg = jlo + piece * pper;
+    rend = min(rbeg + pper, slot + 1);
+  }
+  // each wave owns one contiguous, KPI-aligned share of those keys (balanced: a context of n
   // keys costs every wave ceil(n / NW / KB) blocks instead of giving wave 0 the remainder blocks)
-  const int nkeys = slot - jlo + 1;
+  const int nkeys = max(rend - rbeg, 0);
   const int per = ((nkeys + NW - 1) / NW + KPI - 1) / KPI * KPI;
-  const int jbeg = jlo + wave * per;
-  const int jend = min(jbeg + per, slot + 1);  // exclusive
+  const int jbeg = rbeg + wave * per;
+  const int jend = min(jbeg + per, rend);  // exclusive
 
   u128 kA[NI], vA[NI], kB[NI], vB[NI];
   // Loads are UNCONDITIONAL with the key index clamped into the wave's range: a per-lane `if (j < jend) load`
@@ -363,6 +401,42 @@ __global__ __launch_bounds__(64 * NW) void attention_k(const float* __restrict__
       L += sm_l[w] * sc;
       o += sm_acc[w][tid] * sc;
     }
+    if (SPLIT && n_piece > 1) {
+      // hand-off through memory: partial -> write-through stores -> drain -> ticket; the last arriver merges
+      unsigned* P = reinterpret_cast<unsigned*>(rm.sp_part + ((size_t)su * ATT_SPLIT_MAX + piece) * 66);
+      __hip_atomic_store(P + tid, __float_as_uint(o), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tid == 0) {
+        __hip_atomic_store(P + 64, __float_as_uint(M), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(P + 65, __float_as_uint(L), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's partial has left (tid < 64: wave 0 only)
+      int ticket = 0;
+      if (tid == 0) ticket = __hip_atomic_fetch_add(rm.sp_cnt + su, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ticket = __builtin_amdgcn_readfirstlane(ticket);
+      if (ticket != n_piece - 1) return;
+      const unsigned* Q = reinterpret_cast<const unsigned*>(rm.sp_part + (size_t)su * ATT_SPLIT_MAX * 66);
+      float pm[ATT_SPLIT_MAX], pl[ATT_SPLIT_MAX], po[ATT_SPLIT_MAX];
+      float Mx = -INFINITY;
+#pragma unroll
+      for (int p = 0; p < ATT_SPLIT_MAX; ++p) {
+        if (p < n_piece) {
+          pm[p] = __uint_as_float(__hip_atomic_load(Q + p * 66 + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+          pl[p] = __uint_as_float(__hip_atomic_load(Q + p * 66 + 65, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+          po[p] = __uint_as_float(__hip_atomic_load(Q + p * 66 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+          Mx = fmaxf(Mx, pm[p]);
+        }
+      }
+      L = 0.f; o = 0.f;
+#pragma unroll
+      for (int p = 0; p < ATT_SPLIT_MAX; ++p) {
+        if (p < n_piece) {
+          const float sc = (pm[p] == -INFINITY) ? 0.f : expf(pm[p] - Mx);
+          L += pl[p] * sc;
+          o += po[p] * sc;
+        }
+      }
+      if (tid == 0) __hip_atomic_store(rm.sp_cnt + su, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    }
     store_out<OT>(PKO ? out + pk_off(m, h * HDIM + tid, HID / 32) : out + (size_t)m * HID + h * HDIM + tid, o / L);
   }
 }
@@ -375,7 +449,11 @@ hipError_t launch_attention(const float* qkv, const void* kcache, const void* vc
   if (nw8 < 0) { const char* e = getenv("CTTS_ATT_NW"); nw8 = (e && atoi(e) == 8) ? 1 : 0; }
   if (out_bf16 == 2) {   // decode, perf mode: bf16 output in the fragment-packed order the o_proj kernel of decode.hip reads
     if (!decode || kv_wt != WT_BF16) return hipErrorInvalidValue;
-    CTTS_LAUNCH((attention_k<bf16_t, 4, bf16_t, true>), grid, dim3(256), st, qkv, (const bf16_t*)kcache, (const bf16_t*)vcache, cmax, (bf16_t*)out, rm);
+    if (rm.sp_cus > 0 && rm.sp_part != nullptr && rm.sp_cnt != nullptr)
+      CTTS_LAUNCH((attention_k<bf16_t, 4, bf16_t, true, true>), dim3(NHEAD * M + rm.sp_cus), dim3(256), st, qkv, (const bf16_t*)kcache,
+                  (const bf16_t*)vcache, cmax, (bf16_t*)out, rm);
+    else
+      CTTS_LAUNCH((attention_k<bf16_t, 4, bf16_t, true>), grid, dim3(256), st, qkv, (const bf16_t*)kcache, (const bf16_t*)vcache, cmax, (bf16_t*)out, rm);
     return hipGetLastError();
   }
   if (decode && nw8 && kv_wt == WT_BF16 && out_bf16) {

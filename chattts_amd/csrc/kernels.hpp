@@ -142,7 +142,12 @@ struct GptRowMap {
                             // until every row is done (gpt.py:512-518,592) but truncates their output at end_idx, so
                             // their per-step work is unobservable: the attention kernel skips their KV read.
   const RowDesc* desc;      // decode, optional: this step's row descriptors (replaces the row_map/len/kv_start/finish chain)
+  // decode, perf mode, optional: remainder splitting of the (utterance, head) units over workgroups (see attention_k)
+  float* sp_part;           // [sp_cus][ATT_SPLIT_MAX][66] partial (o[64], m, l) of the split units' pieces
+  int32_t* sp_cnt;          // [sp_cus] arrival counters, zero between launches (the last arriver resets its counter)
+  int sp_cus;               // compute units of the device (0: no splitting)
 };
+#define ATT_SPLIT_MAX 8
 
 // what the first kernel of a decode step additionally produces: the row descriptors, and (xb_packed) the bf16 copy of
 // the embedding in the fragment-packed order of decode.hip instead of row-major

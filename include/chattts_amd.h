@@ -268,6 +268,12 @@ int ctts_k_rope_append(float* qkv, void* kcache, void* vcache, int32_t kv_dtype,
                        int32_t q_per_b, const int32_t* len, const int32_t* kv_start, int32_t M, void* stream);
 int ctts_k_attention(const float* qkv, const void* kcache, const void* vcache, int32_t kv_dtype, int32_t cmax, float* out,
                      int32_t q_per_b, const int32_t* len, const int32_t* kv_start, int32_t M, void* stream);
+/* decode attention of the perf mode: one query row per utterance, bf16 KV cache [slots,12,cmax,64], output bf16 in the fragment-packed
+ * order of csrc/decode.hip; desc [M][4] int32 = {utterance slot (-1: skip), KV slot of the query, RoPE position (unused here), first
+ * visible key}; n_active: device scalar or NULL (M).  n_cu > 0 with part ([n_cu][8][66] f32) and cnt ([n_cu] int32, zeroed) turns on
+ * remainder splitting of the (utterance, head) units over workgroups (csrc/gpt.hip attention_k); n_cu = 0: one workgroup per unit. */
+int ctts_k_attention_dec(const float* qkv, const uint16_t* kcache, const uint16_t* vcache, int32_t cmax, uint16_t* out_packed,
+                         const int32_t* desc, const int32_t* n_active, int32_t M, float* part, int32_t* cnt, int32_t n_cu, void* stream);
 int ctts_k_embed_codes(const float* emb_code, const int64_t* ids_buf, int32_t tcap, const int32_t* len, float* x, int32_t B, void* stream);
 int ctts_k_final_norm(const float* x, int32_t q_per_b, const float* w, float eps, float* hfin, float* hiddens, int32_t max_new,
                       const int32_t* len, int32_t T, int32_t B, void* stream);

@@ -318,6 +318,37 @@ def test_packed_decode_equals_row_major_decode(weights, monkeypatch):
         assert float((a - b).abs().max()) < 1e-4
 
 
+def test_attention_split_in_the_engine(weights, golden, monkeypatch):
+    """the whole decode step with and without the attention remainder splitting, teacher-forced on the same token stream
+    (the c3w batch: 64 utterances whose number drops as they finish, so the split geometry changes from step to step):
+    hidden states agree to bf16-rounding noise at every step"""
+    c = cases.BIG_CASES["c3w"]
+    Gd = golden["generate_big"]
+    ids, mask, tmask = cases.gen_inputs(c)
+    B, n = ids.shape[0], c["max_new"]
+    lens, rows = _golden_rows(Gd, "c3w", B)
+    teacher = np.zeros((B, n, 4), np.int64)
+    for b in range(B):
+        teacher[b, : lens[b]] = rows[b]
+        if lens[b] < n:
+            teacher[b, lens[b]] = 625
+    ids_t, mask_t = torch.from_numpy(ids), torch.from_numpy(mask)
+    warpers, procs = E.gen_logits(625, c["top_P"], c["top_K"], c["rep"])
+    hid = []
+    for split in ("1", "0"):
+        monkeypatch.setenv("CTTS_ATT_SPLIT", split)
+        eng = E.GptEngine(weights["gpt"], weights["embed"], DEV, dtype="bf16")
+        emb = eng.embed_prompt(ids_t, torch.from_numpy(tmask))
+        out = list(eng.generate(emb, ids_t, torch.tensor(c["temperature"]), 625, mask_t, n, c["min_new"], (*procs, *warpers),
+                                return_hidden=True, manual_seed=c["manual_seed"], teacher_ids=torch.from_numpy(teacher)))[-1]
+        assert [int(t.shape[0]) for t in out.ids] == lens.tolist()
+        hid.append([h.cpu().numpy() for h in out.hiddens])
+        del eng
+    worst = max(float(np.abs(a - b).max() / np.abs(b).max()) for a, b in zip(*hid) if len(a))
+    print(f"attention split vs whole units, teacher-forced c3w: worst hidden rel diff {worst:.3e}")
+    assert worst < 1e-2
+
+
 @pytest.mark.parametrize("name", list(cases.CODEC_CASES))
 def test_codec_vs_reference_golden(codec, golden, name):
     c = cases.CODEC_CASES[name]

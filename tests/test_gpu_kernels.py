@@ -439,6 +439,56 @@ def test_rope_attention(G, kv):
         assert err < 2e-5, (extra, err)
 
 
+@pytest.mark.parametrize("n_live", [1, 3, 10, 21, 22, 40, 45, 64])
+def test_attention_decode_remainder_split(G, n_live):
+    """decode attention of the perf mode (bf16 KV, packed bf16 output) with remainder splitting: 12 * n_live units on 256 CUs
+    -- whole units, units cut into 2..8 key ranges that meet through memory (write-through partials, ticket counter, last
+    arriver merges) -- equals the float64 reference and, to bf16 rounding, the unsplit kernel; three launches in a row
+    re-use the partial buffers and the counters (each last arriver resets its own)."""
+    from chattts_amd.engine import unpack_frag
+    lib = _lib.lib()
+    rs = np.random.RandomState(100 + n_live)
+    B, nh, d, H, cmax = 64, 12, 64, 768, 640
+    Bp = 64
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    kc = G.dev(G.bf16_round(rs.standard_normal((B, nh, cmax, d)).astype(f32)), torch.bfloat16)
+    vc = G.dev(G.bf16_round(rs.standard_normal((B, nh, cmax, d)).astype(f32)), torch.bfloat16)
+    Kc, Vc = kc.float().cpu().numpy(), vc.float().cpu().numpy()
+    part = torch.zeros((512 * 8 * 66,), dtype=torch.float32, device=G.DEV)
+    cnt = torch.zeros((512,), dtype=torch.int32, device=G.DEV)
+    na = G.dev(np.array([n_live], np.int32))
+    for rep in range(3):
+        slots_b = rs.permutation(B)[:n_live]                       # compact row m -> utterance slot
+        jlo = rs.randint(0, 30, size=n_live)
+        slot = np.array([rs.randint(jlo[m] + 1, cmax) if rs.rand() < 0.8 else jlo[m] + rs.randint(0, 12) for m in range(n_live)])
+        desc = np.zeros((Bp, 4), np.int32)
+        desc[:n_live, 0], desc[:n_live, 1], desc[:n_live, 2], desc[:n_live, 3] = slots_b, slot, slot - jlo, jlo
+        qkv = rs.standard_normal((Bp, 3 * H)).astype(f32)
+        q_d, desc_d = G.dev(qkv), G.dev(desc)
+        outs = []
+        for n_cu in (ncu, 0):
+            o = torch.full((Bp * H,), float("nan"), dtype=torch.bfloat16, device=G.DEV)
+            _lib.check(lib.ctts_k_attention_dec(q_d.data_ptr(), kc.data_ptr(), vc.data_ptr(), cmax, o.data_ptr(), desc_d.data_ptr(),
+                                                na.data_ptr(), Bp, part.data_ptr(), cnt.data_ptr(), n_cu, None), "attention_dec")
+            torch.cuda.synchronize()
+            outs.append(unpack_frag(o.float().cpu(), Bp, H).numpy())
+        assert int(cnt.abs().sum()) == 0                            # every counter went back to zero
+        ref = np.zeros((n_live, H))
+        for m in range(n_live):
+            b = slots_b[m]
+            q = qkv[m, :H].reshape(nh, d).astype(np.float64)
+            Kb, Vb = Kc[b, :, jlo[m]: slot[m] + 1].astype(np.float64), Vc[b, :, jlo[m]: slot[m] + 1].astype(np.float64)
+            sc = np.einsum("hd,hjd->hj", q, Kb) * 0.125
+            p = np.exp(sc - sc.max(-1, keepdims=True))
+            p /= p.sum(-1, keepdims=True)
+            ref[m] = np.einsum("hj,hjd->hd", p, Vb).reshape(H)
+        split, whole = outs
+        assert np.isfinite(split[:n_live]).all() and np.isnan(split[n_live:]).all()
+        assert np.abs(split[:n_live] - ref).max() < 1.5e-2, np.abs(split[:n_live] - ref).max()      # bf16 output (|o| <~ 3)
+        assert np.abs(split[:n_live] - whole[:n_live]).max() < 1.6e-2                                # at most one bf16 ulp apart
+        assert (split[:n_live] != whole[:n_live]).mean() < 0.02
+
+
 # ------------------------------------------------------------------------------------------------
 def test_embed_and_final_norm(G):
     lib = _lib.lib()
