@@ -86,6 +86,7 @@ SIGNATURES = {
     "ctts_gpt_destroy": (None, [P]),
     "ctts_gpt_workspace_bytes": (SZ, [I32, I32]),
     "ctts_gpt_prefill": (C.c_int, [P, C.POINTER(GenState), P, P]),
+    "ctts_gpt_prefill_chunk": (C.c_int, [P, C.POINTER(GenState), P, I32, I32, I32, P]),
     "ctts_gpt_decode_step": (C.c_int, [P, C.POINTER(GenState), P]),
     "ctts_gpt_graph_build": (C.c_int, [P, C.POINTER(GenState), P]),
     "ctts_gpt_graph_launch": (C.c_int, [P, I32, P]),

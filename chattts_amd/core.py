@@ -78,6 +78,7 @@ class Chat:
         self.tokenizer: Optional[Tokenizer] = None
         self.speaker: Optional[Speaker] = None
         self.normalizer = Normalizer(homophones_map, logger)
+        self.incremental_stream = True   # stream=True decodes token windows with halos, not the whole prefix per yield
 
     def has_loaded(self, use_decoder: bool = True) -> bool:
         """core.py:50-66: the decoder path needs `Decoder.safetensors`, the `use_decoder=False` path the full DVAE"""
@@ -187,29 +188,37 @@ class Chat:
             return np.zeros((0,), np.float32)
         return self.decode_to_wavs(last.hiddens)
 
+    def _stream_piece(self, hiddens, a: int, b: Optional[int], use_decoder: bool = True) -> np.ndarray:
+        """samples [a, b) (b=None: to the end) of the decode of the current prefix (core.py:482-497), from a token window with
+        halos instead of the whole prefix (`CodecEngine.decode_window`); `incremental_stream=False` restores the reference's
+        full re-decode per yield"""
+        Tn = max(int(r.size(0)) for r in hiddens)
+        total = 256 * (2 * Tn - 1) if use_decoder else None
+        if not use_decoder or not self.incremental_stream:
+            wavs = self.decode_to_wavs(hiddens, use_decoder)
+            return wavs[:, a: wavs.shape[1] if b is None else min(b, wavs.shape[1])]
+        hi = total if b is None else min(b, total)
+        return self.codec.decode_window(hiddens, a, hi).cpu().numpy()
+
     def infer_ids_stream(self, input_ids, attention_mask, text_mask, params: InferCodeParams = InferCodeParams(), **kw):
         """stream=True body of `Chat._infer` for one batch (core.py:455-503): every `stream_batch` live steps the
-        generator yields the cumulative result, the prefix is decoded again (the reference's O(n^2) schedule,
-        App. D-10) and the next `stream_speed` samples are emitted; the first `pass_first_n_batches` yields are
-        dropped (their decode is skipped here: its output is discarded by the reference, core.py:488-490);
-        the tail is emitted with all-silent columns removed (core.py:500-503)."""
+        generator yields the cumulative result and the next `stream_speed` samples of the decode of that prefix are
+        emitted; the first `pass_first_n_batches` yields are dropped (core.py:488-490); the tail is emitted with all-silent
+        columns removed (core.py:500-503).  The reference decodes the WHOLE prefix at every yield (O(n^2), App. D-10);
+        here only the token window those samples depend on is decoded (same samples, O(n) in total), on the caller's
+        stream while the generator's own stream already runs the next chunk."""
         length = 0
         pass_batch_count = 0
-        wavs = None
+        result = None
         for result in self.infer_code(input_ids, attention_mask, text_mask, params, stream=True, **kw):
             pass_batch_count += 1
             if pass_batch_count <= params.pass_first_n_batches:
-                wavs = None
                 continue
-            wavs = self.decode_to_wavs(result.hiddens)
-            a = length
-            b = min(a + params.stream_speed, wavs.shape[1])
-            length = b
-            yield wavs[:, a:b]
-        if wavs is None and pass_batch_count > 0:
-            wavs = self.decode_to_wavs(result.hiddens)
-        if wavs is not None:
-            new_wavs = wavs[:, length:]
+            piece = self._stream_piece(result.hiddens, length, length + params.stream_speed)
+            length += piece.shape[1]
+            yield piece
+        if result is not None:
+            new_wavs = self._stream_piece(result.hiddens, length, None)
             keep_cols = np.sum(np.abs(new_wavs) > 1e-5, axis=0) > 0
             yield new_wavs[:, keep_cols]
 
@@ -322,28 +331,25 @@ class Chat:
             batch = text[lo: lo + step]
             if split_text:
                 self.logger.info("infer split %d~%d", lo, lo + len(batch))
-            wavs, skipped = None, None
+            last = None
             for result in self._infer_code(batch, stream, self.device, use_decoder, params_infer_code):
-                if stream:
-                    pass_batch_count += 1
-                    if pass_batch_count <= params_infer_code.pass_first_n_batches:
-                        # the reference decodes these yields and drops the audio (core.py:482-490); the decode is only
-                        # needed if this turns out to be the LAST yield (the tail below reads `wavs`)
-                        wavs, skipped = None, result
-                        continue
-                wavs, skipped = self.decode_to_wavs(result.hiddens if use_decoder else result.ids, use_decoder), None
-                result.destroy()
-                if stream:
-                    a, b = length, min(length + params_infer_code.stream_speed, wavs.shape[1])
-                    length = b
-                    yield wavs[:, a:b]
-                else:
+                if not stream:
+                    wavs = self.decode_to_wavs(result.hiddens if use_decoder else result.ids, use_decoder)
+                    result.destroy()
                     yield wavs
-            if stream:
-                if wavs is None and skipped is not None:
-                    wavs = self.decode_to_wavs(skipped.hiddens if use_decoder else skipped.ids, use_decoder)
-                if wavs is None:
                     continue
-                new_wavs = wavs[:, length:]
+                if last is not None:
+                    last.destroy()
+                last = result
+                pass_batch_count += 1
+                if pass_batch_count <= params_infer_code.pass_first_n_batches:
+                    continue     # the reference decodes these yields and drops the audio (core.py:482-490)
+                piece = self._stream_piece(result.hiddens if use_decoder else result.ids, length,
+                                           length + params_infer_code.stream_speed, use_decoder)
+                length += piece.shape[1]
+                yield piece
+            if stream and last is not None:
+                new_wavs = self._stream_piece(last.hiddens if use_decoder else last.ids, length, None, use_decoder)
+                last.destroy()
                 keep_cols = np.sum(np.abs(new_wavs) > 1e-5, axis=0) > 0
                 yield new_wavs[:, keep_cols]

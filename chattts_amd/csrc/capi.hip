@@ -192,8 +192,9 @@ static bool dev_compact(const ctts_gpt* g, const ctts_gen_state* s) {
 }
 
 // the 20-layer body + heads + sampling over M = B * q_per_b rows
-static int run_step(ctts_gpt* g, const ctts_gen_state* s, int q_per_b, hipStream_t st, bool prof_ok) {
-  const GptWs ws = carve(s->workspace, s->B, s->T);
+static int run_step(ctts_gpt* g, const ctts_gen_state* s, int q_per_b, hipStream_t st, bool prof_ok, int slot0 = 0, bool heads = true,
+                    int ws_T = 0) {
+  const GptWs ws = carve(s->workspace, s->B, ws_T ? ws_T : s->T);
   const int B = s->B, M = B * q_per_b, cmax = s->cap ? s->cap : s->T + s->max_new;
   const int wt = g->w.weight_dtype, kt = g->w.kv_dtype;
   const size_t kv_layer = (size_t)(s->kv_batch ? s->kv_batch : B) * NHEAD * cmax * HDIM * (kt == CTTS_BF16 ? 2 : 4);
@@ -202,7 +203,7 @@ static int run_step(ctts_gpt* g, const ctts_gen_state* s, int q_per_b, hipStream
   // flags (device-side compaction); prefill: row group -> slot of a pool (or null)
   const int32_t* rmap = (dec && dev_compact(g, s)) ? ws.row_map : s->row_map;
   const int32_t* nact = dec ? s->n_active : nullptr;
-  GptRowMap rm{q_per_b, s->len, s->kv_start, rmap, nact, (dec && g->skip_finished) ? s->finish : nullptr, nullptr, nullptr, nullptr, 0};
+  GptRowMap rm{q_per_b, s->len, s->kv_start, rmap, nact, (dec && g->skip_finished) ? s->finish : nullptr, nullptr, nullptr, nullptr, 0, slot0};
   const bool fast = wt == CTTS_BF16;  // perf mode: bf16 activations, RMSNorm gain folded into wqkv / wgu by the loader
   const bool packed = fast && dec && g->dec_packed;   // decode step on fragment-packed operands (decode.hip)
   if (dec) rm.desc = ws.desc;                          // written by the embedding kernel at the head of the step
@@ -236,7 +237,7 @@ static int run_step(ctts_gpt* g, const ctts_gen_state* s, int q_per_b, hipStream
     uint16_t* actb = (uint16_t*)ws.act;
     FastGemmArgs f;
     memset(&f, 0, sizeof(f));
-    f.M = M; f.eps = g->w.rms_eps; f.n_active = nact; f.row_map = rmap;
+    f.M = M; f.eps = g->w.rms_eps; f.n_active = nact; f.row_map = rmap; f.slot0 = slot0;
     // RMSNorm + QKV + RoPE + KV append in one launch (q/k weight rows are permuted by the loader)
     f.A = ws.xb; f.lda = HID; f.W = (const uint16_t*)g->wqkv[l]; f.N = 3 * HID; f.K = HID; f.ssq_in = ws.ssq; f.epi = FEPI_QKV_ROPE;
     f.C32 = ws.qkv; f.ldc = 3 * HID;
@@ -280,6 +281,7 @@ static int run_step(ctts_gpt* g, const ctts_gen_state* s, int q_per_b, hipStream
     a.res = ws.x; a.ldr = HID;
     { Prof p(g, 6, st, prof_ok); CK(launch_gemm_skinny(a, st)); }
   }
+  if (!heads) return 0;   // a prompt chunk that is not the last one: its K/V rows are in the cache, nothing is sampled
   { Prof p(g, 7, st, prof_ok);
     CK(launch_final_norm(ws.x, q_per_b, g->w.norm, g->w.rms_eps, ws.hfin, s->hiddens, s->hid_cap ? s->hid_cap : s->max_new, s->len, s->T, B, rmap,
                          nact, s->prompt_len, st)); }
@@ -312,6 +314,23 @@ extern "C" int ctts_gpt_prefill(ctts_gpt* g, const ctts_gen_state* s, const floa
   CK(hipMemcpyAsync(ws.x, emb, (size_t)s->B * s->T * HID * 4, hipMemcpyDeviceToDevice, st));
   if (g->w.weight_dtype == CTTS_BF16) CK(launch_rows_prep(ws.x, ws.xb, ws.ssq, s->B * s->T, st));
   return run_step(g, s, s->T, st, false);
+}
+
+extern "C" int ctts_gpt_prefill_chunk(ctts_gpt* g, const ctts_gen_state* s, const float* emb_chunk, int32_t t0, int32_t tc, int32_t last,
+                                      void* stream) {
+  if (check_state(g, s)) return -1;
+  if (t0 < 0 || tc <= 0 || t0 + tc > s->T || (last && t0 + tc != s->T)) return fail("ctts_gpt_prefill_chunk: bad chunk [%d, %d) of a %d-slot prompt", t0, t0 + tc, s->T);
+  if (s->workspace_bytes < ctts_gpt_workspace_bytes(s->B, tc)) return fail("workspace too small for the chunk");
+  CttsDeviceGuard dg(stream);
+  hipStream_t st = (hipStream_t)stream;
+  const GptWs ws = carve(s->workspace, s->B, tc);
+  CK(hipMemcpyAsync(ws.x, emb_chunk, (size_t)s->B * tc * HID * 4, hipMemcpyDeviceToDevice, st));
+  if (g->w.weight_dtype == CTTS_BF16) CK(launch_rows_prep(ws.x, ws.xb, ws.ssq, s->B * tc, st));
+  if (run_step(g, s, tc, st, false, t0, last != 0, tc)) return -1;
+  // the decode steps carve the workspace for the whole prompt length: zero THEIR attention-split arrival counters once the
+  // chunk-sized buffers above are dead
+  if (last) CK(hipMemsetAsync(carve(s->workspace, s->B, s->T).att_cnt, 0, (size_t)ATT_CUS_MAX * sizeof(int32_t), st));
+  return 0;
 }
 
 static int decode_body(ctts_gpt* g, const ctts_gen_state* s, hipStream_t st, bool prof_ok) {
@@ -565,13 +584,13 @@ extern "C" int ctts_k_rows_prep(const float* x32, uint16_t* xb, float* ssq, int3
 extern "C" int ctts_k_rope_append(float* qkv, void* kcache, void* vcache, int32_t kv_dtype, int32_t cmax, const float* cos_tab,
                                   const float* sin_tab, int32_t q_per_b, const int32_t* len, const int32_t* kv_start, int32_t M,
                                   void* stream) {
-  GptRowMap rm{q_per_b, len, kv_start, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+  GptRowMap rm{q_per_b, len, kv_start, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
   CK(launch_rope_append(qkv, kcache, vcache, kv_dtype, cmax, cos_tab, sin_tab, rm, M, (hipStream_t)stream));
   return 0;
 }
 extern "C" int ctts_k_attention(const float* qkv, const void* kcache, const void* vcache, int32_t kv_dtype, int32_t cmax, float* out,
                                 int32_t q_per_b, const int32_t* len, const int32_t* kv_start, int32_t M, void* stream) {
-  GptRowMap rm{q_per_b, len, kv_start, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+  GptRowMap rm{q_per_b, len, kv_start, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
   CK(launch_attention(qkv, kcache, vcache, kv_dtype, cmax, out, 0, rm, M, (hipStream_t)stream));
   return 0;
 }
@@ -579,7 +598,7 @@ extern "C" int ctts_k_attention_dec(const float* qkv, const uint16_t* kcache, co
                                     const int32_t* desc, const int32_t* n_active, int32_t M, float* part, int32_t* cnt, int32_t n_cu,
                                     void* stream) {
   if (n_cu < 0 || n_cu > ATT_CUS_MAX) return fail("ctts_k_attention_dec: bad n_cu");
-  GptRowMap rm{1, nullptr, nullptr, nullptr, n_active, nullptr, reinterpret_cast<const RowDesc*>(desc), part, cnt, n_cu};
+  GptRowMap rm{1, nullptr, nullptr, nullptr, n_active, nullptr, reinterpret_cast<const RowDesc*>(desc), part, cnt, n_cu, 0};
   CK(launch_attention(qkv, kcache, vcache, WT_BF16, cmax, out_packed, 2, rm, M, (hipStream_t)stream));
   return 0;
 }

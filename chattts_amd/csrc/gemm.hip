@@ -334,7 +334,7 @@ void gemm_fast_k(FastGemmArgs a) {
       const int row = min(m0 + lane, M - 1);
       int b, slot;
       if (a.q_per_b == 1) { b = a.row_map ? a.row_map[row] : row; slot = a.len[b] - 1; }
-      else { b = row / a.q_per_b; slot = row - b * a.q_per_b; if (a.row_map) b = a.row_map[b]; }
+      else { b = row / a.q_per_b; slot = a.slot0 + row - b * a.q_per_b; if (a.row_map) b = a.row_map[b]; }
       int pos = slot - a.kv_start[b];
       if (pos < 0) pos = 1;
       const float4 c0 = *reinterpret_cast<const float4*>(a.cos_t + pos * 32 + 8 * t4);

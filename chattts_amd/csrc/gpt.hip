@@ -15,7 +15,7 @@
 
 __device__ __forceinline__ void row_to_b_slot(const GptRowMap& rm, int m, int& b, int& slot) {
   if (rm.q_per_b == 1) { b = rm.row_map ? rm.row_map[m] : m; slot = rm.len[b] - 1; }
-  else { b = m / rm.q_per_b; slot = m - b * rm.q_per_b; if (rm.row_map) b = rm.row_map[b]; }  // prefill into a slot pool
+  else { b = m / rm.q_per_b; slot = rm.slot0 + m - b * rm.q_per_b; if (rm.row_map) b = rm.row_map[b]; }  // prefill (chunk), slot pool
 }
 // decode launches keep the captured grid (B rows); rows beyond the compact active count do nothing
 __device__ __forceinline__ bool row_absent(const int32_t* n_active, int m) { return n_active != nullptr && m >= *n_active; }

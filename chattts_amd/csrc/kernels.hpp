@@ -81,6 +81,7 @@ struct FastGemmArgs {
   const int32_t* n_active;      // decode: device scalar, rows >= *n_active are not computed; null = M
   const float* cos_t; const float* sin_t;                     // [max_pos, 32]
   uint16_t* kc; uint16_t* vc; int cmax;                       // this layer's bf16 K / V cache [B,12,cmax,64]
+  int slot0;                    // prefill in chunks: first prompt slot of this chunk (row m -> slot0 + m % q_per_b)
   int force_mb;                 // tests only: 0 = heuristic
   int w_nt;                     // 1: non-temporal W loads when a single M tile reads W (set by the launcher, env CTTS_W_NT=0 disables)
   long long* dbg;               // probes only: [n_workgroups][8] phase stamps, or null
@@ -127,7 +128,8 @@ hipError_t launch_gemm_dec(const DecGemmArgs& a, hipStream_t st);
 
 // ---- GPT step kernels -------------------------------------------------------------------------
 struct GptRowMap {
-  // query row m of a launch maps to (b, slot): prefill (q_per_b = T): b = m / T, slot = m % T;
+  // query row m of a launch maps to (b, slot): prefill (q_per_b = T): b = m / T, slot = slot0 + m % T (slot0 > 0: a later
+  // chunk of a prompt that is prefilled in pieces);
   // decode (q_per_b = 1): b = row_map ? row_map[m] : m, slot = len[b] - 1, and rows m >= *n_active do not exist.
   // Decode activations are COMPACT: the host packs the still-running utterances to the front (row_map, n_active;
   // refreshed at every finish poll), every per-utterance array (ids_buf, len, KV cache, hiddens, q ...) stays
@@ -146,6 +148,7 @@ struct GptRowMap {
   float* sp_part;           // [sp_cus][ATT_SPLIT_MAX][66] partial (o[64], m, l) of the split units' pieces
   int32_t* sp_cnt;          // [sp_cus] arrival counters, zero between launches (the last arriver resets its counter)
   int sp_cus;               // compute units of the device (0: no splitting)
+  int slot0;                // prefill: first prompt slot of the chunk this launch covers
 };
 #define ATT_SPLIT_MAX 8
 

@@ -144,7 +144,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_prefill_k(FastGemmArgs a) {
         int b, slot;
         const int rr = min(row, M - 1);
         if (a.q_per_b == 1) { b = a.row_map ? a.row_map[rr] : rr; slot = a.len[b] - 1; }
-        else { b = rr / a.q_per_b; slot = rr - b * a.q_per_b; if (a.row_map) b = a.row_map[b]; }
+        else { b = rr / a.q_per_b; slot = a.slot0 + rr - b * a.q_per_b; if (a.row_map) b = a.row_map[b]; }
         int pos = slot - a.kv_start[b];
         if (pos < 0) pos = 1;
 #pragma unroll

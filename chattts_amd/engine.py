@@ -299,7 +299,7 @@ class GptEngine:
                  *, use_graph: bool = True, stop_at: Optional[torch.Tensor] = None, row_offset: int = 0,
                  total_rows: Optional[int] = None, profile_tag: Optional[int] = None,
                  profile_stride: int = 1, lanes: Optional[int] = None,
-                 teacher_ids: Optional[torch.Tensor] = None) -> Iterator[GenerationOutputs]:
+                 teacher_ids: Optional[torch.Tensor] = None, prefill_chunk: Optional[int] = None) -> Iterator[GenerationOutputs]:
         """Drop-in for `GPT.generate` (gpt.py:316-337), code mode.  Extra keyword-only arguments:
         `use_graph` (hipGraph replay of the decode step), `stop_at` ([B] int32 forced output lengths,
         benchmark hook), `row_offset`/`total_rows` (this shard's position inside a data-parallel batch:
@@ -308,7 +308,9 @@ class GptEngine:
         with its own captured graph; utterances never interact, so the result is identical, while the
         per-kernel launch / dependent-load latency of one lane overlaps the others' kernels), `teacher_ids`
         ([B, max_new_token, 4] int64: teacher forcing -- the token written at step i is teacher_ids[:, i] instead of
-        the sampled one; evaluation hook used to bound the bf16 mode's drift on the reference's token stream)."""
+        the sampled one; evaluation hook used to bound the bf16 mode's drift on the reference's token stream),
+        `prefill_chunk` (tokens: the prompt is prefilled in pieces of that many slots -- `ctts_gpt_prefill_chunk` -- which
+        bounds the activation workspace of a long prompt such as an `spk_smp` audio-code prompt, core.py:435-453)."""
         if return_attn:
             raise NotImplementedError("return_attn is not supported by the fused attention kernel")
         context = context or Context()
@@ -585,7 +587,17 @@ class GptEngine:
         # ---- step 0: prefill ----
         ensure_q(1)
         for ln in L:
-            _lib.check(lib.ctts_gpt_prefill(ln.handle, C.byref(ln.s), ln.emb.data_ptr(), ln.st.cuda_stream), "ctts_gpt_prefill")
+            if prefill_chunk is None or int(prefill_chunk) >= T:
+                _lib.check(lib.ctts_gpt_prefill(ln.handle, C.byref(ln.s), ln.emb.data_ptr(), ln.st.cuda_stream), "ctts_gpt_prefill")
+            else:
+                tc = max(1, int(prefill_chunk))
+                with torch.cuda.stream(ln.st):
+                    for t0 in range(0, T, tc):
+                        n = min(tc, T - t0)
+                        piece = ln.emb[:, t0: t0 + n].contiguous()
+                        _lib.check(lib.ctts_gpt_prefill_chunk(ln.handle, C.byref(ln.s), piece.data_ptr(), t0, n, int(t0 + n == T),
+                                                              ln.st.cuda_stream), "ctts_gpt_prefill_chunk")
+                        ln.keep_piece = piece   # stream-ordered use: stays alive until the next piece replaces it / the poll syncs
         steps_done = 1
         steps_enq = 1     # steps enqueued so far (>= steps_done: chunks run ahead of the host's finish polls)
         graph_ok = False
@@ -817,6 +829,36 @@ class CodecEngine:
         st = torch.cuda.current_stream(self.device).cuda_stream
         _lib.check(self.lib.ctts_vocos_decode(self.handle, mel.data_ptr(), wav.data_ptr(), B, F, ws.data_ptr(), n, st), "ctts_vocos_decode")
         return wav
+
+    # receptive field of one output sample, in mel frames either side: ISTFT 4 overlapping frames; Vocos embed k7 + 8 ConvNeXt
+    # blocks k7 = 27; DVAE conv_in k3 + k3, 12 ConvNeXt blocks k7 dilation 2, out_conv k3 = 75 (dvae.py:145-161, config.py:83-121)
+    HALO_FRAMES = 27 + 75
+
+    def decode_window(self, result_list: List[torch.Tensor], s_lo: int, s_hi: int) -> torch.Tensor:
+        """Samples [s_lo, s_hi) of `decode_to_wavs(result_list)` WITHOUT decoding the whole batch: the acoustic decoder is a
+        stack of short symmetric convolutions, so those samples depend only on the tokens within HALO_FRAMES mel frames
+        (+ the 4 overlapping ISTFT frames) of them.  Only that token window (zero padded like core.py:525-533) goes
+        through DVAE + Vocos; at the true ends of the sequence the window is the sequence's own edge, so the result equals
+        the full decode up to summation order.  This is what makes streaming O(n): the reference re-decodes the entire
+        prefix at every yield (core.py:482-497) to hand out the next `stream_speed` samples of it."""
+        Tn = max(int(r.size(0)) for r in result_list)
+        total = VOCOS.hop * (2 * Tn - 1)
+        s_lo, s_hi = max(0, int(s_lo)), min(total, int(s_hi))
+        if s_hi <= s_lo:
+            return torch.empty((len(result_list), 0), dtype=torch.float32, device=self.device)
+        hop, nfft = VOCOS.hop, VOCOS.n_fft
+        f_a = (s_lo + nfft // 2) // hop - (nfft // hop - 1)          # first / last ISTFT frame that overlaps the samples
+        f_b = min((s_hi - 1 + nfft // 2) // hop, 2 * Tn - 1)
+        t_lo = max(0, (f_a - self.HALO_FRAMES) // 2)
+        t_hi = min(Tn, (f_b + self.HALO_FRAMES) // 2 + 1)
+        batch = torch.zeros((len(result_list), t_hi - t_lo, GPT.hidden), dtype=torch.float32, device=self.device)
+        for i, r in enumerate(result_list):
+            n = min(int(r.size(0)), t_hi) - t_lo
+            if n > 0:
+                batch[i, :n] = r[t_lo: t_lo + n]
+        wav = self.vocos_decode(self.dvae_decode(batch))
+        off = 2 * hop * t_lo                                          # sample index of the window's first sample
+        return wav[:, s_lo - off: s_hi - off]
 
     def decode_to_wavs(self, result_list: List[torch.Tensor]) -> torch.Tensor:
         """`Chat._decode_to_wavs` (core.py:513-539): zero-pad the per-row [T_b,768] hidden lists to the

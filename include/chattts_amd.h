@@ -129,6 +129,11 @@ size_t ctts_gpt_workspace_bytes(int32_t B, int32_t T);
  * cache, writes hiddens[:,0], samples token 0 into ids_buf[:,T], sets len = T+1.  In bf16 mode the four projections of
  * a layer run on LDS-tiled 128x128x64 MFMA tiles when B*T >= 256 rows (csrc/prefill.hip), on the decode kernels below that. */
 int ctts_gpt_prefill(ctts_gpt* g, const ctts_gen_state* s, const float* emb, void* stream);
+/* The same step 0 in pieces (long prompts, e.g. an `spk_smp` audio-code prompt of hundreds of tokens, core.py:435-453; interleaving
+ * the prefill of newly admitted requests with running decode steps): chunk [t0, t0+tc) of the padded prompt of every row, emb_chunk
+ * [B, tc, 768] f32.  Chunks must be issued in order; keys of earlier chunks are read from the KV cache.  Only the call with last != 0
+ * (t0 + tc == T) runs the final norm / heads / sampling.  The workspace need only hold ctts_gpt_workspace_bytes(B, tc). */
+int ctts_gpt_prefill_chunk(ctts_gpt* g, const ctts_gen_state* s, const float* emb_chunk, int32_t t0, int32_t tc, int32_t last, void* stream);
 /* one iteration i > 0 of gpt.py:394-577, eager launches */
 int ctts_gpt_decode_step(ctts_gpt* g, const ctts_gen_state* s, void* stream);
 /* capture one decode step into a hipGraph (all per-step state is read from device memory, so the

@@ -377,6 +377,41 @@ def test_decode_to_wavs_padding(codec, weights):
     assert float(np.sqrt(np.mean((wav - ref) ** 2))) < 1e-4
 
 
+def test_decode_window_equals_slices_of_the_full_decode(codec):
+    """`CodecEngine.decode_window` (what streaming emits): any sample range of the batch decode, computed from the token
+    window it depends on (+ halos) -- interior ranges, ranges touching either end, ragged rows shorter than the window"""
+    rs = np.random.RandomState(12)
+    rows = [torch.from_numpy(rs.standard_normal((n, 768)).astype(np.float32)).to(DEV) for n in (300, 170, 260, 40)]
+    full = codec.decode_to_wavs(rows).cpu().numpy()
+    total = full.shape[1]
+    assert total == 256 * (2 * 300 - 1)
+    for lo, hi in [(0, 12000), (12000, 24000), (60000, 72000), (100000, 100001), (total - 9000, total), (0, total), (total, total + 5)]:
+        got = codec.decode_window(rows, lo, hi).cpu().numpy()
+        want = full[:, lo: min(hi, total)]
+        assert got.shape == want.shape, (lo, hi, got.shape, want.shape)
+        if want.size:
+            assert float(np.sqrt(np.mean((got - want) ** 2))) < 2e-6, (lo, hi)
+            assert np.abs(got - want).max() < 1e-4
+
+
+@pytest.mark.parametrize("chunk", [5, 16])
+def test_chunked_prefill_bit_exact(gpt_f32, golden, chunk):
+    """the prompt prefilled in pieces (`ctts_gpt_prefill_chunk`: keys of earlier pieces come from the KV cache, only the last
+    piece samples) produces the reference's golden ids like the one-shot prefill -- mixed-length left-padded batch b8"""
+    c = cases.GEN_CASES["b8"]
+    ids, mask, tmask = cases.gen_inputs(c)
+    ids_t, mask_t = torch.from_numpy(ids), torch.from_numpy(mask)
+    emb = gpt_f32.embed_prompt(ids_t, torch.from_numpy(tmask))
+    warpers, procs = E.gen_logits(625, c["top_P"], c["top_K"], c["rep"])
+    out = list(gpt_f32.generate(emb, ids_t, torch.tensor(c["temperature"]), 625, mask_t, c["max_new"], c["min_new"], (*procs, *warpers),
+                                return_hidden=True, manual_seed=c["manual_seed"], prefill_chunk=chunk))[-1]
+    got = np.concatenate([t.cpu().numpy() for t in out.ids], 0)
+    assert np.array_equal(np.array([int(t.shape[0]) for t in out.ids]), golden["generate"]["b8.lens"])
+    assert np.array_equal(got, golden["generate"]["b8.ids"])
+    for b in c["keep_hidden_rows"]:
+        assert np.abs(out.hiddens[b].cpu().numpy() - golden["generate"][f"b8.hid{b}"]).max() < 2e-4
+
+
 def test_full_size_properties(gpt_bf16, codec):
     """BASELINE-size batch (B=64, mixed lengths): size-independent properties -- forced lengths are
     honoured exactly, every id is in range, EOS never appears inside a row, the waveform is finite and
