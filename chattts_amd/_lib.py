@@ -112,6 +112,7 @@ SIGNATURES = {
     "ctts_k_rows_prep": (C.c_int, [P, P, P, I32, P]),
     "ctts_k_rope_append": (C.c_int, [P, P, P, I32, I32, P, P, I32, P, P, I32, P]),
     "ctts_k_attention": (C.c_int, [P, P, P, I32, I32, P, I32, P, P, I32, P]),
+    "ctts_k_attention_prefill": (C.c_int, [P, P, P, I32, P, I32, I32, P, I32, P]),
     "ctts_k_attention_dec": (C.c_int, [P, P, P, I32, P, P, P, I32, P, P, I32, P]),
     "ctts_k_embed_codes": (C.c_int, [P, P, I32, P, P, I32, P]),
     "ctts_k_final_norm": (C.c_int, [P, I32, P, F, P, P, I32, P, I32, I32, P]),

@@ -594,6 +594,12 @@ extern "C" int ctts_k_attention(const float* qkv, const void* kcache, const void
   CK(launch_attention(qkv, kcache, vcache, kv_dtype, cmax, out, 0, rm, M, (hipStream_t)stream));
   return 0;
 }
+extern "C" int ctts_k_attention_prefill(const float* qkv, const uint16_t* kcache, const uint16_t* vcache, int32_t cmax, float* out, int32_t q_per_b,
+                                        int32_t slot0, const int32_t* kv_start, int32_t M, void* stream) {
+  GptRowMap rm{q_per_b, nullptr, kv_start, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, slot0};
+  CK(launch_attention(qkv, kcache, vcache, WT_BF16, cmax, out, 0, rm, M, (hipStream_t)stream));
+  return 0;
+}
 extern "C" int ctts_k_attention_dec(const float* qkv, const uint16_t* kcache, const uint16_t* vcache, int32_t cmax, uint16_t* out_packed,
                                     const int32_t* desc, const int32_t* n_active, int32_t M, float* part, int32_t* cnt, int32_t n_cu,
                                     void* stream) {

@@ -441,10 +441,161 @@ __global__ __launch_bounds__(64 * NW) void attention_k(const float* __restrict__
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// G5 (prefill, perf mode, long prompts): flash-style attention on the matrix cores.  The one-wave-per-(row, head) kernel
+// above re-streams a row's keys for every query row -- O(T^2) cache traffic and scalar FMAs; fine for the 16-48 token text
+// prompts of the benchmark configs (35 us per layer), not for an `spk_smp` audio-code prompt of several hundred tokens
+// (core.py:435-453).  Here a workgroup owns 64 consecutive query rows of one (utterance, head): each of its 4 waves holds 16
+// query rows as the A operand of v_mfma_f32_16x16x32_bf16 (q * 1/8, rounded to bf16), the workgroup walks the visible keys in
+// blocks of 32 staged through LDS once for all 4 waves (K row-major for S = Q K^T, V TRANSPOSED so that a B fragment of
+// P V is one 16-byte LDS read), keeps the running row max / sum of the online softmax in the MFMA C layout
+// (row = 4 (lane >> 4) + r), turns P into an A operand through a per-wave LDS tile, and accumulates O[16 x 64] in 4 MFMA tiles.
+// Mask = the reference's causal + left-pad mask (keys kv_start[b] .. slot; a pad query row sees only itself, its output is never
+// consumed).  Reference math: /root/reference/examples/onnx/modeling_llama.py:455-475 (softmax(q k^T / 8 + mask) v in f32;
+// here P and V enter the second product as bf16, like every other activation of the perf mode).
+// ------------------------------------------------------------------------------------------------
+template <typename OT>
+__global__ __launch_bounds__(256) void attention_prefill_mfma_k(const float* __restrict__ qkv, const bf16_t* __restrict__ kc,
+                                                                const bf16_t* __restrict__ vc, int cmax, OT* __restrict__ out, GptRowMap rm) {
+  constexpr int KB = 32;                 // keys per block
+  constexpr int KLD = HDIM + 8;          // K tile row stride (bf16): 144 B, conflict-free 16-byte fragment reads
+  constexpr int VLD = KB + 8;            // V^T tile row stride (bf16): 80 B
+  __shared__ __attribute__((aligned(16))) bf16_t Ks[KB][KLD];
+  __shared__ __attribute__((aligned(16))) bf16_t Vt[HDIM][VLD];
+  __shared__ __attribute__((aligned(16))) bf16_t Ps[4][16][VLD];
+
+  const int T = rm.q_per_b;
+  const int qt = blockIdx.x, h = blockIdx.y, bq = blockIdx.z;        // query tile of 64 rows, head, prompt row group
+  const int b = rm.row_map ? rm.row_map[bq] : bq;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 15, g = lane >> 4;
+  const int kvs = rm.kv_start[b];
+  const int t0 = qt * 64;                                             // first query index (within the chunk) of this workgroup
+  if (t0 >= T) return;
+  const int tq = t0 + wave * 16;                                      // this wave's first query index
+  // A operand: lane (li, g) holds q[row li][c * 32 + g * 8 .. + 8] for the two 32-wide d chunks, scaled by 1/8
+  // (q stays f32-accurate: q/8 = hi + lo in bf16, two MFMAs per product -- the decode kernel keeps q in f32 as well)
+  bf16x8 qa[2], ql[2];
+  {
+    const int t = min(tq + li, T - 1);
+    const float* qp = qkv + ((size_t)bq * T + t) * (3 * HID) + h * HDIM + g * 8;
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float v = qp[c * 32 + e] * 0.125f;
+        const __bf16 hi = (__bf16)v;
+        qa[c][e] = hi;
+        ql[c][e] = (__bf16)(v - (float)hi);
+      }
+  }
+  // rows of this lane in the C layout: r -> query index tq + 4 g + r, its KV slot and first visible key
+  int slot[4], jlo[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    slot[r] = rm.slot0 + min(tq + 4 * g + r, T - 1);
+    jlo[r] = min(kvs, slot[r]);
+  }
+  float mrun[4], lrun[4];
+  f32x4 o[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { mrun[r] = -INFINITY; lrun[r] = 0.f; }
+#pragma unroll
+  for (int d = 0; d < 4; ++d) o[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const bf16_t* kbase = kc + ((size_t)b * NHEAD + h) * cmax * HDIM;
+  const bf16_t* vbase = vc + ((size_t)b * NHEAD + h) * cmax * HDIM;
+  const int slot_first = rm.slot0 + t0, slot_last = rm.slot0 + min(t0 + 63, T - 1);
+  const int jbeg = min(kvs, slot_first) / KB * KB;
+  for (int j0 = jbeg; j0 <= slot_last; j0 += KB) {
+    __syncthreads();   // the previous block's K / V^T tiles have been consumed
+    {  // stage K [32 keys][64 d] and V^T [64 d][32 keys]: thread -> (key = tid / 8, 8 d starting at (tid % 8) * 8)
+      const int key = tid >> 3, d0 = (tid & 7) * 8;
+      const int j = min(j0 + key, cmax - 1);
+      const u128 kv = load16(kbase + (size_t)j * HDIM + d0);
+      u128 vv = load16(vbase + (size_t)j * HDIM + d0);
+      if (j0 + key > slot_last) vv = u128{0u, 0u, 0u, 0u};   // never-written cache rows: 0 * garbage must not become NaN in P V
+      *reinterpret_cast<u128*>(&Ks[key][d0]) = kv;
+      const bf16_t* ve = reinterpret_cast<const bf16_t*>(&vv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) Vt[d0 + e][key] = ve[e];
+    }
+    __syncthreads();
+    // S = Q K^T for the two 16-key halves of the block
+    f32x4 sc[2];
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) {
+      sc[hb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const bf16x8 kb = *reinterpret_cast<const bf16x8*>(&Ks[hb * 16 + li][c * 32 + g * 8]);
+        sc[hb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ql[c], kb, sc[hb], 0, 0, 0);
+        sc[hb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[c], kb, sc[hb], 0, 0, 0);
+      }
+    }
+    // mask + online softmax per query row (a row's 32 scores sit in the 16 lanes of its lane group, 2 per lane)
+    float p[2][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float s0 = sc[0][r], s1 = sc[1][r];
+      const int ja = j0 + li, jb = j0 + 16 + li;
+      if (ja < jlo[r] || ja > slot[r]) s0 = -INFINITY;
+      if (jb < jlo[r] || jb > slot[r]) s1 = -INFINITY;
+      float bm = fmaxf(s0, s1);
+#pragma unroll
+      for (int x = 1; x < 16; x <<= 1) bm = fmaxf(bm, __shfl_xor(bm, x, 64));
+      const float mnew = fmaxf(mrun[r], bm);
+      const float alpha = (mnew == -INFINITY) ? 1.f : expf(mrun[r] - mnew);   // nothing visible yet: keep the zeros
+      const float p0 = (s0 == -INFINITY) ? 0.f : expf(s0 - mnew), p1 = (s1 == -INFINITY) ? 0.f : expf(s1 - mnew);
+      float ps = p0 + p1;
+#pragma unroll
+      for (int x = 1; x < 16; x <<= 1) ps += __shfl_xor(ps, x, 64);
+      lrun[r] = lrun[r] * alpha + ps;
+      mrun[r] = mnew;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) o[d][r] *= alpha;
+      p[0][r] = p0; p[1][r] = p1;
+    }
+    // P (C layout: row 4g+r, key li / 16+li) -> LDS tile [16 rows][32 keys] -> A operand (row li, keys g*8..)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      Ps[wave][4 * g + r][li] = f32_to_bf16(p[0][r]);
+      Ps[wave][4 * g + r][16 + li] = f32_to_bf16(p[1][r]);
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS writes have landed (same-wave read-after-write)
+    __builtin_amdgcn_wave_barrier();
+    const bf16x8 pa = *reinterpret_cast<const bf16x8*>(&Ps[wave][li][g * 8]);
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const bf16x8 vb = *reinterpret_cast<const bf16x8*>(&Vt[d * 16 + li][g * 8]);
+      o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa, vb, o[d], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int t = tq + 4 * g + r;
+    if (t < T) {
+      const float inv = 1.0f / lrun[r];
+      OT* op = out + ((size_t)bq * T + t) * HID + h * HDIM + li;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) store_out<OT>(op + d * 16, o[d][r] * inv);
+    }
+  }
+}
+
 hipError_t launch_attention(const float* qkv, const void* kcache, const void* vcache, int kv_wt, int cmax, void* out, int out_bf16,
                             GptRowMap rm, int M, hipStream_t st) {
   dim3 grid(NHEAD, M);
   const bool decode = rm.q_per_b == 1;
+  static int flash_min = -1;   // CTTS_FLASH_MIN_T: prompt (chunk) length from which prefill uses the MFMA kernel (0 = never)
+  if (flash_min < 0) { const char* e = getenv("CTTS_FLASH_MIN_T"); flash_min = e ? atoi(e) : 128; }
+  if (!decode && kv_wt == WT_BF16 && flash_min > 0 && rm.q_per_b >= flash_min && M % rm.q_per_b == 0) {
+    dim3 g3((rm.q_per_b + 63) / 64, NHEAD, M / rm.q_per_b);
+    if (out_bf16 == 1) CTTS_LAUNCH((attention_prefill_mfma_k<bf16_t>), g3, dim3(256), st, qkv, (const bf16_t*)kcache, (const bf16_t*)vcache, cmax, (bf16_t*)out, rm);
+    else if (out_bf16 == 0) CTTS_LAUNCH((attention_prefill_mfma_k<float>), g3, dim3(256), st, qkv, (const bf16_t*)kcache, (const bf16_t*)vcache, cmax, (float*)out, rm);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+  }
   static int nw8 = -1;  // CTTS_ATT_NW=8: 8 waves per (utterance, head) in decode (A/B knob)
   if (nw8 < 0) { const char* e = getenv("CTTS_ATT_NW"); nw8 = (e && atoi(e) == 8) ? 1 : 0; }
   if (out_bf16 == 2) {   // decode, perf mode: bf16 output in the fragment-packed order the o_proj kernel of decode.hip reads

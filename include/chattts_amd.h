@@ -273,6 +273,11 @@ int ctts_k_rope_append(float* qkv, void* kcache, void* vcache, int32_t kv_dtype,
                        int32_t q_per_b, const int32_t* len, const int32_t* kv_start, int32_t M, void* stream);
 int ctts_k_attention(const float* qkv, const void* kcache, const void* vcache, int32_t kv_dtype, int32_t cmax, float* out,
                      int32_t q_per_b, const int32_t* len, const int32_t* kv_start, int32_t M, void* stream);
+/* prefill attention of the perf mode over a bf16 KV cache: M = B * q_per_b query rows (row m: utterance m / q_per_b, KV slot
+ * slot0 + m % q_per_b -- slot0 > 0: a later chunk of a prompt prefilled in pieces), f32 output [M,768]; from q_per_b >= 128 the
+ * flash-style MFMA kernel runs (csrc/gpt.hip attention_prefill_mfma_k), the per-row kernel below that */
+int ctts_k_attention_prefill(const float* qkv, const uint16_t* kcache, const uint16_t* vcache, int32_t cmax, float* out, int32_t q_per_b,
+                             int32_t slot0, const int32_t* kv_start, int32_t M, void* stream);
 /* decode attention of the perf mode: one query row per utterance, bf16 KV cache [slots,12,cmax,64], output bf16 in the fragment-packed
  * order of csrc/decode.hip; desc [M][4] int32 = {utterance slot (-1: skip), KV slot of the query, RoPE position (unused here), first
  * visible key}; n_active: device scalar or NULL (M).  n_cu > 0 with part ([n_cu][8][66] f32) and cnt ([n_cu] int32, zeroed) turns on

@@ -377,6 +377,43 @@ def test_decode_to_wavs_padding(codec, weights):
     assert float(np.sqrt(np.mean((wav - ref) ** 2))) < 1e-4
 
 
+def test_long_audio_prompt_prefill_tracks_oracle(gpt_bf16, weights):
+    """a zero-shot style prompt: 40 text tokens followed by ~400 audio-code tokens per row (`spk_smp`, core.py:435-453;
+    tokenizer.py:85-110 puts the codes in the 4 slots with text_mask False), B = 4 mixed lengths, left padded -- the
+    flash-style MFMA prefill attention (T >= 128) -- then 6 teacher-forced decode steps: hidden states stay within the bf16
+    drift bound of the oracle; the same prompt prefilled in chunks of 192 slots gives the same result to rounding"""
+    rs = np.random.RandomState(21)
+    lens = [440, 300, 512, 397]
+    T, B, n = max(lens), 4, 6
+    ids = np.zeros((B, T, 4), np.int64)
+    mask = np.zeros((B, T), bool)
+    tmask = np.zeros((B, T), bool)
+    for b, L in enumerate(lens):
+        ids[b, T - L: T - L + 40] = rs.randint(1, 21178, size=(40, 1))
+        ids[b, T - L + 40:] = rs.randint(0, 625, size=(L - 40, 4))
+        mask[b, T - L:] = True
+        tmask[b, T - L: T - L + 40] = True
+    llama = llama_np.LlamaWeights({k: v.numpy() for k, v in weights["gpt"].items()})
+    esd = {k: v.numpy() for k, v in weights["embed"].items()}
+    heads = generate_np.fold_heads(esd)
+    teacher = rs.randint(0, 625, size=(B, n, 4)).astype(np.int64)
+    ref = generate_np.generate(llama, esd, heads, generate_np.embed_prompt(esd, ids, tmask), ids, mask, temperature=np.array([0.3] * 4, np.float32),
+                               draw_q=lambda i: None, pow_table=None, max_new_token=n, teacher_ids=teacher)
+    ids_t, mask_t = torch.from_numpy(ids), torch.from_numpy(mask)
+    emb = gpt_bf16.embed_prompt(ids_t, torch.from_numpy(tmask))
+    assert np.array_equal(emb.cpu().numpy(), generate_np.embed_prompt(esd, ids, tmask))
+    warpers, procs = E.gen_logits(625, 0.7, 20, 1.05)
+    outs = {}
+    for chunk in (None, 192):
+        out = list(gpt_bf16.generate(emb, ids_t, torch.tensor([0.3] * 4), 625, mask_t, n, 0, (*procs, *warpers), return_hidden=True,
+                                     manual_seed=1, teacher_ids=torch.from_numpy(teacher), prefill_chunk=chunk))[-1]
+        outs[chunk] = [h.cpu().numpy() for h in out.hiddens]
+        worst = max(float((np.abs(g - r).max(1) / np.abs(r).max(1)).max()) for g, r in zip(outs[chunk], ref.hiddens))
+        print(f"long audio prompt (T={T}), prefill_chunk={chunk}: worst hidden rel err vs oracle {worst:.3e}")
+        assert worst < 1.5e-2, worst
+    assert max(float(np.abs(a - b).max() / np.abs(b).max()) for a, b in zip(outs[None], outs[192])) < 1e-2
+
+
 def test_decode_window_equals_slices_of_the_full_decode(codec):
     """`CodecEngine.decode_window` (what streaming emits): any sample range of the batch decode, computed from the token
     window it depends on (+ halos) -- interior ranges, ranges touching either end, ragged rows shorter than the window"""

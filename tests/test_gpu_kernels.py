@@ -439,6 +439,46 @@ def test_rope_attention(G, kv):
         assert err < 2e-5, (extra, err)
 
 
+@pytest.mark.parametrize("T,slot0", [(128, 0), (300, 0), (512, 0), (200, 312)])
+def test_attention_prefill_mfma(G, T, slot0):
+    """flash-style MFMA prefill attention (perf mode, prompt chunks >= 128 rows): causal + left-pad mask, ragged last query tile,
+    a later chunk of a longer prompt (slot0 > 0: the first 312 keys come from the cache), vs float64.  P enters the second
+    product as bf16 (like every activation of the perf mode): tolerance 1e-2 on outputs of magnitude ~1."""
+    lib = _lib.lib()
+    rs = np.random.RandomState(T + slot0)
+    B, nh, d, H = 3, 12, 64, 768
+    cmax = slot0 + T + 40
+    kv_start = np.array([0, 7, min(150, slot0 + T - 3)], np.int32)
+    Kc = G.bf16_round(rs.standard_normal((B, nh, cmax, d)).astype(f32))
+    Vc = G.bf16_round(rs.standard_normal((B, nh, cmax, d)).astype(f32))
+    kc, vc = G.dev(Kc, torch.bfloat16), G.dev(Vc, torch.bfloat16)
+    # rows of the cache the kernel must never use: poison them (beyond the chunk's last slot)
+    kc[:, :, slot0 + T:] = float("nan")
+    vc[:, :, slot0 + T:] = float("nan")
+    qkv = rs.standard_normal((B * T, 3 * H)).astype(f32)
+    q_d, ks_d = G.dev(qkv), G.dev(kv_start)
+    out_d = torch.full((B * T, H), float("nan"), dtype=torch.float32, device=G.DEV)
+    _lib.check(lib.ctts_k_attention_prefill(q_d.data_ptr(), kc.data_ptr(), vc.data_ptr(), cmax, out_d.data_ptr(), T, slot0, ks_d.data_ptr(),
+                                            B * T, None), "attn prefill")
+    torch.cuda.synchronize()
+    got = out_d.cpu().numpy()
+    assert np.isfinite(got).all()
+    worst = 0.0
+    for b in range(B):
+        for t in sorted(set(rs.randint(0, T, size=24).tolist() + [0, T - 1])):
+            slot = slot0 + t
+            lo = min(kv_start[b], slot)
+            q = qkv[b * T + t, :H].reshape(nh, d).astype(np.float64)
+            Kb, Vb = Kc[b, :, lo: slot + 1].astype(np.float64), Vc[b, :, lo: slot + 1].astype(np.float64)
+            sc = np.einsum("hd,hjd->hj", q, Kb) * 0.125
+            p = np.exp(sc - sc.max(-1, keepdims=True))
+            p /= p.sum(-1, keepdims=True)
+            ref = np.einsum("hj,hjd->hd", p, Vb).reshape(H)
+            if slot >= kv_start[b]:      # pad query rows see only themselves; their output is never consumed
+                worst = max(worst, float(np.abs(got[b * T + t] - ref).max()))
+    assert worst < 1e-2, worst
+
+
 @pytest.mark.parametrize("n_live", [1, 3, 10, 21, 22, 40, 45, 64])
 def test_attention_decode_remainder_split(G, n_live):
     """decode attention of the perf mode (bf16 KV, packed bf16 output) with remainder splitting: 12 * n_live units on 256 CUs
