@@ -39,7 +39,13 @@ __global__ __launch_bounds__(256) void dwconv_ln_k(const float* __restrict__ x, 
                                                    const float* __restrict__ lw, const float* __restrict__ lb, float eps, int dil,
                                                    float* __restrict__ y, int F, int rows) {
   constexpr int C = 64 * CPL;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  // XCD-aware frame order: workgroup L runs on XCD L % 8 (observed placement, speed only) and each XCD has its own L2.  The 7
+  // taps of a frame are the rows f - 3 dil .. f + 3 dil; with the plain order every XCD touches every 8th group of 4 frames and
+  // pulls all their neighbours from HBM itself (PMC: 2.2x the algorithmic bytes).  Here each XCD gets ONE contiguous run of
+  // frames, so the neighbouring rows are hits in its own L2.  The grid is padded to a multiple of 8 workgroups.
+  const int per = gridDim.x >> 3;
+  const int blk = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  const int row = blk * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int lane = threadIdx.x & 63, c0 = lane * CPL;
   const int bi = row / F, f = row - bi * F;
@@ -69,8 +75,9 @@ __global__ __launch_bounds__(256) void dwconv_ln_k(const float* __restrict__ x, 
 hipError_t launch_dwconv_ln(const float* x, const float* w, const float* b, const float* ln_w, const float* ln_b, float eps, int dil,
                             float* y, int B, int F, int C, hipStream_t st) {
   const int rows = B * F;
-  if (C == 512) hipLaunchKernelGGL(dwconv_ln_k<8>, dim3((rows + 3) / 4), dim3(256), 0, st, x, w, b, ln_w, ln_b, eps, dil, y, F, rows);
-  else if (C == 256) hipLaunchKernelGGL(dwconv_ln_k<4>, dim3((rows + 3) / 4), dim3(256), 0, st, x, w, b, ln_w, ln_b, eps, dil, y, F, rows);
+  const int nblk = ((rows + 3) / 4 + 7) / 8 * 8;   // multiple of 8: one contiguous run of frames per XCD (see the kernel)
+  if (C == 512) hipLaunchKernelGGL(dwconv_ln_k<8>, dim3(nblk), dim3(256), 0, st, x, w, b, ln_w, ln_b, eps, dil, y, F, rows);
+  else if (C == 256) hipLaunchKernelGGL(dwconv_ln_k<4>, dim3(nblk), dim3(256), 0, st, x, w, b, ln_w, ln_b, eps, dil, y, F, rows);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }

@@ -9,6 +9,7 @@ include/chattts_amd.h.  There is no eager/PyTorch fallback.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import logging
 import math
 from dataclasses import dataclass, field
@@ -539,6 +540,8 @@ class GptEngine:
                 sess["out_ev"].record(caller)
             return GenerationOutputs(ids=ids, attentions=[], hiddens=hid)
 
+        sync_poll = os.environ.get("CTTS_SYNC_POLL") == "1"   # profiling fallback: plain blocking D2H polls, no pinned buffers
+
         def snapshot(ln):
             """stream-ordered, ASYNCHRONOUS D2H of the lane's finish flags and end_idx into pinned host buffers, plus the event
             that marks the copy (and everything enqueued before it) done.  Two buffer sets: up to two chunks are in flight."""
@@ -548,8 +551,12 @@ class GptEngine:
                                 torch.empty((ln.hi - ln.lo,), dtype=torch.int32).pin_memory(), torch.cuda.Event()) for _ in range(2)]
             fin_h, end_h, ev = ln.snap_buf[k]
             with torch.cuda.stream(ln.st):
-                fin_h.copy_(ln.finish, non_blocking=True)
-                end_h.copy_(ln.end_idx, non_blocking=True)
+                if sync_poll:
+                    fin_h.copy_(ln.finish.cpu())
+                    end_h.copy_(ln.end_idx.cpu())
+                else:
+                    fin_h.copy_(ln.finish, non_blocking=True)
+                    end_h.copy_(ln.end_idx, non_blocking=True)
                 ev.record(ln.st)
             return k
 

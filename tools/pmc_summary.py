@@ -43,6 +43,8 @@ def short(name):
         return "heads_gemm"
     if "sample_k" in name:
         return "sample"
+    if "dwconv_ln_k" in name:
+        return "dwconv_ln"
     return None
 
 
