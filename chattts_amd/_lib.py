@@ -54,6 +54,7 @@ class CodecWeights(C.Structure):
         ("v_pw2_w", PP), ("v_pw2_b", PP), ("v_gamma", PP),
         ("v_final_w", P), ("v_final_b", P), ("head_w", P), ("head_b", P), ("window", P), ("twiddle", P),
         ("gemm_mode", C.c_int32),
+        ("d_pw1_x3p", PP), ("d_pw2_x3p", PP), ("v_pw1_x3p", PP), ("v_pw2_x3p", PP),
     ]
 
 
@@ -106,6 +107,7 @@ SIGNATURES = {
     "ctts_dvae_encode": (C.c_int, [P, P, I32, P, P, SZ, P]),
     "ctts_dvae_decode_codes": (C.c_int, [P, P, P, I32, I32, P, SZ, P]),
     "ctts_k_gemm": (C.c_int, [I32, P, P, P, I32, I32, I32, I32, I32, I32, I32, P, F, P, I32, P, P, I32, I32, I32, I32, I32, P]),
+    "ctts_k_gemm_x3p": (C.c_int, [P, P, I32, I32, I32, I32, P, P, P, P, P, P]),
     "ctts_k_gemm_fast": (C.c_int, [P, I32, P, I32, I32, I32, P, F, I32, P, I32, P, I32, P, P]),
     "ctts_k_qkv_rope": (C.c_int, [P, P, I32, P, F, P, P, P, I32, P, P, I32, P, P, I32, P]),
     "ctts_k_gemm_dec": (C.c_int, [P, P, I32, I32, I32, P, P, F, I32, P, I32, P, I32, P, I32, P]),

@@ -203,10 +203,11 @@ static int run_step(ctts_gpt* g, const ctts_gen_state* s, int q_per_b, hipStream
   // flags (device-side compaction); prefill: row group -> slot of a pool (or null)
   const int32_t* rmap = (dec && dev_compact(g, s)) ? ws.row_map : s->row_map;
   const int32_t* nact = dec ? s->n_active : nullptr;
-  GptRowMap rm{q_per_b, s->len, s->kv_start, rmap, nact, (dec && g->skip_finished) ? s->finish : nullptr, nullptr, nullptr, nullptr, 0, slot0};
+  GptRowMap rm{q_per_b, s->len, s->kv_start, rmap, nact, (dec && g->skip_finished) ? s->finish : nullptr, nullptr, nullptr, nullptr, 0, slot0, 0};
   const bool fast = wt == CTTS_BF16;  // perf mode: bf16 activations, RMSNorm gain folded into wqkv / wgu by the loader
   const bool packed = fast && dec && g->dec_packed;   // decode step on fragment-packed operands (decode.hip)
   if (dec) rm.desc = ws.desc;                          // written by the embedding kernel at the head of the step
+  if (dec && dev_compact(g, s)) rm.desc_covers_all = 1; // ... for every row of the grid (absent rows: b = -1)
   if (packed && g->n_cu > 0) { rm.sp_part = ws.att_part; rm.sp_cnt = ws.att_cnt; rm.sp_cus = g->n_cu; }
   for (int l = 0; packed && l < g->w.n_layers; ++l) {
     void* kc = (char*)s->kcache + kv_layer * l;
@@ -417,6 +418,8 @@ extern "C" int ctts_gpt_profile_end(ctts_gpt* g, int32_t* n_samples, double* tot
 struct ctts_codec {
   ctts_codec_weights w;
   std::vector<const float*> d[9], v[9];
+  std::vector<const void*> dx[2], vx[2];   // pwconv1 / pwconv2 as pre-split fragment-order planes (codec_gemm.hip), or empty
+  int x3p_min_rows = 12288;                // frames from which the point-wise layers take the LDS-DMA kernel (env CTTS_X3P_MIN_ROWS, 0 = never)
 };
 
 extern "C" int ctts_codec_create(ctts_codec** out, const ctts_codec_weights* w) {
@@ -429,6 +432,13 @@ extern "C" int ctts_codec_create(ctts_codec** out, const ctts_codec_weights* w) 
     c->d[i].assign(dsrc[i], dsrc[i] + w->n_dvae_blocks);
     c->v[i].assign(vsrc[i], vsrc[i] + w->n_vocos_blocks);
   }
+  if (w->gemm_mode == 1 && w->d_pw1_x3p && w->d_pw2_x3p && w->v_pw1_x3p && w->v_pw2_x3p) {
+    c->dx[0].assign(w->d_pw1_x3p, w->d_pw1_x3p + w->n_dvae_blocks);
+    c->dx[1].assign(w->d_pw2_x3p, w->d_pw2_x3p + w->n_dvae_blocks);
+    c->vx[0].assign(w->v_pw1_x3p, w->v_pw1_x3p + w->n_vocos_blocks);
+    c->vx[1].assign(w->v_pw2_x3p, w->v_pw2_x3p + w->n_vocos_blocks);
+  }
+  { const char* e = getenv("CTTS_X3P_MIN_ROWS"); if (e) c->x3p_min_rows = atoi(e); }
   *out = c;
   return 0;
 }
@@ -439,7 +449,7 @@ struct CodecWs {
   size_t bytes;
 };
 static CodecWs carve_codec(void* base, int B, int F) {
-  const size_t R = (size_t)B * F;
+  const size_t R = ((size_t)B * F + 255) / 256 * 256;   // whole 256-row tiles: the packed planes of codec_gemm.hip are padded to them
   CodecWs w;
   size_t off = 0;
   char* p = (char*)base;
@@ -467,9 +477,24 @@ static GemmArgs conv(const float* X, int cin, const float* W, float* C, int cout
   return a;
 }
 
-static int convnext_stack(const ctts_codec* c, int n, const std::vector<const float*>* p, int inter, int dil, CodecWs& ws, int B, int F, hipStream_t st) {
+static int convnext_stack(const ctts_codec* c, int n, const std::vector<const float*>* p, const std::vector<const void*>* px, int inter, int dil,
+                          CodecWs& ws, int B, int F, hipStream_t st) {
   const int R = B * F;
-  for (int i = 0; i < n; ++i) {
+  const bool x3p = c->w.gemm_mode == 1 && !px[0].empty() && c->x3p_min_rows > 0 && R >= c->x3p_min_rows && inter % 256 == 0;
+  for (int i = 0; x3p && i < n; ++i) {
+    // depthwise conv + LayerNorm -> bf16 planes; pwconv1 + GELU -> bf16 planes; pwconv2 * gamma + residual -> f32 rows
+    uint16_t* bp = reinterpret_cast<uint16_t*>(ws.b);     // [R256][512] as hi / lo planes: the bytes of the f32 buffer
+    uint16_t* bigp = reinterpret_cast<uint16_t*>(ws.big);
+    CK(launch_dwconv_ln(ws.a, p[0][i], p[1][i], p[2][i], p[3][i], 1e-6f, dil, nullptr, B, F, 512, st, bp));
+    X3pArgs g;
+    memset(&g, 0, sizeof(g));
+    g.Ap = bp; g.Wp = (const uint16_t*)px[0][i]; g.M = R; g.N = inter; g.K = 512; g.epi = X3P_GELU_PACKED; g.bias = p[5][i]; g.Cp = bigp;
+    CK(launch_gemm_x3p(g, st));
+    g.Ap = bigp; g.Wp = (const uint16_t*)px[1][i]; g.N = 512; g.K = inter; g.epi = X3P_SCALE_RES; g.bias = p[7][i]; g.gamma = p[8][i];
+    g.res = ws.a; g.ldr = 512; g.C = ws.a; g.ldc = 512; g.Cp = nullptr;
+    CK(launch_gemm_x3p(g, st));
+  }
+  for (int i = 0; !x3p && i < n; ++i) {
     CK(launch_dwconv_ln(ws.a, p[0][i], p[1][i], p[2][i], p[3][i], 1e-6f, dil, ws.b, B, F, 512, st));
     GemmArgs g1 = lin(ws.b, 512, p[4][i], ws.big, inter, R, inter, 512, EPI_BIAS_GELU);
     g1.bias = p[5][i];
@@ -500,7 +525,7 @@ extern "C" int ctts_dvae_decode(ctts_codec* c, const float* hid, float* mel, int
   GemmArgs c2 = conv(ws.big, 128, c->w.conv_in2_w, ws.a, 512, B, F, 3, 1, EPI_BIAS);
   c2.bias = c->w.conv_in2_b;
   CK(dense(c, c2, st));
-  if (convnext_stack(c, c->w.n_dvae_blocks, c->d, 2048, 2, ws, B, F, st)) return -1;
+  if (convnext_stack(c, c->w.n_dvae_blocks, c->d, c->dx, 2048, 2, ws, B, F, st)) return -1;
   CK(dense(c, lin(ws.a, 512, c->w.conv_out_w, ws.mid, 384, B * F, 384, 512, EPI_STORE), st));
   GemmArgs oc = conv(ws.mid, 384, c->w.out_conv_w, mel, 100, B, F, 3, 1, EPI_SCALE);
   oc.gamma = c->w.coef;
@@ -519,7 +544,7 @@ extern "C" int ctts_vocos_decode(ctts_codec* c, const float* mel, float* wav, in
   e.bias = c->w.v_embed_b;
   CK(dense(c, e, st));
   CK(launch_layernorm(ws.b, c->w.v_norm_w, c->w.v_norm_b, 1e-6f, ws.a, B * F, 512, st));
-  if (convnext_stack(c, c->w.n_vocos_blocks, c->v, 1536, 1, ws, B, F, st)) return -1;
+  if (convnext_stack(c, c->w.n_vocos_blocks, c->v, c->vx, 1536, 1, ws, B, F, st)) return -1;
   CK(launch_layernorm(ws.a, c->w.v_final_w, c->w.v_final_b, 1e-6f, ws.b, B * F, 512, st));
   GemmArgs h = lin(ws.b, 512, c->w.head_w, ws.big, 1026, B * F, 1026, 512, EPI_BIAS);
   h.bias = c->w.head_b;
@@ -542,6 +567,14 @@ extern "C" int ctts_k_gemm(int32_t tiled, const float* A, const void* W, float* 
   a.dil = dil;
   { const char* e = getenv("CTTS_X3_DBG_PTR"); if (e) a.dbg = (long long*)strtoull(e, nullptr, 0); }   // probe builds only
   CK(tiled == 2 ? launch_gemm_tiled_bf16x3(a, (hipStream_t)stream) : tiled ? launch_gemm_tiled(a, (hipStream_t)stream) : launch_gemm_skinny(a, (hipStream_t)stream));
+  return 0;
+}
+extern "C" int ctts_k_gemm_x3p(const uint16_t* Ap, const uint16_t* Wp, int32_t M, int32_t N, int32_t K, int32_t epi, const float* bias,
+                               const float* gamma, const float* res, float* C, uint16_t* Cp, void* stream) {
+  X3pArgs g;
+  memset(&g, 0, sizeof(g));
+  g.Ap = Ap; g.Wp = Wp; g.M = M; g.N = N; g.K = K; g.epi = epi; g.bias = bias; g.gamma = gamma; g.res = res; g.ldr = N; g.C = C; g.ldc = N; g.Cp = Cp;
+  CK(launch_gemm_x3p(g, (hipStream_t)stream));
   return 0;
 }
 extern "C" int ctts_k_gemm_fast(const uint16_t* A, int32_t lda, const uint16_t* W, int32_t M, int32_t N, int32_t K, const float* ssq_in,
@@ -584,19 +617,19 @@ extern "C" int ctts_k_rows_prep(const float* x32, uint16_t* xb, float* ssq, int3
 extern "C" int ctts_k_rope_append(float* qkv, void* kcache, void* vcache, int32_t kv_dtype, int32_t cmax, const float* cos_tab,
                                   const float* sin_tab, int32_t q_per_b, const int32_t* len, const int32_t* kv_start, int32_t M,
                                   void* stream) {
-  GptRowMap rm{q_per_b, len, kv_start, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
+  GptRowMap rm{q_per_b, len, kv_start, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
   CK(launch_rope_append(qkv, kcache, vcache, kv_dtype, cmax, cos_tab, sin_tab, rm, M, (hipStream_t)stream));
   return 0;
 }
 extern "C" int ctts_k_attention(const float* qkv, const void* kcache, const void* vcache, int32_t kv_dtype, int32_t cmax, float* out,
                                 int32_t q_per_b, const int32_t* len, const int32_t* kv_start, int32_t M, void* stream) {
-  GptRowMap rm{q_per_b, len, kv_start, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
+  GptRowMap rm{q_per_b, len, kv_start, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
   CK(launch_attention(qkv, kcache, vcache, kv_dtype, cmax, out, 0, rm, M, (hipStream_t)stream));
   return 0;
 }
 extern "C" int ctts_k_attention_prefill(const float* qkv, const uint16_t* kcache, const uint16_t* vcache, int32_t cmax, float* out, int32_t q_per_b,
                                         int32_t slot0, const int32_t* kv_start, int32_t M, void* stream) {
-  GptRowMap rm{q_per_b, nullptr, kv_start, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, slot0};
+  GptRowMap rm{q_per_b, nullptr, kv_start, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, slot0, 0};
   CK(launch_attention(qkv, kcache, vcache, WT_BF16, cmax, out, 0, rm, M, (hipStream_t)stream));
   return 0;
 }
@@ -604,7 +637,7 @@ extern "C" int ctts_k_attention_dec(const float* qkv, const uint16_t* kcache, co
                                     const int32_t* desc, const int32_t* n_active, int32_t M, float* part, int32_t* cnt, int32_t n_cu,
                                     void* stream) {
   if (n_cu < 0 || n_cu > ATT_CUS_MAX) return fail("ctts_k_attention_dec: bad n_cu");
-  GptRowMap rm{1, nullptr, nullptr, nullptr, n_active, nullptr, reinterpret_cast<const RowDesc*>(desc), part, cnt, n_cu, 0};
+  GptRowMap rm{1, nullptr, nullptr, nullptr, n_active, nullptr, reinterpret_cast<const RowDesc*>(desc), part, cnt, n_cu, 0, 0};
   CK(launch_attention(qkv, kcache, vcache, WT_BF16, cmax, out_packed, 2, rm, M, (hipStream_t)stream));
   return 0;
 }

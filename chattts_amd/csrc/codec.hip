@@ -11,9 +11,11 @@
 #include "kernels.hpp"
 
 // channels = 64 lanes x CPL: 512 (CPL 8: both ConvNeXt stacks of the decoder path) or 256 (CPL 4: the full DVAE's trunks)
+// planes != null: the normalised row goes out as hi / lo bf16 planes in the fragment order of codec_gemm.hip (a lane's 8 channels are
+// one 16-byte slot of each plane) instead of f32
 template <int CPL>
 __device__ __forceinline__ void ln_finish(float* y, const float* __restrict__ lw, const float* __restrict__ lb, float eps, int c0,
-                                          float* __restrict__ dst) {
+                                          float* __restrict__ dst, uint16_t* __restrict__ planes = nullptr, int row = 0) {
   constexpr int C = 64 * CPL;
   float s = 0.f;
 #pragma unroll
@@ -29,7 +31,22 @@ __device__ __forceinline__ void ln_finish(float* y, const float* __restrict__ lw
     float4 o;
     o.x = (y[4 * q + 0] - mean) * rstd * w.x + b.x; o.y = (y[4 * q + 1] - mean) * rstd * w.y + b.y;
     o.z = (y[4 * q + 2] - mean) * rstd * w.z + b.z; o.w = (y[4 * q + 3] - mean) * rstd * w.w + b.w;
-    *reinterpret_cast<float4*>(dst + c0 + 4 * q) = o;
+    if (planes == nullptr) *reinterpret_cast<float4*>(dst + c0 + 4 * q) = o;
+    else { y[4 * q] = o.x; y[4 * q + 1] = o.y; y[4 * q + 2] = o.z; y[4 * q + 3] = o.w; }
+  }
+  if constexpr (CPL == 8) {
+   if (planes != nullptr) {
+    constexpr int KB16 = C / 16;
+    uint32_t h[4], l[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      h[q] = pack_bf16x2(y[2 * q], y[2 * q + 1]);
+      l[q] = pack_bf16x2(y[2 * q] - __uint_as_float(h[q] << 16), y[2 * q + 1] - __uint_as_float(h[q] & 0xffff0000u));
+    }
+    const size_t o = ((((size_t)(row >> 5) * KB16 + (c0 >> 4)) * 2) * 64 + (((c0 & 15) >> 3) << 5) + (row & 31)) * 8;
+    *reinterpret_cast<uint4*>(planes + o) = make_uint4(h[0], h[1], h[2], h[3]);
+    *reinterpret_cast<uint4*>(planes + o + 512) = make_uint4(l[0], l[1], l[2], l[3]);
+   }
   }
 }
 
@@ -37,7 +54,7 @@ __device__ __forceinline__ void ln_finish(float* y, const float* __restrict__ lw
 template <int CPL>
 __global__ __launch_bounds__(256) void dwconv_ln_k(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
                                                    const float* __restrict__ lw, const float* __restrict__ lb, float eps, int dil,
-                                                   float* __restrict__ y, int F, int rows) {
+                                                   float* __restrict__ y, int F, int rows, uint16_t* __restrict__ yp) {
   constexpr int C = 64 * CPL;
   // XCD-aware frame order: workgroup L runs on XCD L % 8 (observed placement, speed only) and each XCD has its own L2.  The 7
   // taps of a frame are the rows f - 3 dil .. f + 3 dil; with the plain order every XCD touches every 8th group of 4 frames and
@@ -69,15 +86,16 @@ __global__ __launch_bounds__(256) void dwconv_ln_k(const float* __restrict__ x, 
       }
     }
   }
-  ln_finish<CPL>(acc, lw, lb, eps, c0, y + (size_t)row * C);
+  ln_finish<CPL>(acc, lw, lb, eps, c0, y + (size_t)row * C, yp, row);
 }
 
 hipError_t launch_dwconv_ln(const float* x, const float* w, const float* b, const float* ln_w, const float* ln_b, float eps, int dil,
-                            float* y, int B, int F, int C, hipStream_t st) {
+                            float* y, int B, int F, int C, hipStream_t st, uint16_t* yp) {
   const int rows = B * F;
   const int nblk = ((rows + 3) / 4 + 7) / 8 * 8;   // multiple of 8: one contiguous run of frames per XCD (see the kernel)
-  if (C == 512) hipLaunchKernelGGL(dwconv_ln_k<8>, dim3(nblk), dim3(256), 0, st, x, w, b, ln_w, ln_b, eps, dil, y, F, rows);
-  else if (C == 256) hipLaunchKernelGGL(dwconv_ln_k<4>, dim3(nblk), dim3(256), 0, st, x, w, b, ln_w, ln_b, eps, dil, y, F, rows);
+  if (yp != nullptr && C != 512) return hipErrorInvalidValue;
+  if (C == 512) hipLaunchKernelGGL(dwconv_ln_k<8>, dim3(nblk), dim3(256), 0, st, x, w, b, ln_w, ln_b, eps, dil, y, F, rows, yp);
+  else if (C == 256) hipLaunchKernelGGL(dwconv_ln_k<4>, dim3(nblk), dim3(256), 0, st, x, w, b, ln_w, ln_b, eps, dil, y, F, rows, (uint16_t*)nullptr);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }

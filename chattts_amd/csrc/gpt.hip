@@ -92,7 +92,10 @@ __global__ __launch_bounds__(192) void embed_codes_k(const float* __restrict__ e
     int total;
     b = nth_unfinished(sp.finish, gridDim.x, m, total);
     if (m == 0 && t == 0) *sp.n_active_out = total;
-    if (b < 0) return;
+    if (b < 0) {   // row m does not exist this step: say so in its descriptor (the attention kernel reads nothing else)
+      if (sp.desc != nullptr && t == 0) sp.desc[m] = RowDesc{-1, 0, 0, 0};
+      return;
+    }
     if (t == 0) sp.row_map_out[m] = b;
   } else {
     if (row_absent(n_active, m)) return;
@@ -264,7 +267,7 @@ __global__ __launch_bounds__(64 * NW) void attention_k(const float* __restrict__
     }
     m = unit / NHEAD;
     h = unit - m * NHEAD;
-  } else if (rm.q_per_b == 1 && row_absent(rm.n_active, m)) return;
+  } else if (rm.q_per_b == 1 && !rm.desc_covers_all && row_absent(rm.n_active, m)) return;
   int b, slot, jlo;
   if (rm.desc != nullptr) {   // decode: one 16-byte load instead of the row_map -> len -> kv_start / finish chain
     const RowDesc d = rm.desc[m];
@@ -854,7 +857,10 @@ __global__ __launch_bounds__(192) void embed_text_k(const float* __restrict__ em
     int total;
     b = nth_unfinished(sp.finish, gridDim.x, m, total);
     if (m == 0 && t == 0) *sp.n_active_out = total;
-    if (b < 0) return;
+    if (b < 0) {   // row m does not exist this step: say so in its descriptor (the attention kernel reads nothing else)
+      if (sp.desc != nullptr && t == 0) sp.desc[m] = RowDesc{-1, 0, 0, 0};
+      return;
+    }
     if (t == 0) sp.row_map_out[m] = b;
   } else {
     if (row_absent(n_active, m)) return;

@@ -149,6 +149,8 @@ struct GptRowMap {
   int32_t* sp_cnt;          // [sp_cus] arrival counters, zero between launches (the last arriver resets its counter)
   int sp_cus;               // compute units of the device (0: no splitting)
   int slot0;                // prefill: first prompt slot of the chunk this launch covers
+  int desc_covers_all;      // decode: desc[] is valid for EVERY row of the grid (absent rows carry b = -1), so the attention
+                            // kernel need not read *n_active first (one dependent load less in front of the KV stream)
 };
 #define ATT_SPLIT_MAX 8
 
@@ -210,9 +212,26 @@ hipError_t launch_embed_text(const float* emb_text, int n_text, const int64_t* i
                              uint16_t* xb, float* ssq, int B, const int32_t* row_map, const int32_t* n_active, hipStream_t st,
                              const StepPrep* prep = nullptr);
 
+// ---- split-bf16 GEMM on pre-split, fragment-packed planes, LDS-DMA staged (codec_gemm.hip) -------
+// plane layout of a [rows][K] matrix: [rows/32][K/16][hi|lo][lane = (k%16)/8*32 + row%32][k%8] bf16 (rows padded to 256)
+enum { X3P_GELU_PACKED = 0, X3P_SCALE_RES = 1 };
+struct X3pArgs {
+  const uint16_t* Ap;    // activations, planes, rows padded to a multiple of 256
+  const uint16_t* Wp;    // weights [N][K], planes
+  int M, N, K;           // M valid rows; N % 256 == 0; K % 32 == 0
+  int epi;
+  const float* bias;     // [N]
+  const float* gamma;    // [N]   (X3P_SCALE_RES)
+  const float* res; int ldr;   // residual, f32 row-major (X3P_SCALE_RES)
+  float* C; int ldc;     // X3P_SCALE_RES: C = res + gamma * (acc + bias), f32 row-major
+  uint16_t* Cp;          // X3P_GELU_PACKED: gelu(acc + bias) as planes of a [rows][N] matrix (the next layer's A operand)
+};
+hipError_t launch_gemm_x3p(const X3pArgs& a, hipStream_t st);
+
 // ---- codec kernels (channels-last [B, F, C]) ---------------------------------------------------
+// yp != null (C = 512 only): the output goes out as the two bf16 planes gemm_x3p_k reads instead of f32 rows
 hipError_t launch_dwconv_ln(const float* x, const float* w /*[C,7]*/, const float* b, const float* ln_w, const float* ln_b,
-                            float eps, int dil, float* y, int B, int F, int C, hipStream_t st);
+                            float eps, int dil, float* y, int B, int F, int C, hipStream_t st, uint16_t* yp = nullptr);
 hipError_t launch_layernorm(const float* x, const float* w, const float* b, float eps, float* y, int rows, int C, hipStream_t st);
 hipError_t launch_istft(const float* head /*[B,F,1026]*/, const float* window /*[1024]*/, const float* twiddle /*[512,2]*/,
                         float* frames /*[B,F,1024] scratch*/, float* wav /*[B,256(F-1)]*/, int B, int F, hipStream_t st);

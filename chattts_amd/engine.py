@@ -715,6 +715,26 @@ def split_bf16(w: torch.Tensor) -> torch.Tensor:
     return torch.stack([hi.view(N, Kp // 32, 32), lo.view(N, Kp // 32, 32)], 2).contiguous()
 
 
+def pack_x3p(w: torch.Tensor) -> torch.Tensor:
+    """[R, K] float32 (R % 32 == 0, K % 16 == 0) -> the PRE-SPLIT planes of csrc/codec_gemm.hip in MFMA fragment order,
+    [R/32][K/16][hi | lo][lane = (k%16)/8*32 + r%32][k%8] bfloat16: w = hi + lo up to 2^-17 |w|, and every (32-row tile,
+    16-wide k block, plane) is one contiguous KiB -- what `v_mfma_f32_32x32x16_bf16` takes as an operand, so a tile step is
+    staged by plain LDS-DMA copies."""
+    R, K = w.shape
+    assert R % 32 == 0 and K % 16 == 0
+    w = w.to(torch.float32)
+    hi = w.to(torch.bfloat16)
+    lo = (w - hi.to(torch.float32)).to(torch.bfloat16)
+    x = torch.stack([hi, lo], 0).reshape(2, R // 32, 32, K // 16, 2, 8)
+    return x.permute(1, 3, 0, 4, 2, 5).contiguous()
+
+
+def unpack_x3p(p: torch.Tensor, R: int, K: int) -> torch.Tensor:
+    """inverse of pack_x3p: -> float32 [R, K] = hi + lo (tests)"""
+    x = p.reshape(R // 32, K // 16, 2, 2, 32, 8).permute(2, 0, 4, 1, 3, 5).reshape(2, R, K).to(torch.float32)
+    return x[0] + x[1]
+
+
 # ---------------------------------------------------------------------------------------------
 class CodecEngine:
     """DVAE decoder + Vocos on the device (channels-last)."""
@@ -798,6 +818,14 @@ class CodecEngine:
         kk = torch.arange(VOCOS.n_fft // 2, dtype=torch.float64) * (2.0 * math.pi / VOCOS.n_fft)
         w.twiddle = P(f(torch.stack([kk.cos(), kk.sin()], 1)))
         w.gemm_mode = 1 if gemm == "bf16x3" else 0
+        if gemm == "bf16x3":
+            # the ConvNeXt point-wise layers once more as pre-split fragment-order planes: from 12288 frames they run on the
+            # LDS-DMA staged kernel of csrc/codec_gemm.hip (40 of the 45 GEMM launches of a decode)
+            x3p = lambda t: pack_x3p(t.to(torch.float32).reshape(t.shape[0], -1)).to(dev)
+            w.d_pw1_x3p = PA([x3p(blk(i, "pwconv1.weight")) for i in range(nb)])
+            w.d_pw2_x3p = PA([x3p(blk(i, "pwconv2.weight")) for i in range(nb)])
+            w.v_pw1_x3p = PA([x3p(vb(i, "pwconv1.weight")) for i in range(nv)])
+            w.v_pw2_x3p = PA([x3p(vb(i, "pwconv2.weight")) for i in range(nv)])
         self._w = w
         h = C.c_void_p()
         _lib.check(self.lib.ctts_codec_create(C.byref(h), C.byref(w)), "ctts_codec_create")

@@ -186,6 +186,12 @@ typedef struct {
    *    split-bf16 tensor [N][Kp/32][2][32] (per row and 32-wide k block: hi values, lo values; Kp = K rounded up to 32, zero padded), consumed by
    *    the bf16x3 tiles (3 bf16 MFMAs per product, f32-class accuracy).  Biases/LN/depthwise stay float32. */
   int32_t gemm_mode;
+  /* gemm_mode 1, optional (NULL: the point-wise layers run on the tiles above at every size): the ConvNeXt pwconv1 / pwconv2
+   * weights once more as PRE-SPLIT planes in MFMA fragment order, [N/32][K/16][hi|lo][lane = (k%16)/8*32 + n%32][k%8] bf16, for the
+   * LDS-DMA staged kernel of csrc/codec_gemm.hip (used from 12288 frames; the depthwise-conv + LayerNorm kernel and the GELU
+   * epilogue then write the activations as the same kind of planes) */
+  const void* const* d_pw1_x3p; const void* const* d_pw2_x3p;
+  const void* const* v_pw1_x3p; const void* const* v_pw2_x3p;
 } ctts_codec_weights;
 
 int ctts_codec_create(ctts_codec** out, const ctts_codec_weights* w);
@@ -254,6 +260,11 @@ int ctts_dvae_decode_codes(ctts_dvae* c, const int64_t* codes, float* mel, int32
 int ctts_k_gemm(int32_t tiled /* 0 skinny, 1 f32 tiles, 2 split-bf16 tiles */, const float* A, const void* W, float* C, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldc,
                 int32_t wt, int32_t epi, const float* norm_w, float eps, const float* res, int32_t ldr, const float* bias,
                 const float* gamma, int32_t taps, int32_t cin, int32_t frames, int32_t pad, int32_t dil, void* stream);
+/* split-bf16 GEMM on pre-split planes in MFMA fragment order (csrc/codec_gemm.hip): Ap / Wp / Cp are
+ * [rows/32][K/16][hi|lo][64][8] bf16 with rows padded to 256; epi 0: Cp = planes of gelu(A W^T + bias) (a [rows][N] matrix),
+ * epi 1: C = res + gamma * (A W^T + bias), f32 [M][N].  N % 256 == 0, K % 32 == 0. */
+int ctts_k_gemm_x3p(const uint16_t* Ap, const uint16_t* Wp, int32_t M, int32_t N, int32_t K, int32_t epi, const float* bias,
+                    const float* gamma, const float* res, float* C, uint16_t* Cp, void* stream);
 /* perf-mode projection: bf16 activations/weights, optional per-row 1/rms from 48 partial sums of squares,
  * epi 0 = f32 store, 1 = residual add (+ bf16 copy + new partial sums), 2 = SiLU(gate)*up -> bf16 */
 int ctts_k_gemm_fast(const uint16_t* A, int32_t lda, const uint16_t* W, int32_t M, int32_t N, int32_t K, const float* ssq_in, float eps,

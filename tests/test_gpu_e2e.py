@@ -414,6 +414,29 @@ def test_long_audio_prompt_prefill_tracks_oracle(gpt_bf16, weights):
     assert max(float(np.abs(a - b).max() / np.abs(b).max()) for a, b in zip(outs[None], outs[192])) < 1e-2
 
 
+def test_codec_lds_dma_path_equals_tile_path(weights, monkeypatch):
+    """from 12288 frames the ConvNeXt point-wise layers run on pre-split fragment-order planes staged by LDS-DMA
+    (csrc/codec_gemm.hip; the depthwise-conv + LayerNorm kernel and the GELU epilogue write the planes); below that, and
+    with CTTS_X3P_MIN_ROWS=0, on the register-staged tiles.  Same products, same accumulation order over k: the waveforms
+    of a 16 x 400-token batch (12800 frames, ragged rows) agree to 1e-6 RMS -- and with the numpy oracle on a slice"""
+    rs = np.random.RandomState(33)
+    rows = [torch.from_numpy(rs.standard_normal((n, 768)).astype(np.float32)) for n in [400, 390, 120, 400] + [300] * 12]
+    new = E.CodecEngine(weights["decoder"], weights["vocos"], DEV)
+    w_new = new.decode_to_wavs(rows).cpu().numpy()
+    monkeypatch.setenv("CTTS_X3P_MIN_ROWS", "0")
+    old = E.CodecEngine(weights["decoder"], weights["vocos"], DEV)
+    w_old = old.decode_to_wavs(rows).cpu().numpy()
+    assert w_new.shape == w_old.shape == (16, 256 * 799) and np.isfinite(w_new).all()
+    rms = float(np.sqrt(np.mean((w_new - w_old) ** 2)))
+    print(f"codec LDS-DMA path vs tile path: wav rms diff {rms:.2e} (signal rms {float(np.sqrt(np.mean(w_old ** 2))):.2e})")
+    assert rms < 1e-6, rms
+    dsd = {k: v.numpy() for k, v in weights["decoder"].items()}
+    vsd = {k: v.numpy() for k, v in weights["vocos"].items()}
+    ref = codec_np.decode_to_wavs(dsd, vsd, [rows[2].numpy()])      # a 120-token row alone: its first 100 tokens do not see the padding
+    n = 256 * (2 * 100 - 1) - 256 * 110
+    assert float(np.sqrt(np.mean((w_new[2, :n] - ref[0, :n]) ** 2))) < 1e-4
+
+
 def test_decode_window_equals_slices_of_the_full_decode(codec):
     """`CodecEngine.decode_window` (what streaming emits): any sample range of the batch decode, computed from the token
     window it depends on (+ halos) -- interior ranges, ranges touching either end, ragged rows shorter than the window"""

@@ -316,6 +316,42 @@ def test_gemm_tiled_bf16x3_big_tile_linear(G, M, N, K, epi):
     assert G.relerr(got, ref) < 3e-5, G.relerr(got, ref)
 
 
+@pytest.mark.parametrize("M", [12288, 16400, 300])
+@pytest.mark.parametrize("N,K,epi", [(2048, 512, 0), (512, 2048, 1), (1536, 512, 0), (512, 1536, 1)])
+def test_gemm_x3p(G, M, N, K, epi):
+    """split-bf16 GEMM on pre-split fragment-order planes, LDS-DMA staged (csrc/codec_gemm.hip): both epilogues of the ConvNeXt
+    point-wise pair at every DVAE / Vocos shape, ragged last row tile (M not a multiple of 256), vs float64"""
+    from chattts_amd.engine import pack_x3p, unpack_x3p
+    lib = _lib.lib()
+    rs = np.random.RandomState(M + N + K)
+    Mp = (M + 255) // 256 * 256
+    A = np.zeros((Mp, K), f32)
+    A[:M] = rs.standard_normal((M, K)).astype(f32)
+    W = (rs.standard_normal((N, K)) / np.sqrt(K)).astype(f32)
+    bias = rs.standard_normal(N).astype(f32) * 0.1
+    gam = (0.05 + 0.1 * rs.rand(N)).astype(f32)
+    res = rs.standard_normal((M, N)).astype(f32)
+    Ap = pack_x3p(torch.from_numpy(A)).to(G.DEV)
+    Wp = pack_x3p(torch.from_numpy(W)).to(G.DEV)
+    b_d, g_d = G.dev(bias), G.dev(gam)
+    acc = A[:M].astype(np.float64) @ W.astype(np.float64).T
+    if epi == 0:
+        Cp = torch.zeros((Mp * N * 2,), dtype=torch.bfloat16, device=G.DEV)
+        _lib.check(lib.ctts_k_gemm_x3p(Ap.data_ptr(), Wp.data_ptr(), M, N, K, 0, b_d.data_ptr(), None, None, None, Cp.data_ptr(), None), "x3p gelu")
+        torch.cuda.synchronize()
+        got = unpack_x3p(Cp.cpu(), Mp, N).numpy()[:M]
+        ref = codec_np.gelu((acc + bias).astype(f32))
+    else:
+        C_d = G.dev(res).clone()
+        _lib.check(lib.ctts_k_gemm_x3p(Ap.data_ptr(), Wp.data_ptr(), M, N, K, 1, b_d.data_ptr(), g_d.data_ptr(), C_d.data_ptr(), C_d.data_ptr(),
+                                       None, None), "x3p res")
+        torch.cuda.synchronize()
+        got = C_d.cpu().numpy()
+        ref = res + gam * (acc + bias)
+    assert np.isfinite(got).all()
+    assert G.relerr(got, ref) < 3e-5, G.relerr(got, ref)
+
+
 def test_gemm_tiled_bf16x3_big_tile_conv(G):
     """conv-as-GEMM gather (taps 3, zero padding at both utterance ends) on the two-buffer 256x256 tile: conv_in.2 of the
     DVAE decoder at 4 x 3100 frames (M = 12400 >= 12288)"""
