@@ -574,6 +574,7 @@ extern "C" int ctts_k_gemm_x3p(const uint16_t* Ap, const uint16_t* Wp, int32_t M
   X3pArgs g;
   memset(&g, 0, sizeof(g));
   g.Ap = Ap; g.Wp = Wp; g.M = M; g.N = N; g.K = K; g.epi = epi; g.bias = bias; g.gamma = gamma; g.res = res; g.ldr = N; g.C = C; g.ldc = N; g.Cp = Cp;
+  { const char* e = getenv("CTTS_X3_DBG_PTR"); if (e) g.dbg = (long long*)strtoull(e, nullptr, 0); }   // probe variant only
   CK(launch_gemm_x3p(g, (hipStream_t)stream));
   return 0;
 }

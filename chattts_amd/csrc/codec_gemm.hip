@@ -72,15 +72,22 @@ __global__ __launch_bounds__(512, 2) void gemm_x3p_k(X3pArgs a) {
   // the loop).  Iteration s: (1) wait until THIS wave's 4 pieces of k block s have landed -- the pieces of blocks s+1, s+2 stay
   // in flight (vmcnt counts in order); (2) barrier: every wave's pieces of block s are in LDS, and every wave is done reading
   // slot (s-1) % 4; (3) refill that slot with block s+3; (4) multiply block s.
+  // VAR 3 (probe): wave 0 accumulates 100 MHz realtime deltas: DMA wait, barrier, DMA issue, fragment reads, MFMAs
+  long long tacc[5] = {0, 0, 0, 0, 0}, tprev = 0;
+#define X3P_MARK(i) do { if (VAR == 3) { const long long tn = wall_clock64(); tacc[i] += tn - tprev; tprev = tn; } } while (0)
   issue(0);
   if (kb16 > 1) issue(1);
   if (kb16 > 2) issue(2);
+  if (VAR == 3) tprev = wall_clock64();
   for (int s = 0; s < kb16; ++s) {
     if (s + 2 < kb16) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if (s + 1 < kb16) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    X3P_MARK(0);
     __builtin_amdgcn_s_barrier();
+    X3P_MARK(1);
     if (s + 3 < kb16) issue(s + 3);
+    X3P_MARK(2);
     const uint16_t* la = lds + (s & (NSLOT - 1)) * SLOT + lane * 8;
     const uint16_t* lw = la + 16 * FRAG;
     bf16x8 fah[2], fal[2], fwh[4], fwl[4];
@@ -94,6 +101,7 @@ __global__ __launch_bounds__(512, 2) void gemm_x3p_k(X3pArgs a) {
       fwh[j] = *reinterpret_cast<const bf16x8*>(lw + ((wn * 4 + j) * 2 + 0) * FRAG);
       fwl[j] = *reinterpret_cast<const bf16x8*>(lw + ((wn * 4 + j) * 2 + 1) * FRAG);
     }
+    if (VAR == 3) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); X3P_MARK(3); }
     // per accumulator the order is lo.hi, hi.lo, hi.hi (small terms first).  VAR 1: term-major issue order, so that consecutive
     // MFMAs write DIFFERENT accumulators (8 independent ones between two dependent ones); VAR 2: + raised wave priority
     if (VAR == 0) {
@@ -121,7 +129,16 @@ __global__ __launch_bounds__(512, 2) void gemm_x3p_k(X3pArgs a) {
         for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fwh[j], acc[i][j], 0, 0, 0);
       if (VAR == 2) __builtin_amdgcn_s_setprio(0);
     }
+    if (VAR == 3) {   // make the MFMAs' completion visible to the clock: touch one result register of the last MFMA group
+      asm volatile("s_nop 15\n\ts_nop 15" :: "v"(acc[1][3][0]));
+      X3P_MARK(4);
+    }
   }
+  if (VAR == 3 && a.dbg != nullptr && tid == 0) {
+    long long* d = a.dbg + (size_t)blockIdx.x * 8;
+    for (int i = 0; i < 5; ++i) d[i] = tacc[i];
+  }
+#undef X3P_MARK
   __syncthreads();   // everybody is done with the ring: the epilogue below reuses it as scratch
 
   if (EPI == X3P_GELU_PACKED) {
@@ -189,6 +206,7 @@ hipError_t launch_gemm_x3p(const X3pArgs& a, hipStream_t st) {
   if (var < 0) { const char* e = getenv("CTTS_X3P_VAR"); var = e ? atoi(e) : 1; }
   if (var == 0) x3p_launch<0>(a, grid, st);
   else if (var == 2) x3p_launch<2>(a, grid, st);
+  else if (var == 3) x3p_launch<3>(a, grid, st);
   else x3p_launch<1>(a, grid, st);
   return hipGetLastError();
 }

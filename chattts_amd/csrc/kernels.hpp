@@ -225,6 +225,7 @@ struct X3pArgs {
   const float* res; int ldr;   // residual, f32 row-major (X3P_SCALE_RES)
   float* C; int ldc;     // X3P_SCALE_RES: C = res + gamma * (acc + bias), f32 row-major
   uint16_t* Cp;          // X3P_GELU_PACKED: gelu(acc + bias) as planes of a [rows][N] matrix (the next layer's A operand)
+  long long* dbg;        // probe variant only (CTTS_X3P_VAR=3, tools/x3p_phase_probe.py): [n_workgroups][8] accumulated phase times
 };
 hipError_t launch_gemm_x3p(const X3pArgs& a, hipStream_t st);
 
