@@ -251,7 +251,7 @@ def test_pmc_summary_maps_the_profiled_kernel_names():
     spec = importlib.util.spec_from_file_location("pmc_summary", os.path.join(ROOT, "tools", "pmc_summary.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    with open(os.path.join(ROOT, "profiles", "r2y_kernel_stats.csv")) as f:
+    with open(os.path.join(ROOT, "profiles", "r2z_kernel_stats.csv")) as f:
         names = [r["Name"] for r in csv.DictReader(f)]
     tags = {mod.short(n) for n in names} - {None}
     assert {"attention", "qkv_gemm", "o_proj_gemm", "gate_up_gemm", "down_gemm", "heads_gemm", "sample"} <= tags
