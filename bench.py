@@ -149,7 +149,7 @@ def main():
                                 total_rows=wl["total_rows"], profile_tag=profile_tag, profile_stride=profile_stride, lanes=args.lanes):
             pass
         lens = [int(t.shape[0]) for t in out.ids]
-        wav = codec.decode_to_wavs(out.hiddens).cpu().numpy() if decode_audio else None
+        wav = codec.to_host(codec.decode_to_wavs(out.hiddens)) if decode_audio else None   # what Chat.decode_to_wavs returns
         return lens, wav, ([t.cpu().numpy() for t in out.ids] if keep_ids else None)
 
     def note(msg):

@@ -175,8 +175,8 @@ class Chat:
         if len(result_list) == 0:
             return np.array([], dtype=np.float32)
         if use_decoder:
-            return self.codec.decode_to_wavs(result_list).cpu().numpy()
-        return self.codec.vocos_decode(self.dvae.decode_codes(result_list)).cpu().numpy()
+            return self.codec.to_host(self.codec.decode_to_wavs(result_list))
+        return self.codec.to_host(self.codec.vocos_decode(self.dvae.decode_codes(result_list)))
 
     def infer_ids(self, input_ids, attention_mask, text_mask, params: InferCodeParams = InferCodeParams(), **kw) -> np.ndarray:
         """non-stream `Chat._infer` body for one batch (core.py:469-481, split_text=False, skip_refine_text=True),
@@ -198,7 +198,7 @@ class Chat:
             wavs = self.decode_to_wavs(hiddens, use_decoder)
             return wavs[:, a: wavs.shape[1] if b is None else min(b, wavs.shape[1])]
         hi = total if b is None else min(b, total)
-        return self.codec.decode_window(hiddens, a, hi).cpu().numpy()
+        return self.codec.to_host(self.codec.decode_window(hiddens, a, hi))
 
     def infer_ids_stream(self, input_ids, attention_mask, text_mask, params: InferCodeParams = InferCodeParams(), **kw):
         """stream=True body of `Chat._infer` for one batch (core.py:455-503): every `stream_batch` live steps the
