@@ -5,9 +5,10 @@ finish early idle until the last one is done, :592); only its optional vLLM fork
 (/root/reference/ChatTTS/model/velocity/scheduler.py:130-293, block_manager.py:73-296).  `SlotPool` is the
 MI355X-native equivalent for this engine: a fixed pool of S utterance slots with a dense KV cache per slot
 (288 GB of HBM make paging unnecessary: 64 slots x 2560 positions x 61 KB = 10 GB), ONE captured decode graph
-for the whole session, and three device-side arrays that make admission / retirement free of re-capture:
-`row_map` + `n_active` (which slots the decode step computes) and `prompt_len` (where each slot's generated part
-starts).  Newly admitted requests are prefilled as a group straight into their slots' KV cache.
+for the whole session, and device-side state that makes admission / retirement free of re-capture: the `finish` flags
+(a free or retired slot looks finished; the first kernel of every decode step ranks the unfinished slots and computes exactly
+those -- device-side compaction, include/chattts_amd.h) and `prompt_len` (where each slot's generated part starts).  Admission
+is: write the slot's state, clear its flag.  Newly admitted requests are prefilled as a group straight into their slots' KV cache.
 
 Parity contract: a request produces exactly the tokens `GptEngine.generate` produces for it alone with
 `row_offset = 4*slot, total_rows = 4*S` (the Exp(1) draw of a sampling row is the pool row's), because nothing
@@ -71,8 +72,7 @@ class SlotPool:
             kv_shape = (engine.n_layers, slots, GPT.n_heads, cap, GPT.head_dim)
             self.kcache = torch.zeros(kv_shape, dtype=engine.wdt, device=dev)
             self.vcache = torch.zeros(kv_shape, dtype=engine.wdt, device=dev)
-            self.row_map = torch.zeros((slots,), dtype=torch.int32, device=dev)
-            self.n_active = torch.zeros((1,), dtype=torch.int32, device=dev)
+            self.n_active = torch.zeros((1,), dtype=torch.int32, device=dev)   # written by the step's first kernel
             self.q = ExpDraws(slots * nvq, GPT.n_audio, manual_seed).step(0).to(dev).reshape(1, slots * nvq, GPT.n_audio).contiguous()
             self.temp = torch.tensor(list(temperature), dtype=torch.float32, device=dev)
             ptab = penalty_table(plan.penalty)
@@ -80,7 +80,7 @@ class SlotPool:
             ws_bytes = self.lib.ctts_gpt_workspace_bytes(slots, 1)
             self.ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
         self.plan, self.min_new, self.eos = plan, int(min_new_token), int(eos_token)
-        self.dec = self._state(B=slots, T=1, workspace=self.ws, row_map=self.row_map, n_active=self.n_active)
+        self.dec = self._state(B=slots, T=1, workspace=self.ws, row_map=None, n_active=self.n_active)
         self.st.synchronize()
         _lib.check(self.lib.ctts_gpt_graph_build(self.handle, C.byref(self.dec), self.st.cuda_stream), "ctts_gpt_graph_build")
         self.free: List[int] = list(range(slots))
@@ -173,13 +173,6 @@ class SlotPool:
             self.active[s_] = (r, Tg)
             self.slot_of[r.rid] = s_
 
-    def _publish_active(self) -> None:
-        act = sorted(self.active)
-        with torch.cuda.stream(self.st):
-            if act:
-                self.row_map[: len(act)].copy_(torch.tensor(act, dtype=torch.int32))
-            self.n_active.fill_(len(act))
-
     # -- main loop --------------------------------------------------------------------------------------------
     def run(self) -> Iterator[Tuple[object, torch.Tensor, torch.Tensor]]:
         """Yields (request id, ids [n,4] int64, hiddens [n,768] float32) as requests complete, admitting queued
@@ -187,7 +180,6 @@ class SlotPool:
         while self.queue or self.active:
             self._admit()
             # requests can already be over after the prefill's sample (EOS at step 0) -> handled by the poll below
-            self._publish_active()
             if self.active:
                 _lib.check(self.lib.ctts_gpt_graph_launch(self.handle, self.POLL, self.st.cuda_stream), "ctts_gpt_graph_launch")
                 self.steps += self.POLL

@@ -51,22 +51,21 @@ def fold_heads(embed_sd: dict) -> torch.Tensor:
     return torch.cat(ws, 0)     # [2504, 768]
 
 
-class RepPenalty:   # processors.py:6-35
+class RepPenalty:
+    """Windowed repetition penalty (processors.py:6-35): a token seen n times in the last `past_window` steps has its
+    score multiplied (negative scores) or divided (positive scores) by penalty**n.  As in the reference, the count matrix
+    is zeroed from ROW `max_input_ids` on (processors.py:25-28 narrows dim 0), which never triggers at B*num_vq <= 625."""
+
     def __init__(self, penalty, max_input_ids=625, past_window=16):
         self.penalty, self.max_input_ids, self.past_window = penalty, max_input_ids, past_window
 
-    def __call__(self, input_ids, scores):
-        if input_ids.size(1) > self.past_window:
-            input_ids = input_ids.narrow(1, -self.past_window, self.past_window)
-        freq = torch.nn.functional.one_hot(input_ids, scores.size(1)).sum(1)
-        if freq.size(0) > self.max_input_ids:
-            freq.narrow(0, self.max_input_ids, freq.size(0) - self.max_input_ids).zero_()
-        alpha = torch.pow(self.penalty, freq)
-        scores = scores.contiguous()
-        inp = scores.multiply(alpha)
-        oth = scores.divide(alpha)
-        con = scores < 0
-        return torch.where(con, inp, oth)
+    def __call__(self, hist, scores):
+        recent = hist[:, -self.past_window:]
+        counts = torch.zeros(scores.shape, dtype=torch.int64)
+        counts.scatter_add_(1, recent, torch.ones_like(recent))
+        counts[self.max_input_ids:] = 0
+        alpha = torch.pow(self.penalty, counts)
+        return torch.where(scores < 0, scores * alpha, scores / alpha)
 
 
 @torch.inference_mode()
