@@ -111,6 +111,7 @@ SIGNATURES = {
     "ctts_k_gemm_fast": (C.c_int, [P, I32, P, I32, I32, I32, P, F, I32, P, I32, P, I32, P, P]),
     "ctts_k_qkv_rope": (C.c_int, [P, P, I32, P, F, P, P, P, I32, P, P, I32, P, P, I32, P]),
     "ctts_k_gemm_dec": (C.c_int, [P, P, I32, I32, I32, P, P, F, I32, P, I32, P, I32, P, I32, P]),
+    "ctts_k_gemm_dec32": (C.c_int, [P, P, I32, I32, I32, P, P, I32, P, F, I32, P, I32, P, I32, P, I32, I32, P]),
     "ctts_k_rows_prep": (C.c_int, [P, P, P, I32, P]),
     "ctts_k_rope_append": (C.c_int, [P, P, P, I32, I32, P, P, I32, P, P, I32, P]),
     "ctts_k_attention": (C.c_int, [P, P, P, I32, I32, P, I32, P, P, I32, P]),

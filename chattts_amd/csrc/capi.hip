@@ -34,8 +34,9 @@ static const int HID = 768, INTER = 3072, NHEAD = 12, HDIM = 64, NVQ = 4, NAUDIO
 struct ctts_gpt {
   ctts_gpt_weights w;
   std::vector<const void*> wqkv, wo, wgu, wd;
-  std::vector<const void*> wqkv_pk, wo_pk, wgu_pk, wd_pk;   // fragment-packed copies for the decode step (perf mode), or empty
-  bool dec_packed = false;
+  std::vector<const void*> wqkv_pk, wo_pk, wgu_pk, wd_pk;   // fragment-packed copies for the decode step, or empty
+  bool dec_packed = false;     // perf mode (bf16 weights): decode.hip
+  bool dec_packed32 = false;   // parity mode (f32 weights): decode32.hip
   std::vector<const float*> ln1, ln2;
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
@@ -58,6 +59,7 @@ struct GptWs {
   uint16_t* xb;  // bf16 copy of the residual stream (perf mode); ao / act are reused as bf16 buffers there
   // decode step on fragment-packed operands (decode.hip): row tiles of 16 utterances
   uint16_t *xp, *aop, *actp;
+  float *xp32, *aop32, *actp32;   // the same in float32 (parity mode, decode32.hip)
   RowDesc* desc;
   float* att_part;    // attention remainder splitting: partials of the split units' pieces, and their arrival counters
   int32_t* att_cnt;
@@ -81,6 +83,9 @@ static GptWs carve(void* base, int B, int T) {
   w.xp = (uint16_t*)(p + off); off += align_up(Bp * HID * 2);
   w.aop = (uint16_t*)(p + off); off += align_up(Bp * HID * 2);
   w.actp = (uint16_t*)(p + off); off += align_up(Bp * INTER * 2);
+  w.xp32 = (float*)(p + off); off += align_up(Bp * HID * 4);
+  w.aop32 = (float*)(p + off); off += align_up(Bp * HID * 4);
+  w.actp32 = (float*)(p + off); off += align_up(Bp * INTER * 4);
   w.desc = (RowDesc*)(p + off); off += align_up(Bp * sizeof(RowDesc));
   w.row_map = (int32_t*)(p + off); off += align_up(Bp * sizeof(int32_t));
   w.att_part = (float*)(p + off); off += align_up((size_t)ATT_CUS_MAX * ATT_SPLIT_MAX * 66 * sizeof(float));
@@ -102,14 +107,15 @@ extern "C" int ctts_gpt_create(ctts_gpt** out, const ctts_gpt_weights* w) {
   g->wd.assign(w->wd, w->wd + L);
   g->ln1.assign(w->ln1, w->ln1 + L);
   g->ln2.assign(w->ln2, w->ln2 + L);
-  if (w->weight_dtype == CTTS_BF16 && w->wqkv_pk && w->wo_pk && w->wgu_pk && w->wd_pk) {
+  if (w->wqkv_pk && w->wo_pk && w->wgu_pk && w->wd_pk) {   // packed in the order of the weight dtype's decode kernel
     g->wqkv_pk.assign(w->wqkv_pk, w->wqkv_pk + L);
     g->wo_pk.assign(w->wo_pk, w->wo_pk + L);
     g->wgu_pk.assign(w->wgu_pk, w->wgu_pk + L);
     g->wd_pk.assign(w->wd_pk, w->wd_pk + L);
-    g->dec_packed = true;
     const char* e = getenv("CTTS_DEC_PACKED");   // =0: decode on the row-major kernels (A/B)
-    if (e && atoi(e) == 0) g->dec_packed = false;
+    const bool on = !(e && atoi(e) == 0);
+    g->dec_packed = on && w->weight_dtype == CTTS_BF16;
+    g->dec_packed32 = on && w->weight_dtype != CTTS_BF16 && w->kv_dtype != CTTS_BF16;
   }
   { const char* e = getenv("CTTS_SKIP_FINISHED"); if (e && atoi(e) == 0) g->skip_finished = false; }
   {
@@ -256,7 +262,33 @@ static int run_step(ctts_gpt* g, const ctts_gen_state* s, int q_per_b, hipStream
     f.C32 = ws.x; f.ldc = HID; f.Cb = ws.xb; f.ldcb = HID; f.ssq_out = ws.ssq;
     { Prof p(g, 6, st, prof_ok); CK(launch_gemm_fast(f, st)); }
   }
-  for (int l = 0; !fast && l < g->w.n_layers; ++l) {
+  const bool packed32 = !fast && dec && g->dec_packed32;   // parity mode decode step on fragment-packed f32 operands (decode32.hip)
+  for (int l = 0; packed32 && l < g->w.n_layers; ++l) {
+    void* kc = (char*)s->kcache + kv_layer * l;
+    void* vc = (char*)s->vcache + kv_layer * l;
+    Dec32Args d;
+    memset(&d, 0, sizeof(d));
+    d.M = M; d.eps = g->w.rms_eps; d.n_active = nact;
+    // RMSNorm + QKV
+    d.Ap = ws.xp32; d.Wp = (const float*)g->wqkv_pk[l]; d.N = 3 * HID; d.K = HID; d.X = ws.x; d.ldx = HID; d.norm_w = g->ln1[l];
+    d.epi = EPI_STORE; d.C = ws.qkv; d.ldc = 3 * HID;
+    { Prof p(g, 1, st, prof_ok); CK(launch_gemm_dec32(d, st)); }
+    { Prof p(g, 2, st, prof_ok); CK(launch_rope_append(ws.qkv, kc, vc, kt, cmax, g->w.rope_cos, g->w.rope_sin, rm, M, st)); }
+    { Prof p(g, 3, st, prof_ok); CK(launch_attention(ws.qkv, kc, vc, kt, cmax, ws.aop32, 3, rm, M, st)); }
+    // o_proj + residual
+    d.Ap = ws.aop32; d.Wp = (const float*)g->wo_pk[l]; d.N = HID; d.X = nullptr; d.norm_w = nullptr; d.epi = EPI_RES; d.C = ws.x; d.ldc = HID;
+    d.res = ws.x; d.ldr = HID; d.Cp = ws.xp32; d.kch_out = HID / 16;
+    { Prof p(g, 4, st, prof_ok); CK(launch_gemm_dec32(d, st)); }
+    // RMSNorm + gate/up + SiLU*up
+    d.Ap = ws.xp32; d.Wp = (const float*)g->wgu_pk[l]; d.N = INTER; d.X = ws.x; d.norm_w = g->ln2[l]; d.epi = EPI_SILU_MUL; d.C = nullptr;
+    d.res = nullptr; d.Cp = ws.actp32; d.kch_out = INTER / 16;
+    { Prof p(g, 5, st, prof_ok); CK(launch_gemm_dec32(d, st)); }
+    // down_proj + residual
+    d.Ap = ws.actp32; d.Wp = (const float*)g->wd_pk[l]; d.N = HID; d.K = INTER; d.X = nullptr; d.norm_w = nullptr; d.epi = EPI_RES;
+    d.C = ws.x; d.ldc = HID; d.res = ws.x; d.ldr = HID; d.Cp = ws.xp32; d.kch_out = HID / 16;
+    { Prof p(g, 6, st, prof_ok); CK(launch_gemm_dec32(d, st)); }
+  }
+  for (int l = 0; !fast && !packed32 && l < g->w.n_layers; ++l) {
     void* kc = (char*)s->kcache + kv_layer * l;
     void* vc = (char*)s->vcache + kv_layer * l;
     GemmArgs a;
@@ -339,7 +371,8 @@ static int decode_body(ctts_gpt* g, const ctts_gen_state* s, hipStream_t st, boo
   { Prof p(g, 0, st, prof_ok); const bool fast = g->w.weight_dtype == CTTS_BF16;
     const bool packed = fast && g->dec_packed;
     const bool dc = dev_compact(g, s);
-    StepPrep sp{ws.desc, s->kv_start, g->skip_finished ? s->finish : nullptr, packed ? 1 : 0, dc ? ws.row_map : nullptr,
+    StepPrep sp{ws.desc, s->kv_start, g->skip_finished ? s->finish : nullptr, packed ? 1 : 0, (!fast && g->dec_packed32) ? ws.xp32 : nullptr,
+                dc ? ws.row_map : nullptr,
                 dc ? const_cast<int32_t*>(s->n_active) : nullptr};
     uint16_t* xb = fast ? (packed ? ws.xp : ws.xb) : nullptr;
     if (s->infer_text)
@@ -609,6 +642,16 @@ extern "C" int ctts_k_gemm_dec(const uint16_t* Ap, const uint16_t* Wp, int32_t M
   d.ldc = ldc; d.Cp = Cp; d.kch_out = kch_out; d.ssq_out = ssq_out; d.force_mb = force_mb;
   { const char* e = getenv("CTTS_GEMM_DBG_PTR"); if (e) d.dbg = (long long*)strtoull(e, nullptr, 0); }   // probes only
   CK(launch_gemm_dec(d, (hipStream_t)stream));
+  return 0;
+}
+extern "C" int ctts_k_gemm_dec32(const float* Ap, const float* Wp, int32_t M, int32_t N, int32_t K, const int32_t* n_active, const float* X,
+                                 int32_t ldx, const float* norm_w, float eps, int32_t epi, float* C, int32_t ldc, const float* res, int32_t ldr,
+                                 float* Cp, int32_t kch_out, int32_t force_mb, void* stream) {
+  Dec32Args d;
+  memset(&d, 0, sizeof(d));
+  d.Ap = Ap; d.Wp = Wp; d.M = M; d.N = N; d.K = K; d.n_active = n_active; d.X = X; d.ldx = ldx; d.norm_w = norm_w; d.eps = eps; d.epi = epi;
+  d.C = C; d.ldc = ldc; d.res = res; d.ldr = ldr; d.Cp = Cp; d.kch_out = kch_out; d.force_mb = force_mb;
+  CK(launch_gemm_dec32(d, (hipStream_t)stream));
   return 0;
 }
 extern "C" int ctts_k_rows_prep(const float* x32, uint16_t* xb, float* ssq, int32_t M, void* stream) {

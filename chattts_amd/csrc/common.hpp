@@ -100,3 +100,19 @@ __device__ __forceinline__ u128 load16(const void* p) { return *reinterpret_cast
 __device__ __forceinline__ size_t pk_off(int m, int c, int kch) {
   return ((size_t)((m >> 4) * kch + (c >> 5)) * 64 + (((c & 31) >> 3) << 4) + (m & 15)) * 8 + (c & 7);
 }
+// The float32 twin (decode32.hip, parity mode): [rows/16][C/16][lane = (c%16)/4 * 16 + row%16][c%4] -- one contiguous KiB per
+// (16-row tile, 16-column chunk) in the lane order of four consecutive v_mfma_f32_16x16x4_f32 steps.  kch = C / 16.
+__device__ __forceinline__ size_t pk32_off(int m, int c, int kch) {
+  return ((size_t)((m >> 4) * kch + (c >> 4)) * 64 + (((c & 15) >> 2) << 4) + (m & 15)) * 4 + (c & 3);
+}
+// 1 / rms of one float32 row, evaluated by a whole wave (every lane returns the value).  The f32 parity mode's RMSNorm
+// prologue: gemm_skinny_k and gemm_dec32_k must produce the same bits, so both call this.
+__device__ __forceinline__ float wave_row_rstd(const float* __restrict__ row, int K, float eps, int lane) {
+  float ss = 0.f;
+  for (int k = lane * 4; k < K; k += 256) {
+    const float4 v = *reinterpret_cast<const float4*>(row + k);
+    ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  ss = wave_sum(ss);
+  return 1.0f / sqrtf(ss / (float)K + eps);
+}

@@ -1,0 +1,255 @@
+// Decode-step projections of the GPT path in the float32 PARITY mode, on FRAGMENT-PACKED float32 operands (M <= 64 live rows
+// per tile).
+//
+// Reference op: the four nn.Linear calls of a HF Llama decoder layer reached from /root/reference/ChatTTS/model/gpt.py:419-427
+// (in-tree twin /root/reference/examples/onnx/modeling_llama.py:415-417 q/k/v_proj, :500 o_proj, :293 gate/up/down) with the
+// RMSNorm of :76-84 as prologue and the residual add / SiLU(gate)*up as epilogue.
+//
+// Why: the parity mode is the one whose token ids are bit-identical to the reference's CPU run, and it was still on
+// gemm_skinny_k<float> (gemm.hip), which pulls MFMA fragments out of row-major [rows][K] float32 operands: every 16-byte lane
+// load of a wave instruction is a different 128-byte line, and every workgroup pulls the whole 64 x K activation tile that way
+// (12 288 line visits at K = 768, 49 152 at K = 3072 -- 6 and 23 us of address/tag work per workgroup before any MFMA issues;
+// profiles/r2o_f32_kernel_stats.csv: 25-35 us per projection, 2.6 ms per step).  Here both operands are stored in the order
+// the matrix core consumes them,
+//
+//     packed[tile of 16 rows][k chunk of 16][lane = (k%16)/4 * 16 + row%16][k%4]          (f32, 16 bytes per lane)
+//
+// so a wave instruction reads one contiguous KiB.  THE ARITHMETIC IS UNCHANGED, bit for bit: the goldens of the parity mode were
+// established with gemm_skinny_k<float>, so this kernel keeps its exact operation order per output element -- wave w owns
+// chunks w, w+4, w+8, ...; a chunk is four v_mfma_f32_16x16x4_f32 steps (k%4 = 0,1,2,3; each an exact k-ordered fmaf chain on
+// gfx950); the partial tiles are added ((w0 + w1) + w2) + w3; the RMSNorm scale is applied to the A fragment as
+// norm_w[k] * (x * rstd) with rstd from common.hpp wave_row_rstd (shared with gemm_skinny_k); the epilogues are res + acc and
+// silu(gate) * up.  tests/test_gpu_kernels.py::test_gemm_dec32_bit_identical holds the two kernels to exact equality.
+//
+// Producers write the packed activations: embed_codes_k (StepPrep.xp32), attention_k<float> (packed output), and the RES /
+// SILU_MUL epilogues below.  Weights are packed once at load (engine.py pack_frag32).
+#include <stdlib.h>
+
+#include "common.hpp"
+#include "kernels.hpp"
+
+constexpr int D32_U = 6;   // k chunks of 16 per wave and round: D32_U * (NACC + NMB) 16-byte loads in flight per lane
+
+template <int NMB, int MBT, bool RMS, int EPI>
+__device__ __forceinline__ void dec32_body(const Dec32Args& a, const int M, const int tile, const int mt0,
+                                           u128 (&wf)[(EPI == EPI_SILU_MUL) ? 2 : 1][D32_U],
+                                           float (*red)[(EPI == EPI_SILU_MUL) ? 2 : 1][MBT][64][4], float* rstd_s) {
+  constexpr int NACC = (EPI == EPI_SILU_MUL) ? 2 : 1;
+  constexpr int U = D32_U;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 15, g = lane >> 4;
+  const int n0 = tile * 16, m0 = mt0 * 16;
+  const int N = a.N, K = a.K, KCH = K >> 4;
+
+  // finishing work = 4*NMB (row tile, accumulator register) pairs of 64 outputs; finishing wave w owns PPW consecutive pairs
+  // (see decode.hip): NMB >= 3: wave w finishes row tile w; NMB = 2: tile w/2, registers 2(w&1)..+1; NMB = 1: register w
+  constexpr int PPW = NMB >= 3 ? 4 : NMB;
+  constexpr int NF = NMB >= 3 ? NMB : 4;
+  const int fmb = (wave * PPW) >> 2, fr0 = (wave * PPW) & 3;   // meaningful for wave < NF
+  float pre0[PPW];  // RES: residual, requested before the operand loads
+#pragma unroll
+  for (int q = 0; q < PPW; ++q) pre0[q] = 0.f;
+  if (EPI == EPI_RES && wave < NF) {
+#pragma unroll
+    for (int q = 0; q < PPW; ++q) {
+      const int row = min(m0 + 16 * fmb + 4 * g + fr0 + q, M - 1);
+      pre0[q] = a.res[(size_t)row * a.ldr + n0 + li];
+    }
+  }
+
+  if (RMS) {
+    for (int r = wave; r < 16 * NMB; r += 4) {
+      const int m = min(m0 + r, M - 1);
+      const float rstd = wave_row_rstd(a.X + (size_t)m * a.ldx, K, a.eps, lane);
+      if (lane == 0) rstd_s[r] = rstd;
+    }
+    __syncthreads();
+  }
+  float rs[NMB];
+#pragma unroll
+  for (int mb = 0; mb < NMB; ++mb) rs[mb] = RMS ? rstd_s[16 * mb + li] : 1.0f;
+
+  const int nper = KCH / 4;   // chunks per wave (launcher guarantees nper % U == 0); wave w owns chunks 4 i + w
+  const u128* wp = reinterpret_cast<const u128*>(a.Wp) + ((size_t)tile * KCH + wave) * 64 + lane;
+  const u128* wp2 = wp + (size_t)(N >> 4) * KCH * 64;  // SILU_MUL: the "up" tile of the same columns
+  const u128* ap = reinterpret_cast<const u128*>(a.Ap) + ((size_t)mt0 * KCH + wave) * 64 + lane;
+  const bool w_once = a.w_nt && gridDim.y == 1;  // a single row group reads W: stream it past the caches
+
+  f32x4 acc[NACC][NMB];
+#pragma unroll
+  for (int na = 0; na < NACC; ++na)
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb) acc[na][mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int i = 0; i < nper; i += U) {
+    u128 af[NMB][U];
+    float4 nw[U];
+    if (i > 0) {   // the first round's weight fragments were requested at kernel entry (before *n_active was known)
+      if (w_once) {
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+          wf[0][j] = load16_nt(wp + (size_t)(i + j) * 256);
+          if (NACC == 2) wf[1][j] = load16_nt(wp2 + (size_t)(i + j) * 256);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+          wf[0][j] = load16(wp + (size_t)(i + j) * 256);
+          if (NACC == 2) wf[1][j] = load16(wp2 + (size_t)(i + j) * 256);
+        }
+      }
+    }
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+      for (int j = 0; j < U; ++j) af[mb][j] = load16(ap + (size_t)mb * KCH * 64 + (size_t)(i + j) * 256);
+    if (RMS) {
+#pragma unroll
+      for (int j = 0; j < U; ++j) nw[j] = *reinterpret_cast<const float4*>(a.norm_w + ((i + j) * 4 + wave) * 16 + g * 4);
+    }
+    // every load of the round in flight before the first MFMA (hipcc otherwise sinks each load next to its use)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < U; ++j)
+#pragma unroll
+      for (int mb = 0; mb < NMB; ++mb) {
+        float4 a0 = *reinterpret_cast<const float4*>(&af[mb][j]);
+        if (RMS) {
+          const float s = rs[mb];
+          a0.x = nw[j].x * (a0.x * s); a0.y = nw[j].y * (a0.y * s); a0.z = nw[j].z * (a0.z * s); a0.w = nw[j].w * (a0.w * s);
+        }
+#pragma unroll
+        for (int na = 0; na < NACC; ++na) {
+          const float4 b = *reinterpret_cast<const float4*>(&wf[na][j]);
+          f32x4 c = acc[na][mb];
+          c = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b.x, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b.y, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b.z, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b.w, c, 0, 0, 0);
+          acc[na][mb] = c;
+        }
+      }
+  }
+
+#pragma unroll
+  for (int na = 0; na < NACC; ++na)
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb) *reinterpret_cast<f32x4*>(&red[wave][na][mb][lane][0]) = acc[na][mb];
+  __syncthreads();
+  if (wave >= NF) return;
+
+  float t[4][NACC][PPW];   // the 4 waves' partials of this wave's outputs
+#pragma unroll
+  for (int w = 0; w < 4; ++w)
+#pragma unroll
+    for (int na = 0; na < NACC; ++na) {
+      if constexpr (PPW == 4) {
+        *reinterpret_cast<f32x4*>(t[w][na]) = *reinterpret_cast<const f32x4*>(&red[w][na][fmb][lane][0]);
+      } else if constexpr (PPW == 2) {
+        *reinterpret_cast<float2*>(t[w][na]) = *reinterpret_cast<const float2*>(&red[w][na][fmb][lane][fr0]);
+      } else {
+        t[w][na][0] = red[w][na][fmb][lane][fr0];
+      }
+    }
+
+  const int col = n0 + li;
+#pragma unroll
+  for (int q = 0; q < PPW; ++q) {
+    const int row = m0 + 16 * fmb + 4 * g + fr0 + q;  // C/D map of the 16x16 MFMA: col = lane & 15, row = 4 (lane >> 4) + reg
+    if (row >= M) continue;
+    float v = ((t[0][0][q] + t[1][0][q]) + t[2][0][q]) + t[3][0][q];   // fixed order, as gemm_skinny_k
+    if (EPI == EPI_SILU_MUL) {
+      const float u = ((t[0][NACC - 1][q] + t[1][NACC - 1][q]) + t[2][NACC - 1][q]) + t[3][NACC - 1][q];
+      v = silu_f(v) * u;
+    } else if (EPI == EPI_RES) {
+      v = pre0[q] + v;
+    }
+    if (EPI != EPI_SILU_MUL) a.C[(size_t)row * a.ldc + col] = v;
+    if (EPI != EPI_STORE && a.Cp != nullptr) a.Cp[pk32_off(row, col, a.kch_out)] = v;
+  }
+}
+
+template <int MBT, bool RMS, int EPI>
+__global__ __launch_bounds__(256) void gemm_dec32_k(Dec32Args a) {
+  constexpr int NACC = (EPI == EPI_SILU_MUL) ? 2 : 1;
+  __shared__ __attribute__((aligned(16))) float red[4][NACC][MBT][64][4];
+  __shared__ float rstd_s[16 * MBT];
+
+  const int tile = blockIdx.x, mt0 = blockIdx.y * MBT;
+  // the weight fragments of the first round depend on nothing but the kernel arguments: request them before the live-row
+  // count (a dependent scalar load) is known
+  u128 wf[NACC][D32_U];
+  {
+    const int KCH = a.K >> 4, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const u128* wp = reinterpret_cast<const u128*>(a.Wp) + ((size_t)tile * KCH + wave) * 64 + lane;
+    const u128* wp2 = wp + (size_t)(a.N >> 4) * KCH * 64;
+    const bool w_once = a.w_nt && gridDim.y == 1;
+    if (w_once) {
+#pragma unroll
+      for (int j = 0; j < D32_U; ++j) {
+        wf[0][j] = load16_nt(wp + (size_t)j * 256);
+        if (NACC == 2) wf[1][j] = load16_nt(wp2 + (size_t)j * 256);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < D32_U; ++j) {
+        wf[0][j] = load16(wp + (size_t)j * 256);
+        if (NACC == 2) wf[1][j] = load16(wp2 + (size_t)j * 256);
+      }
+    }
+  }
+  const int M = a.n_active ? min(*a.n_active, a.M) : a.M;   // live (compact) rows
+  if (mt0 * 16 >= M) return;
+  const int nmb = min(MBT, (M - mt0 * 16 + 15) >> 4);
+  if constexpr (MBT == 1) {
+    dec32_body<1, MBT, RMS, EPI>(a, M, tile, mt0, wf, red, rstd_s);
+  } else if constexpr (MBT == 2) {
+    if (nmb == 1) dec32_body<1, MBT, RMS, EPI>(a, M, tile, mt0, wf, red, rstd_s);
+    else dec32_body<2, MBT, RMS, EPI>(a, M, tile, mt0, wf, red, rstd_s);
+  } else {
+    if (nmb == 1) dec32_body<1, MBT, RMS, EPI>(a, M, tile, mt0, wf, red, rstd_s);
+    else if (nmb == 2) dec32_body<2, MBT, RMS, EPI>(a, M, tile, mt0, wf, red, rstd_s);
+    else if (nmb == 3) dec32_body<3, MBT, RMS, EPI>(a, M, tile, mt0, wf, red, rstd_s);
+    else dec32_body<4, MBT, RMS, EPI>(a, M, tile, mt0, wf, red, rstd_s);
+  }
+}
+
+static int env_int32(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
+template <int MBT>
+static hipError_t dec32_dispatch(const Dec32Args& a, hipStream_t st) {
+  const int mt = (a.M + 15) / 16;
+  dim3 grid(a.N / 16, (mt + MBT - 1) / MBT), block(256);
+  const bool rms = a.norm_w != nullptr;
+  if (a.epi == EPI_STORE && rms) CTTS_LAUNCH((gemm_dec32_k<MBT, true, EPI_STORE>), grid, block, st, a);
+  else if (a.epi == EPI_STORE) CTTS_LAUNCH((gemm_dec32_k<MBT, false, EPI_STORE>), grid, block, st, a);
+  else if (a.epi == EPI_RES && !rms) CTTS_LAUNCH((gemm_dec32_k<MBT, false, EPI_RES>), grid, block, st, a);
+  else if (a.epi == EPI_SILU_MUL && rms) CTTS_LAUNCH((gemm_dec32_k<MBT, true, EPI_SILU_MUL>), grid, block, st, a);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+hipError_t launch_gemm_dec32(const Dec32Args& a_in, hipStream_t st) {
+  Dec32Args a = a_in;
+  static int nt = -1, mb_qkv = -1, mb_silu = -1, mb_o = -1, mb_down = -1;
+  if (nt < 0) {
+    nt = env_int32("CTTS_W_NT", 1);
+    mb_qkv = env_int32("CTTS_D32_MB_QKV", 2); mb_silu = env_int32("CTTS_D32_MB_SILU", 2);
+    mb_o = env_int32("CTTS_D32_MB_O", 1); mb_down = env_int32("CTTS_D32_MB_DOWN", 1);
+  }
+  a.w_nt = nt;
+  // K: chunks of 16, 4 waves, rounds of D32_U chunks
+  if (a.M <= 0 || a.N <= 0 || (a.N & 15) || a.K % (16 * 4 * D32_U) != 0) return hipErrorInvalidValue;
+  if (a.norm_w != nullptr && (a.X == nullptr || (a.ldx & 3))) return hipErrorInvalidValue;
+  // Rows per workgroup.  f32 MFMA (256 flop per clock and CU) is what these launches are made of -- 64 x 2304 x 768 costs 3.5k
+  // clocks of every CU if perfectly spread -- so the row tiles are cut until the grid has a few workgroups per CU; the 16-row
+  // workgroups of o / down (48 weight tiles only) are the same choice the bf16 kernel makes.
+  int mb = a.epi == EPI_SILU_MUL ? mb_silu : a.epi == EPI_RES ? (a.K > 768 ? mb_down : mb_o) : mb_qkv;
+  if (a.force_mb) mb = a.force_mb;
+  if (mb >= 4) return dec32_dispatch<4>(a, st);
+  if (mb == 2) return dec32_dispatch<2>(a, st);
+  return dec32_dispatch<1>(a, st);
+}

@@ -47,14 +47,8 @@ __global__ __launch_bounds__(256) void gemm_skinny_k(GemmArgs a) {
   if (RMS) {
     for (int r = wave; r < 16 * MB; r += 4) {
       const int m = min(m0 + r, M - 1);
-      const float* row = a.A + (size_t)m * a.lda;
-      float ss = 0.f;
-      for (int k = lane * 4; k < K; k += 256) {
-        const float4 v = *reinterpret_cast<const float4*>(row + k);
-        ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-      }
-      ss = wave_sum(ss);
-      if (lane == 0) rstd_s[r] = 1.0f / sqrtf(ss / (float)K + a.eps);
+      const float rstd = wave_row_rstd(a.A + (size_t)m * a.lda, K, a.eps, lane);
+      if (lane == 0) rstd_s[r] = rstd;
     }
     __syncthreads();
   }

@@ -27,8 +27,9 @@ __device__ __forceinline__ bool row_absent(const int32_t* n_active, int m) { ret
 // emit one residual-stream row: f32, optional bf16 copy, optional 48 partial sums of squares
 // (thread t owns columns 4t..4t+3; a partial covers 16 columns = 4 consecutive threads)
 __device__ __forceinline__ void emit_row(float4 s, int t, float* __restrict__ x_row, uint16_t* __restrict__ xb_row,
-                                         float* __restrict__ ssq_row) {
+                                         float* __restrict__ ssq_row, float* __restrict__ xp32_at = nullptr) {
   if (x_row) *reinterpret_cast<float4*>(x_row + t * 4) = s;
+  if (xp32_at) *reinterpret_cast<float4*>(xp32_at) = s;   // columns 4t..4t+3 are one lane's 16 bytes of the packed f32 order
   if (xb_row) {
     ushort4 o;
     o.x = f32_to_bf16(s.x); o.y = f32_to_bf16(s.y); o.z = f32_to_bf16(s.z); o.w = f32_to_bf16(s.w);
@@ -112,11 +113,12 @@ __global__ __launch_bounds__(192) void embed_codes_k(const float* __restrict__ e
     const float4 v = *reinterpret_cast<const float4*>(emb + ((size_t)k * NAUDIO + id) * HID + t * 4);
     if (k == 0) s = v; else { s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
   }
-  emit_row(s, t, x + (size_t)m * HID, xb_row_ptr(xb, m, t, sp.xb_packed), ssq ? ssq + (size_t)m * SSQ_PARTS : nullptr);
+  emit_row(s, t, x + (size_t)m * HID, xb_row_ptr(xb, m, t, sp.xb_packed), ssq ? ssq + (size_t)m * SSQ_PARTS : nullptr,
+           sp.xp32 ? sp.xp32 + pk32_off(m, 4 * t, HID / 16) : nullptr);
 }
 
 static StepPrep prep_or_none(const StepPrep* p) {
-  StepPrep sp{nullptr, nullptr, nullptr, 0, nullptr, nullptr};
+  StepPrep sp{nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr};
   if (p) sp = *p;
   return sp;
 }
@@ -217,6 +219,10 @@ template <> __device__ __forceinline__ void unpack16<bf16_t, 8>(const u128& r, f
   f[6] = __uint_as_float(r.w << 16); f[7] = __uint_as_float(r.w & 0xffff0000u);
 }
 
+// packed attention output: the A operand of o_proj in fragment order (bf16: decode.hip, f32: decode32.hip)
+template <typename OT> __device__ __forceinline__ size_t pko_off(int m, int c);
+template <> __device__ __forceinline__ size_t pko_off<bf16_t>(int m, int c) { return pk_off(m, c, HID / 32); }
+template <> __device__ __forceinline__ size_t pko_off<float>(int m, int c) { return pk32_off(m, c, HID / 16); }
 template <typename OT> __device__ __forceinline__ void store_out(OT* p, float v);
 template <> __device__ __forceinline__ void store_out<float>(float* p, float v) { *p = v; }
 template <> __device__ __forceinline__ void store_out<bf16_t>(bf16_t* p, float v) { *p = f32_to_bf16(v); }
@@ -381,7 +387,7 @@ __global__ __launch_bounds__(64 * NW) void attention_k(const float* __restrict__
   if (NW == 1) {
     if (kg == 0) {
       const float inv = 1.0f / lrun;
-      OT* op = PKO ? out + pk_off(m, h * HDIM + dl * DPL, HID / 32) : out + (size_t)m * HID + h * HDIM + dl * DPL;
+      OT* op = PKO ? out + pko_off<OT>(m, h * HDIM + dl * DPL) : out + (size_t)m * HID + h * HDIM + dl * DPL;
 #pragma unroll
       for (int e = 0; e < DPL; ++e) store_out<OT>(op + e, acc[e] * inv);
     }
@@ -440,7 +446,7 @@ __global__ __launch_bounds__(64 * NW) void attention_k(const float* __restrict__
       }
       if (tid == 0) __hip_atomic_store(rm.sp_cnt + su, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
     }
-    store_out<OT>(PKO ? out + pk_off(m, h * HDIM + tid, HID / 32) : out + (size_t)m * HID + h * HDIM + tid, o / L);
+    store_out<OT>(PKO ? out + pko_off<OT>(m, h * HDIM + tid) : out + (size_t)m * HID + h * HDIM + tid, o / L);
   }
 }
 
@@ -608,6 +614,11 @@ hipError_t launch_attention(const float* qkv, const void* kcache, const void* vc
                   (const bf16_t*)vcache, cmax, (bf16_t*)out, rm);
     else
       CTTS_LAUNCH((attention_k<bf16_t, 4, bf16_t, true>), grid, dim3(256), st, qkv, (const bf16_t*)kcache, (const bf16_t*)vcache, cmax, (bf16_t*)out, rm);
+    return hipGetLastError();
+  }
+  if (out_bf16 == 3) {   // decode, f32 parity mode: f32 output in the fragment-packed order o_proj of decode32.hip reads
+    if (!decode || kv_wt == WT_BF16) return hipErrorInvalidValue;
+    CTTS_LAUNCH((attention_k<float, 4, float, true>), grid, dim3(256), st, qkv, (const float*)kcache, (const float*)vcache, cmax, (float*)out, rm);
     return hipGetLastError();
   }
   if (decode && nw8 && kv_wt == WT_BF16 && out_bf16) {
@@ -871,7 +882,8 @@ __global__ __launch_bounds__(192) void embed_text_k(const float* __restrict__ em
   int id = (int)ids_buf[((size_t)b * tcap + slot) * NVQ];  // slot 0 (gpt.py:407)
   id = min(max(id, 0), n_text - 1);
   const float4 s = *reinterpret_cast<const float4*>(emb_text + (size_t)id * HID + t * 4);
-  emit_row(s, t, x + (size_t)m * HID, xb_row_ptr(xb, m, t, sp.xb_packed), ssq ? ssq + (size_t)m * SSQ_PARTS : nullptr);
+  emit_row(s, t, x + (size_t)m * HID, xb_row_ptr(xb, m, t, sp.xb_packed), ssq ? ssq + (size_t)m * SSQ_PARTS : nullptr,
+           sp.xp32 ? sp.xp32 + pk32_off(m, 4 * t, HID / 16) : nullptr);
 }
 
 hipError_t launch_embed_text(const float* emb_text, int n_text, const int64_t* ids_buf, int tcap, const int32_t* len, float* x,

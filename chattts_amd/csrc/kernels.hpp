@@ -126,6 +126,26 @@ struct DecGemmArgs {
 };
 hipError_t launch_gemm_dec(const DecGemmArgs& a, hipStream_t st);
 
+// ---- decode-step projections of the f32 parity mode on fragment-packed float32 operands (decode32.hip) -----------------
+// Same arithmetic, bit for bit, as gemm_skinny_k<float> (the kernel the parity goldens were established with): 4 waves take
+// the 16-wide k chunks round-robin, each chunk is four k-ordered v_mfma_f32_16x16x4_f32 steps, the 4 partial tiles are added
+// ((w0 + w1) + w2) + w3.  Only WHERE the operands live changes (common.hpp pk32_off): one contiguous KiB per wave load.
+struct Dec32Args {
+  const float* Ap;              // activations, packed [ceil(M/16)][K/16][64][4]; with norm_w: the UN-normalised residual stream
+  const float* Wp;              // weights, packed [N/16 (SILU_MUL: gate tiles then up tiles)][K/16][64][4]
+  int M, N, K;                  // M = rows the buffers hold; live rows = *n_active
+  const int32_t* n_active;      // device scalar or null (M)
+  const float* X; int ldx;      // RMSNorm prologue: the same rows, row-major (the sum of squares is taken in gemm_skinny_k's order)
+  const float* norm_w; float eps;   // [K] or null: A' = norm_w[k] * (A[m,k] * rstd[m]) applied to the fragments
+  int epi;                      // EPI_STORE: C row-major | EPI_RES: C = res + acc (row-major) and Cp | EPI_SILU_MUL: Cp only
+  float* C; int ldc;
+  const float* res; int ldr;
+  float* Cp; int kch_out;       // packed f32 copy of the output for the next projection (kch_out = its columns / 16), or null
+  int force_mb;                 // tests only
+  int w_nt;                     // set by the launcher
+};
+hipError_t launch_gemm_dec32(const Dec32Args& a, hipStream_t st);
+
 // ---- GPT step kernels -------------------------------------------------------------------------
 struct GptRowMap {
   // query row m of a launch maps to (b, slot): prefill (q_per_b = T): b = m / T, slot = slot0 + m % T (slot0 > 0: a later
@@ -161,6 +181,7 @@ struct StepPrep {
   const int32_t* kv_start;  // [slots]
   const uint8_t* finish;    // [slots] or null
   int xb_packed;
+  float* xp32;              // f32 parity mode: fragment-packed f32 copy of the new residual rows (pk32_off), or null
   // device-side compaction (optional): compact row m becomes the m-th utterance (ascending slot) whose finish flag is 0;
   // the kernel writes row_map_out[m] for the rows that exist and the live count to *n_active_out, which every later
   // kernel of the step reads -- finished utterances leave the step at once, without the host

@@ -169,6 +169,20 @@ def pack_frag(w: torch.Tensor) -> torch.Tensor:
     return w.reshape(R // 16, 16, Cc // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous()
 
 
+def pack_frag32(w: torch.Tensor) -> torch.Tensor:
+    """float32 twin of pack_frag for the parity mode (csrc/decode32.hip): [R, C] (R % 16 == 0, C % 16 == 0) ->
+    [R/16][C/16][lane = (c%16)/4 * 16 + r%16][c%4], one contiguous KiB per (16-row tile, 16-column chunk) in the lane order of
+    four consecutive v_mfma_f32_16x16x4_f32 steps."""
+    R, Cc = w.shape
+    assert R % 16 == 0 and Cc % 16 == 0
+    return w.reshape(R // 16, 16, Cc // 16, 4, 4).permute(0, 2, 3, 1, 4).contiguous()
+
+
+def unpack_frag32(p: torch.Tensor, R: int, Cc: int) -> torch.Tensor:
+    """inverse of pack_frag32 (tests / debugging)"""
+    return p.reshape(R // 16, Cc // 16, 4, 16, 4).permute(0, 3, 1, 2, 4).reshape(R, Cc).contiguous()
+
+
 def unpack_frag(p: torch.Tensor, R: int, Cc: int) -> torch.Tensor:
     """inverse of pack_frag (tests / debugging)"""
     return p.reshape(R // 16, Cc // 32, 4, 16, 8).permute(0, 3, 1, 2, 4).reshape(R, Cc).contiguous()
@@ -233,9 +247,10 @@ class GptEngine:
         cos, sin = rope_tables(max_pos)
         self.rope_cos, self.rope_sin = cos.to(dev), sin.to(dev)
         self._arrs = [_lib.ptr_array(x) for x in (self.wqkv, self.wo, self.wgu, self.wd, self.ln1, self.ln2)]
-        # perf mode: a second copy of the four matrices in the fragment-packed order the DECODE kernels read (decode.hip);
-        # the row-major copy stays for the LDS-tiled prefill kernels (+0.38 GB of the 288 GB)
-        self.packed = [[pack_frag(t) for t in ws] for ws in (self.wqkv, self.wo, self.wgu, self.wd)] if dtype == "bf16" else None
+        # a second copy of the four matrices in the fragment-packed order the DECODE kernels read (bf16: decode.hip, f32:
+        # decode32.hip); the row-major copy stays for the prefill kernels (+0.38 GB / +0.75 GB of the 288 GB)
+        pk = pack_frag if dtype == "bf16" else pack_frag32
+        self.packed = [[pk(t) for t in ws] for ws in (self.wqkv, self.wo, self.wgu, self.wd)]
         self._pk_arrs = None if self.packed is None else [_lib.ptr_array(x) for x in self.packed]
         w = _lib.GptWeights()
         w.n_layers, w.weight_dtype, w.kv_dtype, w.max_pos = self.n_layers, self.code, self.code, max_pos

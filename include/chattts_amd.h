@@ -62,9 +62,11 @@ typedef struct {
   const float* emb_text;           /* [n_text,768] */
   const float* head_text;          /* [n_text,768] folded weight-norm text head */
   int32_t n_text;                  /* 21178 */
-  /* perf mode, optional (NULL: the decode step uses the row-major kernels): the same four matrices per layer in the
-   * fragment-packed order of csrc/decode.hip -- [rows/16][K/32][lane = (k%32)/8*16 + row%16][k%8] bf16, one contiguous KiB per
-   * (16-row tile, 32-wide k chunk); wqkv with the RoPE row permutation and the folded RMSNorm gain like `wqkv` */
+  /* optional (NULL: the decode step uses the row-major kernels): the same four matrices per layer in the fragment-packed order
+   * of the weight dtype's decode kernel.  bf16 (csrc/decode.hip): [rows/16][K/32][lane = (k%32)/8*16 + row%16][k%8], one contiguous
+   * KiB per (16-row tile, 32-wide k chunk); wqkv with the RoPE row permutation and the folded RMSNorm gain like `wqkv`.
+   * f32 (csrc/decode32.hip, needs an f32 KV cache): [rows/16][K/16][lane = (k%16)/4*16 + row%16][k%4] of the plain matrices;
+   * same arithmetic, bit for bit, as the row-major f32 kernels. */
   const void* const* wqkv_pk;
   const void* const* wo_pk;
   const void* const* wgu_pk;
@@ -279,6 +281,12 @@ int ctts_k_qkv_rope(const uint16_t* A, const uint16_t* W, int32_t M, const float
 int ctts_k_gemm_dec(const uint16_t* Ap, const uint16_t* Wp, int32_t M, int32_t N, int32_t K, const int32_t* n_active, const float* ssq_in,
                     float eps, int32_t epi, float* C32, int32_t ldc, uint16_t* Cp, int32_t kch_out, float* ssq_out, int32_t force_mb,
                     void* stream);
+/* the same for the f32 parity mode (csrc/decode32.hip): Ap [ceil(M/16)][K/16][64][4] f32, Wp packed likewise; norm_w != NULL: RMSNorm
+ * prologue (X = the same rows row-major, ldx) ; epi 0 = store C row-major, 1 = C = res + acc (row-major) and Cp (packed, kch_out = N/16),
+ * 2 = SiLU(gate)*up -> Cp.  Bit-identical to ctts_k_gemm(tiled = 0, wt = f32) on the same values. */
+int ctts_k_gemm_dec32(const float* Ap, const float* Wp, int32_t M, int32_t N, int32_t K, const int32_t* n_active, const float* X, int32_t ldx,
+                      const float* norm_w, float eps, int32_t epi, float* C, int32_t ldc, const float* res, int32_t ldr, float* Cp,
+                      int32_t kch_out, int32_t force_mb, void* stream);
 int ctts_k_rows_prep(const float* x32, uint16_t* xb, float* ssq, int32_t M, void* stream);
 int ctts_k_rope_append(float* qkv, void* kcache, void* vcache, int32_t kv_dtype, int32_t cmax, const float* cos_tab, const float* sin_tab,
                        int32_t q_per_b, const int32_t* len, const int32_t* kv_start, int32_t M, void* stream);

@@ -318,6 +318,21 @@ def test_packed_decode_equals_row_major_decode(weights, monkeypatch):
         assert float((a - b).abs().max()) < 1e-4
 
 
+def test_packed_f32_decode_is_bit_identical_to_row_major(weights, monkeypatch):
+    """parity mode: the decode step on fragment-packed f32 operands (csrc/decode32.hip) keeps the operation order of the
+    row-major kernels the goldens were established with -> identical token ids AND bit-identical hidden states"""
+    c = cases.GEN_CASES["b8"]
+    packed = E.GptEngine(weights["gpt"], weights["embed"], DEV, dtype="f32")
+    outs_p, _ = run_case(packed, c, use_graph=True)
+    monkeypatch.setenv("CTTS_DEC_PACKED", "0")
+    plain = E.GptEngine(weights["gpt"], weights["embed"], DEV, dtype="f32")
+    outs_r, _ = run_case(plain, c, use_graph=True)
+    for a, b in zip(outs_p[0].ids, outs_r[0].ids):
+        assert torch.equal(a, b)
+    for a, b in zip(outs_p[0].hiddens, outs_r[0].hiddens):
+        assert torch.equal(a, b)
+
+
 def test_attention_split_in_the_engine(weights, golden, monkeypatch):
     """the whole decode step with and without the attention remainder splitting, teacher-forced on the same token stream
     (the c3w batch: 64 utterances whose number drops as they finish, so the split geometry changes from step to step):

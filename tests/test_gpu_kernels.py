@@ -178,6 +178,49 @@ def test_gemm_dec_packed(G, M, n_act, force_mb):
 
 
 @pytest.mark.parametrize("force_mb", [0, 1, 2, 4])
+@pytest.mark.parametrize("M,n_act", [(1, None), (9, None), (16, 16), (40, 33), (64, None), (64, 45), (100, 70)])
+def test_gemm_dec32_bit_identical(G, M, n_act, force_mb):
+    """parity-mode decode projections on fragment-packed f32 operands (csrc/decode32.hip) against gemm_skinny_k<float>, the
+    kernel the reference goldens of the f32 mode were established with: EXACT equality of every output (same operation order
+    per element), for the four projections of a layer, partial row tiles and a device-side live-row count"""
+    from chattts_amd.engine import pack_frag32, unpack_frag32
+    lib = _lib.lib()
+    rs = np.random.RandomState(M * 11 + (n_act or 0) + force_mb)
+    Mp = (M + 15) // 16 * 16
+    live = M if n_act is None else n_act
+    na_d = None if n_act is None else G.dev(np.array([n_act], np.int32))
+
+    def packed(a, rows, cols):     # [rows_real, cols] -> packed [rows, cols] (pad rows = NaN: they must never reach a live output)
+        pad = np.full((rows, cols), np.nan, f32)
+        pad[: a.shape[0]] = a
+        return pack_frag32(torch.from_numpy(pad)).to(G.DEV)
+
+    for N, K, epi, rms in SK_SHAPES[:4]:
+        A = (rs.standard_normal((M, K)) * (2.0 if rms else 1.0)).astype(f32)
+        nrows = 2 * N if epi == 2 else N
+        W = (rs.standard_normal((nrows, K)) * 0.03).astype(f32)
+        nw = (1.0 + 0.1 * rs.standard_normal(K)).astype(f32) if rms else None
+        res = rs.standard_normal((M, N)).astype(f32) if epi == 1 else None
+        want = G.gemm(A[:live], W, wt="f32", epi=epi, norm_w=nw, res=None if res is None else res[:live], n_out=N)   # gemm_skinny_k<float>
+        A_d, Ap, Wp = G.dev(A), packed(A, Mp, K), pack_frag32(torch.from_numpy(W)).to(G.DEV)
+        nw_d = None if nw is None else G.dev(nw)
+        Cc = torch.full((M, N), float("nan"), dtype=torch.float32, device=G.DEV)
+        Cp = torch.full((Mp * N,), float("nan"), dtype=torch.float32, device=G.DEV)
+        res_d = None if res is None else G.dev(res)
+        _lib.check(lib.ctts_k_gemm_dec32(Ap.data_ptr(), Wp.data_ptr(), M, N, K, _lib.ptr(na_d), A_d.data_ptr() if rms else None, K,
+                                         _lib.ptr(nw_d), 1e-6, epi, Cc.data_ptr(), N, _lib.ptr(res_d), N, Cp.data_ptr() if epi else None,
+                                         N // 16, force_mb, None), "dec32")
+        torch.cuda.synchronize()
+        got_c, got_p = Cc.cpu().numpy(), unpack_frag32(Cp.cpu(), Mp, N).numpy()
+        if epi != 2:
+            assert np.array_equal(got_c[:live], want), (N, K, epi)
+            assert np.isnan(got_c[live:]).all()                       # rows beyond the live count are not written
+        if epi != 0:
+            assert np.array_equal(got_p[:live], want), (N, K, epi)
+            assert np.isnan(got_p[live:M]).all()
+
+
+@pytest.mark.parametrize("force_mb", [0, 1, 2, 4])
 @pytest.mark.parametrize("decode", [False, True, "tiled", "tiled128"])
 def test_qkv_rope_fused(G, force_mb, decode):
     """perf-mode fused RMSNorm-scale + QKV + RoPE + KV append vs numpy (natural weight order); "tiled": a prompt-sized
