@@ -105,14 +105,41 @@ __device__ __forceinline__ size_t pk_off(int m, int c, int kch) {
 __device__ __forceinline__ size_t pk32_off(int m, int c, int kch) {
   return ((size_t)((m >> 4) * kch + (c >> 4)) * 64 + (((c & 15) >> 2) << 4) + (m & 15)) * 4 + (c & 3);
 }
-// 1 / rms of one float32 row, evaluated by a whole wave (every lane returns the value).  The f32 parity mode's RMSNorm
-// prologue: gemm_skinny_k and gemm_dec32_k must produce the same bits, so both call this.
-__device__ __forceinline__ float wave_row_rstd(const float* __restrict__ row, int K, float eps, int lane) {
-  float ss = 0.f;
-  for (int k = lane * 4; k < K; k += 256) {
-    const float4 v = *reinterpret_cast<const float4*>(row + k);
-    ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-  }
+// RMSNorm statistics of the f32 parity mode.  gemm_skinny_k, gemm_dec32_k (and any later kernel) must produce the SAME BITS for
+// 1 / rms of a row, so the operation order is pinned (contraction off, explicit parentheses) instead of left to the optimiser:
+// lane l owns columns 4l..4l+3 of every 256-column block; a block contributes ((x*x + y*y) + z*z) + w*w (four IEEE multiplies,
+// three adds, no fma -- what hipcc emitted for the plain expression when the goldens were established); blocks are added in
+// ascending order; lanes are summed by the xor butterfly of wave_sum (32, 16, ..., 1); rstd = 1 / sqrt(ss / K + eps) with the
+// correctly rounded divide and square root hipcc uses by default.
+__device__ __forceinline__ float rms_acc4(float ss, const float4 v) {
+#pragma clang fp contract(off)   // honoured under hipcc's default -ffp-contract=fast-honor-pragmas: no mul+add fusion in here
+  const float xx = v.x * v.x, yy = v.y * v.y, zz = v.z * v.z, ww = v.w * v.w;
+  const float t = ((xx + yy) + zz) + ww;
+  return ss + t;
+}
+__device__ __forceinline__ float rms_finish(float ss, int K, float eps) {
   ss = wave_sum(ss);
   return 1.0f / sqrtf(ss / (float)K + eps);
+}
+// one row, any K (a multiple of 4): every lane returns the value
+__device__ __forceinline__ float wave_row_rstd(const float* __restrict__ row, int K, float eps, int lane) {
+  float ss = 0.f;
+  for (int k = lane * 4; k < K; k += 256) ss = rms_acc4(ss, *reinterpret_cast<const float4*>(row + k));
+  return rms_finish(ss, K, eps);
+}
+// NR rows of K = 768 at once: all 3 NR loads of the lane are in flight together (one memory round trip instead of 3 NR)
+template <int NR>
+__device__ __forceinline__ void wave_rows_rstd_768(const float* const (&rows)[NR], float eps, int lane, float (&rstd)[NR]) {
+  float4 v[NR][3];
+#pragma unroll
+  for (int q = 0; q < NR; ++q)
+#pragma unroll
+    for (int t = 0; t < 3; ++t) v[q][t] = *reinterpret_cast<const float4*>(rows[q] + lane * 4 + 256 * t);
+#pragma unroll
+  for (int q = 0; q < NR; ++q) {
+    float ss = 0.f;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) ss = rms_acc4(ss, v[q][t]);
+    rstd[q] = rms_finish(ss, 768, eps);
+  }
 }

@@ -9,7 +9,7 @@
 // gemm_skinny_k<float> (gemm.hip), which pulls MFMA fragments out of row-major [rows][K] float32 operands: every 16-byte lane
 // load of a wave instruction is a different 128-byte line, and every workgroup pulls the whole 64 x K activation tile that way
 // (12 288 line visits at K = 768, 49 152 at K = 3072 -- 6 and 23 us of address/tag work per workgroup before any MFMA issues;
-// profiles/r2o_f32_kernel_stats.csv: 25-35 us per projection, 2.6 ms per step).  Here both operands are stored in the order
+// profiles/r2o_f32_kernel_stats_rowmajor.csv: 25-35 us per projection, 2.6 ms per step).  Here both operands are stored in the order
 // the matrix core consumes them,
 //
 //     packed[tile of 16 rows][k chunk of 16][lane = (k%16)/4 * 16 + row%16][k%4]          (f32, 16 bytes per lane)
@@ -58,10 +58,26 @@ __device__ __forceinline__ void dec32_body(const Dec32Args& a, const int M, cons
   }
 
   if (RMS) {
-    for (int r = wave; r < 16 * NMB; r += 4) {
-      const int m = min(m0 + r, M - 1);
-      const float rstd = wave_row_rstd(a.X + (size_t)m * a.ldx, K, a.eps, lane);
-      if (lane == 0) rstd_s[r] = rstd;
+    // 1 / rms of the 16 NMB rows (gemm_skinny_k's arithmetic, common.hpp): wave w takes rows w, w+4, ...; at K = 768 four rows
+    // (12 loads per lane) are in flight together -- one memory round trip per batch instead of one per 256-column block
+    if (K == 768) {
+#pragma unroll
+      for (int r0 = 0; r0 < 16 * NMB; r0 += 16) {
+        const float* rows[4];
+        float rstd[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rows[q] = a.X + (size_t)min(m0 + r0 + wave + 4 * q, M - 1) * a.ldx;
+        wave_rows_rstd_768<4>(rows, a.eps, lane, rstd);
+        if (lane == 0) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) rstd_s[r0 + wave + 4 * q] = rstd[q];
+        }
+      }
+    } else {
+      for (int r = wave; r < 16 * NMB; r += 4) {
+        const float rstd = wave_row_rstd(a.X + (size_t)min(m0 + r, M - 1) * a.ldx, K, a.eps, lane);
+        if (lane == 0) rstd_s[r] = rstd;
+      }
     }
     __syncthreads();
   }
@@ -237,7 +253,7 @@ hipError_t launch_gemm_dec32(const Dec32Args& a_in, hipStream_t st) {
   static int nt = -1, mb_qkv = -1, mb_silu = -1, mb_o = -1, mb_down = -1;
   if (nt < 0) {
     nt = env_int32("CTTS_W_NT", 1);
-    mb_qkv = env_int32("CTTS_D32_MB_QKV", 2); mb_silu = env_int32("CTTS_D32_MB_SILU", 2);
+    mb_qkv = env_int32("CTTS_D32_MB_QKV", 1); mb_silu = env_int32("CTTS_D32_MB_SILU", 1);
     mb_o = env_int32("CTTS_D32_MB_O", 1); mb_down = env_int32("CTTS_D32_MB_DOWN", 1);
   }
   a.w_nt = nt;
