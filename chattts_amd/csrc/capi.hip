@@ -271,9 +271,10 @@ static int run_step(ctts_gpt* g, const ctts_gen_state* s, int q_per_b, hipStream
     d.M = M; d.eps = g->w.rms_eps; d.n_active = nact;
     // RMSNorm + QKV
     d.Ap = ws.xp32; d.Wp = (const float*)g->wqkv_pk[l]; d.N = 3 * HID; d.K = HID; d.X = ws.x; d.ldx = HID; d.norm_w = g->ln1[l];
-    d.epi = EPI_STORE; d.C = ws.qkv; d.ldc = 3 * HID;
+    // ... + RoPE + KV append in the epilogue (q / k weight rows of the packed copy are permuted by the loader)
+    d.epi = D32_EPI_QKV_ROPE; d.C = ws.qkv; d.ldc = 3 * HID; d.desc = ws.desc; d.cos_t = g->w.rope_cos; d.sin_t = g->w.rope_sin;
+    d.kc = (float*)kc; d.vc = (float*)vc; d.cmax = cmax;
     { Prof p(g, 1, st, prof_ok); CK(launch_gemm_dec32(d, st)); }
-    { Prof p(g, 2, st, prof_ok); CK(launch_rope_append(ws.qkv, kc, vc, kt, cmax, g->w.rope_cos, g->w.rope_sin, rm, M, st)); }
     { Prof p(g, 3, st, prof_ok); CK(launch_attention(ws.qkv, kc, vc, kt, cmax, ws.aop32, 3, rm, M, st)); }
     // o_proj + residual
     d.Ap = ws.aop32; d.Wp = (const float*)g->wo_pk[l]; d.N = HID; d.X = nullptr; d.norm_w = nullptr; d.epi = EPI_RES; d.C = ws.x; d.ldc = HID;

@@ -105,6 +105,18 @@ __device__ __forceinline__ size_t pk_off(int m, int c, int kch) {
 __device__ __forceinline__ size_t pk32_off(int m, int c, int kch) {
   return ((size_t)((m >> 4) * kch + (c >> 4)) * 64 + (((c & 15) >> 2) << 4) + (m & 15)) * 4 + (c & 3);
 }
+// Rotate-half RoPE of one (x[d], x[d+32]) pair in the f32 parity mode, pinned to what hipcc made of rope_append_k's
+// `x1 * c - x2 * s` / `x2 * c + x1 * s` when the goldens were established: one rounded product, then one fma.
+__device__ __forceinline__ float rope_lo(float x1, float x2, float c, float s) {
+#pragma clang fp contract(off)
+  const float p = x2 * s;
+  return __builtin_fmaf(x1, c, -p);
+}
+__device__ __forceinline__ float rope_hi(float x1, float x2, float c, float s) {
+#pragma clang fp contract(off)
+  const float p = x1 * s;
+  return __builtin_fmaf(x2, c, p);
+}
 // RMSNorm statistics of the f32 parity mode.  gemm_skinny_k, gemm_dec32_k (and any later kernel) must produce the SAME BITS for
 // 1 / rms of a row, so the operation order is pinned (contraction off, explicit parentheses) instead of left to the optimiser:
 // lane l owns columns 4l..4l+3 of every 256-column block; a block contributes ((x*x + y*y) + z*z) + w*w (four IEEE multiplies,

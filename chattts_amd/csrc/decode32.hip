@@ -56,6 +56,21 @@ __device__ __forceinline__ void dec32_body(const Dec32Args& a, const int M, cons
       pre0[q] = a.res[(size_t)row * a.ldr + n0 + li];
     }
   }
+  // QKV_ROPE tiles (weight rows permuted by the loader, engine.py rope_row_perm): columns 0..7 of a q/k tile are dims d0..d0+7 of
+  // one head, columns 8..15 are dims d0+32..d0+39, so a rotate-half pair sits 8 lanes apart.  The row's descriptor and the
+  // cos / sin of its position are requested here, before the operand loads.
+  const int sect = n0 / 768, hcol = n0 % 768, head = hcol >> 6, t4 = (hcol & 63) >> 4;
+  const int dlo = 8 * t4 + (li & 7);
+  RowDesc rd[PPW];
+  float rc[PPW], rsn[PPW];
+  if (EPI == D32_EPI_QKV_ROPE && wave < NF) {
+#pragma unroll
+    for (int q = 0; q < PPW; ++q) {
+      rd[q] = a.desc[min(m0 + 16 * fmb + 4 * g + fr0 + q, M - 1)];
+      rc[q] = a.cos_t[rd[q].pos * 32 + dlo];
+      rsn[q] = a.sin_t[rd[q].pos * 32 + dlo];
+    }
+  }
 
   if (RMS) {
     // 1 / rms of the 16 NMB rows (gemm_skinny_k's arithmetic, common.hpp): wave w takes rows w, w+4, ...; at K = 768 four rows
@@ -172,7 +187,6 @@ __device__ __forceinline__ void dec32_body(const Dec32Args& a, const int M, cons
 #pragma unroll
   for (int q = 0; q < PPW; ++q) {
     const int row = m0 + 16 * fmb + 4 * g + fr0 + q;  // C/D map of the 16x16 MFMA: col = lane & 15, row = 4 (lane >> 4) + reg
-    if (row >= M) continue;
     float v = ((t[0][0][q] + t[1][0][q]) + t[2][0][q]) + t[3][0][q];   // fixed order, as gemm_skinny_k
     if (EPI == EPI_SILU_MUL) {
       const float u = ((t[0][NACC - 1][q] + t[1][NACC - 1][q]) + t[2][NACC - 1][q]) + t[3][NACC - 1][q];
@@ -180,6 +194,20 @@ __device__ __forceinline__ void dec32_body(const Dec32Args& a, const int M, cons
     } else if (EPI == EPI_RES) {
       v = pre0[q] + v;
     }
+    if (EPI == D32_EPI_QKV_ROPE) {   // q -> roped, qkv buffer; k -> roped, KV cache; v -> KV cache  (rope_append_k, gpt.hip)
+      const float other = __shfl_xor(v, 8, 64);   // every lane of the wave is here (rows are skipped below, not above)
+      const bool hi = li >= 8;
+      const float roped = hi ? rope_hi(other, v, rc[q], rsn[q]) : rope_lo(v, other, rc[q], rsn[q]);
+      const int d = dlo + (hi ? 32 : 0);
+      if (row < M && rd[q].b >= 0) {
+        const size_t cbase = (((size_t)rd[q].b * 12 + head) * a.cmax + rd[q].slot) * 64;
+        if (sect == 0) a.C[(size_t)row * a.ldc + head * 64 + d] = roped;
+        else if (sect == 1) a.kc[cbase + d] = roped;
+        else a.vc[cbase + (hcol & 63) + li] = v;
+      }
+      continue;
+    }
+    if (row >= M) continue;
     if (EPI != EPI_SILU_MUL) a.C[(size_t)row * a.ldc + col] = v;
     if (EPI != EPI_STORE && a.Cp != nullptr) a.Cp[pk32_off(row, col, a.kch_out)] = v;
   }
@@ -230,6 +258,137 @@ __global__ __launch_bounds__(256) void gemm_dec32_k(Dec32Args a) {
   }
 }
 
+// The default geometry -- 16-row workgroups, K known at compile time -- with every load the workgroup can issue up front in
+// flight at kernel entry: K = 768: ALL 12 chunks of the wave (W and A fragments, RMSNorm gains) are requested before the
+// live-row count is even known, so the workgroup pays one memory round trip, not one per stage; K = 3072: stages of 6 chunks,
+// double-buffered (stage r+1 requested before stage r is multiplied).  Same operation order per output element as above.
+template <int KT, bool RMS, int EPI>
+__global__ __launch_bounds__(256) void gemm_dec32_m16_k(Dec32Args a) {
+  constexpr int NACC = (EPI == EPI_SILU_MUL) ? 2 : 1;
+  constexpr int KCH = KT / 16, NPER = KCH / 4;   // chunks per wave: 12 / 48
+  constexpr int U = (KT == 768) ? 12 : 6;         // chunks per stage
+  constexpr int ROUNDS = NPER / U;                // 1 / 8
+  static_assert(ROUNDS == 1 || ROUNDS % 2 == 0, "stages are consumed in pairs");
+  __shared__ __attribute__((aligned(16))) float red[4][NACC][64][4];
+  __shared__ float rstd_s[16];
+  struct Stage { u128 w[NACC][U]; u128 a[U]; float4 nw[U]; };
+
+  const int tile = blockIdx.x, mt0 = blockIdx.y;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 15, g = lane >> 4;
+  const int n0 = tile * 16, m0 = mt0 * 16;
+  const u128* wp = reinterpret_cast<const u128*>(a.Wp) + ((size_t)tile * KCH + wave) * 64 + lane;   // wave w owns chunks 4 i + w
+  const u128* wp2 = wp + (size_t)(a.N >> 4) * KCH * 64;
+  const u128* ap = reinterpret_cast<const u128*>(a.Ap) + ((size_t)mt0 * KCH + wave) * 64 + lane;
+  const bool w_once = a.w_nt && gridDim.y == 1;
+  auto load_stage = [&](Stage& s, const int r) {
+    if (w_once) {
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        s.w[0][j] = load16_nt(wp + (size_t)(r * U + j) * 256);
+        if (NACC == 2) s.w[1][j] = load16_nt(wp2 + (size_t)(r * U + j) * 256);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        s.w[0][j] = load16(wp + (size_t)(r * U + j) * 256);
+        if (NACC == 2) s.w[1][j] = load16(wp2 + (size_t)(r * U + j) * 256);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < U; ++j) s.a[j] = load16(ap + (size_t)(r * U + j) * 256);
+    if (RMS) {
+#pragma unroll
+      for (int j = 0; j < U; ++j) s.nw[j] = *reinterpret_cast<const float4*>(a.norm_w + ((r * U + j) * 4 + wave) * 16 + g * 4);
+    }
+  };
+  Stage s0;
+  load_stage(s0, 0);   // the row tile's buffer exists whether or not its rows are live: nothing here depends on *n_active
+  const int M = a.n_active ? min(*a.n_active, a.M) : a.M;
+  if (m0 >= M) return;
+
+  float pre0 = 0.f;   // RES: wave w finishes accumulator register w
+  if (EPI == EPI_RES) pre0 = a.res[(size_t)min(m0 + 4 * g + wave, M - 1) * a.ldr + n0 + li];
+  float rs = 1.0f;
+  if (RMS) {
+    static_assert(!RMS || KT == 768, "the RMSNorm prologue is the K = 768 one");
+    const float* rows[4];
+    float rstd[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) rows[q] = a.X + (size_t)min(m0 + wave + 4 * q, M - 1) * a.ldx;
+    wave_rows_rstd_768<4>(rows, a.eps, lane, rstd);
+    if (lane == 0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) rstd_s[wave + 4 * q] = rstd[q];
+    }
+    __syncthreads();
+    rs = rstd_s[li];
+  }
+
+  f32x4 acc[NACC];
+#pragma unroll
+  for (int na = 0; na < NACC; ++na) acc[na] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  auto mul_stage = [&](const Stage& s) {
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      float4 a0 = *reinterpret_cast<const float4*>(&s.a[j]);
+      if (RMS) { a0.x = s.nw[j].x * (a0.x * rs); a0.y = s.nw[j].y * (a0.y * rs); a0.z = s.nw[j].z * (a0.z * rs); a0.w = s.nw[j].w * (a0.w * rs); }
+#pragma unroll
+      for (int na = 0; na < NACC; ++na) {
+        const float4 b = *reinterpret_cast<const float4*>(&s.w[na][j]);
+        f32x4 c = acc[na];
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b.x, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b.y, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b.z, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b.w, c, 0, 0, 0);
+        acc[na] = c;
+      }
+    }
+  };
+  if constexpr (ROUNDS == 1) {
+    mul_stage(s0);
+  } else {
+    Stage s1;
+    for (int r = 0; r < ROUNDS; r += 2) {
+      load_stage(s1, r + 1);
+      __builtin_amdgcn_sched_barrier(0);   // keep the next stage's loads ahead of this stage's MFMAs
+      mul_stage(s0);
+      if (r + 2 < ROUNDS) load_stage(s0, r + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      mul_stage(s1);
+    }
+  }
+
+#pragma unroll
+  for (int na = 0; na < NACC; ++na) *reinterpret_cast<f32x4*>(&red[wave][na][lane][0]) = acc[na];
+  __syncthreads();
+  const int row = m0 + 4 * g + wave, col = n0 + li;   // C/D map: col = lane & 15, row = 4 (lane >> 4) + register (= wave here)
+  if (row >= M) return;
+  float v = ((red[0][0][lane][wave] + red[1][0][lane][wave]) + red[2][0][lane][wave]) + red[3][0][lane][wave];   // fixed order
+  if (EPI == EPI_SILU_MUL) {
+    const float u = ((red[0][NACC - 1][lane][wave] + red[1][NACC - 1][lane][wave]) + red[2][NACC - 1][lane][wave]) + red[3][NACC - 1][lane][wave];
+    v = silu_f(v) * u;
+  } else if (EPI == EPI_RES) {
+    v = pre0 + v;
+  }
+  if (EPI != EPI_SILU_MUL) a.C[(size_t)row * a.ldc + col] = v;
+  if (EPI != EPI_STORE && a.Cp != nullptr) a.Cp[pk32_off(row, col, a.kch_out)] = v;
+}
+
+template <int KT>
+static hipError_t dec32_dispatch_m16(const Dec32Args& a, hipStream_t st) {
+  dim3 grid(a.N / 16, (a.M + 15) / 16), block(256);
+  const bool rms = a.norm_w != nullptr;
+  if constexpr (KT == 768) {
+    if (a.epi == EPI_STORE && rms) { CTTS_LAUNCH((gemm_dec32_m16_k<KT, true, EPI_STORE>), grid, block, st, a); return hipGetLastError(); }
+    if (a.epi == EPI_SILU_MUL && rms) { CTTS_LAUNCH((gemm_dec32_m16_k<KT, true, EPI_SILU_MUL>), grid, block, st, a); return hipGetLastError(); }
+  }
+  if (a.epi == EPI_STORE && !rms) CTTS_LAUNCH((gemm_dec32_m16_k<KT, false, EPI_STORE>), grid, block, st, a);
+  else if (a.epi == EPI_RES && !rms) CTTS_LAUNCH((gemm_dec32_m16_k<KT, false, EPI_RES>), grid, block, st, a);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
 static int env_int32(const char* name, int dflt) {
   const char* e = getenv(name);
   return e ? atoi(e) : dflt;
@@ -244,6 +403,7 @@ static hipError_t dec32_dispatch(const Dec32Args& a, hipStream_t st) {
   else if (a.epi == EPI_STORE) CTTS_LAUNCH((gemm_dec32_k<MBT, false, EPI_STORE>), grid, block, st, a);
   else if (a.epi == EPI_RES && !rms) CTTS_LAUNCH((gemm_dec32_k<MBT, false, EPI_RES>), grid, block, st, a);
   else if (a.epi == EPI_SILU_MUL && rms) CTTS_LAUNCH((gemm_dec32_k<MBT, true, EPI_SILU_MUL>), grid, block, st, a);
+  else if (a.epi == D32_EPI_QKV_ROPE && rms) CTTS_LAUNCH((gemm_dec32_k<MBT, true, D32_EPI_QKV_ROPE>), grid, block, st, a);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }
@@ -260,11 +420,19 @@ hipError_t launch_gemm_dec32(const Dec32Args& a_in, hipStream_t st) {
   // K: chunks of 16, 4 waves, rounds of D32_U chunks
   if (a.M <= 0 || a.N <= 0 || (a.N & 15) || a.K % (16 * 4 * D32_U) != 0) return hipErrorInvalidValue;
   if (a.norm_w != nullptr && (a.X == nullptr || (a.ldx & 3))) return hipErrorInvalidValue;
+  if (a.epi == D32_EPI_QKV_ROPE && (a.N != 2304 || a.K != 768 || !a.desc || !a.kc || !a.vc)) return hipErrorInvalidValue;
   // Rows per workgroup.  f32 MFMA (256 flop per clock and CU) is what these launches are made of -- 64 x 2304 x 768 costs 3.5k
   // clocks of every CU if perfectly spread -- so the row tiles are cut until the grid has a few workgroups per CU; the 16-row
   // workgroups of o / down (48 weight tiles only) are the same choice the bf16 kernel makes.
   int mb = a.epi == EPI_SILU_MUL ? mb_silu : a.epi == EPI_RES ? (a.K > 768 ? mb_down : mb_o) : mb_qkv;
   if (a.force_mb) mb = a.force_mb;
+  // 16-row workgroups WITHOUT an RMSNorm prologue (o / down) take the everything-up-front kernel; with the prologue its 200+
+  // VGPRs cost more occupancy than the saved round trips are worth (profiles/r2s_*: gate/up 16.8 vs 13.3 us)
+  static int m16 = -1;   // CTTS_D32_M16=0: the generic body for every launch, 2: the m16 kernels for the RMSNorm launches too (A/B)
+  if (m16 < 0) m16 = env_int32("CTTS_D32_M16", 1);
+  const bool m16_ok = m16 == 2 ? a.epi != D32_EPI_QKV_ROPE : (m16 == 1 && a.norm_w == nullptr);
+  if (mb == 1 && m16_ok && a.K == 768) return dec32_dispatch_m16<768>(a, st);
+  if (mb == 1 && m16_ok && a.K == 3072 && a.norm_w == nullptr) return dec32_dispatch_m16<3072>(a, st);
   if (mb >= 4) return dec32_dispatch<4>(a, st);
   if (mb == 2) return dec32_dispatch<2>(a, st);
   return dec32_dispatch<1>(a, st);

@@ -167,15 +167,15 @@ __global__ __launch_bounds__(384) void rope_append_k(float* __restrict__ qkv, KT
   {
     float* q = row + h * HDIM;
     const float x1 = q[d], x2 = q[d + 32];
-    q[d] = x1 * c - x2 * s;
-    q[d + 32] = x2 * c + x1 * s;
+    q[d] = rope_lo(x1, x2, c, s);
+    q[d + 32] = rope_hi(x1, x2, c, s);
   }
   const size_t base = (((size_t)b * NHEAD + h) * cmax + slot) * HDIM;
   {
     const float* k = row + HID + h * HDIM;
     const float x1 = k[d], x2 = k[d + 32];
-    kc[base + d] = to_kt<KT>(x1 * c - x2 * s);
-    kc[base + d + 32] = to_kt<KT>(x2 * c + x1 * s);
+    kc[base + d] = to_kt<KT>(rope_lo(x1, x2, c, s));
+    kc[base + d + 32] = to_kt<KT>(rope_hi(x1, x2, c, s));
   }
   {
     const float* v = row + 2 * HID + h * HDIM;

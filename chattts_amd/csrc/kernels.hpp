@@ -141,9 +141,15 @@ struct Dec32Args {
   float* C; int ldc;
   const float* res; int ldr;
   float* Cp; int kch_out;       // packed f32 copy of the output for the next projection (kch_out = its columns / 16), or null
+  // D32_EPI_QKV_ROPE (N = 2304, K = 768, q/k weight rows in the rope_row_perm order of engine.py): RoPE on q -> C (qkv buffer, natural
+  // column order), RoPE on k -> KV cache, v -> KV cache, all float32, at (desc[row].b, desc[row].slot); rope_append_k's arithmetic
+  const RowDesc* desc;
+  const float* cos_t; const float* sin_t;
+  float* kc; float* vc; int cmax;
   int force_mb;                 // tests only
   int w_nt;                     // set by the launcher
 };
+enum { D32_EPI_QKV_ROPE = 100 };
 hipError_t launch_gemm_dec32(const Dec32Args& a, hipStream_t st);
 
 // ---- GPT step kernels -------------------------------------------------------------------------

@@ -251,6 +251,12 @@ class GptEngine:
         # decode32.hip); the row-major copy stays for the prefill kernels (+0.38 GB / +0.75 GB of the 288 GB)
         pk = pack_frag if dtype == "bf16" else pack_frag32
         self.packed = [[pk(t) for t in ws] for ws in (self.wqkv, self.wo, self.wgu, self.wd)]
+        if dtype != "bf16":
+            # the packed f32 QKV matrix carries the RoPE row permutation too (its decode kernel rotates in the epilogue); an output
+            # column's dot product does not depend on where the column sits, so the parity arithmetic is untouched
+            rp = rope_row_perm().to(dev)
+            qk_perm = torch.cat([rp, GPT.hidden + rp, 2 * GPT.hidden + torch.arange(GPT.hidden, device=dev)])
+            self.packed[0] = [pack_frag32(t[qk_perm]) for t in self.wqkv]
         self._pk_arrs = None if self.packed is None else [_lib.ptr_array(x) for x in self.packed]
         w = _lib.GptWeights()
         w.n_layers, w.weight_dtype, w.kv_dtype, w.max_pos = self.n_layers, self.code, self.code, max_pos

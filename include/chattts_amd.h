@@ -65,8 +65,8 @@ typedef struct {
   /* optional (NULL: the decode step uses the row-major kernels): the same four matrices per layer in the fragment-packed order
    * of the weight dtype's decode kernel.  bf16 (csrc/decode.hip): [rows/16][K/32][lane = (k%32)/8*16 + row%16][k%8], one contiguous
    * KiB per (16-row tile, 32-wide k chunk); wqkv with the RoPE row permutation and the folded RMSNorm gain like `wqkv`.
-   * f32 (csrc/decode32.hip, needs an f32 KV cache): [rows/16][K/16][lane = (k%16)/4*16 + row%16][k%4] of the plain matrices;
-   * same arithmetic, bit for bit, as the row-major f32 kernels. */
+   * f32 (csrc/decode32.hip, needs an f32 KV cache): [rows/16][K/16][lane = (k%16)/4*16 + row%16][k%4] of the plain matrices, wqkv
+   * with the RoPE row permutation (no gain folding); same arithmetic, bit for bit, as the row-major f32 kernels. */
   const void* const* wqkv_pk;
   const void* const* wo_pk;
   const void* const* wgu_pk;
