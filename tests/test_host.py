@@ -67,6 +67,26 @@ def test_rope_row_perm_is_a_permutation_pairing_halves():
     assert torch.equal(t[:, :, 8:] - t[:, :, :8], torch.full((12, 4, 8), 32))
 
 
+def test_fragment_packing_round_trips_and_matches_the_kernel_offsets():
+    """pack_frag / pack_frag32 (engine.py) against the device-side offset functions they must agree with (csrc/common.hpp
+    pk_off / pk32_off, restated here): element (r, c) of a [R, C] matrix lands where the decode kernels look for it"""
+    from chattts_amd.engine import pack_frag, pack_frag32, unpack_frag, unpack_frag32
+    R, Cc = 48, 96
+    w = torch.arange(R * Cc, dtype=torch.float32).reshape(R, Cc)
+
+    def pk_off(m, c, kch):      # bf16: [rows/16][C/32][lane = (c%32)/8*16 + row%16][c%8]
+        return (((m >> 4) * kch + (c >> 5)) * 64 + (((c & 31) >> 3) << 4) + (m & 15)) * 8 + (c & 7)
+
+    def pk32_off(m, c, kch):    # f32: [rows/16][C/16][lane = (c%16)/4*16 + row%16][c%4]
+        return (((m >> 4) * kch + (c >> 4)) * 64 + (((c & 15) >> 2) << 4) + (m & 15)) * 4 + (c & 3)
+
+    p16, p32 = pack_frag(w).flatten(), pack_frag32(w).flatten()
+    for m, c in [(0, 0), (1, 0), (0, 1), (15, 31), (16, 32), (17, 9), (47, 95), (33, 70)]:
+        assert p16[pk_off(m, c, Cc // 32)] == w[m, c]
+        assert p32[pk32_off(m, c, Cc // 16)] == w[m, c]
+    assert torch.equal(unpack_frag(pack_frag(w), R, Cc), w) and torch.equal(unpack_frag32(pack_frag32(w), R, Cc), w)
+
+
 def test_asset_layout_round_trip(tmp_path):
     """the four hot-path safetensors files in the reference's asset layout (config.py:4-11): save -> load is lossless,
     HF's `model.` prefix and the unused embed_tokens (gpt.py:78) are handled"""
