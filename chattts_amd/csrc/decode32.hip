@@ -72,6 +72,27 @@ __device__ __forceinline__ void dec32_body(const Dec32Args& a, const int M, cons
     }
   }
 
+  const int nper = KCH / 4;   // chunks per wave (launcher guarantees nper % U == 0); wave w owns chunks 4 i + w
+  const u128* wp = reinterpret_cast<const u128*>(a.Wp) + ((size_t)tile * KCH + wave) * 64 + lane;
+  const u128* wp2 = wp + (size_t)(N >> 4) * KCH * 64;  // SILU_MUL: the "up" tile of the same columns
+  const u128* ap = reinterpret_cast<const u128*>(a.Ap) + ((size_t)mt0 * KCH + wave) * 64 + lane;
+  const bool w_once = a.w_nt && gridDim.y == 1;  // a single row group reads W: stream it past the caches
+  u128 af[NMB][U];
+  float4 nw[U];
+  auto load_a = [&](const int i) {
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+      for (int j = 0; j < U; ++j) af[mb][j] = load16(ap + (size_t)mb * KCH * 64 + (size_t)(i + j) * 256);
+    if (RMS) {
+#pragma unroll
+      for (int j = 0; j < U; ++j) nw[j] = *reinterpret_cast<const float4*>(a.norm_w + ((i + j) * 4 + wave) * 16 + g * 4);
+    }
+  };
+  // with an RMSNorm prologue: the first round's activation fragments and gains are requested BEFORE the prologue's row loads, so
+  // the statistics cost no extra memory round trip
+  const bool early = RMS && a.a_early;
+  if (early) load_a(0);
   if (RMS) {
     // 1 / rms of the 16 NMB rows (gemm_skinny_k's arithmetic, common.hpp): wave w takes rows w, w+4, ...; at K = 768 four rows
     // (12 loads per lane) are in flight together -- one memory round trip per batch instead of one per 256-column block
@@ -100,11 +121,6 @@ __device__ __forceinline__ void dec32_body(const Dec32Args& a, const int M, cons
 #pragma unroll
   for (int mb = 0; mb < NMB; ++mb) rs[mb] = RMS ? rstd_s[16 * mb + li] : 1.0f;
 
-  const int nper = KCH / 4;   // chunks per wave (launcher guarantees nper % U == 0); wave w owns chunks 4 i + w
-  const u128* wp = reinterpret_cast<const u128*>(a.Wp) + ((size_t)tile * KCH + wave) * 64 + lane;
-  const u128* wp2 = wp + (size_t)(N >> 4) * KCH * 64;  // SILU_MUL: the "up" tile of the same columns
-  const u128* ap = reinterpret_cast<const u128*>(a.Ap) + ((size_t)mt0 * KCH + wave) * 64 + lane;
-  const bool w_once = a.w_nt && gridDim.y == 1;  // a single row group reads W: stream it past the caches
 
   f32x4 acc[NACC][NMB];
 #pragma unroll
@@ -113,8 +129,6 @@ __device__ __forceinline__ void dec32_body(const Dec32Args& a, const int M, cons
     for (int mb = 0; mb < NMB; ++mb) acc[na][mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   for (int i = 0; i < nper; i += U) {
-    u128 af[NMB][U];
-    float4 nw[U];
     if (i > 0) {   // the first round's weight fragments were requested at kernel entry (before *n_active was known)
       if (w_once) {
 #pragma unroll
@@ -130,14 +144,7 @@ __device__ __forceinline__ void dec32_body(const Dec32Args& a, const int M, cons
         }
       }
     }
-#pragma unroll
-    for (int mb = 0; mb < NMB; ++mb)
-#pragma unroll
-      for (int j = 0; j < U; ++j) af[mb][j] = load16(ap + (size_t)mb * KCH * 64 + (size_t)(i + j) * 256);
-    if (RMS) {
-#pragma unroll
-      for (int j = 0; j < U; ++j) nw[j] = *reinterpret_cast<const float4*>(a.norm_w + ((i + j) * 4 + wave) * 16 + g * 4);
-    }
+    if (i > 0 || !early) load_a(i);
     // every load of the round in flight before the first MFMA (hipcc otherwise sinks each load next to its use)
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -410,13 +417,15 @@ static hipError_t dec32_dispatch(const Dec32Args& a, hipStream_t st) {
 
 hipError_t launch_gemm_dec32(const Dec32Args& a_in, hipStream_t st) {
   Dec32Args a = a_in;
-  static int nt = -1, mb_qkv = -1, mb_silu = -1, mb_o = -1, mb_down = -1;
+  static int nt = -1, mb_qkv = -1, mb_silu = -1, mb_o = -1, mb_down = -1, a_early = 1;
   if (nt < 0) {
     nt = env_int32("CTTS_W_NT", 1);
+    a_early = env_int32("CTTS_D32_A_EARLY", 1);
     mb_qkv = env_int32("CTTS_D32_MB_QKV", 1); mb_silu = env_int32("CTTS_D32_MB_SILU", 1);
     mb_o = env_int32("CTTS_D32_MB_O", 1); mb_down = env_int32("CTTS_D32_MB_DOWN", 1);
   }
   a.w_nt = nt;
+  a.a_early = a_early;
   // K: chunks of 16, 4 waves, rounds of D32_U chunks
   if (a.M <= 0 || a.N <= 0 || (a.N & 15) || a.K % (16 * 4 * D32_U) != 0) return hipErrorInvalidValue;
   if (a.norm_w != nullptr && (a.X == nullptr || (a.ldx & 3))) return hipErrorInvalidValue;

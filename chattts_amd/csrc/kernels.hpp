@@ -148,6 +148,7 @@ struct Dec32Args {
   float* kc; float* vc; int cmax;
   int force_mb;                 // tests only
   int w_nt;                     // set by the launcher
+  int a_early;                  // set by the launcher (CTTS_D32_A_EARLY): first activation round requested before the RMSNorm prologue
 };
 enum { D32_EPI_QKV_ROPE = 100 };
 hipError_t launch_gemm_dec32(const Dec32Args& a, hipStream_t st);
