@@ -202,6 +202,7 @@ def main():
         note("parity mode (f32)")
         gpt32 = E.GptEngine(sds["gpt"], sds["embed"], dev, dtype="f32")
         dt32 = timed(gpt32, 1, 1)
+        steps32, dec32_ms = gpt32.last_stats.get("steps", 0), gpt32.last_stats.get("decode_ms", 0.0)
         _, _, rows = one_pass(gpt32, keep_ids=True, decode_audio=False)
         got = ids_digest(rows)
         want = None
@@ -209,7 +210,11 @@ def main():
         if os.path.exists(gpath) and (args.batch, args.min_len, args.max_len) == (64, 128, 512):
             want = str(np.load(gpath)["sha256"])
         result["parity_mode"] = {"dtype": "f32", "value": round(audio_seconds(stop) / dt32, 2), "unit": "audio-s/s",
-                                 "ms_per_step": round(1000.0 * dt32, 3), "ids_sha256": got, "golden_sha256": want,
+                                 "ms_per_step": round(1000.0 * dt32, 3),
+                                 "decode_ms_per_gpt_step": round(dec32_ms / max(1, steps32), 4),
+                                 "kernels": "decode projections on fragment-packed f32 operands (csrc/decode32.hip), operation order of "
+                                            "the row-major f32 kernels kept bit for bit",
+                                 "ids_sha256": got, "golden_sha256": want,
                                  "ids_match_reference": (got == want) if want else None,
                                  "golden": "tests/golden/bench_c3.npz: the reference's GPT.generate on this workload (oracle/make_bench_golden.py)"}
         del gpt32
