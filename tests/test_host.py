@@ -1,5 +1,6 @@
 """CPU-side tests: the C-ABI library loads and exports every declared symbol (no compute calls),
 host logic of the engine, sharding + weight broadcast over gloo (world_size 2)."""
+import ctypes as C
 import os
 import re
 import socket
@@ -22,6 +23,31 @@ def test_library_exports_every_declared_symbol():
     assert lib.ctts_version() == 1
     assert lib.ctts_gpt_workspace_bytes(64, 48) > 64 * 48 * (768 + 2304 + 768 + 3072) * 4
     assert lib.ctts_codec_workspace_bytes(2, 10) > 0
+
+
+def test_ctypes_structs_match_the_header_layout(tmp_path):
+    """every struct that crosses the C ABI: sizeof and the offset of every field as gcc lays out include/chattts_amd.h
+    == what chattts_amd/_lib.py tells ctypes (a field added, dropped or reordered on one side only fails here, on CPU)"""
+    import subprocess
+    pairs = [("ctts_gpt_weights", _lib.GptWeights), ("ctts_gen_state", _lib.GenState), ("ctts_codec_weights", _lib.CodecWeights),
+             ("ctts_trunk_weights", _lib.TrunkWeights), ("ctts_dvae_weights", _lib.DvaeWeights)]
+    lines = ['#include <stdio.h>', '#include "chattts_amd.h"', 'int main(void) {']
+    for cname, cls in pairs:
+        lines.append(f'  printf("%zu\\n", sizeof({cname}));')
+        for fname, *_ in cls._fields_:
+            lines.append(f'  printf("%zu\\n", offsetof({cname}, {fname}));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    inc = os.path.join(ROOT, "include")
+    subprocess.run(["gcc", "-std=c99", "-I", inc, str(src), "-o", str(exe)], check=True)
+    got = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    want = []
+    for _, cls in pairs:
+        want.append(C.sizeof(cls))
+        want += [getattr(cls, fname).offset for fname, *_ in cls._fields_]
+    assert got == want
 
 
 def test_engine_fails_loudly_without_gpu():
