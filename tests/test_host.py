@@ -25,6 +25,36 @@ def test_library_exports_every_declared_symbol():
     assert lib.ctts_codec_workspace_bytes(2, 10) > 0
 
 
+def test_ctypes_signatures_match_the_header_prototypes():
+    """every prototype of include/chattts_amd.h against chattts_amd/_lib.py SIGNATURES: same number of parameters, and each
+    parameter of the same class (pointer / int32 / float / size_t / int64) -- a prototype edited on one side only fails on CPU"""
+    hdr = open(os.path.join(ROOT, "include", "chattts_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", " ", hdr, flags=re.S)
+    protos = re.findall(r"\b(?:int|size_t|void|const char\*|int32_t)\s+(ctts_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.S)
+    assert {n for n, _ in protos} == set(_lib.SIGNATURES)
+
+    def klass_c(param: str) -> str:
+        param = " ".join(param.split())
+        if param == "void":
+            return ""
+        if "*" in param:
+            return "ptr"
+        for t, k in (("int32_t", "i32"), ("int64_t", "i64"), ("size_t", "size"), ("float", "f32"), ("int", "i32")):
+            if re.match(rf"(const )?{t}\b", param):
+                return k
+        raise AssertionError(f"unclassified parameter {param!r}")
+
+    def klass_py(t) -> str:
+        if t in (C.c_void_p, C.c_char_p) or isinstance(t, type) and issubclass(t, (C._Pointer,)):
+            return "ptr"
+        return {C.c_int32: "i32", C.c_int: "i32", C.c_int64: "i64", C.c_size_t: "size", C.c_float: "f32"}[t]
+
+    for name, params in protos:
+        want = [k for k in (klass_c(p) for p in params.split(",")) if k]
+        got = [klass_py(t) for t in _lib.SIGNATURES[name][1]]
+        assert got == want, (name, got, want)
+
+
 def test_ctypes_structs_match_the_header_layout(tmp_path):
     """every struct that crosses the C ABI: sizeof and the offset of every field as gcc lays out include/chattts_amd.h
     == what chattts_amd/_lib.py tells ctypes (a field added, dropped or reordered on one side only fails here, on CPU)"""
