@@ -129,10 +129,8 @@ __device__ __forceinline__ float rms_acc4(float ss, const float4 v) {
   const float t = ((xx + yy) + zz) + ww;
   return ss + t;
 }
-__device__ __forceinline__ float rms_finish(float ss, int K, float eps) {
-  ss = wave_sum(ss);
-  return 1.0f / sqrtf(ss / (float)K + eps);
-}
+__device__ __forceinline__ float rms_rstd_of(float ss, int K, float eps) { return 1.0f / sqrtf(ss / (float)K + eps); }
+__device__ __forceinline__ float rms_finish(float ss, int K, float eps) { return rms_rstd_of(wave_sum(ss), K, eps); }
 // one row, any K (a multiple of 4): every lane returns the value
 __device__ __forceinline__ float wave_row_rstd(const float* __restrict__ row, int K, float eps, int lane) {
   float ss = 0.f;

@@ -382,6 +382,137 @@ __global__ __launch_bounds__(256) void gemm_dec32_m16_k(Dec32Args a) {
   if (EPI != EPI_STORE && a.Cp != nullptr) a.Cp[pk32_off(row, col, a.kch_out)] = v;
 }
 
+// RMSNorm launches (QKV, gate/up) as 16-row workgroups WITHOUT re-reading the residual rows for their statistics: the workgroup
+// already holds the whole 16 x 768 activation tile as MFMA fragments (12 chunks per wave), and the pinned summation order of
+// wave_row_rstd (common.hpp) happens to decompose along the fragment layout.  wave_row_rstd gives "virtual lane" l columns
+// 256 t + 4 l .. + 3 (t = 0, 1, 2), adds the three blocks in order, then runs the xor butterfly 32, 16, 8, 4, 2, 1 over l.
+// Columns 256 t + 4 l sit in chunk 16 t + l / 4, lane group g = l % 4 -- chunks 16 t + c0 all belong to wave c0 % 4 -- so the
+// fragment lane (g, row) of wave w owns the virtual lanes l = 16 q + 4 w + g, q = 0..3 (local chunks q, q + 4, q + 8), and the
+// butterfly becomes: levels 32 and 16 = adds between the lane's own four partials (q ^ 2, then q ^ 1), levels 8 and 4 = adds
+// across the four waves (w ^ 2, then w ^ 1; one 1 KiB LDS exchange), levels 2 and 1 = adds across lane groups (lane ^ 32, then
+// lane ^ 16).  Same operands, same association, same bits -- and the launch moves 25 % less through the L2s and loses a
+// dependent memory round trip.  Weights come in rounds of 6 (gate/up: 4) chunks (VGPR budget: 3 workgroups per CU).
+template <int EPI>
+__global__ __launch_bounds__(256, 3) void gemm_dec32_rms16_k(Dec32Args a) {
+  constexpr int NACC = (EPI == EPI_SILU_MUL) ? 2 : 1;
+  constexpr int KCH = 48, NPER = 12;
+  constexpr int WU = (NACC == 2) ? 4 : 6;          // weight chunks per round (VGPR budget: 3 workgroups per CU)
+  __shared__ __attribute__((aligned(16))) float red[4][NACC][64][4];
+  __shared__ float bs[4][64];
+
+  const int tile = blockIdx.x, mt0 = blockIdx.y;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 15, g = lane >> 4;
+  const int n0 = tile * 16, m0 = mt0 * 16;
+  const u128* wp = reinterpret_cast<const u128*>(a.Wp) + ((size_t)tile * KCH + wave) * 64 + lane;   // wave w owns chunks 4 i + w
+  const u128* wp2 = wp + (size_t)(a.N >> 4) * KCH * 64;
+  const u128* ap = reinterpret_cast<const u128*>(a.Ap) + ((size_t)mt0 * KCH + wave) * 64 + lane;
+  const bool w_once = a.w_nt && gridDim.y == 1;
+  u128 wf[NACC][WU], af[NPER];
+  float4 nw[WU];
+  auto load_w = [&](const int i0) {
+    if (w_once) {
+#pragma unroll
+      for (int j = 0; j < WU; ++j) {
+        wf[0][j] = load16_nt(wp + (size_t)(i0 + j) * 256);
+        if (NACC == 2) wf[1][j] = load16_nt(wp2 + (size_t)(i0 + j) * 256);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < WU; ++j) {
+        wf[0][j] = load16(wp + (size_t)(i0 + j) * 256);
+        if (NACC == 2) wf[1][j] = load16(wp2 + (size_t)(i0 + j) * 256);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < WU; ++j) nw[j] = *reinterpret_cast<const float4*>(a.norm_w + ((i0 + j) * 4 + wave) * 16 + g * 4);
+  };
+  // everything the workgroup can ask for without knowing the live-row count (its row tile's buffer exists either way)
+#pragma unroll
+  for (int i = 0; i < NPER; ++i) af[i] = load16(ap + (size_t)i * 256);
+  load_w(0);
+  const int M = a.n_active ? min(*a.n_active, a.M) : a.M;
+  if (m0 >= M) return;
+
+  const int row = m0 + 4 * g + wave, col = n0 + li;   // C/D map: col = lane & 15, row = 4 (lane >> 4) + register (= wave here)
+  const int sect = n0 / 768, hcol = n0 % 768, head = hcol >> 6, t4 = (hcol & 63) >> 4;
+  const int dlo = 8 * t4 + (li & 7);
+  RowDesc rd = RowDesc{-1, 0, 0, 0};
+  float rc = 0.f, rsn = 0.f;
+  if (EPI == D32_EPI_QKV_ROPE) {
+    rd = a.desc[min(row, M - 1)];
+    rc = a.cos_t[rd.pos * 32 + dlo];
+    rsn = a.sin_t[rd.pos * 32 + dlo];
+  }
+
+  // 1 / rms of row li from the fragments (see above)
+  float sq[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float s = rms_acc4(0.f, *reinterpret_cast<const float4*>(&af[q]));
+    s = rms_acc4(s, *reinterpret_cast<const float4*>(&af[q + 4]));
+    sq[q] = rms_acc4(s, *reinterpret_cast<const float4*>(&af[q + 8]));
+  }
+  float rs;
+  {
+#pragma clang fp contract(off)
+    const float b = (sq[0] + sq[2]) + (sq[1] + sq[3]);          // butterfly levels 32, 16
+    bs[wave][lane] = b;
+    __syncthreads();
+    const float c = (bs[wave][lane] + bs[wave ^ 2][lane]) + (bs[wave ^ 1][lane] + bs[wave ^ 3][lane]);   // levels 8, 4
+    const float e = c + __shfl_xor(c, 32, 64);                  // level 2
+    const float f = e + __shfl_xor(e, 16, 64);                  // level 1
+    rs = rms_rstd_of(f, 768, a.eps);
+  }
+
+  f32x4 acc[NACC];
+#pragma unroll
+  for (int na = 0; na < NACC; ++na) acc[na] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i0 = 0; i0 < NPER; i0 += WU) {
+    if (i0 > 0) load_w(i0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < WU; ++j) {
+      float4 a0 = *reinterpret_cast<const float4*>(&af[i0 + j]);
+      a0.x = nw[j].x * (a0.x * rs); a0.y = nw[j].y * (a0.y * rs); a0.z = nw[j].z * (a0.z * rs); a0.w = nw[j].w * (a0.w * rs);
+#pragma unroll
+      for (int na = 0; na < NACC; ++na) {
+        const float4 b = *reinterpret_cast<const float4*>(&wf[na][j]);
+        f32x4 c = acc[na];
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b.x, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b.y, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b.z, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b.w, c, 0, 0, 0);
+        acc[na] = c;
+      }
+    }
+  }
+
+#pragma unroll
+  for (int na = 0; na < NACC; ++na) *reinterpret_cast<f32x4*>(&red[wave][na][lane][0]) = acc[na];
+  __syncthreads();
+  float v = ((red[0][0][lane][wave] + red[1][0][lane][wave]) + red[2][0][lane][wave]) + red[3][0][lane][wave];   // fixed order
+  if (EPI == EPI_SILU_MUL) {
+    const float u = ((red[0][NACC - 1][lane][wave] + red[1][NACC - 1][lane][wave]) + red[2][NACC - 1][lane][wave]) + red[3][NACC - 1][lane][wave];
+    v = silu_f(v) * u;
+    if (row < M && a.Cp != nullptr) a.Cp[pk32_off(row, col, a.kch_out)] = v;
+  } else if (EPI == D32_EPI_QKV_ROPE) {
+    const float other = __shfl_xor(v, 8, 64);
+    const bool hi = li >= 8;
+    const float roped = hi ? rope_hi(other, v, rc, rsn) : rope_lo(v, other, rc, rsn);
+    const int d = dlo + (hi ? 32 : 0);
+    if (row < M && rd.b >= 0) {
+      const size_t cbase = (((size_t)rd.b * 12 + head) * a.cmax + rd.slot) * 64;
+      if (sect == 0) a.C[(size_t)row * a.ldc + head * 64 + d] = roped;
+      else if (sect == 1) a.kc[cbase + d] = roped;
+      else a.vc[cbase + (hcol & 63) + li] = v;
+    }
+  } else {
+    if (row < M) a.C[(size_t)row * a.ldc + col] = v;
+  }
+}
+
 template <int KT>
 static hipError_t dec32_dispatch_m16(const Dec32Args& a, hipStream_t st) {
   dim3 grid(a.N / 16, (a.M + 15) / 16), block(256);
@@ -437,6 +568,16 @@ hipError_t launch_gemm_dec32(const Dec32Args& a_in, hipStream_t st) {
   if (a.force_mb) mb = a.force_mb;
   // 16-row workgroups WITHOUT an RMSNorm prologue (o / down) take the everything-up-front kernel; with the prologue its 200+
   // VGPRs cost more occupancy than the saved round trips are worth (profiles/r2s_*: gate/up 16.8 vs 13.3 us)
+  static int rms16 = -1;   // CTTS_D32_RMS16=0: RMSNorm launches re-read the residual rows for their statistics (generic body; A/B)
+  if (rms16 < 0) rms16 = env_int32("CTTS_D32_RMS16", 1);
+  if (mb == 1 && rms16 && a.norm_w != nullptr && a.K == 768) {
+    dim3 grid(a.N / 16, (a.M + 15) / 16), block(256);
+    if (a.epi == EPI_SILU_MUL) CTTS_LAUNCH((gemm_dec32_rms16_k<EPI_SILU_MUL>), grid, block, st, a);
+    else if (a.epi == D32_EPI_QKV_ROPE) CTTS_LAUNCH((gemm_dec32_rms16_k<D32_EPI_QKV_ROPE>), grid, block, st, a);
+    else if (a.epi == EPI_STORE) CTTS_LAUNCH((gemm_dec32_rms16_k<EPI_STORE>), grid, block, st, a);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+  }
   static int m16 = -1;   // CTTS_D32_M16=0: the generic body for every launch, 2: the m16 kernels for the RMSNorm launches too (A/B)
   if (m16 < 0) m16 = env_int32("CTTS_D32_M16", 1);
   const bool m16_ok = m16 == 2 ? a.epi != D32_EPI_QKV_ROPE : (m16 == 1 && a.norm_w == nullptr);
