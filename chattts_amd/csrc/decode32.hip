@@ -265,20 +265,20 @@ __global__ __launch_bounds__(256) void gemm_dec32_k(Dec32Args a) {
   }
 }
 
-// The default geometry -- 16-row workgroups, K known at compile time -- with every load the workgroup can issue up front in
-// flight at kernel entry: K = 768: ALL 12 chunks of the wave (W and A fragments, RMSNorm gains) are requested before the
+// o_proj / down_proj (no RMSNorm prologue) as 16-row workgroups, K known at compile time, with every load the workgroup can
+// issue up front in flight at kernel entry: K = 768: ALL 12 chunks of the wave (W and A fragments) are requested before the
 // live-row count is even known, so the workgroup pays one memory round trip, not one per stage; K = 3072: stages of 6 chunks,
 // double-buffered (stage r+1 requested before stage r is multiplied).  Same operation order per output element as above.
-template <int KT, bool RMS, int EPI>
+// (With an RMSNorm prologue this shape was SLOWER than the generic body -- 200+ VGPRs, profiles/r2s_* -- see gemm_dec32_rms16_k.)
+template <int KT, int EPI>
 __global__ __launch_bounds__(256) void gemm_dec32_m16_k(Dec32Args a) {
-  constexpr int NACC = (EPI == EPI_SILU_MUL) ? 2 : 1;
+  constexpr int NACC = 1;
   constexpr int KCH = KT / 16, NPER = KCH / 4;   // chunks per wave: 12 / 48
   constexpr int U = (KT == 768) ? 12 : 6;         // chunks per stage
   constexpr int ROUNDS = NPER / U;                // 1 / 8
   static_assert(ROUNDS == 1 || ROUNDS % 2 == 0, "stages are consumed in pairs");
   __shared__ __attribute__((aligned(16))) float red[4][NACC][64][4];
-  __shared__ float rstd_s[16];
-  struct Stage { u128 w[NACC][U]; u128 a[U]; float4 nw[U]; };
+  struct Stage { u128 w[NACC][U]; u128 a[U]; };
 
   const int tile = blockIdx.x, mt0 = blockIdx.y;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -304,10 +304,6 @@ __global__ __launch_bounds__(256) void gemm_dec32_m16_k(Dec32Args a) {
     }
 #pragma unroll
     for (int j = 0; j < U; ++j) s.a[j] = load16(ap + (size_t)(r * U + j) * 256);
-    if (RMS) {
-#pragma unroll
-      for (int j = 0; j < U; ++j) s.nw[j] = *reinterpret_cast<const float4*>(a.norm_w + ((r * U + j) * 4 + wave) * 16 + g * 4);
-    }
   };
   Stage s0;
   load_stage(s0, 0);   // the row tile's buffer exists whether or not its rows are live: nothing here depends on *n_active
@@ -316,30 +312,13 @@ __global__ __launch_bounds__(256) void gemm_dec32_m16_k(Dec32Args a) {
 
   float pre0 = 0.f;   // RES: wave w finishes accumulator register w
   if (EPI == EPI_RES) pre0 = a.res[(size_t)min(m0 + 4 * g + wave, M - 1) * a.ldr + n0 + li];
-  float rs = 1.0f;
-  if (RMS) {
-    static_assert(!RMS || KT == 768, "the RMSNorm prologue is the K = 768 one");
-    const float* rows[4];
-    float rstd[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) rows[q] = a.X + (size_t)min(m0 + wave + 4 * q, M - 1) * a.ldx;
-    wave_rows_rstd_768<4>(rows, a.eps, lane, rstd);
-    if (lane == 0) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) rstd_s[wave + 4 * q] = rstd[q];
-    }
-    __syncthreads();
-    rs = rstd_s[li];
-  }
-
   f32x4 acc[NACC];
 #pragma unroll
   for (int na = 0; na < NACC; ++na) acc[na] = (f32x4){0.f, 0.f, 0.f, 0.f};
   auto mul_stage = [&](const Stage& s) {
 #pragma unroll
     for (int j = 0; j < U; ++j) {
-      float4 a0 = *reinterpret_cast<const float4*>(&s.a[j]);
-      if (RMS) { a0.x = s.nw[j].x * (a0.x * rs); a0.y = s.nw[j].y * (a0.y * rs); a0.z = s.nw[j].z * (a0.z * rs); a0.w = s.nw[j].w * (a0.w * rs); }
+      const float4 a0 = *reinterpret_cast<const float4*>(&s.a[j]);
 #pragma unroll
       for (int na = 0; na < NACC; ++na) {
         const float4 b = *reinterpret_cast<const float4*>(&s.w[na][j]);
@@ -516,13 +495,9 @@ __global__ __launch_bounds__(256, 3) void gemm_dec32_rms16_k(Dec32Args a) {
 template <int KT>
 static hipError_t dec32_dispatch_m16(const Dec32Args& a, hipStream_t st) {
   dim3 grid(a.N / 16, (a.M + 15) / 16), block(256);
-  const bool rms = a.norm_w != nullptr;
-  if constexpr (KT == 768) {
-    if (a.epi == EPI_STORE && rms) { CTTS_LAUNCH((gemm_dec32_m16_k<KT, true, EPI_STORE>), grid, block, st, a); return hipGetLastError(); }
-    if (a.epi == EPI_SILU_MUL && rms) { CTTS_LAUNCH((gemm_dec32_m16_k<KT, true, EPI_SILU_MUL>), grid, block, st, a); return hipGetLastError(); }
-  }
-  if (a.epi == EPI_STORE && !rms) CTTS_LAUNCH((gemm_dec32_m16_k<KT, false, EPI_STORE>), grid, block, st, a);
-  else if (a.epi == EPI_RES && !rms) CTTS_LAUNCH((gemm_dec32_m16_k<KT, false, EPI_RES>), grid, block, st, a);
+  if (a.norm_w != nullptr) return hipErrorInvalidValue;
+  if (a.epi == EPI_STORE) CTTS_LAUNCH((gemm_dec32_m16_k<KT, EPI_STORE>), grid, block, st, a);
+  else if (a.epi == EPI_RES) CTTS_LAUNCH((gemm_dec32_m16_k<KT, EPI_RES>), grid, block, st, a);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }
@@ -566,23 +541,11 @@ hipError_t launch_gemm_dec32(const Dec32Args& a_in, hipStream_t st) {
   // workgroups of o / down (48 weight tiles only) are the same choice the bf16 kernel makes.
   int mb = a.epi == EPI_SILU_MUL ? mb_silu : a.epi == EPI_RES ? (a.K > 768 ? mb_down : mb_o) : mb_qkv;
   if (a.force_mb) mb = a.force_mb;
-  // 16-row workgroups WITHOUT an RMSNorm prologue (o / down) take the everything-up-front kernel; with the prologue its 200+
-  // VGPRs cost more occupancy than the saved round trips are worth (profiles/r2s_*: gate/up 16.8 vs 13.3 us)
-  static int rms16 = -1;   // CTTS_D32_RMS16=0: RMSNorm launches re-read the residual rows for their statistics (generic body; A/B)
-  if (rms16 < 0) rms16 = env_int32("CTTS_D32_RMS16", 1);
-  if (mb == 1 && rms16 && a.norm_w != nullptr && a.K == 768) {
-    dim3 grid(a.N / 16, (a.M + 15) / 16), block(256);
-    if (a.epi == EPI_SILU_MUL) CTTS_LAUNCH((gemm_dec32_rms16_k<EPI_SILU_MUL>), grid, block, st, a);
-    else if (a.epi == D32_EPI_QKV_ROPE) CTTS_LAUNCH((gemm_dec32_rms16_k<D32_EPI_QKV_ROPE>), grid, block, st, a);
-    else if (a.epi == EPI_STORE) CTTS_LAUNCH((gemm_dec32_rms16_k<EPI_STORE>), grid, block, st, a);
-    else return hipErrorInvalidValue;
-    return hipGetLastError();
-  }
-  static int m16 = -1;   // CTTS_D32_M16=0: the generic body for every launch, 2: the m16 kernels for the RMSNorm launches too (A/B)
+  // 16-row workgroups without an RMSNorm prologue (o / down) take the everything-up-front kernel
+  static int m16 = -1;   // CTTS_D32_M16=0: the generic body instead (A/B)
   if (m16 < 0) m16 = env_int32("CTTS_D32_M16", 1);
-  const bool m16_ok = m16 == 2 ? a.epi != D32_EPI_QKV_ROPE : (m16 == 1 && a.norm_w == nullptr);
-  if (mb == 1 && m16_ok && a.K == 768) return dec32_dispatch_m16<768>(a, st);
-  if (mb == 1 && m16_ok && a.K == 3072 && a.norm_w == nullptr) return dec32_dispatch_m16<3072>(a, st);
+  if (mb == 1 && m16 && a.norm_w == nullptr && a.K == 768) return dec32_dispatch_m16<768>(a, st);
+  if (mb == 1 && m16 && a.norm_w == nullptr && a.K == 3072) return dec32_dispatch_m16<3072>(a, st);
   if (mb >= 4) return dec32_dispatch<4>(a, st);
   if (mb == 2) return dec32_dispatch<2>(a, st);
   return dec32_dispatch<1>(a, st);
