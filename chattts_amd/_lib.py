@@ -24,6 +24,7 @@ class GptWeights(C.Structure):
         ("rms_eps", C.c_float),
         ("emb_text", P), ("head_text", P), ("n_text", C.c_int32),
         ("wqkv_pk", PP), ("wo_pk", PP), ("wgu_pk", PP), ("wd_pk", PP),
+        ("heads_pk", P), ("head_text_pk", P),
     ]
 
 
@@ -111,7 +112,8 @@ SIGNATURES = {
     "ctts_k_gemm_fast": (C.c_int, [P, I32, P, I32, I32, I32, P, F, I32, P, I32, P, I32, P, P]),
     "ctts_k_qkv_rope": (C.c_int, [P, P, I32, P, F, P, P, P, I32, P, P, I32, P, P, I32, P]),
     "ctts_k_gemm_dec": (C.c_int, [P, P, I32, I32, I32, P, P, F, I32, P, I32, P, I32, P, I32, P]),
-    "ctts_k_gemm_dec32": (C.c_int, [P, P, I32, I32, I32, P, P, I32, P, F, I32, P, I32, P, I32, P, I32, I32, P]),
+    "ctts_k_dec32_last_variant": (C.c_char_p, []),
+    "ctts_k_gemm_dec32": (C.c_int, [P, P, I32, I32, I32, P, P, I32, P, F, I32, P, I32, P, I32, P, I32, I32, I32, P]),
     "ctts_k_rows_prep": (C.c_int, [P, P, P, I32, P]),
     "ctts_k_rope_append": (C.c_int, [P, P, P, I32, I32, P, P, I32, P, P, I32, P]),
     "ctts_k_attention": (C.c_int, [P, P, P, I32, I32, P, I32, P, P, I32, P]),

@@ -37,6 +37,7 @@ struct ctts_gpt {
   std::vector<const void*> wqkv_pk, wo_pk, wgu_pk, wd_pk;   // fragment-packed copies for the decode step, or empty
   bool dec_packed = false;     // perf mode (bf16 weights): decode.hip
   bool dec_packed32 = false;   // parity mode (f32 weights): decode32.hip
+  bool heads_packed = false;   // heads GEMM on packed f32 operands (decode32.hip), both modes
   std::vector<const float*> ln1, ln2;
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
@@ -60,6 +61,7 @@ struct GptWs {
   // decode step on fragment-packed operands (decode.hip): row tiles of 16 utterances
   uint16_t *xp, *aop, *actp;
   float *xp32, *aop32, *actp32;   // the same in float32 (parity mode, decode32.hip)
+  float* hfinp;                   // final-norm rows in the packed f32 order (A operand of the packed heads GEMM, both modes)
   RowDesc* desc;
   float* att_part;    // attention remainder splitting: partials of the split units' pieces, and their arrival counters
   int32_t* att_cnt;
@@ -86,6 +88,7 @@ static GptWs carve(void* base, int B, int T) {
   w.xp32 = (float*)(p + off); off += align_up(Bp * HID * 4);
   w.aop32 = (float*)(p + off); off += align_up(Bp * HID * 4);
   w.actp32 = (float*)(p + off); off += align_up(Bp * INTER * 4);
+  w.hfinp = (float*)(p + off); off += align_up(Bp * HID * 4);
   w.desc = (RowDesc*)(p + off); off += align_up(Bp * sizeof(RowDesc));
   w.row_map = (int32_t*)(p + off); off += align_up(Bp * sizeof(int32_t));
   w.att_part = (float*)(p + off); off += align_up((size_t)ATT_CUS_MAX * ATT_SPLIT_MAX * 66 * sizeof(float));
@@ -117,6 +120,7 @@ extern "C" int ctts_gpt_create(ctts_gpt** out, const ctts_gpt_weights* w) {
     g->dec_packed = on && w->weight_dtype == CTTS_BF16;
     g->dec_packed32 = on && w->weight_dtype != CTTS_BF16 && w->kv_dtype != CTTS_BF16;
   }
+  { const char* e = getenv("CTTS_DEC_PACKED"); g->heads_packed = w->heads_pk != nullptr && !(e && atoi(e) == 0); }
   { const char* e = getenv("CTTS_SKIP_FINISHED"); if (e && atoi(e) == 0) g->skip_finished = false; }
   {
     int dev = 0, cus = 0;
@@ -318,9 +322,18 @@ static int run_step(ctts_gpt* g, const ctts_gen_state* s, int q_per_b, hipStream
   if (!heads) return 0;   // a prompt chunk that is not the last one: its K/V rows are in the cache, nothing is sampled
   { Prof p(g, 7, st, prof_ok);
     CK(launch_final_norm(ws.x, q_per_b, g->w.norm, g->w.rms_eps, ws.hfin, s->hiddens, s->hid_cap ? s->hid_cap : s->max_new, s->len, s->T, B, rmap,
-                         nact, s->prompt_len, st)); }
+                         nact, s->prompt_len, st, ws.hfinp)); }
   {
     const int nlog = s->infer_text ? g->w.n_text : NVQ * NAUDIO;   // gpt.py:439-440 text head | :441-454 four code heads
+    const float* hpk = s->infer_text ? g->w.head_text_pk : g->w.heads_pk;
+    if (g->heads_packed && hpk != nullptr) {   // same arithmetic as the row-major kernel below, operands in fragment order
+      Dec32Args d;
+      memset(&d, 0, sizeof(d));
+      d.Ap = ws.hfinp; d.Wp = hpk; d.M = B; d.N = (nlog + 15) / 16 * 16; d.K = HID; d.n_active = nact; d.epi = EPI_STORE;
+      d.C = ws.logits; d.ldc = nlog; d.n_cols = nlog;
+      Prof p(g, 8, st, prof_ok);
+      CK(launch_gemm_dec32(d, st));
+    } else {
     GemmArgs a;
     memset(&a, 0, sizeof(a));
     a.taps = 1;
@@ -328,6 +341,7 @@ static int run_step(ctts_gpt* g, const ctts_gen_state* s, int q_per_b, hipStream
     a.K = HID; a.wt = WT_F32; a.epi = EPI_STORE; a.n_active = nact;
     Prof p(g, 8, st, prof_ok);
     CK(launch_gemm_skinny(a, st));
+    }
   }
   {
     Prof p(g, 9, st, prof_ok);
@@ -647,14 +661,16 @@ extern "C" int ctts_k_gemm_dec(const uint16_t* Ap, const uint16_t* Wp, int32_t M
 }
 extern "C" int ctts_k_gemm_dec32(const float* Ap, const float* Wp, int32_t M, int32_t N, int32_t K, const int32_t* n_active, const float* X,
                                  int32_t ldx, const float* norm_w, float eps, int32_t epi, float* C, int32_t ldc, const float* res, int32_t ldr,
-                                 float* Cp, int32_t kch_out, int32_t force_mb, void* stream) {
+                                 float* Cp, int32_t kch_out, int32_t force_mb, int32_t n_cols, void* stream) {
   Dec32Args d;
   memset(&d, 0, sizeof(d));
+  d.n_cols = n_cols;
   d.Ap = Ap; d.Wp = Wp; d.M = M; d.N = N; d.K = K; d.n_active = n_active; d.X = X; d.ldx = ldx; d.norm_w = norm_w; d.eps = eps; d.epi = epi;
   d.C = C; d.ldc = ldc; d.res = res; d.ldr = ldr; d.Cp = Cp; d.kch_out = kch_out; d.force_mb = force_mb;
   CK(launch_gemm_dec32(d, (hipStream_t)stream));
   return 0;
 }
+extern "C" const char* ctts_k_dec32_last_variant(void) { return dec32_last_variant(); }
 extern "C" int ctts_k_rows_prep(const float* x32, uint16_t* xb, float* ssq, int32_t M, void* stream) {
   CK(launch_rows_prep(x32, xb, ssq, M, (hipStream_t)stream));
   return 0;

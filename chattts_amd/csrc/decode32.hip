@@ -214,7 +214,7 @@ __device__ __forceinline__ void dec32_body(const Dec32Args& a, const int M, cons
       }
       continue;
     }
-    if (row >= M) continue;
+    if (row >= M || (EPI == EPI_STORE && col >= a.n_cols)) continue;
     if (EPI != EPI_SILU_MUL) a.C[(size_t)row * a.ldc + col] = v;
     if (EPI != EPI_STORE && a.Cp != nullptr) a.Cp[pk32_off(row, col, a.kch_out)] = v;
   }
@@ -357,6 +357,7 @@ __global__ __launch_bounds__(256) void gemm_dec32_m16_k(Dec32Args a) {
   } else if (EPI == EPI_RES) {
     v = pre0 + v;
   }
+  if (EPI == EPI_STORE && col >= a.n_cols) return;   // padded columns of the last tile (heads)
   if (EPI != EPI_SILU_MUL) a.C[(size_t)row * a.ldc + col] = v;
   if (EPI != EPI_STORE && a.Cp != nullptr) a.Cp[pk32_off(row, col, a.kch_out)] = v;
 }
@@ -488,7 +489,7 @@ __global__ __launch_bounds__(256, 3) void gemm_dec32_rms16_k(Dec32Args a) {
       else a.vc[cbase + (hcol & 63) + li] = v;
     }
   } else {
-    if (row < M) a.C[(size_t)row * a.ldc + col] = v;
+    if (row < M && col < a.n_cols) a.C[(size_t)row * a.ldc + col] = v;
   }
 }
 
@@ -521,6 +522,11 @@ static hipError_t dec32_dispatch(const Dec32Args& a, hipStream_t st) {
   return hipGetLastError();
 }
 
+// which kernel the last launch_gemm_dec32 of this thread picked: every variant produces the same bits, so only this (and a
+// profiler) can tell a dispatch regression from the intended path (tests/test_gpu_kernels.py asserts the default choices)
+static thread_local const char* g_d32_variant = "";
+const char* dec32_last_variant() { return g_d32_variant; }
+
 hipError_t launch_gemm_dec32(const Dec32Args& a_in, hipStream_t st) {
   Dec32Args a = a_in;
   static int nt = -1, mb_qkv = -1, mb_silu = -1, mb_o = -1, mb_down = -1, a_early = 1;
@@ -532,6 +538,7 @@ hipError_t launch_gemm_dec32(const Dec32Args& a_in, hipStream_t st) {
   }
   a.w_nt = nt;
   a.a_early = a_early;
+  if (a.n_cols <= 0 || a.n_cols > a.N) a.n_cols = a.N;
   // K: chunks of 16, 4 waves, rounds of D32_U chunks
   if (a.M <= 0 || a.N <= 0 || (a.N & 15) || a.K % (16 * 4 * D32_U) != 0) return hipErrorInvalidValue;
   if (a.norm_w != nullptr && (a.X == nullptr || (a.ldx & 3))) return hipErrorInvalidValue;
@@ -541,11 +548,25 @@ hipError_t launch_gemm_dec32(const Dec32Args& a_in, hipStream_t st) {
   // workgroups of o / down (48 weight tiles only) are the same choice the bf16 kernel makes.
   int mb = a.epi == EPI_SILU_MUL ? mb_silu : a.epi == EPI_RES ? (a.K > 768 ? mb_down : mb_o) : mb_qkv;
   if (a.force_mb) mb = a.force_mb;
-  // 16-row workgroups without an RMSNorm prologue (o / down) take the everything-up-front kernel
+  // 16-row RMSNorm launches (QKV, gate/up): statistics from the fragments, no re-read of the residual rows
+  static int rms16 = -1;   // CTTS_D32_RMS16=0: the generic body (statistics from the row-major rows) instead (A/B)
+  if (rms16 < 0) rms16 = env_int32("CTTS_D32_RMS16", 1);
+  if (mb == 1 && rms16 && a.norm_w != nullptr && a.K == 768) {
+    g_d32_variant = "rms16";
+    dim3 grid(a.N / 16, (a.M + 15) / 16), block(256);
+    if (a.epi == EPI_SILU_MUL) CTTS_LAUNCH((gemm_dec32_rms16_k<EPI_SILU_MUL>), grid, block, st, a);
+    else if (a.epi == D32_EPI_QKV_ROPE) CTTS_LAUNCH((gemm_dec32_rms16_k<D32_EPI_QKV_ROPE>), grid, block, st, a);
+    else if (a.epi == EPI_STORE) CTTS_LAUNCH((gemm_dec32_rms16_k<EPI_STORE>), grid, block, st, a);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+  }
+  // 16-row workgroups without an RMSNorm prologue (o / down, the heads) take the everything-up-front kernel
   static int m16 = -1;   // CTTS_D32_M16=0: the generic body instead (A/B)
   if (m16 < 0) m16 = env_int32("CTTS_D32_M16", 1);
+  g_d32_variant = "m16";
   if (mb == 1 && m16 && a.norm_w == nullptr && a.K == 768) return dec32_dispatch_m16<768>(a, st);
   if (mb == 1 && m16 && a.norm_w == nullptr && a.K == 3072) return dec32_dispatch_m16<3072>(a, st);
+  g_d32_variant = "generic";
   if (mb >= 4) return dec32_dispatch<4>(a, st);
   if (mb == 2) return dec32_dispatch<2>(a, st);
   return dec32_dispatch<1>(a, st);

@@ -644,7 +644,8 @@ hipError_t launch_attention(const float* qkv, const void* kcache, const void* vc
 __global__ __launch_bounds__(192) void final_norm_k(const float* __restrict__ x, int q_per_b, const float* __restrict__ w, float eps,
                                                     float* __restrict__ hfin, float* __restrict__ hiddens, int max_new,
                                                     const int32_t* __restrict__ len, int T, const int32_t* __restrict__ row_map,
-                                                    const int32_t* __restrict__ n_active, const int32_t* __restrict__ prompt_len) {
+                                                    const int32_t* __restrict__ n_active, const int32_t* __restrict__ prompt_len,
+                                                    float* __restrict__ hfin_p) {
   __shared__ float part[3];
   const int m = blockIdx.x, t = threadIdx.x;
   if (row_absent(n_active, m)) return;
@@ -660,6 +661,7 @@ __global__ __launch_bounds__(192) void final_norm_k(const float* __restrict__ x,
   float4 o;
   o.x = g.x * (v.x * rstd); o.y = g.y * (v.y * rstd); o.z = g.z * (v.z * rstd); o.w = g.w * (v.w * rstd);
   *reinterpret_cast<float4*>(hfin + (size_t)m * HID + t * 4) = o;
+  if (hfin_p != nullptr) *reinterpret_cast<float4*>(hfin_p + pk32_off(m, 4 * t, HID / 16)) = o;   // A operand of the packed heads GEMM
   const int gen = len[b] - (prompt_len ? prompt_len[b] : T);
   if (hiddens != nullptr && gen >= 0 && gen < max_new)
     *reinterpret_cast<float4*>(hiddens + ((size_t)b * max_new + gen) * HID + t * 4) = o;
@@ -667,8 +669,8 @@ __global__ __launch_bounds__(192) void final_norm_k(const float* __restrict__ x,
 
 hipError_t launch_final_norm(const float* x, int q_per_b, const float* w, float eps, float* hfin, float* hiddens, int max_new,
                              const int32_t* len, int T, int B, const int32_t* row_map, const int32_t* n_active,
-                             const int32_t* prompt_len, hipStream_t st) {
-  CTTS_LAUNCH(final_norm_k, dim3(B), dim3(192), st, x, q_per_b, w, eps, hfin, hiddens, max_new, len, T, row_map, n_active, prompt_len);
+                             const int32_t* prompt_len, hipStream_t st, float* hfin_packed) {
+  CTTS_LAUNCH(final_norm_k, dim3(B), dim3(192), st, x, q_per_b, w, eps, hfin, hiddens, max_new, len, T, row_map, n_active, prompt_len, hfin_packed);
   return hipGetLastError();
 }
 

@@ -141,6 +141,7 @@ struct Dec32Args {
   float* C; int ldc;
   const float* res; int ldr;
   float* Cp; int kch_out;       // packed f32 copy of the output for the next projection (kch_out = its columns / 16), or null
+  int n_cols;                   // EPI_STORE: columns of C that exist (the heads: N is padded to a multiple of 16); 0 = N
   // D32_EPI_QKV_ROPE (N = 2304, K = 768, q/k weight rows in the rope_row_perm order of engine.py): RoPE on q -> C (qkv buffer, natural
   // column order), RoPE on k -> KV cache, v -> KV cache, all float32, at (desc[row].b, desc[row].slot); rope_append_k's arithmetic
   const RowDesc* desc;
@@ -152,6 +153,7 @@ struct Dec32Args {
 };
 enum { D32_EPI_QKV_ROPE = 100 };
 hipError_t launch_gemm_dec32(const Dec32Args& a, hipStream_t st);
+const char* dec32_last_variant();   // "rms16" | "m16" | "generic": the kernel the calling thread's last launch picked (tests)
 
 // ---- GPT step kernels -------------------------------------------------------------------------
 struct GptRowMap {
@@ -205,7 +207,8 @@ hipError_t launch_attention(const float* qkv, const void* kcache, const void* vc
                             GptRowMap rm, int M, hipStream_t st);
 hipError_t launch_final_norm(const float* x, int q_per_b, const float* w, float eps, float* hfin /*[B,768]*/,
                              float* hiddens /*[slots,max_new,768]*/, int max_new, const int32_t* len, int T, int B,
-                             const int32_t* row_map, const int32_t* n_active, const int32_t* prompt_len, hipStream_t st);
+                             const int32_t* row_map, const int32_t* n_active, const int32_t* prompt_len, hipStream_t st,
+                             float* hfin_packed = nullptr /* the same rows in the packed f32 order of decode32.hip, or null */);
 
 struct SampleArgs {
   const float* logits;      // [B, 4*626]

@@ -258,6 +258,11 @@ class GptEngine:
             qk_perm = torch.cat([rp, GPT.hidden + rp, 2 * GPT.hidden + torch.arange(GPT.hidden, device=dev)])
             self.packed[0] = [pack_frag32(t[qk_perm]) for t in self.wqkv]
         self._pk_arrs = None if self.packed is None else [_lib.ptr_array(x) for x in self.packed]
+
+        def pad16(t):      # zero rows up to a multiple of 16: the padded columns of the last logits tile are never stored
+            r = (-t.shape[0]) % 16
+            return t if r == 0 else torch.cat([t, torch.zeros((r, t.shape[1]), dtype=t.dtype, device=t.device)], 0)
+        self.heads_pk, self.head_text_pk = pack_frag32(pad16(self.heads)), pack_frag32(pad16(self.head_text))
         w = _lib.GptWeights()
         w.n_layers, w.weight_dtype, w.kv_dtype, w.max_pos = self.n_layers, self.code, self.code, max_pos
         w.wqkv, w.wo, w.wgu, w.wd, w.ln1, w.ln2 = [C.cast(a, _lib.PP) for a in self._arrs]
@@ -267,6 +272,7 @@ class GptEngine:
         w.emb_text, w.head_text, w.n_text = self.emb_text.data_ptr(), self.head_text.data_ptr(), GPT.n_text
         if self._pk_arrs is not None:
             w.wqkv_pk, w.wo_pk, w.wgu_pk, w.wd_pk = [C.cast(a, _lib.PP) for a in self._pk_arrs]
+        w.heads_pk, w.head_text_pk = self.heads_pk.data_ptr(), self.head_text_pk.data_ptr()
         self._w = w
         h = C.c_void_p()
         _lib.check(self.lib.ctts_gpt_create(C.byref(h), C.byref(w)), "ctts_gpt_create")

@@ -71,6 +71,10 @@ typedef struct {
   const void* const* wo_pk;
   const void* const* wgu_pk;
   const void* const* wd_pk;
+  /* optional (NULL: row-major heads GEMM): `heads` / `head_text` zero-padded to a multiple of 16 rows, in the packed f32 order above
+   * ([rows/16][768/16][64][4]); both modes (the heads are always f32); bit-identical logits */
+  const float* heads_pk;
+  const float* head_text_pk;
 } ctts_gpt_weights;
 
 /* One generate() call's device state (every array is caller-allocated, device memory). */
@@ -286,7 +290,10 @@ int ctts_k_gemm_dec(const uint16_t* Ap, const uint16_t* Wp, int32_t M, int32_t N
  * 2 = SiLU(gate)*up -> Cp.  Bit-identical to ctts_k_gemm(tiled = 0, wt = f32) on the same values. */
 int ctts_k_gemm_dec32(const float* Ap, const float* Wp, int32_t M, int32_t N, int32_t K, const int32_t* n_active, const float* X, int32_t ldx,
                       const float* norm_w, float eps, int32_t epi, float* C, int32_t ldc, const float* res, int32_t ldr, float* Cp,
-                      int32_t kch_out, int32_t force_mb, void* stream);
+                      int32_t kch_out, int32_t force_mb, int32_t n_cols /* epi 0: columns of C that exist (N padded to 16), 0 = N */,
+                      void* stream);
+/* which decode32 kernel the calling thread's last ctts_k_gemm_dec32 / decode step picked: "rms16" | "m16" | "generic" (all bit-identical) */
+const char* ctts_k_dec32_last_variant(void);
 int ctts_k_rows_prep(const float* x32, uint16_t* xb, float* ssq, int32_t M, void* stream);
 int ctts_k_rope_append(float* qkv, void* kcache, void* vcache, int32_t kv_dtype, int32_t cmax, const float* cos_tab, const float* sin_tab,
                        int32_t q_per_b, const int32_t* len, const int32_t* kv_start, int32_t M, void* stream);

@@ -195,23 +195,29 @@ def test_gemm_dec32_bit_identical(G, M, n_act, force_mb):
         pad[: a.shape[0]] = a
         return pack_frag32(torch.from_numpy(pad)).to(G.DEV)
 
-    for N, K, epi, rms in SK_SHAPES[:4]:
+    for N, K, epi, rms in SK_SHAPES:      # the last one is the heads GEMM: N = 2504 is padded to 2512 zero rows, n_cols = 2504
         A = (rs.standard_normal((M, K)) * (2.0 if rms else 1.0)).astype(f32)
         nrows = 2 * N if epi == 2 else N
         W = (rs.standard_normal((nrows, K)) * 0.03).astype(f32)
+        Np = (N + 15) // 16 * 16
         nw = (1.0 + 0.1 * rs.standard_normal(K)).astype(f32) if rms else None
         res = rs.standard_normal((M, N)).astype(f32) if epi == 1 else None
         want = G.gemm(A[:live], W, wt="f32", epi=epi, norm_w=nw, res=None if res is None else res[:live], n_out=N)   # gemm_skinny_k<float>
-        A_d, Ap, Wp = G.dev(A), packed(A, Mp, K), pack_frag32(torch.from_numpy(W)).to(G.DEV)
+        Wpad = W if Np == N else np.concatenate([W, np.zeros((Np - N, K), f32)], 0)
+        A_d, Ap, Wp = G.dev(A), packed(A, Mp, K), pack_frag32(torch.from_numpy(Wpad)).to(G.DEV)
         nw_d = None if nw is None else G.dev(nw)
         Cc = torch.full((M, N), float("nan"), dtype=torch.float32, device=G.DEV)
         Cp = torch.full((Mp * N,), float("nan"), dtype=torch.float32, device=G.DEV)
         res_d = None if res is None else G.dev(res)
-        _lib.check(lib.ctts_k_gemm_dec32(Ap.data_ptr(), Wp.data_ptr(), M, N, K, _lib.ptr(na_d), A_d.data_ptr() if rms else None, K,
+        _lib.check(lib.ctts_k_gemm_dec32(Ap.data_ptr(), Wp.data_ptr(), M, Np, K, _lib.ptr(na_d), A_d.data_ptr() if rms else None, K,
                                          _lib.ptr(nw_d), 1e-6, epi, Cc.data_ptr(), N, _lib.ptr(res_d), N, Cp.data_ptr() if epi else None,
-                                         N // 16, force_mb, None), "dec32")
+                                         N // 16, force_mb, N, None), "dec32")
         torch.cuda.synchronize()
-        got_c, got_p = Cc.cpu().numpy(), unpack_frag32(Cp.cpu(), Mp, N).numpy()
+        # the variants are bit-identical, so a dispatch regression would be invisible below: pin the intended choices
+        variant = lib.ctts_k_dec32_last_variant().decode()
+        assert variant == ("generic" if force_mb in (2, 4) else "rms16" if rms else "m16"), (N, K, epi, force_mb, variant)
+        got_c = Cc.cpu().numpy()
+        got_p = unpack_frag32(Cp.cpu(), Mp, N).numpy() if epi != 0 else None
         if epi != 2:
             assert np.array_equal(got_c[:live], want), (N, K, epi)
             assert np.isnan(got_c[live:]).all()                       # rows beyond the live count are not written
