@@ -281,6 +281,7 @@ __global__ __launch_bounds__(256) void gemm_dec32_m16_k(Dec32Args a) {
   struct Stage { u128 w[NACC][U]; u128 a[U]; };
 
   const int tile = blockIdx.x, mt0 = blockIdx.y;
+  if (tile >= (a.N >> 4)) return;   // the grid's x extent is rounded up to a multiple of 8 (see dec32_dispatch_m16)
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int li = lane & 15, g = lane >> 4;
   const int n0 = tile * 16, m0 = mt0 * 16;
@@ -495,7 +496,10 @@ __global__ __launch_bounds__(256, 3) void gemm_dec32_rms16_k(Dec32Args a) {
 
 template <int KT>
 static hipError_t dec32_dispatch_m16(const Dec32Args& a, hipStream_t st) {
-  dim3 grid(a.N / 16, (a.M + 15) / 16), block(256);
+  // x extent a multiple of 8: workgroup (tile, row tile) then runs on XCD tile % 8 for EVERY row tile, so a weight tile is fetched
+  // from HBM once (into that XCD's L2) and not once per row tile.  Only the heads need it (157 tiles: PMC showed 32.9 MB per
+  // launch against 8.2 MB of weights); 48 / 144 / 192 tiles are multiples of 8 already.
+  dim3 grid((a.N / 16 + 7) / 8 * 8, (a.M + 15) / 16), block(256);
   if (a.norm_w != nullptr) return hipErrorInvalidValue;
   if (a.epi == EPI_STORE) CTTS_LAUNCH((gemm_dec32_m16_k<KT, EPI_STORE>), grid, block, st, a);
   else if (a.epi == EPI_RES) CTTS_LAUNCH((gemm_dec32_m16_k<KT, EPI_RES>), grid, block, st, a);
