@@ -21,8 +21,13 @@
 // norm_w[k] * (x * rstd) with rstd from common.hpp wave_row_rstd (shared with gemm_skinny_k); the epilogues are res + acc and
 // silu(gate) * up.  tests/test_gpu_kernels.py::test_gemm_dec32_bit_identical holds the two kernels to exact equality.
 //
-// Producers write the packed activations: embed_codes_k (StepPrep.xp32), attention_k<float> (packed output), and the RES /
-// SILU_MUL epilogues below.  Weights are packed once at load (engine.py pack_frag32).
+// Producers write the packed activations: embed_codes_k (StepPrep.xp32), attention_k<float> (packed output), final_norm_k (the
+// heads' operand) and the RES / SILU_MUL epilogues below.  Weights are packed once at load (engine.py pack_frag32).
+//
+// Three kernels, one arithmetic (launch_gemm_dec32 picks; ctts_k_dec32_last_variant tells which):
+//   gemm_dec32_rms16_k  RMSNorm launches (QKV + RoPE + KV append, gate/up), 16-row workgroups, statistics from the fragments
+//   gemm_dec32_m16_k    o_proj, down_proj, the heads: 16-row workgroups, every load up front / double-buffered stages
+//   gemm_dec32_k        the general body (1, 2 or 4 row tiles per workgroup, statistics from the row-major rows): A/B knobs, tests
 #include <stdlib.h>
 
 #include "common.hpp"
