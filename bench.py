@@ -80,6 +80,102 @@ def decode_step_bytes(es: int, valid_prompt: np.ndarray, stop: np.ndarray, n_ste
     return wbytes + kv_m + live_m * (2 * GPT.n_layers * 768 * es + 4 * 626 * 4 * 2)
 
 
+MFMA_BF16_PEAK_TFS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (the 5 PF figure includes 2:1 sparsity)
+
+
+def teacher_from_golden(gold, max_new: int):
+    """[B, max_new, 4] teacher stream of the bench workload from the reference's own run (tests/golden/bench_c3.npz): the golden
+    rows, then the EOS step itself (gpt.py:512-518), so a teacher-forced row finishes exactly where the reference's did."""
+    lens = gold["lens"].astype(np.int64)
+    off = np.concatenate([[0], np.cumsum(lens)])
+    rows = [gold["ids"][off[b]: off[b + 1]].astype(np.int64) for b in range(len(lens))]
+    teacher = np.zeros((len(lens), max_new, 4), np.int64)
+    for b, r in enumerate(rows):
+        teacher[b, : len(r)] = r
+        if len(r) < max_new:
+            teacher[b, len(r)] = GPT.n_audio - 1
+    return lens, rows, teacher
+
+
+def parity_metrics(hid_a, hid_ref, samp_a, rows, heads: np.ndarray) -> dict:
+    """Teacher-forced distance of one numeric mode (a) from the pinned one (ref) over EVERY step of every row: relative hidden
+    error, |delta logit| through the folded heads (float32 matmul of the DIFFERENCE), first- vs last-quarter growth, and the
+    token agreement rate -- the fraction of (row, step, codebook) at which mode a's own sample under the same Exp(1) draw is the
+    reference's token."""
+    worst_h, worst_l, first_q, last_q, agree, total, rows_all = 0.0, 0.0, [], [], 0, 0, 0
+    sum_h, n_h = 0.0, 0
+    for b, want_ids in enumerate(rows):
+        a = hid_a[b].astype(np.float32)
+        r = hid_ref[b].astype(np.float32)
+        n = len(want_ids)
+        assert a.shape == r.shape == (n, GPT.hidden), (a.shape, r.shape, n)
+        d = a - r
+        rel = np.abs(d).max(1) / np.abs(r).max(1)
+        dl = np.abs(d @ heads.T).max(1)
+        worst_h, worst_l = max(worst_h, float(rel.max())), max(worst_l, float(dl.max()))
+        sum_h += float(rel.sum()); n_h += n
+        q = max(1, n // 4)
+        first_q.append(float(rel[:q].mean())); last_q.append(float(rel[-q:].mean()))
+        eq = (samp_a[b] == want_ids)
+        agree += int(eq.sum()); total += eq.size
+        rows_all += int(eq.all(1).sum())
+    return {"worst_rel_hidden_err": round(worst_h, 6), "mean_rel_hidden_err": round(sum_h / max(1, n_h), 6),
+            "worst_abs_dlogit": round(worst_l, 5),
+            "rel_hidden_err_first_quarter": round(float(np.mean(first_q)), 6), "rel_hidden_err_last_quarter": round(float(np.mean(last_q)), 6),
+            "token_agreement": round(agree / max(1, total), 6), "tokens_compared": total,
+            "token_rows_all4_agree": round(rows_all / max(1, total // 4), 6)}
+
+
+def mfma_rooflines(dev) -> dict:
+    """SURVEY 8d's MFMA-side entries, measured here with HIP events on the launch stream: the acoustic decoder's dominant GEMM
+    (ConvNeXt pwconv1, `gemm_x3p_k`, at the C3 batch's 65,536 frames) and the prefill's gate/up GEMM (`gemm_prefill_k`, the C3
+    batch's 64 x 48 prompt rows), as algorithmic flops / (time x 2.5 PFLOP/s dense bf16)."""
+    from chattts_amd import _lib
+    from chattts_amd.engine import pack_x3p
+    lib = _lib.lib()
+    st = torch.cuda.current_stream(dev).cuda_stream
+
+    def timed(fn, n=10):
+        fn(); fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        return e0.elapsed_time(e1) / n * 1e-3
+
+    out = {}
+    g = torch.Generator().manual_seed(7)
+    M, N, K = 65536, 2048, 512
+    A, Wt = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / K ** 0.5
+    Ap, Wp = pack_x3p(A).to(dev), pack_x3p(Wt).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    Cp = torch.empty(M * N * 2, dtype=torch.bfloat16, device=dev)
+    t = timed(lambda: _lib.check(lib.ctts_k_gemm_x3p(Ap.data_ptr(), Wp.data_ptr(), M, N, K, 0, bias.data_ptr(), None, None, None, Cp.data_ptr(), st), "x3p"))
+    fl = 2.0 * M * N * K
+    out["codec_pwconv1_gemm_x3p"] = {
+        "kernel": "gemm_x3p_k<GELU_PACKED> (csrc/codec_gemm.hip)", "bound": "mfma", "M": M, "N": N, "K": K, "avg_launch_us": round(t * 1e6, 1),
+        "alg_flops_per_launch": fl, "achieved": round(fl / t / 1e12, 1), "peak": MFMA_BF16_PEAK_TFS, "unit": "TFLOP/s",
+        "frac": round(fl / t / 1e12 / MFMA_BF16_PEAK_TFS, 4),
+        "mfma_work_frac": round(3 * fl / t / 1e12 / MFMA_BF16_PEAK_TFS, 4),
+        "note": "split-bf16: every f32 product is 3 bf16 MFMAs (hi*hi + hi*lo + lo*hi); `frac` prices the ALGORITHMIC 2MNK flops against "
+                "the dense bf16 peak, `mfma_work_frac` the bf16 MFMA work actually issued"}
+    del Ap, Wp, Cp
+    M, N, K = 64 * 48, 3072, 768
+    Ab = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
+    Wb = (torch.randn(2 * N, K, generator=g) * 0.02).to(torch.bfloat16).to(dev)
+    ssq = torch.full((M, 48), 16.0, dtype=torch.float32, device=dev)
+    Cb = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+    t = timed(lambda: _lib.check(lib.ctts_k_gemm_fast(Ab.data_ptr(), K, Wb.data_ptr(), M, N, K, ssq.data_ptr(), 1e-6, 2, None, 0, Cb.data_ptr(), N, None, st), "gemm_fast"))
+    fl = 2.0 * M * (2 * N) * K
+    out["prefill_gate_up_gemm"] = {
+        "kernel": "gemm_prefill_k<SILU> (csrc/prefill.hip)", "bound": "mfma", "M": M, "N": 2 * N, "K": K, "avg_launch_us": round(t * 1e6, 1),
+        "alg_flops_per_launch": fl, "achieved": round(fl / t / 1e12, 1), "peak": MFMA_BF16_PEAK_TFS, "unit": "TFLOP/s",
+        "frac": round(fl / t / 1e12 / MFMA_BF16_PEAK_TFS, 4)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -94,6 +190,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-ttfs", action="store_true")
     ap.add_argument("--no-parity-mode", action="store_true")
+    ap.add_argument("--no-bf16-parity", action="store_true")
+    ap.add_argument("--parity-steps", type=int, default=5, help="timed passes of the f32 parity mode")
     ap.add_argument("--lanes", type=int, default=1, help="concurrent decode lanes (HIP streams) the batch is cut into")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) run the CPU baseline leg alone and print its JSON")
     args = ap.parse_args()
@@ -120,10 +218,23 @@ def main():
     from chattts_amd import dist as D
     from chattts_amd import engine as E
 
+    def note(msg):
+        if rank == 0:
+            print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
     # ---- weights: rank 0 builds the synthetic checkpoint, everyone else receives it over RCCL ----
+    bcast = None
     if dist is not None:
         sds = W.synthetic_all() if rank == 0 else None
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        t0 = time.perf_counter()
         sds = D.broadcast_state_dicts(sds, src=0, device=dev, meta=D.weights_meta(GPT.n_layers))
+        torch.cuda.synchronize(dev)
+        bcast = {"ms": round(1e3 * (time.perf_counter() - t0), 2),
+                 "bytes": int(sum(v.numel() * v.element_size() for sd in sds.values() for v in sd.values())),
+                 "what": "ONE RCCL broadcast of the checkpoint from rank 0 at load (flat per-dtype buffers, chattts_amd/dist.py); "
+                         "first use of the communicator, so ring set-up is inside the figure"}
         sds = {n: {k: v.cpu() for k, v in sd.items()} for n, sd in sds.items()}  # the engines repack from host tensors
     else:
         sds = W.synthetic_all()
@@ -141,20 +252,19 @@ def main():
     emb = gpt.embed_prompt(ids_t, tm_t)
     ids_d, mask_d = ids_t.to(dev), mask_t
 
-    def one_pass(eng, use_graph=True, profile_tag=None, decode_audio=True, profile_stride=1, keep_ids=False):
+    def one_pass(eng, use_graph=True, profile_tag=None, decode_audio=True, profile_stride=1, keep_ids=False, teacher=None, keep_hidden=False):
         """generate -> DVAE -> Vocos -> host numpy (the reference path's last op is `.cpu().numpy()`, core.py:508-510)"""
         out = None
         for out in eng.generate(emb, ids_d, temp, 625, mask_d, max_new, 0, (*procs, *warpers), return_hidden=True,
                                 manual_seed=42, use_graph=use_graph, stop_at=stop_t, row_offset=wl["row_offset"],
-                                total_rows=wl["total_rows"], profile_tag=profile_tag, profile_stride=profile_stride, lanes=args.lanes):
+                                total_rows=wl["total_rows"], profile_tag=profile_tag, profile_stride=profile_stride, lanes=args.lanes,
+                                teacher_ids=teacher, return_sampled=teacher is not None):
             pass
         lens = [int(t.shape[0]) for t in out.ids]
         wav = codec.to_host(codec.decode_to_wavs(out.hiddens)) if decode_audio else None   # what Chat.decode_to_wavs returns
+        if keep_hidden:
+            return lens, [h.cpu().numpy() for h in out.hiddens], [t.cpu().numpy() for t in out.ids]
         return lens, wav, ([t.cpu().numpy() for t in out.ids] if keep_ids else None)
-
-    def note(msg):
-        if rank == 0:
-            print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -162,25 +272,33 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    def timed(eng, steps, warmup):
+    rank_times = {}
+
+    def timed(eng, steps, warmup, tag=None):
         for _ in range(warmup):
             one_pass(eng, use_graph=not args.no_graph)
         barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
             lens, wav, _ = one_pass(eng, use_graph=not args.no_graph)
+        torch.cuda.synchronize(dev)
+        dt_own = time.perf_counter() - t0      # this rank's own time for its K passes (before waiting for the others)
         barrier()
         dt = time.perf_counter() - t0
         if dist is not None:
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
+            own = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+            dist.all_gather(own, torch.tensor([dt_own], dtype=torch.float64, device=dev))
+            if tag:
+                rank_times[tag] = [round(1e3 * float(x.item()) / steps, 3) for x in own]
         assert lens == wl["stop"].tolist(), "forced lengths not honoured"
         assert wav is not None and wav.dtype == np.float32 and bool(np.isfinite(wav).all())
         return dt
 
     note("timed passes (bf16)" if args.dtype == "bf16" else "timed passes")
-    dt = timed(gpt, args.steps, args.warmup)
+    dt = timed(gpt, args.steps, args.warmup, tag="main")
     total_audio = audio_seconds(stop) * args.steps  # all ranks, all steps
     value = total_audio / dt
     gpt_steps = gpt.last_stats.get("steps", 0)
@@ -196,56 +314,40 @@ def main():
                    "global_batch": Bg, "decode_steps_per_pass": gpt_steps, "parallelism": f"dp{world}", "lanes_per_gpu": args.lanes,
                    "tokens_per_pass": int(stop.sum()), "audio_s_per_pass": round(audio_seconds(stop), 2)},
     }
+    if world > 1:   # self-diagnosing multi-GPU line: who was slow, what the one collective cost
+        rt = rank_times.get("main", [])
+        result["ranks"] = {"world": world, "pass_ms_per_rank": rt, "pass_ms_min": min(rt) if rt else None, "pass_ms_max": max(rt) if rt else None,
+                           "weight_broadcast": bcast,
+                           "data_path_collectives": "none (utterances are independent; only the timing barrier / max-over-ranks all-reduce)"}
 
-    # ---- the parity mode (f32: token ids bit-exact vs the reference) on the same workload, same invocation ----
-    if world == 1 and args.dtype == "bf16" and not args.no_parity_mode:
-        note("parity mode (f32)")
-        gpt32 = E.GptEngine(sds["gpt"], sds["embed"], dev, dtype="f32")
-        dt32 = timed(gpt32, 1, 1)
-        steps32, dec32_ms = gpt32.last_stats.get("steps", 0), gpt32.last_stats.get("decode_ms", 0.0)
-        _, _, rows = one_pass(gpt32, keep_ids=True, decode_audio=False)
-        got = ids_digest(rows)
-        want = None
-        gpath = os.path.join(ROOT, "tests", "golden", "bench_c3.npz")
-        if os.path.exists(gpath) and (args.batch, args.min_len, args.max_len) == (64, 128, 512):
-            want = str(np.load(gpath)["sha256"])
-        result["parity_mode"] = {"dtype": "f32", "value": round(audio_seconds(stop) / dt32, 2), "unit": "audio-s/s",
-                                 "ms_per_step": round(1000.0 * dt32, 3),
-                                 "decode_ms_per_gpt_step": round(dec32_ms / max(1, steps32), 4),
-                                 "kernels": "decode projections on fragment-packed f32 operands (csrc/decode32.hip), operation order of "
-                                            "the row-major f32 kernels kept bit for bit",
-                                 "ids_sha256": got, "golden_sha256": want,
-                                 "ids_match_reference": (got == want) if want else None,
-                                 "golden": "tests/golden/bench_c3.npz: the reference's GPT.generate on this workload (oracle/make_bench_golden.py)"}
-        del gpt32
-        torch.cuda.empty_cache()
+    es = 2 if args.dtype == "bf16" else 4
+    valid_prompt = wl["mask"].sum(1).astype(np.int64)
+    st_ = wl["stop"].astype(np.int64)
 
-    # ---- roofline: HIP start/stop events of sampled launches (hipExtLaunchKernel, on the launch stream), in an eager pass of the
-    #      SAME workload (every 5th launch of the tag over all decode steps); plus the whole decode step against the HBM roof ----
-    if rank == 0 and not args.no_roofline:
-        note("roofline leg (eager passes with per-launch events)")
+    def alg_bytes(es_, n_steps):
+        """SURVEY 8d per-launch algorithmic bytes of every kernel of the decode step, averaged over the decode steps of the pass.
+        Attention: KV read 2*768*s bytes per visible key per LIVE row per layer (+ q read / out write); at decode step i row b sees
+        valid_prompt[b] + i keys and is live while i <= stop[b] (after its EOS the engine drops it from the step -- the reference
+        would keep reading its KV, but no output depends on it).  Projections: the weight matrix once + the live rows' activations."""
+        ctx = [((valid_prompt + i) * (st_ >= i)).sum() for i in range(1, n_steps)]
+        live = float(np.mean([int((st_ >= i).sum()) for i in range(1, n_steps)]))
+        return {3: float(np.mean(ctx)) * 2 * 768 * es_ + live * 768 * (4 + es_),
+                1: 3 * 768 * 768 * es_ + live * (768 * es_ + 2304 * 4), 4: 768 * 768 * es_ + live * 768 * (es_ + 8 + es_),
+                5: 2 * 3072 * 768 * es_ + live * (768 + 3072) * es_, 6: 768 * 3072 * es_ + live * (3072 * es_ + 768 * (8 + es_)),
+                8: 2504 * 768 * 4 + live * (768 + 2504) * 4, 9: live * 4 * 626 * 8, 0: live * (4 * 3072 + 3072 + 1536), 7: live * 768 * 12}
+
+    def roofline_leg(eng, es_, tags, n_steps, step_ms, pmc_key_suffix=""):
+        """HIP start/stop events of sampled launches (hipExtLaunchKernel, on the launch stream; events created without the
+        system-scope fence, so the dispatch timestamps are the ones rocprofv3's kernel trace reads) in EAGER passes of the SAME
+        workload: every 5th launch of the tag over all decode steps."""
         per_tag = {}
-        for tag in (0, 1, 3, 4, 5, 6, 7, 8, 9):
+        for tag in tags:
             calls = GPT.n_layers if tag in (1, 3, 4, 5, 6) else 1
-            stride = 1 if calls == 1 else 5
-            one_pass(gpt, use_graph=False, profile_tag=tag, profile_stride=stride, decode_audio=False)
-            per_tag[tag] = gpt.last_stats.get("profile", (0, 0.0))
+            one_pass(eng, use_graph=False, profile_tag=tag, profile_stride=1 if calls == 1 else 5, decode_audio=False)
+            per_tag[tag] = eng.last_stats.get("profile", (0, 0.0))
         calls_per_step = {t: (GPT.n_layers if t in (1, 3, 4, 5, 6) else 1) for t in per_tag}
         avg_us = {t: 1e3 * per_tag[t][1] / max(1, per_tag[t][0]) for t in per_tag}
-        es = 2 if args.dtype == "bf16" else 4
-        B = hi - lo
-        valid_prompt = wl["mask"].sum(1).astype(np.int64)
-        st_ = wl["stop"].astype(np.int64)
-        # SURVEY 8d per-unit figures.  Attention: KV read 2*768*s bytes per visible key per LIVE row per layer (+ q read / out
-        # write); at decode step i row b sees valid_prompt[b] + i keys and is live while i <= stop[b] (after its EOS the engine
-        # drops it from the step -- the reference would keep reading its KV, but no output depends on it).  Projections: the
-        # weight matrix once + the activations of the live rows.
-        ctx = [((valid_prompt + i) * (st_ >= i)).sum() for i in range(1, gpt_steps)]
-        live = float(np.mean([int((st_ >= i).sum()) for i in range(1, gpt_steps)]))
-        alg = {3: float(np.mean(ctx)) * 2 * 768 * es + live * 768 * (4 + es),
-               1: 3 * 768 * 768 * es + live * (768 * es + 2304 * 4), 4: 768 * 768 * es + live * 768 * (es + 8 + es),
-               5: 2 * 3072 * 768 * es + live * (768 + 3072) * es, 6: 768 * 3072 * es + live * (3072 * es + 768 * (8 + es)),
-               8: 2504 * 768 * 4 + live * (768 + 2504) * 4, 9: live * 4 * 626 * 8, 0: live * (4 * 3072 + 3072 + 1536), 7: live * 768 * 12}
+        alg = alg_bytes(es_, n_steps)
         kernels = {TAGS[t]: {"avg_launch_us": round(avg_us[t], 2), "launches_per_step": calls_per_step[t],
                              "alg_bytes_per_launch": int(alg[t]),
                              "frac_of_hbm_peak": round(alg[t] / (avg_us[t] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if avg_us[t] > 0 else None}
@@ -257,26 +359,86 @@ def main():
         traffic, tsrc = None, None
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
-                traffic = json.load(fh).get(TAGS[dom], {}).get("hbm_bytes_per_launch")
+                traffic = json.load(fh).get(TAGS[dom] + pmc_key_suffix, {}).get("hbm_bytes_per_launch")
                 tsrc = "profiles/pmc_traffic.json: builder-collected rocprofv3 --pmc passes of this command, not measured in this run"
         except OSError:
             pass
-        result["roofline"] = {"kernel": TAGS[dom], "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
-                              "avg_launch_us": round(avg_us[dom], 2), "launches_timed": per_tag[dom][0],
-                              "alg_bytes_per_launch": int(alg[dom])}
-        step_bytes = decode_step_bytes(es, valid_prompt, st_, gpt_steps)
-        step_ms = decode_ms / max(1, gpt_steps - 1)
-        result["roofline"]["whole_decode_step"] = {
+        roof = {"kernel": TAGS[dom], "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
+                "avg_launch_us": round(avg_us[dom], 2), "launches_timed": per_tag[dom][0], "alg_bytes_per_launch": int(alg[dom]),
+                "clock": "HIP start/stop events of the dispatch (hipExtLaunchKernel, no system-scope fence), every 5th launch of the "
+                         "kernel over all decode steps of an eager pass of the workload; cross-check: profiles/ *_kernel_stats.csv "
+                         "(rocprofv3 --kernel-trace --stats of this command)"}
+        step_bytes = decode_step_bytes(es_, valid_prompt, st_, n_steps)
+        roof["whole_decode_step"] = {
             "alg_bytes_per_step": int(step_bytes), "ms_per_step": round(step_ms, 4),
             "achieved": round(step_bytes / (step_ms * 1e-3) / 1e9, 1) if step_ms > 0 else None,
             "frac": round(step_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if step_ms > 0 else None,
             "note": "weights + KV of live rows + logits/draws per step (SURVEY 8d) / host wall of the graph-replayed decode loop of the "
                     "last timed pass (finish polls included)"}
+        return roof, kernels
+
+    gold, gpath = None, os.path.join(ROOT, "tests", "golden", "bench_c3.npz")
+    if os.path.exists(gpath) and (args.batch, args.min_len, args.max_len) == (64, 128, 512) and world == 1:
+        gold = np.load(gpath)
+
+    # ---- the parity mode (f32: token ids bit-exact vs the reference) on the same workload, same invocation: timed like the main
+    #      leg, its own roofline entry, and the reference it gives the bf16 mode's distance measurement ----
+    hid32 = None
+    if world == 1 and args.dtype == "bf16" and not args.no_parity_mode:
+        note("parity mode (f32): %d timed passes" % args.parity_steps)
+        gpt32 = E.GptEngine(sds["gpt"], sds["embed"], dev, dtype="f32")
+        dt32 = timed(gpt32, args.parity_steps, 1)
+        steps32, dec32_ms = gpt32.last_stats.get("steps", 0), gpt32.last_stats.get("decode_ms", 0.0)
+        _, hid32, rows = one_pass(gpt32, keep_hidden=True, decode_audio=False)
+        got = ids_digest(rows)
+        want = str(gold["sha256"]) if gold is not None else None
+        result["parity_mode"] = {"dtype": "f32", "value": round(audio_seconds(stop) * args.parity_steps / dt32, 2), "unit": "audio-s/s",
+                                 "steps": args.parity_steps, "warmup": 1, "ms_per_step": round(1000.0 * dt32 / args.parity_steps, 3),
+                                 "decode_ms_per_gpt_step": round(dec32_ms / max(1, steps32 - 1), 4),
+                                 "kernels": "decode projections on fragment-packed f32 operands (csrc/decode32.hip), operation order of "
+                                            "the row-major f32 kernels kept bit for bit",
+                                 "ids_sha256": got, "golden_sha256": want,
+                                 "ids_match_reference": (got == want) if want else None,
+                                 "golden": "tests/golden/bench_c3.npz: the reference's GPT.generate on this workload (oracle/make_bench_golden.py)"}
+        if not args.no_roofline:
+            roof32, k32 = roofline_leg(gpt32, 4, (3,), steps32, dec32_ms / max(1, steps32 - 1), pmc_key_suffix="_f32")
+            result["parity_mode"]["roofline"] = roof32
+        del gpt32
+        torch.cuda.empty_cache()
+
+    # ---- bf16 (the mode `value` is quoted in) vs f32 (pinned to the reference), both TEACHER-FORCED on the reference's own token
+    #      stream of this workload: all 64 rows, all ~508 steps (gpt.py:497-508: free running, one flipped argmax diverges the suffix,
+    #      so agreement is measured per step under the reference's history) ----
+    if gold is not None and hid32 is not None and not args.no_bf16_parity:
+        note("bf16 parity leg (teacher-forced on the reference's token stream)")
+        lens_g, rows_g, teacher = teacher_from_golden(gold, max_new)
+        _, hid16, ids16 = one_pass(gpt, keep_hidden=True, decode_audio=False, teacher=torch.from_numpy(teacher))
+        assert all(np.array_equal(a, b) for a, b in zip(ids16, rows_g)), "the forced stream was not followed"
+        samp16 = [t.cpu().numpy() for t in gpt.last_sampled]
+        heads = generate_heads(sds["embed"])
+        pm = parity_metrics(hid16, hid32, samp16, rows_g, heads)
+        pm.update({"mode": "bf16 vs f32 engine, both on the reference's golden ids (tests/golden/bench_c3.npz)",
+                   "rows": len(rows_g), "steps_max": int(lens_g.max()),
+                   "f32_is_the_reference_stream": result["parity_mode"]["ids_match_reference"],
+                   "what": "hidden = final-norm output of every step (the DVAE's input); dlogit = |(h16 - h32) @ heads^T| (logit std ~4); "
+                           "token_agreement = the bf16 sampler's own draw (same Exp(1) tensor, same history) == the reference's token"})
+        result["bf16_parity"] = pm
+        del hid16, samp16
+    hid32 = None
+
+    # ---- roofline: the dominant decode kernel + the whole decode step against the HBM roof; MFMA-side entries ----
+    if rank == 0 and not args.no_roofline:
+        note("roofline leg (eager passes with per-launch events)")
+        tags = (0, 1, 3, 4, 5, 6, 7, 8, 9) if world == 1 else (3,)   # N > 1: the other ranks wait for rank 0 here -- attention only
+        roof, kernels = roofline_leg(gpt, es, tags, gpt_steps, decode_ms / max(1, gpt_steps - 1))
+        result["roofline"] = roof
         result["decode_kernels"] = kernels
+        if world == 1:
+            result["roofline_mfma"] = mfma_rooflines(dev)
 
     # ---- time to first sample: stream=True with the reference's yield schedule (first audio after 3 x 24 tokens) ----
-    if rank == 0 and not args.no_ttfs:
+    if rank == 0 and world == 1 and not args.no_ttfs:
         note("time to first sample")
         from chattts_amd.core import Chat, InferCodeParams
         chat = Chat()
@@ -301,7 +463,15 @@ def main():
     if rank == 0:
         print(json.dumps(result), flush=True)
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
+
+
+def generate_heads(embed_sd) -> np.ndarray:
+    """[2504, 768] float32: the four weight-normed code heads folded (chattts_amd.weights.fold_weight_norm) -- measurement only"""
+    return np.concatenate([W.fold_weight_norm(embed_sd[f"head_code.{k}.parametrizations.weight.original0"].float(),
+                                              embed_sd[f"head_code.{k}.parametrizations.weight.original1"].float()).numpy()
+                           for k in range(GPT.n_vq)], 0).astype(np.float32)
 
 
 def cpu_baseline_guarded(args, limit_s: float = 150.0):

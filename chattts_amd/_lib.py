@@ -38,7 +38,7 @@ class GenState(C.Structure):
         ("min_new", C.c_int32), ("eos", C.c_int32), ("row_offset", C.c_int32),
         ("stop_at", P), ("workspace", P), ("workspace_bytes", C.c_size_t), ("row_map", P), ("n_active", P),
         ("cap", C.c_int32), ("hid_cap", C.c_int32), ("kv_batch", C.c_int32), ("q_batch", C.c_int32), ("prompt_len", P),
-        ("infer_text", C.c_int32), ("teacher_ids", P),
+        ("infer_text", C.c_int32), ("teacher_ids", P), ("sampled_ids", P), ("order", P),
     ]
 
 

@@ -103,8 +103,18 @@ class Chat:
             return False
         device = device or torch.device("cuda:0")
         root = custom_path if custom_path is not None else os.getcwd()
-        sds = state_dicts if state_dicts is not None else W.load_assets(root)
-        self.gpt = GptEngine(sds["gpt"], sds["embed"], device, dtype=dtype, logger=self.logger)
+        try:
+            sds = state_dicts if state_dicts is not None else W.load_assets(root)
+        except W.AssetError as e:
+            self.logger.error("%s", e)
+            return False
+        try:
+            for name in W.ASSET_FILES:      # key set / shapes / dtypes against SURVEY App. B: a diff, not a KeyError in the repacking
+                W.validate_state_dict(name, sds[name])
+        except (W.AssetError, KeyError) as e:   # the reference's load logs and returns False (core.py:131-135,384)
+            self.logger.error("%s", e)
+            return False
+        self.gpt = GptEngine(sds["gpt"], sds["embed"], device, dtype=dtype, logger=self.logger, **sds.get("gpt_config", {}))
         self.codec = CodecEngine(sds["decoder"], sds["vocos"], device)
         self.dvae = DvaeEngine(sds["dvae"], device) if "dvae" in sds else None
         self.device = device

@@ -173,17 +173,20 @@ static SampleArgs make_sample_args(const ctts_gen_state* s, const float* logits)
   a.top_p_thr = s->top_p_thr; a.use_top_p = s->use_top_p; a.top_k = s->top_k; a.use_top_k = s->use_top_k;
   a.min_new = s->min_new; a.eos = s->eos; a.row_offset = s->row_offset; a.max_input_ids = NAUDIO - 1; a.stop_at = s->stop_at;
   a.B = s->B; a.row_map = nullptr; a.n_active = nullptr; a.prompt_len = s->prompt_len; a.q_rows = s->q_batch ? s->q_batch : s->B;
-  a.teacher = s->teacher_ids; a.teacher_stride = s->hid_cap ? s->hid_cap : s->max_new;
+  a.teacher = s->teacher_ids; a.teacher_stride = s->hid_cap ? s->hid_cap : s->max_new; a.sampled = s->sampled_ids;
   return a;
 }
 
-static int check_state(const ctts_gpt* g, const ctts_gen_state* s) {
+// ws_T: prompt slots the workspace must hold for THIS call (a prompt chunk needs ctts_gpt_workspace_bytes(B, tc) only; the decode
+// step carves for one row per utterance but keeps the prefill's carve layout, so it is checked against the geometry the caller
+// allocated for: s->T unless `decode_ws_T` says otherwise)
+static int check_state(const ctts_gpt* g, const ctts_gen_state* s, int ws_T = 0) {
   if (!g || !s) return fail("null engine/state");
   if (s->B <= 0 || s->T <= 0 || s->max_new <= 0) return fail("bad B/T/max_new");
   const int cap_ = s->cap ? s->cap : s->T + s->max_new;
   if (cap_ > g->w.max_pos) return fail("slot capacity T + max_new (%d) exceeds the RoPE table (%d)", cap_, g->w.max_pos);
   if (s->cap && s->T + 1 > s->cap) return fail("prompt does not fit the slot capacity");
-  if (s->workspace_bytes < ctts_gpt_workspace_bytes(s->B, s->T)) return fail("workspace too small");
+  if (s->workspace_bytes < ctts_gpt_workspace_bytes(s->B, ws_T > 0 ? ws_T : s->T)) return fail("workspace too small");
   if (s->nq <= 0 || !s->q) return fail("q draws missing");
   if (g->w.weight_dtype == CTTS_BF16 && g->w.kv_dtype != CTTS_BF16) return fail("perf mode needs a bf16 KV cache");
   if (s->infer_text) {
@@ -212,7 +215,10 @@ static int run_step(ctts_gpt* g, const ctts_gen_state* s, int q_per_b, hipStream
   // decode: compact row -> slot (see GptRowMap) -- the host's map, or the one the step's first kernel derives from the finish
   // flags (device-side compaction); prefill: row group -> slot of a pool (or null)
   const int32_t* rmap = (dec && dev_compact(g, s)) ? ws.row_map : s->row_map;
-  const int32_t* nact = dec ? s->n_active : nullptr;
+  // CTTS_SKIP_FINISHED=0 with a caller that left the compaction to the device (row_map == NULL): nobody writes *n_active then,
+  // so it must not be read -- every row steps, like the reference (gpt.py:512-518,592)
+  const bool no_compact = dec && !g->skip_finished && s->row_map == nullptr;
+  const int32_t* nact = (dec && !no_compact) ? s->n_active : nullptr;
   GptRowMap rm{q_per_b, s->len, s->kv_start, rmap, nact, (dec && g->skip_finished) ? s->finish : nullptr, nullptr, nullptr, nullptr, 0, slot0, 0};
   const bool fast = wt == CTTS_BF16;  // perf mode: bf16 activations, RMSNorm gain folded into wqkv / wgu by the loader
   const bool packed = fast && dec && g->dec_packed;   // decode step on fragment-packed operands (decode.hip)
@@ -361,12 +367,16 @@ extern "C" int ctts_gpt_prefill(ctts_gpt* g, const ctts_gen_state* s, const floa
   CK(hipMemsetAsync(ws.att_cnt, 0, (size_t)ATT_CUS_MAX * sizeof(int32_t), st));   // arrival counters of the attention split
   CK(hipMemcpyAsync(ws.x, emb, (size_t)s->B * s->T * HID * 4, hipMemcpyDeviceToDevice, st));
   if (g->w.weight_dtype == CTTS_BF16) CK(launch_rows_prep(ws.x, ws.xb, ws.ssq, s->B * s->T, st));
-  return run_step(g, s, s->T, st, false);
+  if (run_step(g, s, s->T, st, false)) return -1;
+  // arrival counters of the attention split at the place the DECODE steps carve them (one row per utterance), once the
+  // prompt-sized buffers above are dead
+  CK(hipMemsetAsync(carve(s->workspace, s->B, 1).att_cnt, 0, (size_t)ATT_CUS_MAX * sizeof(int32_t), st));
+  return 0;
 }
 
 extern "C" int ctts_gpt_prefill_chunk(ctts_gpt* g, const ctts_gen_state* s, const float* emb_chunk, int32_t t0, int32_t tc, int32_t last,
                                       void* stream) {
-  if (check_state(g, s)) return -1;
+  if (check_state(g, s, tc > 0 ? tc : 1)) return -1;
   if (t0 < 0 || tc <= 0 || t0 + tc > s->T || (last && t0 + tc != s->T)) return fail("ctts_gpt_prefill_chunk: bad chunk [%d, %d) of a %d-slot prompt", t0, t0 + tc, s->T);
   if (s->workspace_bytes < ctts_gpt_workspace_bytes(s->B, tc)) return fail("workspace too small for the chunk");
   CttsDeviceGuard dg(stream);
@@ -375,45 +385,49 @@ extern "C" int ctts_gpt_prefill_chunk(ctts_gpt* g, const ctts_gen_state* s, cons
   CK(hipMemcpyAsync(ws.x, emb_chunk, (size_t)s->B * tc * HID * 4, hipMemcpyDeviceToDevice, st));
   if (g->w.weight_dtype == CTTS_BF16) CK(launch_rows_prep(ws.x, ws.xb, ws.ssq, s->B * tc, st));
   if (run_step(g, s, tc, st, false, t0, last != 0, tc)) return -1;
-  // the decode steps carve the workspace for the whole prompt length: zero THEIR attention-split arrival counters once the
+  // the decode steps carve the workspace for one row per utterance: zero THEIR attention-split arrival counters once the
   // chunk-sized buffers above are dead
-  if (last) CK(hipMemsetAsync(carve(s->workspace, s->B, s->T).att_cnt, 0, (size_t)ATT_CUS_MAX * sizeof(int32_t), st));
+  if (last) CK(hipMemsetAsync(carve(s->workspace, s->B, 1).att_cnt, 0, (size_t)ATT_CUS_MAX * sizeof(int32_t), st));
   return 0;
 }
 
+// The decode step carves the workspace for ONE row per utterance (ctts_gpt_workspace_bytes(B, 1)) whatever the prompt length was: a
+// caller that prefills in chunks of tc slots needs max(bytes(B, tc), bytes(B, 1)), not bytes(B, T).  Nothing in the workspace
+// survives from the prefill into the decode steps (all generation state lives in ctts_gen_state's own arrays).
 static int decode_body(ctts_gpt* g, const ctts_gen_state* s, hipStream_t st, bool prof_ok) {
-  const GptWs ws = carve(s->workspace, s->B, s->T);
+  const GptWs ws = carve(s->workspace, s->B, 1);
   { Prof p(g, 0, st, prof_ok); const bool fast = g->w.weight_dtype == CTTS_BF16;
     const bool packed = fast && g->dec_packed;
     const bool dc = dev_compact(g, s);
     StepPrep sp{ws.desc, s->kv_start, g->skip_finished ? s->finish : nullptr, packed ? 1 : 0, (!fast && g->dec_packed32) ? ws.xp32 : nullptr,
                 dc ? ws.row_map : nullptr,
-                dc ? const_cast<int32_t*>(s->n_active) : nullptr};
+                dc ? const_cast<int32_t*>(s->n_active) : nullptr, dc ? s->order : nullptr};
+    const int32_t* nact0 = (!g->skip_finished && s->row_map == nullptr) ? nullptr : s->n_active;
     uint16_t* xb = fast ? (packed ? ws.xp : ws.xb) : nullptr;
     if (s->infer_text)
       CK(launch_embed_text(g->w.emb_text, g->w.n_text, s->ids_buf, s->cap ? s->cap : s->T + s->max_new, s->len, ws.x, xb,
-                           fast ? ws.ssq : nullptr, s->B, s->row_map, s->n_active, st, &sp));
+                           fast ? ws.ssq : nullptr, s->B, s->row_map, nact0, st, &sp));
     else
       CK(launch_embed_codes(g->w.emb_code, s->ids_buf, s->cap ? s->cap : s->T + s->max_new, s->len, ws.x, xb, fast ? ws.ssq : nullptr, s->B,
-                            s->row_map, s->n_active, st, &sp)); }
-  return run_step(g, s, 1, st, prof_ok);
+                            s->row_map, nact0, st, &sp)); }
+  return run_step(g, s, 1, st, prof_ok, 0, true, 1);
 }
 
 extern "C" int ctts_gpt_decode_step(ctts_gpt* g, const ctts_gen_state* s, void* stream) {
-  if (check_state(g, s)) return -1;
+  if (check_state(g, s, 1)) return -1;
   CttsDeviceGuard dg(stream);
   return decode_body(g, s, (hipStream_t)stream, true);
 }
 
 extern "C" int ctts_gpt_graph_build(ctts_gpt* g, const ctts_gen_state* s, void* stream) {
-  if (check_state(g, s)) return -1;
+  if (check_state(g, s, 1)) return -1;
   CttsDeviceGuard dg(stream);
   ctts_gpt_graph_destroy(g);
   hipStream_t st = (hipStream_t)stream;
   if (st == nullptr) return fail("graph capture needs a non-default stream");
   {  // the decode workspace may never have seen a prefill (slot pools prefill into their own): zero the arrival counters of the
      // attention split once, stream-ordered before anything the graph will run
-    const GptWs ws = carve(s->workspace, s->B, s->T);
+    const GptWs ws = carve(s->workspace, s->B, 1);
     CK(hipMemsetAsync(ws.att_cnt, 0, (size_t)ATT_CUS_MAX * sizeof(int32_t), st));
   }
   CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
@@ -438,8 +452,13 @@ extern "C" int ctts_gpt_profile_begin(ctts_gpt* g, int32_t tag, int32_t max_samp
   if (!g || max_samples <= 0 || stride <= 0) return fail("bad profile args");
   while ((int)g->ev0.size() < max_samples) {
     hipEvent_t a, b;
-    CK(hipEventCreate(&a));
-    CK(hipEventCreate(&b));
+    // hipEventDisableSystemFence: a default event makes the dispatch that signals it end with a system-scope release (L2
+    // write-back towards the host) -- time that rocprofv3's own completion signals do not add to a kernel
+    static int sysfence = -1;
+    if (sysfence < 0) { const char* e = getenv("CTTS_PROF_SYSFENCE"); sysfence = (e && atoi(e) == 1) ? 1 : 0; }
+    const unsigned fl = sysfence ? hipEventDefault : hipEventDisableSystemFence;
+    CK(hipEventCreateWithFlags(&a, fl));
+    CK(hipEventCreateWithFlags(&b, fl));
     g->ev0.push_back(a);
     g->ev1.push_back(b);
   }

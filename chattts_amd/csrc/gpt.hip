@@ -56,19 +56,23 @@ __device__ __forceinline__ void write_desc(const StepPrep& sp, int m, int b, int
 }
 // Device-side compaction: which utterance is compact row m, and how many rows are live.  Every wave of the workgroup
 // evaluates this itself (the finish bytes are one load for B <= 64; no barrier).  Returns -1 when row m does not exist.
-__device__ __forceinline__ int nth_unfinished(const uint8_t* __restrict__ finish, int B, int m, int& total) {
+// `order` (optional): the utterances are visited in that order instead of ascending slot (host: descending context, so that the
+// attention grid's first workgroups are its longest units); the return value is the utterance SLOT either way.
+__device__ __forceinline__ int nth_unfinished(const uint8_t* __restrict__ finish, const int32_t* __restrict__ order, int B, int m,
+                                              int& total) {
   const int lane = threadIdx.x & 63;
   int cnt = 0, found = -1;
   for (int base = 0; base < B; base += 64) {
     const int idx = base + lane;
-    const bool alive = idx < B && finish[idx] == 0;
+    const int slot = idx < B ? (order ? order[idx] : idx) : 0;
+    const bool alive = idx < B && finish[slot] == 0;
     const unsigned long long mask = __ballot(alive);
     const int c = __popcll(mask);
     if (found < 0 && m < cnt + c) {
       const int r = m - cnt;   // the r-th set bit of mask
       const bool mine = alive && __popcll(mask & ((1ull << lane) - 1ull)) == r;
       const unsigned long long pick = __ballot(mine);
-      found = base + (int)__ffsll((long long)pick) - 1;
+      found = __shfl(slot, (int)__ffsll((long long)pick) - 1, 64);
     }
     cnt += c;
   }
@@ -91,7 +95,7 @@ __global__ __launch_bounds__(192) void embed_codes_k(const float* __restrict__ e
   int b;
   if (sp.row_map_out != nullptr) {   // device-side compaction: this step's row order comes from the finish flags
     int total;
-    b = nth_unfinished(sp.finish, gridDim.x, m, total);
+    b = nth_unfinished(sp.finish, sp.order, gridDim.x, m, total);
     if (m == 0 && t == 0) *sp.n_active_out = total;
     if (b < 0) {   // row m does not exist this step: say so in its descriptor (the attention kernel reads nothing else)
       if (sp.desc != nullptr && t == 0) sp.desc[m] = RowDesc{-1, 0, 0, 0};
@@ -118,7 +122,7 @@ __global__ __launch_bounds__(192) void embed_codes_k(const float* __restrict__ e
 }
 
 static StepPrep prep_or_none(const StepPrep* p) {
-  StepPrep sp{nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr};
+  StepPrep sp{nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr};
   if (p) sp = *p;
   return sp;
 }
@@ -607,18 +611,30 @@ hipError_t launch_attention(const float* qkv, const void* kcache, const void* vc
   }
   static int nw8 = -1;  // CTTS_ATT_NW=8: 8 waves per (utterance, head) in decode (A/B knob)
   if (nw8 < 0) { const char* e = getenv("CTTS_ATT_NW"); nw8 = (e && atoi(e) == 8) ? 1 : 0; }
+  // CTTS_ATT_LDS=<bytes>: dynamic LDS the decode attention workgroups declare (and never touch).  It bounds the workgroups a CU
+  // holds at once (160 KiB / bytes), which turns the dispatcher into a greedy list scheduler: with the rows ordered by descending
+  // context (ctts_gen_state.order) the longest units start first and the short ones fill the CUs that free up.  0 = no bound.
+  static int att_lds = -1;
+  if (att_lds < 0) {
+    const char* e = getenv("CTTS_ATT_LDS");
+    att_lds = e ? atoi(e) : 0;
+    if (att_lds > 65536) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_k<bf16_t, 4, bf16_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, att_lds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_k<float, 4, float, true>), hipFuncAttributeMaxDynamicSharedMemorySize, att_lds);
+    }
+  }
   if (out_bf16 == 2) {   // decode, perf mode: bf16 output in the fragment-packed order the o_proj kernel of decode.hip reads
     if (!decode || kv_wt != WT_BF16) return hipErrorInvalidValue;
     if (rm.sp_cus > 0 && rm.sp_part != nullptr && rm.sp_cnt != nullptr)
       CTTS_LAUNCH((attention_k<bf16_t, 4, bf16_t, true, true>), dim3(NHEAD * M + rm.sp_cus), dim3(256), st, qkv, (const bf16_t*)kcache,
                   (const bf16_t*)vcache, cmax, (bf16_t*)out, rm);
     else
-      CTTS_LAUNCH((attention_k<bf16_t, 4, bf16_t, true>), grid, dim3(256), st, qkv, (const bf16_t*)kcache, (const bf16_t*)vcache, cmax, (bf16_t*)out, rm);
+      CTTS_LAUNCH_SMEM((attention_k<bf16_t, 4, bf16_t, true>), grid, dim3(256), att_lds, st, qkv, (const bf16_t*)kcache, (const bf16_t*)vcache, cmax, (bf16_t*)out, rm);
     return hipGetLastError();
   }
   if (out_bf16 == 3) {   // decode, f32 parity mode: f32 output in the fragment-packed order o_proj of decode32.hip reads
     if (!decode || kv_wt == WT_BF16) return hipErrorInvalidValue;
-    CTTS_LAUNCH((attention_k<float, 4, float, true>), grid, dim3(256), st, qkv, (const float*)kcache, (const float*)vcache, cmax, (float*)out, rm);
+    CTTS_LAUNCH_SMEM((attention_k<float, 4, float, true>), grid, dim3(256), att_lds, st, qkv, (const float*)kcache, (const float*)vcache, cmax, (float*)out, rm);
     return hipGetLastError();
   }
   if (decode && nw8 && kv_wt == WT_BF16 && out_bf16) {
@@ -833,6 +849,7 @@ __global__ __launch_bounds__(256) void sample_k(SampleArgs a) {
   float wv; int wi;
   wave_argmax(bv, bi, wv, wi);
   if (force_eos) wi = a.eos;
+  if (a.sampled != nullptr && gen < a.teacher_stride && lane == 0) a.sampled[((size_t)b * a.teacher_stride + gen) * NVQ + k] = (int64_t)wi;
   if (a.teacher != nullptr && gen < a.teacher_stride) wi = (int)a.teacher[((size_t)b * a.teacher_stride + gen) * NVQ + k];
   if (lane == 0) {
     a.ids_buf[((size_t)b * a.tcap + len) * NVQ + k] = (int64_t)wi;
@@ -868,7 +885,7 @@ __global__ __launch_bounds__(192) void embed_text_k(const float* __restrict__ em
   int b;
   if (sp.row_map_out != nullptr) {   // device-side compaction (see embed_codes_k)
     int total;
-    b = nth_unfinished(sp.finish, gridDim.x, m, total);
+    b = nth_unfinished(sp.finish, sp.order, gridDim.x, m, total);
     if (m == 0 && t == 0) *sp.n_active_out = total;
     if (b < 0) {   // row m does not exist this step: say so in its descriptor (the attention kernel reads nothing else)
       if (sp.desc != nullptr && t == 0) sp.desc[m] = RowDesc{-1, 0, 0, 0};

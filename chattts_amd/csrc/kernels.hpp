@@ -20,6 +20,17 @@ extern thread_local hipEvent_t ctts_prof_start, ctts_prof_stop;
     }                                                                                                             \
   } while (0)
 
+// the same with `smem` bytes of dynamic LDS (used only to bound how many workgroups a CU holds at once)
+#define CTTS_LAUNCH_SMEM(kern, grid, block, smem, st, ...)                                                        \
+  do {                                                                                                            \
+    if (ctts_prof_start) {                                                                                        \
+      hipExtLaunchKernelGGL(kern, grid, block, smem, st, ctts_prof_start, ctts_prof_stop, 0, __VA_ARGS__);        \
+      ctts_prof_start = nullptr; ctts_prof_stop = nullptr;                                                        \
+    } else {                                                                                                      \
+      hipLaunchKernelGGL(kern, grid, block, smem, st, __VA_ARGS__);                                               \
+    }                                                                                                             \
+  } while (0)
+
 enum { WT_F32 = 0, WT_BF16 = 1 };
 
 // ---- GEMM  C[M,N] = epi( pro(A)[M,K] * W[N,K]^T ) ------------------------------------------
@@ -196,6 +207,7 @@ struct StepPrep {
   // kernel of the step reads -- finished utterances leave the step at once, without the host
   int32_t* row_map_out;     // [B] or null
   int32_t* n_active_out;    // device scalar or null
+  const int32_t* order;     // [B] or null: visiting order of the compaction (permutation of the slots; host: descending context)
 };
 hipError_t launch_embed_codes(const float* emb_code /*[4,626,768]*/, const int64_t* ids_buf, int ids_row_stride /*Tcap*/,
                               const int32_t* len, float* x, uint16_t* xb /*null ok*/, float* ssq /*null ok*/, int B,
@@ -235,6 +247,7 @@ struct SampleArgs {
   int q_rows;               // utterance slots in q (>= B)
   const int64_t* teacher;   // [slots, teacher_stride, 4] or null: teacher forcing (evaluation hook)
   int teacher_stride;
+  int64_t* sampled;         // [slots, teacher_stride, 4] or null: the sampler's own draw of every step (before teacher forcing)
 };
 hipError_t launch_sample(const SampleArgs& a, hipStream_t st);
 // refine-text mode: logits [B, V], q [nq, B, V], temperature[0]; no repetition penalty (see gpt.hip)

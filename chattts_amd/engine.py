@@ -205,7 +205,10 @@ class GptEngine:
     POLL = 16      # decode steps enqueued between two looks at the device-side finish flags
 
     def __init__(self, gpt_sd: dict, embed_sd: dict, device: torch.device, dtype: str = "bf16",
-                 max_pos: int = GPT.max_pos, logger: logging.Logger = log):
+                 max_pos: int = GPT.max_pos, logger: logging.Logger = log, rms_eps: float = GPT.rms_eps,
+                 rope_theta: float = GPT.rope_theta):
+        """`rms_eps` / `rope_theta` / `max_pos`: the run-time fields of `asset/gpt/config.json` (weights.check_gpt_config;
+        `LlamaModel.from_pretrained`, gpt.py:75); everything else in that file is the geometry the kernels are compiled for."""
         if dtype not in ("bf16", "f32"):
             raise ValueError("dtype must be 'bf16' (perf) or 'f32' (parity)")
         self.lib = _lib.lib()
@@ -244,35 +247,40 @@ class GptEngine:
                                   for k in range(GPT.n_vq)], 0))
         self.head_text = f(fold_weight_norm(embed_sd["head_text.parametrizations.weight.original0"].float(),
                                             embed_sd["head_text.parametrizations.weight.original1"].float()))
-        cos, sin = rope_tables(max_pos)
+        cos, sin = rope_tables(max_pos, theta=rope_theta)
         self.rope_cos, self.rope_sin = cos.to(dev), sin.to(dev)
         self._arrs = [_lib.ptr_array(x) for x in (self.wqkv, self.wo, self.wgu, self.wd, self.ln1, self.ln2)]
         # a second copy of the four matrices in the fragment-packed order the DECODE kernels read (bf16: decode.hip, f32:
         # decode32.hip); the row-major copy stays for the prefill kernels (+0.38 GB / +0.75 GB of the 288 GB)
+        # (CTTS_DEC_PACKED=0, the A/B switch back to the row-major decode kernels, skips building them)
+        use_packed = os.environ.get("CTTS_DEC_PACKED", "1") != "0"
         pk = pack_frag if dtype == "bf16" else pack_frag32
-        self.packed = [[pk(t) for t in ws] for ws in (self.wqkv, self.wo, self.wgu, self.wd)]
-        if dtype != "bf16":
-            # the packed f32 QKV matrix carries the RoPE row permutation too (its decode kernel rotates in the epilogue); an output
-            # column's dot product does not depend on where the column sits, so the parity arithmetic is untouched
-            rp = rope_row_perm().to(dev)
-            qk_perm = torch.cat([rp, GPT.hidden + rp, 2 * GPT.hidden + torch.arange(GPT.hidden, device=dev)])
-            self.packed[0] = [pack_frag32(t[qk_perm]) for t in self.wqkv]
-        self._pk_arrs = None if self.packed is None else [_lib.ptr_array(x) for x in self.packed]
+        self.packed, self._pk_arrs = None, None
+        if use_packed:
+            self.packed = [[pk(t) for t in ws] for ws in (self.wqkv, self.wo, self.wgu, self.wd)]
+            if dtype != "bf16":
+                # the packed f32 QKV matrix carries the RoPE row permutation too (its decode kernel rotates in the epilogue); an
+                # output column's dot product does not depend on where the column sits, so the parity arithmetic is untouched
+                rp = rope_row_perm().to(dev)
+                qk_perm = torch.cat([rp, GPT.hidden + rp, 2 * GPT.hidden + torch.arange(GPT.hidden, device=dev)])
+                self.packed[0] = [pack_frag32(t[qk_perm]) for t in self.wqkv]
+            self._pk_arrs = [_lib.ptr_array(x) for x in self.packed]
 
         def pad16(t):      # zero rows up to a multiple of 16: the padded columns of the last logits tile are never stored
             r = (-t.shape[0]) % 16
             return t if r == 0 else torch.cat([t, torch.zeros((r, t.shape[1]), dtype=t.dtype, device=t.device)], 0)
-        self.heads_pk, self.head_text_pk = pack_frag32(pad16(self.heads)), pack_frag32(pad16(self.head_text))
+        self.heads_pk = pack_frag32(pad16(self.heads)) if use_packed else None
+        self.head_text_pk = pack_frag32(pad16(self.head_text)) if use_packed else None
         w = _lib.GptWeights()
         w.n_layers, w.weight_dtype, w.kv_dtype, w.max_pos = self.n_layers, self.code, self.code, max_pos
         w.wqkv, w.wo, w.wgu, w.wd, w.ln1, w.ln2 = [C.cast(a, _lib.PP) for a in self._arrs]
         w.norm, w.emb_code, w.heads = self.norm.data_ptr(), self.emb_code.data_ptr(), self.heads.data_ptr()
         w.rope_cos, w.rope_sin = self.rope_cos.data_ptr(), self.rope_sin.data_ptr()
-        w.rms_eps = GPT.rms_eps
+        w.rms_eps = float(rms_eps)
         w.emb_text, w.head_text, w.n_text = self.emb_text.data_ptr(), self.head_text.data_ptr(), GPT.n_text
         if self._pk_arrs is not None:
             w.wqkv_pk, w.wo_pk, w.wgu_pk, w.wd_pk = [C.cast(a, _lib.PP) for a in self._pk_arrs]
-        w.heads_pk, w.head_text_pk = self.heads_pk.data_ptr(), self.head_text_pk.data_ptr()
+        w.heads_pk, w.head_text_pk = _lib.ptr(self.heads_pk), _lib.ptr(self.head_text_pk)
         self._w = w
         h = C.c_void_p()
         _lib.check(self.lib.ctts_gpt_create(C.byref(h), C.byref(w)), "ctts_gpt_create")
@@ -327,7 +335,8 @@ class GptEngine:
                  *, use_graph: bool = True, stop_at: Optional[torch.Tensor] = None, row_offset: int = 0,
                  total_rows: Optional[int] = None, profile_tag: Optional[int] = None,
                  profile_stride: int = 1, lanes: Optional[int] = None,
-                 teacher_ids: Optional[torch.Tensor] = None, prefill_chunk: Optional[int] = None) -> Iterator[GenerationOutputs]:
+                 teacher_ids: Optional[torch.Tensor] = None, prefill_chunk: Optional[int] = None,
+                 return_sampled: bool = False) -> Iterator[GenerationOutputs]:
         """Drop-in for `GPT.generate` (gpt.py:316-337), code mode.  Extra keyword-only arguments:
         `use_graph` (hipGraph replay of the decode step), `stop_at` ([B] int32 forced output lengths,
         benchmark hook), `row_offset`/`total_rows` (this shard's position inside a data-parallel batch:
@@ -338,7 +347,10 @@ class GptEngine:
         ([B, max_new_token, 4] int64: teacher forcing -- the token written at step i is teacher_ids[:, i] instead of
         the sampled one; evaluation hook used to bound the bf16 mode's drift on the reference's token stream),
         `prefill_chunk` (tokens: the prompt is prefilled in pieces of that many slots -- `ctts_gpt_prefill_chunk` -- which
-        bounds the activation workspace of a long prompt such as an `spk_smp` audio-code prompt, core.py:435-453)."""
+        bounds the activation workspace of a long prompt such as an `spk_smp` audio-code prompt, core.py:435-453: the workspace is
+        then sized for a piece, not for the whole prompt), `return_sampled` (evaluation hook, the companion of `teacher_ids`: after
+        the call `self.last_sampled` holds, per utterance, the [T_b, 4] tokens the sampler itself drew at every step before teacher
+        forcing replaced them -- the teacher-forced token agreement of a numeric mode)."""
         if return_attn:
             raise NotImplementedError("return_attn is not supported by the fused attention kernel")
         context = context or Context()
@@ -391,7 +403,8 @@ class GptEngine:
         top_p_thr = float(np.float32(1.0 - plan.top_p)) if plan.top_p is not None else 0.0
         key = (tuple(bounds), T, max_new, nrow, V, nq, self.dtype, top_p_thr, plan.top_p is not None, int(plan.top_k or 0),
                plan.top_k is not None, int(min_new_token), int(eos_token), int(row_offset), bool(infer_text), stop_at is not None,
-               ptab is not None, teacher_ids is not None)
+               ptab is not None, teacher_ids is not None, bool(return_sampled),
+               None if prefill_chunk is None else int(prefill_chunk))
         sess = self._session if (self._session is not None and self._session["key"] == key) else None
         if sess is None:
             self._session = None     # drop the previous session's buffers before allocating new ones
@@ -405,19 +418,23 @@ class GptEngine:
                     ln.ids_buf = torch.empty((Bl, T + max_new, nvq), dtype=torch.int64, device=dev)  # gpt.py:372-379
                     ln.len_d = torch.empty((Bl,), dtype=torch.int32, device=dev)
                     ln.finish = torch.empty((Bl,), dtype=torch.uint8, device=dev)             # gpt.py:346
-                    ln.row_map = torch.empty((Bl,), dtype=torch.int32, device=dev)            # compact decode row -> batch slot
+                    ln.order = torch.empty((Bl,), dtype=torch.int32, device=dev)              # visiting order of the device-side compaction
                     ln.n_active = torch.empty((1,), dtype=torch.int32, device=dev)
                     ln.end_idx = torch.empty((Bl,), dtype=torch.int32, device=dev)            # gpt.py:343
                     ln.hiddens = torch.empty((Bl, max_new, GPT.hidden), dtype=torch.float32, device=dev)
                     kv_shape = (self.n_layers, Bl, GPT.n_heads, T + max_new, GPT.head_dim)
                     ln.kcache = torch.empty(kv_shape, dtype=self.wdt, device=dev)
                     ln.vcache = torch.empty(kv_shape, dtype=self.wdt, device=dev)
-                    ln.ws_bytes = lib.ctts_gpt_workspace_bytes(Bl, T)
+                    # the prefill carves for the rows it pushes through the layers at once (the whole prompt, or one chunk of it);
+                    # the decode steps for one row per utterance
+                    tc_ws = T if (prefill_chunk is None or int(prefill_chunk) >= T) else max(1, int(prefill_chunk))
+                    ln.ws_bytes = max(lib.ctts_gpt_workspace_bytes(Bl, tc_ws), lib.ctts_gpt_workspace_bytes(Bl, 1))
                     ln.workspace = torch.empty((ln.ws_bytes,), dtype=torch.uint8, device=dev)
                     ln.kv_start = torch.empty((Bl,), dtype=kv_start_all.dtype, device=dev)
                     ln.stop_d = None if stop_at is None else torch.empty((Bl,), dtype=torch.int32, device=dev)
                     ln.q_d = torch.empty((nq, Bl * nrow, V), dtype=torch.float32, device=dev)
                     ln.teacher = None if teacher_ids is None else torch.empty((Bl, max_new, nvq), dtype=torch.int64, device=dev)
+                    ln.sampled = torch.zeros((Bl, max_new, nvq), dtype=torch.int64, device=dev) if return_sampled else None
                 s = _lib.GenState()
                 s.B, s.T, s.max_new = Bl, T, max_new
                 s.ids_buf, s.len, s.kv_start = ln.ids_buf.data_ptr(), ln.len_d.data_ptr(), ln.kv_start.data_ptr()
@@ -434,6 +451,10 @@ class GptEngine:
                 s.infer_text = int(infer_text)
                 s.stop_at = _lib.ptr(ln.stop_d)
                 s.teacher_ids = _lib.ptr(ln.teacher)
+                s.sampled_ids = _lib.ptr(ln.sampled)
+                # compaction order: utterances by descending context = ascending left padding (contexts of a batch differ only by
+                # the static valid prompt length), so the attention grid starts its longest units first.  CTTS_ORDER=0: ascending slot
+                s.order = ln.order.data_ptr() if os.environ.get("CTTS_ORDER", "1") != "0" else None
                 s.workspace, s.workspace_bytes = ln.workspace.data_ptr(), ln.ws_bytes
                 # no row_map: the library compacts on the device -- the first kernel of every decode step ranks the utterances
                 # whose finish flag is 0 and writes n_active (include/chattts_amd.h), so finished utterances leave the step
@@ -447,7 +468,7 @@ class GptEngine:
         for ln in L:
             lo, hi = ln.lo, ln.hi
             Bl = hi - lo
-            ln.done, ln.end_snap, ln.n_act_host = False, None, Bl
+            ln.done, ln.end_snap = False, None
             with torch.cuda.stream(ln.st):
                 if sess.get("out_ev") is not None:
                     ln.st.wait_event(sess["out_ev"])   # the previous call's result copies have read these buffers
@@ -455,7 +476,7 @@ class GptEngine:
                 ln.ids_buf[:, :T] = ids_all[lo:hi]
                 ln.len_d.fill_(T)
                 ln.finish.zero_()
-                ln.row_map.copy_(torch.arange(Bl, dtype=torch.int32))
+                ln.order.copy_(torch.argsort(kv_start_all[lo:hi].to(torch.int64), stable=True).to(torch.int32))
                 ln.n_active.fill_(Bl)
                 ln.end_idx.zero_()
                 ln.kv_start.copy_(kv_start_all[lo:hi])
@@ -647,7 +668,8 @@ class GptEngine:
                                          min_new_token, logits_processors, infer_text, return_attn, return_hidden,
                                          stream, show_tqdm, ensure_non_empty, stream_batch, manual_seed, context,
                                          use_graph=use_graph, stop_at=stop_at, row_offset=row_offset, total_rows=total_rows,
-                                         lanes=lanes)
+                                         profile_tag=profile_tag, profile_stride=profile_stride, lanes=lanes,
+                                         teacher_ids=teacher_ids, prefill_chunk=prefill_chunk, return_sampled=return_sampled)
             return  # gpt.py:570: the seeded case yields nothing
 
         graph_ok = use_graph and max_new > 1
@@ -702,6 +724,16 @@ class GptEngine:
                 # yield boundary is still handed out.  Granularity here is one chunk (POLL / stream_batch steps), not one step.
                 if context.get():
                     interrupted = True
+                    # run-ahead: a chunk may already be enqueued behind the one just collected.  Its tokens WILL be in the buffers
+                    # the final outputs() reads, so it is collected and counted too -- tokens, `steps` and the rewound position of
+                    # the global CPU generator (unseeded mode) then describe the same number of steps.
+                    while inflight:
+                        n2, snaps2 = inflight.pop(0)
+                        for ln, k in zip(L, snaps2):
+                            if k is not None and not ln.done:
+                                collect(ln, k)
+                        steps_done += n2
+                    all_done = all(ln.done for ln in L)
                     break
             if profile_tag is not None:
                 n_s, tot = C.c_int32(0), C.c_double(0.0)
@@ -725,6 +757,8 @@ class GptEngine:
         # steps the reference loop would have executed: up to and including the step at which the last row hit EOS
         steps_ref = (max(max(ln.end_snap) for ln in L) + 1) if all_done else min(steps_done, max_new)
         finish_rng(min(steps_ref, max_new))
+        if return_sampled:
+            self.last_sampled = [ln.sampled[b, : ln.end_snap[b]].clone() for ln in L for b in range(ln.hi - ln.lo)]
         yield outputs()
 
 

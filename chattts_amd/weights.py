@@ -224,21 +224,156 @@ def save_assets(root: str, sds: Dict[str, StateDict]) -> None:
         save_file({k: v.contiguous() for k, v in sds[name].items()}, path)
 
 
-def load_assets(root: str) -> Dict[str, StateDict]:
-    """Mirror of `load_safetensors` (/root/reference/ChatTTS/utils/io.py:19-25) over the four hot-path files."""
+class AssetError(ValueError):
+    """a checkpoint file does not have the layout the engine repacks from; the message is a key / shape diff"""
+
+
+def _convnext_keys(prefix: str, dim: int, inter: int, gamma: str) -> Dict[str, tuple]:
+    return {prefix + gamma: (dim,), prefix + "dwconv.weight": (dim, 1, 7), prefix + "dwconv.bias": (dim,),
+            prefix + "norm.weight": (dim,), prefix + "norm.bias": (dim,),
+            prefix + "pwconv1.weight": (inter, dim), prefix + "pwconv1.bias": (inter,),
+            prefix + "pwconv2.weight": (dim, inter), prefix + "pwconv2.bias": (dim,)}
+
+
+def expected_schema(name: str, n_layers: int = GPT.n_layers) -> Dict[str, tuple]:
+    """key -> shape of the four hot-path checkpoints as the reference ships them: `gpt` = HF LlamaModel state
+    dict without `embed_tokens` (gpt.py:75-78), `embed` (embed.py:18-35), `decoder` (dvae.py:145-161,226,239), `vocos` (the
+    package's documented module tree: backbone.embed / norm / convnext.{i} / final_layer_norm, head.out, head.istft.window)."""
+    H, I = GPT.hidden, GPT.inter
+    if name == "gpt":
+        sch: Dict[str, tuple] = {"norm.weight": (H,)}
+        for i in range(n_layers):
+            p = f"layers.{i}."
+            for k in ("q_proj", "k_proj", "v_proj", "o_proj"):
+                sch[p + f"self_attn.{k}.weight"] = (H, H)
+            sch[p + "mlp.gate_proj.weight"] = (I, H)
+            sch[p + "mlp.up_proj.weight"] = (I, H)
+            sch[p + "mlp.down_proj.weight"] = (H, I)
+            sch[p + "input_layernorm.weight"] = (H,)
+            sch[p + "post_attention_layernorm.weight"] = (H,)
+        return sch
+    if name == "embed":
+        sch = {"emb_text.weight": (GPT.n_text, H), "head_text.parametrizations.weight.original0": (GPT.n_text, 1),
+               "head_text.parametrizations.weight.original1": (GPT.n_text, H)}
+        for k in range(GPT.n_vq):
+            sch[f"emb_code.{k}.weight"] = (GPT.n_audio, H)
+            sch[f"head_code.{k}.parametrizations.weight.original0"] = (GPT.n_audio, 1)
+            sch[f"head_code.{k}.parametrizations.weight.original1"] = (GPT.n_audio, H)
+        return sch
+    if name == "decoder":
+        D = DVAE
+        sch = {"coef": (1, D.n_mels, 1), "decoder.conv_in.0.weight": (D.bn_dim, D.idim, 3), "decoder.conv_in.0.bias": (D.bn_dim,),
+               "decoder.conv_in.2.weight": (D.hidden, D.bn_dim, 3), "decoder.conv_in.2.bias": (D.hidden,),
+               "decoder.conv_out.weight": (D.odim, D.hidden, 1), "out_conv.weight": (D.n_mels, D.odim, 3)}
+        for i in range(D.n_layers):
+            sch.update(_convnext_keys(f"decoder.decoder_block.{i}.", D.hidden, 4 * D.hidden, "weight"))
+        return sch
+    if name == "vocos":
+        V = VOCOS
+        sch = {"backbone.embed.weight": (V.dim, V.n_mels, 7), "backbone.embed.bias": (V.dim,), "backbone.norm.weight": (V.dim,),
+               "backbone.norm.bias": (V.dim,), "backbone.final_layer_norm.weight": (V.dim,), "backbone.final_layer_norm.bias": (V.dim,),
+               "head.out.weight": (V.n_fft + 2, V.dim), "head.out.bias": (V.n_fft + 2,), "head.istft.window": (V.n_fft,)}
+        for i in range(V.n_layers):
+            sch.update(_convnext_keys(f"backbone.convnext.{i}.", V.dim, V.inter, "gamma"))
+        return sch
+    raise KeyError(name)
+
+
+# keys a real checkpoint may carry that the hot path does not read (not an error, not listed as unexpected)
+IGNORED_PREFIXES = {"gpt": ("embed_tokens.", "rotary_emb.", "layers.0.self_attn.rotary_emb."), "embed": (), "decoder": (),
+                    "vocos": ("feature_extractor.",)}
+
+
+def validate_state_dict(name: str, sd: StateDict, where: str = "") -> None:
+    """Raises AssetError with a diff-style message (missing / unexpected keys, wrong shapes, non-float dtypes) if `sd` is not
+    the layout `expected_schema(name)` describes -- so that the first contact with a real asset is a readable message, not a
+    KeyError deep in the engine's repacking.  The GPT layer count is whatever the file holds (contiguous from 0)."""
+    n_layers = gpt_layer_count(sd) if name == "gpt" else GPT.n_layers
+    if name == "gpt" and n_layers == 0:
+        raise AssetError(f"{where or name}: no `layers.0.input_layernorm.weight` -- not a LlamaModel state dict "
+                         f"(first keys: {sorted(sd)[:5]})")
+    want = expected_schema(name, n_layers)
+    ign = IGNORED_PREFIXES.get(name, ())
+    missing = [k for k in want if k not in sd]
+    extra = [k for k in sd if k not in want and not any(k.startswith(p) or (".rotary_emb." in k) for p in ign + ("\0",))]
+    wrong = [f"{k}: file {tuple(sd[k].shape)} != expected {want[k]}" for k in want if k in sd and tuple(sd[k].shape) != tuple(want[k])]
+    bad_dt = [f"{k}: {sd[k].dtype}" for k in want if k in sd and not sd[k].dtype.is_floating_point]
+    if not (missing or extra or wrong or bad_dt):
+        return
+    lines = [f"{where or name}: checkpoint does not match the layout the engine repacks from (SURVEY App. B):"]
+    for title, items in (("missing", missing), ("unexpected", extra), ("wrong shape", wrong), ("not floating point", bad_dt)):
+        if items:
+            lines.append(f"  {title} ({len(items)}): " + "; ".join(items[:8]) + (" ..." if len(items) > 8 else ""))
+    raise AssetError("\n".join(lines))
+
+
+def load_gpt_config(root: str):
+    """`asset/gpt/config.json` (what `LlamaModel.from_pretrained` reads, gpt.py:75) as a dict, or None when the file is absent
+    (the in-tree statement of the same numbers is config.py:50-63)."""
+    import json
+    path = os.path.join(root, "gpt", "config.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as fh:
+        return json.load(fh)
+
+
+def check_gpt_config(cfg, n_layers_in_file: int = None) -> dict:
+    """The kernels are compiled for ONE Llama geometry (hidden 768, 12 heads of 64, intermediate 3072, SiLU, MHA, no biases,
+    default RoPE): anything else in config.json is an error here, with the offending fields named.  Returns the fields that ARE
+    run-time parameters of the engine: {"rms_eps", "rope_theta", "max_pos"}."""
+    out = {"rms_eps": GPT.rms_eps, "rope_theta": GPT.rope_theta, "max_pos": GPT.max_pos}
+    if not cfg:
+        return out
+    fixed = {"hidden_size": GPT.hidden, "intermediate_size": GPT.inter, "num_attention_heads": GPT.n_heads,
+             "num_key_value_heads": GPT.n_heads, "hidden_act": "silu", "attention_bias": False, "mlp_bias": False}
+    bad = [f"{k} = {cfg[k]!r} (kernels are built for {v!r})" for k, v in fixed.items() if k in cfg and cfg[k] is not None and cfg[k] != v]
+    if cfg.get("head_dim") not in (None, GPT.head_dim):
+        bad.append(f"head_dim = {cfg['head_dim']!r} (kernels are built for {GPT.head_dim})")
+    if cfg.get("rope_scaling") not in (None, {}) and (cfg["rope_scaling"] or {}).get("rope_type", "default") != "default":
+        bad.append(f"rope_scaling = {cfg['rope_scaling']!r} (only the default RoPE is implemented)")
+    if n_layers_in_file is not None and cfg.get("num_hidden_layers") not in (None, n_layers_in_file):
+        bad.append(f"num_hidden_layers = {cfg['num_hidden_layers']} but model.safetensors holds {n_layers_in_file} layers")
+    if bad:
+        raise AssetError("asset/gpt/config.json does not describe the model the HIP kernels are built for:\n  " + "\n  ".join(bad))
+    if cfg.get("rms_norm_eps") is not None:
+        out["rms_eps"] = float(cfg["rms_norm_eps"])
+    if cfg.get("rope_theta") is not None:
+        out["rope_theta"] = float(cfg["rope_theta"])
+    if cfg.get("max_position_embeddings") is not None:
+        out["max_pos"] = int(cfg["max_position_embeddings"])
+    return out
+
+
+def load_assets(root: str, validate: bool = True) -> Dict[str, StateDict]:
+    """Mirror of `load_safetensors` (/root/reference/ChatTTS/utils/io.py:19-25) over the four hot-path files, plus what
+    `LlamaModel.from_pretrained` takes from `asset/gpt/config.json` (gpt.py:75): every state dict is checked against
+    `expected_schema` (key set, shapes, dtypes) and the config against the geometry the kernels are built for, so a checkpoint
+    that does not fit fails HERE with a diff.  The run-time fields of the config come back as `out["gpt_config"]`
+    (rms_eps / rope_theta / max_pos; `GptEngine(..., **out["gpt_config"])`)."""
     from safetensors import safe_open
 
+    # `root` is either the directory that HOLDS `asset/` (the reference's download_path: core.py:118-129 + config.py:4-11) or the
+    # asset directory itself
+    if os.path.isdir(os.path.join(root, "asset")) and not os.path.exists(os.path.join(root, ASSET_FILES["embed"])):
+        root = os.path.join(root, "asset")
     out: Dict[str, StateDict] = {}
     for name, rel in {**ASSET_FILES, **OPTIONAL_ASSET_FILES}.items():
-        if name in OPTIONAL_ASSET_FILES and not os.path.exists(os.path.join(root, rel)):
+        path = os.path.join(root, rel)
+        if name in OPTIONAL_ASSET_FILES and not os.path.exists(path):
             continue
+        if not os.path.exists(path):
+            raise AssetError(f"{path} not found (expected the reference's asset layout, config.py:4-11: {sorted(ASSET_FILES.values())})")
         sd: StateDict = {}
-        with safe_open(os.path.join(root, rel), framework="pt") as f:
+        with safe_open(path, framework="pt") as f:
             for k in f.keys():
                 kk = k[len("model."):] if (name == "gpt" and k.startswith("model.")) else k
                 sd[kk] = f.get_tensor(k)
         sd.pop("embed_tokens.weight", None)  # gpt.py:78  (`del self.gpt.embed_tokens`)
+        if validate and name in ASSET_FILES:
+            validate_state_dict(name, sd, where=path)
         out[name] = sd
+    out["gpt_config"] = check_gpt_config(load_gpt_config(root), gpt_layer_count(out["gpt"]))
     return out
 
 

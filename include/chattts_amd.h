@@ -125,6 +125,15 @@ typedef struct {
                                       token WRITTEN at generation step i of utterance b is teacher_ids[b, i, :] instead of the
                                       sampled one; everything else (finish on EOS, lengths, hidden capture) is unchanged.  Used
                                       to bound the bf16 mode's drift against the reference's golden token stream. */
+  int64_t* sampled_ids;            /* [slots, max_new (hid_cap), 4] or NULL: evaluation hook, the companion of teacher_ids -- the token
+                                      the sampler itself drew at generation step i (after stop_at forcing, BEFORE teacher forcing
+                                      replaced it).  With teacher_ids = the reference's stream this gives the teacher-forced token
+                                      agreement rate of a numeric mode (bench.py `bf16_parity`). */
+  const int32_t* order;            /* [B] or NULL: visiting order of the device-side compaction (a permutation of the utterance
+                                      slots): compact row m of a decode step is the m-th utterance IN THIS ORDER whose finish flag
+                                      is 0.  The host passes the utterances by descending context (the contexts of a batch differ
+                                      only by the static valid prompt length), so the attention grid starts its longest
+                                      (utterance, head) units first.  NULL = ascending slot.  No result depends on it. */
 } ctts_gen_state;
 
 int ctts_gpt_create(ctts_gpt** out, const ctts_gpt_weights* w);

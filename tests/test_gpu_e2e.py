@@ -782,3 +782,150 @@ def test_session_reuse_has_no_stale_state(gpt_f32, weights):
     first, ids0, hid0 = kept
     assert all(torch.equal(a, b) for a, b in zip(first.ids, ids0)) and all(torch.equal(a, b) for a, b in zip(first.hiddens, hid0))
     assert gpt_f32._session is not None and gpt_f32._session["graph"]
+
+
+def test_bf16_parity_on_the_bench_workload(gpt_bf16, gpt_f32, weights):
+    """Parity evidence for the configuration bench.py's `value` is quoted in (bf16, C3: 64 utterances, 513 steps, contexts to 560
+    keys): both engines are TEACHER-FORCED on the reference's own token stream of this workload (tests/golden/bench_c3.npz, all
+    64 rows, all steps); the f32 engine is the pinned one (its free run IS that stream, `test_bench_workload_f32_equals_...`).
+    Bounds at every step of every row: relative hidden error, |delta logit| through the folded heads, no growth from the first to
+    the last quarter of a row, and the teacher-forced token agreement rate -- the fraction of (row, step, codebook) where the bf16
+    sampler's own draw under the same Exp(1) tensor is the reference's token (SURVEY 7 hard parts (iv); gpt.py:497-508: free
+    running, one flipped argmax diverges the suffix, which is why agreement is measured under the reference's history).
+    The numbers bench.py prints as `bf16_parity` come from the same functions."""
+    import os
+    import bench
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bench_c3.npz"))
+    wl = bench.shard_workload(64, 1, 0, 128, 512)
+    max_new = int(wl["stop_all"].max()) + 1
+    lens, rows, teacher = bench.teacher_from_golden(gold, max_new)
+    ids_t, mask_t = torch.from_numpy(wl["ids"]), torch.from_numpy(wl["mask"])
+    warpers, procs = E.gen_logits(625, 0.7, 20, 1.05)
+
+    def forced(eng):
+        emb = eng.embed_prompt(ids_t, torch.from_numpy(wl["tmask"]))
+        out = list(eng.generate(emb, ids_t, torch.tensor([0.3] * 4), 625, mask_t, max_new, 0, (*procs, *warpers), return_hidden=True,
+                                manual_seed=42, stop_at=torch.from_numpy(wl["stop"]), teacher_ids=torch.from_numpy(teacher),
+                                return_sampled=True))[-1]
+        for b in range(64):
+            assert np.array_equal(out.ids[b].cpu().numpy(), rows[b]), b      # the forced stream was followed, lengths included
+        return [h.cpu().numpy() for h in out.hiddens], [t.cpu().numpy() for t in eng.last_sampled]
+
+    hid32, samp32 = forced(gpt_f32)
+    # the f32 engine under teacher forcing draws the reference's tokens itself, every one of them (it is bit-exact free running)
+    assert all(np.array_equal(a, b) for a, b in zip(samp32, rows))
+    hid16, samp16 = forced(gpt_bf16)
+    pm = bench.parity_metrics(hid16, hid32, samp16, rows, bench.generate_heads(weights["embed"]))
+    print("bf16 vs f32, teacher-forced on the bench workload:", pm)
+    assert pm["tokens_compared"] == 4 * int(lens.sum()) == 4 * 21438
+    assert pm["worst_rel_hidden_err"] < 1.5e-2, pm
+    assert pm["worst_abs_dlogit"] < 0.25, pm
+    assert pm["rel_hidden_err_last_quarter"] < 2.0 * pm["rel_hidden_err_first_quarter"] + 1e-3, pm   # no growth with the step index / context
+    assert pm["token_agreement"] > 0.90, pm
+
+
+def test_slot_pool_with_finished_rows_kept_in_the_step(weights, monkeypatch):
+    """CTTS_SKIP_FINISHED=0 (the reference's own behaviour: finished rows keep stepping, gpt.py:512-518,592) with a caller that left
+    the compaction to the device (row_map = NULL, a zero-initialised n_active): nobody writes the live count then, so the step must
+    not read it -- every slot steps.  (Regression: the pool span forever on *n_active == 0.)"""
+    from chattts_amd.serving import SlotPool
+    eng = E.GptEngine(weights["gpt"], weights["embed"], DEV, dtype="f32")
+    monkeypatch.setenv("CTTS_SKIP_FINISHED", "0")
+    pool = SlotPool(eng, slots=3, cap=96, hid_cap=32, manual_seed=21)     # the pool's own handle reads the variable at creation
+    monkeypatch.delenv("CTTS_SKIP_FINISHED")
+    rs = np.random.RandomState(3)
+    reqs = {}
+    for i, n in enumerate([4, 11, 7, 9]):
+        T = int(rs.randint(5, 12))
+        ids = np.repeat(rs.randint(1, 21178, size=(T, 1)), 4, axis=1).astype(np.int64)
+        reqs[i] = (ids, n)
+        pool.submit(i, ids, max_new_token=24, stop_at=n)
+    got = {}
+    for k, (rid, ids, hid) in enumerate(pool.run()):
+        got[rid] = ids.cpu().numpy()
+        assert pool.steps < 400, "the pool is not making progress"
+    assert sorted(got) == [0, 1, 2, 3]
+    ref_eng = E.GptEngine(weights["gpt"], weights["embed"], DEV, dtype="f32")
+    warpers, procs = E.gen_logits(625, 0.7, 20, 1.05)
+    for rid, (ids, n) in reqs.items():
+        assert got[rid].shape == (n, 4)
+        ids_t = torch.from_numpy(ids)[None]
+        emb = ref_eng.embed_prompt(ids_t, torch.ones((1, ids.shape[0]), dtype=torch.bool))
+        ref = list(ref_eng.generate(emb, ids_t, torch.tensor([0.3] * 4), 625, None, 32, 0, (*procs, *warpers), return_hidden=False,
+                                    manual_seed=21, stop_at=torch.tensor([n], dtype=torch.int32), row_offset=4 * pool.slot_of[rid],
+                                    total_rows=12))[-1]
+        assert np.array_equal(got[rid], ref.ids[0].cpu().numpy()), rid
+    pool.close()
+
+
+def test_compaction_order_does_not_change_results(weights, golden, monkeypatch):
+    """ctts_gen_state.order (utterances visited by descending context in the device-side compaction, so the attention grid starts
+    its longest units first) moves utterances between compact rows, nothing else: token ids AND hidden states of the f32 engine are
+    bit-identical with CTTS_ORDER=0 (ascending slot) on the left-padded golden batch with rows finishing at different steps."""
+    c = cases.BIG_CASES["c3w"]
+    eng = E.GptEngine(weights["gpt"], weights["embed"], DEV, dtype="f32")
+    a, _ = run_case(eng, c, use_graph=True)
+    monkeypatch.setenv("CTTS_ORDER", "0")
+    eng._session = None
+    b, _ = run_case(eng, c, use_graph=True)
+    for x, y in zip(a[-1].ids, b[-1].ids):
+        assert torch.equal(x, y)
+    for x, y in zip(a[-1].hiddens, b[-1].hiddens):
+        assert torch.equal(x, y)
+
+
+def test_interrupt_keeps_tokens_steps_and_outputs_consistent(gpt_f32):
+    """Chat.interrupt() (core.py:272-273 -> Context, gpt.py:592) while a chunk is already enqueued behind the one being looked at
+    (run-ahead): the tokens handed out, `last_stats['steps']` and the lengths all describe the same number of steps."""
+    B = 3
+    ids, mask, tmask = synth.make_prompts(B, 8, 12, seed=2)
+    ids_t, mask_t = torch.from_numpy(ids), torch.from_numpy(mask)
+    emb = gpt_f32.embed_prompt(ids_t, torch.from_numpy(tmask))
+    warpers, procs = E.gen_logits(625, 0.7, 20, 1.05)
+    ctx = E.Context()
+
+    class Trip(E.Context):
+        """reports an interrupt from the second look on: the first look let chunk 2 be enqueued behind chunk 1 (run-ahead), the second --
+        right after chunk 1 was collected -- stops the loop with chunk 2 still in flight"""
+        def __init__(self):
+            super().__init__()
+            self.n = 0
+
+        def get(self):
+            self.n += 1
+            return self.n >= 2
+
+    out = list(gpt_f32.generate(emb, ids_t, torch.tensor([0.3] * 4), 625, mask_t, 200, 200, (*procs, *warpers), return_hidden=True,
+                                manual_seed=5, context=Trip()))[-1]
+    steps = gpt_f32.last_stats["steps"]
+    assert 1 < steps < 200
+    for b in range(B):
+        assert out.ids[b].shape[0] == steps == out.hiddens[b].shape[0], (b, out.ids[b].shape, steps)
+    full = list(gpt_f32.generate(emb, ids_t, torch.tensor([0.3] * 4), 625, mask_t, 200, 200, (*procs, *warpers), return_hidden=False,
+                                 manual_seed=5, context=ctx))[-1]
+    for b in range(B):
+        assert torch.equal(out.ids[b], full.ids[b][:steps])     # an interrupted run is a prefix of the uninterrupted one
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
+def test_engines_on_a_non_current_device(weights):
+    """Chat.load(device=cuda:1) without torch.cuda.set_device: every C-ABI entry point makes the device that owns the stream it was
+    given current while it enqueues (CttsDeviceGuard, csrc/kernels.hpp), so engines built for a non-current device work."""
+    d1 = torch.device("cuda:1")
+    assert torch.cuda.current_device() == 0
+    gpt = E.GptEngine(weights["gpt"], weights["embed"], d1, dtype="f32")
+    cod = E.CodecEngine(weights["decoder"], weights["vocos"], d1)
+    ids, mask, tmask = synth.make_prompts(2, 6, 9, seed=1)
+    ids_t, mask_t = torch.from_numpy(ids), torch.from_numpy(mask)
+    warpers, procs = E.gen_logits(625, 0.7, 20, 1.05)
+    out = list(gpt.generate(gpt.embed_prompt(ids_t, torch.from_numpy(tmask)), ids_t, torch.tensor([0.3] * 4), 625, mask_t, 12, 12,
+                            (*procs, *warpers), return_hidden=True, manual_seed=3))[-1]
+    ref = E.GptEngine(weights["gpt"], weights["embed"], DEV, dtype="f32")
+    out0 = list(ref.generate(ref.embed_prompt(ids_t, torch.from_numpy(tmask)), ids_t, torch.tensor([0.3] * 4), 625, mask_t, 12, 12,
+                             (*procs, *warpers), return_hidden=True, manual_seed=3))[-1]
+    for a, b in zip(out.ids, out0.ids):
+        assert torch.equal(a.cpu(), b.cpu())
+    with torch.cuda.device(d1):
+        wav = cod.decode_to_wavs(out.hiddens)
+    assert torch.isfinite(wav).all() and wav.device == d1
+    assert torch.cuda.current_device() == 0

@@ -151,7 +151,7 @@ def test_asset_layout_round_trip(tmp_path):
     sds = {"gpt": W.synthetic_gpt(n_layers=1), "embed": {"emb_code.0.weight": torch.randn(626, 8)},
            "decoder": {"coef": torch.rand(1, 100, 1)}, "vocos": {"head.istft.window": torch.hann_window(1024)}}
     W.save_assets(str(tmp_path), sds)
-    got = W.load_assets(str(tmp_path))
+    got = W.load_assets(str(tmp_path), validate=False)      # toy dicts: the layout check is test_asset_validation's subject
     for name in sds:
         assert set(got[name]) == set(sds[name])
         assert all(torch.equal(got[name][k], sds[name][k]) for k in sds[name])
@@ -159,8 +159,52 @@ def test_asset_layout_round_trip(tmp_path):
     pref = {"model." + k: v for k, v in sds["gpt"].items()}
     pref["model.embed_tokens.weight"] = torch.zeros(4, 768)
     save_file(pref, os.path.join(str(tmp_path), "gpt", "model.safetensors"))
-    got = W.load_assets(str(tmp_path))["gpt"]
+    got = W.load_assets(str(tmp_path), validate=False)["gpt"]
     assert set(got) == set(sds["gpt"]) and W.gpt_layer_count(got) == 1
+
+
+def test_asset_validation_and_gpt_config(tmp_path, weights):
+    """first contact with a checkpoint is a diff-style message, not a KeyError in the repacking: `load_assets` checks every state
+    dict against SURVEY App. B (`expected_schema`: key set, shapes, dtypes), accepts the reference's `<root>/asset/...` layout
+    (config.py:4-11), and reads `asset/gpt/config.json` like `LlamaModel.from_pretrained` (gpt.py:75) -- geometry fields must be
+    the ones the kernels are built for, rms_norm_eps / rope_theta / max_position_embeddings come back as run-time parameters"""
+    import json
+    from chattts_amd import weights as W
+    for name in W.ASSET_FILES:      # the synthetic recipe IS the documented layout
+        W.validate_state_dict(name, weights[name])
+        assert set(W.expected_schema(name)) == set(weights[name])
+    small = dict(weights, gpt=W.synthetic_gpt(n_layers=2))
+    root = os.path.join(str(tmp_path), "dl")
+    W.save_assets(os.path.join(root, "asset"), small)
+    with open(os.path.join(root, "asset", "gpt", "config.json"), "w") as fh:
+        json.dump({"hidden_size": 768, "intermediate_size": 3072, "num_attention_heads": 12, "num_hidden_layers": 2, "hidden_act": "silu",
+                   "rms_norm_eps": 1e-5, "rope_theta": 50000.0, "max_position_embeddings": 2048, "vocab_size": 21178}, fh)
+    got = W.load_assets(root)       # the directory that HOLDS asset/
+    assert got["gpt_config"] == {"rms_eps": 1e-5, "rope_theta": 50000.0, "max_pos": 2048}
+    assert W.gpt_layer_count(got["gpt"]) == 2 and set(got["vocos"]) == set(weights["vocos"])
+    # a Vocos file with other key names / a wrong shape / a missing tensor: every problem is named
+    bad = {("backbone.convnext." + k[len("backbone.convnext."):].replace("gamma", "layer_scale") if k.startswith("backbone.convnext.0.g") else k): v
+           for k, v in weights["vocos"].items()}
+    bad["head.out.weight"] = torch.zeros(1026, 256)
+    del bad["head.istft.window"]
+    with pytest.raises(W.AssetError) as ei:
+        W.validate_state_dict("vocos", bad, where="Vocos.safetensors")
+    msg = str(ei.value)
+    assert "missing (2)" in msg and "backbone.convnext.0.gamma" in msg and "head.istft.window" in msg
+    assert "unexpected (1)" in msg and "backbone.convnext.0.layer_scale" in msg
+    assert "wrong shape (1)" in msg and "(1026, 256) != expected (1026, 512)" in msg
+    W.validate_state_dict("vocos", dict(weights["vocos"], **{"feature_extractor.mel_spec.mel_scale.fb": torch.zeros(513, 100)}))   # ignored extras
+    # config.json for another geometry / another layer count
+    with pytest.raises(W.AssetError, match="hidden_size = 1024"):
+        W.check_gpt_config({"hidden_size": 1024, "num_attention_heads": 16})
+    with pytest.raises(W.AssetError, match="holds 2 layers"):
+        W.check_gpt_config({"num_hidden_layers": 20}, 2)
+    with pytest.raises(W.AssetError, match="rope_scaling"):
+        W.check_gpt_config({"rope_scaling": {"rope_type": "llama3", "factor": 8.0}})
+    assert W.check_gpt_config(None) == {"rms_eps": 1e-6, "rope_theta": 10000.0, "max_pos": 4096}
+    os.remove(os.path.join(root, "asset", "Decoder.safetensors"))
+    with pytest.raises(W.AssetError, match="Decoder.safetensors not found"):
+        W.load_assets(root)
 
 
 def test_left_pad_starts():
