@@ -41,6 +41,11 @@ struct ctts_gpt {
   std::vector<const float*> ln1, ln2;
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
+  // optional second executable graph of `multi_steps` consecutive decode steps (env CTTS_GRAPH_STEPS > 1): one hipGraphLaunch per
+  // multi_steps steps instead of one per step
+  hipGraph_t graph_multi = nullptr;
+  hipGraphExec_t exec_multi = nullptr;
+  int multi_steps = 1;
   // profiling (eager decode only)
   int prof_tag = -1;
   int prof_max = 0;
@@ -139,6 +144,8 @@ extern "C" void ctts_gpt_graph_destroy(ctts_gpt* g) {
   if (!g) return;
   if (g->exec) { (void)hipGraphExecDestroy(g->exec); g->exec = nullptr; }
   if (g->graph) { (void)hipGraphDestroy(g->graph); g->graph = nullptr; }
+  if (g->exec_multi) { (void)hipGraphExecDestroy(g->exec_multi); g->exec_multi = nullptr; }
+  if (g->graph_multi) { (void)hipGraphDestroy(g->graph_multi); g->graph_multi = nullptr; }
 }
 
 extern "C" void ctts_gpt_destroy(ctts_gpt* g) {
@@ -438,13 +445,29 @@ extern "C" int ctts_gpt_graph_build(ctts_gpt* g, const ctts_gen_state* s, void* 
   if (e != hipSuccess) return fail("hipStreamEndCapture: %s", hipGetErrorString(e));
   g->graph = graph;
   CK(hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0));
+  { const char* e2 = getenv("CTTS_GRAPH_STEPS"); g->multi_steps = e2 ? atoi(e2) : 1; }
+  if (g->multi_steps > 1 && g->multi_steps <= 64) {
+    CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    int rc2 = 0;
+    for (int i = 0; i < g->multi_steps && rc2 == 0; ++i) rc2 = decode_body(g, s, st, false);
+    hipGraph_t gm = nullptr;
+    hipError_t e3 = hipStreamEndCapture(st, &gm);
+    if (rc2 != 0) { if (gm) (void)hipGraphDestroy(gm); return -1; }
+    if (e3 != hipSuccess) return fail("hipStreamEndCapture (multi-step graph): %s", hipGetErrorString(e3));
+    g->graph_multi = gm;
+    CK(hipGraphInstantiate(&g->exec_multi, g->graph_multi, nullptr, nullptr, 0));
+  } else {
+    g->multi_steps = 1;
+  }
   return 0;
 }
 
 extern "C" int ctts_gpt_graph_launch(ctts_gpt* g, int32_t n_steps, void* stream) {
   if (!g || !g->exec) return fail("no captured graph");
   CttsDeviceGuard dg(stream);
-  for (int i = 0; i < n_steps; ++i) CK(hipGraphLaunch(g->exec, (hipStream_t)stream));
+  int left = n_steps;
+  while (g->exec_multi && left >= g->multi_steps) { CK(hipGraphLaunch(g->exec_multi, (hipStream_t)stream)); left -= g->multi_steps; }
+  for (int i = 0; i < left; ++i) CK(hipGraphLaunch(g->exec, (hipStream_t)stream));
   return 0;
 }
 

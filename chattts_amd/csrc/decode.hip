@@ -215,6 +215,7 @@ void gemm_dec_k(DecGemmArgs a) {
   __shared__ float cs_s[(EPI == FEPI_QKV_ROPE) ? 16 * MBT : 1][16];   // per row: cos[8], sin[8] of this tile's dims
   __shared__ int meta_s[(EPI == FEPI_QKV_ROPE) ? 16 * MBT : 1][2];    // per row: utterance b (-1: finished), KV slot
 
+  CTTS_PROBE_RETURN();
   const int tile = blockIdx.x, mt0 = blockIdx.y * MBT;
   if (a.dbg && threadIdx.x == 0) a.dbg[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8] = wall_clock64();
   // The weight fragments of the first round do not depend on anything but the kernel arguments: request them before

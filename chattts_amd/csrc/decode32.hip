@@ -284,6 +284,7 @@ __global__ __launch_bounds__(256) void gemm_dec32_m16_k(Dec32Args a) {
   static_assert(ROUNDS == 1 || ROUNDS % 2 == 0, "stages are consumed in pairs");
   __shared__ __attribute__((aligned(16))) float red[4][NACC][64][4];
   struct Stage { u128 w[NACC][U]; u128 a[U]; };
+  CTTS_PROBE_RETURN();
 
   const int tile = blockIdx.x, mt0 = blockIdx.y;
   if (tile >= (a.N >> 4)) return;   // the grid's x extent is rounded up to a multiple of 8 (see dec32_dispatch_m16)

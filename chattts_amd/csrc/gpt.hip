@@ -91,6 +91,7 @@ __global__ __launch_bounds__(192) void embed_codes_k(const float* __restrict__ e
                                                      uint16_t* __restrict__ xb, float* __restrict__ ssq,
                                                      const int32_t* __restrict__ row_map, const int32_t* __restrict__ n_active,
                                                      StepPrep sp) {
+  CTTS_PROBE_RETURN();
   const int m = blockIdx.x, t = threadIdx.x;
   int b;
   if (sp.row_map_out != nullptr) {   // device-side compaction: this step's row order comes from the finish flags
@@ -254,6 +255,7 @@ __global__ __launch_bounds__(64 * NW) void attention_k(const float* __restrict__
   constexpr int KB = KPI * NI;      // keys per wave-block: 32 / 16
   constexpr bool KV_NT = NW > 1;    // decode: every KV byte is read once per step by exactly one workgroup -> non-temporal
   __shared__ float sm_m[NW], sm_l[NW], sm_acc[NW][HDIM];
+  if (NW > 1) CTTS_PROBE_RETURN();
 
   int h = blockIdx.x, m = blockIdx.y;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -663,6 +665,7 @@ __global__ __launch_bounds__(192) void final_norm_k(const float* __restrict__ x,
                                                     const int32_t* __restrict__ n_active, const int32_t* __restrict__ prompt_len,
                                                     float* __restrict__ hfin_p) {
   __shared__ float part[3];
+  CTTS_PROBE_RETURN();
   const int m = blockIdx.x, t = threadIdx.x;
   if (row_absent(n_active, m)) return;
   const int b = row_map ? row_map[m] : m;   // compact activation row m belongs to utterance b
@@ -716,6 +719,7 @@ __device__ __forceinline__ void wave_argmax(float v, int idx, float& bv, int& bi
 
 __global__ __launch_bounds__(256) void sample_k(SampleArgs a) {
   __shared__ int tok_s[NVQ];
+  CTTS_PROBE_RETURN();
   const int m = blockIdx.x;                       // compact logits row
   if (row_absent(a.n_active, m)) return;
   const int b = a.row_map ? a.row_map[m] : m;     // utterance (batch slot)

@@ -31,6 +31,15 @@ extern thread_local hipEvent_t ctts_prof_start, ctts_prof_stop;
     }                                                                                                             \
   } while (0)
 
+// Probe builds only (python -m chattts_amd.build --variant probe -DCTTS_PROBE_EXIT=1, tools/step_floor_probe.py): every kernel of
+// the decode step returns at entry WITHOUT touching memory -- what a replay of the captured step then costs is launch + dispatch
+// alone, to be set against the "every utterance finished" replay of the normal build (launch + one dependent load of the live count).
+#ifdef CTTS_PROBE_EXIT
+#define CTTS_PROBE_RETURN() do { return; } while (0)
+#else
+#define CTTS_PROBE_RETURN() do { } while (0)
+#endif
+
 enum { WT_F32 = 0, WT_BF16 = 1 };
 
 // ---- GEMM  C[M,N] = epi( pro(A)[M,K] * W[N,K]^T ) ------------------------------------------

@@ -280,7 +280,7 @@ def expected_schema(name: str, n_layers: int = GPT.n_layers) -> Dict[str, tuple]
 
 
 # keys a real checkpoint may carry that the hot path does not read (not an error, not listed as unexpected)
-IGNORED_PREFIXES = {"gpt": ("embed_tokens.", "rotary_emb.", "layers.0.self_attn.rotary_emb."), "embed": (), "decoder": (),
+IGNORED_PREFIXES = {"gpt": ("embed_tokens.", "rotary_emb."), "embed": (), "decoder": (),
                     "vocos": ("feature_extractor.",)}
 
 
@@ -295,7 +295,7 @@ def validate_state_dict(name: str, sd: StateDict, where: str = "") -> None:
     want = expected_schema(name, n_layers)
     ign = IGNORED_PREFIXES.get(name, ())
     missing = [k for k in want if k not in sd]
-    extra = [k for k in sd if k not in want and not any(k.startswith(p) or (".rotary_emb." in k) for p in ign + ("\0",))]
+    extra = [k for k in sd if k not in want and not (ign and k.startswith(ign)) and ".rotary_emb." not in k]
     wrong = [f"{k}: file {tuple(sd[k].shape)} != expected {want[k]}" for k in want if k in sd and tuple(sd[k].shape) != tuple(want[k])]
     bad_dt = [f"{k}: {sd[k].dtype}" for k in want if k in sd and not sd[k].dtype.is_floating_point]
     if not (missing or extra or wrong or bad_dt):
