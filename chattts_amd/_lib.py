@@ -39,6 +39,7 @@ class GenState(C.Structure):
         ("stop_at", P), ("workspace", P), ("workspace_bytes", C.c_size_t), ("row_map", P), ("n_active", P),
         ("cap", C.c_int32), ("hid_cap", C.c_int32), ("kv_batch", C.c_int32), ("q_batch", C.c_int32), ("prompt_len", P),
         ("infer_text", C.c_int32), ("teacher_ids", P), ("sampled_ids", P), ("order", P),
+        ("rng_device", C.c_int32), ("rng_per_step", C.c_int32), ("rng_seed", P),
     ]
 
 
@@ -122,6 +123,7 @@ SIGNATURES = {
     "ctts_k_embed_codes": (C.c_int, [P, P, I32, P, P, I32, P]),
     "ctts_k_final_norm": (C.c_int, [P, I32, P, F, P, P, I32, P, I32, I32, P]),
     "ctts_k_sample": (C.c_int, [C.POINTER(GenState), P, P]),
+    "ctts_k_exp_draws": (C.c_int, [C.c_uint64, I32, I32, I32, I32, P, P]),
     "ctts_k_dwconv_ln": (C.c_int, [P, P, P, P, P, F, I32, P, I32, I32, P]),
     "ctts_k_layernorm": (C.c_int, [P, P, P, F, P, I32, P]),
     "ctts_k_istft": (C.c_int, [P, P, P, P, P, I32, I32, P]),

@@ -181,6 +181,7 @@ static SampleArgs make_sample_args(const ctts_gen_state* s, const float* logits)
   a.min_new = s->min_new; a.eos = s->eos; a.row_offset = s->row_offset; a.max_input_ids = NAUDIO - 1; a.stop_at = s->stop_at;
   a.B = s->B; a.row_map = nullptr; a.n_active = nullptr; a.prompt_len = s->prompt_len; a.q_rows = s->q_batch ? s->q_batch : s->B;
   a.teacher = s->teacher_ids; a.teacher_stride = s->hid_cap ? s->hid_cap : s->max_new; a.sampled = s->sampled_ids;
+  a.desc = nullptr; a.rng_device = s->rng_device; a.rng_per_step = s->rng_per_step; a.rng_seed = reinterpret_cast<const unsigned long long*>(s->rng_seed);
   return a;
 }
 
@@ -194,7 +195,9 @@ static int check_state(const ctts_gpt* g, const ctts_gen_state* s, int ws_T = 0)
   if (cap_ > g->w.max_pos) return fail("slot capacity T + max_new (%d) exceeds the RoPE table (%d)", cap_, g->w.max_pos);
   if (s->cap && s->T + 1 > s->cap) return fail("prompt does not fit the slot capacity");
   if (s->workspace_bytes < ctts_gpt_workspace_bytes(s->B, ws_T > 0 ? ws_T : s->T)) return fail("workspace too small");
-  if (s->nq <= 0 || !s->q) return fail("q draws missing");
+  if (!s->rng_device && (s->nq <= 0 || !s->q)) return fail("q draws missing");
+  if (s->rng_device && !s->rng_seed) return fail("rng_device needs the rng_seed device scalar");
+  if (s->rng_device && s->infer_text) return fail("the device generator serves the code mode only (refine-text samples from `q`)");
   if (g->w.weight_dtype == CTTS_BF16 && g->w.kv_dtype != CTTS_BF16) return fail("perf mode needs a bf16 KV cache");
   if (s->infer_text) {
     if (!g->w.emb_text || !g->w.head_text || g->w.n_text <= 0 || g->w.n_text > NTEXT_MAX) return fail("text head/embedding not loaded");
@@ -360,6 +363,7 @@ static int run_step(ctts_gpt* g, const ctts_gen_state* s, int q_per_b, hipStream
     Prof p(g, 9, st, prof_ok);
     SampleArgs sa = make_sample_args(s, ws.logits);
     sa.row_map = rmap; sa.n_active = nact;
+    if (dec && dev_compact(g, s)) sa.desc = ws.desc;   // one load instead of the n_active -> row_map -> len chain
     if (s->infer_text) CK(launch_sample_text(sa, g->w.n_text, st));
     else CK(launch_sample(sa, st));
   }
@@ -757,6 +761,11 @@ extern "C" int ctts_k_final_norm(const float* x, int32_t q_per_b, const float* w
 extern "C" int ctts_k_sample(const ctts_gen_state* s, const float* logits, void* stream) {
   if (!s || !logits) return fail("ctts_k_sample: bad arguments");
   CK(launch_sample(make_sample_args(s, logits), (hipStream_t)stream));
+  return 0;
+}
+extern "C" int ctts_k_exp_draws(uint64_t seed, int32_t step, int32_t row0, int32_t rows, int32_t V, float* out, void* stream) {
+  if (!out || rows <= 0 || V <= 0) return fail("ctts_k_exp_draws: bad arguments");
+  CK(launch_exp_draws(seed, step, row0, rows, V, out, (hipStream_t)stream));
   return 0;
 }
 extern "C" int ctts_k_dwconv_ln(const float* x, const float* w, const float* b, const float* ln_w, const float* ln_b, float eps,

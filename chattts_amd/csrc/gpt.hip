@@ -717,14 +717,65 @@ __device__ __forceinline__ void wave_argmax(float v, int idx, float& bv, int& bi
   bi = wave_min_dpp(v == bv ? idx : 0x7fffffff);
 }
 
+// Exp(1) draws of the opt-in DEVICE generator (ctts_gen_state.rng_device): Philox4x32-10 keyed on the call's seed, counter =
+// (token group, global sampling row, step, stream tag).  One call yields the draws of 4 consecutive tokens of one row:
+// q = -log(u), u = (x + 1) * 2^-32 in (0, 1].  The reference on a GPU device draws from the device generator too (gpt.py:39:
+// torch.Generator(device=device)); its CPU stream stays the parity default (rng.py).
+__device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t k0, uint32_t k1) {
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+  c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+}
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c0, c1, c2, c3, k0, k1);
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __forceinline__ float exp1_from_bits(uint32_t x) {
+  const float u = ((float)(x >> 8) + 1.0f) * (1.0f / 16777216.0f);   // 24 bits -> (0, 1], exactly representable
+  return -logf(u);
+}
+// the 4 draws of tokens 4 grp .. 4 grp + 3 of global sampling row `grow` at generation step `step`
+__device__ __forceinline__ void device_exp_draws4(unsigned long long seed, int grow, int step, int grp, float (&q)[4]) {
+  uint32_t r[4];
+  philox4x32_10((uint32_t)grp, (uint32_t)grow, (uint32_t)step, 0x43545453u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) q[i] = exp1_from_bits(r[i]);
+}
+
+__global__ __launch_bounds__(256) void exp_draws_k(unsigned long long seed, int step, int row0, int V, float* __restrict__ out) {
+  const int row = blockIdx.x, grp = threadIdx.x + blockIdx.y * 256;   // tests: the generator's draws as a [rows, V] tensor
+  if (4 * grp >= V) return;
+  float q[4];
+  device_exp_draws4(seed, row0 + row, step, grp, q);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) if (4 * grp + i < V) out[(size_t)row * V + 4 * grp + i] = q[i];
+}
+hipError_t launch_exp_draws(unsigned long long seed, int step, int row0, int rows, int V, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(exp_draws_k, dim3(rows, (V / 4 + 255) / 256), dim3(256), 0, st, seed, step, row0, V, out);
+  return hipGetLastError();
+}
+
 __global__ __launch_bounds__(256) void sample_k(SampleArgs a) {
   __shared__ int tok_s[NVQ];
+  __shared__ float cand_v[NVQ][64], cand_e[NVQ][64];
+  __shared__ int cand_i[NVQ][64];
   CTTS_PROBE_RETURN();
   const int m = blockIdx.x;                       // compact logits row
-  if (row_absent(a.n_active, m)) return;
-  const int b = a.row_map ? a.row_map[m] : m;     // utterance (batch slot)
   const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int len = a.len[b];
+  int b, len;
+  if (a.desc != nullptr) {    // decode with device-side compaction: ONE load gives the utterance and its length (and says whether
+    const RowDesc d = a.desc[m];   // the row exists this step) instead of the n_active -> row_map -> len chain
+    if (d.b < 0) return;
+    b = d.b; len = d.slot + 1;
+  } else {
+    if (row_absent(a.n_active, m)) return;
+    b = a.row_map ? a.row_map[m] : m;     // utterance (batch slot)
+    len = a.len[b];
+  }
   if (len >= a.tcap) {  // slot full (slot pools only; generate() never steps past max_new_token): stop, write nothing
     if (threadIdx.x == 0) a.finish[b] = 1;
     return;
@@ -732,22 +783,48 @@ __global__ __launch_bounds__(256) void sample_k(SampleArgs a) {
   const int gen = len - (a.prompt_len ? a.prompt_len[b] : a.T);  // tokens generated so far == step index i of gpt.py:394
   const float* lrow = a.logits + ((size_t)m * NVQ + k) * NAUDIO;
   const float temp = a.temperature[k];
+  const int grow = a.row_offset + b * NVQ + k;    // global sampling row (multi-GPU shards keep the reference's numbering)
+  const unsigned long long seed = a.rng_device ? *a.rng_seed : 0ull;
 
-  float x[SLOTS];
+  // everything that depends only on (b, k, gen) is requested NOW, in one round: the logits, the Exp(1) draws consumed at the very
+  // end, the <= 16 history tokens, the harness hooks
+  float x[SLOTS], qv[SLOTS];
   int cnt[SLOTS];
 #pragma unroll
   for (int s = 0; s < SLOTS; ++s) {
     const int v = s * 64 + lane;
-    x[s] = (v < NAUDIO) ? lrow[v] / temp : -INFINITY;
+    x[s] = (v < NAUDIO) ? lrow[v] : 0.f;
     cnt[s] = 0;
   }
+  if (a.rng_device == 0) {
+    const float* qrow = a.q + ((size_t)(gen % a.nq) * a.q_rows * NVQ + (size_t)b * NVQ + k) * NAUDIO;
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) qv[s] = (s * 64 + lane < NAUDIO) ? qrow[s * 64 + lane] : 1.f;
+  }
+  const bool penal = a.pow_table != nullptr && grow < a.max_input_ids;
+  const int nh = min(gen, 16);
+  // the <=16 history tokens are fetched by 16 lanes in ONE load round and broadcast (a serial loop of
+  // dependent global loads costs one L2 round trip per token)
+  const int mine = (penal && lane < nh) ? (int)a.ids_buf[((size_t)b * a.tcap + (len - 1 - lane)) * NVQ + k] : -1;
+  const float ptab_warm = penal ? a.pow_table[lane & 15] : 0.f;   // pulls the 17-entry table's line into this CU's L1
+  asm volatile("" ::"v"(ptab_warm));   // keep the warming load
+  const int sa = a.stop_at != nullptr ? a.stop_at[b] : -1;
+  const bool forced_t = a.teacher != nullptr && gen < a.teacher_stride;
+  const int64_t teach = forced_t ? a.teacher[((size_t)b * a.teacher_stride + gen) * NVQ + k] : 0;
+  if (a.rng_device != 0) {   // device generator: the draws of this lane's tokens (token v = 64 s + lane sits in group v / 4)
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+      const int v = s * 64 + lane;
+      float q4[4];
+      device_exp_draws4(seed, grow, a.rng_per_step ? gen : 0, v >> 2, q4);
+      qv[s] = q4[v & 3];
+    }
+  }
+
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s) x[s] = (s * 64 + lane < NAUDIO) ? x[s] / temp : -INFINITY;   // gpt.py:487
   // repetition penalty
-  const int grow = a.row_offset + b * NVQ + k;
-  if (a.pow_table != nullptr && grow < a.max_input_ids) {
-    const int nh = min(gen, 16);
-    // the <=16 history tokens are fetched by 16 lanes in ONE load round and broadcast (a serial loop of
-    // dependent global loads costs one L2 round trip per token)
-    const int mine = (lane < nh) ? (int)a.ids_buf[((size_t)b * a.tcap + (len - 1 - lane)) * NVQ + k] : -1;
+  if (penal) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       const int t = __shfl(mine, j, 64);  // -1 beyond the history: matches no vocabulary slot
@@ -765,7 +842,8 @@ __global__ __launch_bounds__(256) void sample_k(SampleArgs a) {
   float mx = -INFINITY;
 #pragma unroll
   for (int s = 0; s < SLOTS; ++s) mx = fmaxf(mx, x[s]);
-  mx = wave_max(mx);
+  const float lane_max = mx;
+  mx = wave_max_dpp(mx);
   float e[SLOTS];
   float zs = 0.f;
 #pragma unroll
@@ -777,65 +855,123 @@ __global__ __launch_bounds__(256) void sample_k(SampleArgs a) {
   for (int s = 0; s < SLOTS; ++s) { e[s] = e[s] * rz; sall += (double)e[s]; }  // e = softmax prob (f32)
   sall = wave_sum_d(sall);
 
-  // prefix extraction in descending order
+  // ---- the kept set.  Both warpers keep a PREFIX of the descending order (value desc, ties: lowest index first), so it is
+  // described by its last element (v_last, i_last): kept = everything at or before it in that order.
   const int kk = a.use_top_k ? min(max(a.top_k, 3), NAUDIO) : NAUDIO;
   const float thr = a.top_p_thr;  // float32(1 - top_p): `cum <= (1 - top_p)` on a float tensor casts the scalar to float
-  unsigned taken = 0;                // bit s: slot s of this lane already extracted
-  unsigned kept = 0;
-  double mass_above = 0.0;
-  float kth_val = 0.f;
-  int n = 0;
   const bool any_filter = a.use_top_p || a.use_top_k;
-  while (any_filter && n < NAUDIO) {
-    float bv = -INFINITY; int bi = 0x7fffffff;
+  float v_last = INFINITY; int i_last = -1;   // nothing kept yet
+  int n_kept = 0;
+  bool done = !any_filter;
+  // FAST PATH (top-k <= 64, the reference's default 20): the prefix can only end inside the top kk (+ ties with the kk-th value).
+  // t = the kk-th largest LANE maximum bounds the kk-th largest value from below (kk elements are >= t), so the candidates
+  // {x >= t} contain the whole prefix; they are compacted to one per lane, ranked by counting (value desc, index asc -- the same
+  // total order as the serial extraction), and the warpers' decisions walk the ranks with the probability mass above accumulated
+  // in double in exactly the order the serial loop used.  Falls back to the serial loop when more than 64 candidates survive.
+  if (any_filter && a.use_top_k && kk <= 64) {
+    int rk = 0;
 #pragma unroll
-    for (int s = 0; s < SLOTS; ++s) {
-      const bool avail = !((taken >> s) & 1u) && (s * 64 + lane < NAUDIO);
-      if (avail && (x[s] > bv)) { bv = x[s]; bi = s * 64 + lane; }  // ascending s => lowest index on ties
+    for (int j = 0; j < 64; ++j) {
+      const float o = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lane_max), j));
+      rk += ((o > lane_max) || (o == lane_max && j < lane)) ? 1 : 0;
     }
-    float wv; int wi;
-    wave_argmax(bv, bi, wv, wi);
-    // top-p decision for the n-th largest element
-    bool keep = true;
-    if (a.use_top_p && n >= 3) {
-      const float cum = (float)(sall - mass_above);  // ascending cumulative prob up to and including it
-      keep = !(cum <= thr);
-    }
-    if (!keep) break;  // everything below is removed by top-p as well
-    if (a.use_top_k && n >= kk) {
-      if (!(wv == kth_val)) break;  // below the k-th largest value; ties with it survive
-    }
-    // accept
-    const int ws = wi >> 6, wl = wi & 63;
-    float pe = 0.f;
+    const unsigned long long pick = __ballot(rk == kk - 1);
+    if (pick != 0ull) {
+      const float t = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lane_max), (int)__ffsll((long long)pick) - 1));
+      int base = 0;
 #pragma unroll
-    for (int s = 0; s < SLOTS; ++s) if (s == ws) pe = e[s];
-    pe = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pe), wl));  // wl is wave-uniform
-    mass_above += (double)pe;
-    if (lane == wl) { taken |= 1u << ws; kept |= 1u << ws; }
-    if (n == kk - 1) kth_val = wv;
-    ++n;
+      for (int s = 0; s < SLOTS; ++s) {
+        const bool c = x[s] >= t;   // padded slots hold -inf
+        const unsigned long long ms = __ballot(c);
+        const int pos = base + (int)__popcll(ms & ((1ull << lane) - 1ull));
+        if (c && pos < 64) { cand_v[k][pos] = x[s]; cand_e[k][pos] = e[s]; cand_i[k][pos] = s * 64 + lane; }
+        base += (int)__popcll(ms);
+      }
+      const int C = base;   // >= kk
+      if (C <= 64) {
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's LDS writes have landed (same-wave read-after-write)
+        __builtin_amdgcn_wave_barrier();
+        const bool act = lane < C;
+        const float cv = act ? cand_v[k][lane] : -INFINITY, ce = act ? cand_e[k][lane] : 0.f;
+        const int ci = act ? cand_i[k][lane] : 0x7fffffff;
+        int rank = 0;
+        for (int j = 0; j < C; ++j) {
+          const float o = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cv), j));
+          const int oi = __builtin_amdgcn_readlane(ci, j);
+          rank += ((o > cv) || (o == cv && oi < ci)) ? 1 : 0;
+        }
+        double mass_above = 0.0;
+        float kth_val = 0.f;
+        int n = 0;
+        while (n < C) {
+          const unsigned long long who = __ballot(act && rank == n);
+          const int src = (int)__ffsll((long long)who) - 1;
+          const float wv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cv), src));
+          if (a.use_top_p && n >= 3) {
+            const float cum = (float)(sall - mass_above);  // ascending cumulative prob up to and including it
+            if (cum <= thr) break;                         // everything below is removed by top-p as well
+          }
+          if (n >= kk && !(wv == kth_val)) break;          // below the k-th largest value; ties with it survive
+          mass_above += (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(ce), src));
+          v_last = wv; i_last = __builtin_amdgcn_readlane(ci, src);
+          if (n == kk - 1) kth_val = wv;
+          ++n;
+        }
+        n_kept = n;
+        done = true;
+      }
+    }
   }
-  if (!any_filter) kept = 0x3ffu;
+  if (!done) {
+    // SERIAL PATH: repeated extraction of the wave-wide maximum (ties: lowest index first) while accumulating the probability
+    // mass above it in double -- cum_ascending(v) = fl32(S_all - mass_above(v)), the value ATen's double-accumulated cumsum rounds to
+    unsigned taken = 0;                // bit s: slot s of this lane already extracted
+    double mass_above = 0.0;
+    float kth_val = 0.f;
+    int n = 0;
+    while (n < NAUDIO) {
+      float bv = -INFINITY; int bi = 0x7fffffff;
+#pragma unroll
+      for (int s = 0; s < SLOTS; ++s) {
+        const bool avail = !((taken >> s) & 1u) && (s * 64 + lane < NAUDIO);
+        if (avail && (x[s] > bv)) { bv = x[s]; bi = s * 64 + lane; }  // ascending s => lowest index on ties
+      }
+      float wv; int wi;
+      wave_argmax(bv, bi, wv, wi);
+      if (a.use_top_p && n >= 3) {
+        const float cum = (float)(sall - mass_above);
+        if (cum <= thr) break;
+      }
+      if (a.use_top_k && n >= kk && !(wv == kth_val)) break;
+      const int ws = wi >> 6, wl = wi & 63;
+      float pe = 0.f;
+#pragma unroll
+      for (int s = 0; s < SLOTS; ++s) if (s == ws) pe = e[s];
+      pe = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pe), wl));  // wl is wave-uniform
+      mass_above += (double)pe;
+      if (lane == wl) taken |= 1u << ws;
+      v_last = wv; i_last = wi;
+      if (n == kk - 1) kth_val = wv;
+      ++n;
+    }
+    n_kept = n;
+  }
 
   // EOS handling (min_new_token and the bench harness's stop_at hook)
   bool mask_eos = gen < a.min_new;
   bool force_eos = false;
-  if (a.stop_at != nullptr) {
-    const int sa = a.stop_at[b];
-    if (sa >= 0) { mask_eos = mask_eos || (gen < sa); force_eos = gen >= sa; }
-  }
+  if (sa >= 0) { mask_eos = mask_eos || (gen < sa); force_eos = gen >= sa; }
   // final softmax over the kept set and argmax(p / q)
-  const float* qrow = a.q + ((size_t)(gen % a.nq) * a.q_rows * NVQ + (size_t)b * NVQ + k) * NAUDIO;
   float m2 = -INFINITY;
   bool live[SLOTS];
 #pragma unroll
   for (int s = 0; s < SLOTS; ++s) {
     const int v = s * 64 + lane;
-    live[s] = ((kept >> s) & 1u) && v < NAUDIO && !(mask_eos && v == a.eos);
+    const bool kept = !any_filter || (n_kept > 0 && (x[s] > v_last || (x[s] == v_last && v <= i_last)));
+    live[s] = kept && v < NAUDIO && !(mask_eos && v == a.eos);
     if (live[s]) m2 = fmaxf(m2, x[s]);
   }
-  m2 = wave_max(m2);
+  m2 = wave_max_dpp(m2);
   float z2 = 0.f, p2[SLOTS];
 #pragma unroll
   for (int s = 0; s < SLOTS; ++s) { p2[s] = live[s] ? expf(x[s] - m2) : 0.f; z2 += p2[s]; }
@@ -846,7 +982,7 @@ __global__ __launch_bounds__(256) void sample_k(SampleArgs a) {
   for (int s = 0; s < SLOTS; ++s) {
     const int v = s * 64 + lane;
     if (v < NAUDIO) {
-      const float r = (p2[s] * rz2) / qrow[v];
+      const float r = (p2[s] * rz2) / qv[s];
       if (r > bv) { bv = r; bi = v; }
     }
   }
@@ -854,7 +990,7 @@ __global__ __launch_bounds__(256) void sample_k(SampleArgs a) {
   wave_argmax(bv, bi, wv, wi);
   if (force_eos) wi = a.eos;
   if (a.sampled != nullptr && gen < a.teacher_stride && lane == 0) a.sampled[((size_t)b * a.teacher_stride + gen) * NVQ + k] = (int64_t)wi;
-  if (a.teacher != nullptr && gen < a.teacher_stride) wi = (int)a.teacher[((size_t)b * a.teacher_stride + gen) * NVQ + k];
+  if (forced_t) wi = (int)teach;
   if (lane == 0) {
     a.ids_buf[((size_t)b * a.tcap + len) * NVQ + k] = (int64_t)wi;
     tok_s[k] = wi;

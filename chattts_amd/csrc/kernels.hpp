@@ -257,7 +257,13 @@ struct SampleArgs {
   const int64_t* teacher;   // [slots, teacher_stride, 4] or null: teacher forcing (evaluation hook)
   int teacher_stride;
   int64_t* sampled;         // [slots, teacher_stride, 4] or null: the sampler's own draw of every step (before teacher forcing)
+  const RowDesc* desc;      // decode with device-side compaction: this step's row descriptors (utterance + length in ONE load), or null
+  int rng_device;           // 1: Exp(1) draws from the device generator (Philox4x32-10 keyed on rng_seed) instead of `q`
+  int rng_per_step;         // device generator: 1 = a fresh draw every step (the reference's manual_seed=None), 0 = the same draw
+                            // every step (manual_seed set: the reference re-seeds its generator at every step, gpt.py:504-507)
+  const unsigned long long* rng_seed;   // device scalar
 };
+hipError_t launch_exp_draws(unsigned long long seed, int step, int row0, int rows, int V, float* out, hipStream_t st);
 hipError_t launch_sample(const SampleArgs& a, hipStream_t st);
 // refine-text mode: logits [B, V], q [nq, B, V], temperature[0]; no repetition penalty (see gpt.hip)
 hipError_t launch_sample_text(const SampleArgs& a, int V, hipStream_t st);

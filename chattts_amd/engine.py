@@ -288,6 +288,7 @@ class GptEngine:
         self.stream = torch.cuda.Stream(device=dev)
         self._lane_res = [(self.handle, self.stream)]
         self.default_lanes = 1
+        self.rng = "host"         # default source of the multinomial's Exp(1) draws: "host" (the reference's CPU stream) | "device"
         self.last_stats = {}
         self._session = None      # buffers + instantiated graph of the last generate() geometry (see generate)
         self._draws_cache = None  # (key, ExpDraws) of the last seeded call: the constant Exp(1) tensor
@@ -336,7 +337,7 @@ class GptEngine:
                  total_rows: Optional[int] = None, profile_tag: Optional[int] = None,
                  profile_stride: int = 1, lanes: Optional[int] = None,
                  teacher_ids: Optional[torch.Tensor] = None, prefill_chunk: Optional[int] = None,
-                 return_sampled: bool = False) -> Iterator[GenerationOutputs]:
+                 return_sampled: bool = False, rng: Optional[str] = None, rng_seed: Optional[int] = None) -> Iterator[GenerationOutputs]:
         """Drop-in for `GPT.generate` (gpt.py:316-337), code mode.  Extra keyword-only arguments:
         `use_graph` (hipGraph replay of the decode step), `stop_at` ([B] int32 forced output lengths,
         benchmark hook), `row_offset`/`total_rows` (this shard's position inside a data-parallel batch:
@@ -350,7 +351,12 @@ class GptEngine:
         bounds the activation workspace of a long prompt such as an `spk_smp` audio-code prompt, core.py:435-453: the workspace is
         then sized for a piece, not for the whole prompt), `return_sampled` (evaluation hook, the companion of `teacher_ids`: after
         the call `self.last_sampled` holds, per utterance, the [T_b, 4] tokens the sampler itself drew at every step before teacher
-        forcing replaced them -- the teacher-forced token agreement of a numeric mode)."""
+        forcing replaced them -- the teacher-forced token agreement of a numeric mode), `rng` ("host" | "device", default
+        `self.rng` = "host"): where the Exp(1) draws of the multinomial come from.  "host" is the parity contract -- the reference's
+        CPU generator call, uploaded (rng.py).  "device" draws them inside the sampling kernel (Philox4x32-10, counter = token / global
+        row / step; the reference on a GPU device draws from the device generator too, gpt.py:39): with `manual_seed=None` -- the
+        reference's DEFAULT -- that removes the ~2 ms per-step host draw + upload; the key is `rng_seed` or, if None, one draw from
+        torch's global CPU generator (so `torch.manual_seed` still makes a run repeatable).  Code mode only."""
         if return_attn:
             raise NotImplementedError("return_attn is not supported by the fused attention kernel")
         context = context or Context()
@@ -377,14 +383,23 @@ class GptEngine:
         # seeded sampling re-seeds the CPU generator at every step (gpt.py:504-507): ONE constant tensor per (seed, batch
         # geometry).  Drawing it costs ~4 ms of host time per 256 rows (30 ms for the 2048 rows of an 8-GPU batch), so the
         # last one is kept across calls.
+        rng_mode = rng or self.rng
+        if rng_mode not in ("host", "device"):
+            raise ValueError("rng must be 'host' or 'device'")
+        device_rng = rng_mode == "device" and not infer_text     # refine-text keeps the host stream
         dkey = (total_rows if total_rows is not None else B * nrow, V, manual_seed, row_offset, B * nrow)
-        if manual_seed is not None and self._draws_cache is not None and self._draws_cache[0] == dkey:
+        if device_rng:
+            draws = None
+            seed_val = int(rng_seed) if rng_seed is not None else (int(manual_seed) if manual_seed is not None
+                                                                    else int(torch.randint(0, 2 ** 62, (1,)).item()))
+        elif manual_seed is not None and self._draws_cache is not None and self._draws_cache[0] == dkey:
             draws = self._draws_cache[1]
         else:
             draws = ExpDraws(dkey[0], V, manual_seed, row_begin=row_offset, row_end=row_offset + B * nrow)
             self._draws_cache = (dkey, draws) if draws.constant else None
+        const_q = device_rng or draws.constant      # no per-step host draw / upload
         ptab = penalty_table(plan.penalty)
-        nq = 1 if draws.constant else self.NQ_RING
+        nq = 1 if const_q else self.NQ_RING
         emb_all = emb.to(torch.float32).contiguous().to(dev)
         ids_all = inputs_ids.to(dev)
         temp_d = temperature.to(torch.float32).reshape(-1).to(dev)
@@ -404,12 +419,13 @@ class GptEngine:
         key = (tuple(bounds), T, max_new, nrow, V, nq, self.dtype, top_p_thr, plan.top_p is not None, int(plan.top_k or 0),
                plan.top_k is not None, int(min_new_token), int(eos_token), int(row_offset), bool(infer_text), stop_at is not None,
                ptab is not None, teacher_ids is not None, bool(return_sampled),
-               None if prefill_chunk is None else int(prefill_chunk))
+               None if prefill_chunk is None else int(prefill_chunk), device_rng, manual_seed is None)
         sess = self._session if (self._session is not None and self._session["key"] == key) else None
         if sess is None:
             self._session = None     # drop the previous session's buffers before allocating new ones
             sess = dict(key=key, lanes=[], graph=False, temp=torch.empty((nrow,), dtype=torch.float32, device=dev),
-                        ptab=None if ptab is None else torch.empty_like(ptab, device=dev), q_sig=None)
+                        ptab=None if ptab is None else torch.empty_like(ptab, device=dev), q_sig=None,
+                        seed=torch.zeros((1,), dtype=torch.int64, device=dev))
             for (lo, hi), (handle, st) in zip(bounds, res):
                 ln = Lane()
                 ln.lo, ln.hi, ln.handle, ln.st = lo, hi, handle, st
@@ -432,7 +448,7 @@ class GptEngine:
                     ln.workspace = torch.empty((ln.ws_bytes,), dtype=torch.uint8, device=dev)
                     ln.kv_start = torch.empty((Bl,), dtype=kv_start_all.dtype, device=dev)
                     ln.stop_d = None if stop_at is None else torch.empty((Bl,), dtype=torch.int32, device=dev)
-                    ln.q_d = torch.empty((nq, Bl * nrow, V), dtype=torch.float32, device=dev)
+                    ln.q_d = torch.empty((1,) if device_rng else (nq, Bl * nrow, V), dtype=torch.float32, device=dev)
                     ln.teacher = None if teacher_ids is None else torch.empty((Bl, max_new, nvq), dtype=torch.int64, device=dev)
                     ln.sampled = torch.zeros((Bl, max_new, nvq), dtype=torch.int64, device=dev) if return_sampled else None
                 s = _lib.GenState()
@@ -452,6 +468,7 @@ class GptEngine:
                 s.stop_at = _lib.ptr(ln.stop_d)
                 s.teacher_ids = _lib.ptr(ln.teacher)
                 s.sampled_ids = _lib.ptr(ln.sampled)
+                s.rng_device, s.rng_per_step, s.rng_seed = int(device_rng), int(manual_seed is None), sess["seed"].data_ptr()
                 # compaction order: utterances by descending context = ascending left padding (contexts of a batch differ only by
                 # the static valid prompt length), so the attention grid starts its longest units first.  CTTS_ORDER=0: ascending slot
                 s.order = ln.order.data_ptr() if os.environ.get("CTTS_ORDER", "1") != "0" else None
@@ -464,7 +481,7 @@ class GptEngine:
                 sess["lanes"].append(ln)
             self._session = sess
         L = sess["lanes"]
-        q_sig = (draws.total_rows, V, manual_seed, row_offset, B * nrow) if draws.constant else None
+        q_sig = (draws.total_rows, V, manual_seed, row_offset, B * nrow) if (draws is not None and draws.constant) else None
         for ln in L:
             lo, hi = ln.lo, ln.hi
             Bl = hi - lo
@@ -486,9 +503,11 @@ class GptEngine:
                     assert tuple(teacher_ids.shape) == (B, max_new, nvq)
                     ln.teacher.copy_(teacher_ids[lo:hi].to(torch.int64))
                 ln.emb = emb_all[lo:hi].contiguous()
-                if draws.constant and sess["q_sig"] != q_sig:
+                if draws is not None and draws.constant and sess["q_sig"] != q_sig:
                     ln.q_d[0].copy_(draws.step(0)[lo * nrow: hi * nrow])
                 if ln is L[0]:
+                    if device_rng:
+                        sess["seed"].fill_(seed_val)
                     sess["temp"].copy_(temp_d)
                     if ptab is not None:
                         sess["ptab"].copy_(ptab)
@@ -505,7 +524,7 @@ class GptEngine:
         # uploads are stream-ordered behind the launches that still read the ring half they overwrite (no host sync).
         half = nq // 2
         feeder = None
-        if not draws.constant:
+        if not const_q:
             from concurrent.futures import ThreadPoolExecutor
             feeder = dict(pool=ThreadPoolExecutor(max_workers=1), bufs=[torch.empty((half, B * nrow, V), dtype=torch.float32).pin_memory()
                                                                            for _ in range(2)],
@@ -669,7 +688,8 @@ class GptEngine:
                                          stream, show_tqdm, ensure_non_empty, stream_batch, manual_seed, context,
                                          use_graph=use_graph, stop_at=stop_at, row_offset=row_offset, total_rows=total_rows,
                                          profile_tag=profile_tag, profile_stride=profile_stride, lanes=lanes,
-                                         teacher_ids=teacher_ids, prefill_chunk=prefill_chunk, return_sampled=return_sampled)
+                                         teacher_ids=teacher_ids, prefill_chunk=prefill_chunk, return_sampled=return_sampled,
+                                         rng=rng, rng_seed=None)
             return  # gpt.py:570: the seeded case yields nothing
 
         graph_ok = use_graph and max_new > 1

@@ -134,6 +134,15 @@ typedef struct {
                                       is 0.  The host passes the utterances by descending context (the contexts of a batch differ
                                       only by the static valid prompt length), so the attention grid starts its longest
                                       (utterance, head) units first.  NULL = ascending slot.  No result depends on it. */
+  /* Opt-in DEVICE generator for the Exp(1) draws of the multinomial (code mode only).  The reference draws them from
+   * `torch.Generator(device=device)` (gpt.py:39,501-508): on its CPU path that is torch's CPU stream -- the parity contract, served
+   * by `q` above -- and on a GPU device its device stream.  With rng_device = 1 `q` is not read: the sampling kernel draws
+   * q = -log(u) itself from Philox4x32-10 keyed on rng_seed with counter (token / 4, global sampling row, step), so the default
+   * unseeded path needs no per-step host draw / upload.  rng_per_step = 1: a fresh draw every step (manual_seed = None);
+   * 0: the same draw every step (manual_seed set -- the reference re-seeds its generator at every step, gpt.py:504-507). */
+  int32_t rng_device;
+  int32_t rng_per_step;
+  const uint64_t* rng_seed;        /* DEVICE scalar (read by the kernel at every step, so a captured graph serves every seed) */
 } ctts_gen_state;
 
 int ctts_gpt_create(ctts_gpt** out, const ctts_gpt_weights* w);
@@ -323,6 +332,9 @@ int ctts_k_embed_codes(const float* emb_code, const int64_t* ids_buf, int32_t tc
 int ctts_k_final_norm(const float* x, int32_t q_per_b, const float* w, float eps, float* hfin, float* hiddens, int32_t max_new,
                       const int32_t* len, int32_t T, int32_t B, void* stream);
 int ctts_k_sample(const ctts_gen_state* s, const float* logits, void* stream);
+/* the device generator's Exp(1) draws (ctts_gen_state.rng_device) of sampling rows row0 .. row0+rows-1 at generation step `step`
+ * as a [rows, V] float32 tensor -- distribution tests */
+int ctts_k_exp_draws(uint64_t seed, int32_t step, int32_t row0, int32_t rows, int32_t V, float* out, void* stream);
 int ctts_k_dwconv_ln(const float* x, const float* w, const float* b, const float* ln_w, const float* ln_b, float eps, int32_t dil,
                      float* y, int32_t B, int32_t F, void* stream);
 int ctts_k_layernorm(const float* x, const float* w, const float* b, float eps, float* y, int32_t rows, void* stream);

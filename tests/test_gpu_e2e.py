@@ -929,3 +929,59 @@ def test_engines_on_a_non_current_device(weights):
         wav = cod.decode_to_wavs(out.hiddens)
     assert torch.isfinite(wav).all() and wav.device == d1
     assert torch.cuda.current_device() == 0
+
+
+def test_device_generator_mode(gpt_f32, weights):
+    """rng="device" (the sampling kernel draws the multinomial's Exp(1) variates itself; the reference on a GPU device uses the
+    device generator too, gpt.py:39).  manual_seed=None -- the reference's default -- is repeatable under torch.manual_seed (the
+    key is ONE draw from torch's global CPU generator) and differs between keys; a shard reproduces its rows of the full batch
+    (counter = global row); a seeded call repeats its draw at every step like the reference's re-seeded generator; SlotPool serves
+    unseeded requests and each equals its isolated generation."""
+    from chattts_amd.serving import SlotPool
+    B = 6
+    ids, mask, tmask = synth.make_prompts(B, 8, 14, seed=9)
+    ids_t, mask_t = torch.from_numpy(ids), torch.from_numpy(mask)
+    emb = gpt_f32.embed_prompt(ids_t, torch.from_numpy(tmask))
+    warpers, procs = E.gen_logits(625, 0.7, 20, 1.05)
+
+    def run(sl=slice(0, B), seed=None, **kw):
+        out = list(gpt_f32.generate(emb[sl], ids_t[sl], torch.tensor([0.3] * 4), 625, mask_t[sl], 40, 40, (*procs, *warpers),
+                                    return_hidden=False, manual_seed=seed, rng="device", row_offset=4 * sl.start, total_rows=4 * B, **kw))[-1]
+        return [t.cpu().numpy() for t in out.ids]
+
+    torch.manual_seed(77)
+    a = run()
+    state = torch.get_rng_state()
+    torch.manual_seed(77)
+    b = run()
+    assert all(np.array_equal(x, y) for x, y in zip(a, b)) and torch.equal(torch.get_rng_state(), state)
+    c = run()      # the global generator moved on: another key
+    assert any(not np.array_equal(x, y) for x, y in zip(a, c))
+    assert all(len(x) == 40 and x.min() >= 0 and x.max() < 625 for x in a)
+    # explicit key; shard [2, 5) == rows 2..4 of the full batch
+    full = run(rng_seed=4242)
+    part = run(slice(2, 5), rng_seed=4242)
+    assert all(np.array_equal(full[2 + i], part[i]) for i in range(3))
+    # unseeded = a fresh draw per step; seeded = the same draw at every step (so the two differ for the same key)
+    seeded = run(seed=4242)
+    assert any(not np.array_equal(x, y) for x, y in zip(full, seeded))
+    assert all(np.array_equal(x, y) for x, y in zip(seeded, run(seed=4242)))
+    # continuous batching without a seed
+    S = 3
+    pool = SlotPool(gpt_f32, slots=S, cap=96, hid_cap=48, manual_seed=None, rng="device", rng_seed=99)
+    rs = np.random.RandomState(8)
+    reqs = {}
+    for i, n in enumerate([6, 13, 9, 4, 11]):
+        T = int(rs.randint(5, 12))
+        rid = np.repeat(rs.randint(1, 21178, size=(T, 1)), 4, axis=1).astype(np.int64)
+        reqs[i] = (rid, n)
+        pool.submit(i, rid, max_new_token=32, stop_at=n)
+    got = {rid: t.cpu().numpy() for rid, t, _ in pool.run()}
+    for rid, (pid, n) in reqs.items():
+        p_t = torch.from_numpy(pid)[None]
+        e1 = gpt_f32.embed_prompt(p_t, torch.ones((1, pid.shape[0]), dtype=torch.bool))
+        ref = list(gpt_f32.generate(e1, p_t, torch.tensor([0.3] * 4), 625, None, 40, 0, (*procs, *warpers), manual_seed=None, rng="device",
+                                    rng_seed=99, stop_at=torch.tensor([n], dtype=torch.int32), row_offset=4 * pool.slot_of[rid],
+                                    total_rows=4 * S))[-1]
+        assert np.array_equal(got[rid], ref.ids[0].cpu().numpy()), rid
+    pool.close()

@@ -797,3 +797,78 @@ def test_istft(G, B, F):
     got = wav.cpu().numpy()
     assert got.shape == ref.shape
     assert np.abs(got - ref).max() < 5e-5 * max(1.0, np.abs(ref).max()), np.abs(got - ref).max()
+
+
+# ------------------------------------------------------------------------------------------------
+# opt-in device generator for the multinomial's Exp(1) draws (ctts_gen_state.rng_device)
+# ------------------------------------------------------------------------------------------------
+def _device_draws(seed, step, row0, rows, V=626):
+    lib = _lib.lib()
+    out = torch.empty((rows, V), dtype=torch.float32, device="cuda:0")
+    _lib.check(lib.ctts_k_exp_draws(seed, step, row0, rows, V, out.data_ptr(), None), "exp_draws")
+    torch.cuda.synchronize()
+    return out.cpu().numpy().astype(np.float64)
+
+
+def test_device_generator_draws_are_exp1(G):
+    """the sampling kernel's own generator (Philox4x32-10 -> u in (0,1] -> -log u): Kolmogorov-Smirnov against Exp(1) on 160k
+    draws, first two moments, and streams that differ by seed / step / row are distinct and uncorrelated"""
+    q = _device_draws(12345, 7, 0, 256)
+    x = np.sort(q.reshape(-1))
+    n = x.size
+    assert x[0] > 0 and np.isfinite(x).all()
+    cdf = 1.0 - np.exp(-x)
+    D = max(np.abs(cdf - np.arange(1, n + 1) / n).max(), np.abs(cdf - np.arange(0, n) / n).max())
+    assert D < 1.63 / np.sqrt(n), (D, 1.63 / np.sqrt(n))        # 1 % critical value of the KS statistic
+    assert abs(x.mean() - 1.0) < 0.01 and abs(x.var() - 1.0) < 0.03
+    for other in (_device_draws(12346, 7, 0, 256), _device_draws(12345, 8, 0, 256), _device_draws(12345, 7, 256, 256)):
+        assert not np.array_equal(other, q)
+        r = np.corrcoef(other.reshape(-1), q.reshape(-1))[0, 1]
+        assert abs(r) < 0.01, r
+    # prefix property in the row index (what keeps an N-way sharded batch equal to the unsharded one): rows 100..131 of a draw
+    # that starts at row 0 are the draw that starts at row 100
+    assert np.array_equal(_device_draws(12345, 7, 100, 32), q[100:132])
+    # neighbouring tokens of one row (the 4 outputs of one Philox call) are uncorrelated too
+    assert abs(np.corrcoef(q[:, 0::4].reshape(-1), q[:, 1::4][:, : q[:, 0::4].shape[1]].reshape(-1))[0, 1]) < 0.01
+
+
+def test_device_generator_token_histogram(G):
+    """chi-square of 102,400 tokens sampled with the device generator from ONE fixed distribution (top-8 of a fixed logits row,
+    temperature 1) against the exact softmax probabilities of the kept set: argmax(p / q) with q ~ Exp(1) IS a multinomial draw"""
+    lib = _lib.lib()
+    rs = np.random.RandomState(4)
+    row = (rs.standard_normal(626) * 2.0).astype(f32)
+    B, steps, V = 256, 100, 626
+    logits = np.tile(row, (B * 4, 1))
+    keep = []
+    d = lambda a: (keep.append(G.dev(a)), keep[-1])[1]
+    T, tcap = 1, 1 + steps + 1
+    s = _lib.GenState()
+    s.B, s.T, s.max_new = B, T, steps + 1
+    ids_d = d(np.zeros((B, tcap, 4), np.int64))
+    len_d, fin_d, end_d = d(np.full(B, T, np.int32)), d(np.zeros(B, np.uint8)), d(np.zeros(B, np.int32))
+    s.ids_buf, s.len, s.finish, s.end_idx = ids_d.data_ptr(), len_d.data_ptr(), fin_d.data_ptr(), end_d.data_ptr()
+    s.q, s.nq = None, 0
+    s.rng_device, s.rng_per_step, s.rng_seed = 1, 1, d(np.array([987654321], np.int64)).data_ptr()
+    s.temperature = d(np.ones(4, f32)).data_ptr()
+    s.pow_table = None
+    s.top_p_thr, s.use_top_p, s.top_k, s.use_top_k = 0.0, 0, 8, 1
+    s.min_new, s.eos, s.row_offset = steps + 5, 625, 0        # EOS masked throughout: nothing finishes
+    lg = d(logits.reshape(B, 4 * V))
+    for _ in range(steps):
+        _lib.check(lib.ctts_k_sample(C.byref(s), lg.data_ptr(), None), "sample")
+    torch.cuda.synchronize()
+    toks = ids_d.cpu().numpy()[:, T: T + steps, :].reshape(-1)
+    top = np.argsort(-row.astype(np.float64), kind="stable")[:8]
+    top = top[top != 625][:8]
+    assert set(np.unique(toks)) <= set(top.tolist())
+    p = np.exp(row[top].astype(np.float64) - row[top].max())
+    p /= p.sum()
+    obs = np.array([(toks == t).sum() for t in top], np.float64)
+    exp = p * toks.size
+    chi2 = float(((obs - exp) ** 2 / exp).sum())
+    print("device generator chi2 (7 dof):", chi2, obs.astype(int).tolist())
+    assert toks.size == B * 4 * steps and chi2 < 24.3, chi2        # 0.1 % critical value at 7 degrees of freedom
+    # per-step freshness: consecutive steps of one row are not the same token stream shifted / repeated
+    t0 = ids_d.cpu().numpy()[:, T: T + steps, 0]
+    assert (t0[:, 1:] != t0[:, :-1]).mean() > 0.5

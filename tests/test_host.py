@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_ctypes_signatures_match_the_header_prototypes():
     """every prototype of include/chattts_amd.h against chattts_amd/_lib.py SIGNATURES: same number of parameters, and each
-    parameter of the same class (pointer / int32 / float / size_t / int64) -- a prototype edited on one side only fails on CPU"""
+    parameter of the same class (pointer / int32 / float / size_t = uint64 (one ctypes type on LP64) / int64) -- a prototype edited on one side only fails on CPU"""
     hdr = open(os.path.join(ROOT, "include", "chattts_amd.h")).read()
     hdr = re.sub(r"/\*.*?\*/", " ", hdr, flags=re.S)
     protos = re.findall(r"\b(?:int|size_t|void|const char\*|int32_t)\s+(ctts_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.S)
@@ -39,7 +39,7 @@ def test_ctypes_signatures_match_the_header_prototypes():
             return ""
         if "*" in param:
             return "ptr"
-        for t, k in (("int32_t", "i32"), ("int64_t", "i64"), ("size_t", "size"), ("float", "f32"), ("int", "i32")):
+        for t, k in (("int32_t", "i32"), ("uint64_t", "size"), ("int64_t", "i64"), ("size_t", "size"), ("float", "f32"), ("int", "i32")):
             if re.match(rf"(const )?{t}\b", param):
                 return k
         raise AssertionError(f"unclassified parameter {param!r}")
