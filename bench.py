@@ -334,7 +334,7 @@ def main():
         return {3: float(np.mean(ctx)) * 2 * 768 * es_ + live * 768 * (4 + es_),
                 1: 3 * 768 * 768 * es_ + live * (768 * es_ + 2304 * 4), 4: 768 * 768 * es_ + live * 768 * (es_ + 8 + es_),
                 5: 2 * 3072 * 768 * es_ + live * (768 + 3072) * es_, 6: 768 * 3072 * es_ + live * (3072 * es_ + 768 * (8 + es_)),
-                8: 2504 * 768 * 4 + live * (768 + 2504) * 4, 9: live * 4 * 626 * 8, 0: live * (4 * 3072 + 3072 + 1536), 7: live * 768 * 12}
+                8: 2504 * 768 * 4 + live * (768 * 4 * 2 + 2504 * 4), 9: live * 4 * 626 * 8, 0: live * (4 * 3072 + 3072 + 1536), 7: live * 768 * 12}
 
     def roofline_leg(eng, es_, tags, n_steps, step_ms, pmc_key_suffix=""):
         """HIP start/stop events of sampled launches (hipExtLaunchKernel, on the launch stream; events created without the
@@ -345,6 +345,7 @@ def main():
             calls = GPT.n_layers if tag in (1, 3, 4, 5, 6) else 1
             one_pass(eng, use_graph=False, profile_tag=tag, profile_stride=1 if calls == 1 else 5, decode_audio=False)
             per_tag[tag] = eng.last_stats.get("profile", (0, 0.0))
+        per_tag = {t: v for t, v in per_tag.items() if v[0] > 0}   # e.g. final_norm: fused into the heads launch on the packed decode path
         calls_per_step = {t: (GPT.n_layers if t in (1, 3, 4, 5, 6) else 1) for t in per_tag}
         avg_us = {t: 1e3 * per_tag[t][1] / max(1, per_tag[t][0]) for t in per_tag}
         alg = alg_bytes(es_, n_steps)

@@ -38,6 +38,7 @@ struct ctts_gpt {
   bool dec_packed = false;     // perf mode (bf16 weights): decode.hip
   bool dec_packed32 = false;   // parity mode (f32 weights): decode32.hip
   bool heads_packed = false;   // heads GEMM on packed f32 operands (decode32.hip), both modes
+  bool fnorm_fuse = true;      // decode: final norm + hidden capture + heads in one launch (env CTTS_FNORM_FUSE=0: separate launches)
   std::vector<const float*> ln1, ln2;
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
@@ -127,6 +128,7 @@ extern "C" int ctts_gpt_create(ctts_gpt** out, const ctts_gpt_weights* w) {
   }
   { const char* e = getenv("CTTS_DEC_PACKED"); g->heads_packed = w->heads_pk != nullptr && !(e && atoi(e) == 0); }
   { const char* e = getenv("CTTS_SKIP_FINISHED"); if (e && atoi(e) == 0) g->skip_finished = false; }
+  { const char* e = getenv("CTTS_FNORM_FUSE"); if (e && atoi(e) == 0) g->fnorm_fuse = false; }
   {
     int dev = 0, cus = 0;
     // OFF by default: measured on the C3 bench it does not pay (attention 9.3 -> 9.8 us per launch, 1296 -> 1280 audio-s/s,
@@ -235,6 +237,11 @@ static int run_step(ctts_gpt* g, const ctts_gen_state* s, int q_per_b, hipStream
   if (dec) rm.desc = ws.desc;                          // written by the embedding kernel at the head of the step
   if (dec && dev_compact(g, s)) rm.desc_covers_all = 1; // ... for every row of the grid (absent rows: b = -1)
   if (packed && g->n_cu > 0) { rm.sp_part = ws.att_part; rm.sp_cnt = ws.att_cnt; rm.sp_cus = g->n_cu; }
+  // decode on packed operands: final RMSNorm + hidden capture + heads are ONE launch (decode32.hip gemm_dec32_fnorm16_k; the residual
+  // stream reaches it in the packed f32 order: parity mode keeps it that way anyway, perf mode has the last down_proj write it)
+  const bool packed32_ = !fast && dec && g->dec_packed32;
+  const bool fuse_fnorm = dec && heads && g->fnorm_fuse && g->heads_packed && (packed || packed32_) &&
+                          (s->infer_text ? g->w.head_text_pk : g->w.heads_pk) != nullptr;
   for (int l = 0; packed && l < g->w.n_layers; ++l) {
     void* kc = (char*)s->kcache + kv_layer * l;
     void* vc = (char*)s->vcache + kv_layer * l;
@@ -255,6 +262,7 @@ static int run_step(ctts_gpt* g, const ctts_gen_state* s, int q_per_b, hipStream
     { Prof p(g, 5, st, prof_ok); CK(launch_gemm_dec(d, st)); }
     d.Ap = ws.actp; d.Wp = (const uint16_t*)g->wd_pk[l]; d.N = HID; d.K = INTER; d.ssq_in = nullptr; d.epi = FEPI_RES; d.C32 = ws.x;
     d.ldc = HID; d.Cp = ws.xp; d.kch_out = HID / 32; d.ssq_out = ws.ssq;
+    d.Cp32 = (fuse_fnorm && l == g->w.n_layers - 1) ? ws.xp32 : nullptr;   // operand of the fused final-norm + heads launch
     { Prof p(g, 6, st, prof_ok); CK(launch_gemm_dec(d, st)); }
   }
   for (int l = 0; fast && !packed && l < g->w.n_layers; ++l) {
@@ -336,6 +344,17 @@ static int run_step(ctts_gpt* g, const ctts_gen_state* s, int q_per_b, hipStream
     { Prof p(g, 6, st, prof_ok); CK(launch_gemm_skinny(a, st)); }
   }
   if (!heads) return 0;   // a prompt chunk that is not the last one: its K/V rows are in the cache, nothing is sampled
+  if (fuse_fnorm) {
+    const int nlog = s->infer_text ? g->w.n_text : NVQ * NAUDIO;
+    Dec32Args d;
+    memset(&d, 0, sizeof(d));
+    d.Ap = ws.xp32; d.Wp = s->infer_text ? g->w.head_text_pk : g->w.heads_pk; d.M = B; d.N = (nlog + 15) / 16 * 16; d.K = HID; d.n_active = nact;
+    d.epi = EPI_STORE; d.C = ws.logits; d.ldc = nlog; d.n_cols = nlog;
+    d.fnorm = 1; d.norm_w = g->w.norm; d.eps = g->w.rms_eps; d.desc = ws.desc; d.hid = s->hiddens; d.hid_cap = s->hid_cap ? s->hid_cap : s->max_new;
+    d.T = s->T; d.prompt_len = s->prompt_len;
+    Prof p(g, 8, st, prof_ok);
+    CK(launch_gemm_dec32(d, st));
+  } else {
   { Prof p(g, 7, st, prof_ok);
     CK(launch_final_norm(ws.x, q_per_b, g->w.norm, g->w.rms_eps, ws.hfin, s->hiddens, s->hid_cap ? s->hid_cap : s->max_new, s->len, s->T, B, rmap,
                          nact, s->prompt_len, st, ws.hfinp)); }
@@ -358,6 +377,7 @@ static int run_step(ctts_gpt* g, const ctts_gen_state* s, int q_per_b, hipStream
     Prof p(g, 8, st, prof_ok);
     CK(launch_gemm_skinny(a, st));
     }
+  }
   }
   {
     Prof p(g, 9, st, prof_ok);

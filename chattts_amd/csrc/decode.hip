@@ -179,6 +179,7 @@ __device__ __forceinline__ void dec_body(const DecGemmArgs& a, const int M, cons
         xn = pre0[q] + v;
         a.C32[(size_t)row * a.ldc + col] = xn;
         a.Cp[pk_off(row, col, a.kch_out)] = f32_to_bf16(xn);
+        if (a.Cp32 != nullptr) a.Cp32[pk32_off(row, col, 768 / 16)] = xn;
       }
       float sq = xn * xn;
       sq += __shfl_xor(sq, 1, 64);

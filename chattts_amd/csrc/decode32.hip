@@ -500,6 +500,110 @@ __global__ __launch_bounds__(256, 3) void gemm_dec32_rms16_k(Dec32Args a) {
   }
 }
 
+// FINAL RMSNorm + hidden capture + heads in ONE launch (decode step, both numeric modes; replaces final_norm_k + the m16 heads
+// launch).  Reference ops: `hidden_states = outputs.last_hidden_state` after LlamaModel's final norm, `hiddens.append(hidden_states[:, -1])`
+// and the four weight-normed heads (gpt.py:430-454).  16-row workgroups like gemm_dec32_rms16_k: the workgroup holds its row tile's whole
+// 16 x 768 UN-normalised residual as MFMA fragments, so the statistics come from the fragments -- but in final_norm_k's association,
+// not wave_row_rstd's, because the goldens of the parity mode were established with final_norm_k: thread t of that kernel owns columns
+// 4t..4t+3, wave W = t / 64 butterflies its 64 partial sums (xor 32, 16, 8, 4, 2, 1) and the three wave sums are added (P0 + P1) + P2.
+// Column 4t sits in chunk c = t / 4, lane group g = t % 4; chunk c = 4 i + w belongs to wave w as its i-th chunk, so t = 16 i + 4 w + g:
+// W = i / 4 (this wave's chunks 0-3, 4-7, 8-11) and the butterfly index is l = 16 (i % 4) + 4 w + g -- levels 32 and 16 are adds
+// between the lane's own four partials of a block (i ^ 2, then i ^ 1), levels 8 and 4 adds across the four waves (w ^ 2, then w ^ 1,
+// through LDS), levels 2 and 1 adds across lane groups (lane ^ 32, then lane ^ 16).  Same operands, same association, same bits as
+// final_norm_k; the scaled fragment g[k] * (x * rstd) IS the hidden state, and the workgroups of weight tile 0 store it.
+__global__ __launch_bounds__(256, 3) void gemm_dec32_fnorm16_k(Dec32Args a) {
+  constexpr int KCH = 48, NPER = 12, WU = 6;
+  __shared__ __attribute__((aligned(16))) float red[4][64][4];
+  __shared__ float bs[3][4][64];
+  CTTS_PROBE_RETURN();
+
+  const int tile = blockIdx.x, mt0 = blockIdx.y;
+  if (tile >= (a.N >> 4)) return;   // the grid's x extent is rounded up to a multiple of 8 (one XCD per weight tile, see dec32_dispatch_m16)
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 15, g = lane >> 4;
+  const int n0 = tile * 16, m0 = mt0 * 16;
+  const u128* wp = reinterpret_cast<const u128*>(a.Wp) + ((size_t)tile * KCH + wave) * 64 + lane;   // wave w owns chunks 4 i + w
+  const u128* ap = reinterpret_cast<const u128*>(a.Ap) + ((size_t)mt0 * KCH + wave) * 64 + lane;
+  const bool w_once = a.w_nt && gridDim.y == 1;
+  u128 wf[WU], af[NPER];
+  float4 nw[WU];
+  auto load_w = [&](const int i0) {
+    if (w_once) {
+#pragma unroll
+      for (int j = 0; j < WU; ++j) wf[j] = load16_nt(wp + (size_t)(i0 + j) * 256);
+    } else {
+#pragma unroll
+      for (int j = 0; j < WU; ++j) wf[j] = load16(wp + (size_t)(i0 + j) * 256);
+    }
+#pragma unroll
+    for (int j = 0; j < WU; ++j) nw[j] = *reinterpret_cast<const float4*>(a.norm_w + ((i0 + j) * 4 + wave) * 16 + g * 4);
+  };
+  // everything the workgroup can ask for without knowing the live-row count (its row tile's buffer exists either way)
+#pragma unroll
+  for (int i = 0; i < NPER; ++i) af[i] = load16(ap + (size_t)i * 256);
+  load_w(0);
+  const int M = a.n_active ? min(*a.n_active, a.M) : a.M;
+  if (m0 >= M) return;
+  // hidden capture (weight tile 0 only): where row li of this tile goes
+  const bool cap = tile == 0 && a.hid != nullptr;
+  RowDesc rd = RowDesc{-1, 0, 0, 0};
+  int plen = a.T;
+  if (cap && m0 + li < M) {
+    rd = a.desc[m0 + li];
+    if (a.prompt_len != nullptr && rd.b >= 0) plen = a.prompt_len[rd.b];
+  }
+
+  // 1 / rms of row li, final_norm_k's arithmetic (see above)
+  float rs;
+  {
+#pragma clang fp contract(off)
+    float b3[3];
+#pragma unroll
+    for (int B = 0; B < 3; ++B) {
+      const float s0 = rms_acc4(0.f, *reinterpret_cast<const float4*>(&af[4 * B + 0]));
+      const float s1 = rms_acc4(0.f, *reinterpret_cast<const float4*>(&af[4 * B + 1]));
+      const float s2 = rms_acc4(0.f, *reinterpret_cast<const float4*>(&af[4 * B + 2]));
+      const float s3 = rms_acc4(0.f, *reinterpret_cast<const float4*>(&af[4 * B + 3]));
+      b3[B] = (s0 + s2) + (s1 + s3);                              // butterfly levels 32, 16
+      bs[B][wave][lane] = b3[B];
+    }
+    __syncthreads();
+    float P[3];
+#pragma unroll
+    for (int B = 0; B < 3; ++B) {
+      const float c = (bs[B][wave][lane] + bs[B][wave ^ 2][lane]) + (bs[B][wave ^ 1][lane] + bs[B][wave ^ 3][lane]);   // levels 8, 4
+      const float e = c + __shfl_xor(c, 32, 64);                  // level 2
+      P[B] = e + __shfl_xor(e, 16, 64);                           // level 1
+    }
+    rs = rms_rstd_of((P[0] + P[1]) + P[2], 768, a.eps);
+  }
+
+  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int gen = rd.slot + 1 - plen;
+  float* hrow = (cap && rd.b >= 0 && gen >= 0 && gen < a.hid_cap) ? a.hid + ((size_t)rd.b * a.hid_cap + gen) * 768 + g * 4 : nullptr;
+#pragma unroll
+  for (int i0 = 0; i0 < NPER; i0 += WU) {
+    if (i0 > 0) load_w(i0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < WU; ++j) {
+      float4 a0 = *reinterpret_cast<const float4*>(&af[i0 + j]);
+      a0.x = nw[j].x * (a0.x * rs); a0.y = nw[j].y * (a0.y * rs); a0.z = nw[j].z * (a0.z * rs); a0.w = nw[j].w * (a0.w * rs);
+      if (hrow != nullptr) *reinterpret_cast<float4*>(hrow + ((i0 + j) * 4 + wave) * 16) = a0;   // the step's hidden state
+      const float4 b = *reinterpret_cast<const float4*>(&wf[j]);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b.w, acc, 0, 0, 0);
+    }
+  }
+  *reinterpret_cast<f32x4*>(&red[wave][lane][0]) = acc;
+  __syncthreads();
+  const int row = m0 + 4 * g + wave, col = n0 + li;   // C/D map: col = lane & 15, row = 4 (lane >> 4) + register (= wave here)
+  const float v = ((red[0][lane][wave] + red[1][lane][wave]) + red[2][lane][wave]) + red[3][lane][wave];   // fixed order
+  if (row < M && col < a.n_cols) a.C[(size_t)row * a.ldc + col] = v;
+}
+
 template <int KT>
 static hipError_t dec32_dispatch_m16(const Dec32Args& a, hipStream_t st) {
   // x extent a multiple of 8: workgroup (tile, row tile) then runs on XCD tile % 8 for EVERY row tile, so a weight tile is fetched
@@ -551,13 +655,20 @@ hipError_t launch_gemm_dec32(const Dec32Args& a_in, hipStream_t st) {
   if (a.n_cols <= 0 || a.n_cols > a.N) a.n_cols = a.N;
   // K: chunks of 16, 4 waves, rounds of D32_U chunks
   if (a.M <= 0 || a.N <= 0 || (a.N & 15) || a.K % (16 * 4 * D32_U) != 0) return hipErrorInvalidValue;
-  if (a.norm_w != nullptr && (a.X == nullptr || (a.ldx & 3))) return hipErrorInvalidValue;
+  if (!a.fnorm && a.norm_w != nullptr && (a.X == nullptr || (a.ldx & 3))) return hipErrorInvalidValue;
   if (a.epi == D32_EPI_QKV_ROPE && (a.N != 2304 || a.K != 768 || !a.desc || !a.kc || !a.vc)) return hipErrorInvalidValue;
   // Rows per workgroup.  f32 MFMA (256 flop per clock and CU) is what these launches are made of -- 64 x 2304 x 768 costs 3.5k
   // clocks of every CU if perfectly spread -- so the row tiles are cut until the grid has a few workgroups per CU; the 16-row
   // workgroups of o / down (48 weight tiles only) are the same choice the bf16 kernel makes.
   int mb = a.epi == EPI_SILU_MUL ? mb_silu : a.epi == EPI_RES ? (a.K > 768 ? mb_down : mb_o) : mb_qkv;
   if (a.force_mb) mb = a.force_mb;
+  if (a.fnorm) {   // final RMSNorm + hidden capture + heads (decode step)
+    if (a.norm_w == nullptr || a.K != 768 || a.epi != EPI_STORE || (a.hid != nullptr && a.desc == nullptr)) return hipErrorInvalidValue;
+    g_d32_variant = "fnorm16";
+    dim3 grid((a.N / 16 + 7) / 8 * 8, (a.M + 15) / 16), block(256);
+    CTTS_LAUNCH(gemm_dec32_fnorm16_k, grid, block, st, a);
+    return hipGetLastError();
+  }
   // 16-row RMSNorm launches (QKV, gate/up): statistics from the fragments, no re-read of the residual rows
   static int rms16 = -1;   // CTTS_D32_RMS16=0: the generic body (statistics from the row-major rows) instead (A/B)
   if (rms16 < 0) rms16 = env_int32("CTTS_D32_RMS16", 1);

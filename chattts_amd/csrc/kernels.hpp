@@ -136,6 +136,8 @@ struct DecGemmArgs {
   int epi;                      // FastEpi
   float* C32; int ldc;          // QKV_ROPE: f32 qkv buffer; RES: f32 residual, updated in place
   uint16_t* Cp; int kch_out;    // packed bf16 output (RES: new residual, SILU: activation) with kch_out = columns / 32
+  float* Cp32;                  // RES, optional: the new residual once more in the packed f32 order of decode32.hip (pk32_off, 768 / 16
+                                // chunks): the last layer's down_proj feeds the fused final-norm + heads launch with it
   float* ssq_out;               // RES: [M,48]
   const RowDesc* desc;          // QKV_ROPE
   const float* cos_t; const float* sin_t;
@@ -170,6 +172,13 @@ struct Dec32Args {
   int force_mb;                 // tests only
   int w_nt;                     // set by the launcher
   int a_early;                  // set by the launcher (CTTS_D32_A_EARLY): first activation round requested before the RMSNorm prologue
+  // FINAL-NORM fusion (decode heads, both modes): with `fnorm` the launch is `final RMSNorm -> hidden capture -> heads` in one kernel:
+  // Ap = the UN-normalised residual stream (packed f32), norm_w = the final norm's gain, the row statistics are final_norm_k's
+  // (gpt.hip) bit for bit, taken from the fragments; workgroups of weight tile 0 also write the normalised rows -- the step's hidden
+  // states (gpt.py:430-436) -- to hid[desc[row].b][gen] with gen = desc[row].slot + 1 - (prompt_len ? prompt_len[b] : T)
+  int fnorm;
+  float* hid; int hid_cap;      // [slots, hid_cap, 768] or null
+  int T; const int32_t* prompt_len;
 };
 enum { D32_EPI_QKV_ROPE = 100 };
 hipError_t launch_gemm_dec32(const Dec32Args& a, hipStream_t st);

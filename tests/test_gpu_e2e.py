@@ -985,3 +985,22 @@ def test_device_generator_mode(gpt_f32, weights):
                                     total_rows=4 * S))[-1]
         assert np.array_equal(got[rid], ref.ids[0].cpu().numpy()), rid
     pool.close()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_fused_final_norm_heads_is_bit_identical(weights, golden, monkeypatch, dtype):
+    """decode step: final RMSNorm + hidden capture + heads as ONE launch (decode32.hip gemm_dec32_fnorm16_k: row statistics from the
+    MFMA fragments in final_norm_k's association) vs the separate final_norm_k + heads launches (CTTS_FNORM_FUSE=0): token ids AND
+    the captured hidden states are bit-identical, in both numeric modes (rows finishing at different steps, left padding)."""
+    c = cases.GEN_CASES["b8"]
+    fused = E.GptEngine(weights["gpt"], weights["embed"], DEV, dtype=dtype)
+    a, _ = run_case(fused, c, use_graph=True)
+    monkeypatch.setenv("CTTS_FNORM_FUSE", "0")
+    sep = E.GptEngine(weights["gpt"], weights["embed"], DEV, dtype=dtype)
+    monkeypatch.delenv("CTTS_FNORM_FUSE")
+    b, _ = run_case(sep, c, use_graph=True)
+    assert len(a[-1].ids) == len(b[-1].ids) == 8
+    for x, y in zip(a[-1].ids, b[-1].ids):
+        assert torch.equal(x, y)
+    for x, y in zip(a[-1].hiddens, b[-1].hiddens):
+        assert x.shape == y.shape and torch.equal(x, y)
