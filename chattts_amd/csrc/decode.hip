@@ -31,7 +31,7 @@ template <int NMB, int MBT, int NW, bool SCALE, int EPI>
 __device__ __forceinline__ void dec_body(const DecGemmArgs& a, const int M, const int tile, const int mt0,
                                          u128 (&wf)[(EPI == FEPI_SILU) ? 2 : 1][DEC_U],
                                          float (*red)[(EPI == FEPI_SILU) ? 2 : 1][MBT][64][4], float* rstd_s,
-                                         float (*cs_s)[16], int (*meta_s)[2]) {
+                                         float (*cs_s)[16], int (*meta_s)[2], const u128 (&af0)[DEC_U], const bool a_pre) {
   constexpr int NACC = (EPI == FEPI_SILU) ? 2 : 1;
   constexpr int U = DEC_U;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -101,10 +101,15 @@ __device__ __forceinline__ void dec_body(const DecGemmArgs& a, const int M, cons
         }
       }
     }
+    if (NMB == 1 && a_pre && i == 0) {   // small batches: row tile 0's fragments were requested at kernel entry
 #pragma unroll
-    for (int mb = 0; mb < NMB; ++mb)
+      for (int j = 0; j < U; ++j) af[0][j] = af0[j];
+    } else {
 #pragma unroll
-      for (int j = 0; j < U; ++j) af[mb][j] = load16(ap + ((size_t)mb * KCH + i + j) * 64);
+      for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+        for (int j = 0; j < U; ++j) af[mb][j] = load16(ap + ((size_t)mb * KCH + i + j) * 64);
+    }
     // every load of the round in flight before the first MFMA (hipcc otherwise sinks each load next to its use)
     __builtin_amdgcn_sched_barrier(0);
     if (i == 0) STAMP(2);
@@ -222,10 +227,19 @@ void gemm_dec_k(DecGemmArgs a) {
   // The weight fragments of the first round do not depend on anything but the kernel arguments: request them before
   // the live-row count (a dependent scalar load) is known.  Decode weights are read by one row group (<= 64 live
   // rows with MBT = 4; the 16-row workgroups of o/down re-read them from L2), streamed non-temporal when so.
-  u128 wf[NACC][DEC_U];
+  u128 wf[NACC][DEC_U], af0[DEC_U];
   const bool is_helper = EPI == FEPI_QKV_ROPE && (threadIdx.x >> 6) == NW;
+  // Batches of <= 16 utterances (BASELINE C2: batch 1) are ONE row tile whose buffer exists whatever the live count is: its
+  // activation fragments are requested here too, so the kernel's critical path is one memory round trip (weights || activations)
+  // instead of live-count -> activations.  (With more row tiles this measured slower: profiles/r2d_*, r2v_*.)
+  const bool a_pre = a.a_early && a.M <= 16 && blockIdx.y == 0;
   if (!is_helper) {
     const int KCH = a.K >> 5, nper = KCH / NW, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (a_pre) {
+      const u128* ap0 = reinterpret_cast<const u128*>(a.Ap) + ((size_t)wave * nper) * 64 + lane;
+#pragma unroll
+      for (int j = 0; j < DEC_U; ++j) af0[j] = load16(ap0 + (size_t)j * 64);
+    }
     const u128* wp = reinterpret_cast<const u128*>(a.Wp) + ((size_t)tile * KCH + wave * nper) * 64 + lane;
     const u128* wp2 = wp + (size_t)(a.N >> 4) * KCH * 64;
     const bool w_once = a.w_nt && gridDim.y == 1;
@@ -268,15 +282,15 @@ void gemm_dec_k(DecGemmArgs a) {
   }
 
   if constexpr (MBT == 1) {
-    dec_body<1, MBT, NW, SCALE, EPI>(a, M, tile, mt0, wf, red, rstd_s, cs_s, meta_s);
+    dec_body<1, MBT, NW, SCALE, EPI>(a, M, tile, mt0, wf, red, rstd_s, cs_s, meta_s, af0, a_pre);
   } else if constexpr (MBT == 2) {
-    if (nmb == 1) dec_body<1, MBT, NW, SCALE, EPI>(a, M, tile, mt0, wf, red, rstd_s, cs_s, meta_s);
-    else dec_body<2, MBT, NW, SCALE, EPI>(a, M, tile, mt0, wf, red, rstd_s, cs_s, meta_s);
+    if (nmb == 1) dec_body<1, MBT, NW, SCALE, EPI>(a, M, tile, mt0, wf, red, rstd_s, cs_s, meta_s, af0, a_pre);
+    else dec_body<2, MBT, NW, SCALE, EPI>(a, M, tile, mt0, wf, red, rstd_s, cs_s, meta_s, af0, a_pre);
   } else {
-    if (nmb == 1) dec_body<1, MBT, NW, SCALE, EPI>(a, M, tile, mt0, wf, red, rstd_s, cs_s, meta_s);
-    else if (nmb == 2) dec_body<2, MBT, NW, SCALE, EPI>(a, M, tile, mt0, wf, red, rstd_s, cs_s, meta_s);
-    else if (nmb == 3) dec_body<3, MBT, NW, SCALE, EPI>(a, M, tile, mt0, wf, red, rstd_s, cs_s, meta_s);
-    else dec_body<4, MBT, NW, SCALE, EPI>(a, M, tile, mt0, wf, red, rstd_s, cs_s, meta_s);
+    if (nmb == 1) dec_body<1, MBT, NW, SCALE, EPI>(a, M, tile, mt0, wf, red, rstd_s, cs_s, meta_s, af0, a_pre);
+    else if (nmb == 2) dec_body<2, MBT, NW, SCALE, EPI>(a, M, tile, mt0, wf, red, rstd_s, cs_s, meta_s, af0, a_pre);
+    else if (nmb == 3) dec_body<3, MBT, NW, SCALE, EPI>(a, M, tile, mt0, wf, red, rstd_s, cs_s, meta_s, af0, a_pre);
+    else dec_body<4, MBT, NW, SCALE, EPI>(a, M, tile, mt0, wf, red, rstd_s, cs_s, meta_s, af0, a_pre);
   }
 }
 
@@ -308,13 +322,15 @@ static hipError_t dec_dispatch_k3072(const DecGemmArgs& a, hipStream_t st) {
 
 hipError_t launch_gemm_dec(const DecGemmArgs& a_in, hipStream_t st) {
   DecGemmArgs a = a_in;
-  static int nt = -1, mb_qkv = -1, mb_silu = -1, mb_o = -1, mb_down = -1;
+  static int nt = -1, mb_qkv = -1, mb_silu = -1, mb_o = -1, mb_down = -1, a_early = 1;
   if (nt < 0) {
     nt = env_int("CTTS_W_NT", 1);
+    a_early = env_int("CTTS_DEC_A_EARLY", 1);
     mb_qkv = env_int("CTTS_DEC_MB_QKV", 4); mb_silu = env_int("CTTS_DEC_MB_SILU", 4);
     mb_o = env_int("CTTS_DEC_MB_O", 1); mb_down = env_int("CTTS_DEC_MB_DOWN", 1);
   }
   a.w_nt = nt;
+  a.a_early = a_early;
   if (a.M <= 0 || a.N <= 0 || (a.N & 15) || !(a.K == 768 || a.K == 3072)) return hipErrorInvalidValue;
   if (a.epi == FEPI_RES && a.N != 16 * SSQ_PARTS) return hipErrorInvalidValue;
   if (a.epi == FEPI_QKV_ROPE && (a.N != 2304 || a.K != 768 || !a.desc)) return hipErrorInvalidValue;

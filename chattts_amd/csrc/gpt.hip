@@ -616,8 +616,9 @@ hipError_t launch_attention(const float* qkv, const void* kcache, const void* vc
   // CTTS_ATT_LDS=<bytes>: dynamic LDS the decode attention workgroups declare (and never touch).  It bounds the workgroups a CU
   // holds at once (160 KiB / bytes), which turns the dispatcher into a greedy list scheduler: with the rows ordered by descending
   // context (ctts_gen_state.order) the longest units start first and the short ones fill the CUs that free up.  0 = no bound.
-  static int att_lds = -1;
+  static int att_lds = -1, att_small_m = 5;
   if (att_lds < 0) {
+    { const char* e2 = getenv("CTTS_ATT_SMALL_M"); if (e2) att_small_m = atoi(e2); }   // batches up to this many rows: 16-wave units (0 = never)
     const char* e = getenv("CTTS_ATT_LDS");
     att_lds = e ? atoi(e) : 0;
     if (att_lds > 65536) {
@@ -630,6 +631,12 @@ hipError_t launch_attention(const float* qkv, const void* kcache, const void* vc
     if (rm.sp_cus > 0 && rm.sp_part != nullptr && rm.sp_cnt != nullptr)
       CTTS_LAUNCH((attention_k<bf16_t, 4, bf16_t, true, true>), dim3(NHEAD * M + rm.sp_cus), dim3(256), st, qkv, (const bf16_t*)kcache,
                   (const bf16_t*)vcache, cmax, (bf16_t*)out, rm);
+    else if (M <= att_small_m)
+      // tiny batches (BASELINE C2: batch 1 = 12 units on 256 CUs): a unit is one CU's job and a CU's stream is bounded by what it has
+      // in flight (4 waves x 16 KiB per round trip), so 16 waves per unit -- a long context in ONE round trip instead of three.
+      // (Static choice by batch size: perf-mode results of a batch of <= att_small_m utterances may differ in the last bf16 bit
+      // from the same utterances inside a bigger batch; the f32 parity mode never takes this path.)
+      CTTS_LAUNCH((attention_k<bf16_t, 16, bf16_t, true>), grid, dim3(1024), st, qkv, (const bf16_t*)kcache, (const bf16_t*)vcache, cmax, (bf16_t*)out, rm);
     else
       CTTS_LAUNCH_SMEM((attention_k<bf16_t, 4, bf16_t, true>), grid, dim3(256), att_lds, st, qkv, (const bf16_t*)kcache, (const bf16_t*)vcache, cmax, (bf16_t*)out, rm);
     return hipGetLastError();

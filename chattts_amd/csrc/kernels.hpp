@@ -144,6 +144,7 @@ struct DecGemmArgs {
   uint16_t* kc; uint16_t* vc; int cmax;
   int force_mb;                 // tests only
   int w_nt;                     // set by the launcher
+  int a_early;                  // set by the launcher (CTTS_DEC_A_EARLY): batches of <= 16 rows request their activation tile at entry
   long long* dbg;               // probes only (tools/dec_phase_probe.py): [n_workgroups][8] phase stamps, or null
 };
 hipError_t launch_gemm_dec(const DecGemmArgs& a, hipStream_t st);

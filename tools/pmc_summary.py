@@ -28,6 +28,8 @@ def short(name):
     EPI 3 = QKV+RoPE, 2 = SiLU gate/up, 1 = residual (NW 4: o_proj, K = 768; NW 8/16: down_proj, K = 3072);
     gemm_fast_k<MB, NW, SCALE, EPI> are the row-major kernels (prefill below 256 rows, CTTS_DEC_PACKED=0)."""
     import re
+    if "attention_k<float" in name:
+        return "attention_f32"      # parity mode (f32 KV cache): bench.py's parity_mode.roofline
     if "attention_k" in name:
         return "attention"
     m = re.search(r"gemm_(dec|fast)_k<(\d+), (\d+), (true|false), (\d+)>", name)
@@ -39,8 +41,8 @@ def short(name):
             return "gate_up_gemm"
         if epi == 1:
             return "o_proj_gemm" if nw == 4 else "down_gemm"
-    if "gemm_skinny_k<float" in name:
-        return "heads_gemm"
+    if "gemm_dec32_fnorm16_k" in name or "gemm_dec32_m16_k<768, 0>" in name or "gemm_skinny_k<float" in name:
+        return "heads_gemm"         # fused final-norm + heads | packed heads | row-major heads
     if "sample_k" in name:
         return "sample"
     if "dwconv_ln_k" in name:
@@ -51,6 +53,9 @@ def short(name):
 def main(d_fetch, d_write, out):
     fe, wr = collect(d_fetch, "FETCH_SIZE"), collect(d_write, "WRITE_SIZE")
     res = {}
+    if os.path.exists(out):      # a second call (e.g. the f32 passes) ADDS its kernels to the file
+        with open(out) as fh:
+            res = json.load(fh)
     print("kernel, dispatches, mean FETCH_SIZE KiB, mean WRITE_SIZE KiB, HBM bytes/launch (2*FETCH+WRITE)")
     for k, (n, tot) in sorted(fe.items(), key=lambda kv: -kv[1][1]):
         f = tot / max(n, 1)
