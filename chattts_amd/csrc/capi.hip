@@ -469,7 +469,9 @@ extern "C" int ctts_gpt_graph_build(ctts_gpt* g, const ctts_gen_state* s, void* 
   if (e != hipSuccess) return fail("hipStreamEndCapture: %s", hipGetErrorString(e));
   g->graph = graph;
   CK(hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0));
-  { const char* e2 = getenv("CTTS_GRAPH_STEPS"); g->multi_steps = e2 ? atoi(e2) : 1; }
+  // default 8 steps per launch of the multi-step graph: +0.5 % on the C3 bench over one hipGraphLaunch per step
+  // (profiles/r3b_ab_fnorm_graphsteps.log: 1325 -> 1331-1334 audio-s/s with 8, 1328-1331 with 16)
+  { const char* e2 = getenv("CTTS_GRAPH_STEPS"); g->multi_steps = e2 ? atoi(e2) : 8; }
   if (g->multi_steps > 1 && g->multi_steps <= 64) {
     CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
     int rc2 = 0;

@@ -616,7 +616,7 @@ hipError_t launch_attention(const float* qkv, const void* kcache, const void* vc
   // CTTS_ATT_LDS=<bytes>: dynamic LDS the decode attention workgroups declare (and never touch).  It bounds the workgroups a CU
   // holds at once (160 KiB / bytes), which turns the dispatcher into a greedy list scheduler: with the rows ordered by descending
   // context (ctts_gen_state.order) the longest units start first and the short ones fill the CUs that free up.  0 = no bound.
-  static int att_lds = -1, att_small_m = 5;
+  static int att_lds = -1, att_small_m = 0;
   if (att_lds < 0) {
     { const char* e2 = getenv("CTTS_ATT_SMALL_M"); if (e2) att_small_m = atoi(e2); }   // batches up to this many rows: 16-wave units (0 = never)
     const char* e = getenv("CTTS_ATT_LDS");
@@ -632,10 +632,10 @@ hipError_t launch_attention(const float* qkv, const void* kcache, const void* vc
       CTTS_LAUNCH((attention_k<bf16_t, 4, bf16_t, true, true>), dim3(NHEAD * M + rm.sp_cus), dim3(256), st, qkv, (const bf16_t*)kcache,
                   (const bf16_t*)vcache, cmax, (bf16_t*)out, rm);
     else if (M <= att_small_m)
-      // tiny batches (BASELINE C2: batch 1 = 12 units on 256 CUs): a unit is one CU's job and a CU's stream is bounded by what it has
-      // in flight (4 waves x 16 KiB per round trip), so 16 waves per unit -- a long context in ONE round trip instead of three.
-      // (Static choice by batch size: perf-mode results of a batch of <= att_small_m utterances may differ in the last bf16 bit
-      // from the same utterances inside a bigger batch; the f32 parity mode never takes this path.)
+      // A/B knob, OFF by default (CTTS_ATT_SMALL_M=<rows>): 16 waves per unit for tiny batches (BASELINE C2: batch 1 = 12 units on
+      // 256 CUs), so a long context is in flight in one round trip.  MEASURED at batch 1 (profiles/r3b_c2_ab.log): 0.482 ms per
+      // step with it, 0.478 without -- the 16-way LDS merge costs what the shorter stream saves -- and it would make a row's
+      // perf-mode bits depend on the batch size.
       CTTS_LAUNCH((attention_k<bf16_t, 16, bf16_t, true>), grid, dim3(1024), st, qkv, (const bf16_t*)kcache, (const bf16_t*)vcache, cmax, (bf16_t*)out, rm);
     else
       CTTS_LAUNCH_SMEM((attention_k<bf16_t, 4, bf16_t, true>), grid, dim3(256), att_lds, st, qkv, (const bf16_t*)kcache, (const bf16_t*)vcache, cmax, (bf16_t*)out, rm);
@@ -813,8 +813,7 @@ __global__ __launch_bounds__(256) void sample_k(SampleArgs a) {
   // the <=16 history tokens are fetched by 16 lanes in ONE load round and broadcast (a serial loop of
   // dependent global loads costs one L2 round trip per token)
   const int mine = (penal && lane < nh) ? (int)a.ids_buf[((size_t)b * a.tcap + (len - 1 - lane)) * NVQ + k] : -1;
-  const float ptab_warm = penal ? a.pow_table[lane & 15] : 0.f;   // pulls the 17-entry table's line into this CU's L1
-  asm volatile("" ::"v"(ptab_warm));   // keep the warming load
+  const float ptab_reg = penal ? a.pow_table[min(lane, 16)] : 1.f;   // the 17-entry table penalty^count, one entry per lane
   const int sa = a.stop_at != nullptr ? a.stop_at[b] : -1;
   const bool forced_t = a.teacher != nullptr && gen < a.teacher_stride;
   const int64_t teach = forced_t ? a.teacher[((size_t)b * a.teacher_stride + gen) * NVQ + k] : 0;
@@ -832,16 +831,28 @@ __global__ __launch_bounds__(256) void sample_k(SampleArgs a) {
   for (int s = 0; s < SLOTS; ++s) x[s] = (s * 64 + lane < NAUDIO) ? x[s] / temp : -INFINITY;   // gpt.py:487
   // repetition penalty
   if (penal) {
+    // occurrences of this lane's 10 tokens among the <= 16 history tokens, 5 bits per slot in one 64-bit word: history token t
+    // (wave-uniform) belongs to lane t % 64, slot t / 64
+    unsigned long long packed = 0ull;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-      const int t = __shfl(mine, j, 64);  // -1 beyond the history: matches no vocabulary slot
+      const int t = __builtin_amdgcn_readlane(mine, j);  // -1 beyond the history: matches no vocabulary slot
+      const int d = t - lane;
+      const bool hit = (d & 63) == 0 && (unsigned)d < (unsigned)(SLOTS * 64);
+      packed += hit ? (1ull << (5 * (d >> 6))) : 0ull;
+    }
+    // alpha = penalty^count from the table held in registers (one cross-lane read per slot instead of a dependent global load
+    // per slot), then BOTH candidates -- logit * alpha and logit / alpha -- and a select: no divergent branches
+    float al[SLOTS];
 #pragma unroll
-      for (int s = 0; s < SLOTS; ++s) cnt[s] += (t == s * 64 + lane) ? 1 : 0;
+    for (int s = 0; s < SLOTS; ++s) {
+      cnt[s] = (int)((packed >> (5 * s)) & 31ull);
+      al[s] = __shfl(ptab_reg, cnt[s], 64);
     }
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
-      const float al = a.pow_table[cnt[s]];
-      x[s] = (x[s] < 0.f) ? x[s] * al : x[s] / al;
+      const float mu = x[s] * al[s], dv = x[s] / al[s];
+      x[s] = (x[s] < 0.f) ? mu : dv;
     }
   }
 
