@@ -38,8 +38,7 @@ class GenState(C.Structure):
         ("min_new", C.c_int32), ("eos", C.c_int32), ("row_offset", C.c_int32),
         ("stop_at", P), ("workspace", P), ("workspace_bytes", C.c_size_t), ("row_map", P), ("n_active", P),
         ("cap", C.c_int32), ("hid_cap", C.c_int32), ("kv_batch", C.c_int32), ("q_batch", C.c_int32), ("prompt_len", P),
-        ("infer_text", C.c_int32), ("teacher_ids", P), ("sampled_ids", P), ("order", P),
-        ("rng_device", C.c_int32), ("rng_per_step", C.c_int32), ("rng_seed", P),
+        ("infer_text", C.c_int32), ("teacher_ids", P),
     ]
 
 
@@ -99,7 +98,6 @@ SIGNATURES = {
     "ctts_codec_create": (C.c_int, [PP, C.POINTER(CodecWeights)]),
     "ctts_codec_destroy": (None, [P]),
     "ctts_codec_workspace_bytes": (SZ, [I32, I32]),
-    "ctts_copy_bytes": (C.c_int, [P, P, SZ, P]),
     "ctts_dvae_decode": (C.c_int, [P, P, P, I32, I32, P, SZ, P]),
     "ctts_vocos_decode": (C.c_int, [P, P, P, I32, I32, P, SZ, P]),
     "ctts_dvae_create": (C.c_int, [PP, C.POINTER(DvaeWeights)]),
@@ -124,7 +122,6 @@ SIGNATURES = {
     "ctts_k_embed_codes": (C.c_int, [P, P, I32, P, P, I32, P]),
     "ctts_k_final_norm": (C.c_int, [P, I32, P, F, P, P, I32, P, I32, I32, P]),
     "ctts_k_sample": (C.c_int, [C.POINTER(GenState), P, P]),
-    "ctts_k_exp_draws": (C.c_int, [C.c_uint64, I32, I32, I32, I32, P, P]),
     "ctts_k_dwconv_ln": (C.c_int, [P, P, P, P, P, F, I32, P, I32, I32, P]),
     "ctts_k_layernorm": (C.c_int, [P, P, P, F, P, I32, P]),
     "ctts_k_istft": (C.c_int, [P, P, P, P, P, I32, I32, P]),

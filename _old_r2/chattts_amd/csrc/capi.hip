@@ -38,15 +38,9 @@ struct ctts_gpt {
   bool dec_packed = false;     // perf mode (bf16 weights): decode.hip
   bool dec_packed32 = false;   // parity mode (f32 weights): decode32.hip
   bool heads_packed = false;   // heads GEMM on packed f32 operands (decode32.hip), both modes
-  bool fnorm_fuse = true;      // decode: final norm + hidden capture + heads in one launch (env CTTS_FNORM_FUSE=0: separate launches)
   std::vector<const float*> ln1, ln2;
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
-  // optional second executable graph of `multi_steps` consecutive decode steps (env CTTS_GRAPH_STEPS > 1): one hipGraphLaunch per
-  // multi_steps steps instead of one per step
-  hipGraph_t graph_multi = nullptr;
-  hipGraphExec_t exec_multi = nullptr;
-  int multi_steps = 1;
   // profiling (eager decode only)
   int prof_tag = -1;
   int prof_max = 0;
@@ -128,7 +122,6 @@ extern "C" int ctts_gpt_create(ctts_gpt** out, const ctts_gpt_weights* w) {
   }
   { const char* e = getenv("CTTS_DEC_PACKED"); g->heads_packed = w->heads_pk != nullptr && !(e && atoi(e) == 0); }
   { const char* e = getenv("CTTS_SKIP_FINISHED"); if (e && atoi(e) == 0) g->skip_finished = false; }
-  { const char* e = getenv("CTTS_FNORM_FUSE"); if (e && atoi(e) == 0) g->fnorm_fuse = false; }
   {
     int dev = 0, cus = 0;
     // OFF by default: measured on the C3 bench it does not pay (attention 9.3 -> 9.8 us per launch, 1296 -> 1280 audio-s/s,
@@ -146,8 +139,6 @@ extern "C" void ctts_gpt_graph_destroy(ctts_gpt* g) {
   if (!g) return;
   if (g->exec) { (void)hipGraphExecDestroy(g->exec); g->exec = nullptr; }
   if (g->graph) { (void)hipGraphDestroy(g->graph); g->graph = nullptr; }
-  if (g->exec_multi) { (void)hipGraphExecDestroy(g->exec_multi); g->exec_multi = nullptr; }
-  if (g->graph_multi) { (void)hipGraphDestroy(g->graph_multi); g->graph_multi = nullptr; }
 }
 
 extern "C" void ctts_gpt_destroy(ctts_gpt* g) {
@@ -182,24 +173,18 @@ static SampleArgs make_sample_args(const ctts_gen_state* s, const float* logits)
   a.top_p_thr = s->top_p_thr; a.use_top_p = s->use_top_p; a.top_k = s->top_k; a.use_top_k = s->use_top_k;
   a.min_new = s->min_new; a.eos = s->eos; a.row_offset = s->row_offset; a.max_input_ids = NAUDIO - 1; a.stop_at = s->stop_at;
   a.B = s->B; a.row_map = nullptr; a.n_active = nullptr; a.prompt_len = s->prompt_len; a.q_rows = s->q_batch ? s->q_batch : s->B;
-  a.teacher = s->teacher_ids; a.teacher_stride = s->hid_cap ? s->hid_cap : s->max_new; a.sampled = s->sampled_ids;
-  a.desc = nullptr; a.rng_device = s->rng_device; a.rng_per_step = s->rng_per_step; a.rng_seed = reinterpret_cast<const unsigned long long*>(s->rng_seed);
+  a.teacher = s->teacher_ids; a.teacher_stride = s->hid_cap ? s->hid_cap : s->max_new;
   return a;
 }
 
-// ws_T: prompt slots the workspace must hold for THIS call (a prompt chunk needs ctts_gpt_workspace_bytes(B, tc) only; the decode
-// step carves for one row per utterance but keeps the prefill's carve layout, so it is checked against the geometry the caller
-// allocated for: s->T unless `decode_ws_T` says otherwise)
-static int check_state(const ctts_gpt* g, const ctts_gen_state* s, int ws_T = 0) {
+static int check_state(const ctts_gpt* g, const ctts_gen_state* s) {
   if (!g || !s) return fail("null engine/state");
   if (s->B <= 0 || s->T <= 0 || s->max_new <= 0) return fail("bad B/T/max_new");
   const int cap_ = s->cap ? s->cap : s->T + s->max_new;
   if (cap_ > g->w.max_pos) return fail("slot capacity T + max_new (%d) exceeds the RoPE table (%d)", cap_, g->w.max_pos);
   if (s->cap && s->T + 1 > s->cap) return fail("prompt does not fit the slot capacity");
-  if (s->workspace_bytes < ctts_gpt_workspace_bytes(s->B, ws_T > 0 ? ws_T : s->T)) return fail("workspace too small");
-  if (!s->rng_device && (s->nq <= 0 || !s->q)) return fail("q draws missing");
-  if (s->rng_device && !s->rng_seed) return fail("rng_device needs the rng_seed device scalar");
-  if (s->rng_device && s->infer_text) return fail("the device generator serves the code mode only (refine-text samples from `q`)");
+  if (s->workspace_bytes < ctts_gpt_workspace_bytes(s->B, s->T)) return fail("workspace too small");
+  if (s->nq <= 0 || !s->q) return fail("q draws missing");
   if (g->w.weight_dtype == CTTS_BF16 && g->w.kv_dtype != CTTS_BF16) return fail("perf mode needs a bf16 KV cache");
   if (s->infer_text) {
     if (!g->w.emb_text || !g->w.head_text || g->w.n_text <= 0 || g->w.n_text > NTEXT_MAX) return fail("text head/embedding not loaded");
@@ -227,21 +212,13 @@ static int run_step(ctts_gpt* g, const ctts_gen_state* s, int q_per_b, hipStream
   // decode: compact row -> slot (see GptRowMap) -- the host's map, or the one the step's first kernel derives from the finish
   // flags (device-side compaction); prefill: row group -> slot of a pool (or null)
   const int32_t* rmap = (dec && dev_compact(g, s)) ? ws.row_map : s->row_map;
-  // CTTS_SKIP_FINISHED=0 with a caller that left the compaction to the device (row_map == NULL): nobody writes *n_active then,
-  // so it must not be read -- every row steps, like the reference (gpt.py:512-518,592)
-  const bool no_compact = dec && !g->skip_finished && s->row_map == nullptr;
-  const int32_t* nact = (dec && !no_compact) ? s->n_active : nullptr;
+  const int32_t* nact = dec ? s->n_active : nullptr;
   GptRowMap rm{q_per_b, s->len, s->kv_start, rmap, nact, (dec && g->skip_finished) ? s->finish : nullptr, nullptr, nullptr, nullptr, 0, slot0, 0};
   const bool fast = wt == CTTS_BF16;  // perf mode: bf16 activations, RMSNorm gain folded into wqkv / wgu by the loader
   const bool packed = fast && dec && g->dec_packed;   // decode step on fragment-packed operands (decode.hip)
   if (dec) rm.desc = ws.desc;                          // written by the embedding kernel at the head of the step
   if (dec && dev_compact(g, s)) rm.desc_covers_all = 1; // ... for every row of the grid (absent rows: b = -1)
   if (packed && g->n_cu > 0) { rm.sp_part = ws.att_part; rm.sp_cnt = ws.att_cnt; rm.sp_cus = g->n_cu; }
-  // decode on packed operands: final RMSNorm + hidden capture + heads are ONE launch (decode32.hip gemm_dec32_fnorm16_k; the residual
-  // stream reaches it in the packed f32 order: parity mode keeps it that way anyway, perf mode has the last down_proj write it)
-  const bool packed32_ = !fast && dec && g->dec_packed32;
-  const bool fuse_fnorm = dec && heads && g->fnorm_fuse && g->heads_packed && (packed || packed32_) &&
-                          (s->infer_text ? g->w.head_text_pk : g->w.heads_pk) != nullptr;
   for (int l = 0; packed && l < g->w.n_layers; ++l) {
     void* kc = (char*)s->kcache + kv_layer * l;
     void* vc = (char*)s->vcache + kv_layer * l;
@@ -262,7 +239,6 @@ static int run_step(ctts_gpt* g, const ctts_gen_state* s, int q_per_b, hipStream
     { Prof p(g, 5, st, prof_ok); CK(launch_gemm_dec(d, st)); }
     d.Ap = ws.actp; d.Wp = (const uint16_t*)g->wd_pk[l]; d.N = HID; d.K = INTER; d.ssq_in = nullptr; d.epi = FEPI_RES; d.C32 = ws.x;
     d.ldc = HID; d.Cp = ws.xp; d.kch_out = HID / 32; d.ssq_out = ws.ssq;
-    d.Cp32 = (fuse_fnorm && l == g->w.n_layers - 1) ? ws.xp32 : nullptr;   // operand of the fused final-norm + heads launch
     { Prof p(g, 6, st, prof_ok); CK(launch_gemm_dec(d, st)); }
   }
   for (int l = 0; fast && !packed && l < g->w.n_layers; ++l) {
@@ -344,17 +320,6 @@ static int run_step(ctts_gpt* g, const ctts_gen_state* s, int q_per_b, hipStream
     { Prof p(g, 6, st, prof_ok); CK(launch_gemm_skinny(a, st)); }
   }
   if (!heads) return 0;   // a prompt chunk that is not the last one: its K/V rows are in the cache, nothing is sampled
-  if (fuse_fnorm) {
-    const int nlog = s->infer_text ? g->w.n_text : NVQ * NAUDIO;
-    Dec32Args d;
-    memset(&d, 0, sizeof(d));
-    d.Ap = ws.xp32; d.Wp = s->infer_text ? g->w.head_text_pk : g->w.heads_pk; d.M = B; d.N = (nlog + 15) / 16 * 16; d.K = HID; d.n_active = nact;
-    d.epi = EPI_STORE; d.C = ws.logits; d.ldc = nlog; d.n_cols = nlog;
-    d.fnorm = 1; d.norm_w = g->w.norm; d.eps = g->w.rms_eps; d.desc = ws.desc; d.hid = s->hiddens; d.hid_cap = s->hid_cap ? s->hid_cap : s->max_new;
-    d.T = s->T; d.prompt_len = s->prompt_len;
-    Prof p(g, 8, st, prof_ok);
-    CK(launch_gemm_dec32(d, st));
-  } else {
   { Prof p(g, 7, st, prof_ok);
     CK(launch_final_norm(ws.x, q_per_b, g->w.norm, g->w.rms_eps, ws.hfin, s->hiddens, s->hid_cap ? s->hid_cap : s->max_new, s->len, s->T, B, rmap,
                          nact, s->prompt_len, st, ws.hfinp)); }
@@ -378,12 +343,10 @@ static int run_step(ctts_gpt* g, const ctts_gen_state* s, int q_per_b, hipStream
     CK(launch_gemm_skinny(a, st));
     }
   }
-  }
   {
     Prof p(g, 9, st, prof_ok);
     SampleArgs sa = make_sample_args(s, ws.logits);
     sa.row_map = rmap; sa.n_active = nact;
-    if (dec && dev_compact(g, s)) sa.desc = ws.desc;   // one load instead of the n_active -> row_map -> len chain
     if (s->infer_text) CK(launch_sample_text(sa, g->w.n_text, st));
     else CK(launch_sample(sa, st));
   }
@@ -398,16 +361,12 @@ extern "C" int ctts_gpt_prefill(ctts_gpt* g, const ctts_gen_state* s, const floa
   CK(hipMemsetAsync(ws.att_cnt, 0, (size_t)ATT_CUS_MAX * sizeof(int32_t), st));   // arrival counters of the attention split
   CK(hipMemcpyAsync(ws.x, emb, (size_t)s->B * s->T * HID * 4, hipMemcpyDeviceToDevice, st));
   if (g->w.weight_dtype == CTTS_BF16) CK(launch_rows_prep(ws.x, ws.xb, ws.ssq, s->B * s->T, st));
-  if (run_step(g, s, s->T, st, false)) return -1;
-  // arrival counters of the attention split at the place the DECODE steps carve them (one row per utterance), once the
-  // prompt-sized buffers above are dead
-  CK(hipMemsetAsync(carve(s->workspace, s->B, 1).att_cnt, 0, (size_t)ATT_CUS_MAX * sizeof(int32_t), st));
-  return 0;
+  return run_step(g, s, s->T, st, false);
 }
 
 extern "C" int ctts_gpt_prefill_chunk(ctts_gpt* g, const ctts_gen_state* s, const float* emb_chunk, int32_t t0, int32_t tc, int32_t last,
                                       void* stream) {
-  if (check_state(g, s, tc > 0 ? tc : 1)) return -1;
+  if (check_state(g, s)) return -1;
   if (t0 < 0 || tc <= 0 || t0 + tc > s->T || (last && t0 + tc != s->T)) return fail("ctts_gpt_prefill_chunk: bad chunk [%d, %d) of a %d-slot prompt", t0, t0 + tc, s->T);
   if (s->workspace_bytes < ctts_gpt_workspace_bytes(s->B, tc)) return fail("workspace too small for the chunk");
   CttsDeviceGuard dg(stream);
@@ -416,49 +375,45 @@ extern "C" int ctts_gpt_prefill_chunk(ctts_gpt* g, const ctts_gen_state* s, cons
   CK(hipMemcpyAsync(ws.x, emb_chunk, (size_t)s->B * tc * HID * 4, hipMemcpyDeviceToDevice, st));
   if (g->w.weight_dtype == CTTS_BF16) CK(launch_rows_prep(ws.x, ws.xb, ws.ssq, s->B * tc, st));
   if (run_step(g, s, tc, st, false, t0, last != 0, tc)) return -1;
-  // the decode steps carve the workspace for one row per utterance: zero THEIR attention-split arrival counters once the
+  // the decode steps carve the workspace for the whole prompt length: zero THEIR attention-split arrival counters once the
   // chunk-sized buffers above are dead
-  if (last) CK(hipMemsetAsync(carve(s->workspace, s->B, 1).att_cnt, 0, (size_t)ATT_CUS_MAX * sizeof(int32_t), st));
+  if (last) CK(hipMemsetAsync(carve(s->workspace, s->B, s->T).att_cnt, 0, (size_t)ATT_CUS_MAX * sizeof(int32_t), st));
   return 0;
 }
 
-// The decode step carves the workspace for ONE row per utterance (ctts_gpt_workspace_bytes(B, 1)) whatever the prompt length was: a
-// caller that prefills in chunks of tc slots needs max(bytes(B, tc), bytes(B, 1)), not bytes(B, T).  Nothing in the workspace
-// survives from the prefill into the decode steps (all generation state lives in ctts_gen_state's own arrays).
 static int decode_body(ctts_gpt* g, const ctts_gen_state* s, hipStream_t st, bool prof_ok) {
-  const GptWs ws = carve(s->workspace, s->B, 1);
+  const GptWs ws = carve(s->workspace, s->B, s->T);
   { Prof p(g, 0, st, prof_ok); const bool fast = g->w.weight_dtype == CTTS_BF16;
     const bool packed = fast && g->dec_packed;
     const bool dc = dev_compact(g, s);
     StepPrep sp{ws.desc, s->kv_start, g->skip_finished ? s->finish : nullptr, packed ? 1 : 0, (!fast && g->dec_packed32) ? ws.xp32 : nullptr,
                 dc ? ws.row_map : nullptr,
-                dc ? const_cast<int32_t*>(s->n_active) : nullptr, dc ? s->order : nullptr};
-    const int32_t* nact0 = (!g->skip_finished && s->row_map == nullptr) ? nullptr : s->n_active;
+                dc ? const_cast<int32_t*>(s->n_active) : nullptr};
     uint16_t* xb = fast ? (packed ? ws.xp : ws.xb) : nullptr;
     if (s->infer_text)
       CK(launch_embed_text(g->w.emb_text, g->w.n_text, s->ids_buf, s->cap ? s->cap : s->T + s->max_new, s->len, ws.x, xb,
-                           fast ? ws.ssq : nullptr, s->B, s->row_map, nact0, st, &sp));
+                           fast ? ws.ssq : nullptr, s->B, s->row_map, s->n_active, st, &sp));
     else
       CK(launch_embed_codes(g->w.emb_code, s->ids_buf, s->cap ? s->cap : s->T + s->max_new, s->len, ws.x, xb, fast ? ws.ssq : nullptr, s->B,
-                            s->row_map, nact0, st, &sp)); }
-  return run_step(g, s, 1, st, prof_ok, 0, true, 1);
+                            s->row_map, s->n_active, st, &sp)); }
+  return run_step(g, s, 1, st, prof_ok);
 }
 
 extern "C" int ctts_gpt_decode_step(ctts_gpt* g, const ctts_gen_state* s, void* stream) {
-  if (check_state(g, s, 1)) return -1;
+  if (check_state(g, s)) return -1;
   CttsDeviceGuard dg(stream);
   return decode_body(g, s, (hipStream_t)stream, true);
 }
 
 extern "C" int ctts_gpt_graph_build(ctts_gpt* g, const ctts_gen_state* s, void* stream) {
-  if (check_state(g, s, 1)) return -1;
+  if (check_state(g, s)) return -1;
   CttsDeviceGuard dg(stream);
   ctts_gpt_graph_destroy(g);
   hipStream_t st = (hipStream_t)stream;
   if (st == nullptr) return fail("graph capture needs a non-default stream");
   {  // the decode workspace may never have seen a prefill (slot pools prefill into their own): zero the arrival counters of the
      // attention split once, stream-ordered before anything the graph will run
-    const GptWs ws = carve(s->workspace, s->B, 1);
+    const GptWs ws = carve(s->workspace, s->B, s->T);
     CK(hipMemsetAsync(ws.att_cnt, 0, (size_t)ATT_CUS_MAX * sizeof(int32_t), st));
   }
   CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
@@ -469,31 +424,13 @@ extern "C" int ctts_gpt_graph_build(ctts_gpt* g, const ctts_gen_state* s, void* 
   if (e != hipSuccess) return fail("hipStreamEndCapture: %s", hipGetErrorString(e));
   g->graph = graph;
   CK(hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0));
-  // default 8 steps per launch of the multi-step graph: +0.5 % on the C3 bench over one hipGraphLaunch per step
-  // (profiles/r3b_ab_fnorm_graphsteps.log: 1325 -> 1331-1334 audio-s/s with 8, 1328-1331 with 16)
-  { const char* e2 = getenv("CTTS_GRAPH_STEPS"); g->multi_steps = e2 ? atoi(e2) : 8; }
-  if (g->multi_steps > 1 && g->multi_steps <= 64) {
-    CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-    int rc2 = 0;
-    for (int i = 0; i < g->multi_steps && rc2 == 0; ++i) rc2 = decode_body(g, s, st, false);
-    hipGraph_t gm = nullptr;
-    hipError_t e3 = hipStreamEndCapture(st, &gm);
-    if (rc2 != 0) { if (gm) (void)hipGraphDestroy(gm); return -1; }
-    if (e3 != hipSuccess) return fail("hipStreamEndCapture (multi-step graph): %s", hipGetErrorString(e3));
-    g->graph_multi = gm;
-    CK(hipGraphInstantiate(&g->exec_multi, g->graph_multi, nullptr, nullptr, 0));
-  } else {
-    g->multi_steps = 1;
-  }
   return 0;
 }
 
 extern "C" int ctts_gpt_graph_launch(ctts_gpt* g, int32_t n_steps, void* stream) {
   if (!g || !g->exec) return fail("no captured graph");
   CttsDeviceGuard dg(stream);
-  int left = n_steps;
-  while (g->exec_multi && left >= g->multi_steps) { CK(hipGraphLaunch(g->exec_multi, (hipStream_t)stream)); left -= g->multi_steps; }
-  for (int i = 0; i < left; ++i) CK(hipGraphLaunch(g->exec, (hipStream_t)stream));
+  for (int i = 0; i < n_steps; ++i) CK(hipGraphLaunch(g->exec, (hipStream_t)stream));
   return 0;
 }
 
@@ -501,13 +438,8 @@ extern "C" int ctts_gpt_profile_begin(ctts_gpt* g, int32_t tag, int32_t max_samp
   if (!g || max_samples <= 0 || stride <= 0) return fail("bad profile args");
   while ((int)g->ev0.size() < max_samples) {
     hipEvent_t a, b;
-    // hipEventDisableSystemFence: a default event makes the dispatch that signals it end with a system-scope release (L2
-    // write-back towards the host) -- time that rocprofv3's own completion signals do not add to a kernel
-    static int sysfence = -1;
-    if (sysfence < 0) { const char* e = getenv("CTTS_PROF_SYSFENCE"); sysfence = (e && atoi(e) == 1) ? 1 : 0; }
-    const unsigned fl = sysfence ? hipEventDefault : hipEventDisableSystemFence;
-    CK(hipEventCreateWithFlags(&a, fl));
-    CK(hipEventCreateWithFlags(&b, fl));
+    CK(hipEventCreate(&a));
+    CK(hipEventCreate(&b));
     g->ev0.push_back(a);
     g->ev1.push_back(b);
   }
@@ -783,17 +715,6 @@ extern "C" int ctts_k_final_norm(const float* x, int32_t q_per_b, const float* w
 extern "C" int ctts_k_sample(const ctts_gen_state* s, const float* logits, void* stream) {
   if (!s || !logits) return fail("ctts_k_sample: bad arguments");
   CK(launch_sample(make_sample_args(s, logits), (hipStream_t)stream));
-  return 0;
-}
-extern "C" int ctts_copy_bytes(void* dst, const void* src, size_t bytes, void* stream) {
-  if (!dst || !src || (bytes & 15) || (((uintptr_t)dst | (uintptr_t)src) & 15)) return fail("ctts_copy_bytes: pointers and size must be 16-byte aligned");
-  CttsDeviceGuard dg(stream);
-  CK(launch_copy16(src, dst, bytes, (hipStream_t)stream));
-  return 0;
-}
-extern "C" int ctts_k_exp_draws(uint64_t seed, int32_t step, int32_t row0, int32_t rows, int32_t V, float* out, void* stream) {
-  if (!out || rows <= 0 || V <= 0) return fail("ctts_k_exp_draws: bad arguments");
-  CK(launch_exp_draws(seed, step, row0, rows, V, out, (hipStream_t)stream));
   return 0;
 }
 extern "C" int ctts_k_dwconv_ln(const float* x, const float* w, const float* b, const float* ln_w, const float* ln_b, float eps,

@@ -190,20 +190,3 @@ hipError_t launch_istft(const float* head, const float* window, const float* twi
   hipLaunchKernelGGL(istft_ola_k, dim3((wlen + 255) / 256, B), dim3(256), 0, st, frames, window, wav, F, wlen);
   return hipGetLastError();
 }
-
-
-// ------------------------------------------------------------------------------------------------
-// Shader copy: n bytes (a multiple of 16, both pointers 16-byte aligned) src -> dst.  The destination may be PINNED HOST memory (it
-// is mapped into the device's address space): the result tensors of the path then reach the host without the copy engines, as
-// plain stores over PCIe.  (`Chat._decode_to_wavs` ends with `.cpu().numpy()`, core.py:508-510.)
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void copy16_k(const u128* __restrict__ src, u128* __restrict__ dst, size_t n16) {
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
-}
-hipError_t launch_copy16(const void* src, void* dst, size_t bytes, hipStream_t st) {
-  const size_t n16 = bytes / 16;
-  if (n16 == 0) return hipSuccess;
-  const size_t blocks = (n16 + 255) / 256;
-  hipLaunchKernelGGL(copy16_k, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, st, (const u128*)src, (u128*)dst, n16);
-  return hipGetLastError();
-}

@@ -1,0 +1,212 @@
+// Split-bf16 ("bf16x3") GEMM of the acoustic decoder's ConvNeXt point-wise layers on PRE-SPLIT, FRAGMENT-PACKED operands, staged by
+// LDS-DMA.  Reference ops: `ConvNeXtBlock.pwconv1 -> GELU -> pwconv2 -> * gamma -> + residual`
+// (/root/reference/ChatTTS/model/dvae.py:46-66 and vocos.modules.ConvNeXtBlock) -- 40 of the 45 GEMM launches and 95 % of the
+// flops of DVAE decode + Vocos.
+//
+// gemm_tiled_bf16x3_k (gemm.hip) takes f32 activations: every k-step each wave pulls its share of the tile into registers,
+// splits x = hi + lo on the VALU, writes four LDS planes, and only then multiplies -- and the 8 waves of a workgroup do these
+// phases in lock-step, so a 256x256x32 step costs about their SUM (4.4 us against 1.3 us of MFMA issue, round-1 phase
+// probe).  Here nothing but the multiply is left to the waves:
+//   * the PRODUCERS write both bf16 planes (the depthwise-conv + LayerNorm kernel, and this kernel's own GELU epilogue), in
+//     MFMA fragment order:   plane[row / 32][k / 16][hi | lo][lane = (k % 16) / 8 * 32 + row % 32][k % 8]
+//     -- one (32-row tile, 16-wide k block, plane) is one contiguous KiB, exactly what v_mfma_f32_32x32x16_bf16 takes as A / B;
+//     weights are packed the same way once at load;
+//   * a 16-wide k block of the 256x256 tile is 32 such KiB fragments (16 A + 16 W) copied global -> LDS by
+//     `global_load_lds_dwordx4` (4 per wave, no VGPR round trip, no ds_write) into a ring of 4 slots: the DMA runs THREE k blocks
+//     ahead of the MFMAs (96 KiB in flight per CU), kept in flight across the per-block barrier by counted `s_waitcnt vmcnt(8)`
+//     + raw `s_barrier` (a __syncthreads would drain it to one block: measured 3.8 us per 32-wide step that way);
+//   * fragment reads are lane-linear ds_read_b128 (conflict free), 12 per wave and k block for 24 MFMAs.
+// Numerics are those of gemm_tiled_bf16x3_k: a.w ~= a_lo w_hi + a_hi w_lo + a_hi w_hi, f32 accumulation over k in order.
+#include <stdlib.h>
+
+#include "common.hpp"
+#include "kernels.hpp"
+
+__device__ __forceinline__ size_t x3p_off(int r, int k, int p, int kb16) {
+  return ((((size_t)(r >> 5) * kb16 + (k >> 4)) * 2 + p) * 64 + (((k & 15) >> 3) << 5) + (r & 31)) * 8 + (k & 7);
+}
+
+template <int EPI, int VAR>
+__global__ __launch_bounds__(512, 2) void gemm_x3p_k(X3pArgs a) {
+  constexpr int BM = 256, BN = 256;
+  constexpr int FRAG = 512;                 // bf16 elements of one fragment (1 KiB)
+  constexpr int SLOT = 32 * FRAG;           // one ring slot = one 16-wide k block of the tile: 16 A + 16 W fragments = 32 KiB
+  constexpr int NSLOT = 4;                  // ring of 4 slots (128 KiB): the DMA runs 3 k blocks ahead of the MFMAs
+  __shared__ __attribute__((aligned(16))) uint16_t lds[NSLOT * SLOT];
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = wave & 3, wn = wave >> 2;  // 4 x 2 waves, each 64 rows x 128 columns = 2 x 4 MFMA blocks of 32 x 32
+  const int M = a.M, N = a.N, K = a.K;
+  // XCD-aware tile order (workgroup L runs on XCD L % 8, each XCD has its own L2): a contiguous run of tiles per XCD, so the
+  // column tiles that share one activation row panel hit the same L2
+  const int nx = N / BN, ny = (M + BM - 1) / BM, T = nx * ny, per = (T + 7) / 8;
+  const int t = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= per || t >= T) return;
+  const int m0 = (t / nx) * BM, n0 = (t % nx) * BN;
+  const int kb16 = K >> 4;                  // k blocks = ring steps
+
+  // wave w stages row tile w of the A panel and column tile w of the W panel: per k block the hi and the lo fragment, 2 contiguous KiB
+  const uint16_t* ag = a.Ap + ((size_t)((m0 >> 5) + wave) * kb16) * 2 * FRAG + lane * 8;
+  const uint16_t* wg = a.Wp + ((size_t)((n0 >> 5) + wave) * kb16) * 2 * FRAG + lane * 8;
+  auto issue = [&](int kb) {   // 4 LDS-DMA pieces of 1 KiB per wave
+    uint16_t* la = lds + (kb & (NSLOT - 1)) * SLOT + wave * 2 * FRAG;
+    uint16_t* lw = la + 16 * FRAG;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ag + ((size_t)kb * 2 + p) * FRAG),
+                                       (__attribute__((address_space(3))) void*)(la + p * FRAG), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wg + ((size_t)kb * 2 + p) * FRAG),
+                                       (__attribute__((address_space(3))) void*)(lw + p * FRAG), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // Ring protocol (MI355X guide, "pipelining across barriers": counted vmcnt + raw s_barrier, never a draining __syncthreads in
+  // the loop).  Iteration s: (1) wait until THIS wave's 4 pieces of k block s have landed -- the pieces of blocks s+1, s+2 stay
+  // in flight (vmcnt counts in order); (2) barrier: every wave's pieces of block s are in LDS, and every wave is done reading
+  // slot (s-1) % 4; (3) refill that slot with block s+3; (4) multiply block s.
+  // VAR 3 (probe): wave 0 accumulates 100 MHz realtime deltas: DMA wait, barrier, DMA issue, fragment reads, MFMAs
+  long long tacc[5] = {0, 0, 0, 0, 0}, tprev = 0;
+#define X3P_MARK(i) do { if (VAR == 3) { const long long tn = wall_clock64(); tacc[i] += tn - tprev; tprev = tn; } } while (0)
+  issue(0);
+  if (kb16 > 1) issue(1);
+  if (kb16 > 2) issue(2);
+  if (VAR == 3) tprev = wall_clock64();
+  for (int s = 0; s < kb16; ++s) {
+    if (s + 2 < kb16) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (s + 1 < kb16) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    X3P_MARK(0);
+    __builtin_amdgcn_s_barrier();
+    X3P_MARK(1);
+    if (s + 3 < kb16) issue(s + 3);
+    X3P_MARK(2);
+    const uint16_t* la = lds + (s & (NSLOT - 1)) * SLOT + lane * 8;
+    const uint16_t* lw = la + 16 * FRAG;
+    bf16x8 fah[2], fal[2], fwh[4], fwl[4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      fah[i] = *reinterpret_cast<const bf16x8*>(la + ((wm * 2 + i) * 2 + 0) * FRAG);
+      fal[i] = *reinterpret_cast<const bf16x8*>(la + ((wm * 2 + i) * 2 + 1) * FRAG);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      fwh[j] = *reinterpret_cast<const bf16x8*>(lw + ((wn * 4 + j) * 2 + 0) * FRAG);
+      fwl[j] = *reinterpret_cast<const bf16x8*>(lw + ((wn * 4 + j) * 2 + 1) * FRAG);
+    }
+    if (VAR == 3) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); X3P_MARK(3); }
+    // per accumulator the order is lo.hi, hi.lo, hi.hi (small terms first).  VAR 1: term-major issue order, so that consecutive
+    // MFMAs write DIFFERENT accumulators (8 independent ones between two dependent ones); VAR 2: + raised wave priority
+    if (VAR == 0) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[i], fwh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fwl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fwh[j], acc[i][j], 0, 0, 0);
+        }
+    } else {
+      if (VAR == 2) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[i], fwh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fwl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fwh[j], acc[i][j], 0, 0, 0);
+      if (VAR == 2) __builtin_amdgcn_s_setprio(0);
+    }
+    if (VAR == 3) {   // make the MFMAs' completion visible to the clock: touch one result register of the last MFMA group
+      asm volatile("s_nop 15\n\ts_nop 15" :: "v"(acc[1][3][0]));
+      X3P_MARK(4);
+    }
+  }
+  if (VAR == 3 && a.dbg != nullptr && tid == 0) {
+    long long* d = a.dbg + (size_t)blockIdx.x * 8;
+    for (int i = 0; i < 5; ++i) d[i] = tacc[i];
+  }
+#undef X3P_MARK
+  __syncthreads();   // everybody is done with the ring: the epilogue below reuses it as scratch
+
+  if (EPI == X3P_GELU_PACKED) {
+    // C layout (one column per lane, 16 rows) -> 8 consecutive columns of one row per lane, through a wave-private LDS tile:
+    // bias + GELU, split hi / lo, and store the two planes in fragment order for the NEXT gemm_x3p_k (K' = N)
+    float* scr = reinterpret_cast<float*>(lds) + wave * (32 * 36);
+    const int nb16 = N >> 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int cb = n0 + (wn * 4 + j) * 32;
+        const float bias = a.bias[cb + (lane & 31)];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          scr[rr * 36 + (lane & 31)] = gelu_erf(acc[i][j][r] + bias);
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const int item = lane + 64 * it, rr = item >> 2, cg = item & 3;
+          const float4 v0 = *reinterpret_cast<const float4*>(scr + rr * 36 + cg * 8);
+          const float4 v1 = *reinterpret_cast<const float4*>(scr + rr * 36 + cg * 8 + 4);
+          const uint32_t h0 = pack_bf16x2(v0.x, v0.y), h1 = pack_bf16x2(v0.z, v0.w), h2 = pack_bf16x2(v1.x, v1.y), h3 = pack_bf16x2(v1.z, v1.w);
+          const uint32_t l0 = pack_bf16x2(v0.x - __uint_as_float(h0 << 16), v0.y - __uint_as_float(h0 & 0xffff0000u));
+          const uint32_t l1 = pack_bf16x2(v0.z - __uint_as_float(h1 << 16), v0.w - __uint_as_float(h1 & 0xffff0000u));
+          const uint32_t l2 = pack_bf16x2(v1.x - __uint_as_float(h2 << 16), v1.y - __uint_as_float(h2 & 0xffff0000u));
+          const uint32_t l3 = pack_bf16x2(v1.z - __uint_as_float(h3 << 16), v1.w - __uint_as_float(h3 & 0xffff0000u));
+          const int row = m0 + (wm * 2 + i) * 32 + rr;   // rows >= M land in the buffer's padding (allocated to a multiple of 256)
+          const size_t o = x3p_off(row, cb + cg * 8, 0, nb16);
+          *reinterpret_cast<uint4*>(a.Cp + o) = make_uint4(h0, h1, h2, h3);
+          *reinterpret_cast<uint4*>(a.Cp + o + FRAG) = make_uint4(l0, l1, l2, l3);
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+  } else {   // X3P_SCALE_RES: C = res + gamma * (acc + bias), f32 row-major (the residual stream the depthwise conv reads)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = n0 + (wn * 4 + j) * 32 + (lane & 31);
+      const float bias = a.bias[col], gam = a.gamma[col];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (row < M) a.C[(size_t)row * a.ldc + col] = a.res[(size_t)row * a.ldr + col] + gam * (acc[i][j][r] + bias);
+        }
+    }
+  }
+}
+
+template <int VAR>
+static void x3p_launch(const X3pArgs& a, dim3 grid, hipStream_t st) {
+  if (a.epi == X3P_GELU_PACKED) CTTS_LAUNCH((gemm_x3p_k<X3P_GELU_PACKED, VAR>), grid, dim3(512), st, a);
+  else CTTS_LAUNCH((gemm_x3p_k<X3P_SCALE_RES, VAR>), grid, dim3(512), st, a);
+}
+
+hipError_t launch_gemm_x3p(const X3pArgs& a, hipStream_t st) {
+  if (a.M <= 0 || (a.N % 256) != 0 || (a.K % 32) != 0 || a.K < 32) return hipErrorInvalidValue;
+  if (a.epi != X3P_GELU_PACKED && a.epi != X3P_SCALE_RES) return hipErrorInvalidValue;
+  const int tiles = (a.N / 256) * ((a.M + 255) / 256);
+  dim3 grid(((tiles + 7) / 8) * 8);
+  static int var = -1;   // CTTS_X3P_VAR: MFMA issue order / priority variant (A/B, tools/x3p_probe.py)
+  if (var < 0) { const char* e = getenv("CTTS_X3P_VAR"); var = e ? atoi(e) : 1; }
+  if (var == 0) x3p_launch<0>(a, grid, st);
+  else if (var == 2) x3p_launch<2>(a, grid, st);
+  else if (var == 3) x3p_launch<3>(a, grid, st);
+  else x3p_launch<1>(a, grid, st);
+  return hipGetLastError();
+}

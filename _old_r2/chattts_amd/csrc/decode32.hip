@@ -1,0 +1,582 @@
+// Decode-step projections of the GPT path in the float32 PARITY mode, on FRAGMENT-PACKED float32 operands (M <= 64 live rows
+// per tile).
+//
+// Reference op: the four nn.Linear calls of a HF Llama decoder layer reached from /root/reference/ChatTTS/model/gpt.py:419-427
+// (in-tree twin /root/reference/examples/onnx/modeling_llama.py:415-417 q/k/v_proj, :500 o_proj, :293 gate/up/down) with the
+// RMSNorm of :76-84 as prologue and the residual add / SiLU(gate)*up as epilogue.
+//
+// Why: the parity mode is the one whose token ids are bit-identical to the reference's CPU run, and it was still on
+// gemm_skinny_k<float> (gemm.hip), which pulls MFMA fragments out of row-major [rows][K] float32 operands: every 16-byte lane
+// load of a wave instruction is a different 128-byte line, and every workgroup pulls the whole 64 x K activation tile that way
+// (12 288 line visits at K = 768, 49 152 at K = 3072 -- 6 and 23 us of address/tag work per workgroup before any MFMA issues;
+// profiles/r2o_f32_kernel_stats_rowmajor.csv: 25-35 us per projection, 2.6 ms per step).  Here both operands are stored in the order
+// the matrix core consumes them,
+//
+//     packed[tile of 16 rows][k chunk of 16][lane = (k%16)/4 * 16 + row%16][k%4]          (f32, 16 bytes per lane)
+//
+// so a wave instruction reads one contiguous KiB.  THE ARITHMETIC IS UNCHANGED, bit for bit: the goldens of the parity mode were
+// established with gemm_skinny_k<float>, so this kernel keeps its exact operation order per output element -- wave w owns
+// chunks w, w+4, w+8, ...; a chunk is four v_mfma_f32_16x16x4_f32 steps (k%4 = 0,1,2,3; each an exact k-ordered fmaf chain on
+// gfx950); the partial tiles are added ((w0 + w1) + w2) + w3; the RMSNorm scale is applied to the A fragment as
+// norm_w[k] * (x * rstd) with rstd from common.hpp wave_row_rstd (shared with gemm_skinny_k); the epilogues are res + acc and
+// silu(gate) * up.  tests/test_gpu_kernels.py::test_gemm_dec32_bit_identical holds the two kernels to exact equality.
+//
+// Producers write the packed activations: embed_codes_k (StepPrep.xp32), attention_k<float> (packed output), final_norm_k (the
+// heads' operand) and the RES / SILU_MUL epilogues below.  Weights are packed once at load (engine.py pack_frag32).
+//
+// Three kernels, one arithmetic (launch_gemm_dec32 picks; ctts_k_dec32_last_variant tells which):
+//   gemm_dec32_rms16_k  RMSNorm launches (QKV + RoPE + KV append, gate/up), 16-row workgroups, statistics from the fragments
+//   gemm_dec32_m16_k    o_proj, down_proj, the heads: 16-row workgroups, every load up front / double-buffered stages
+//   gemm_dec32_k        the general body (1, 2 or 4 row tiles per workgroup, statistics from the row-major rows): A/B knobs, tests
+#include <stdlib.h>
+
+#include "common.hpp"
+#include "kernels.hpp"
+
+constexpr int D32_U = 6;   // k chunks of 16 per wave and round: D32_U * (NACC + NMB) 16-byte loads in flight per lane
+
+template <int NMB, int MBT, bool RMS, int EPI>
+__device__ __forceinline__ void dec32_body(const Dec32Args& a, const int M, const int tile, const int mt0,
+                                           u128 (&wf)[(EPI == EPI_SILU_MUL) ? 2 : 1][D32_U],
+                                           float (*red)[(EPI == EPI_SILU_MUL) ? 2 : 1][MBT][64][4], float* rstd_s) {
+  constexpr int NACC = (EPI == EPI_SILU_MUL) ? 2 : 1;
+  constexpr int U = D32_U;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 15, g = lane >> 4;
+  const int n0 = tile * 16, m0 = mt0 * 16;
+  const int N = a.N, K = a.K, KCH = K >> 4;
+
+  // finishing work = 4*NMB (row tile, accumulator register) pairs of 64 outputs; finishing wave w owns PPW consecutive pairs
+  // (see decode.hip): NMB >= 3: wave w finishes row tile w; NMB = 2: tile w/2, registers 2(w&1)..+1; NMB = 1: register w
+  constexpr int PPW = NMB >= 3 ? 4 : NMB;
+  constexpr int NF = NMB >= 3 ? NMB : 4;
+  const int fmb = (wave * PPW) >> 2, fr0 = (wave * PPW) & 3;   // meaningful for wave < NF
+  float pre0[PPW];  // RES: residual, requested before the operand loads
+#pragma unroll
+  for (int q = 0; q < PPW; ++q) pre0[q] = 0.f;
+  if (EPI == EPI_RES && wave < NF) {
+#pragma unroll
+    for (int q = 0; q < PPW; ++q) {
+      const int row = min(m0 + 16 * fmb + 4 * g + fr0 + q, M - 1);
+      pre0[q] = a.res[(size_t)row * a.ldr + n0 + li];
+    }
+  }
+  // QKV_ROPE tiles (weight rows permuted by the loader, engine.py rope_row_perm): columns 0..7 of a q/k tile are dims d0..d0+7 of
+  // one head, columns 8..15 are dims d0+32..d0+39, so a rotate-half pair sits 8 lanes apart.  The row's descriptor and the
+  // cos / sin of its position are requested here, before the operand loads.
+  const int sect = n0 / 768, hcol = n0 % 768, head = hcol >> 6, t4 = (hcol & 63) >> 4;
+  const int dlo = 8 * t4 + (li & 7);
+  RowDesc rd[PPW];
+  float rc[PPW], rsn[PPW];
+  if (EPI == D32_EPI_QKV_ROPE && wave < NF) {
+#pragma unroll
+    for (int q = 0; q < PPW; ++q) {
+      rd[q] = a.desc[min(m0 + 16 * fmb + 4 * g + fr0 + q, M - 1)];
+      rc[q] = a.cos_t[rd[q].pos * 32 + dlo];
+      rsn[q] = a.sin_t[rd[q].pos * 32 + dlo];
+    }
+  }
+
+  const int nper = KCH / 4;   // chunks per wave (launcher guarantees nper % U == 0); wave w owns chunks 4 i + w
+  const u128* wp = reinterpret_cast<const u128*>(a.Wp) + ((size_t)tile * KCH + wave) * 64 + lane;
+  const u128* wp2 = wp + (size_t)(N >> 4) * KCH * 64;  // SILU_MUL: the "up" tile of the same columns
+  const u128* ap = reinterpret_cast<const u128*>(a.Ap) + ((size_t)mt0 * KCH + wave) * 64 + lane;
+  const bool w_once = a.w_nt && gridDim.y == 1;  // a single row group reads W: stream it past the caches
+  u128 af[NMB][U];
+  float4 nw[U];
+  auto load_a = [&](const int i) {
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+      for (int j = 0; j < U; ++j) af[mb][j] = load16(ap + (size_t)mb * KCH * 64 + (size_t)(i + j) * 256);
+    if (RMS) {
+#pragma unroll
+      for (int j = 0; j < U; ++j) nw[j] = *reinterpret_cast<const float4*>(a.norm_w + ((i + j) * 4 + wave) * 16 + g * 4);
+    }
+  };
+  // with an RMSNorm prologue: the first round's activation fragments and gains are requested BEFORE the prologue's row loads, so
+  // the statistics cost no extra memory round trip
+  const bool early = RMS && a.a_early;
+  if (early) load_a(0);
+  if (RMS) {
+    // 1 / rms of the 16 NMB rows (gemm_skinny_k's arithmetic, common.hpp): wave w takes rows w, w+4, ...; at K = 768 four rows
+    // (12 loads per lane) are in flight together -- one memory round trip per batch instead of one per 256-column block
+    if (K == 768) {
+#pragma unroll
+      for (int r0 = 0; r0 < 16 * NMB; r0 += 16) {
+        const float* rows[4];
+        float rstd[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rows[q] = a.X + (size_t)min(m0 + r0 + wave + 4 * q, M - 1) * a.ldx;
+        wave_rows_rstd_768<4>(rows, a.eps, lane, rstd);
+        if (lane == 0) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) rstd_s[r0 + wave + 4 * q] = rstd[q];
+        }
+      }
+    } else {
+      for (int r = wave; r < 16 * NMB; r += 4) {
+        const float rstd = wave_row_rstd(a.X + (size_t)min(m0 + r, M - 1) * a.ldx, K, a.eps, lane);
+        if (lane == 0) rstd_s[r] = rstd;
+      }
+    }
+    __syncthreads();
+  }
+  float rs[NMB];
+#pragma unroll
+  for (int mb = 0; mb < NMB; ++mb) rs[mb] = RMS ? rstd_s[16 * mb + li] : 1.0f;
+
+
+  f32x4 acc[NACC][NMB];
+#pragma unroll
+  for (int na = 0; na < NACC; ++na)
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb) acc[na][mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int i = 0; i < nper; i += U) {
+    if (i > 0) {   // the first round's weight fragments were requested at kernel entry (before *n_active was known)
+      if (w_once) {
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+          wf[0][j] = load16_nt(wp + (size_t)(i + j) * 256);
+          if (NACC == 2) wf[1][j] = load16_nt(wp2 + (size_t)(i + j) * 256);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+          wf[0][j] = load16(wp + (size_t)(i + j) * 256);
+          if (NACC == 2) wf[1][j] = load16(wp2 + (size_t)(i + j) * 256);
+        }
+      }
+    }
+    if (i > 0 || !early) load_a(i);
+    // every load of the round in flight before the first MFMA (hipcc otherwise sinks each load next to its use)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < U; ++j)
+#pragma unroll
+      for (int mb = 0; mb < NMB; ++mb) {
+        float4 a0 = *reinterpret_cast<const float4*>(&af[mb][j]);
+        if (RMS) {
+          const float s = rs[mb];
+          a0.x = nw[j].x * (a0.x * s); a0.y = nw[j].y * (a0.y * s); a0.z = nw[j].z * (a0.z * s); a0.w = nw[j].w * (a0.w * s);
+        }
+#pragma unroll
+        for (int na = 0; na < NACC; ++na) {
+          const float4 b = *reinterpret_cast<const float4*>(&wf[na][j]);
+          f32x4 c = acc[na][mb];
+          c = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b.x, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b.y, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b.z, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b.w, c, 0, 0, 0);
+          acc[na][mb] = c;
+        }
+      }
+  }
+
+#pragma unroll
+  for (int na = 0; na < NACC; ++na)
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb) *reinterpret_cast<f32x4*>(&red[wave][na][mb][lane][0]) = acc[na][mb];
+  __syncthreads();
+  if (wave >= NF) return;
+
+  float t[4][NACC][PPW];   // the 4 waves' partials of this wave's outputs
+#pragma unroll
+  for (int w = 0; w < 4; ++w)
+#pragma unroll
+    for (int na = 0; na < NACC; ++na) {
+      if constexpr (PPW == 4) {
+        *reinterpret_cast<f32x4*>(t[w][na]) = *reinterpret_cast<const f32x4*>(&red[w][na][fmb][lane][0]);
+      } else if constexpr (PPW == 2) {
+        *reinterpret_cast<float2*>(t[w][na]) = *reinterpret_cast<const float2*>(&red[w][na][fmb][lane][fr0]);
+      } else {
+        t[w][na][0] = red[w][na][fmb][lane][fr0];
+      }
+    }
+
+  const int col = n0 + li;
+#pragma unroll
+  for (int q = 0; q < PPW; ++q) {
+    const int row = m0 + 16 * fmb + 4 * g + fr0 + q;  // C/D map of the 16x16 MFMA: col = lane & 15, row = 4 (lane >> 4) + reg
+    float v = ((t[0][0][q] + t[1][0][q]) + t[2][0][q]) + t[3][0][q];   // fixed order, as gemm_skinny_k
+    if (EPI == EPI_SILU_MUL) {
+      const float u = ((t[0][NACC - 1][q] + t[1][NACC - 1][q]) + t[2][NACC - 1][q]) + t[3][NACC - 1][q];
+      v = silu_f(v) * u;
+    } else if (EPI == EPI_RES) {
+      v = pre0[q] + v;
+    }
+    if (EPI == D32_EPI_QKV_ROPE) {   // q -> roped, qkv buffer; k -> roped, KV cache; v -> KV cache  (rope_append_k, gpt.hip)
+      const float other = __shfl_xor(v, 8, 64);   // every lane of the wave is here (rows are skipped below, not above)
+      const bool hi = li >= 8;
+      const float roped = hi ? rope_hi(other, v, rc[q], rsn[q]) : rope_lo(v, other, rc[q], rsn[q]);
+      const int d = dlo + (hi ? 32 : 0);
+      if (row < M && rd[q].b >= 0) {
+        const size_t cbase = (((size_t)rd[q].b * 12 + head) * a.cmax + rd[q].slot) * 64;
+        if (sect == 0) a.C[(size_t)row * a.ldc + head * 64 + d] = roped;
+        else if (sect == 1) a.kc[cbase + d] = roped;
+        else a.vc[cbase + (hcol & 63) + li] = v;
+      }
+      continue;
+    }
+    if (row >= M || (EPI == EPI_STORE && col >= a.n_cols)) continue;
+    if (EPI != EPI_SILU_MUL) a.C[(size_t)row * a.ldc + col] = v;
+    if (EPI != EPI_STORE && a.Cp != nullptr) a.Cp[pk32_off(row, col, a.kch_out)] = v;
+  }
+}
+
+template <int MBT, bool RMS, int EPI>
+__global__ __launch_bounds__(256) void gemm_dec32_k(Dec32Args a) {
+  constexpr int NACC = (EPI == EPI_SILU_MUL) ? 2 : 1;
+  __shared__ __attribute__((aligned(16))) float red[4][NACC][MBT][64][4];
+  __shared__ float rstd_s[16 * MBT];
+
+  const int tile = blockIdx.x, mt0 = blockIdx.y * MBT;
+  // the weight fragments of the first round depend on nothing but the kernel arguments: request them before the live-row
+  // count (a dependent scalar load) is known
+  u128 wf[NACC][D32_U];
+  {
+    const int KCH = a.K >> 4, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const u128* wp = reinterpret_cast<const u128*>(a.Wp) + ((size_t)tile * KCH + wave) * 64 + lane;
+    const u128* wp2 = wp + (size_t)(a.N >> 4) * KCH * 64;
+    const bool w_once = a.w_nt && gridDim.y == 1;
+    if (w_once) {
+#pragma unroll
+      for (int j = 0; j < D32_U; ++j) {
+        wf[0][j] = load16_nt(wp + (size_t)j * 256);
+        if (NACC == 2) wf[1][j] = load16_nt(wp2 + (size_t)j * 256);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < D32_U; ++j) {
+        wf[0][j] = load16(wp + (size_t)j * 256);
+        if (NACC == 2) wf[1][j] = load16(wp2 + (size_t)j * 256);
+      }
+    }
+  }
+  const int M = a.n_active ? min(*a.n_active, a.M) : a.M;   // live (compact) rows
+  if (mt0 * 16 >= M) return;
+  const int nmb = min(MBT, (M - mt0 * 16 + 15) >> 4);
+  if constexpr (MBT == 1) {
+    dec32_body<1, MBT, RMS, EPI>(a, M, tile, mt0, wf, red, rstd_s);
+  } else if constexpr (MBT == 2) {
+    if (nmb == 1) dec32_body<1, MBT, RMS, EPI>(a, M, tile, mt0, wf, red, rstd_s);
+    else dec32_body<2, MBT, RMS, EPI>(a, M, tile, mt0, wf, red, rstd_s);
+  } else {
+    if (nmb == 1) dec32_body<1, MBT, RMS, EPI>(a, M, tile, mt0, wf, red, rstd_s);
+    else if (nmb == 2) dec32_body<2, MBT, RMS, EPI>(a, M, tile, mt0, wf, red, rstd_s);
+    else if (nmb == 3) dec32_body<3, MBT, RMS, EPI>(a, M, tile, mt0, wf, red, rstd_s);
+    else dec32_body<4, MBT, RMS, EPI>(a, M, tile, mt0, wf, red, rstd_s);
+  }
+}
+
+// o_proj / down_proj (no RMSNorm prologue) as 16-row workgroups, K known at compile time, with every load the workgroup can
+// issue up front in flight at kernel entry: K = 768: ALL 12 chunks of the wave (W and A fragments) are requested before the
+// live-row count is even known, so the workgroup pays one memory round trip, not one per stage; K = 3072: stages of 6 chunks,
+// double-buffered (stage r+1 requested before stage r is multiplied).  Same operation order per output element as above.
+// (With an RMSNorm prologue this shape was SLOWER than the generic body -- 200+ VGPRs, profiles/r2s_* -- see gemm_dec32_rms16_k.)
+template <int KT, int EPI>
+__global__ __launch_bounds__(256) void gemm_dec32_m16_k(Dec32Args a) {
+  constexpr int NACC = 1;
+  constexpr int KCH = KT / 16, NPER = KCH / 4;   // chunks per wave: 12 / 48
+  constexpr int U = (KT == 768) ? 12 : 6;         // chunks per stage
+  constexpr int ROUNDS = NPER / U;                // 1 / 8
+  static_assert(ROUNDS == 1 || ROUNDS % 2 == 0, "stages are consumed in pairs");
+  __shared__ __attribute__((aligned(16))) float red[4][NACC][64][4];
+  struct Stage { u128 w[NACC][U]; u128 a[U]; };
+
+  const int tile = blockIdx.x, mt0 = blockIdx.y;
+  if (tile >= (a.N >> 4)) return;   // the grid's x extent is rounded up to a multiple of 8 (see dec32_dispatch_m16)
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 15, g = lane >> 4;
+  const int n0 = tile * 16, m0 = mt0 * 16;
+  const u128* wp = reinterpret_cast<const u128*>(a.Wp) + ((size_t)tile * KCH + wave) * 64 + lane;   // wave w owns chunks 4 i + w
+  const u128* wp2 = wp + (size_t)(a.N >> 4) * KCH * 64;
+  const u128* ap = reinterpret_cast<const u128*>(a.Ap) + ((size_t)mt0 * KCH + wave) * 64 + lane;
+  const bool w_once = a.w_nt && gridDim.y == 1;
+  auto load_stage = [&](Stage& s, const int r) {
+    if (w_once) {
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        s.w[0][j] = load16_nt(wp + (size_t)(r * U + j) * 256);
+        if (NACC == 2) s.w[1][j] = load16_nt(wp2 + (size_t)(r * U + j) * 256);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        s.w[0][j] = load16(wp + (size_t)(r * U + j) * 256);
+        if (NACC == 2) s.w[1][j] = load16(wp2 + (size_t)(r * U + j) * 256);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < U; ++j) s.a[j] = load16(ap + (size_t)(r * U + j) * 256);
+  };
+  Stage s0;
+  load_stage(s0, 0);   // the row tile's buffer exists whether or not its rows are live: nothing here depends on *n_active
+  const int M = a.n_active ? min(*a.n_active, a.M) : a.M;
+  if (m0 >= M) return;
+
+  float pre0 = 0.f;   // RES: wave w finishes accumulator register w
+  if (EPI == EPI_RES) pre0 = a.res[(size_t)min(m0 + 4 * g + wave, M - 1) * a.ldr + n0 + li];
+  f32x4 acc[NACC];
+#pragma unroll
+  for (int na = 0; na < NACC; ++na) acc[na] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  auto mul_stage = [&](const Stage& s) {
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      const float4 a0 = *reinterpret_cast<const float4*>(&s.a[j]);
+#pragma unroll
+      for (int na = 0; na < NACC; ++na) {
+        const float4 b = *reinterpret_cast<const float4*>(&s.w[na][j]);
+        f32x4 c = acc[na];
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b.x, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b.y, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b.z, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b.w, c, 0, 0, 0);
+        acc[na] = c;
+      }
+    }
+  };
+  if constexpr (ROUNDS == 1) {
+    mul_stage(s0);
+  } else {
+    Stage s1;
+    for (int r = 0; r < ROUNDS; r += 2) {
+      load_stage(s1, r + 1);
+      __builtin_amdgcn_sched_barrier(0);   // keep the next stage's loads ahead of this stage's MFMAs
+      mul_stage(s0);
+      if (r + 2 < ROUNDS) load_stage(s0, r + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      mul_stage(s1);
+    }
+  }
+
+#pragma unroll
+  for (int na = 0; na < NACC; ++na) *reinterpret_cast<f32x4*>(&red[wave][na][lane][0]) = acc[na];
+  __syncthreads();
+  const int row = m0 + 4 * g + wave, col = n0 + li;   // C/D map: col = lane & 15, row = 4 (lane >> 4) + register (= wave here)
+  if (row >= M) return;
+  float v = ((red[0][0][lane][wave] + red[1][0][lane][wave]) + red[2][0][lane][wave]) + red[3][0][lane][wave];   // fixed order
+  if (EPI == EPI_SILU_MUL) {
+    const float u = ((red[0][NACC - 1][lane][wave] + red[1][NACC - 1][lane][wave]) + red[2][NACC - 1][lane][wave]) + red[3][NACC - 1][lane][wave];
+    v = silu_f(v) * u;
+  } else if (EPI == EPI_RES) {
+    v = pre0 + v;
+  }
+  if (EPI == EPI_STORE && col >= a.n_cols) return;   // padded columns of the last tile (heads)
+  if (EPI != EPI_SILU_MUL) a.C[(size_t)row * a.ldc + col] = v;
+  if (EPI != EPI_STORE && a.Cp != nullptr) a.Cp[pk32_off(row, col, a.kch_out)] = v;
+}
+
+// RMSNorm launches (QKV, gate/up) as 16-row workgroups WITHOUT re-reading the residual rows for their statistics: the workgroup
+// already holds the whole 16 x 768 activation tile as MFMA fragments (12 chunks per wave), and the pinned summation order of
+// wave_row_rstd (common.hpp) happens to decompose along the fragment layout.  wave_row_rstd gives "virtual lane" l columns
+// 256 t + 4 l .. + 3 (t = 0, 1, 2), adds the three blocks in order, then runs the xor butterfly 32, 16, 8, 4, 2, 1 over l.
+// Columns 256 t + 4 l sit in chunk 16 t + l / 4, lane group g = l % 4 -- chunks 16 t + c0 all belong to wave c0 % 4 -- so the
+// fragment lane (g, row) of wave w owns the virtual lanes l = 16 q + 4 w + g, q = 0..3 (local chunks q, q + 4, q + 8), and the
+// butterfly becomes: levels 32 and 16 = adds between the lane's own four partials (q ^ 2, then q ^ 1), levels 8 and 4 = adds
+// across the four waves (w ^ 2, then w ^ 1; one 1 KiB LDS exchange), levels 2 and 1 = adds across lane groups (lane ^ 32, then
+// lane ^ 16).  Same operands, same association, same bits -- and the launch moves 25 % less through the L2s and loses a
+// dependent memory round trip.  Weights come in rounds of 6 (gate/up: 4) chunks (VGPR budget: 3 workgroups per CU).
+template <int EPI>
+__global__ __launch_bounds__(256, 3) void gemm_dec32_rms16_k(Dec32Args a) {
+  constexpr int NACC = (EPI == EPI_SILU_MUL) ? 2 : 1;
+  constexpr int KCH = 48, NPER = 12;
+  constexpr int WU = (NACC == 2) ? 4 : 6;          // weight chunks per round (VGPR budget: 3 workgroups per CU)
+  __shared__ __attribute__((aligned(16))) float red[4][NACC][64][4];
+  __shared__ float bs[4][64];
+
+  const int tile = blockIdx.x, mt0 = blockIdx.y;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 15, g = lane >> 4;
+  const int n0 = tile * 16, m0 = mt0 * 16;
+  const u128* wp = reinterpret_cast<const u128*>(a.Wp) + ((size_t)tile * KCH + wave) * 64 + lane;   // wave w owns chunks 4 i + w
+  const u128* wp2 = wp + (size_t)(a.N >> 4) * KCH * 64;
+  const u128* ap = reinterpret_cast<const u128*>(a.Ap) + ((size_t)mt0 * KCH + wave) * 64 + lane;
+  const bool w_once = a.w_nt && gridDim.y == 1;
+  u128 wf[NACC][WU], af[NPER];
+  float4 nw[WU];
+  auto load_w = [&](const int i0) {
+    if (w_once) {
+#pragma unroll
+      for (int j = 0; j < WU; ++j) {
+        wf[0][j] = load16_nt(wp + (size_t)(i0 + j) * 256);
+        if (NACC == 2) wf[1][j] = load16_nt(wp2 + (size_t)(i0 + j) * 256);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < WU; ++j) {
+        wf[0][j] = load16(wp + (size_t)(i0 + j) * 256);
+        if (NACC == 2) wf[1][j] = load16(wp2 + (size_t)(i0 + j) * 256);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < WU; ++j) nw[j] = *reinterpret_cast<const float4*>(a.norm_w + ((i0 + j) * 4 + wave) * 16 + g * 4);
+  };
+  // everything the workgroup can ask for without knowing the live-row count (its row tile's buffer exists either way)
+#pragma unroll
+  for (int i = 0; i < NPER; ++i) af[i] = load16(ap + (size_t)i * 256);
+  load_w(0);
+  const int M = a.n_active ? min(*a.n_active, a.M) : a.M;
+  if (m0 >= M) return;
+
+  const int row = m0 + 4 * g + wave, col = n0 + li;   // C/D map: col = lane & 15, row = 4 (lane >> 4) + register (= wave here)
+  const int sect = n0 / 768, hcol = n0 % 768, head = hcol >> 6, t4 = (hcol & 63) >> 4;
+  const int dlo = 8 * t4 + (li & 7);
+  RowDesc rd = RowDesc{-1, 0, 0, 0};
+  float rc = 0.f, rsn = 0.f;
+  if (EPI == D32_EPI_QKV_ROPE) {
+    rd = a.desc[min(row, M - 1)];
+    rc = a.cos_t[rd.pos * 32 + dlo];
+    rsn = a.sin_t[rd.pos * 32 + dlo];
+  }
+
+  // 1 / rms of row li from the fragments (see above)
+  float sq[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float s = rms_acc4(0.f, *reinterpret_cast<const float4*>(&af[q]));
+    s = rms_acc4(s, *reinterpret_cast<const float4*>(&af[q + 4]));
+    sq[q] = rms_acc4(s, *reinterpret_cast<const float4*>(&af[q + 8]));
+  }
+  float rs;
+  {
+#pragma clang fp contract(off)
+    const float b = (sq[0] + sq[2]) + (sq[1] + sq[3]);          // butterfly levels 32, 16
+    bs[wave][lane] = b;
+    __syncthreads();
+    const float c = (bs[wave][lane] + bs[wave ^ 2][lane]) + (bs[wave ^ 1][lane] + bs[wave ^ 3][lane]);   // levels 8, 4
+    const float e = c + __shfl_xor(c, 32, 64);                  // level 2
+    const float f = e + __shfl_xor(e, 16, 64);                  // level 1
+    rs = rms_rstd_of(f, 768, a.eps);
+  }
+
+  f32x4 acc[NACC];
+#pragma unroll
+  for (int na = 0; na < NACC; ++na) acc[na] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i0 = 0; i0 < NPER; i0 += WU) {
+    if (i0 > 0) load_w(i0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < WU; ++j) {
+      float4 a0 = *reinterpret_cast<const float4*>(&af[i0 + j]);
+      a0.x = nw[j].x * (a0.x * rs); a0.y = nw[j].y * (a0.y * rs); a0.z = nw[j].z * (a0.z * rs); a0.w = nw[j].w * (a0.w * rs);
+#pragma unroll
+      for (int na = 0; na < NACC; ++na) {
+        const float4 b = *reinterpret_cast<const float4*>(&wf[na][j]);
+        f32x4 c = acc[na];
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b.x, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b.y, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b.z, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b.w, c, 0, 0, 0);
+        acc[na] = c;
+      }
+    }
+  }
+
+#pragma unroll
+  for (int na = 0; na < NACC; ++na) *reinterpret_cast<f32x4*>(&red[wave][na][lane][0]) = acc[na];
+  __syncthreads();
+  float v = ((red[0][0][lane][wave] + red[1][0][lane][wave]) + red[2][0][lane][wave]) + red[3][0][lane][wave];   // fixed order
+  if (EPI == EPI_SILU_MUL) {
+    const float u = ((red[0][NACC - 1][lane][wave] + red[1][NACC - 1][lane][wave]) + red[2][NACC - 1][lane][wave]) + red[3][NACC - 1][lane][wave];
+    v = silu_f(v) * u;
+    if (row < M && a.Cp != nullptr) a.Cp[pk32_off(row, col, a.kch_out)] = v;
+  } else if (EPI == D32_EPI_QKV_ROPE) {
+    const float other = __shfl_xor(v, 8, 64);
+    const bool hi = li >= 8;
+    const float roped = hi ? rope_hi(other, v, rc, rsn) : rope_lo(v, other, rc, rsn);
+    const int d = dlo + (hi ? 32 : 0);
+    if (row < M && rd.b >= 0) {
+      const size_t cbase = (((size_t)rd.b * 12 + head) * a.cmax + rd.slot) * 64;
+      if (sect == 0) a.C[(size_t)row * a.ldc + head * 64 + d] = roped;
+      else if (sect == 1) a.kc[cbase + d] = roped;
+      else a.vc[cbase + (hcol & 63) + li] = v;
+    }
+  } else {
+    if (row < M && col < a.n_cols) a.C[(size_t)row * a.ldc + col] = v;
+  }
+}
+
+template <int KT>
+static hipError_t dec32_dispatch_m16(const Dec32Args& a, hipStream_t st) {
+  // x extent a multiple of 8: workgroup (tile, row tile) then runs on XCD tile % 8 for EVERY row tile, so a weight tile is fetched
+  // from HBM once (into that XCD's L2) and not once per row tile.  Only the heads need it (157 tiles: PMC showed 32.9 MB per
+  // launch against 8.2 MB of weights); 48 / 144 / 192 tiles are multiples of 8 already.
+  dim3 grid((a.N / 16 + 7) / 8 * 8, (a.M + 15) / 16), block(256);
+  if (a.norm_w != nullptr) return hipErrorInvalidValue;
+  if (a.epi == EPI_STORE) CTTS_LAUNCH((gemm_dec32_m16_k<KT, EPI_STORE>), grid, block, st, a);
+  else if (a.epi == EPI_RES) CTTS_LAUNCH((gemm_dec32_m16_k<KT, EPI_RES>), grid, block, st, a);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+static int env_int32(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
+template <int MBT>
+static hipError_t dec32_dispatch(const Dec32Args& a, hipStream_t st) {
+  const int mt = (a.M + 15) / 16;
+  dim3 grid(a.N / 16, (mt + MBT - 1) / MBT), block(256);
+  const bool rms = a.norm_w != nullptr;
+  if (a.epi == EPI_STORE && rms) CTTS_LAUNCH((gemm_dec32_k<MBT, true, EPI_STORE>), grid, block, st, a);
+  else if (a.epi == EPI_STORE) CTTS_LAUNCH((gemm_dec32_k<MBT, false, EPI_STORE>), grid, block, st, a);
+  else if (a.epi == EPI_RES && !rms) CTTS_LAUNCH((gemm_dec32_k<MBT, false, EPI_RES>), grid, block, st, a);
+  else if (a.epi == EPI_SILU_MUL && rms) CTTS_LAUNCH((gemm_dec32_k<MBT, true, EPI_SILU_MUL>), grid, block, st, a);
+  else if (a.epi == D32_EPI_QKV_ROPE && rms) CTTS_LAUNCH((gemm_dec32_k<MBT, true, D32_EPI_QKV_ROPE>), grid, block, st, a);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+// which kernel the last launch_gemm_dec32 of this thread picked: every variant produces the same bits, so only this (and a
+// profiler) can tell a dispatch regression from the intended path (tests/test_gpu_kernels.py asserts the default choices)
+static thread_local const char* g_d32_variant = "";
+const char* dec32_last_variant() { return g_d32_variant; }
+
+hipError_t launch_gemm_dec32(const Dec32Args& a_in, hipStream_t st) {
+  Dec32Args a = a_in;
+  static int nt = -1, mb_qkv = -1, mb_silu = -1, mb_o = -1, mb_down = -1, a_early = 1;
+  if (nt < 0) {
+    nt = env_int32("CTTS_W_NT", 1);
+    a_early = env_int32("CTTS_D32_A_EARLY", 1);
+    mb_qkv = env_int32("CTTS_D32_MB_QKV", 1); mb_silu = env_int32("CTTS_D32_MB_SILU", 1);
+    mb_o = env_int32("CTTS_D32_MB_O", 1); mb_down = env_int32("CTTS_D32_MB_DOWN", 1);
+  }
+  a.w_nt = nt;
+  a.a_early = a_early;
+  if (a.n_cols <= 0 || a.n_cols > a.N) a.n_cols = a.N;
+  // K: chunks of 16, 4 waves, rounds of D32_U chunks
+  if (a.M <= 0 || a.N <= 0 || (a.N & 15) || a.K % (16 * 4 * D32_U) != 0) return hipErrorInvalidValue;
+  if (a.norm_w != nullptr && (a.X == nullptr || (a.ldx & 3))) return hipErrorInvalidValue;
+  if (a.epi == D32_EPI_QKV_ROPE && (a.N != 2304 || a.K != 768 || !a.desc || !a.kc || !a.vc)) return hipErrorInvalidValue;
+  // Rows per workgroup.  f32 MFMA (256 flop per clock and CU) is what these launches are made of -- 64 x 2304 x 768 costs 3.5k
+  // clocks of every CU if perfectly spread -- so the row tiles are cut until the grid has a few workgroups per CU; the 16-row
+  // workgroups of o / down (48 weight tiles only) are the same choice the bf16 kernel makes.
+  int mb = a.epi == EPI_SILU_MUL ? mb_silu : a.epi == EPI_RES ? (a.K > 768 ? mb_down : mb_o) : mb_qkv;
+  if (a.force_mb) mb = a.force_mb;
+  // 16-row RMSNorm launches (QKV, gate/up): statistics from the fragments, no re-read of the residual rows
+  static int rms16 = -1;   // CTTS_D32_RMS16=0: the generic body (statistics from the row-major rows) instead (A/B)
+  if (rms16 < 0) rms16 = env_int32("CTTS_D32_RMS16", 1);
+  if (mb == 1 && rms16 && a.norm_w != nullptr && a.K == 768) {
+    g_d32_variant = "rms16";
+    dim3 grid(a.N / 16, (a.M + 15) / 16), block(256);
+    if (a.epi == EPI_SILU_MUL) CTTS_LAUNCH((gemm_dec32_rms16_k<EPI_SILU_MUL>), grid, block, st, a);
+    else if (a.epi == D32_EPI_QKV_ROPE) CTTS_LAUNCH((gemm_dec32_rms16_k<D32_EPI_QKV_ROPE>), grid, block, st, a);
+    else if (a.epi == EPI_STORE) CTTS_LAUNCH((gemm_dec32_rms16_k<EPI_STORE>), grid, block, st, a);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+  }
+  // 16-row workgroups without an RMSNorm prologue (o / down, the heads) take the everything-up-front kernel
+  static int m16 = -1;   // CTTS_D32_M16=0: the generic body instead (A/B)
+  if (m16 < 0) m16 = env_int32("CTTS_D32_M16", 1);
+  g_d32_variant = "m16";
+  if (mb == 1 && m16 && a.norm_w == nullptr && a.K == 768) return dec32_dispatch_m16<768>(a, st);
+  if (mb == 1 && m16 && a.norm_w == nullptr && a.K == 3072) return dec32_dispatch_m16<3072>(a, st);
+  g_d32_variant = "generic";
+  if (mb >= 4) return dec32_dispatch<4>(a, st);
+  if (mb == 2) return dec32_dispatch<2>(a, st);
+  return dec32_dispatch<1>(a, st);
+}

@@ -1,0 +1,1045 @@
+// GPT-step kernels for gfx950 other than the projections: code-embedding sum, RoPE + KV append,
+// decode/prefill attention, final RMSNorm + hidden capture, and the fused sampling chain.
+// Reference call sites are cited per kernel; all of them live in the per-step body of
+// /root/reference/ChatTTS/model/gpt.py:396-577 or in the HF LlamaModel forward it calls.
+#include <stdlib.h>
+
+#include "common.hpp"
+#include "kernels.hpp"
+
+#define HID 768
+#define NHEAD 12
+#define HDIM 64
+#define NVQ 4
+#define NAUDIO 626
+
+__device__ __forceinline__ void row_to_b_slot(const GptRowMap& rm, int m, int& b, int& slot) {
+  if (rm.q_per_b == 1) { b = rm.row_map ? rm.row_map[m] : m; slot = rm.len[b] - 1; }
+  else { b = m / rm.q_per_b; slot = rm.slot0 + m - b * rm.q_per_b; if (rm.row_map) b = rm.row_map[b]; }  // prefill (chunk), slot pool
+}
+// decode launches keep the captured grid (B rows); rows beyond the compact active count do nothing
+__device__ __forceinline__ bool row_absent(const int32_t* n_active, int m) { return n_active != nullptr && m >= *n_active; }
+
+// ------------------------------------------------------------------------------------------------
+// G1  x[b] = sum_k emb_code[k][ids_buf[b, len[b]-1, k]]     (gpt.py:403-415; k-ordered f32 adds
+//     like torch.stack(code_emb, 3).sum(3))
+// ------------------------------------------------------------------------------------------------
+// emit one residual-stream row: f32, optional bf16 copy, optional 48 partial sums of squares
+// (thread t owns columns 4t..4t+3; a partial covers 16 columns = 4 consecutive threads)
+__device__ __forceinline__ void emit_row(float4 s, int t, float* __restrict__ x_row, uint16_t* __restrict__ xb_row,
+                                         float* __restrict__ ssq_row, float* __restrict__ xp32_at = nullptr) {
+  if (x_row) *reinterpret_cast<float4*>(x_row + t * 4) = s;
+  if (xp32_at) *reinterpret_cast<float4*>(xp32_at) = s;   // columns 4t..4t+3 are one lane's 16 bytes of the packed f32 order
+  if (xb_row) {
+    ushort4 o;
+    o.x = f32_to_bf16(s.x); o.y = f32_to_bf16(s.y); o.z = f32_to_bf16(s.z); o.w = f32_to_bf16(s.w);
+    *reinterpret_cast<ushort4*>(xb_row + t * 4) = o;   // columns 4t..4t+3 share one 8-column group in either layout
+  }
+  if (ssq_row) {
+    float q = (s.x * s.x + s.y * s.y) + (s.z * s.z + s.w * s.w);
+    q += __shfl_xor(q, 1, 64);
+    q += __shfl_xor(q, 2, 64);
+    if ((t & 3) == 0) ssq_row[t >> 2] = q;
+  }
+}
+
+// The first kernel of a decode step also writes the step's row descriptors (kernels.hpp RowDesc): it walks
+// row_map -> len -> kv_start -> finish once, the 20 QKV epilogues and 20 attention launches behind it start from desc[m].
+__device__ __forceinline__ void write_desc(const StepPrep& sp, int m, int b, int slot) {
+  RowDesc d;
+  const int ks = sp.kv_start[b];
+  d.b = (sp.finish != nullptr && sp.finish[b]) ? -1 : b;
+  d.slot = slot;
+  d.pos = slot - ks < 0 ? 1 : slot - ks;   // pad slots get position 1 (gpt.py:234-241)
+  d.jlo = ks > slot ? slot : ks;
+  sp.desc[m] = d;
+}
+// Device-side compaction: which utterance is compact row m, and how many rows are live.  Every wave of the workgroup
+// evaluates this itself (the finish bytes are one load for B <= 64; no barrier).  Returns -1 when row m does not exist.
+__device__ __forceinline__ int nth_unfinished(const uint8_t* __restrict__ finish, int B, int m, int& total) {
+  const int lane = threadIdx.x & 63;
+  int cnt = 0, found = -1;
+  for (int base = 0; base < B; base += 64) {
+    const int idx = base + lane;
+    const bool alive = idx < B && finish[idx] == 0;
+    const unsigned long long mask = __ballot(alive);
+    const int c = __popcll(mask);
+    if (found < 0 && m < cnt + c) {
+      const int r = m - cnt;   // the r-th set bit of mask
+      const bool mine = alive && __popcll(mask & ((1ull << lane) - 1ull)) == r;
+      const unsigned long long pick = __ballot(mine);
+      found = base + (int)__ffsll((long long)pick) - 1;
+    }
+    cnt += c;
+  }
+  total = cnt;
+  return found;
+}
+
+__device__ __forceinline__ uint16_t* xb_row_ptr(uint16_t* xb, int m, int t, int packed) {
+  // emit_row adds 4t itself: hand it a base such that base + 4t is where columns 4t..4t+3 of row m live
+  if (!xb) return nullptr;
+  return packed ? xb + pk_off(m, 4 * t, HID / 32) - 4 * t : xb + (size_t)m * HID;
+}
+
+__global__ __launch_bounds__(192) void embed_codes_k(const float* __restrict__ emb, const int64_t* __restrict__ ids_buf,
+                                                     int tcap, const int32_t* __restrict__ len, float* __restrict__ x,
+                                                     uint16_t* __restrict__ xb, float* __restrict__ ssq,
+                                                     const int32_t* __restrict__ row_map, const int32_t* __restrict__ n_active,
+                                                     StepPrep sp) {
+  const int m = blockIdx.x, t = threadIdx.x;
+  int b;
+  if (sp.row_map_out != nullptr) {   // device-side compaction: this step's row order comes from the finish flags
+    int total;
+    b = nth_unfinished(sp.finish, gridDim.x, m, total);
+    if (m == 0 && t == 0) *sp.n_active_out = total;
+    if (b < 0) {   // row m does not exist this step: say so in its descriptor (the attention kernel reads nothing else)
+      if (sp.desc != nullptr && t == 0) sp.desc[m] = RowDesc{-1, 0, 0, 0};
+      return;
+    }
+    if (t == 0) sp.row_map_out[m] = b;
+  } else {
+    if (row_absent(n_active, m)) return;
+    b = row_map ? row_map[m] : m;
+  }
+  const int slot = len[b] - 1;
+  if (sp.desc != nullptr && t == 0) write_desc(sp, m, b, slot);
+  const int64_t* tok = ids_buf + ((size_t)b * tcap + slot) * NVQ;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int k = 0; k < NVQ; ++k) {
+    int id = (int)tok[k];
+    id = min(max(id, 0), NAUDIO - 1);
+    const float4 v = *reinterpret_cast<const float4*>(emb + ((size_t)k * NAUDIO + id) * HID + t * 4);
+    if (k == 0) s = v; else { s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+  }
+  emit_row(s, t, x + (size_t)m * HID, xb_row_ptr(xb, m, t, sp.xb_packed), ssq ? ssq + (size_t)m * SSQ_PARTS : nullptr,
+           sp.xp32 ? sp.xp32 + pk32_off(m, 4 * t, HID / 16) : nullptr);
+}
+
+static StepPrep prep_or_none(const StepPrep* p) {
+  StepPrep sp{nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr};
+  if (p) sp = *p;
+  return sp;
+}
+
+hipError_t launch_embed_codes(const float* emb_code, const int64_t* ids_buf, int tcap, const int32_t* len, float* x, uint16_t* xb,
+                              float* ssq, int B, const int32_t* row_map, const int32_t* n_active, hipStream_t st, const StepPrep* prep) {
+  CTTS_LAUNCH(embed_codes_k, dim3(B), dim3(192), st, emb_code, ids_buf, tcap, len, x, xb, ssq, row_map, n_active, prep_or_none(prep));
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(192) void rows_prep_k(const float* __restrict__ x, uint16_t* __restrict__ xb, float* __restrict__ ssq) {
+  const int m = blockIdx.x, t = threadIdx.x;
+  const float4 s = *reinterpret_cast<const float4*>(x + (size_t)m * HID + t * 4);
+  emit_row(s, t, nullptr, xb + (size_t)m * HID, ssq + (size_t)m * SSQ_PARTS);
+}
+
+hipError_t launch_rows_prep(const float* x32, uint16_t* xb, float* ssq, int M, hipStream_t st) {
+  CTTS_LAUNCH(rows_prep_k, dim3(M), dim3(192), st, x32, xb, ssq);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// G4  RoPE (rotate-half, HF modeling_llama apply_rotary_pos_emb; in-tree twin
+//     /root/reference/examples/onnx/modeling_llama.py:239-256) on q (in place) and k, then append k,v
+//     to the cache at `slot`.  Position = slot - kv_start[b] (gpt.py:234-241; pad slots get 1).
+//     cos/sin come from a host table built with the reference's own f32 ops.
+// ------------------------------------------------------------------------------------------------
+template <typename KT> __device__ __forceinline__ KT to_kt(float v);
+template <> __device__ __forceinline__ float to_kt<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t to_kt<bf16_t>(float v) { return f32_to_bf16(v); }
+
+template <typename KT>
+__global__ __launch_bounds__(384) void rope_append_k(float* __restrict__ qkv, KT* __restrict__ kc, KT* __restrict__ vc, int cmax,
+                                                     const float* __restrict__ cos_t, const float* __restrict__ sin_t,
+                                                     GptRowMap rm) {
+  const int m = blockIdx.x, t = threadIdx.x;  // t: head = t / 32, pair d = t % 32
+  if (rm.q_per_b == 1 && row_absent(rm.n_active, m)) return;
+  int b, slot;
+  row_to_b_slot(rm, m, b, slot);
+  int pos = slot - rm.kv_start[b];
+  if (pos < 0) pos = 1;
+  const int h = t >> 5, d = t & 31;
+  const float c = cos_t[pos * 32 + d], s = sin_t[pos * 32 + d];
+  float* row = qkv + (size_t)m * (3 * HID);
+  // q
+  {
+    float* q = row + h * HDIM;
+    const float x1 = q[d], x2 = q[d + 32];
+    q[d] = rope_lo(x1, x2, c, s);
+    q[d + 32] = rope_hi(x1, x2, c, s);
+  }
+  const size_t base = (((size_t)b * NHEAD + h) * cmax + slot) * HDIM;
+  {
+    const float* k = row + HID + h * HDIM;
+    const float x1 = k[d], x2 = k[d + 32];
+    kc[base + d] = to_kt<KT>(rope_lo(x1, x2, c, s));
+    kc[base + d + 32] = to_kt<KT>(rope_hi(x1, x2, c, s));
+  }
+  {
+    const float* v = row + 2 * HID + h * HDIM;
+    vc[base + d] = to_kt<KT>(v[d]);
+    vc[base + d + 32] = to_kt<KT>(v[d + 32]);
+  }
+}
+
+hipError_t launch_rope_append(float* qkv, void* kcache, void* vcache, int kv_wt, int cmax, const float* cos_tab,
+                              const float* sin_tab, GptRowMap rm, int M, hipStream_t st) {
+  if (kv_wt == WT_BF16)
+    CTTS_LAUNCH((rope_append_k<bf16_t>), dim3(M), dim3(384), st, qkv, (bf16_t*)kcache, (bf16_t*)vcache, cmax, cos_tab,
+                       sin_tab, rm);
+  else
+    CTTS_LAUNCH((rope_append_k<float>), dim3(M), dim3(384), st, qkv, (float*)kcache, (float*)vcache, cmax, cos_tab,
+                       sin_tab, rm);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// G5  attention for one query row and one head: softmax_f32(q.K^T / 8 + mask) V with the causal +
+//     left-pad mask of the reference (keys in [kv_start[b], slot]).  KV is streamed from HBM with
+//     fully coalesced 16-byte lane loads: LPK lanes share one key row (128 B bf16 / 256 B f32), a wave
+//     load instruction covers 64/LPK consecutive keys = 1 KiB contiguous, 8 K-loads + 8 V-loads are in
+//     flight per wave per block; the dot product is finished with log2(LPK) xor-shuffles, softmax is
+//     online (running max / sum per wave) and the NW waves of a workgroup split the key blocks and
+//     merge through LDS.
+// ------------------------------------------------------------------------------------------------
+template <typename KT> struct KTraits;
+template <> struct KTraits<float>  { static constexpr int DPL = 4; };  // dims per lane (16 B)
+template <> struct KTraits<bf16_t> { static constexpr int DPL = 8; };
+
+template <typename KT, int DPL> __device__ __forceinline__ void unpack16(const u128& r, float* f);
+template <> __device__ __forceinline__ void unpack16<float, 4>(const u128& r, float* f) {
+  f[0] = __uint_as_float(r.x); f[1] = __uint_as_float(r.y); f[2] = __uint_as_float(r.z); f[3] = __uint_as_float(r.w);
+}
+template <> __device__ __forceinline__ void unpack16<bf16_t, 8>(const u128& r, float* f) {
+  f[0] = __uint_as_float(r.x << 16); f[1] = __uint_as_float(r.x & 0xffff0000u);
+  f[2] = __uint_as_float(r.y << 16); f[3] = __uint_as_float(r.y & 0xffff0000u);
+  f[4] = __uint_as_float(r.z << 16); f[5] = __uint_as_float(r.z & 0xffff0000u);
+  f[6] = __uint_as_float(r.w << 16); f[7] = __uint_as_float(r.w & 0xffff0000u);
+}
+
+// packed attention output: the A operand of o_proj in fragment order (bf16: decode.hip, f32: decode32.hip)
+template <typename OT> __device__ __forceinline__ size_t pko_off(int m, int c);
+template <> __device__ __forceinline__ size_t pko_off<bf16_t>(int m, int c) { return pk_off(m, c, HID / 32); }
+template <> __device__ __forceinline__ size_t pko_off<float>(int m, int c) { return pk32_off(m, c, HID / 16); }
+template <typename OT> __device__ __forceinline__ void store_out(OT* p, float v);
+template <> __device__ __forceinline__ void store_out<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void store_out<bf16_t>(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+
+// SPLIT (decode, perf mode): "remainder splitting".  A (utterance, head) unit streams ctx * 256 bytes of KV and a CU ingests
+// only ~25 GB/s of that, so the kernel lasts as long as the CU with the most units: U = 12 * n_active units on C CUs cost
+// ceil(U / C) units of time although the average CU holds U / C (540 units on 256 CUs: 3 instead of 2.1; below 256 units whole
+// CUs idle).  Here the first floor(U / C) * C units stay whole (one workgroup each, merged through LDS as before) and each
+// of the R = U mod C remainder units is cut into S = min(8, C / R) key ranges handled by S workgroups -- R * S <= C small
+// workgroups, about one per CU -- that meet through memory: every piece writes its partial (o[64], m, l) write-through, draws
+// a ticket from the unit's counter, and the LAST arriver reads the S partials (L1-bypassing loads), merges them and writes the
+// output (MI355X guide, Guideline 16 hand-off in its counter form: sc1 payload -> vmcnt(0) -> relaxed agent atomic; placement
+// independent).  grid = 12 * rows + C workgroups.  MEASURED (profiles/r2e_*): correct (tests/test_gpu_kernels.py), but on the C3
+// bench the launch gets 0.5 us SLOWER (9.3 -> 9.8 us) -- the pieces' hand-off latency is not hidden behind the whole units --
+// and the split geometry depends on the live-row count, which costs bf16 mode its batch invariance.  Kept behind
+// CTTS_ATT_SPLIT=1 (default off) as a recorded negative result.
+template <typename KT, int NW, typename OT, bool PKO = false, bool SPLIT = false>
+__global__ __launch_bounds__(64 * NW) void attention_k(const float* __restrict__ qkv, const KT* __restrict__ kc,
+                                                       const KT* __restrict__ vc, int cmax, OT* __restrict__ out, GptRowMap rm) {
+  constexpr int DPL = KTraits<KT>::DPL;
+  constexpr int LPK = HDIM / DPL;   // lanes per key: 8 (bf16) / 16 (f32)
+  constexpr int KPI = 64 / LPK;     // keys per load instruction: 8 / 4
+  constexpr int NI = 4;             // load instructions per block and operand (K and V): 8 loads per block in flight,
+                                    // and the NEXT block's 8 are issued before the current block is consumed
+  constexpr int KB = KPI * NI;      // keys per wave-block: 32 / 16
+  constexpr bool KV_NT = NW > 1;    // decode: every KV byte is read once per step by exactly one workgroup -> non-temporal
+  __shared__ float sm_m[NW], sm_l[NW], sm_acc[NW][HDIM];
+
+  int h = blockIdx.x, m = blockIdx.y;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int kg = lane / LPK, dl = lane % LPK;
+  int n_piece = 1, piece = 0, su = 0;   // SPLIT: pieces of this unit, this workgroup's piece, index among the split units
+  if (SPLIT) {
+    const int nact = rm.n_active ? *rm.n_active : (int)(gridDim.x - rm.sp_cus) / NHEAD;
+    const int U = nact * NHEAD, C = rm.sp_cus;
+    const int k = U / C, R = U - k * C;
+    const int full = R == 0 ? U : k * C;                 // units [0, full) stay whole
+    const int S = R == 0 ? 1 : min(ATT_SPLIT_MAX, C / R);
+    const int w = blockIdx.x;
+    int unit = w;
+    if (w >= full) {
+      const int idx = w - full;
+      su = idx / S;
+      unit = full + su;
+      piece = idx - su * S;
+      n_piece = S;
+      if (unit >= U) return;
+    }
+    m = unit / NHEAD;
+    h = unit - m * NHEAD;
+  } else if (rm.q_per_b == 1 && !rm.desc_covers_all && row_absent(rm.n_active, m)) return;
+  int b, slot, jlo;
+  if (rm.desc != nullptr) {   // decode: one 16-byte load instead of the row_map -> len -> kv_start / finish chain
+    const RowDesc d = rm.desc[m];
+    if (d.b < 0) return;      // finished since the last compaction: nothing downstream is ever read
+    b = d.b; slot = d.slot; jlo = d.jlo;
+  } else {
+    row_to_b_slot(rm, m, b, slot);
+    if (rm.finish != nullptr && rm.finish[b]) return;
+    jlo = rm.kv_start[b];
+    if (jlo > slot) jlo = slot;  // pad query row: sees only itself (its output is never consumed)
+  }
+
+  float q[DPL];
+  {
+    const float* qp = qkv + (size_t)m * (3 * HID) + h * HDIM + dl * DPL;
+#pragma unroll
+    for (int i = 0; i < DPL; ++i) q[i] = qp[i] * 0.125f;  // 1/sqrt(64), exact power of two
+  }
+  const KT* kbase = kc + ((size_t)b * NHEAD + h) * cmax * HDIM + dl * DPL;
+  const KT* vbase = vc + ((size_t)b * NHEAD + h) * cmax * HDIM + dl * DPL;
+
+  float mrun = -INFINITY, lrun = 0.f, acc[DPL];
+#pragma unroll
+  for (int i = 0; i < DPL; ++i) acc[i] = 0.f;
+
+  // this workgroup's key range [rbeg, rend): all visible keys, or one of n_piece KPI-aligned pieces of them
+  int rbeg = jlo, rend = slot + 1;
+  if (SPLIT && n_piece > 1) {
+    const int pper = ((slot + 1 - jlo + n_piece - 1) / n_piece + KPI - 1) / KPI * KPI;
+    rbeg = jlo + piece * pper;
+    rend = min(rbeg + pper, slot + 1);
+  }
+  // each wave owns one contiguous, KPI-aligned share of those keys (balanced: a context of n
+  // keys costs every wave ceil(n / NW / KB) blocks instead of giving wave 0 the remainder blocks)
+  const int nkeys = max(rend - rbeg, 0);
+  const int per = ((nkeys + NW - 1) / NW + KPI - 1) / KPI * KPI;
+  const int jbeg = rbeg + wave * per;
+  const int jend = min(jbeg + per, rend);  // exclusive
+
+  u128 kA[NI], vA[NI], kB[NI], vB[NI];
+  // Loads are UNCONDITIONAL with the key index clamped into the wave's range: a per-lane `if (j < jend) load`
+  // makes hipcc branch around every load and wait vmcnt(0) in between (one memory round trip per load).
+  // Clamped lanes re-read the last key (an L1 hit) and are masked where they are consumed.
+  const int jlast = max(jend - 1, jlo);
+  auto load_blk = [&](u128* kr, u128* vr, int j0) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) kr[i] = KV_NT ? load16_nt(kbase + (size_t)min(j0 + i * KPI + kg, jlast) * HDIM)
+                                               : load16(kbase + (size_t)min(j0 + i * KPI + kg, jlast) * HDIM);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) vr[i] = KV_NT ? load16_nt(vbase + (size_t)min(j0 + i * KPI + kg, jlast) * HDIM)
+                                               : load16(vbase + (size_t)min(j0 + i * KPI + kg, jlast) * HDIM);
+  };
+  auto use_blk = [&](const u128* kr, const u128* vr, int j0) {
+    float s[NI];
+    bool ok[NI];
+    float bmax = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      ok[i] = (j0 + i * KPI + kg) < jend;
+      float kf[DPL];
+      float d = 0.f;
+      unpack16<KT, DPL>(kr[i], kf);
+#pragma unroll
+      for (int e = 0; e < DPL; ++e) d = fmaf(q[e], kf[e], d);
+#pragma unroll
+      for (int o = 1; o < LPK; o <<= 1) d += __shfl_xor(d, o, 64);
+      s[i] = ok[i] ? d : -INFINITY;
+      bmax = fmaxf(bmax, s[i]);
+    }
+#pragma unroll
+    for (int o = LPK; o < 64; o <<= 1) bmax = fmaxf(bmax, __shfl_xor(bmax, o, 64));
+    // bmax is finite: key j0 (i = 0, kg = 0) is always < jend for a block that is consumed
+    const float mnew = fmaxf(mrun, bmax);
+    const float alpha = expf(mrun - mnew);  // exp(-inf) = 0 on the first block
+    lrun *= alpha;
+#pragma unroll
+    for (int e = 0; e < DPL; ++e) acc[e] *= alpha;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const float p = expf(s[i] - mnew);  // masked lanes: s = -inf -> p = 0 (their V is a finite, clamped re-read)
+      lrun += p;
+      float vf[DPL];
+      unpack16<KT, DPL>(vr[i], vf);
+#pragma unroll
+      for (int e = 0; e < DPL; ++e) acc[e] = fmaf(p, vf[e], acc[e]);
+    }
+    mrun = mnew;
+  };
+
+  int j = jbeg;
+  load_blk(kA, vA, j);
+  while (j < jend) {
+    load_blk(kB, vB, j + KB);   // prefetch (clamped, so harmless past the end)
+    __builtin_amdgcn_sched_barrier(0);  // keep the 8 prefetch loads ahead of the consumer (hipcc sinks them otherwise)
+    use_blk(kA, vA, j);
+    j += KB;
+    if (!(j < jend)) break;
+    load_blk(kA, vA, j + KB);
+    __builtin_amdgcn_sched_barrier(0);
+    use_blk(kB, vB, j);
+    j += KB;
+  }
+
+  // merge the key groups of this wave (same running max in every lane)
+#pragma unroll
+  for (int o = LPK; o < 64; o <<= 1) {
+    lrun += __shfl_xor(lrun, o, 64);
+#pragma unroll
+    for (int e = 0; e < DPL; ++e) acc[e] += __shfl_xor(acc[e], o, 64);
+  }
+  if (NW == 1) {
+    if (kg == 0) {
+      const float inv = 1.0f / lrun;
+      OT* op = PKO ? out + pko_off<OT>(m, h * HDIM + dl * DPL) : out + (size_t)m * HID + h * HDIM + dl * DPL;
+#pragma unroll
+      for (int e = 0; e < DPL; ++e) store_out<OT>(op + e, acc[e] * inv);
+    }
+    return;
+  }
+  if (kg == 0) {
+    if (dl == 0) { sm_m[wave] = mrun; sm_l[wave] = lrun; }
+#pragma unroll
+    for (int e = 0; e < DPL; ++e) sm_acc[wave][dl * DPL + e] = acc[e];
+  }
+  __syncthreads();
+  if (tid < HDIM) {
+    float M = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) M = fmaxf(M, sm_m[w]);
+    float L = 0.f, o = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const float sc = (sm_m[w] == -INFINITY) ? 0.f : expf(sm_m[w] - M);
+      L += sm_l[w] * sc;
+      o += sm_acc[w][tid] * sc;
+    }
+    if (SPLIT && n_piece > 1) {
+      // hand-off through memory: partial -> write-through stores -> drain -> ticket; the last arriver merges
+      unsigned* P = reinterpret_cast<unsigned*>(rm.sp_part + ((size_t)su * ATT_SPLIT_MAX + piece) * 66);
+      __hip_atomic_store(P + tid, __float_as_uint(o), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tid == 0) {
+        __hip_atomic_store(P + 64, __float_as_uint(M), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(P + 65, __float_as_uint(L), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's partial has left (tid < 64: wave 0 only)
+      int ticket = 0;
+      if (tid == 0) ticket = __hip_atomic_fetch_add(rm.sp_cnt + su, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ticket = __builtin_amdgcn_readfirstlane(ticket);
+      if (ticket != n_piece - 1) return;
+      const unsigned* Q = reinterpret_cast<const unsigned*>(rm.sp_part + (size_t)su * ATT_SPLIT_MAX * 66);
+      float pm[ATT_SPLIT_MAX], pl[ATT_SPLIT_MAX], po[ATT_SPLIT_MAX];
+      float Mx = -INFINITY;
+#pragma unroll
+      for (int p = 0; p < ATT_SPLIT_MAX; ++p) {
+        if (p < n_piece) {
+          pm[p] = __uint_as_float(__hip_atomic_load(Q + p * 66 + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+          pl[p] = __uint_as_float(__hip_atomic_load(Q + p * 66 + 65, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+          po[p] = __uint_as_float(__hip_atomic_load(Q + p * 66 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+          Mx = fmaxf(Mx, pm[p]);
+        }
+      }
+      L = 0.f; o = 0.f;
+#pragma unroll
+      for (int p = 0; p < ATT_SPLIT_MAX; ++p) {
+        if (p < n_piece) {
+          const float sc = (pm[p] == -INFINITY) ? 0.f : expf(pm[p] - Mx);
+          L += pl[p] * sc;
+          o += po[p] * sc;
+        }
+      }
+      if (tid == 0) __hip_atomic_store(rm.sp_cnt + su, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    }
+    store_out<OT>(PKO ? out + pko_off<OT>(m, h * HDIM + tid) : out + (size_t)m * HID + h * HDIM + tid, o / L);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// G5 (prefill, perf mode, long prompts): flash-style attention on the matrix cores.  The one-wave-per-(row, head) kernel
+// above re-streams a row's keys for every query row -- O(T^2) cache traffic and scalar FMAs; fine for the 16-48 token text
+// prompts of the benchmark configs (35 us per layer), not for an `spk_smp` audio-code prompt of several hundred tokens
+// (core.py:435-453).  Here a workgroup owns 64 consecutive query rows of one (utterance, head): each of its 4 waves holds 16
+// query rows as the A operand of v_mfma_f32_16x16x32_bf16 (q * 1/8, rounded to bf16), the workgroup walks the visible keys in
+// blocks of 32 staged through LDS once for all 4 waves (K row-major for S = Q K^T, V TRANSPOSED so that a B fragment of
+// P V is one 16-byte LDS read), keeps the running row max / sum of the online softmax in the MFMA C layout
+// (row = 4 (lane >> 4) + r), turns P into an A operand through a per-wave LDS tile, and accumulates O[16 x 64] in 4 MFMA tiles.
+// Mask = the reference's causal + left-pad mask (keys kv_start[b] .. slot; a pad query row sees only itself, its output is never
+// consumed).  Reference math: /root/reference/examples/onnx/modeling_llama.py:455-475 (softmax(q k^T / 8 + mask) v in f32;
+// here P and V enter the second product as bf16, like every other activation of the perf mode).
+// ------------------------------------------------------------------------------------------------
+template <typename OT>
+__global__ __launch_bounds__(256) void attention_prefill_mfma_k(const float* __restrict__ qkv, const bf16_t* __restrict__ kc,
+                                                                const bf16_t* __restrict__ vc, int cmax, OT* __restrict__ out, GptRowMap rm) {
+  constexpr int KB = 32;                 // keys per block
+  constexpr int KLD = HDIM + 8;          // K tile row stride (bf16): 144 B, conflict-free 16-byte fragment reads
+  constexpr int VLD = KB + 8;            // V^T tile row stride (bf16): 80 B
+  __shared__ __attribute__((aligned(16))) bf16_t Ks[KB][KLD];
+  __shared__ __attribute__((aligned(16))) bf16_t Vt[HDIM][VLD];
+  __shared__ __attribute__((aligned(16))) bf16_t Ps[4][16][VLD];
+
+  const int T = rm.q_per_b;
+  const int qt = blockIdx.x, h = blockIdx.y, bq = blockIdx.z;        // query tile of 64 rows, head, prompt row group
+  const int b = rm.row_map ? rm.row_map[bq] : bq;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 15, g = lane >> 4;
+  const int kvs = rm.kv_start[b];
+  const int t0 = qt * 64;                                             // first query index (within the chunk) of this workgroup
+  if (t0 >= T) return;
+  const int tq = t0 + wave * 16;                                      // this wave's first query index
+  // A operand: lane (li, g) holds q[row li][c * 32 + g * 8 .. + 8] for the two 32-wide d chunks, scaled by 1/8
+  // (q stays f32-accurate: q/8 = hi + lo in bf16, two MFMAs per product -- the decode kernel keeps q in f32 as well)
+  bf16x8 qa[2], ql[2];
+  {
+    const int t = min(tq + li, T - 1);
+    const float* qp = qkv + ((size_t)bq * T + t) * (3 * HID) + h * HDIM + g * 8;
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float v = qp[c * 32 + e] * 0.125f;
+        const __bf16 hi = (__bf16)v;
+        qa[c][e] = hi;
+        ql[c][e] = (__bf16)(v - (float)hi);
+      }
+  }
+  // rows of this lane in the C layout: r -> query index tq + 4 g + r, its KV slot and first visible key
+  int slot[4], jlo[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    slot[r] = rm.slot0 + min(tq + 4 * g + r, T - 1);
+    jlo[r] = min(kvs, slot[r]);
+  }
+  float mrun[4], lrun[4];
+  f32x4 o[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { mrun[r] = -INFINITY; lrun[r] = 0.f; }
+#pragma unroll
+  for (int d = 0; d < 4; ++d) o[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const bf16_t* kbase = kc + ((size_t)b * NHEAD + h) * cmax * HDIM;
+  const bf16_t* vbase = vc + ((size_t)b * NHEAD + h) * cmax * HDIM;
+  const int slot_first = rm.slot0 + t0, slot_last = rm.slot0 + min(t0 + 63, T - 1);
+  const int jbeg = min(kvs, slot_first) / KB * KB;
+  for (int j0 = jbeg; j0 <= slot_last; j0 += KB) {
+    __syncthreads();   // the previous block's K / V^T tiles have been consumed
+    {  // stage K [32 keys][64 d] and V^T [64 d][32 keys]: thread -> (key = tid / 8, 8 d starting at (tid % 8) * 8)
+      const int key = tid >> 3, d0 = (tid & 7) * 8;
+      const int j = min(j0 + key, cmax - 1);
+      const u128 kv = load16(kbase + (size_t)j * HDIM + d0);
+      u128 vv = load16(vbase + (size_t)j * HDIM + d0);
+      if (j0 + key > slot_last) vv = u128{0u, 0u, 0u, 0u};   // never-written cache rows: 0 * garbage must not become NaN in P V
+      *reinterpret_cast<u128*>(&Ks[key][d0]) = kv;
+      const bf16_t* ve = reinterpret_cast<const bf16_t*>(&vv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) Vt[d0 + e][key] = ve[e];
+    }
+    __syncthreads();
+    // S = Q K^T for the two 16-key halves of the block
+    f32x4 sc[2];
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) {
+      sc[hb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const bf16x8 kb = *reinterpret_cast<const bf16x8*>(&Ks[hb * 16 + li][c * 32 + g * 8]);
+        sc[hb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ql[c], kb, sc[hb], 0, 0, 0);
+        sc[hb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[c], kb, sc[hb], 0, 0, 0);
+      }
+    }
+    // mask + online softmax per query row (a row's 32 scores sit in the 16 lanes of its lane group, 2 per lane)
+    float p[2][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float s0 = sc[0][r], s1 = sc[1][r];
+      const int ja = j0 + li, jb = j0 + 16 + li;
+      if (ja < jlo[r] || ja > slot[r]) s0 = -INFINITY;
+      if (jb < jlo[r] || jb > slot[r]) s1 = -INFINITY;
+      float bm = fmaxf(s0, s1);
+#pragma unroll
+      for (int x = 1; x < 16; x <<= 1) bm = fmaxf(bm, __shfl_xor(bm, x, 64));
+      const float mnew = fmaxf(mrun[r], bm);
+      const float alpha = (mnew == -INFINITY) ? 1.f : expf(mrun[r] - mnew);   // nothing visible yet: keep the zeros
+      const float p0 = (s0 == -INFINITY) ? 0.f : expf(s0 - mnew), p1 = (s1 == -INFINITY) ? 0.f : expf(s1 - mnew);
+      float ps = p0 + p1;
+#pragma unroll
+      for (int x = 1; x < 16; x <<= 1) ps += __shfl_xor(ps, x, 64);
+      lrun[r] = lrun[r] * alpha + ps;
+      mrun[r] = mnew;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) o[d][r] *= alpha;
+      p[0][r] = p0; p[1][r] = p1;
+    }
+    // P (C layout: row 4g+r, key li / 16+li) -> LDS tile [16 rows][32 keys] -> A operand (row li, keys g*8..)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      Ps[wave][4 * g + r][li] = f32_to_bf16(p[0][r]);
+      Ps[wave][4 * g + r][16 + li] = f32_to_bf16(p[1][r]);
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS writes have landed (same-wave read-after-write)
+    __builtin_amdgcn_wave_barrier();
+    const bf16x8 pa = *reinterpret_cast<const bf16x8*>(&Ps[wave][li][g * 8]);
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const bf16x8 vb = *reinterpret_cast<const bf16x8*>(&Vt[d * 16 + li][g * 8]);
+      o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa, vb, o[d], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int t = tq + 4 * g + r;
+    if (t < T) {
+      const float inv = 1.0f / lrun[r];
+      OT* op = out + ((size_t)bq * T + t) * HID + h * HDIM + li;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) store_out<OT>(op + d * 16, o[d][r] * inv);
+    }
+  }
+}
+
+hipError_t launch_attention(const float* qkv, const void* kcache, const void* vcache, int kv_wt, int cmax, void* out, int out_bf16,
+                            GptRowMap rm, int M, hipStream_t st) {
+  dim3 grid(NHEAD, M);
+  const bool decode = rm.q_per_b == 1;
+  static int flash_min = -1;   // CTTS_FLASH_MIN_T: prompt (chunk) length from which prefill uses the MFMA kernel (0 = never)
+  if (flash_min < 0) { const char* e = getenv("CTTS_FLASH_MIN_T"); flash_min = e ? atoi(e) : 128; }
+  if (!decode && kv_wt == WT_BF16 && flash_min > 0 && rm.q_per_b >= flash_min && M % rm.q_per_b == 0) {
+    dim3 g3((rm.q_per_b + 63) / 64, NHEAD, M / rm.q_per_b);
+    if (out_bf16 == 1) CTTS_LAUNCH((attention_prefill_mfma_k<bf16_t>), g3, dim3(256), st, qkv, (const bf16_t*)kcache, (const bf16_t*)vcache, cmax, (bf16_t*)out, rm);
+    else if (out_bf16 == 0) CTTS_LAUNCH((attention_prefill_mfma_k<float>), g3, dim3(256), st, qkv, (const bf16_t*)kcache, (const bf16_t*)vcache, cmax, (float*)out, rm);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+  }
+  static int nw8 = -1;  // CTTS_ATT_NW=8: 8 waves per (utterance, head) in decode (A/B knob)
+  if (nw8 < 0) { const char* e = getenv("CTTS_ATT_NW"); nw8 = (e && atoi(e) == 8) ? 1 : 0; }
+  if (out_bf16 == 2) {   // decode, perf mode: bf16 output in the fragment-packed order the o_proj kernel of decode.hip reads
+    if (!decode || kv_wt != WT_BF16) return hipErrorInvalidValue;
+    if (rm.sp_cus > 0 && rm.sp_part != nullptr && rm.sp_cnt != nullptr)
+      CTTS_LAUNCH((attention_k<bf16_t, 4, bf16_t, true, true>), dim3(NHEAD * M + rm.sp_cus), dim3(256), st, qkv, (const bf16_t*)kcache,
+                  (const bf16_t*)vcache, cmax, (bf16_t*)out, rm);
+    else
+      CTTS_LAUNCH((attention_k<bf16_t, 4, bf16_t, true>), grid, dim3(256), st, qkv, (const bf16_t*)kcache, (const bf16_t*)vcache, cmax, (bf16_t*)out, rm);
+    return hipGetLastError();
+  }
+  if (out_bf16 == 3) {   // decode, f32 parity mode: f32 output in the fragment-packed order o_proj of decode32.hip reads
+    if (!decode || kv_wt == WT_BF16) return hipErrorInvalidValue;
+    CTTS_LAUNCH((attention_k<float, 4, float, true>), grid, dim3(256), st, qkv, (const float*)kcache, (const float*)vcache, cmax, (float*)out, rm);
+    return hipGetLastError();
+  }
+  if (decode && nw8 && kv_wt == WT_BF16 && out_bf16) {
+    CTTS_LAUNCH((attention_k<bf16_t, 8, bf16_t>), grid, dim3(512), st, qkv, (const bf16_t*)kcache, (const bf16_t*)vcache, cmax, (bf16_t*)out, rm);
+    return hipGetLastError();
+  }
+#define ATT(KT, NW, OT) CTTS_LAUNCH((attention_k<KT, NW, OT>), grid, dim3(64 * NW), st, qkv, (const KT*)kcache, (const KT*)vcache, cmax, (OT*)out, rm)
+  if (kv_wt == WT_BF16) {
+    if (out_bf16) { if (decode) ATT(bf16_t, 4, bf16_t); else ATT(bf16_t, 1, bf16_t); }
+    else { if (decode) ATT(bf16_t, 4, float); else ATT(bf16_t, 1, float); }
+  } else {
+    if (out_bf16) { if (decode) ATT(float, 4, bf16_t); else ATT(float, 1, bf16_t); }
+    else { if (decode) ATT(float, 4, float); else ATT(float, 1, float); }
+  }
+#undef ATT
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// G8  final RMSNorm of the last position of every row; the f32 result is the step's hidden state
+//     (gpt.py:430-436) -> hiddens[b, gen] and the staging row read by the heads GEMM.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(192) void final_norm_k(const float* __restrict__ x, int q_per_b, const float* __restrict__ w, float eps,
+                                                    float* __restrict__ hfin, float* __restrict__ hiddens, int max_new,
+                                                    const int32_t* __restrict__ len, int T, const int32_t* __restrict__ row_map,
+                                                    const int32_t* __restrict__ n_active, const int32_t* __restrict__ prompt_len,
+                                                    float* __restrict__ hfin_p) {
+  __shared__ float part[3];
+  const int m = blockIdx.x, t = threadIdx.x;
+  if (row_absent(n_active, m)) return;
+  const int b = row_map ? row_map[m] : m;   // compact activation row m belongs to utterance b
+  const float* row = x + ((size_t)m * q_per_b + (q_per_b - 1)) * HID;
+  const float4 v = *reinterpret_cast<const float4*>(row + t * 4);
+  float ss = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  ss = wave_sum(ss);
+  if ((t & 63) == 0) part[t >> 6] = ss;
+  __syncthreads();
+  const float rstd = 1.0f / sqrtf(((part[0] + part[1]) + part[2]) / (float)HID + eps);
+  const float4 g = *reinterpret_cast<const float4*>(w + t * 4);
+  float4 o;
+  o.x = g.x * (v.x * rstd); o.y = g.y * (v.y * rstd); o.z = g.z * (v.z * rstd); o.w = g.w * (v.w * rstd);
+  *reinterpret_cast<float4*>(hfin + (size_t)m * HID + t * 4) = o;
+  if (hfin_p != nullptr) *reinterpret_cast<float4*>(hfin_p + pk32_off(m, 4 * t, HID / 16)) = o;   // A operand of the packed heads GEMM
+  const int gen = len[b] - (prompt_len ? prompt_len[b] : T);
+  if (hiddens != nullptr && gen >= 0 && gen < max_new)
+    *reinterpret_cast<float4*>(hiddens + ((size_t)b * max_new + gen) * HID + t * 4) = o;
+}
+
+hipError_t launch_final_norm(const float* x, int q_per_b, const float* w, float eps, float* hfin, float* hiddens, int max_new,
+                             const int32_t* len, int T, int B, const int32_t* row_map, const int32_t* n_active,
+                             const int32_t* prompt_len, hipStream_t st, float* hfin_packed) {
+  CTTS_LAUNCH(final_norm_k, dim3(B), dim3(192), st, x, q_per_b, w, eps, hfin, hiddens, max_new, len, T, row_map, n_active, prompt_len, hfin_packed);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// G10 + G11  fused sampling chain, one wave per (b, k) row, one workgroup per batch row b.
+//   logits / temperature                                   gpt.py:487
+//   repetition penalty over the last <=16 generated ids    processors.py:18-35 (rows >= 625: none)
+//   TopP(min_keep 3) then TopK(min_keep 3)                 processors.py:38-58 + transformers warpers
+//   EOS mask while gen < min_new_token                     gpt.py:494-495
+//   softmax, argmax(p / q), q ~ Exp(1) from the CPU stream gpt.py:497-508 (host draws q)
+//   finish |= any(tok == eos); ids_buf[:, T+gen] = tok; end_idx += !finish; len += 1   gpt.py:512-577
+//
+// The sort the reference does per row (626 logits) is replaced by an exact equivalent that needs
+// no sort: both warpers keep a PREFIX of the descending order, so the kept set is found by
+// repeatedly extracting the wave-wide maximum (ties: lowest index first) while accumulating the
+// probability mass above it in double -- cum_ascending(v) = fl32(S_all - mass_above(v)), the same
+// value ATen's double-accumulated cumsum rounds to float.  At most max(top_k,3)+ties extractions.
+// ------------------------------------------------------------------------------------------------
+#define SLOTS 10  // ceil(626 / 64)
+
+__device__ __forceinline__ void wave_argmax(float v, int idx, float& bv, int& bi) {
+  // max value, ties -> lowest index; result uniform across the wave.  Two DPP reductions (max of the values,
+  // then min of the indices that hold it) instead of a 6-step (value, index) butterfly on ds_bpermute.
+  bv = wave_max_dpp(v);
+  bi = wave_min_dpp(v == bv ? idx : 0x7fffffff);
+}
+
+__global__ __launch_bounds__(256) void sample_k(SampleArgs a) {
+  __shared__ int tok_s[NVQ];
+  const int m = blockIdx.x;                       // compact logits row
+  if (row_absent(a.n_active, m)) return;
+  const int b = a.row_map ? a.row_map[m] : m;     // utterance (batch slot)
+  const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int len = a.len[b];
+  if (len >= a.tcap) {  // slot full (slot pools only; generate() never steps past max_new_token): stop, write nothing
+    if (threadIdx.x == 0) a.finish[b] = 1;
+    return;
+  }
+  const int gen = len - (a.prompt_len ? a.prompt_len[b] : a.T);  // tokens generated so far == step index i of gpt.py:394
+  const float* lrow = a.logits + ((size_t)m * NVQ + k) * NAUDIO;
+  const float temp = a.temperature[k];
+
+  float x[SLOTS];
+  int cnt[SLOTS];
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s) {
+    const int v = s * 64 + lane;
+    x[s] = (v < NAUDIO) ? lrow[v] / temp : -INFINITY;
+    cnt[s] = 0;
+  }
+  // repetition penalty
+  const int grow = a.row_offset + b * NVQ + k;
+  if (a.pow_table != nullptr && grow < a.max_input_ids) {
+    const int nh = min(gen, 16);
+    // the <=16 history tokens are fetched by 16 lanes in ONE load round and broadcast (a serial loop of
+    // dependent global loads costs one L2 round trip per token)
+    const int mine = (lane < nh) ? (int)a.ids_buf[((size_t)b * a.tcap + (len - 1 - lane)) * NVQ + k] : -1;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int t = __shfl(mine, j, 64);  // -1 beyond the history: matches no vocabulary slot
+#pragma unroll
+      for (int s = 0; s < SLOTS; ++s) cnt[s] += (t == s * 64 + lane) ? 1 : 0;
+    }
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+      const float al = a.pow_table[cnt[s]];
+      x[s] = (x[s] < 0.f) ? x[s] * al : x[s] / al;
+    }
+  }
+
+  // softmax statistics over the whole row (needed by top-p)
+  float mx = -INFINITY;
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s) mx = fmaxf(mx, x[s]);
+  mx = wave_max(mx);
+  float e[SLOTS];
+  float zs = 0.f;
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s) { e[s] = (s * 64 + lane < NAUDIO) ? expf(x[s] - mx) : 0.f; zs += e[s]; }
+  zs = wave_sum(zs);
+  const float rz = 1.0f / zs;
+  double sall = 0.0;
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s) { e[s] = e[s] * rz; sall += (double)e[s]; }  // e = softmax prob (f32)
+  sall = wave_sum_d(sall);
+
+  // prefix extraction in descending order
+  const int kk = a.use_top_k ? min(max(a.top_k, 3), NAUDIO) : NAUDIO;
+  const float thr = a.top_p_thr;  // float32(1 - top_p): `cum <= (1 - top_p)` on a float tensor casts the scalar to float
+  unsigned taken = 0;                // bit s: slot s of this lane already extracted
+  unsigned kept = 0;
+  double mass_above = 0.0;
+  float kth_val = 0.f;
+  int n = 0;
+  const bool any_filter = a.use_top_p || a.use_top_k;
+  while (any_filter && n < NAUDIO) {
+    float bv = -INFINITY; int bi = 0x7fffffff;
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+      const bool avail = !((taken >> s) & 1u) && (s * 64 + lane < NAUDIO);
+      if (avail && (x[s] > bv)) { bv = x[s]; bi = s * 64 + lane; }  // ascending s => lowest index on ties
+    }
+    float wv; int wi;
+    wave_argmax(bv, bi, wv, wi);
+    // top-p decision for the n-th largest element
+    bool keep = true;
+    if (a.use_top_p && n >= 3) {
+      const float cum = (float)(sall - mass_above);  // ascending cumulative prob up to and including it
+      keep = !(cum <= thr);
+    }
+    if (!keep) break;  // everything below is removed by top-p as well
+    if (a.use_top_k && n >= kk) {
+      if (!(wv == kth_val)) break;  // below the k-th largest value; ties with it survive
+    }
+    // accept
+    const int ws = wi >> 6, wl = wi & 63;
+    float pe = 0.f;
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) if (s == ws) pe = e[s];
+    pe = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pe), wl));  // wl is wave-uniform
+    mass_above += (double)pe;
+    if (lane == wl) { taken |= 1u << ws; kept |= 1u << ws; }
+    if (n == kk - 1) kth_val = wv;
+    ++n;
+  }
+  if (!any_filter) kept = 0x3ffu;
+
+  // EOS handling (min_new_token and the bench harness's stop_at hook)
+  bool mask_eos = gen < a.min_new;
+  bool force_eos = false;
+  if (a.stop_at != nullptr) {
+    const int sa = a.stop_at[b];
+    if (sa >= 0) { mask_eos = mask_eos || (gen < sa); force_eos = gen >= sa; }
+  }
+  // final softmax over the kept set and argmax(p / q)
+  const float* qrow = a.q + ((size_t)(gen % a.nq) * a.q_rows * NVQ + (size_t)b * NVQ + k) * NAUDIO;
+  float m2 = -INFINITY;
+  bool live[SLOTS];
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s) {
+    const int v = s * 64 + lane;
+    live[s] = ((kept >> s) & 1u) && v < NAUDIO && !(mask_eos && v == a.eos);
+    if (live[s]) m2 = fmaxf(m2, x[s]);
+  }
+  m2 = wave_max(m2);
+  float z2 = 0.f, p2[SLOTS];
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s) { p2[s] = live[s] ? expf(x[s] - m2) : 0.f; z2 += p2[s]; }
+  z2 = wave_sum(z2);
+  const float rz2 = 1.0f / z2;
+  float bv = -1.f; int bi = 0x7fffffff;
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s) {
+    const int v = s * 64 + lane;
+    if (v < NAUDIO) {
+      const float r = (p2[s] * rz2) / qrow[v];
+      if (r > bv) { bv = r; bi = v; }
+    }
+  }
+  float wv; int wi;
+  wave_argmax(bv, bi, wv, wi);
+  if (force_eos) wi = a.eos;
+  if (a.teacher != nullptr && gen < a.teacher_stride) wi = (int)a.teacher[((size_t)b * a.teacher_stride + gen) * NVQ + k];
+  if (lane == 0) {
+    a.ids_buf[((size_t)b * a.tcap + len) * NVQ + k] = (int64_t)wi;
+    tok_s[k] = wi;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    bool fin = a.finish[b] != 0;
+#pragma unroll
+    for (int c = 0; c < NVQ; ++c) fin = fin || (tok_s[c] == a.eos);
+    a.finish[b] = fin ? 1 : 0;
+    if (!fin) a.end_idx[b] += 1;
+    a.len[b] = len + 1;
+  }
+}
+
+hipError_t launch_sample(const SampleArgs& a, hipStream_t st) {
+  CTTS_LAUNCH(sample_k, dim3(a.B), dim3(256), st, a);
+  return hipGetLastError();
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// refine-text mode (infer_text=True, gpt.py:406-407,439-440,477-485,519-525): the decode input is
+// emb_text[last token], the head is the 21178-way text head, one sampling row per utterance.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(192) void embed_text_k(const float* __restrict__ emb_text, int n_text, const int64_t* __restrict__ ids_buf,
+                                                    int tcap, const int32_t* __restrict__ len, float* __restrict__ x,
+                                                    uint16_t* __restrict__ xb, float* __restrict__ ssq,
+                                                    const int32_t* __restrict__ row_map, const int32_t* __restrict__ n_active,
+                                                    StepPrep sp) {
+  const int m = blockIdx.x, t = threadIdx.x;
+  int b;
+  if (sp.row_map_out != nullptr) {   // device-side compaction (see embed_codes_k)
+    int total;
+    b = nth_unfinished(sp.finish, gridDim.x, m, total);
+    if (m == 0 && t == 0) *sp.n_active_out = total;
+    if (b < 0) {   // row m does not exist this step: say so in its descriptor (the attention kernel reads nothing else)
+      if (sp.desc != nullptr && t == 0) sp.desc[m] = RowDesc{-1, 0, 0, 0};
+      return;
+    }
+    if (t == 0) sp.row_map_out[m] = b;
+  } else {
+    if (row_absent(n_active, m)) return;
+    b = row_map ? row_map[m] : m;
+  }
+  const int slot = len[b] - 1;
+  if (sp.desc != nullptr && t == 0) write_desc(sp, m, b, slot);
+  int id = (int)ids_buf[((size_t)b * tcap + slot) * NVQ];  // slot 0 (gpt.py:407)
+  id = min(max(id, 0), n_text - 1);
+  const float4 s = *reinterpret_cast<const float4*>(emb_text + (size_t)id * HID + t * 4);
+  emit_row(s, t, x + (size_t)m * HID, xb_row_ptr(xb, m, t, sp.xb_packed), ssq ? ssq + (size_t)m * SSQ_PARTS : nullptr,
+           sp.xp32 ? sp.xp32 + pk32_off(m, 4 * t, HID / 16) : nullptr);
+}
+
+hipError_t launch_embed_text(const float* emb_text, int n_text, const int64_t* ids_buf, int tcap, const int32_t* len, float* x,
+                             uint16_t* xb, float* ssq, int B, const int32_t* row_map, const int32_t* n_active, hipStream_t st,
+                             const StepPrep* prep) {
+  CTTS_LAUNCH(embed_text_k, dim3(B), dim3(192), st, emb_text, n_text, ids_buf, tcap, len, x, xb, ssq, row_map, n_active, prep_or_none(prep));
+  return hipGetLastError();
+}
+
+#define TEXT_VMAX 21248  // >= num_text_tokens (21178), multiple of 256
+
+struct BlockRed {
+  float f[4]; int i[4]; double d[4];
+};
+__device__ __forceinline__ float block_max4(float v, BlockRed& r, int wave, int lane) {
+  v = wave_max(v);
+  __syncthreads();
+  if (lane == 0) r.f[wave] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(r.f[0], r.f[1]), fmaxf(r.f[2], r.f[3]));
+}
+__device__ __forceinline__ float block_sum4(float v, BlockRed& r, int wave, int lane) {
+  v = wave_sum(v);
+  __syncthreads();
+  if (lane == 0) r.f[wave] = v;
+  __syncthreads();
+  return (r.f[0] + r.f[1]) + (r.f[2] + r.f[3]);
+}
+__device__ __forceinline__ double block_sum4d(double v, BlockRed& r, int wave, int lane) {
+  v = wave_sum_d(v);
+  __syncthreads();
+  if (lane == 0) r.d[wave] = v;
+  __syncthreads();
+  return (r.d[0] + r.d[1]) + (r.d[2] + r.d[3]);
+}
+// max value, ties -> lowest index, uniform over the 256-thread block
+__device__ __forceinline__ void block_argmax4(float v, int idx, BlockRed& r, int wave, int lane, float& bv, int& bi) {
+  float wv; int wi;
+  wave_argmax(v, idx, wv, wi);
+  __syncthreads();
+  if (lane == 0) { r.f[wave] = wv; r.i[wave] = wi; }
+  __syncthreads();
+  bv = r.f[0]; bi = r.i[0];
+#pragma unroll
+  for (int w = 1; w < 4; ++w)
+    if (r.f[w] > bv || (r.f[w] == bv && r.i[w] < bi)) { bv = r.f[w]; bi = r.i[w]; }
+}
+
+// One 256-thread workgroup per utterance; the tempered logits live in LDS, the kept set is a bitmask.
+// Same sort-free prefix extraction as sample_k (see there), block-wide instead of wave-wide.
+__global__ __launch_bounds__(256) void sample_text_k(SampleArgs a, int V) {
+  __shared__ float xs[TEXT_VMAX];
+  __shared__ unsigned keptbits[TEXT_VMAX / 32];
+  __shared__ BlockRed red;
+  const int m = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  if (row_absent(a.n_active, m)) return;
+  const int b = a.row_map ? a.row_map[m] : m;
+  const int len = a.len[b];
+  if (len >= a.tcap) {
+    if (tid == 0) a.finish[b] = 1;
+    return;
+  }
+  const int gen = len - (a.prompt_len ? a.prompt_len[b] : a.T);
+  const float* lrow = a.logits + (size_t)m * V;
+  const float temp = a.temperature[0];
+
+  float mx = -INFINITY;
+  for (int v = tid; v < TEXT_VMAX; v += 256) {
+    const float x = (v < V) ? lrow[v] / temp : -INFINITY;   // gpt.py:487 (repetition penalty is not supported in this mode)
+    xs[v] = x;
+    mx = fmaxf(mx, x);
+  }
+  for (int w = tid; w < TEXT_VMAX / 32; w += 256) keptbits[w] = 0u;
+  mx = block_max4(mx, red, wave, lane);
+  float zs = 0.f;
+  for (int v = tid; v < V; v += 256) zs += expf(xs[v] - mx);
+  zs = block_sum4(zs, red, wave, lane);
+  const float rz = 1.0f / zs;
+  double sall = 0.0;
+  for (int v = tid; v < V; v += 256) sall += (double)(expf(xs[v] - mx) * rz);
+  sall = block_sum4d(sall, red, wave, lane);
+
+  const int kk = a.use_top_k ? min(max(a.top_k, 3), V) : V;
+  const float thr = a.top_p_thr;
+  const bool any_filter = a.use_top_p || a.use_top_k;
+  double mass_above = 0.0;
+  float kth_val = 0.f;
+  int n = 0;
+  while (any_filter && n < V) {
+    float bv = -INFINITY; int bi = 0x7fffffff;
+    for (int v = tid; v < V; v += 256) {
+      const bool avail = !((keptbits[v >> 5] >> (v & 31)) & 1u);
+      const float x = xs[v];
+      if (avail && x > bv) { bv = x; bi = v; }   // ascending v => lowest index on ties
+    }
+    float wv; int wi;
+    block_argmax4(bv, bi, red, wave, lane, wv, wi);
+    bool keep = true;
+    if (a.use_top_p && n >= 3) {
+      const float cum = (float)(sall - mass_above);
+      keep = !(cum <= thr);
+    }
+    if (!keep) break;
+    if (a.use_top_k && n >= kk) {
+      if (!(wv == kth_val)) break;
+    }
+    mass_above += (double)(expf(wv - mx) * rz);
+    if (tid == 0) keptbits[wi >> 5] |= 1u << (wi & 31);
+    if (n == kk - 1) kth_val = wv;
+    ++n;
+    __syncthreads();
+  }
+  __syncthreads();
+
+  bool mask_eos = gen < a.min_new;
+  bool force_eos = false;
+  if (a.stop_at != nullptr) {
+    const int sa = a.stop_at[b];
+    if (sa >= 0) { mask_eos = mask_eos || (gen < sa); force_eos = gen >= sa; }
+  }
+  const float* qrow = a.q + ((size_t)(gen % a.nq) * a.q_rows + b) * V;
+  float m2 = -INFINITY;
+  for (int v = tid; v < V; v += 256) {
+    const bool live = (!any_filter || ((keptbits[v >> 5] >> (v & 31)) & 1u)) && !(mask_eos && v == a.eos);
+    if (live) m2 = fmaxf(m2, xs[v]);
+  }
+  m2 = block_max4(m2, red, wave, lane);
+  float z2 = 0.f;
+  for (int v = tid; v < V; v += 256) {
+    const bool live = (!any_filter || ((keptbits[v >> 5] >> (v & 31)) & 1u)) && !(mask_eos && v == a.eos);
+    if (live) z2 += expf(xs[v] - m2);
+  }
+  z2 = block_sum4(z2, red, wave, lane);
+  const float rz2 = 1.0f / z2;
+  float bv = -1.f; int bi = 0x7fffffff;
+  for (int v = tid; v < V; v += 256) {
+    const bool live = (!any_filter || ((keptbits[v >> 5] >> (v & 31)) & 1u)) && !(mask_eos && v == a.eos);
+    const float r = (live ? expf(xs[v] - m2) * rz2 : 0.f) / qrow[v];
+    if (r > bv) { bv = r; bi = v; }
+  }
+  float wv; int wi;
+  block_argmax4(bv, bi, red, wave, lane, wv, wi);
+  if (force_eos) wi = a.eos;
+  if (tid < NVQ) a.ids_buf[((size_t)b * a.tcap + len) * NVQ + tid] = (int64_t)wi;   // gpt.py:522-525: replicated over the 4 slots
+  if (tid == 0) {
+    const bool fin = (a.finish[b] != 0) || (wi == a.eos);
+    a.finish[b] = fin ? 1 : 0;
+    if (!fin) a.end_idx[b] += 1;
+    a.len[b] = len + 1;
+  }
+}
+
+hipError_t launch_sample_text(const SampleArgs& a, int V, hipStream_t st) {
+  if (V > TEXT_VMAX || a.pow_table != nullptr) return hipErrorInvalidValue;
+  CTTS_LAUNCH(sample_text_k, dim3(a.B), dim3(256), st, a, V);
+  return hipGetLastError();
+}

@@ -20,26 +20,6 @@ extern thread_local hipEvent_t ctts_prof_start, ctts_prof_stop;
     }                                                                                                             \
   } while (0)
 
-// the same with `smem` bytes of dynamic LDS (used only to bound how many workgroups a CU holds at once)
-#define CTTS_LAUNCH_SMEM(kern, grid, block, smem, st, ...)                                                        \
-  do {                                                                                                            \
-    if (ctts_prof_start) {                                                                                        \
-      hipExtLaunchKernelGGL(kern, grid, block, smem, st, ctts_prof_start, ctts_prof_stop, 0, __VA_ARGS__);        \
-      ctts_prof_start = nullptr; ctts_prof_stop = nullptr;                                                        \
-    } else {                                                                                                      \
-      hipLaunchKernelGGL(kern, grid, block, smem, st, __VA_ARGS__);                                               \
-    }                                                                                                             \
-  } while (0)
-
-// Probe builds only (python -m chattts_amd.build --variant probe -DCTTS_PROBE_EXIT=1, tools/step_floor_probe.py): every kernel of
-// the decode step returns at entry WITHOUT touching memory -- what a replay of the captured step then costs is launch + dispatch
-// alone, to be set against the "every utterance finished" replay of the normal build (launch + one dependent load of the live count).
-#ifdef CTTS_PROBE_EXIT
-#define CTTS_PROBE_RETURN() do { return; } while (0)
-#else
-#define CTTS_PROBE_RETURN() do { } while (0)
-#endif
-
 enum { WT_F32 = 0, WT_BF16 = 1 };
 
 // ---- GEMM  C[M,N] = epi( pro(A)[M,K] * W[N,K]^T ) ------------------------------------------
@@ -136,15 +116,12 @@ struct DecGemmArgs {
   int epi;                      // FastEpi
   float* C32; int ldc;          // QKV_ROPE: f32 qkv buffer; RES: f32 residual, updated in place
   uint16_t* Cp; int kch_out;    // packed bf16 output (RES: new residual, SILU: activation) with kch_out = columns / 32
-  float* Cp32;                  // RES, optional: the new residual once more in the packed f32 order of decode32.hip (pk32_off, 768 / 16
-                                // chunks): the last layer's down_proj feeds the fused final-norm + heads launch with it
   float* ssq_out;               // RES: [M,48]
   const RowDesc* desc;          // QKV_ROPE
   const float* cos_t; const float* sin_t;
   uint16_t* kc; uint16_t* vc; int cmax;
   int force_mb;                 // tests only
   int w_nt;                     // set by the launcher
-  int a_early;                  // set by the launcher (CTTS_DEC_A_EARLY): batches of <= 16 rows request their activation tile at entry
   long long* dbg;               // probes only (tools/dec_phase_probe.py): [n_workgroups][8] phase stamps, or null
 };
 hipError_t launch_gemm_dec(const DecGemmArgs& a, hipStream_t st);
@@ -173,13 +150,6 @@ struct Dec32Args {
   int force_mb;                 // tests only
   int w_nt;                     // set by the launcher
   int a_early;                  // set by the launcher (CTTS_D32_A_EARLY): first activation round requested before the RMSNorm prologue
-  // FINAL-NORM fusion (decode heads, both modes): with `fnorm` the launch is `final RMSNorm -> hidden capture -> heads` in one kernel:
-  // Ap = the UN-normalised residual stream (packed f32), norm_w = the final norm's gain, the row statistics are final_norm_k's
-  // (gpt.hip) bit for bit, taken from the fragments; workgroups of weight tile 0 also write the normalised rows -- the step's hidden
-  // states (gpt.py:430-436) -- to hid[desc[row].b][gen] with gen = desc[row].slot + 1 - (prompt_len ? prompt_len[b] : T)
-  int fnorm;
-  float* hid; int hid_cap;      // [slots, hid_cap, 768] or null
-  int T; const int32_t* prompt_len;
 };
 enum { D32_EPI_QKV_ROPE = 100 };
 hipError_t launch_gemm_dec32(const Dec32Args& a, hipStream_t st);
@@ -226,7 +196,6 @@ struct StepPrep {
   // kernel of the step reads -- finished utterances leave the step at once, without the host
   int32_t* row_map_out;     // [B] or null
   int32_t* n_active_out;    // device scalar or null
-  const int32_t* order;     // [B] or null: visiting order of the compaction (permutation of the slots; host: descending context)
 };
 hipError_t launch_embed_codes(const float* emb_code /*[4,626,768]*/, const int64_t* ids_buf, int ids_row_stride /*Tcap*/,
                               const int32_t* len, float* x, uint16_t* xb /*null ok*/, float* ssq /*null ok*/, int B,
@@ -266,14 +235,7 @@ struct SampleArgs {
   int q_rows;               // utterance slots in q (>= B)
   const int64_t* teacher;   // [slots, teacher_stride, 4] or null: teacher forcing (evaluation hook)
   int teacher_stride;
-  int64_t* sampled;         // [slots, teacher_stride, 4] or null: the sampler's own draw of every step (before teacher forcing)
-  const RowDesc* desc;      // decode with device-side compaction: this step's row descriptors (utterance + length in ONE load), or null
-  int rng_device;           // 1: Exp(1) draws from the device generator (Philox4x32-10 keyed on rng_seed) instead of `q`
-  int rng_per_step;         // device generator: 1 = a fresh draw every step (the reference's manual_seed=None), 0 = the same draw
-                            // every step (manual_seed set: the reference re-seeds its generator at every step, gpt.py:504-507)
-  const unsigned long long* rng_seed;   // device scalar
 };
-hipError_t launch_exp_draws(unsigned long long seed, int step, int row0, int rows, int V, float* out, hipStream_t st);
 hipError_t launch_sample(const SampleArgs& a, hipStream_t st);
 // refine-text mode: logits [B, V], q [nq, B, V], temperature[0]; no repetition penalty (see gpt.hip)
 hipError_t launch_sample_text(const SampleArgs& a, int V, hipStream_t st);
@@ -305,8 +267,6 @@ hipError_t launch_dwconv_ln(const float* x, const float* w /*[C,7]*/, const floa
 hipError_t launch_layernorm(const float* x, const float* w, const float* b, float eps, float* y, int rows, int C, hipStream_t st);
 hipError_t launch_istft(const float* head /*[B,F,1026]*/, const float* window /*[1024]*/, const float* twiddle /*[512,2]*/,
                         float* frames /*[B,F,1024] scratch*/, float* wav /*[B,256(F-1)]*/, int B, int F, hipStream_t st);
-
-hipError_t launch_copy16(const void* src, void* dst, size_t bytes, hipStream_t st);   // shader copy (dst may be pinned host memory)
 
 // ---- full DVAE: mel front end + GFSQ (dvae.hip) ------------------------------------------------
 // |STFT| of one waveform: center=True reflect padding, frame f = padded[256 f, 256 f + 1024) * window, 1024-point FFT,

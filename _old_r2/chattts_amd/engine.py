@@ -19,7 +19,6 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._sync import wait_event, wait_stream
 from .config import DVAE, GPT, VOCOS
 from .rng import ExpDraws, penalty_table
 from .weights import fold_weight_norm, gpt_layer_count
@@ -132,7 +131,7 @@ class _EventGroup:
 
     def synchronize(self):
         for e in self.evs:
-            wait_event(e)
+            e.synchronize()
 
 
 def left_pad_starts(attention_mask: torch.Tensor) -> torch.Tensor:
@@ -206,10 +205,7 @@ class GptEngine:
     POLL = 16      # decode steps enqueued between two looks at the device-side finish flags
 
     def __init__(self, gpt_sd: dict, embed_sd: dict, device: torch.device, dtype: str = "bf16",
-                 max_pos: int = GPT.max_pos, logger: logging.Logger = log, rms_eps: float = GPT.rms_eps,
-                 rope_theta: float = GPT.rope_theta):
-        """`rms_eps` / `rope_theta` / `max_pos`: the run-time fields of `asset/gpt/config.json` (weights.check_gpt_config;
-        `LlamaModel.from_pretrained`, gpt.py:75); everything else in that file is the geometry the kernels are compiled for."""
+                 max_pos: int = GPT.max_pos, logger: logging.Logger = log):
         if dtype not in ("bf16", "f32"):
             raise ValueError("dtype must be 'bf16' (perf) or 'f32' (parity)")
         self.lib = _lib.lib()
@@ -248,40 +244,35 @@ class GptEngine:
                                   for k in range(GPT.n_vq)], 0))
         self.head_text = f(fold_weight_norm(embed_sd["head_text.parametrizations.weight.original0"].float(),
                                             embed_sd["head_text.parametrizations.weight.original1"].float()))
-        cos, sin = rope_tables(max_pos, theta=rope_theta)
+        cos, sin = rope_tables(max_pos)
         self.rope_cos, self.rope_sin = cos.to(dev), sin.to(dev)
         self._arrs = [_lib.ptr_array(x) for x in (self.wqkv, self.wo, self.wgu, self.wd, self.ln1, self.ln2)]
         # a second copy of the four matrices in the fragment-packed order the DECODE kernels read (bf16: decode.hip, f32:
         # decode32.hip); the row-major copy stays for the prefill kernels (+0.38 GB / +0.75 GB of the 288 GB)
-        # (CTTS_DEC_PACKED=0, the A/B switch back to the row-major decode kernels, skips building them)
-        use_packed = os.environ.get("CTTS_DEC_PACKED", "1") != "0"
         pk = pack_frag if dtype == "bf16" else pack_frag32
-        self.packed, self._pk_arrs = None, None
-        if use_packed:
-            self.packed = [[pk(t) for t in ws] for ws in (self.wqkv, self.wo, self.wgu, self.wd)]
-            if dtype != "bf16":
-                # the packed f32 QKV matrix carries the RoPE row permutation too (its decode kernel rotates in the epilogue); an
-                # output column's dot product does not depend on where the column sits, so the parity arithmetic is untouched
-                rp = rope_row_perm().to(dev)
-                qk_perm = torch.cat([rp, GPT.hidden + rp, 2 * GPT.hidden + torch.arange(GPT.hidden, device=dev)])
-                self.packed[0] = [pack_frag32(t[qk_perm]) for t in self.wqkv]
-            self._pk_arrs = [_lib.ptr_array(x) for x in self.packed]
+        self.packed = [[pk(t) for t in ws] for ws in (self.wqkv, self.wo, self.wgu, self.wd)]
+        if dtype != "bf16":
+            # the packed f32 QKV matrix carries the RoPE row permutation too (its decode kernel rotates in the epilogue); an output
+            # column's dot product does not depend on where the column sits, so the parity arithmetic is untouched
+            rp = rope_row_perm().to(dev)
+            qk_perm = torch.cat([rp, GPT.hidden + rp, 2 * GPT.hidden + torch.arange(GPT.hidden, device=dev)])
+            self.packed[0] = [pack_frag32(t[qk_perm]) for t in self.wqkv]
+        self._pk_arrs = None if self.packed is None else [_lib.ptr_array(x) for x in self.packed]
 
         def pad16(t):      # zero rows up to a multiple of 16: the padded columns of the last logits tile are never stored
             r = (-t.shape[0]) % 16
             return t if r == 0 else torch.cat([t, torch.zeros((r, t.shape[1]), dtype=t.dtype, device=t.device)], 0)
-        self.heads_pk = pack_frag32(pad16(self.heads)) if use_packed else None
-        self.head_text_pk = pack_frag32(pad16(self.head_text)) if use_packed else None
+        self.heads_pk, self.head_text_pk = pack_frag32(pad16(self.heads)), pack_frag32(pad16(self.head_text))
         w = _lib.GptWeights()
         w.n_layers, w.weight_dtype, w.kv_dtype, w.max_pos = self.n_layers, self.code, self.code, max_pos
         w.wqkv, w.wo, w.wgu, w.wd, w.ln1, w.ln2 = [C.cast(a, _lib.PP) for a in self._arrs]
         w.norm, w.emb_code, w.heads = self.norm.data_ptr(), self.emb_code.data_ptr(), self.heads.data_ptr()
         w.rope_cos, w.rope_sin = self.rope_cos.data_ptr(), self.rope_sin.data_ptr()
-        w.rms_eps = float(rms_eps)
+        w.rms_eps = GPT.rms_eps
         w.emb_text, w.head_text, w.n_text = self.emb_text.data_ptr(), self.head_text.data_ptr(), GPT.n_text
         if self._pk_arrs is not None:
             w.wqkv_pk, w.wo_pk, w.wgu_pk, w.wd_pk = [C.cast(a, _lib.PP) for a in self._pk_arrs]
-        w.heads_pk, w.head_text_pk = _lib.ptr(self.heads_pk), _lib.ptr(self.head_text_pk)
+        w.heads_pk, w.head_text_pk = self.heads_pk.data_ptr(), self.head_text_pk.data_ptr()
         self._w = w
         h = C.c_void_p()
         _lib.check(self.lib.ctts_gpt_create(C.byref(h), C.byref(w)), "ctts_gpt_create")
@@ -289,7 +280,6 @@ class GptEngine:
         self.stream = torch.cuda.Stream(device=dev)
         self._lane_res = [(self.handle, self.stream)]
         self.default_lanes = 1
-        self.rng = "host"         # default source of the multinomial's Exp(1) draws: "host" (the reference's CPU stream) | "device"
         self.last_stats = {}
         self._session = None      # buffers + instantiated graph of the last generate() geometry (see generate)
         self._draws_cache = None  # (key, ExpDraws) of the last seeded call: the constant Exp(1) tensor
@@ -337,8 +327,7 @@ class GptEngine:
                  *, use_graph: bool = True, stop_at: Optional[torch.Tensor] = None, row_offset: int = 0,
                  total_rows: Optional[int] = None, profile_tag: Optional[int] = None,
                  profile_stride: int = 1, lanes: Optional[int] = None,
-                 teacher_ids: Optional[torch.Tensor] = None, prefill_chunk: Optional[int] = None,
-                 return_sampled: bool = False, rng: Optional[str] = None, rng_seed: Optional[int] = None) -> Iterator[GenerationOutputs]:
+                 teacher_ids: Optional[torch.Tensor] = None, prefill_chunk: Optional[int] = None) -> Iterator[GenerationOutputs]:
         """Drop-in for `GPT.generate` (gpt.py:316-337), code mode.  Extra keyword-only arguments:
         `use_graph` (hipGraph replay of the decode step), `stop_at` ([B] int32 forced output lengths,
         benchmark hook), `row_offset`/`total_rows` (this shard's position inside a data-parallel batch:
@@ -349,15 +338,7 @@ class GptEngine:
         ([B, max_new_token, 4] int64: teacher forcing -- the token written at step i is teacher_ids[:, i] instead of
         the sampled one; evaluation hook used to bound the bf16 mode's drift on the reference's token stream),
         `prefill_chunk` (tokens: the prompt is prefilled in pieces of that many slots -- `ctts_gpt_prefill_chunk` -- which
-        bounds the activation workspace of a long prompt such as an `spk_smp` audio-code prompt, core.py:435-453: the workspace is
-        then sized for a piece, not for the whole prompt), `return_sampled` (evaluation hook, the companion of `teacher_ids`: after
-        the call `self.last_sampled` holds, per utterance, the [T_b, 4] tokens the sampler itself drew at every step before teacher
-        forcing replaced them -- the teacher-forced token agreement of a numeric mode), `rng` ("host" | "device", default
-        `self.rng` = "host"): where the Exp(1) draws of the multinomial come from.  "host" is the parity contract -- the reference's
-        CPU generator call, uploaded (rng.py).  "device" draws them inside the sampling kernel (Philox4x32-10, counter = token / global
-        row / step; the reference on a GPU device draws from the device generator too, gpt.py:39): with `manual_seed=None` -- the
-        reference's DEFAULT -- that removes the ~2 ms per-step host draw + upload; the key is `rng_seed` or, if None, one draw from
-        torch's global CPU generator (so `torch.manual_seed` still makes a run repeatable).  Code mode only."""
+        bounds the activation workspace of a long prompt such as an `spk_smp` audio-code prompt, core.py:435-453)."""
         if return_attn:
             raise NotImplementedError("return_attn is not supported by the fused attention kernel")
         context = context or Context()
@@ -384,29 +365,20 @@ class GptEngine:
         # seeded sampling re-seeds the CPU generator at every step (gpt.py:504-507): ONE constant tensor per (seed, batch
         # geometry).  Drawing it costs ~4 ms of host time per 256 rows (30 ms for the 2048 rows of an 8-GPU batch), so the
         # last one is kept across calls.
-        rng_mode = rng or self.rng
-        if rng_mode not in ("host", "device"):
-            raise ValueError("rng must be 'host' or 'device'")
-        device_rng = rng_mode == "device" and not infer_text     # refine-text keeps the host stream
         dkey = (total_rows if total_rows is not None else B * nrow, V, manual_seed, row_offset, B * nrow)
-        if device_rng:
-            draws = None
-            seed_val = int(rng_seed) if rng_seed is not None else (int(manual_seed) if manual_seed is not None
-                                                                    else int(torch.randint(0, 2 ** 62, (1,)).item()))
-        elif manual_seed is not None and self._draws_cache is not None and self._draws_cache[0] == dkey:
+        if manual_seed is not None and self._draws_cache is not None and self._draws_cache[0] == dkey:
             draws = self._draws_cache[1]
         else:
             draws = ExpDraws(dkey[0], V, manual_seed, row_begin=row_offset, row_end=row_offset + B * nrow)
             self._draws_cache = (dkey, draws) if draws.constant else None
-        const_q = device_rng or draws.constant      # no per-step host draw / upload
         ptab = penalty_table(plan.penalty)
-        nq = 1 if const_q else self.NQ_RING
+        nq = 1 if draws.constant else self.NQ_RING
         emb_all = emb.to(torch.float32).contiguous().to(dev)
         ids_all = inputs_ids.to(dev)
         temp_d = temperature.to(torch.float32).reshape(-1).to(dev)
         assert temp_d.numel() == nrow, "temperature must have one entry per sampling row of an utterance"
         ptab_d = None if ptab is None else ptab.to(dev)
-        wait_stream(caller)  # inputs above were produced on the caller's stream
+        caller.synchronize()  # inputs above were produced on the caller's stream
 
         class Lane:
             pass
@@ -419,14 +391,12 @@ class GptEngine:
         top_p_thr = float(np.float32(1.0 - plan.top_p)) if plan.top_p is not None else 0.0
         key = (tuple(bounds), T, max_new, nrow, V, nq, self.dtype, top_p_thr, plan.top_p is not None, int(plan.top_k or 0),
                plan.top_k is not None, int(min_new_token), int(eos_token), int(row_offset), bool(infer_text), stop_at is not None,
-               ptab is not None, teacher_ids is not None, bool(return_sampled),
-               None if prefill_chunk is None else int(prefill_chunk), device_rng, manual_seed is None)
+               ptab is not None, teacher_ids is not None)
         sess = self._session if (self._session is not None and self._session["key"] == key) else None
         if sess is None:
             self._session = None     # drop the previous session's buffers before allocating new ones
             sess = dict(key=key, lanes=[], graph=False, temp=torch.empty((nrow,), dtype=torch.float32, device=dev),
-                        ptab=None if ptab is None else torch.empty_like(ptab, device=dev), q_sig=None,
-                        seed=torch.zeros((1,), dtype=torch.int64, device=dev))
+                        ptab=None if ptab is None else torch.empty_like(ptab, device=dev), q_sig=None)
             for (lo, hi), (handle, st) in zip(bounds, res):
                 ln = Lane()
                 ln.lo, ln.hi, ln.handle, ln.st = lo, hi, handle, st
@@ -434,28 +404,20 @@ class GptEngine:
                 with torch.cuda.stream(st):
                     ln.ids_buf = torch.empty((Bl, T + max_new, nvq), dtype=torch.int64, device=dev)  # gpt.py:372-379
                     ln.len_d = torch.empty((Bl,), dtype=torch.int32, device=dev)
-                    # finish flags and end_idx live in ONE padded device block (16-byte granules: [Bp] uint8 | [Bp] int32) so that a
-                    # poll is one shader copy of it into pinned host memory (ctts_copy_bytes) -- see snapshot()
-                    Bp = (Bl + 15) // 16 * 16
-                    ln.state_blk = torch.zeros((5 * Bp,), dtype=torch.uint8, device=dev)
-                    ln.finish = ln.state_blk[:Bl]                                             # gpt.py:346
-                    ln.order = torch.empty((Bl,), dtype=torch.int32, device=dev)              # visiting order of the device-side compaction
+                    ln.finish = torch.empty((Bl,), dtype=torch.uint8, device=dev)             # gpt.py:346
+                    ln.row_map = torch.empty((Bl,), dtype=torch.int32, device=dev)            # compact decode row -> batch slot
                     ln.n_active = torch.empty((1,), dtype=torch.int32, device=dev)
-                    ln.end_idx = ln.state_blk[Bp:].view(torch.int32)[:Bl]                     # gpt.py:343
+                    ln.end_idx = torch.empty((Bl,), dtype=torch.int32, device=dev)            # gpt.py:343
                     ln.hiddens = torch.empty((Bl, max_new, GPT.hidden), dtype=torch.float32, device=dev)
                     kv_shape = (self.n_layers, Bl, GPT.n_heads, T + max_new, GPT.head_dim)
                     ln.kcache = torch.empty(kv_shape, dtype=self.wdt, device=dev)
                     ln.vcache = torch.empty(kv_shape, dtype=self.wdt, device=dev)
-                    # the prefill carves for the rows it pushes through the layers at once (the whole prompt, or one chunk of it);
-                    # the decode steps for one row per utterance
-                    tc_ws = T if (prefill_chunk is None or int(prefill_chunk) >= T) else max(1, int(prefill_chunk))
-                    ln.ws_bytes = max(lib.ctts_gpt_workspace_bytes(Bl, tc_ws), lib.ctts_gpt_workspace_bytes(Bl, 1))
+                    ln.ws_bytes = lib.ctts_gpt_workspace_bytes(Bl, T)
                     ln.workspace = torch.empty((ln.ws_bytes,), dtype=torch.uint8, device=dev)
                     ln.kv_start = torch.empty((Bl,), dtype=kv_start_all.dtype, device=dev)
                     ln.stop_d = None if stop_at is None else torch.empty((Bl,), dtype=torch.int32, device=dev)
-                    ln.q_d = torch.empty((1,) if device_rng else (nq, Bl * nrow, V), dtype=torch.float32, device=dev)
+                    ln.q_d = torch.empty((nq, Bl * nrow, V), dtype=torch.float32, device=dev)
                     ln.teacher = None if teacher_ids is None else torch.empty((Bl, max_new, nvq), dtype=torch.int64, device=dev)
-                    ln.sampled = torch.zeros((Bl, max_new, nvq), dtype=torch.int64, device=dev) if return_sampled else None
                 s = _lib.GenState()
                 s.B, s.T, s.max_new = Bl, T, max_new
                 s.ids_buf, s.len, s.kv_start = ln.ids_buf.data_ptr(), ln.len_d.data_ptr(), ln.kv_start.data_ptr()
@@ -472,11 +434,6 @@ class GptEngine:
                 s.infer_text = int(infer_text)
                 s.stop_at = _lib.ptr(ln.stop_d)
                 s.teacher_ids = _lib.ptr(ln.teacher)
-                s.sampled_ids = _lib.ptr(ln.sampled)
-                s.rng_device, s.rng_per_step, s.rng_seed = int(device_rng), int(manual_seed is None), sess["seed"].data_ptr()
-                # compaction order: utterances by descending context = ascending left padding (contexts of a batch differ only by
-                # the static valid prompt length), so the attention grid starts its longest units first.  CTTS_ORDER=0: ascending slot
-                s.order = ln.order.data_ptr() if os.environ.get("CTTS_ORDER", "1") != "0" else None
                 s.workspace, s.workspace_bytes = ln.workspace.data_ptr(), ln.ws_bytes
                 # no row_map: the library compacts on the device -- the first kernel of every decode step ranks the utterances
                 # whose finish flag is 0 and writes n_active (include/chattts_amd.h), so finished utterances leave the step
@@ -486,11 +443,11 @@ class GptEngine:
                 sess["lanes"].append(ln)
             self._session = sess
         L = sess["lanes"]
-        q_sig = (draws.total_rows, V, manual_seed, row_offset, B * nrow) if (draws is not None and draws.constant) else None
+        q_sig = (draws.total_rows, V, manual_seed, row_offset, B * nrow) if draws.constant else None
         for ln in L:
             lo, hi = ln.lo, ln.hi
             Bl = hi - lo
-            ln.done, ln.end_snap = False, None
+            ln.done, ln.end_snap, ln.n_act_host = False, None, Bl
             with torch.cuda.stream(ln.st):
                 if sess.get("out_ev") is not None:
                     ln.st.wait_event(sess["out_ev"])   # the previous call's result copies have read these buffers
@@ -498,7 +455,7 @@ class GptEngine:
                 ln.ids_buf[:, :T] = ids_all[lo:hi]
                 ln.len_d.fill_(T)
                 ln.finish.zero_()
-                ln.order.copy_(torch.argsort(kv_start_all[lo:hi].to(torch.int64), stable=True).to(torch.int32))
+                ln.row_map.copy_(torch.arange(Bl, dtype=torch.int32))
                 ln.n_active.fill_(Bl)
                 ln.end_idx.zero_()
                 ln.kv_start.copy_(kv_start_all[lo:hi])
@@ -508,11 +465,9 @@ class GptEngine:
                     assert tuple(teacher_ids.shape) == (B, max_new, nvq)
                     ln.teacher.copy_(teacher_ids[lo:hi].to(torch.int64))
                 ln.emb = emb_all[lo:hi].contiguous()
-                if draws is not None and draws.constant and sess["q_sig"] != q_sig:
+                if draws.constant and sess["q_sig"] != q_sig:
                     ln.q_d[0].copy_(draws.step(0)[lo * nrow: hi * nrow])
                 if ln is L[0]:
-                    if device_rng:
-                        sess["seed"].fill_(seed_val)
                     sess["temp"].copy_(temp_d)
                     if ptab is not None:
                         sess["ptab"].copy_(ptab)
@@ -529,7 +484,7 @@ class GptEngine:
         # uploads are stream-ordered behind the launches that still read the ring half they overwrite (no host sync).
         half = nq // 2
         feeder = None
-        if not const_q:
+        if not draws.constant:
             from concurrent.futures import ThreadPoolExecutor
             feeder = dict(pool=ThreadPoolExecutor(max_workers=1), bufs=[torch.empty((half, B * nrow, V), dtype=torch.float32).pin_memory()
                                                                            for _ in range(2)],
@@ -538,8 +493,7 @@ class GptEngine:
             def draw_block(blk):
                 buf = feeder["bufs"][blk % 2]
                 if feeder["evs"][blk % 2] is not None:
-                    e_ = feeder["evs"][blk % 2]                 # the H2D copy that last read this buffer is done
-                    e_.synchronize() if isinstance(e_, _EventGroup) else wait_event(e_)
+                    feeder["evs"][blk % 2].synchronize()       # the H2D copy that last read this buffer is done
                 feeder["states"].append((blk, torch.get_rng_state()))
                 nthr = torch.get_num_threads()
                 torch.set_num_threads(1)   # exponential_ is a serial stream; a 100+-thread OpenMP wake-up costs ~10 ms per call
@@ -619,30 +573,25 @@ class GptEngine:
             """stream-ordered, ASYNCHRONOUS D2H of the lane's finish flags and end_idx into pinned host buffers, plus the event
             that marks the copy (and everything enqueued before it) done.  Two buffer sets: up to two chunks are in flight."""
             k = ln.snap_i = (getattr(ln, "snap_i", 0) + 1) % 2
-            Bl_, Bp_ = ln.hi - ln.lo, ln.state_blk.numel() // 5
             if not hasattr(ln, "snap_buf"):
-                ln.snap_buf = []
-                for _ in range(2):
-                    blk = torch.empty((5 * Bp_,), dtype=torch.uint8).pin_memory()
-                    ln.snap_buf.append((blk[:Bl_], blk[Bp_:].view(torch.int32)[:Bl_], torch.cuda.Event(), blk))
-            fin_h, end_h, ev, blk = ln.snap_buf[k]
+                ln.snap_buf = [(torch.empty((ln.hi - ln.lo,), dtype=torch.uint8).pin_memory(),
+                                torch.empty((ln.hi - ln.lo,), dtype=torch.int32).pin_memory(), torch.cuda.Event()) for _ in range(2)]
+            fin_h, end_h, ev = ln.snap_buf[k]
             with torch.cuda.stream(ln.st):
                 if sync_poll:
                     fin_h.copy_(ln.finish.cpu())
                     end_h.copy_(ln.end_idx.cpu())
                 else:
-                    # a SHADER copy into the pinned block, not hipMemcpyAsync: a runtime-mediated D2H behind in-flight kernels
-                    # intermittently stalls 60-90 ms on this pool's hosts (profiles/r3h_stall_probe.log); a kernel is just the next
-                    # packet of the stream
-                    _lib.check(lib.ctts_copy_bytes(blk.data_ptr(), ln.state_blk.data_ptr(), blk.numel(), ln.st.cuda_stream), "ctts_copy_bytes")
+                    fin_h.copy_(ln.finish, non_blocking=True)
+                    end_h.copy_(ln.end_idx, non_blocking=True)
                 ev.record(ln.st)
             return k
 
         def collect(ln, k):
             """wait for snapshot k; the reference keeps stepping finished rows until the last one is done (gpt.py:512-518,592)
             but cuts their output at end_idx -- here they left the step on the device the moment they finished"""
-            fin_h, end_h, ev, _ = ln.snap_buf[k]
-            wait_event(ev)
+            fin_h, end_h, ev = ln.snap_buf[k]
+            ev.synchronize()
             ln.ev = ev
             ln.end_snap = end_h.tolist()
             ln.done = bool(fin_h.all())
@@ -698,9 +647,7 @@ class GptEngine:
                                          min_new_token, logits_processors, infer_text, return_attn, return_hidden,
                                          stream, show_tqdm, ensure_non_empty, stream_batch, manual_seed, context,
                                          use_graph=use_graph, stop_at=stop_at, row_offset=row_offset, total_rows=total_rows,
-                                         profile_tag=profile_tag, profile_stride=profile_stride, lanes=lanes,
-                                         teacher_ids=teacher_ids, prefill_chunk=prefill_chunk, return_sampled=return_sampled,
-                                         rng=rng, rng_seed=None)
+                                         lanes=lanes)
             return  # gpt.py:570: the seeded case yields nothing
 
         graph_ok = use_graph and max_new > 1
@@ -755,16 +702,6 @@ class GptEngine:
                 # yield boundary is still handed out.  Granularity here is one chunk (POLL / stream_batch steps), not one step.
                 if context.get():
                     interrupted = True
-                    # run-ahead: a chunk may already be enqueued behind the one just collected.  Its tokens WILL be in the buffers
-                    # the final outputs() reads, so it is collected and counted too -- tokens, `steps` and the rewound position of
-                    # the global CPU generator (unseeded mode) then describe the same number of steps.
-                    while inflight:
-                        n2, snaps2 = inflight.pop(0)
-                        for ln, k in zip(L, snaps2):
-                            if k is not None and not ln.done:
-                                collect(ln, k)
-                        steps_done += n2
-                    all_done = all(ln.done for ln in L)
                     break
             if profile_tag is not None:
                 n_s, tot = C.c_int32(0), C.c_double(0.0)
@@ -774,7 +711,7 @@ class GptEngine:
             if feeder is not None:
                 feeder["pool"].shutdown(wait=True)   # idempotent; the generator-state rewind happens in finish_rng
             for ln in L:
-                wait_stream(ln.st)   # nothing of this call is still running when its buffers are handed to the next one
+                ln.st.synchronize()   # nothing of this call is still running when its buffers are handed to the next one
             self.last_stats["decode_ms"] = 1e3 * (_time.perf_counter() - t_dec0)   # host wall of the decode loop (streaming: incl. consumer time)
         if not all_done:
             if interrupted:
@@ -788,8 +725,6 @@ class GptEngine:
         # steps the reference loop would have executed: up to and including the step at which the last row hit EOS
         steps_ref = (max(max(ln.end_snap) for ln in L) + 1) if all_done else min(steps_done, max_new)
         finish_rng(min(steps_ref, max_new))
-        if return_sampled:
-            self.last_sampled = [ln.sampled[b, : ln.end_snap[b]].clone() for ln in L for b in range(ln.hi - ln.lo)]
         yield outputs()
 
 
@@ -932,21 +867,8 @@ class CodecEngine:
             pass
 
     def _ws(self, B, F):
-        """the codec workspace: ONE buffer per engine that only ever grows.  A streamed utterance asks for a different window size
-        at every yield; going through the caching allocator each time meant a device allocation per yield whenever no cached block
-        fitted (tens of milliseconds each on this pool's hosts, profiles/r3e_c5_sched_probe.log).  Kernels of consecutive calls
-        are stream-ordered on the caller's stream, so sharing the buffer needs no extra synchronisation as long as ONE stream
-        drives the engine at a time (the documented contract of a handle, include/chattts_amd.h)."""
         n = self.lib.ctts_codec_workspace_bytes(B, F)
-        cur = torch.cuda.current_stream(self.device)
-        buf = getattr(self, "_ws_buf", None)
-        if buf is None or buf.numel() < n or getattr(self, "_ws_stream", None) != cur.cuda_stream:
-            if buf is not None:
-                buf.record_stream(cur)
-            with torch.cuda.stream(cur):
-                self._ws_buf = buf = torch.empty((max(n, 0 if buf is None else buf.numel()),), dtype=torch.uint8, device=self.device)
-            self._ws_stream = cur.cuda_stream
-        return buf, buf.numel()
+        return torch.empty((n,), dtype=torch.uint8, device=self.device), n
 
     def dvae_decode(self, hid: torch.Tensor) -> torch.Tensor:
         """hid [B,T,768] f32 (zero padded rows) -> mel [B,2T,100]   (dvae.py:276-297)."""
@@ -1010,17 +932,10 @@ class CodecEngine:
             return np.zeros(tuple(t.shape), dtype=np.float32)
         buf = getattr(self, "_pinned", None)
         if buf is None or buf.numel() < n or buf.dtype != t.dtype:
-            buf = self._pinned = torch.empty(((n + 3) // 4 * 4,), dtype=t.dtype).pin_memory()
+            buf = self._pinned = torch.empty((n,), dtype=t.dtype).pin_memory()
         view = buf[:n].view(t.shape)
-        nbytes = n * t.element_size()
-        if nbytes % 16 == 0 and t.data_ptr() % 16 == 0 and os.environ.get("CTTS_D2H_SHADER", "1") != "0":
-            # shader copy (plain stores over PCIe into the pinned buffer) instead of hipMemcpyAsync: same rate (67 MB in 1.2 ms), and
-            # no runtime-mediated hand-off behind the decode kernels, which intermittently stalls 60-90 ms on this pool's hosts
-            _lib.check(self.lib.ctts_copy_bytes(view.data_ptr(), t.data_ptr(), nbytes, torch.cuda.current_stream(self.device).cuda_stream),
-                       "ctts_copy_bytes")
-        else:
-            view.copy_(t, non_blocking=True)
-        wait_stream(torch.cuda.current_stream(self.device))
+        view.copy_(t, non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
         return view.clone().numpy()     # torch's multi-threaded host copy; the result does not alias the staging buffer
 
     def decode_to_wavs(self, result_list: List[torch.Tensor]) -> torch.Tensor:

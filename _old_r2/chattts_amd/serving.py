@@ -12,8 +12,8 @@ is: write the slot's state, clear its flag.  Newly admitted requests are prefill
 
 Parity contract: a request produces exactly the tokens `GptEngine.generate` produces for it alone with
 `row_offset = 4*slot, total_rows = 4*S` (the Exp(1) draw of a sampling row is the pool row's), because nothing
-in the step mixes utterances.  With the host generator, seeded sampling only (`manual_seed`: the reference re-seeds its CPU
-generator every step, so the draw is one constant tensor for the whole session); `rng="device"` serves unseeded sampling too.
+in the step mixes utterances.  Seeded sampling only (`manual_seed`): the reference re-seeds its CPU generator every
+step, so the draw is one constant tensor for the whole session.
 """
 from __future__ import annotations
 
@@ -26,7 +26,6 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._sync import wait_stream
 from .config import GPT
 from .engine import GptEngine, gen_logits, plan_from_processors
 from .rng import ExpDraws, penalty_table
@@ -46,15 +45,9 @@ class SlotPool:
 
     def __init__(self, engine: GptEngine, slots: int = 64, cap: int = 1536, hid_cap: int = 1024, *, temperature=(0.3,) * 4,
                  top_P: Optional[float] = 0.7, top_K: Optional[int] = 20, repetition_penalty: float = 1.05, manual_seed: int = 42,
-                 min_new_token: int = 0, eos_token: int = GPT.n_audio - 1, rng: str = "host", rng_seed: Optional[int] = None):
-        """`rng="device"`: the Exp(1) draws come from the sampling kernel's own generator (engine.generate's `rng`), which is what
-        makes the reference's DEFAULT `manual_seed=None` servable here: a fresh draw per (request step, pool row) without any
-        per-step host work.  The host stream (`rng="host"`) needs `manual_seed` (one constant tensor per session)."""
-        if rng not in ("host", "device"):
-            raise ValueError("rng must be 'host' or 'device'")
-        if manual_seed is None and rng != "device":
-            raise NotImplementedError("SlotPool with the host generator needs manual_seed (one constant Exp(1) draw per session); "
-                                      "use rng='device' for unseeded sampling")
+                 min_new_token: int = 0, eos_token: int = GPT.n_audio - 1):
+        if manual_seed is None:
+            raise NotImplementedError("SlotPool needs manual_seed (one constant Exp(1) draw per session)")
         if cap > engine.max_pos:
             raise ValueError("slot capacity exceeds max_position_embeddings")
         self.eng, self.S, self.cap, self.hid_cap = engine, slots, cap, hid_cap
@@ -71,12 +64,8 @@ class SlotPool:
             self.ids_buf = torch.zeros((slots, cap, nvq), dtype=torch.int64, device=dev)
             self.len = torch.ones((slots,), dtype=torch.int32, device=dev)
             self.kv_start = torch.zeros((slots,), dtype=torch.int32, device=dev)
-            # finish flags + end_idx in one padded block: a poll is one shader copy of it into pinned memory (engine.snapshot)
-            self._Sp = (slots + 15) // 16 * 16
-            self.state_blk = torch.zeros((5 * self._Sp,), dtype=torch.uint8, device=dev)
-            self.finish = self.state_blk[:slots]
-            self.finish.fill_(1)                                                    # free slots look finished
-            self.end_idx = self.state_blk[self._Sp:].view(torch.int32)[:slots]
+            self.finish = torch.ones((slots,), dtype=torch.uint8, device=dev)      # free slots look finished
+            self.end_idx = torch.zeros((slots,), dtype=torch.int32, device=dev)
             self.prompt_len = torch.ones((slots,), dtype=torch.int32, device=dev)
             self.stop_at = torch.full((slots,), -1, dtype=torch.int32, device=dev)
             self.hiddens = torch.empty((slots, hid_cap, GPT.hidden), dtype=torch.float32, device=dev)
@@ -84,15 +73,7 @@ class SlotPool:
             self.kcache = torch.zeros(kv_shape, dtype=engine.wdt, device=dev)
             self.vcache = torch.zeros(kv_shape, dtype=engine.wdt, device=dev)
             self.n_active = torch.zeros((1,), dtype=torch.int32, device=dev)   # written by the step's first kernel
-            self.device_rng, self.rng_per_step = rng == "device", manual_seed is None
-            if self.device_rng:
-                self.q = torch.zeros((1,), dtype=torch.float32, device=dev)
-                seed = int(rng_seed) if rng_seed is not None else (int(manual_seed) if manual_seed is not None
-                                                                   else int(torch.randint(0, 2 ** 62, (1,)).item()))
-                self.rng_seed = torch.tensor([seed], dtype=torch.int64, device=dev)
-            else:
-                self.q = ExpDraws(slots * nvq, GPT.n_audio, manual_seed).step(0).to(dev).reshape(1, slots * nvq, GPT.n_audio).contiguous()
-                self.rng_seed = None
+            self.q = ExpDraws(slots * nvq, GPT.n_audio, manual_seed).step(0).to(dev).reshape(1, slots * nvq, GPT.n_audio).contiguous()
             self.temp = torch.tensor(list(temperature), dtype=torch.float32, device=dev)
             ptab = penalty_table(plan.penalty)
             self.ptab = None if ptab is None else ptab.to(dev)
@@ -138,7 +119,6 @@ class SlotPool:
         s.cap, s.hid_cap, s.kv_batch, s.q_batch = self.cap, self.hid_cap, self.S, self.S
         s.prompt_len = self.prompt_len.data_ptr()
         s.infer_text = 0
-        s.rng_device, s.rng_per_step, s.rng_seed = int(self.device_rng), int(self.rng_per_step), _lib.ptr(self.rng_seed)
         return s
 
     # -- request intake ---------------------------------------------------------------------------------------
@@ -203,13 +183,9 @@ class SlotPool:
             if self.active:
                 _lib.check(self.lib.ctts_gpt_graph_launch(self.handle, self.POLL, self.st.cuda_stream), "ctts_gpt_graph_launch")
                 self.steps += self.POLL
-            if not hasattr(self, "_blk_h"):
-                self._blk_h = torch.empty((5 * self._Sp,), dtype=torch.uint8).pin_memory()
-            _lib.check(self.lib.ctts_copy_bytes(self._blk_h.data_ptr(), self.state_blk.data_ptr(), self._blk_h.numel(), self.st.cuda_stream),
-                       "ctts_copy_bytes")
-            wait_stream(self.st)     # polled, not an interrupt wait (chattts_amd/_sync.py)
-            fin = self._blk_h[: self.S].clone()
-            end = self._blk_h[self._Sp:].view(torch.int32)[: self.S].clone()
+            with torch.cuda.stream(self.st):
+                fin = self.finish.cpu()
+                end = self.end_idx.cpu()
             done = [s for s, (r, _) in self.active.items() if bool(fin[s]) or int(end[s]) >= r.max_new]
             for s in done:
                 r, Tg = self.active.pop(s)
@@ -218,7 +194,7 @@ class SlotPool:
                     ids = self.ids_buf[s, Tg: Tg + n].clone()
                     hid = self.hiddens[s, :n].clone()
                     self.finish[s] = 1      # a request cut at max_new_token stops costing attention bandwidth
-                wait_stream(self.st)
+                self.st.synchronize()
                 self.free.append(s)
                 self.free.sort()
                 yield r.rid, ids, hid

@@ -1,0 +1,102 @@
+"""Seeded input recipes for the golden cases (shared by oracle/make_goldens.py and tests/).
+numpy RandomState only, so the inputs are bit-reproducible everywhere.  TEST INFRASTRUCTURE."""
+from __future__ import annotations
+
+import numpy as np
+
+from chattts_amd import synth
+
+f32 = np.float32
+V = 626
+
+# ---- sampling-kernel unit cases (rows = B*4) -------------------------------------------------
+SAMPLING_CASES = {
+    # default InferCodeParams (core.py:195-206): top_P .7, top_K 20, rep 1.05, temp .3
+    "default_h0": dict(rows=32, hist=0, top_P=0.7, top_K=20, rep=1.05, temp=0.3, seed=42, mask_eos=False, scale=4.0, inseed=1),
+    "default_h5": dict(rows=32, hist=5, top_P=0.7, top_K=20, rep=1.05, temp=0.3, seed=42, mask_eos=False, scale=4.0, inseed=2),
+    "default_h16": dict(rows=32, hist=16, top_P=0.7, top_K=20, rep=1.05, temp=0.3, seed=7, mask_eos=True, scale=4.0, inseed=3),
+    "default_h40": dict(rows=64, hist=40, top_P=0.7, top_K=20, rep=1.05, temp=0.3, seed=42, mask_eos=False, scale=4.0, inseed=4),
+    # tests/#511.py:31-37 "greedy": top_K=1, top_P=0.005 (min_tokens_to_keep=3 still keeps 3)
+    "greedy511": dict(rows=32, hist=8, top_P=0.005, top_K=1, rep=1.05, temp=0.3, seed=42, mask_eos=False, scale=4.0, inseed=5),
+    # flat distribution: top-p keeps many, top-k cuts to 20
+    "flat": dict(rows=32, hist=3, top_P=0.7, top_K=20, rep=1.05, temp=1.0, seed=11, mask_eos=False, scale=0.5, inseed=6),
+    # top-p only / top-k only / neither / no penalty
+    "p_only": dict(rows=16, hist=4, top_P=0.9, top_K=None, rep=1.2, temp=0.7, seed=3, mask_eos=False, scale=2.0, inseed=7),
+    "k_only_ties": dict(rows=16, hist=4, top_P=None, top_K=5, rep=None, temp=1.0, seed=3, mask_eos=False, scale=2.0, inseed=8, quant=0.5),
+    "none": dict(rows=16, hist=4, top_P=None, top_K=None, rep=None, temp=0.5, seed=5, mask_eos=True, scale=3.0, inseed=9),
+    # processors.py:24-27 quirk: rows >= 625 get no penalty (B >= 157)
+    "rows640": dict(rows=640, hist=12, top_P=0.7, top_K=20, rep=1.5, temp=0.3, seed=42, mask_eos=False, scale=4.0, inseed=10),
+}
+
+
+def sampling_inputs(c):
+    rs = np.random.RandomState(c["inseed"])
+    logits = (rs.standard_normal((c["rows"], V)) * c["scale"]).astype(f32)
+    if c.get("quant"):
+        logits = (np.round(logits / c["quant"]) * c["quant"]).astype(f32)
+    # histories drawn from the likely tokens so penalties actually hit the head of the distribution
+    top = np.argsort(-logits, axis=1)[:, :8]
+    pick = rs.randint(0, 8, size=(c["rows"], c["hist"]))
+    hist = np.take_along_axis(top, pick, axis=1).astype(np.int64) if c["hist"] else np.zeros((c["rows"], 0), np.int64)
+    temp = np.full(c["rows"], c["temp"], dtype=f32)
+    return logits, hist, temp
+
+
+# ---- end-to-end generation cases -------------------------------------------------------------
+GEN_CASES = {
+    # BASELINE config C1: one 16-token sentence, near-greedy (tests/#511.py:31-37 parameters)
+    "c1": dict(B=1, t_min=16, t_max=16, pseed=0, temperature=[0.3] * 4, top_P=0.005, top_K=1, rep=1.05,
+               max_new=48, min_new=0, manual_seed=42, keep_hidden_rows=[0], keep_logit_steps=[0, 1, 47]),
+    # mixed-length left-padded batch, default sampling
+    "b8": dict(B=8, t_min=12, t_max=28, pseed=1, temperature=[0.3] * 4, top_P=0.7, top_K=20, rep=1.05,
+               max_new=64, min_new=8, manual_seed=42, keep_hidden_rows=[0, 5], keep_logit_steps=[0, 1, 30, 63]),
+    # long run: 320 autoregressive steps (context up to ~350 keys: several attention blocks per wave); any argmax flip
+    # anywhere would diverge the whole suffix
+    "long": dict(B=2, t_min=20, t_max=30, pseed=3, temperature=[0.3] * 4, top_P=0.7, top_K=20, rep=1.05,
+                 max_new=320, min_new=320, manual_seed=1234, keep_hidden_rows=[], keep_logit_steps=[]),
+    # per-codebook temperatures, no seed => torch global CPU generator advances per step
+    "unseeded": dict(B=2, t_min=10, t_max=14, pseed=2, temperature=[0.3, 0.5, 0.7, 1.0], top_P=0.7, top_K=20, rep=1.05,
+                     max_new=24, min_new=0, manual_seed=None, global_seed=7, keep_hidden_rows=[1], keep_logit_steps=[0, 23]),
+}
+
+
+# ---- BASELINE-size cases (tests/golden/generate_big.npz): the widths / lengths BASELINE.json's configs name --------
+BIG_CASES = {
+    # C3 at full width: 64 utterances, the bench's own mixed-length left-padded prompts (synth seed 0, 16..48 tokens),
+    # default sampling; rows hit EOS naturally at different steps after min_new (compaction across 64 rows, the
+    # M = 64 projection tiles, 4-row groups up to global sampling row 255)
+    "c3w": dict(B=64, t_min=16, t_max=48, pseed=0, temperature=[0.3] * 4, top_P=0.7, top_K=20, rep=1.05,
+                max_new=40, min_new=6, manual_seed=42, keep_hidden_rows=[0, 37, 63], keep_logit_steps=[0, 39]),
+    # C2: batch 1, 512 speech tokens (context up to 544 keys), nothing may flip over 512 autoregressive steps
+    "c2": dict(B=1, t_min=32, t_max=32, pseed=7, temperature=[0.3] * 4, top_P=0.7, top_K=20, rep=1.05,
+               max_new=512, min_new=512, manual_seed=42, keep_hidden_rows=[0], keep_logit_steps=[0, 511]),
+}
+
+
+# refine-text mode (core.py:665-751 defaults: temperature 0.7, top_P 0.7, top_K 20, repetition_penalty 1.0)
+TEXT_EOS = 21000  # stands in for tokenizer.eos_token ([Ebreak]); any id works with synthetic weights
+TEXT_CASES = {
+    "text3": dict(B=3, t_min=9, t_max=15, pseed=4, temperature=[0.7], top_P=0.7, top_K=20, rep=1.0, max_new=24, min_new=2,
+                  manual_seed=12345, keep_hidden_rows=[2], keep_logit_steps=[0, 5]),
+    "text1_greedyish": dict(B=1, t_min=12, t_max=12, pseed=5, temperature=[0.3], top_P=0.1, top_K=3, rep=1.0, max_new=16, min_new=0,
+                            manual_seed=7, keep_hidden_rows=[0], keep_logit_steps=[0]),
+}
+
+
+def gen_inputs(c):
+    return synth.make_prompts(c["B"], c["t_min"], c["t_max"], seed=c["pseed"])
+
+
+# ---- acoustic decoder cases ------------------------------------------------------------------
+CODEC_CASES = {
+    "c24": dict(B=2, T=24, seed=0),
+    "c1x5": dict(B=1, T=5, seed=1),   # shorter than the receptive field: edge handling
+}
+
+
+def codec_inputs(c):
+    rs = np.random.RandomState(100 + c["seed"])
+    hid = rs.standard_normal((c["B"], c["T"], 768)).astype(f32)
+    if c["B"] > 1:
+        hid[1, c["T"] * 2 // 3:] = 0  # a shorter row zero-padded like core.py:525-533
+    return hid

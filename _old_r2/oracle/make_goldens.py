@@ -1,0 +1,138 @@
+"""Generates tests/golden/*.npz by running the reference itself (oracle/ref_harness.py) on CPU.
+
+Run in the build container only:   python -m oracle.make_goldens
+Inputs are NOT stored: every test re-creates them from the seeded recipes in `cases.py`
+(chattts_amd.synth / numpy RandomState) and the weight recipe in chattts_amd.weights, whose sha256
+fingerprints ARE stored, so a drifting recipe fails loudly instead of silently mis-comparing.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from chattts_amd import weights as W  # noqa: E402
+from oracle import cases, ref_harness  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def golden_sampling():
+    m = ref_harness.ref_modules()
+    out = {}
+    for name, c in cases.SAMPLING_CASES.items():
+        logits, hist, temp = cases.sampling_inputs(c)
+        rows, V = logits.shape
+        warpers, procs = m["processors"].gen_logits(num_code=V - 1, top_P=c["top_P"], top_K=c["top_K"],
+                                                    repetition_penalty=c["rep"])
+        x = torch.from_numpy(logits).clone()
+        x /= torch.from_numpy(temp).view(-1, 1)  # gpt.py:487
+        for p in (*procs, *warpers):  # core.py:649 order
+            x = p(torch.from_numpy(hist), x)
+        if c["mask_eos"]:
+            x[:, V - 1] = -torch.inf  # gpt.py:494-495
+        scores = torch.nn.functional.softmax(x, dim=-1)
+        g = torch.Generator()
+        idx = torch.multinomial(scores, 1, generator=g.manual_seed(c["seed"])).view(-1)  # gpt.py:501-508
+        out[name + ".idx"] = idx.numpy()
+        out[name + ".kept"] = np.packbits(torch.isfinite(x).numpy(), axis=1)
+    np.savez_compressed(os.path.join(OUT, "sampling.npz"), **out)
+    print("sampling.npz", {k: v.shape for k, v in out.items()})
+
+
+def golden_generate(sds, which=None, fname="generate.npz"):
+    embed, gpt = ref_harness.build_gpt(sds)
+    out = {}
+    for name, c in (which or cases.GEN_CASES).items():
+        t0 = time.time()
+        ids, mask, tmask = cases.gen_inputs(c)
+        if c["manual_seed"] is None:
+            torch.manual_seed(c["global_seed"])
+        res, emb, cap = ref_harness.run_generate(
+            embed, gpt, ids, mask, tmask, temperature=c["temperature"], top_P=c["top_P"], top_K=c["top_K"],
+            repetition_penalty=c["rep"], max_new_token=c["max_new"], min_new_token=c["min_new"],
+            manual_seed=c["manual_seed"], capture_logits=True)
+        B = ids.shape[0]
+        out[name + ".emb_sum"] = np.array([np.abs(emb).sum(dtype=np.float64)])
+        out[name + ".emb_row0"] = emb[0]
+        out[name + ".lens"] = np.array([r.shape[0] for r in res.ids], dtype=np.int64)
+        out[name + ".ids"] = np.concatenate([r.numpy() for r in res.ids], 0)
+        for b in c["keep_hidden_rows"]:
+            out[name + f".hid{b}"] = res.hiddens[b].numpy()
+        for s in c["keep_logit_steps"]:
+            if s < len(cap):
+                out[name + f".tlogits{s}"] = cap[s]  # logits / temperature at step s, [B*4, 626]
+        print(name, "steps", len(cap), "lens", out[name + ".lens"].tolist(), f"{time.time() - t0:.1f}s")
+    np.savez_compressed(os.path.join(OUT, fname), **out)
+
+
+def golden_text(sds):
+    embed, gpt = ref_harness.build_gpt(sds)
+    out = {}
+    for name, c in cases.TEXT_CASES.items():
+        ids, mask, tmask = cases.gen_inputs(c)
+        res, emb, cap = ref_harness.run_generate(
+            embed, gpt, ids, mask, tmask, temperature=c["temperature"], top_P=c["top_P"], top_K=c["top_K"],
+            repetition_penalty=c["rep"], max_new_token=c["max_new"], min_new_token=c["min_new"],
+            manual_seed=c["manual_seed"], capture_logits=True, infer_text=True, eos_token=cases.TEXT_EOS)
+        out[name + ".lens"] = np.array([r.shape[0] for r in res.ids], dtype=np.int64)
+        out[name + ".ids"] = np.concatenate([r.numpy().reshape(-1) for r in res.ids], 0)
+        for b in c["keep_hidden_rows"]:
+            out[name + f".hid{b}"] = res.hiddens[b].numpy()
+        for s in c["keep_logit_steps"]:
+            if s < len(cap):
+                out[name + f".tlogits{s}"] = cap[s].astype(np.float16)  # [B, 21178] logits / temperature (f16: size)
+        print(name, "steps", len(cap), "lens", out[name + ".lens"].tolist())
+    np.savez_compressed(os.path.join(OUT, "text.npz"), **out)
+
+
+def golden_codec(sds):
+    dec = ref_harness.build_decoder(sds)
+    out = {}
+    for name, c in cases.CODEC_CASES.items():
+        hid = cases.codec_inputs(c)  # [B, T, 768]
+        with torch.inference_mode():
+            mel = dec(torch.from_numpy(hid).permute(0, 2, 1).contiguous())  # core.py:519-535 layout (B,768,T)
+            wav = ref_harness.torch_vocos_decode(sds["vocos"], mel)
+        out[name + ".mel"] = mel.numpy()  # [B, 100, 2T]
+        out[name + ".wav"] = wav.numpy()  # [B, 256(2T-1)]
+        print(name, mel.shape, wav.shape, "wav rms", float(wav.pow(2).mean().sqrt()))
+    np.savez_compressed(os.path.join(OUT, "codec.npz"), **out)
+
+
+def main():
+    assert ref_harness.available(), "/root/reference is required to generate goldens"
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(os.cpu_count())
+    sds = W.synthetic_all()
+    fp = {k: W.fingerprint(v) for k, v in sds.items()}
+    fpath = os.path.join(OUT, "weights_fingerprint.txt")
+    keep = {}
+    if os.path.exists(fpath):     # lines other generators own (make_dvae_goldens.py: "dvae") stay
+        with open(fpath) as f:
+            keep = dict(line.split(None, 1) for line in f if line.strip())
+    keep.update({k: fp[k] + "\n" for k in fp})
+    keep["torch"] = torch.__version__ + "\n"
+    with open(fpath, "w") as f:
+        for k in sorted(keep):
+            f.write(f"{k} {keep[k]}")
+    which = sys.argv[1:] or ["sampling", "generate", "codec", "text"]
+    if "sampling" in which:
+        golden_sampling()
+    if "generate" in which:
+        golden_generate(sds)
+    if "big" in which:   # BASELINE-size cases (C3 at B = 64, C2 at 512 steps): separate file, ~2 min of reference CPU time
+        golden_generate(sds, cases.BIG_CASES, "generate_big.npz")
+    if "codec" in which:
+        golden_codec(sds)
+    if "text" in which:
+        golden_text(sds)
+
+
+if __name__ == "__main__":
+    main()

@@ -221,6 +221,10 @@ typedef struct {
 int ctts_codec_create(ctts_codec** out, const ctts_codec_weights* w);
 void ctts_codec_destroy(ctts_codec* c);
 size_t ctts_codec_workspace_bytes(int32_t B, int32_t F); /* F = mel frames = 2T */
+/* Shader copy of `bytes` (a multiple of 16; both pointers 16-byte aligned) on `stream`.  `dst` may be PINNED HOST memory (mapped into
+ * the device's address space): the float32 waveforms then reach the host -- the `.cpu().numpy()` that ends `Chat._decode_to_wavs`,
+ * ChatTTS/core.py:508-510 -- as plain stores over PCIe, without the copy engines. */
+int ctts_copy_bytes(void* dst, const void* src, size_t bytes, void* stream);
 int ctts_dvae_decode(ctts_codec* c, const float* hid, float* mel, int32_t B, int32_t T, void* workspace, size_t ws_bytes, void* stream);
 int ctts_vocos_decode(ctts_codec* c, const float* mel, float* wav, int32_t B, int32_t F, void* workspace, size_t ws_bytes, void* stream);
 
