@@ -42,6 +42,20 @@ TAGS = {0: "embed", 1: "qkv_gemm", 2: "rope_append", 3: "attention", 4: "o_proj_
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s peak (about 6.3 TB/s achievable)
 
 
+def host_cpu_quota() -> int:
+    """CPUs this process may actually use: the cgroup CFS quota (cpu.max) when there is one, else the affinity mask.  On this pool the
+    hosts show 256 hardware threads under a 16-CPU quota; a torch intra-op pool sized for 128 threads then stalls for tens of
+    milliseconds whenever it wakes up (profiles/r3l_hostcopy_probe.log)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def audio_seconds(lens) -> float:
     return float(sum(256 * (2 * int(t) - 1) for t in lens if t > 0)) / SAMPLE_RATE
 
@@ -201,6 +215,7 @@ def main():
         print("CPU_BASELINE_JSON " + json.dumps(cpu_baseline(W.synthetic_all(), wl["ids"], wl["mask"], wl["tmask"], wl["stop_all"])), flush=True)
         return
 
+    torch.set_num_threads(max(1, min(torch.get_num_threads(), host_cpu_quota())))   # no host-side pool wider than the CPU quota
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -523,7 +538,7 @@ def cpu_baseline(sds, ids, mask, tmask, stop, n_steps: int = 33, codec_rows: int
     try:
         # all hardware threads only on hosts where that is sane: on the 256-thread EPYC 9575F box of this pool the batch-64
         # prefill alone took 115 s at 256 torch threads against 2.6 s at 32 (profiles/r2c_bench.log)
-        cands = {min(cores, 32), min(cores, 64)} | ({cores} if cores <= 96 else set())
+        cands = {min(cores, 32), min(cores, 64), min(cores, host_cpu_quota())} | ({cores} if cores <= 96 else set())
         for nthr in sorted(cands):
             if calib and time.perf_counter() - t_start > 0.35 * budget_s:
                 break
@@ -553,7 +568,7 @@ def cpu_baseline(sds, ids, mask, tmask, stop, n_steps: int = 33, codec_rows: int
     return {"value": round(audio_seconds(stop) / wall, 3), "unit": "audio-s/s", "cores": best, "kind": "port",
             "what": "torch/MKL f32 restatement on the reference's stack: transformers LlamaModel + DynamicCache + TopP/TopK warpers, "
                     "torch.multinomial, torch conv/linear DVAE + Vocos (oracle/torch_port.py)",
-            "host_threads_available": cores,
+            "host_threads_available": cores, "host_cpu_quota": host_cpu_quota(),
             "calibration_prefill_s_and_decode_step_s_by_threads": {str(k): [round(v[0], 3), round(v[1], 4)] for k, v in calib.items()},
             "sample": f"B={B}: prefill {t_prefill:.2f}s + {len(ss) - 1} decode steps at {t_step * 1e3:.1f} ms/step ({best} threads, contexts <= "
                       f"{ids.shape[1] + len(ss)} keys: favours the CPU), DVAE/Vocos {t_codec_per_tok * 1e3:.2f} ms/token on {codec_rows}x{codec_T} tokens; "

@@ -1021,7 +1021,24 @@ class CodecEngine:
         else:
             view.copy_(t, non_blocking=True)
         wait_stream(torch.cuda.current_stream(self.device))
-        return view.clone().numpy()     # torch's multi-threaded host copy; the result does not alias the staging buffer
+        # The result must not alias the staging buffer: copy it out with plain memcpy (numpy), NOT `view.clone()`: torch's intra-op
+        # pool has one thread per hardware thread (128 here) and this pool's hosts run under a 16-CPU cgroup quota, so waking it up
+        # intermittently costs 60-90 ms of CFS throttling (profiles/r3l_hostcopy_probe.log: clone max 92 ms vs numpy 0.1 ms for one
+        # streamed chunk) -- that was what turned the streaming config C5 from 266 into 600 ms per batch.  Large results are cut into
+        # 4 slices copied by 4 plain threads (memcpy releases the GIL).
+        src = view.numpy()
+        out = np.empty(src.shape, dtype=src.dtype)
+        flat_s, flat_o = src.reshape(-1), out.reshape(-1)
+        if flat_s.nbytes < (8 << 20):
+            np.copyto(flat_o, flat_s)
+        else:
+            pool = getattr(self, "_copy_pool", None)
+            if pool is None:
+                from concurrent.futures import ThreadPoolExecutor
+                pool = self._copy_pool = ThreadPoolExecutor(max_workers=4)
+            step = (flat_s.size + 3) // 4
+            list(pool.map(lambda i: np.copyto(flat_o[i * step: (i + 1) * step], flat_s[i * step: (i + 1) * step]), range(4)))
+        return out
 
     def decode_to_wavs(self, result_list: List[torch.Tensor]) -> torch.Tensor:
         """`Chat._decode_to_wavs` (core.py:513-539): zero-pad the per-row [T_b,768] hidden lists to the
