@@ -183,6 +183,8 @@ static SampleArgs make_sample_args(const ctts_gen_state* s, const float* logits)
   a.min_new = s->min_new; a.eos = s->eos; a.row_offset = s->row_offset; a.max_input_ids = NAUDIO - 1; a.stop_at = s->stop_at;
   a.B = s->B; a.row_map = nullptr; a.n_active = nullptr; a.prompt_len = s->prompt_len; a.q_rows = s->q_batch ? s->q_batch : s->B;
   a.teacher = s->teacher_ids; a.teacher_stride = s->hid_cap ? s->hid_cap : s->max_new; a.sampled = s->sampled_ids;
+  a.dbg = nullptr;
+  { const char* e = getenv("CTTS_SAMPLE_DBG_PTR"); if (e) a.dbg = (long long*)strtoull(e, nullptr, 0); }   // probes only
   a.desc = nullptr; a.rng_device = s->rng_device; a.rng_per_step = s->rng_per_step; a.rng_seed = reinterpret_cast<const unsigned long long*>(s->rng_seed);
   return a;
 }

@@ -773,6 +773,9 @@ __global__ __launch_bounds__(256) void sample_k(SampleArgs a) {
   CTTS_PROBE_RETURN();
   const int m = blockIdx.x;                       // compact logits row
   const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  long long* dbg = a.dbg ? a.dbg + (size_t)m * 8 : nullptr;
+#define SSTAMP(i) do { if (dbg && threadIdx.x == 0) dbg[i] = wall_clock64(); } while (0)
+  SSTAMP(0);
   int b, len;
   if (a.desc != nullptr) {    // decode with device-side compaction: ONE load gives the utterance and its length (and says whether
     const RowDesc d = a.desc[m];   // the row exists this step) instead of the n_active -> row_map -> len chain
@@ -789,6 +792,7 @@ __global__ __launch_bounds__(256) void sample_k(SampleArgs a) {
   }
   const int gen = len - (a.prompt_len ? a.prompt_len[b] : a.T);  // tokens generated so far == step index i of gpt.py:394
   const float* lrow = a.logits + ((size_t)m * NVQ + k) * NAUDIO;
+  SSTAMP(1);   // row known
   const float temp = a.temperature[k];
   const int grow = a.row_offset + b * NVQ + k;    // global sampling row (multi-GPU shards keep the reference's numbering)
   const unsigned long long seed = a.rng_device ? *a.rng_seed : 0ull;
@@ -829,6 +833,8 @@ __global__ __launch_bounds__(256) void sample_k(SampleArgs a) {
 
 #pragma unroll
   for (int s = 0; s < SLOTS; ++s) x[s] = (s * 64 + lane < NAUDIO) ? x[s] / temp : -INFINITY;   // gpt.py:487
+  if (dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+  SSTAMP(2);   // every load landed
   // repetition penalty
   if (penal) {
     // occurrences of this lane's 10 tokens among the <= 16 history tokens, 5 bits per slot in one 64-bit word: history token t
@@ -858,6 +864,7 @@ __global__ __launch_bounds__(256) void sample_k(SampleArgs a) {
 
   // softmax statistics over the whole row (needed by top-p)
   float mx = -INFINITY;
+  SSTAMP(3);   // penalty done
 #pragma unroll
   for (int s = 0; s < SLOTS; ++s) mx = fmaxf(mx, x[s]);
   const float lane_max = mx;
@@ -872,6 +879,7 @@ __global__ __launch_bounds__(256) void sample_k(SampleArgs a) {
 #pragma unroll
   for (int s = 0; s < SLOTS; ++s) { e[s] = e[s] * rz; sall += (double)e[s]; }  // e = softmax prob (f32)
   sall = wave_sum_d(sall);
+  SSTAMP(4);   // softmax statistics done
 
   // ---- the kept set.  Both warpers keep a PREFIX of the descending order (value desc, ties: lowest index first), so it is
   // described by its last element (v_last, i_last): kept = everything at or before it in that order.
@@ -883,61 +891,58 @@ __global__ __launch_bounds__(256) void sample_k(SampleArgs a) {
   bool done = !any_filter;
   // FAST PATH (top-k <= 64, the reference's default 20): the prefix can only end inside the top kk (+ ties with the kk-th value).
   // t = the kk-th largest LANE maximum bounds the kk-th largest value from below (kk elements are >= t), so the candidates
-  // {x >= t} contain the whole prefix; they are compacted to one per lane, ranked by counting (value desc, index asc -- the same
-  // total order as the serial extraction), and the warpers' decisions walk the ranks with the probability mass above accumulated
-  // in double in exactly the order the serial loop used.  Falls back to the serial loop when more than 64 candidates survive.
+  // {x >= t} contain the whole prefix; they are compacted to one per lane and ranked by counting (value desc, index asc -- the same
+  // total order as the serial extraction) together with the probability mass before them (double); then every candidate applies the
+  // warpers' tests to itself and the prefix ends before the first one removed.  Falls back to the serial loop when more than 64
+  // candidates survive.
   if (any_filter && a.use_top_k && kk <= 64) {
-    int rk = 0;
+    // t: the smallest lane maximum that has fewer than kk lane maxima strictly above it = the kk-th largest lane maximum
+    int gtc = 0;
 #pragma unroll
     for (int j = 0; j < 64; ++j) {
       const float o = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lane_max), j));
-      rk += ((o > lane_max) || (o == lane_max && j < lane)) ? 1 : 0;
+      gtc += (o > lane_max) ? 1 : 0;
     }
-    const unsigned long long pick = __ballot(rk == kk - 1);
-    if (pick != 0ull) {
-      const float t = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lane_max), (int)__ffsll((long long)pick) - 1));
-      int base = 0;
+    const float t = -wave_max_dpp(gtc < kk ? -lane_max : -INFINITY);
+    int base = 0;
 #pragma unroll
-      for (int s = 0; s < SLOTS; ++s) {
-        const bool c = x[s] >= t;   // padded slots hold -inf
-        const unsigned long long ms = __ballot(c);
-        const int pos = base + (int)__popcll(ms & ((1ull << lane) - 1ull));
-        if (c && pos < 64) { cand_v[k][pos] = x[s]; cand_e[k][pos] = e[s]; cand_i[k][pos] = s * 64 + lane; }
-        base += (int)__popcll(ms);
+    for (int s = 0; s < SLOTS; ++s) {
+      const bool c = x[s] >= t;   // padded slots hold -inf
+      const unsigned long long ms = __ballot(c);
+      const int pos = base + (int)__popcll(ms & ((1ull << lane) - 1ull));
+      if (c && pos < 64) { cand_v[k][pos] = x[s]; cand_e[k][pos] = e[s]; cand_i[k][pos] = s * 64 + lane; }
+      base += (int)__popcll(ms);
+    }
+    const int C = base;   // >= kk
+    if (C <= 64) {
+      __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's LDS writes have landed (same-wave read-after-write)
+      __builtin_amdgcn_wave_barrier();
+      const bool act = lane < C;
+      const float cv = act ? cand_v[k][lane] : -INFINITY, ce = act ? cand_e[k][lane] : 0.f;
+      const int ci = act ? cand_i[k][lane] : 0x7fffffff;
+      // rank of this lane's candidate in the order (value desc, index asc), and the probability mass of everything before it
+      int rank = 0;
+      double mass_above = 0.0;
+      for (int j = 0; j < C; ++j) {
+        const float o = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cv), j));
+        const int oi = __builtin_amdgcn_readlane(ci, j);
+        const float oe = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ce), j));
+        const bool before = (o > cv) || (o == cv && oi < ci);
+        rank += before ? 1 : 0;
+        mass_above += before ? (double)oe : 0.0;
       }
-      const int C = base;   // >= kk
-      if (C <= 64) {
-        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's LDS writes have landed (same-wave read-after-write)
-        __builtin_amdgcn_wave_barrier();
-        const bool act = lane < C;
-        const float cv = act ? cand_v[k][lane] : -INFINITY, ce = act ? cand_e[k][lane] : 0.f;
-        const int ci = act ? cand_i[k][lane] : 0x7fffffff;
-        int rank = 0;
-        for (int j = 0; j < C; ++j) {
-          const float o = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cv), j));
-          const int oi = __builtin_amdgcn_readlane(ci, j);
-          rank += ((o > cv) || (o == cv && oi < ci)) ? 1 : 0;
-        }
-        double mass_above = 0.0;
-        float kth_val = 0.f;
-        int n = 0;
-        while (n < C) {
-          const unsigned long long who = __ballot(act && rank == n);
-          const int src = (int)__ffsll((long long)who) - 1;
-          const float wv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cv), src));
-          if (a.use_top_p && n >= 3) {
-            const float cum = (float)(sall - mass_above);  // ascending cumulative prob up to and including it
-            if (cum <= thr) break;                         // everything below is removed by top-p as well
-          }
-          if (n >= kk && !(wv == kth_val)) break;          // below the k-th largest value; ties with it survive
-          mass_above += (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(ce), src));
-          v_last = wv; i_last = __builtin_amdgcn_readlane(ci, src);
-          if (n == kk - 1) kth_val = wv;
-          ++n;
-        }
-        n_kept = n;
-        done = true;
-      }
+      // every candidate judges itself; the kept prefix ends before the first (lowest-rank) candidate a warper removes
+      const unsigned long long whok = __ballot(act && rank == kk - 1);     // exists: C >= kk
+      const float kth_val = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cv), (int)__ffsll((long long)whok) - 1));
+      const bool ok_p = !(a.use_top_p && rank >= 3 && (float)(sall - mass_above) <= thr);   // ascending cumulative prob incl. itself <= 1 - top_p
+      const bool ok_k = rank < kk || cv == kth_val;                                          // ties with the k-th largest value survive
+      const int n = wave_min_dpp((act && !(ok_p && ok_k)) ? rank : C);
+      const unsigned long long wlast = __ballot(act && rank == n - 1);      // n >= 3 (min_tokens_to_keep)
+      const int src = (int)__ffsll((long long)wlast) - 1;
+      v_last = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cv), src));
+      i_last = __builtin_amdgcn_readlane(ci, src);
+      n_kept = n;
+      done = true;
     }
   }
   if (!done) {
@@ -977,6 +982,7 @@ __global__ __launch_bounds__(256) void sample_k(SampleArgs a) {
 
   // EOS handling (min_new_token and the bench harness's stop_at hook)
   bool mask_eos = gen < a.min_new;
+  SSTAMP(5);   // kept set known
   bool force_eos = false;
   if (sa >= 0) { mask_eos = mask_eos || (gen < sa); force_eos = gen >= sa; }
   // final softmax over the kept set and argmax(p / q)
@@ -1007,6 +1013,7 @@ __global__ __launch_bounds__(256) void sample_k(SampleArgs a) {
   float wv; int wi;
   wave_argmax(bv, bi, wv, wi);
   if (force_eos) wi = a.eos;
+  SSTAMP(6);   // token drawn
   if (a.sampled != nullptr && gen < a.teacher_stride && lane == 0) a.sampled[((size_t)b * a.teacher_stride + gen) * NVQ + k] = (int64_t)wi;
   if (forced_t) wi = (int)teach;
   if (lane == 0) {
@@ -1022,6 +1029,8 @@ __global__ __launch_bounds__(256) void sample_k(SampleArgs a) {
     if (!fin) a.end_idx[b] += 1;
     a.len[b] = len + 1;
   }
+  SSTAMP(7);
+#undef SSTAMP
 }
 
 hipError_t launch_sample(const SampleArgs& a, hipStream_t st) {

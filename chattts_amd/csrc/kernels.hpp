@@ -272,6 +272,7 @@ struct SampleArgs {
   int rng_per_step;         // device generator: 1 = a fresh draw every step (the reference's manual_seed=None), 0 = the same draw
                             // every step (manual_seed set: the reference re-seeds its generator at every step, gpt.py:504-507)
   const unsigned long long* rng_seed;   // device scalar
+  long long* dbg;           // probes only (tools/sample_phase_probe.py, env CTTS_SAMPLE_DBG_PTR): [rows][8] phase stamps (100 MHz), or null
 };
 hipError_t launch_exp_draws(unsigned long long seed, int step, int row0, int rows, int V, float* out, hipStream_t st);
 hipError_t launch_sample(const SampleArgs& a, hipStream_t st);

@@ -371,11 +371,14 @@ def test_pmc_summary_maps_the_profiled_kernel_names():
     spec = importlib.util.spec_from_file_location("pmc_summary", os.path.join(ROOT, "tools", "pmc_summary.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    with open(os.path.join(ROOT, "profiles", "r2z_kernel_stats.csv")) as f:
+    with open(os.path.join(ROOT, "profiles", "r3b_kernel_stats_bf16.csv")) as f:
         names = [r["Name"] for r in csv.DictReader(f)]
     tags = {mod.short(n) for n in names} - {None}
     assert {"attention", "qkv_gemm", "o_proj_gemm", "gate_up_gemm", "down_gemm", "heads_gemm", "sample"} <= tags
+    with open(os.path.join(ROOT, "profiles", "r3b_kernel_stats_f32.csv")) as f:      # the parity mode's own roofline entry
+        assert "attention_f32" in {mod.short(r["Name"]) for r in csv.DictReader(f)}
     import json
     with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
         traffic = json.load(f)
     assert traffic["attention"]["hbm_bytes_per_launch"] > 1e7 and traffic["attention"]["dispatches"] > 1000
+    assert traffic["attention_f32"]["hbm_bytes_per_launch"] > 2e7 and traffic["heads_gemm"]["dispatches"] > 100
