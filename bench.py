@@ -205,6 +205,7 @@ def main():
     ap.add_argument("--no-ttfs", action="store_true")
     ap.add_argument("--no-parity-mode", action="store_true")
     ap.add_argument("--no-bf16-parity", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true", help="one batch after the other (no overlap of batch i's acoustic decode with batch i+1's generation)")
     ap.add_argument("--parity-steps", type=int, default=5, help="timed passes of the f32 parity mode")
     ap.add_argument("--lanes", type=int, default=1, help="concurrent decode lanes (HIP streams) the batch is cut into")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) run the CPU baseline leg alone and print its JSON")
@@ -289,13 +290,37 @@ def main():
 
     rank_times = {}
 
+    def gpt_pass(eng):
+        out = None
+        for out in eng.generate(emb, ids_d, temp, 625, mask_d, max_new, 0, (*procs, *warpers), return_hidden=True,
+                                manual_seed=42, use_graph=not args.no_graph, stop_at=stop_t, row_offset=wl["row_offset"],
+                                total_rows=wl["total_rows"], lanes=args.lanes):
+            pass
+        return out
+
     def timed(eng, steps, warmup, tag=None):
+        """K passes.  Default: SOFTWARE-PIPELINED over the queue of batches -- the acoustic decode + waveform D2H of batch i run on the
+        codec engine's side stream while batch i+1 is generated (CodecEngine.decode_to_wavs_async; every batch's float32 waveforms
+        are on the host, as numpy, before the clock stops).  --no-pipeline: one batch after the other."""
         for _ in range(warmup):
             one_pass(eng, use_graph=not args.no_graph)
+        if not args.no_pipeline:     # the side stream's buffers exist before the clock starts
+            codec.decode_to_wavs_async(gpt_pass(eng).hiddens).result()
         barrier()
         t0 = time.perf_counter()
+        pend, lens, wav = None, None, None
         for _ in range(steps):
-            lens, wav, _ = one_pass(eng, use_graph=not args.no_graph)
+            if args.no_pipeline:
+                lens, wav, _ = one_pass(eng, use_graph=not args.no_graph)
+                continue
+            out = gpt_pass(eng)
+            lens = [int(t.shape[0]) for t in out.ids]
+            nxt = codec.decode_to_wavs_async(out.hiddens)
+            if pend is not None:
+                wav = pend.result()
+            pend = nxt
+        if pend is not None:
+            wav = pend.result()
         torch.cuda.synchronize(dev)
         dt_own = time.perf_counter() - t0      # this rank's own time for its K passes (before waiting for the others)
         barrier()
@@ -325,7 +350,10 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "C3: batch=64/GPU mixed-length (prompts 16-48 tok, outputs U{%d..%d} tok), top-p .7/top-k 20/rep 1.05/"
                                "temp .3, manual_seed 42, hipGraph decode + DVAE + Vocos + waveform D2H (.cpu().numpy()); prompt "
-                               "embedding gather outside the timed region" % (args.min_len, args.max_len),
+                               "embedding gather outside the timed region; %s" % (args.min_len, args.max_len,
+                               "one batch after the other" if args.no_pipeline else
+                               "the K batches are software-pipelined: DVAE + Vocos + D2H of batch i on a side HIP stream while batch i+1 is generated"),
+                   "pipelined": not args.no_pipeline,
                    "global_batch": Bg, "decode_steps_per_pass": gpt_steps, "parallelism": f"dp{world}", "lanes_per_gpu": args.lanes,
                    "tokens_per_pass": int(stop.sum()), "audio_s_per_pass": round(audio_seconds(stop), 2)},
     }

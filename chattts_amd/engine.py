@@ -631,9 +631,7 @@ class GptEngine:
                     fin_h.copy_(ln.finish.cpu())
                     end_h.copy_(ln.end_idx.cpu())
                 else:
-                    # a SHADER copy into the pinned block, not hipMemcpyAsync: a runtime-mediated D2H behind in-flight kernels
-                    # intermittently stalls 60-90 ms on this pool's hosts (profiles/r3h_stall_probe.log); a kernel is just the next
-                    # packet of the stream
+                    # a SHADER copy into the pinned block (one packet of the stream; no copy-engine hand-off behind the step's kernels)
                     _lib.check(lib.ctts_copy_bytes(blk.data_ptr(), ln.state_blk.data_ptr(), blk.numel(), ln.st.cuda_stream), "ctts_copy_bytes")
                 ev.record(ln.st)
             return k
@@ -828,6 +826,23 @@ def unpack_x3p(p: torch.Tensor, R: int, K: int) -> torch.Tensor:
 
 
 # ---------------------------------------------------------------------------------------------
+class PendingWavs:
+    """result of `CodecEngine.decode_to_wavs_async`: the float32 waveforms of one batch, in flight"""
+
+    def __init__(self, codec, view, done, keep):
+        self._codec, self._view, self._done, self._keep, self._out = codec, view, done, keep, None
+
+    def done(self) -> bool:
+        return self._out is not None or self._done.query()
+
+    def result(self) -> np.ndarray:
+        if self._out is None:
+            wait_event(self._done)
+            self._out = self._codec._copy_out(self._view) if self._view.numel() else np.zeros(tuple(self._view.shape), np.float32)
+            self._keep = None
+        return self._out
+
+
 class CodecEngine:
     """DVAE decoder + Vocos on the device (channels-last)."""
 
@@ -1014,8 +1029,8 @@ class CodecEngine:
         view = buf[:n].view(t.shape)
         nbytes = n * t.element_size()
         if nbytes % 16 == 0 and t.data_ptr() % 16 == 0 and os.environ.get("CTTS_D2H_SHADER", "1") != "0":
-            # shader copy (plain stores over PCIe into the pinned buffer) instead of hipMemcpyAsync: same rate (67 MB in 1.2 ms), and
-            # no runtime-mediated hand-off behind the decode kernels, which intermittently stalls 60-90 ms on this pool's hosts
+            # shader copy (plain stores over PCIe into the pinned buffer): the same rate as hipMemcpyAsync (67 MB in 1.2 ms,
+            # profiles/r3j_d2h_probe.log) and just the next packet of the stream -- no copy-engine hand-off behind the decode kernels
             _lib.check(self.lib.ctts_copy_bytes(view.data_ptr(), t.data_ptr(), nbytes, torch.cuda.current_stream(self.device).cuda_stream),
                        "ctts_copy_bytes")
         else:
@@ -1026,6 +1041,46 @@ class CodecEngine:
         # intermittently costs 60-90 ms of CFS throttling (profiles/r3l_hostcopy_probe.log: clone max 92 ms vs numpy 0.1 ms for one
         # streamed chunk) -- that was what turned the streaming config C5 from 266 into 600 ms per batch.  Large results are cut into
         # 4 slices copied by 4 plain threads (memcpy releases the GIL).
+        return self._copy_out(view)
+
+    # -- software pipelining across batches ------------------------------------------------------------------------------------
+    def decode_to_wavs_async(self, result_list: List[torch.Tensor]) -> "PendingWavs":
+        """`decode_to_wavs` + the `.cpu().numpy()` of core.py:508-510, ASYNCHRONOUSLY on the engine's own side stream: the call
+        returns at once (everything is enqueued), `PendingWavs.result()` hands out the numpy array.  A caller that works through a
+        queue of batches starts the NEXT batch's generation before asking for the result, so the acoustic decode (MFMA-bound, big
+        kernels) overlaps the next batch's decode steps (latency-bound, most SIMDs idle) on the same GPU -- the batch-level form of
+        what BASELINE config 4 does per streamed chunk.  The input tensors must not be modified until `result()` returned
+        (`GptEngine.generate` hands out copies, so its outputs qualify).  Results are bit-identical to the synchronous calls."""
+        dev = self.device
+        if not hasattr(self, "_side"):
+            self._side = torch.cuda.Stream(device=dev)
+            self._side_pins = [None, None]     # two staging buffers: a result may still be in its buffer when the next decode is enqueued
+            self._side_n = 0
+        caller = torch.cuda.current_stream(dev)
+        ready = torch.cuda.Event()
+        ready.record(caller)                   # the hidden states were produced on the caller's stream
+        k = self._side_n = (self._side_n + 1) % 2
+        with torch.cuda.stream(self._side):
+            self._side.wait_event(ready)
+            wav = self.decode_to_wavs(result_list)
+            n = wav.numel()
+            pin = self._side_pins[k]
+            if pin is None or pin.numel() < n:
+                pin = self._side_pins[k] = torch.empty(((n + 3) // 4 * 4,), dtype=torch.float32).pin_memory()
+            view = pin[:n].view(wav.shape)
+            if n and (n * 4) % 16 == 0:
+                _lib.check(self.lib.ctts_copy_bytes(view.data_ptr(), wav.data_ptr(), n * 4, self._side.cuda_stream), "ctts_copy_bytes")
+            elif n:
+                view.copy_(wav, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(self._side)
+            for r in result_list:
+                r.record_stream(self._side)
+            wav.record_stream(self._side)
+        return PendingWavs(self, view, done, wav)
+
+    def _copy_out(self, view: torch.Tensor) -> np.ndarray:
+        """pinned staging view -> fresh numpy array by plain memcpy (see to_host)"""
         src = view.numpy()
         out = np.empty(src.shape, dtype=src.dtype)
         flat_s, flat_o = src.reshape(-1), out.reshape(-1)

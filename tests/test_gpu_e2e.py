@@ -1004,3 +1004,27 @@ def test_fused_final_norm_heads_is_bit_identical(weights, golden, monkeypatch, d
         assert torch.equal(x, y)
     for x, y in zip(a[-1].hiddens, b[-1].hiddens):
         assert x.shape == y.shape and torch.equal(x, y)
+
+
+def test_pipelined_batches_equal_sequential(weights):
+    """`Chat.infer_ids_pipelined` (acoustic decode + D2H of batch i on the codec engine's side stream while batch i+1 is generated,
+    `CodecEngine.decode_to_wavs_async`) yields, per batch and in order, exactly what `Chat.infer_ids` returns for that batch --
+    different batch geometries back to back (the GPT session and the codec workspace are re-used / re-grown underneath)."""
+    from chattts_amd.core import Chat, InferCodeParams
+    chat = Chat()
+    assert chat.load(state_dicts=weights, device=DEV, dtype="f32")
+    p = InferCodeParams(max_new_token=40, manual_seed=3, show_tqdm=False)
+    batches = []
+    for i, (B, stop) in enumerate([(3, [9, 20, 14]), (5, [30, 7, 12, 25, 18]), (3, [11, 11, 5]), (1, [33])]):
+        ids, mask, tmask = synth.make_prompts(B, 6, 12, seed=20 + i)
+        batches.append((torch.from_numpy(ids), torch.from_numpy(mask), torch.from_numpy(tmask), {"stop_at": torch.tensor(stop, dtype=torch.int32)}))
+    seq = [chat.infer_ids(*b[:3], p, **b[3]) for b in batches]
+    pip = list(chat.infer_ids_pipelined(batches, p))
+    assert len(pip) == len(seq)
+    for a, b in zip(seq, pip):
+        assert a.shape == b.shape and a.dtype == b.dtype == np.float32 and np.array_equal(a, b)
+    # a pending result can be asked for late, and twice
+    out = list(chat.infer_code(*batches[0][:3], p, **batches[0][3]))[-1]
+    fut = chat.codec.decode_to_wavs_async(out.hiddens)
+    list(chat.infer_code(*batches[1][:3], p, **batches[1][3]))
+    assert np.array_equal(fut.result(), seq[0]) and fut.result() is fut.result() and fut.done()
