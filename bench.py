@@ -205,7 +205,8 @@ def main():
     ap.add_argument("--no-ttfs", action="store_true")
     ap.add_argument("--no-parity-mode", action="store_true")
     ap.add_argument("--no-bf16-parity", action="store_true")
-    ap.add_argument("--no-pipeline", action="store_true", help="one batch after the other (no overlap of batch i's acoustic decode with batch i+1's generation)")
+    ap.add_argument("--pipeline", action="store_true", help="time the main leg as a software-pipelined queue of batches (batch i's acoustic decode "
+                    "overlaps batch i+1's generation); default: one batch after the other, the pipelined figure is reported beside it")
     ap.add_argument("--parity-steps", type=int, default=5, help="timed passes of the f32 parity mode")
     ap.add_argument("--lanes", type=int, default=1, help="concurrent decode lanes (HIP streams) the batch is cut into")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) run the CPU baseline leg alone and print its JSON")
@@ -298,19 +299,20 @@ def main():
             pass
         return out
 
-    def timed(eng, steps, warmup, tag=None):
-        """K passes.  Default: SOFTWARE-PIPELINED over the queue of batches -- the acoustic decode + waveform D2H of batch i run on the
-        codec engine's side stream while batch i+1 is generated (CodecEngine.decode_to_wavs_async; every batch's float32 waveforms
-        are on the host, as numpy, before the clock stops).  --no-pipeline: one batch after the other."""
+    def timed(eng, steps, warmup, tag=None, pipeline=None):
+        """K passes, one batch after the other -- or (pipeline) SOFTWARE-PIPELINED over the queue of batches: the acoustic decode + waveform
+        D2H of batch i run on the codec engine's side stream while batch i+1 is generated (CodecEngine.decode_to_wavs_async; every
+        batch's float32 waveforms are on the host, as numpy, before the clock stops)."""
+        pipeline = args.pipeline if pipeline is None else pipeline
         for _ in range(warmup):
             one_pass(eng, use_graph=not args.no_graph)
-        if not args.no_pipeline:     # the side stream's buffers exist before the clock starts
+        if pipeline:     # the side stream's buffers exist before the clock starts
             codec.decode_to_wavs_async(gpt_pass(eng).hiddens).result()
         barrier()
         t0 = time.perf_counter()
         pend, lens, wav = None, None, None
         for _ in range(steps):
-            if args.no_pipeline:
+            if not pipeline:
                 lens, wav, _ = one_pass(eng, use_graph=not args.no_graph)
                 continue
             out = gpt_pass(eng)
@@ -351,12 +353,20 @@ def main():
         "config": {"workload": "C3: batch=64/GPU mixed-length (prompts 16-48 tok, outputs U{%d..%d} tok), top-p .7/top-k 20/rep 1.05/"
                                "temp .3, manual_seed 42, hipGraph decode + DVAE + Vocos + waveform D2H (.cpu().numpy()); prompt "
                                "embedding gather outside the timed region; %s" % (args.min_len, args.max_len,
-                               "one batch after the other" if args.no_pipeline else
-                               "the K batches are software-pipelined: DVAE + Vocos + D2H of batch i on a side HIP stream while batch i+1 is generated"),
-                   "pipelined": not args.no_pipeline,
+                               "the K batches are software-pipelined: DVAE + Vocos + D2H of batch i on a side HIP stream while batch i+1 is generated"
+                               if args.pipeline else "one batch after the other"),
+                   "pipelined": bool(args.pipeline),
                    "global_batch": Bg, "decode_steps_per_pass": gpt_steps, "parallelism": f"dp{world}", "lanes_per_gpu": args.lanes,
                    "tokens_per_pass": int(stop.sum()), "audio_s_per_pass": round(audio_seconds(stop), 2)},
     }
+    if world == 1 and not args.pipeline and not args.no_parity_mode:
+        # the same workload as a software-pipelined QUEUE of batches (Chat.infer_ids_pipelined / CodecEngine.decode_to_wavs_async):
+        # reported beside `value`, which stays one-batch-after-the-other
+        note("pipelined queue of batches")
+        dtp = timed(gpt, 4, 0, pipeline=True)
+        result["pipelined_queue"] = {"value": round(audio_seconds(stop) * 4 / dtp, 2), "unit": "audio-s/s", "steps": 4, "ms_per_step": round(1000.0 * dtp / 4, 3),
+                                     "what": "the acoustic decode + waveform D2H of batch i on the codec engine's side HIP stream while batch i+1 is "
+                                             "generated; all waveforms on the host before the clock stops"}
     if world > 1:   # self-diagnosing multi-GPU line: who was slow, what the one collective cost
         rt = rank_times.get("main", [])
         result["ranks"] = {"world": world, "pass_ms_per_rank": rt, "pass_ms_min": min(rt) if rt else None, "pass_ms_max": max(rt) if rt else None,
