@@ -38,6 +38,7 @@ struct ctts_gpt {
   bool dec_packed = false;     // perf mode (bf16 weights): decode.hip
   bool dec_packed32 = false;   // parity mode (f32 weights): decode32.hip
   bool heads_packed = false;   // heads GEMM on packed f32 operands (decode32.hip), both modes
+  int temporal_layers = 0;     // env CTTS_W_TEMPORAL_LAYERS: decode weights of layers [0, N) loaded WITHOUT the non-temporal hint (A/B)
   bool fnorm_fuse = true;      // decode: final norm + hidden capture + heads in one launch (env CTTS_FNORM_FUSE=0: separate launches)
   std::vector<const float*> ln1, ln2;
   hipGraph_t graph = nullptr;
@@ -129,6 +130,7 @@ extern "C" int ctts_gpt_create(ctts_gpt** out, const ctts_gpt_weights* w) {
   { const char* e = getenv("CTTS_DEC_PACKED"); g->heads_packed = w->heads_pk != nullptr && !(e && atoi(e) == 0); }
   { const char* e = getenv("CTTS_SKIP_FINISHED"); if (e && atoi(e) == 0) g->skip_finished = false; }
   { const char* e = getenv("CTTS_FNORM_FUSE"); if (e && atoi(e) == 0) g->fnorm_fuse = false; }
+  { const char* e = getenv("CTTS_W_TEMPORAL_LAYERS"); if (e) g->temporal_layers = atoi(e); }
   {
     int dev = 0, cus = 0;
     // OFF by default: measured on the C3 bench it does not pay (attention 9.3 -> 9.8 us per launch, 1296 -> 1280 audio-s/s,
@@ -250,6 +252,7 @@ static int run_step(ctts_gpt* g, const ctts_gen_state* s, int q_per_b, hipStream
     DecGemmArgs d;
     memset(&d, 0, sizeof(d));
     d.M = M; d.eps = g->w.rms_eps; d.n_active = nact;
+    d.force_nt = l < g->temporal_layers ? 1 : 0;   // A/B knob: the first N layers' weights with plain loads (candidates for the Infinity Cache)
     // RMSNorm scale + QKV + RoPE + KV append
     d.Ap = ws.xp; d.Wp = (const uint16_t*)g->wqkv_pk[l]; d.N = 3 * HID; d.K = HID; d.ssq_in = ws.ssq; d.epi = FEPI_QKV_ROPE;
     d.C32 = ws.qkv; d.ldc = 3 * HID; d.desc = ws.desc; d.cos_t = g->w.rope_cos; d.sin_t = g->w.rope_sin;

@@ -75,6 +75,48 @@ __global__ __launch_bounds__(512, 2) void gemm_x3p_k(X3pArgs a) {
   // VAR 3 (probe): wave 0 accumulates 100 MHz realtime deltas: DMA wait, barrier, DMA issue, fragment reads, MFMAs
   long long tacc[5] = {0, 0, 0, 0, 0}, tprev = 0;
 #define X3P_MARK(i) do { if (VAR == 3) { const long long tn = wall_clock64(); tacc[i] += tn - tprev; tprev = tn; } } while (0)
+  if (VAR == 4) {
+    // STAGES OF TWO k blocks (slots {0,1} / {2,3}), double-buffered: one barrier per 32-wide k step instead of one per 16 -- the phase
+    // probe put 0.47 of a k block's 1.3 us on the barrier (profiles/r2k_x3p_phase_probe.log).  The refill of a stage is issued
+    // right after the barrier that proves every wave has finished reading it (it was consumed in the previous iteration), so a
+    // stage is in flight for exactly one iteration (48 MFMAs per wave); same accumulation order as the ring variants, same bits.
+    const int np = kb16 >> 1;   // K % 32 == 0
+    issue(0); issue(1);
+    for (int p = 0; p < np; ++p) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (p + 1 < np) { issue(2 * p + 2); issue(2 * p + 3); }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int sl = (2 * p + h) & (NSLOT - 1);
+        const uint16_t* la = lds + sl * SLOT + lane * 8;
+        const uint16_t* lw = la + 16 * FRAG;
+        bf16x8 fah[2], fal[2], fwh[4], fwl[4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          fah[i] = *reinterpret_cast<const bf16x8*>(la + ((wm * 2 + i) * 2 + 0) * FRAG);
+          fal[i] = *reinterpret_cast<const bf16x8*>(la + ((wm * 2 + i) * 2 + 1) * FRAG);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          fwh[j] = *reinterpret_cast<const bf16x8*>(lw + ((wn * 4 + j) * 2 + 0) * FRAG);
+          fwl[j] = *reinterpret_cast<const bf16x8*>(lw + ((wn * 4 + j) * 2 + 1) * FRAG);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[i], fwh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fwl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fwh[j], acc[i][j], 0, 0, 0);
+      }
+    }
+  } else {
   issue(0);
   if (kb16 > 1) issue(1);
   if (kb16 > 2) issue(2);
@@ -133,6 +175,7 @@ __global__ __launch_bounds__(512, 2) void gemm_x3p_k(X3pArgs a) {
       asm volatile("s_nop 15\n\ts_nop 15" :: "v"(acc[1][3][0]));
       X3P_MARK(4);
     }
+  }
   }
   if (VAR == 3 && a.dbg != nullptr && tid == 0) {
     long long* d = a.dbg + (size_t)blockIdx.x * 8;
@@ -207,6 +250,7 @@ hipError_t launch_gemm_x3p(const X3pArgs& a, hipStream_t st) {
   if (var == 0) x3p_launch<0>(a, grid, st);
   else if (var == 2) x3p_launch<2>(a, grid, st);
   else if (var == 3) x3p_launch<3>(a, grid, st);
+  else if (var == 4) x3p_launch<4>(a, grid, st);
   else x3p_launch<1>(a, grid, st);
   return hipGetLastError();
 }

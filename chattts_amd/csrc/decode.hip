@@ -329,7 +329,7 @@ hipError_t launch_gemm_dec(const DecGemmArgs& a_in, hipStream_t st) {
     mb_qkv = env_int("CTTS_DEC_MB_QKV", 4); mb_silu = env_int("CTTS_DEC_MB_SILU", 4);
     mb_o = env_int("CTTS_DEC_MB_O", 1); mb_down = env_int("CTTS_DEC_MB_DOWN", 1);
   }
-  a.w_nt = nt;
+  a.w_nt = a.force_nt ? (a.force_nt == 2) : nt;
   a.a_early = a_early;
   if (a.M <= 0 || a.N <= 0 || (a.N & 15) || !(a.K == 768 || a.K == 3072)) return hipErrorInvalidValue;
   if (a.epi == FEPI_RES && a.N != 16 * SSQ_PARTS) return hipErrorInvalidValue;

@@ -145,6 +145,7 @@ struct DecGemmArgs {
   int force_mb;                 // tests only
   int w_nt;                     // set by the launcher
   int a_early;                  // set by the launcher (CTTS_DEC_A_EARLY): batches of <= 16 rows request their activation tile at entry
+  int force_nt;                 // 0: the launcher's policy (CTTS_W_NT); 1: plain (temporal) weight loads; 2: non-temporal (A/B: CTTS_W_TEMPORAL_LAYERS)
   long long* dbg;               // probes only (tools/dec_phase_probe.py): [n_workgroups][8] phase stamps, or null
 };
 hipError_t launch_gemm_dec(const DecGemmArgs& a, hipStream_t st);
