@@ -246,7 +246,8 @@ hipError_t launch_gemm_x3p(const X3pArgs& a, hipStream_t st) {
   const int tiles = (a.N / 256) * ((a.M + 255) / 256);
   dim3 grid(((tiles + 7) / 8) * 8);
   static int var = -1;   // CTTS_X3P_VAR: MFMA issue order / priority variant (A/B, tools/x3p_probe.py)
-  if (var < 0) { const char* e = getenv("CTTS_X3P_VAR"); var = e ? atoi(e) : 1; }
+  // default 4: two k blocks per barrier (-1.7 ... -2.6 % per GEMM against the 4-slot ring of variant 1, profiles/r3q_x3p_probe.log; bit-identical)
+  if (var < 0) { const char* e = getenv("CTTS_X3P_VAR"); var = e ? atoi(e) : 4; }
   if (var == 0) x3p_launch<0>(a, grid, st);
   else if (var == 2) x3p_launch<2>(a, grid, st);
   else if (var == 3) x3p_launch<3>(a, grid, st);
