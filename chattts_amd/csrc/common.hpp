@@ -153,3 +153,32 @@ __device__ __forceinline__ void wave_rows_rstd_768(const float* const (&rows)[NR
     rstd[q] = rms_finish(ss, 768, eps);
   }
 }
+
+// ---- cross-kernel weight prefetch ------------------------------------------------------------------------------------------
+// A decode step is a chain of short, latency-bound kernels; each projection starts with an HBM round trip for weights that nothing
+// upstream has touched (phase probe: +0.6 ... 1.5 us per launch with cold weights).  The NEXT kernel's weights are known when the
+// current one starts, so one extra wave per workgroup touches them -- one 4-byte load per 64-byte granule, data discarded -- which
+// pulls them into the L2 of the XCD this workgroup runs on.  Workgroup b runs on XCD b % 8 (observed placement, used for speed only)
+// and weight tile t of the next launch is consumed by a workgroup with linear id = t (mod 8), so a prefetching workgroup on XCD x takes
+// its share of the tiles t = x, x + 8, ...  The HBM traffic is the same bytes, moved one kernel earlier, while the pipe is idle.
+struct PfDesc {
+  const char* base;      // first tile, or null: nothing to prefetch
+  unsigned tile_bytes;   // contiguous bytes of one weight tile (a multiple of 64)
+  unsigned n_tiles;
+};
+__device__ __forceinline__ void prefetch_weight_tiles(const PfDesc& pf, int lane, unsigned wg, unsigned n_wg) {
+  if (pf.base == nullptr) return;
+  const unsigned x = wg & 7u, q = wg >> 3;
+  if (x >= pf.n_tiles || x >= n_wg) return;
+  const unsigned nq = (n_wg - x + 7u) >> 3;            // workgroups of this launch on XCD x
+  const unsigned nt = (pf.n_tiles - x + 7u) >> 3;      // tiles the next launch consumes on XCD x
+  const unsigned gpt = pf.tile_bytes >> 6;             // 64-byte granules per tile
+  const unsigned G = nt * gpt, per = (G + nq - 1u) / nq;
+  const unsigned beg = q * per, end = min(G, beg + per);
+  for (unsigned g = beg + (unsigned)lane; g < end; g += 64u) {
+    const unsigned ti = g / gpt;
+    const char* p = pf.base + (size_t)(x + 8u * ti) * pf.tile_bytes + ((size_t)(g - ti * gpt) << 6);
+    unsigned sink;
+    asm volatile("global_load_dword %0, %1, off" : "=v"(sink) : "v"(p) : "memory");
+  }
+}

@@ -244,8 +244,8 @@ template <> __device__ __forceinline__ void store_out<bf16_t>(bf16_t* p, float v
 // bench the launch gets 0.5 us SLOWER (9.3 -> 9.8 us) -- the pieces' hand-off latency is not hidden behind the whole units --
 // and the split geometry depends on the live-row count, which costs bf16 mode its batch invariance.  Kept behind
 // CTTS_ATT_SPLIT=1 (default off) as a recorded negative result.
-template <typename KT, int NW, typename OT, bool PKO = false, bool SPLIT = false>
-__global__ __launch_bounds__(64 * NW) void attention_k(const float* __restrict__ qkv, const KT* __restrict__ kc,
+template <typename KT, int NW, typename OT, bool PKO = false, bool SPLIT = false, bool PF = false>
+__global__ __launch_bounds__(64 * NW + (PF ? 64 : 0)) void attention_k(const float* __restrict__ qkv, const KT* __restrict__ kc,
                                                        const KT* __restrict__ vc, int cmax, OT* __restrict__ out, GptRowMap rm) {
   constexpr int DPL = KTraits<KT>::DPL;
   constexpr int LPK = HDIM / DPL;   // lanes per key: 8 (bf16) / 16 (f32)
@@ -256,6 +256,10 @@ __global__ __launch_bounds__(64 * NW) void attention_k(const float* __restrict__
   constexpr bool KV_NT = NW > 1;    // decode: every KV byte is read once per step by exactly one workgroup -> non-temporal
   __shared__ float sm_m[NW], sm_l[NW], sm_acc[NW][HDIM];
   if (NW > 1) CTTS_PROBE_RETURN();
+  if (PF && (threadIdx.x >> 6) == NW) {   // fifth wave: this layer's gate/up weights towards this XCD's L2 (common.hpp), then gone
+    prefetch_weight_tiles(rm.pf, threadIdx.x & 63, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    return;
+  }
 
   int h = blockIdx.x, m = blockIdx.y;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -637,6 +641,8 @@ hipError_t launch_attention(const float* qkv, const void* kcache, const void* vc
       // step with it, 0.478 without -- the 16-way LDS merge costs what the shorter stream saves -- and it would make a row's
       // perf-mode bits depend on the batch size.
       CTTS_LAUNCH((attention_k<bf16_t, 16, bf16_t, true>), grid, dim3(1024), st, qkv, (const bf16_t*)kcache, (const bf16_t*)vcache, cmax, (bf16_t*)out, rm);
+    else if (rm.pf.base != nullptr)
+      CTTS_LAUNCH_SMEM((attention_k<bf16_t, 4, bf16_t, true, false, true>), grid, dim3(320), att_lds, st, qkv, (const bf16_t*)kcache, (const bf16_t*)vcache, cmax, (bf16_t*)out, rm);
     else
       CTTS_LAUNCH_SMEM((attention_k<bf16_t, 4, bf16_t, true>), grid, dim3(256), att_lds, st, qkv, (const bf16_t*)kcache, (const bf16_t*)vcache, cmax, (bf16_t*)out, rm);
     return hipGetLastError();

@@ -6,6 +6,8 @@
 #include <hip/hip_ext.h>
 #include <stdint.h>
 
+#include "common.hpp"
+
 // Per-kernel timing for bench.py's roofline leg: when capi.hip arms these two events, the NEXT launch goes
 // through hipExtLaunchKernelGGL, which stamps them with the dispatch's own start/stop timestamps (the same
 // clock rocprofv3's kernel trace reads) -- no marker packets, so the figure agrees with the rocprof summary.
@@ -146,6 +148,7 @@ struct DecGemmArgs {
   int w_nt;                     // set by the launcher
   int a_early;                  // set by the launcher (CTTS_DEC_A_EARLY): batches of <= 16 rows request their activation tile at entry
   int force_nt;                 // 0: the launcher's policy (CTTS_W_NT); 1: plain (temporal) weight loads; 2: non-temporal (A/B: CTTS_W_TEMPORAL_LAYERS)
+  PfDesc pf[2];                 // weights of later launches of the step this launch's auxiliary wave pulls towards L2 (QKV_ROPE, SILU), or {null}
   long long* dbg;               // probes only (tools/dec_phase_probe.py): [n_workgroups][8] phase stamps, or null
 };
 hipError_t launch_gemm_dec(const DecGemmArgs& a, hipStream_t st);
@@ -211,6 +214,7 @@ struct GptRowMap {
   int slot0;                // prefill: first prompt slot of the chunk this launch covers
   int desc_covers_all;      // decode: desc[] is valid for EVERY row of the grid (absent rows carry b = -1), so the attention
                             // kernel need not read *n_active first (one dependent load less in front of the KV stream)
+  PfDesc pf;                // decode, perf mode: the gate/up weights of this layer, pulled towards L2 by a fifth wave per workgroup
 };
 #define ATT_SPLIT_MAX 8
 
