@@ -175,10 +175,14 @@ __device__ __forceinline__ void prefetch_weight_tiles(const PfDesc& pf, int lane
   const unsigned gpt = pf.tile_bytes >> 6;             // 64-byte granules per tile
   const unsigned G = nt * gpt, per = (G + nq - 1u) / nq;
   const unsigned beg = q * per, end = min(G, beg + per);
+  // The loads return asynchronously: their destination register must stay reserved until they have landed, or late data would
+  // overwrite whatever the compiler put there next (it believes an asm's output is written when the asm ends).  One sink register,
+  // read-write in every asm so that it is live across the loop, and a final wait that consumes it.
+  unsigned sink = 0;
   for (unsigned g = beg + (unsigned)lane; g < end; g += 64u) {
     const unsigned ti = g / gpt;
     const char* p = pf.base + (size_t)(x + 8u * ti) * pf.tile_bytes + ((size_t)(g - ti * gpt) << 6);
-    unsigned sink;
-    asm volatile("global_load_dword %0, %1, off" : "=v"(sink) : "v"(p) : "memory");
+    asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(p) : "memory");
   }
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink) : : "memory");
 }
