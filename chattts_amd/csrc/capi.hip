@@ -38,7 +38,7 @@ struct ctts_gpt {
   bool dec_packed = false;     // perf mode (bf16 weights): decode.hip
   bool dec_packed32 = false;   // parity mode (f32 weights): decode32.hip
   bool heads_packed = false;   // heads GEMM on packed f32 operands (decode32.hip), both modes
-  int pf_mask = 15;            // env CTTS_PF: cross-kernel weight prefetch, bit mask (1 QKV->o, 2 attention->gate/up, 4 gate/up->down, 8 gate/up->next QKV / heads)
+  int pf_mask = 0;             // env CTTS_PF: cross-kernel weight prefetch, bit mask (1 QKV->o_proj, 16 QKV->gate/up, 2 attention->gate/up)
   int temporal_layers = 0;     // env CTTS_W_TEMPORAL_LAYERS: decode weights of layers [0, N) loaded WITHOUT the non-temporal hint (A/B)
   bool fnorm_fuse = true;      // decode: final norm + hidden capture + heads in one launch (env CTTS_FNORM_FUSE=0: separate launches)
   std::vector<const float*> ln1, ln2;
@@ -263,7 +263,7 @@ static int run_step(ctts_gpt* g, const ctts_gen_state* s, int q_per_b, hipStream
     const PfDesc pf_d{(const char*)g->wd_pk[l], 16u * INTER * 2u, HID / 16u};
     const PfDesc pf_next = l + 1 < g->w.n_layers ? PfDesc{(const char*)g->wqkv_pk[l + 1], 16u * HID * 2u, 3u * HID / 16u}
                            : (fuse_fnorm && !s->infer_text) ? PfDesc{(const char*)g->w.heads_pk, 16u * HID * 4u, (NVQ * NAUDIO + 15u) / 16u} : pf_none;
-    d.pf[0] = (g->pf_mask & 1) ? pf_o : pf_none; d.pf[1] = pf_none;
+    d.pf[0] = (g->pf_mask & 1) ? pf_o : pf_none; d.pf[1] = (g->pf_mask & 16) ? pf_gu : pf_none;
     rm.pf = (g->pf_mask & 2) ? pf_gu : pf_none;
     // RMSNorm scale + QKV + RoPE + KV append
     d.Ap = ws.xp; d.Wp = (const uint16_t*)g->wqkv_pk[l]; d.N = 3 * HID; d.K = HID; d.ssq_in = ws.ssq; d.epi = FEPI_QKV_ROPE;
@@ -276,7 +276,7 @@ static int run_step(ctts_gpt* g, const ctts_gen_state* s, int q_per_b, hipStream
     { Prof p(g, 4, st, prof_ok); CK(launch_gemm_dec(d, st)); }
     d.Ap = ws.xp; d.Wp = (const uint16_t*)g->wgu_pk[l]; d.N = INTER; d.ssq_in = ws.ssq; d.epi = FEPI_SILU; d.C32 = nullptr;
     d.Cp = ws.actp; d.kch_out = INTER / 32; d.ssq_out = nullptr;
-    d.pf[0] = (g->pf_mask & 4) ? pf_d : pf_none; d.pf[1] = (g->pf_mask & 8) ? pf_next : pf_none;
+    d.pf[0] = pf_none; d.pf[1] = pf_none; (void)pf_d; (void)pf_next;   // (gate/up has no auxiliary wave: see decode.hip)
     { Prof p(g, 5, st, prof_ok); CK(launch_gemm_dec(d, st)); }
     d.Ap = ws.actp; d.Wp = (const uint16_t*)g->wd_pk[l]; d.N = HID; d.K = INTER; d.ssq_in = nullptr; d.epi = FEPI_RES; d.C32 = ws.x;
     d.ldc = HID; d.Cp = ws.xp; d.kch_out = HID / 32; d.ssq_out = ws.ssq;

@@ -213,7 +213,7 @@ __device__ __forceinline__ void dec_body(const DecGemmArgs& a, const int M, cons
 }
 
 template <int MBT, int NW, bool SCALE, int EPI>
-__global__ __launch_bounds__(64 * (NW + ((EPI == FEPI_QKV_ROPE || EPI == FEPI_SILU) ? 1 : 0)))
+__global__ __launch_bounds__(64 * (NW + (EPI == FEPI_QKV_ROPE ? 1 : 0)))
 void gemm_dec_k(DecGemmArgs a) {
   constexpr int NACC = (EPI == FEPI_SILU) ? 2 : 1;
   __shared__ __attribute__((aligned(16))) float red[NW][NACC][MBT][64][4];
@@ -222,12 +222,12 @@ void gemm_dec_k(DecGemmArgs a) {
   __shared__ int meta_s[(EPI == FEPI_QKV_ROPE) ? 16 * MBT : 1][2];    // per row: utterance b (-1: finished), KV slot
 
   CTTS_PROBE_RETURN();
-  // auxiliary wave (index NW; QKV: the RoPE helper, gate/up: prefetch only): weights of later launches of the step towards this XCD's L2
-  if ((EPI == FEPI_QKV_ROPE || EPI == FEPI_SILU) && (threadIdx.x >> 6) == NW) {
+  // QKV: the RoPE helper wave (index NW) first pulls weights of later launches of the step towards this XCD's L2 (common.hpp).  An
+  // extra wave for this in the gate/up kernel cost that kernel +0.6 us by itself (profiles/r3s_ab_prefetch.log): not there.
+  if (EPI == FEPI_QKV_ROPE && (threadIdx.x >> 6) == NW) {
     const unsigned wg = blockIdx.y * gridDim.x + blockIdx.x, n_wg = gridDim.x * gridDim.y;
     prefetch_weight_tiles(a.pf[0], threadIdx.x & 63, wg, n_wg);
     prefetch_weight_tiles(a.pf[1], threadIdx.x & 63, wg, n_wg);
-    if (EPI == FEPI_SILU) return;
   }
   const int tile = blockIdx.x, mt0 = blockIdx.y * MBT;
   if (a.dbg && threadIdx.x == 0) a.dbg[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8] = wall_clock64();
@@ -313,7 +313,7 @@ static hipError_t dec_dispatch_k768(const DecGemmArgs& a, hipStream_t st) {
   dim3 grid(a.N / 16, (mt + MBT - 1) / MBT);
   const bool scale = a.ssq_in != nullptr;
   if (a.epi == FEPI_QKV_ROPE && scale) CTTS_LAUNCH((gemm_dec_k<MBT, NW, true, FEPI_QKV_ROPE>), grid, dim3(64 * NW + 64), st, a);
-  else if (a.epi == FEPI_SILU && scale) CTTS_LAUNCH((gemm_dec_k<MBT, NW, true, FEPI_SILU>), grid, dim3(64 * NW + 64), st, a);
+  else if (a.epi == FEPI_SILU && scale) CTTS_LAUNCH((gemm_dec_k<MBT, NW, true, FEPI_SILU>), grid, dim3(64 * NW), st, a);
   else if (a.epi == FEPI_RES && !scale) CTTS_LAUNCH((gemm_dec_k<MBT, NW, false, FEPI_RES>), grid, dim3(64 * NW), st, a);
   else return hipErrorInvalidValue;
   return hipGetLastError();
