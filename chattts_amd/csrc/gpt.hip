@@ -620,8 +620,9 @@ hipError_t launch_attention(const float* qkv, const void* kcache, const void* vc
   // CTTS_ATT_LDS=<bytes>: dynamic LDS the decode attention workgroups declare (and never touch).  It bounds the workgroups a CU
   // holds at once (160 KiB / bytes), which turns the dispatcher into a greedy list scheduler: with the rows ordered by descending
   // context (ctts_gen_state.order) the longest units start first and the short ones fill the CUs that free up.  0 = no bound.
-  static int att_lds = -1, att_small_m = 0;
+  static int att_lds = -1, att_small_m = 0, nw_packed = 4;
   if (att_lds < 0) {
+    { const char* e3 = getenv("CTTS_ATT_NW_PACKED"); if (e3) nw_packed = atoi(e3); }   // waves per (utterance, head) unit of the perf-mode decode attention: 4 | 8 | 16
     { const char* e2 = getenv("CTTS_ATT_SMALL_M"); if (e2) att_small_m = atoi(e2); }   // batches up to this many rows: 16-wave units (0 = never)
     const char* e = getenv("CTTS_ATT_LDS");
     att_lds = e ? atoi(e) : 0;
@@ -643,6 +644,10 @@ hipError_t launch_attention(const float* qkv, const void* kcache, const void* vc
       CTTS_LAUNCH((attention_k<bf16_t, 16, bf16_t, true>), grid, dim3(1024), st, qkv, (const bf16_t*)kcache, (const bf16_t*)vcache, cmax, (bf16_t*)out, rm);
     else if (rm.pf.base != nullptr)
       CTTS_LAUNCH_SMEM((attention_k<bf16_t, 4, bf16_t, true, false, true>), grid, dim3(320), att_lds, st, qkv, (const bf16_t*)kcache, (const bf16_t*)vcache, cmax, (bf16_t*)out, rm);
+    else if (nw_packed == 8)
+      CTTS_LAUNCH_SMEM((attention_k<bf16_t, 8, bf16_t, true>), grid, dim3(512), att_lds, st, qkv, (const bf16_t*)kcache, (const bf16_t*)vcache, cmax, (bf16_t*)out, rm);
+    else if (nw_packed == 16)
+      CTTS_LAUNCH_SMEM((attention_k<bf16_t, 16, bf16_t, true>), grid, dim3(1024), att_lds, st, qkv, (const bf16_t*)kcache, (const bf16_t*)vcache, cmax, (bf16_t*)out, rm);
     else
       CTTS_LAUNCH_SMEM((attention_k<bf16_t, 4, bf16_t, true>), grid, dim3(256), att_lds, st, qkv, (const bf16_t*)kcache, (const bf16_t*)vcache, cmax, (bf16_t*)out, rm);
     return hipGetLastError();
