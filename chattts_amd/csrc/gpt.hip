@@ -644,6 +644,8 @@ hipError_t launch_attention(const float* qkv, const void* kcache, const void* vc
       CTTS_LAUNCH((attention_k<bf16_t, 16, bf16_t, true>), grid, dim3(1024), st, qkv, (const bf16_t*)kcache, (const bf16_t*)vcache, cmax, (bf16_t*)out, rm);
     else if (rm.pf.base != nullptr)
       CTTS_LAUNCH_SMEM((attention_k<bf16_t, 4, bf16_t, true, false, true>), grid, dim3(320), att_lds, st, qkv, (const bf16_t*)kcache, (const bf16_t*)vcache, cmax, (bf16_t*)out, rm);
+    else if (nw_packed == 2)
+      CTTS_LAUNCH_SMEM((attention_k<bf16_t, 2, bf16_t, true>), grid, dim3(128), att_lds, st, qkv, (const bf16_t*)kcache, (const bf16_t*)vcache, cmax, (bf16_t*)out, rm);
     else if (nw_packed == 8)
       CTTS_LAUNCH_SMEM((attention_k<bf16_t, 8, bf16_t, true>), grid, dim3(512), att_lds, st, qkv, (const bf16_t*)kcache, (const bf16_t*)vcache, cmax, (bf16_t*)out, rm);
     else if (nw_packed == 16)
