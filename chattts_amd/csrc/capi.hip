@@ -243,6 +243,7 @@ static int run_step(ctts_gpt* g, const ctts_gen_state* s, int q_per_b, hipStream
   if (dec) rm.desc = ws.desc;                          // written by the embedding kernel at the head of the step
   if (dec && dev_compact(g, s)) rm.desc_covers_all = 1; // ... for every row of the grid (absent rows: b = -1)
   if (packed && g->n_cu > 0) { rm.sp_part = ws.att_part; rm.sp_cnt = ws.att_cnt; rm.sp_cus = g->n_cu; }
+  if (packed) { const char* e = getenv("CTTS_ATT_DBG_PTR"); if (e) rm.dbg = (long long*)strtoull(e, nullptr, 0); }   // probes only
   // decode on packed operands: final RMSNorm + hidden capture + heads are ONE launch (decode32.hip gemm_dec32_fnorm16_k; the residual
   // stream reaches it in the packed f32 order: parity mode keeps it that way anyway, perf mode has the last down_proj write it)
   const bool packed32_ = !fast && dec && g->dec_packed32;

@@ -264,6 +264,9 @@ __global__ __launch_bounds__(64 * NW + (PF ? 64 : 0)) void attention_k(const flo
   int h = blockIdx.x, m = blockIdx.y;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int kg = lane / LPK, dl = lane % LPK;
+  long long* dbg = (PKO && rm.dbg) ? rm.dbg + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 : nullptr;
+#define ASTAMP(i) do { if (dbg && tid == 0) dbg[i] = wall_clock64(); } while (0)
+  ASTAMP(0);
   int n_piece = 1, piece = 0, su = 0;   // SPLIT: pieces of this unit, this workgroup's piece, index among the split units
   if (SPLIT) {
     const int nact = rm.n_active ? *rm.n_active : (int)(gridDim.x - rm.sp_cus) / NHEAD;
@@ -296,6 +299,8 @@ __global__ __launch_bounds__(64 * NW + (PF ? 64 : 0)) void attention_k(const flo
     if (jlo > slot) jlo = slot;  // pad query row: sees only itself (its output is never consumed)
   }
 
+  ASTAMP(1);   // row descriptor known
+  if (dbg && tid == 0) { dbg[6] = slot + 1 - jlo; }   // visible keys of this unit
   float q[DPL];
   {
     const float* qp = qkv + (size_t)m * (3 * HID) + h * HDIM + dl * DPL;
@@ -375,10 +380,13 @@ __global__ __launch_bounds__(64 * NW + (PF ? 64 : 0)) void attention_k(const flo
 
   int j = jbeg;
   load_blk(kA, vA, j);
+  ASTAMP(2);   // q read, first block requested
+  bool first_blk = true;
   while (j < jend) {
     load_blk(kB, vB, j + KB);   // prefetch (clamped, so harmless past the end)
     __builtin_amdgcn_sched_barrier(0);  // keep the 8 prefetch loads ahead of the consumer (hipcc sinks them otherwise)
     use_blk(kA, vA, j);
+    if (dbg && first_blk) { asm volatile("" :: "v"(lrun)); ASTAMP(3); first_blk = false; }   // first block consumed (= landed)
     j += KB;
     if (!(j < jend)) break;
     load_blk(kA, vA, j + KB);
@@ -387,6 +395,7 @@ __global__ __launch_bounds__(64 * NW + (PF ? 64 : 0)) void attention_k(const flo
     j += KB;
   }
 
+  if (dbg) { asm volatile("" :: "v"(lrun)); ASTAMP(4); }   // this wave's keys done
   // merge the key groups of this wave (same running max in every lane)
 #pragma unroll
   for (int o = LPK; o < 64; o <<= 1) {
@@ -458,6 +467,8 @@ __global__ __launch_bounds__(64 * NW + (PF ? 64 : 0)) void attention_k(const flo
     }
     store_out<OT>(PKO ? out + pko_off<OT>(m, h * HDIM + tid) : out + (size_t)m * HID + h * HDIM + tid, o / L);
   }
+  ASTAMP(5);
+#undef ASTAMP
 }
 
 // ------------------------------------------------------------------------------------------------

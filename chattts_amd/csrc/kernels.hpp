@@ -215,6 +215,7 @@ struct GptRowMap {
   int desc_covers_all;      // decode: desc[] is valid for EVERY row of the grid (absent rows carry b = -1), so the attention
                             // kernel need not read *n_active first (one dependent load less in front of the KV stream)
   PfDesc pf;                // decode, perf mode: the gate/up weights of this layer, pulled towards L2 by a fifth wave per workgroup
+  long long* dbg;           // probes only (tools/attn_phase_probe.py, env CTTS_ATT_DBG_PTR): [workgroups][8] phase stamps (100 MHz), or null
 };
 #define ATT_SPLIT_MAX 8
 
