@@ -301,12 +301,12 @@ __global__ __launch_bounds__(64 * NW + (PF ? 64 : 0)) void attention_k(const flo
 
   ASTAMP(1);   // row descriptor known
   if (dbg && tid == 0) { dbg[6] = slot + 1 - jlo; }   // visible keys of this unit
+  // q is REQUESTED after the first KV block (below) and stays unscaled: the 1/sqrt(64) = 2^-3 is applied to the finished dot product,
+  // which is the same number bit for bit (a power-of-two scale commutes with every rounding of the fmaf chain and of the shuffle
+  // adds).  Reading q first put one L2 miss (0.7 us median, and several us for a workgroup whose load queued behind a co-resident
+  // workgroup's 64 KB of KV requests) in front of the whole KV stream (profiles/r3x_attn_phase_probe.log).
   float q[DPL];
-  {
-    const float* qp = qkv + (size_t)m * (3 * HID) + h * HDIM + dl * DPL;
-#pragma unroll
-    for (int i = 0; i < DPL; ++i) q[i] = qp[i] * 0.125f;  // 1/sqrt(64), exact power of two
-  }
+  const float* qp = qkv + (size_t)m * (3 * HID) + h * HDIM + dl * DPL;
   const KT* kbase = kc + ((size_t)b * NHEAD + h) * cmax * HDIM + dl * DPL;
   const KT* vbase = vc + ((size_t)b * NHEAD + h) * cmax * HDIM + dl * DPL;
 
@@ -355,6 +355,7 @@ __global__ __launch_bounds__(64 * NW + (PF ? 64 : 0)) void attention_k(const flo
       for (int e = 0; e < DPL; ++e) d = fmaf(q[e], kf[e], d);
 #pragma unroll
       for (int o = 1; o < LPK; o <<= 1) d += __shfl_xor(d, o, 64);
+      d *= 0.125f;   // 1/sqrt(64), exact
       s[i] = ok[i] ? d : -INFINITY;
       bmax = fmaxf(bmax, s[i]);
     }
@@ -380,7 +381,15 @@ __global__ __launch_bounds__(64 * NW + (PF ? 64 : 0)) void attention_k(const flo
 
   int j = jbeg;
   load_blk(kA, vA, j);
-  ASTAMP(2);   // q read, first block requested
+  {   // q: 16-byte vector loads, issued behind the first block's requests
+    constexpr int NV = DPL / 4;
+    float4 qv[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) qv[i] = reinterpret_cast<const float4*>(qp)[i];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { q[4 * i] = qv[i].x; q[4 * i + 1] = qv[i].y; q[4 * i + 2] = qv[i].z; q[4 * i + 3] = qv[i].w; }
+  }
+  ASTAMP(2);   // first block and q requested
   bool first_blk = true;
   while (j < jend) {
     load_blk(kB, vB, j + KB);   // prefetch (clamped, so harmless past the end)
