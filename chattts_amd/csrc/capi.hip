@@ -40,6 +40,7 @@ struct ctts_gpt {
   bool heads_packed = false;   // heads GEMM on packed f32 operands (decode32.hip), both modes
   int pf_mask = 0;             // env CTTS_PF: cross-kernel weight prefetch, bit mask (1 QKV->o_proj, 16 QKV->gate/up, 2 attention->gate/up)
   int temporal_layers = 0;     // env CTTS_W_TEMPORAL_LAYERS: decode weights of layers [0, N) loaded WITHOUT the non-temporal hint (A/B)
+  bool pre32_packed = true;    // parity mode: prompt pass on the packed f32 kernels (env CTTS_PRE32_PACKED=0: row-major gemm_skinny_k)
   bool fnorm_fuse = true;      // decode: final norm + hidden capture + heads in one launch (env CTTS_FNORM_FUSE=0: separate launches)
   std::vector<const float*> ln1, ln2;
   hipGraph_t graph = nullptr;
@@ -93,11 +94,13 @@ static GptWs carve(void* base, int B, int T) {
   w.xp = (uint16_t*)(p + off); off += align_up(Bp * HID * 2);
   w.aop = (uint16_t*)(p + off); off += align_up(Bp * HID * 2);
   w.actp = (uint16_t*)(p + off); off += align_up(Bp * INTER * 2);
-  w.xp32 = (float*)(p + off); off += align_up(Bp * HID * 4);
-  w.aop32 = (float*)(p + off); off += align_up(Bp * HID * 4);
-  w.actp32 = (float*)(p + off); off += align_up(Bp * INTER * 4);
+  // the packed f32 buffers and the row descriptors also serve the parity mode's PREFILL (M = B * T rows in 16-row tiles)
+  const size_t Mp = (M + 15) / 16 * 16;
+  w.xp32 = (float*)(p + off); off += align_up(Mp * HID * 4);
+  w.aop32 = (float*)(p + off); off += align_up(Mp * HID * 4);
+  w.actp32 = (float*)(p + off); off += align_up(Mp * INTER * 4);
   w.hfinp = (float*)(p + off); off += align_up(Bp * HID * 4);
-  w.desc = (RowDesc*)(p + off); off += align_up(Bp * sizeof(RowDesc));
+  w.desc = (RowDesc*)(p + off); off += align_up(Mp * sizeof(RowDesc));
   w.row_map = (int32_t*)(p + off); off += align_up(Bp * sizeof(int32_t));
   w.att_part = (float*)(p + off); off += align_up((size_t)ATT_CUS_MAX * ATT_SPLIT_MAX * 66 * sizeof(float));
   w.att_cnt = (int32_t*)(p + off); off += align_up((size_t)ATT_CUS_MAX * sizeof(int32_t));
@@ -133,6 +136,7 @@ extern "C" int ctts_gpt_create(ctts_gpt** out, const ctts_gpt_weights* w) {
   { const char* e = getenv("CTTS_FNORM_FUSE"); if (e && atoi(e) == 0) g->fnorm_fuse = false; }
   { const char* e = getenv("CTTS_W_TEMPORAL_LAYERS"); if (e) g->temporal_layers = atoi(e); }
   { const char* e = getenv("CTTS_PF"); if (e) g->pf_mask = atoi(e); }
+  { const char* e = getenv("CTTS_PRE32_PACKED"); if (e && atoi(e) == 0) g->pre32_packed = false; }
   {
     int dev = 0, cus = 0;
     // OFF by default: measured on the C3 bench it does not pay (attention 9.3 -> 9.8 us per launch, 1296 -> 1280 audio-s/s,
@@ -336,7 +340,36 @@ static int run_step(ctts_gpt* g, const ctts_gen_state* s, int q_per_b, hipStream
     d.C = ws.x; d.ldc = HID; d.res = ws.x; d.ldr = HID; d.Cp = ws.xp32; d.kch_out = HID / 16;
     { Prof p(g, 6, st, prof_ok); CK(launch_gemm_dec32(d, st)); }
   }
-  for (int l = 0; !fast && !packed32 && l < g->w.n_layers; ++l) {
+  // parity mode PREFILL on the same packed kernels (round 3): the prompt rows are packed once, every projection reads fragment-order
+  // operands in 64-row workgroups (the generic body of decode32.hip: same k chunks per wave, same ((w0+w1)+w2)+w3, RMS statistics
+  // from the row-major rows like gemm_skinny_k), RoPE + KV append run in the QKV epilogue from per-row descriptors, attention
+  // writes its output packed.  Bit-identical to the row-major prefill (CTTS_PRE32_PACKED=0), which the goldens were made with.
+  const bool pre32 = !fast && !dec && g->dec_packed32 && g->pre32_packed;
+  if (pre32) {
+    CK(launch_prefill_prep32(ws.x, ws.xp32, ws.desc, q_per_b, slot0, s->kv_start, s->row_map, M, st));
+  }
+  for (int l = 0; pre32 && l < g->w.n_layers; ++l) {
+    void* kc = (char*)s->kcache + kv_layer * l;
+    void* vc = (char*)s->vcache + kv_layer * l;
+    Dec32Args d;
+    memset(&d, 0, sizeof(d));
+    d.M = M; d.eps = g->w.rms_eps; d.n_active = nullptr; d.force_mb = 4;
+    d.Ap = ws.xp32; d.Wp = (const float*)g->wqkv_pk[l]; d.N = 3 * HID; d.K = HID; d.X = ws.x; d.ldx = HID; d.norm_w = g->ln1[l];
+    d.epi = D32_EPI_QKV_ROPE; d.C = ws.qkv; d.ldc = 3 * HID; d.desc = ws.desc; d.cos_t = g->w.rope_cos; d.sin_t = g->w.rope_sin;
+    d.kc = (float*)kc; d.vc = (float*)vc; d.cmax = cmax;
+    CK(launch_gemm_dec32(d, st));
+    CK(launch_attention(ws.qkv, kc, vc, kt, cmax, ws.aop32, 3, rm, M, st));
+    d.Ap = ws.aop32; d.Wp = (const float*)g->wo_pk[l]; d.N = HID; d.X = nullptr; d.norm_w = nullptr; d.epi = EPI_RES; d.C = ws.x; d.ldc = HID;
+    d.res = ws.x; d.ldr = HID; d.Cp = ws.xp32; d.kch_out = HID / 16;
+    CK(launch_gemm_dec32(d, st));
+    d.Ap = ws.xp32; d.Wp = (const float*)g->wgu_pk[l]; d.N = INTER; d.X = ws.x; d.norm_w = g->ln2[l]; d.epi = EPI_SILU_MUL; d.C = nullptr;
+    d.res = nullptr; d.Cp = ws.actp32; d.kch_out = INTER / 16;
+    CK(launch_gemm_dec32(d, st));
+    d.Ap = ws.actp32; d.Wp = (const float*)g->wd_pk[l]; d.N = HID; d.K = INTER; d.X = nullptr; d.norm_w = nullptr; d.epi = EPI_RES;
+    d.C = ws.x; d.ldc = HID; d.res = ws.x; d.ldr = HID; d.Cp = ws.xp32; d.kch_out = HID / 16;
+    CK(launch_gemm_dec32(d, st));
+  }
+  for (int l = 0; !fast && !packed32 && !pre32 && l < g->w.n_layers; ++l) {
     void* kc = (char*)s->kcache + kv_layer * l;
     void* vc = (char*)s->vcache + kv_layer * l;
     GemmArgs a;

@@ -140,6 +140,25 @@ __global__ __launch_bounds__(192) void rows_prep_k(const float* __restrict__ x, 
   emit_row(s, t, nullptr, xb + (size_t)m * HID, ssq + (size_t)m * SSQ_PARTS);
 }
 
+__global__ __launch_bounds__(192) void prefill_prep32_k(const float* __restrict__ x, float* __restrict__ xp32, RowDesc* __restrict__ desc,
+                                                        int q_per_b, int slot0, const int32_t* __restrict__ kv_start,
+                                                        const int32_t* __restrict__ row_map) {
+  const int m = blockIdx.x, t = threadIdx.x;
+  const float4 v = *reinterpret_cast<const float4*>(x + (size_t)m * HID + t * 4);
+  *reinterpret_cast<float4*>(xp32 + pk32_off(m, 4 * t, HID / 16)) = v;   // columns 4t..4t+3 are one lane's 16 bytes of the packed order
+  if (t == 0) {
+    const int bq = m / q_per_b, slot = slot0 + m - bq * q_per_b;
+    const int b = row_map ? row_map[bq] : bq;
+    const int ks = kv_start[b];
+    desc[m] = RowDesc{b, slot, slot - ks < 0 ? 1 : slot - ks, ks > slot ? slot : ks};   // as write_desc / rope_append_k (pad slots: position 1)
+  }
+}
+hipError_t launch_prefill_prep32(const float* x, float* xp32, RowDesc* desc, int q_per_b, int slot0, const int32_t* kv_start,
+                                 const int32_t* row_map, int M, hipStream_t st) {
+  CTTS_LAUNCH(prefill_prep32_k, dim3(M), dim3(192), st, x, xp32, desc, q_per_b, slot0, kv_start, row_map);
+  return hipGetLastError();
+}
+
 hipError_t launch_rows_prep(const float* x32, uint16_t* xb, float* ssq, int M, hipStream_t st) {
   CTTS_LAUNCH(rows_prep_k, dim3(M), dim3(192), st, x32, xb, ssq);
   return hipGetLastError();
@@ -672,6 +691,11 @@ hipError_t launch_attention(const float* qkv, const void* kcache, const void* vc
       CTTS_LAUNCH_SMEM((attention_k<bf16_t, 16, bf16_t, true>), grid, dim3(1024), att_lds, st, qkv, (const bf16_t*)kcache, (const bf16_t*)vcache, cmax, (bf16_t*)out, rm);
     else
       CTTS_LAUNCH_SMEM((attention_k<bf16_t, 4, bf16_t, true>), grid, dim3(256), att_lds, st, qkv, (const bf16_t*)kcache, (const bf16_t*)vcache, cmax, (bf16_t*)out, rm);
+    return hipGetLastError();
+  }
+  if (out_bf16 == 3 && !decode) {   // prefill, f32 parity mode: one wave per (row, head), output in the packed f32 order
+    if (kv_wt == WT_BF16) return hipErrorInvalidValue;
+    CTTS_LAUNCH((attention_k<float, 1, float, true>), grid, dim3(64), st, qkv, (const float*)kcache, (const float*)vcache, cmax, (float*)out, rm);
     return hipGetLastError();
   }
   if (out_bf16 == 3) {   // decode, f32 parity mode: f32 output in the fragment-packed order o_proj of decode32.hip reads

@@ -237,6 +237,10 @@ struct StepPrep {
 hipError_t launch_embed_codes(const float* emb_code /*[4,626,768]*/, const int64_t* ids_buf, int ids_row_stride /*Tcap*/,
                               const int32_t* len, float* x, uint16_t* xb /*null ok*/, float* ssq /*null ok*/, int B,
                               const int32_t* row_map, const int32_t* n_active, hipStream_t st, const StepPrep* prep = nullptr);
+// parity mode prefill on packed operands: x [M,768] row-major -> the packed f32 order (pk32_off), and desc[m] of every prompt row
+// (utterance = row_map ? row_map[m / q_per_b] : m / q_per_b, KV slot = slot0 + m % q_per_b, RoPE position, first visible key)
+hipError_t launch_prefill_prep32(const float* x, float* xp32, RowDesc* desc, int q_per_b, int slot0, const int32_t* kv_start,
+                                 const int32_t* row_map, int M, hipStream_t st);
 hipError_t launch_rope_append(float* qkv /*[M,2304]*/, void* kcache, void* vcache, int kv_wt, int cmax,
                               const float* cos_tab, const float* sin_tab /*[max_pos,32]*/, GptRowMap rm, int M, hipStream_t st);
 hipError_t launch_attention(const float* qkv, const void* kcache, const void* vcache, int kv_wt, int cmax,

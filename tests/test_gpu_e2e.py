@@ -1028,3 +1028,29 @@ def test_pipelined_batches_equal_sequential(weights):
     fut = chat.codec.decode_to_wavs_async(out.hiddens)
     list(chat.infer_code(*batches[1][:3], p, **batches[1][3]))
     assert np.array_equal(fut.result(), seq[0]) and fut.result() is fut.result() and fut.done()
+
+
+def test_packed_f32_prefill_is_bit_identical_to_row_major(weights, golden, monkeypatch):
+    """parity mode: the prompt pass on fragment-packed f32 operands (decode32.hip's 64-row workgroups, RoPE + KV append in the QKV
+    epilogue from per-row descriptors, packed attention output) against the row-major kernels the goldens were established with
+    (CTTS_PRE32_PACKED=0): token ids AND hidden states torch.equal -- left-padded batch, whole prompt and prefill in chunks."""
+    c = cases.GEN_CASES["b8"]
+    new = E.GptEngine(weights["gpt"], weights["embed"], DEV, dtype="f32")
+    monkeypatch.setenv("CTTS_PRE32_PACKED", "0")
+    old = E.GptEngine(weights["gpt"], weights["embed"], DEV, dtype="f32")
+    monkeypatch.delenv("CTTS_PRE32_PACKED")
+    ids, mask, tmask = cases.gen_inputs(c)
+    ids_t, mask_t, tm_t = torch.from_numpy(ids), torch.from_numpy(mask), torch.from_numpy(tmask)
+    warpers, procs = E.gen_logits(625, c["top_P"], c["top_K"], c["rep"])
+
+    def run(eng, chunk):
+        emb = eng.embed_prompt(ids_t, tm_t)
+        return list(eng.generate(emb, ids_t, torch.tensor(c["temperature"]), 625, mask_t, 24, c["min_new"], (*procs, *warpers),
+                                 return_hidden=True, manual_seed=c["manual_seed"], prefill_chunk=chunk))[-1]
+
+    for chunk in (None, 5):
+        a, b = run(new, chunk), run(old, chunk)
+        for x, y in zip(a.ids, b.ids):
+            assert torch.equal(x, y)
+        for x, y in zip(a.hiddens, b.hiddens):
+            assert x.shape == y.shape and torch.equal(x, y)
