@@ -8,7 +8,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libchattts_amd.so")
-SOURCES = ["gemm.hip", "decode.hip", "decode32.hip", "prefill.hip", "gpt.hip", "codec.hip", "codec_gemm.hip", "dvae.hip", "capi.hip"]
+SOURCES = ["gemm.hip", "decode.hip", "decode32.hip", "prefill.hip", "prefill32.hip", "gpt.hip", "codec.hip", "codec_gemm.hip", "dvae.hip", "capi.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result"]
 
 

@@ -71,6 +71,7 @@ struct GptWs {
   uint16_t *xp, *aop, *actp;
   float *xp32, *aop32, *actp32;   // the same in float32 (parity mode, decode32.hip)
   float* hfinp;                   // final-norm rows in the packed f32 order (A operand of the packed heads GEMM, both modes)
+  float* rstd;                    // parity mode prefill: 1 / rms of every prompt row (prefill32.hip)
   RowDesc* desc;
   float* att_part;    // attention remainder splitting: partials of the split units' pieces, and their arrival counters
   int32_t* att_cnt;
@@ -101,6 +102,7 @@ static GptWs carve(void* base, int B, int T) {
   w.actp32 = (float*)(p + off); off += align_up(Mp * INTER * 4);
   w.hfinp = (float*)(p + off); off += align_up(Bp * HID * 4);
   w.desc = (RowDesc*)(p + off); off += align_up(Mp * sizeof(RowDesc));
+  w.rstd = (float*)(p + off); off += align_up(Mp * sizeof(float));
   w.row_map = (int32_t*)(p + off); off += align_up(Bp * sizeof(int32_t));
   w.att_part = (float*)(p + off); off += align_up((size_t)ATT_CUS_MAX * ATT_SPLIT_MAX * 66 * sizeof(float));
   w.att_cnt = (int32_t*)(p + off); off += align_up((size_t)ATT_CUS_MAX * sizeof(int32_t));
@@ -340,10 +342,11 @@ static int run_step(ctts_gpt* g, const ctts_gen_state* s, int q_per_b, hipStream
     d.C = ws.x; d.ldc = HID; d.res = ws.x; d.ldr = HID; d.Cp = ws.xp32; d.kch_out = HID / 16;
     { Prof p(g, 6, st, prof_ok); CK(launch_gemm_dec32(d, st)); }
   }
-  // parity mode PREFILL on the same packed kernels (round 3): the prompt rows are packed once, every projection reads fragment-order
-  // operands in 64-row workgroups (the generic body of decode32.hip: same k chunks per wave, same ((w0+w1)+w2)+w3, RMS statistics
-  // from the row-major rows like gemm_skinny_k), RoPE + KV append run in the QKV epilogue from per-row descriptors, attention
-  // writes its output packed.  Bit-identical to the row-major prefill (CTTS_PRE32_PACKED=0), which the goldens were made with.
+  // parity mode PREFILL on packed operands (round 3, prefill32.hip): the prompt rows are packed once, every projection is a
+  // register-blocked launch over fragment-order operands (one wave = 32 x 32 outputs x the 4 k-chunk classes; same chunk order per
+  // class, same ((s0+s1)+s2)+s3, 1/rms per row from wave_row_rstd like gemm_skinny_k), RoPE + KV append run in the QKV epilogue from
+  // per-row descriptors, attention writes its output packed.  Bit-identical to the row-major prefill (CTTS_PRE32_PACKED=0), which
+  // the goldens were made with.  (The decode kernels' generic 64-row body was tried first: no faster than row-major at this M.)
   const bool pre32 = !fast && !dec && g->dec_packed32 && g->pre32_packed;
   if (pre32) {
     CK(launch_prefill_prep32(ws.x, ws.xp32, ws.desc, q_per_b, slot0, s->kv_start, s->row_map, M, st));
@@ -353,21 +356,23 @@ static int run_step(ctts_gpt* g, const ctts_gen_state* s, int q_per_b, hipStream
     void* vc = (char*)s->vcache + kv_layer * l;
     Dec32Args d;
     memset(&d, 0, sizeof(d));
-    d.M = M; d.eps = g->w.rms_eps; d.n_active = nullptr; d.force_mb = 4;
-    d.Ap = ws.xp32; d.Wp = (const float*)g->wqkv_pk[l]; d.N = 3 * HID; d.K = HID; d.X = ws.x; d.ldx = HID; d.norm_w = g->ln1[l];
+    d.M = M; d.eps = g->w.rms_eps; d.n_active = nullptr;
+    CK(launch_rows_rstd32(ws.x, HID, M, g->w.rms_eps, ws.rstd, st));
+    d.Ap = ws.xp32; d.Wp = (const float*)g->wqkv_pk[l]; d.N = 3 * HID; d.K = HID; d.norm_w = g->ln1[l];
     d.epi = D32_EPI_QKV_ROPE; d.C = ws.qkv; d.ldc = 3 * HID; d.desc = ws.desc; d.cos_t = g->w.rope_cos; d.sin_t = g->w.rope_sin;
     d.kc = (float*)kc; d.vc = (float*)vc; d.cmax = cmax;
-    CK(launch_gemm_dec32(d, st));
+    CK(launch_gemm_pre32(d, ws.rstd, st));
     CK(launch_attention(ws.qkv, kc, vc, kt, cmax, ws.aop32, 3, rm, M, st));
-    d.Ap = ws.aop32; d.Wp = (const float*)g->wo_pk[l]; d.N = HID; d.X = nullptr; d.norm_w = nullptr; d.epi = EPI_RES; d.C = ws.x; d.ldc = HID;
+    d.Ap = ws.aop32; d.Wp = (const float*)g->wo_pk[l]; d.N = HID; d.norm_w = nullptr; d.epi = EPI_RES; d.C = ws.x; d.ldc = HID;
     d.res = ws.x; d.ldr = HID; d.Cp = ws.xp32; d.kch_out = HID / 16;
-    CK(launch_gemm_dec32(d, st));
-    d.Ap = ws.xp32; d.Wp = (const float*)g->wgu_pk[l]; d.N = INTER; d.X = ws.x; d.norm_w = g->ln2[l]; d.epi = EPI_SILU_MUL; d.C = nullptr;
+    CK(launch_gemm_pre32(d, nullptr, st));
+    CK(launch_rows_rstd32(ws.x, HID, M, g->w.rms_eps, ws.rstd, st));
+    d.Ap = ws.xp32; d.Wp = (const float*)g->wgu_pk[l]; d.N = INTER; d.norm_w = g->ln2[l]; d.epi = EPI_SILU_MUL; d.C = nullptr;
     d.res = nullptr; d.Cp = ws.actp32; d.kch_out = INTER / 16;
-    CK(launch_gemm_dec32(d, st));
-    d.Ap = ws.actp32; d.Wp = (const float*)g->wd_pk[l]; d.N = HID; d.K = INTER; d.X = nullptr; d.norm_w = nullptr; d.epi = EPI_RES;
+    CK(launch_gemm_pre32(d, ws.rstd, st));
+    d.Ap = ws.actp32; d.Wp = (const float*)g->wd_pk[l]; d.N = HID; d.K = INTER; d.norm_w = nullptr; d.epi = EPI_RES;
     d.C = ws.x; d.ldc = HID; d.res = ws.x; d.ldr = HID; d.Cp = ws.xp32; d.kch_out = HID / 16;
-    CK(launch_gemm_dec32(d, st));
+    CK(launch_gemm_pre32(d, nullptr, st));
   }
   for (int l = 0; !fast && !packed32 && !pre32 && l < g->w.n_layers; ++l) {
     void* kc = (char*)s->kcache + kv_layer * l;

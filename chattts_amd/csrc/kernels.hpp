@@ -187,6 +187,10 @@ struct Dec32Args {
 };
 enum { D32_EPI_QKV_ROPE = 100 };
 hipError_t launch_gemm_dec32(const Dec32Args& a, hipStream_t st);
+// prefill32.hip: the same arithmetic for prompt-sized M, register-blocked (one wave = 32 x 32 outputs x the 4 k-chunk classes), no LDS.
+// rstd [M]: 1 / rms per row (launch_rows_rstd32) when a.norm_w is set.  epi: D32_EPI_QKV_ROPE | EPI_RES | EPI_SILU_MUL.
+hipError_t launch_rows_rstd32(const float* X, int ldx, int M, float eps, float* rstd, hipStream_t st);
+hipError_t launch_gemm_pre32(const Dec32Args& a, const float* rstd, hipStream_t st);
 const char* dec32_last_variant();   // "rms16" | "m16" | "generic": the kernel the calling thread's last launch picked (tests)
 
 // ---- GPT step kernels -------------------------------------------------------------------------
