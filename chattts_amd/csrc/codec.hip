@@ -72,30 +72,18 @@ __global__ __launch_bounds__(256) void dwconv_ln_k(const float* __restrict__ x, 
     const float4 b0 = *reinterpret_cast<const float4*>(b + c0 + 4 * q);
     acc[4 * q] = b0.x; acc[4 * q + 1] = b0.y; acc[4 * q + 2] = b0.z; acc[4 * q + 3] = b0.w;
   }
-  // All 7 taps' rows are requested UNCONDITIONALLY with the frame index clamped into the utterance, and a tap outside it is
-  // dropped by a select afterwards: a load under `if (fs in range)` makes hipcc branch around every tap and wait for it before the
-  // next one is requested -- seven dependent memory round trips per frame (134 us per launch at 65,536 frames = 2 TB/s, round 2).
-  // Same fmaf chain per channel for the taps that exist, same bits.
-  float4 xv[7][CPL / 4];
-  bool ok[7];
 #pragma unroll
   for (int j = 0; j < 7; ++j) {
     const int fs = f + (j - 3) * dil;
-    ok[j] = fs >= 0 && fs < F;
-    const float* xp = x + ((size_t)bi * F + min(max(fs, 0), F - 1)) * C + c0;
+    if (fs >= 0 && fs < F) {
+      const float* xp = x + ((size_t)bi * F + fs) * C + c0;
 #pragma unroll
-    for (int q = 0; q < CPL / 4; ++q) xv[j][q] = *reinterpret_cast<const float4*>(xp + 4 * q);
-  }
-#pragma unroll
-  for (int j = 0; j < 7; ++j) {
-#pragma unroll
-    for (int q = 0; q < CPL / 4; ++q) {
-      const float4 x0 = xv[j][q];
-      const float4 w0 = *reinterpret_cast<const float4*>(w + j * C + c0 + 4 * q);
-      const float a0 = fmaf(w0.x, x0.x, acc[4 * q]), a1 = fmaf(w0.y, x0.y, acc[4 * q + 1]);
-      const float a2 = fmaf(w0.z, x0.z, acc[4 * q + 2]), a3 = fmaf(w0.w, x0.w, acc[4 * q + 3]);
-      acc[4 * q] = ok[j] ? a0 : acc[4 * q]; acc[4 * q + 1] = ok[j] ? a1 : acc[4 * q + 1];
-      acc[4 * q + 2] = ok[j] ? a2 : acc[4 * q + 2]; acc[4 * q + 3] = ok[j] ? a3 : acc[4 * q + 3];
+      for (int q = 0; q < CPL / 4; ++q) {
+        const float4 x0 = *reinterpret_cast<const float4*>(xp + 4 * q);
+        const float4 w0 = *reinterpret_cast<const float4*>(w + j * C + c0 + 4 * q);
+        acc[4 * q] = fmaf(w0.x, x0.x, acc[4 * q]); acc[4 * q + 1] = fmaf(w0.y, x0.y, acc[4 * q + 1]);
+        acc[4 * q + 2] = fmaf(w0.z, x0.z, acc[4 * q + 2]); acc[4 * q + 3] = fmaf(w0.w, x0.w, acc[4 * q + 3]);
+      }
     }
   }
   ln_finish<CPL>(acc, lw, lb, eps, c0, y + (size_t)row * C, yp, row);
