@@ -217,8 +217,9 @@ def main():
         print("CPU_BASELINE_JSON " + json.dumps(cpu_baseline(W.synthetic_all(), wl["ids"], wl["mask"], wl["tmask"], wl["stop_all"])), flush=True)
         return
 
-    torch.set_num_threads(max(1, min(torch.get_num_threads(), host_cpu_quota())))   # no host-side pool wider than the CPU quota
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # no host-side pool wider than this rank's share of the CPU quota (the quota is the container's, shared by all ranks)
+    torch.set_num_threads(max(1, min(torch.get_num_threads(), host_cpu_quota() // max(1, world))))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
