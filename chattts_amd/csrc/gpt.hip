@@ -263,7 +263,12 @@ template <> __device__ __forceinline__ void store_out<bf16_t>(bf16_t* p, float v
 // bench the launch gets 0.5 us SLOWER (9.3 -> 9.8 us) -- the pieces' hand-off latency is not hidden behind the whole units --
 // and the split geometry depends on the live-row count, which costs bf16 mode its batch invariance.  Kept behind
 // CTTS_ATT_SPLIT=1 (default off) as a recorded negative result.
-template <typename KT, int NW, typename OT, bool PKO = false, bool SPLIT = false, bool PF = false>
+//
+// NBUF (round 3): KV blocks in flight per wave.  2 = the block being consumed + the next one; 3 = one more.  A wave's share of a
+// 500-key context is 4 blocks, and with fewer units than CUs (the last quarter of a C3 batch, every step of C2) nothing else on
+// the CU covers the round trip between them (profiles/r3y_attn_phase_probe.log: 240 units at 430 keys spend 3.0 us behind the
+// first block).  The order in which blocks are consumed is untouched, so the result is the same bit for bit in both modes.
+template <typename KT, int NW, typename OT, bool PKO = false, bool SPLIT = false, bool PF = false, int NBUF = 2>
 __global__ __launch_bounds__(64 * NW + (PF ? 64 : 0)) void attention_k(const float* __restrict__ qkv, const KT* __restrict__ kc,
                                                        const KT* __restrict__ vc, int cmax, OT* __restrict__ out, GptRowMap rm) {
   constexpr int DPL = KTraits<KT>::DPL;
@@ -347,7 +352,7 @@ __global__ __launch_bounds__(64 * NW + (PF ? 64 : 0)) void attention_k(const flo
   const int jbeg = rbeg + wave * per;
   const int jend = min(jbeg + per, rend);  // exclusive
 
-  u128 kA[NI], vA[NI], kB[NI], vB[NI];
+  u128 kA[NI], vA[NI], kB[NI], vB[NI], kC[NBUF > 2 ? NI : 1], vC[NBUF > 2 ? NI : 1];
   // Loads are UNCONDITIONAL with the key index clamped into the wave's range: a per-lane `if (j < jend) load`
   // makes hipcc branch around every load and wait vmcnt(0) in between (one memory round trip per load).
   // Clamped lanes re-read the last key (an L1 hit) and are masked where they are consumed.
@@ -410,6 +415,26 @@ __global__ __launch_bounds__(64 * NW + (PF ? 64 : 0)) void attention_k(const flo
   }
   ASTAMP(2);   // first block and q requested
   bool first_blk = true;
+  if (NBUF > 2) {   // ring of three: blocks j + KB and j + 2 KB are on their way while block j is consumed
+    load_blk(kB, vB, j + KB);
+    while (j < jend) {
+      load_blk(kC, vC, j + 2 * KB);
+      __builtin_amdgcn_sched_barrier(0);
+      use_blk(kA, vA, j);
+      if (dbg && first_blk) { asm volatile("" :: "v"(lrun)); ASTAMP(3); first_blk = false; }
+      j += KB;
+      if (!(j < jend)) break;
+      load_blk(kA, vA, j + 2 * KB);
+      __builtin_amdgcn_sched_barrier(0);
+      use_blk(kB, vB, j);
+      j += KB;
+      if (!(j < jend)) break;
+      load_blk(kB, vB, j + 2 * KB);
+      __builtin_amdgcn_sched_barrier(0);
+      use_blk(kC, vC, j);
+      j += KB;
+    }
+  } else
   while (j < jend) {
     load_blk(kB, vB, j + KB);   // prefetch (clamped, so harmless past the end)
     __builtin_amdgcn_sched_barrier(0);  // keep the 8 prefetch loads ahead of the consumer (hipcc sinks them otherwise)
@@ -659,8 +684,9 @@ hipError_t launch_attention(const float* qkv, const void* kcache, const void* vc
   // CTTS_ATT_LDS=<bytes>: dynamic LDS the decode attention workgroups declare (and never touch).  It bounds the workgroups a CU
   // holds at once (160 KiB / bytes), which turns the dispatcher into a greedy list scheduler: with the rows ordered by descending
   // context (ctts_gen_state.order) the longest units start first and the short ones fill the CUs that free up.  0 = no bound.
-  static int att_lds = -1, att_small_m = 0, nw_packed = 4;
+  static int att_lds = -1, att_small_m = 0, nw_packed = 4, att_nbuf = 2;
   if (att_lds < 0) {
+    { const char* e4 = getenv("CTTS_ATT_NBUF"); if (e4) att_nbuf = atoi(e4); }          // KV blocks in flight per wave of the packed decode attention: 2 | 3
     { const char* e3 = getenv("CTTS_ATT_NW_PACKED"); if (e3) nw_packed = atoi(e3); }   // waves per (utterance, head) unit of the perf-mode decode attention: 4 | 8 | 16
     { const char* e2 = getenv("CTTS_ATT_SMALL_M"); if (e2) att_small_m = atoi(e2); }   // batches up to this many rows: 16-wave units (0 = never)
     const char* e = getenv("CTTS_ATT_LDS");
@@ -689,6 +715,8 @@ hipError_t launch_attention(const float* qkv, const void* kcache, const void* vc
       CTTS_LAUNCH_SMEM((attention_k<bf16_t, 8, bf16_t, true>), grid, dim3(512), att_lds, st, qkv, (const bf16_t*)kcache, (const bf16_t*)vcache, cmax, (bf16_t*)out, rm);
     else if (nw_packed == 16)
       CTTS_LAUNCH_SMEM((attention_k<bf16_t, 16, bf16_t, true>), grid, dim3(1024), att_lds, st, qkv, (const bf16_t*)kcache, (const bf16_t*)vcache, cmax, (bf16_t*)out, rm);
+    else if (att_nbuf == 3)
+      CTTS_LAUNCH_SMEM((attention_k<bf16_t, 4, bf16_t, true, false, false, 3>), grid, dim3(256), att_lds, st, qkv, (const bf16_t*)kcache, (const bf16_t*)vcache, cmax, (bf16_t*)out, rm);
     else
       CTTS_LAUNCH_SMEM((attention_k<bf16_t, 4, bf16_t, true>), grid, dim3(256), att_lds, st, qkv, (const bf16_t*)kcache, (const bf16_t*)vcache, cmax, (bf16_t*)out, rm);
     return hipGetLastError();
@@ -700,7 +728,10 @@ hipError_t launch_attention(const float* qkv, const void* kcache, const void* vc
   }
   if (out_bf16 == 3) {   // decode, f32 parity mode: f32 output in the fragment-packed order o_proj of decode32.hip reads
     if (!decode || kv_wt == WT_BF16) return hipErrorInvalidValue;
-    CTTS_LAUNCH_SMEM((attention_k<float, 4, float, true>), grid, dim3(256), att_lds, st, qkv, (const float*)kcache, (const float*)vcache, cmax, (float*)out, rm);
+    if (att_nbuf == 3)
+      CTTS_LAUNCH_SMEM((attention_k<float, 4, float, true, false, false, 3>), grid, dim3(256), att_lds, st, qkv, (const float*)kcache, (const float*)vcache, cmax, (float*)out, rm);
+    else
+      CTTS_LAUNCH_SMEM((attention_k<float, 4, float, true>), grid, dim3(256), att_lds, st, qkv, (const float*)kcache, (const float*)vcache, cmax, (float*)out, rm);
     return hipGetLastError();
   }
   if (decode && nw8 && kv_wt == WT_BF16 && out_bf16) {

@@ -417,7 +417,30 @@ for l in sys.stdin:
   cd "$R"
 }
 
+r3ac() {   # would a KV prefetch one layer ahead pay?  (tools/mall_probe.hip)
+  T=r3ac
+  hipcc --offload-arch=gfx950 -O3 tools/mall_probe.hip -o /tmp/mall_probe && timeout 120 /tmp/mall_probe > gpurun_out/${T}_mall_probe.log 2>&1
+  cat gpurun_out/${T}_mall_probe.log
+}
+
+r3ad() {   # three KV blocks in flight per wave (CTTS_ATT_NBUF=3) vs two: parity first, then C3 and C2
+  T=r3ad
+  CTTS_ATT_NBUF=3 timeout 400 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -k "attention or bit_exact or bench_workload or invariance" > gpurun_out/${T}_tests_nbuf3.log 2>&1; tail -2 gpurun_out/${T}_tests_nbuf3.log
+  Q="--steps 4 --warmup 1 --no-cpu-baseline --no-ttfs --no-bf16-parity --parity-steps 2"
+  ab() { L=$1; shift; echo "== $L" >> gpurun_out/${T}_ab.log
+    env "$@" timeout 200 python bench.py $Q 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], 'parity', d['parity_mode']['value'], d['parity_mode']['ids_match_reference'], d['parity_mode']['roofline']['avg_launch_us'], {k: v['avg_launch_us'] for k, v in d['decode_kernels'].items()})" >> gpurun_out/${T}_ab.log 2>&1; }
+  for rep in 1 2; do
+  ab "2 blocks in flight" CTTS_ATT_NBUF=2
+  ab "3 blocks in flight" CTTS_ATT_NBUF=3
+  done
+  for E in CTTS_ATT_NBUF=2 CTTS_ATT_NBUF=3 CTTS_ATT_NBUF=2 CTTS_ATT_NBUF=3; do
+    echo "== C2 with $E" >> gpurun_out/${T}_ab.log
+    env $E timeout 120 python tools/c2_run.py 3 2>/dev/null | tail -1 >> gpurun_out/${T}_ab.log
+  done
+  cut -c1-420 gpurun_out/${T}_ab.log
+}
+
 case "$1" in
-  r3a|r3b|r3c|r3d|r3e|r3f|r3g|r3h|r3i|r3j|r3k|r3l|r3m|r3n|r3o|r3p|r3q|r3r|r3s|r3t|r3u|r3v|r3w|r3x|r3y|r3z|r3ab) "$1" ;;
+  r3a|r3b|r3c|r3d|r3e|r3f|r3g|r3h|r3i|r3j|r3k|r3l|r3m|r3n|r3o|r3p|r3q|r3r|r3s|r3t|r3u|r3v|r3w|r3x|r3y|r3z|r3ab|r3ac|r3ad|r3ae|r3af) "$1" ;;
   *) echo "usage: round3.sh <" 'r3a r3b r3c r3d r3e r3f r3g r3h r3i r3j r3k r3l r3m r3n r3o r3p r3q r3r r3s r3t r3u r3v r3w r3x r3y r3z' ">"; exit 2 ;;
 esac
