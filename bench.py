@@ -176,6 +176,16 @@ def mfma_rooflines(dev) -> dict:
         "note": "split-bf16: every f32 product is 3 bf16 MFMAs (hi*hi + hi*lo + lo*hi); `frac` prices the ALGORITHMIC 2MNK flops against "
                 "the dense bf16 peak, `mfma_work_frac` the bf16 MFMA work actually issued"}
     del Ap, Wp, Cp
+    from chattts_amd.engine import pack_h1p
+    Ah, Wh = pack_h1p(A).to(dev), pack_h1p(Wt).to(dev)
+    Ch = torch.empty(M * N, dtype=torch.float16, device=dev)
+    t = timed(lambda: _lib.check(lib.ctts_k_gemm_h1p(Ah.data_ptr(), Wh.data_ptr(), M, N, K, 0, bias.data_ptr(), None, None, None, Ch.data_ptr(), st), "h1p"))
+    out["codec_pwconv1_gemm_h1p"] = {
+        "kernel": "gemm_h1p_k<GELU_PACKED> (csrc/codec_gemm.hip), the perf mode's decoder (gemm=\"f16\")", "bound": "mfma", "M": M, "N": N, "K": K,
+        "avg_launch_us": round(t * 1e6, 1), "alg_flops_per_launch": fl, "achieved": round(fl / t / 1e12, 1), "peak": MFMA_BF16_PEAK_TFS,
+        "unit": "TFLOP/s", "frac": round(fl / t / 1e12 / MFMA_BF16_PEAK_TFS, 4),
+        "note": "one fp16 MFMA per product (dense fp16 peak = dense bf16 peak)"}
+    del Ah, Wh, Ch
     M, N, K = 64 * 48, 3072, 768
     Ab = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
     Wb = (torch.randn(2 * N, K, generator=g) * 0.02).to(torch.bfloat16).to(dev)
@@ -208,6 +218,9 @@ def main():
     ap.add_argument("--pipeline", action="store_true", help="time the main leg as a software-pipelined queue of batches (batch i's acoustic decode "
                     "overlaps batch i+1's generation); default: one batch after the other, the pipelined figure is reported beside it")
     ap.add_argument("--parity-steps", type=int, default=5, help="timed passes of the f32 parity mode")
+    ap.add_argument("--codec-gemm", default=None, choices=["f16", "bf16x3", "f32"],
+                    help="dense-layer arithmetic of the acoustic decoder in the main leg (default: f16 with --dtype bf16, bf16x3 with f32; "
+                         "the parity-mode leg always decodes with bf16x3)")
     ap.add_argument("--lanes", type=int, default=1, help="concurrent decode lanes (HIP streams) the batch is cut into")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) run the CPU baseline leg alone and print its JSON")
     args = ap.parse_args()
@@ -257,7 +270,8 @@ def main():
     else:
         sds = W.synthetic_all()
     gpt = E.GptEngine(sds["gpt"], sds["embed"], dev, dtype=args.dtype)
-    codec = E.CodecEngine(sds["decoder"], sds["vocos"], dev)
+    codec_gemm = args.codec_gemm or ("f16" if args.dtype == "bf16" else "bf16x3")
+    codec_main = codec = E.CodecEngine(sds["decoder"], sds["vocos"], dev, gemm=codec_gemm)   # `codec` is rebound for the parity-mode leg
 
     # ---- workload: global batch sharded in contiguous row blocks ----
     wl = shard_workload(args.batch, world, rank, args.min_len, args.max_len)
@@ -357,6 +371,9 @@ def main():
                                "the K batches are software-pipelined: DVAE + Vocos + D2H of batch i on a side HIP stream while batch i+1 is generated"
                                if args.pipeline else "one batch after the other"),
                    "pipelined": bool(args.pipeline),
+                   "acoustic_decoder_gemm": codec_gemm + {"f16": ": ConvNeXt point-wise pairs on one fp16 MFMA per product, f32 accumulation "
+                                                                 "(waveform vs the f32-class decoder on the same hidden states: `codec_parity`)",
+                                                          "bf16x3": ": split-bf16, f32-class", "f32": ": f32 MFMA tiles"}[codec_gemm],
                    "global_batch": Bg, "decode_steps_per_pass": gpt_steps, "parallelism": f"dp{world}", "lanes_per_gpu": args.lanes,
                    "tokens_per_pass": int(stop.sum()), "audio_s_per_pass": round(audio_seconds(stop), 2)},
     }
@@ -443,6 +460,8 @@ def main():
     if world == 1 and args.dtype == "bf16" and not args.no_parity_mode:
         note("parity mode (f32): %d timed passes" % args.parity_steps)
         gpt32 = E.GptEngine(sds["gpt"], sds["embed"], dev, dtype="f32")
+        if codec_gemm != "bf16x3":      # the parity mode decodes with the f32-class decoder
+            codec = E.CodecEngine(sds["decoder"], sds["vocos"], dev, gemm="bf16x3")
         dt32 = timed(gpt32, args.parity_steps, 1)
         steps32, dec32_ms = gpt32.last_stats.get("steps", 0), gpt32.last_stats.get("decode_ms", 0.0)
         _, hid32, rows = one_pass(gpt32, keep_hidden=True, decode_audio=False)
@@ -452,13 +471,25 @@ def main():
                                  "steps": args.parity_steps, "warmup": 1, "ms_per_step": round(1000.0 * dt32 / args.parity_steps, 3),
                                  "decode_ms_per_gpt_step": round(dec32_ms / max(1, steps32 - 1), 4),
                                  "kernels": "decode projections on fragment-packed f32 operands (csrc/decode32.hip), operation order of "
-                                            "the row-major f32 kernels kept bit for bit",
+                                            "the row-major f32 kernels kept bit for bit; acoustic decoder gemm=bf16x3 (4e-7 RMS from the f32 oracle)",
                                  "ids_sha256": got, "golden_sha256": want,
                                  "ids_match_reference": (got == want) if want else None,
                                  "golden": "tests/golden/bench_c3.npz: the reference's GPT.generate on this workload (oracle/make_bench_golden.py)"}
         if not args.no_roofline:
             roof32, k32 = roofline_leg(gpt32, 4, (3,), steps32, dec32_ms / max(1, steps32 - 1), pmc_key_suffix="_f32")
             result["parity_mode"]["roofline"] = roof32
+        if codec is not codec_main:
+            # the perf mode's decoder (one fp16 MFMA per product) against the parity mode's on the SAME hidden states: this pass's 64 rows
+            hs = [torch.from_numpy(h).to(dev) for h in hid32]
+            w_ref = codec.decode_to_wavs(hs).cpu().numpy()
+            w_main = codec_main.decode_to_wavs(hs).cpu().numpy()
+            d = (w_main.astype(np.float64) - w_ref.astype(np.float64))
+            result["codec_parity"] = {"gemm": codec_gemm, "against": "gemm=bf16x3 on the same hidden states (the f32 engine's, all %d rows)" % len(hs),
+                                      "wav_rms_diff": float(np.sqrt(np.mean(d ** 2))), "wav_max_abs_diff": float(np.abs(d).max()),
+                                      "wav_rms": float(np.sqrt(np.mean(w_ref.astype(np.float64) ** 2))), "bar": 1e-4,
+                                      "what": "north_star: float32 waveform within 1e-4 RMS; tests/test_gpu_e2e.py states 2e-5 for this mode"}
+            del hs, w_ref, w_main, d
+            codec = codec_main
         del gpt32
         torch.cuda.empty_cache()
 

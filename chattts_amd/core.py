@@ -87,13 +87,15 @@ class Chat:
     def load(self, source: str = "local", force_redownload: bool = False, compile: bool = False, custom_path: Optional[str] = None,
              device: Optional[torch.device] = None, coef=None, use_flash_attn: bool = False, use_vllm: bool = False,
              experimental: bool = False, *, dtype: str = "bf16", state_dicts: Optional[dict] = None,
-             tokenizer: Union[None, str, Tokenizer] = None, spk_stat: Optional[str] = None) -> bool:
+             tokenizer: Union[None, str, Tokenizer] = None, spk_stat: Optional[str] = None, codec_gemm: Optional[str] = None) -> bool:
         """`Chat.load` with the reference's positional parameters and defaults (core.py:137-148), for `source="local"` /
         `"custom"` (assets already on disk; there is no network path here, `"huggingface"` returns False): the four
         hot-path safetensors files under `custom_path` (default: the working directory, like the reference's "local"
         source) and `asset/tokenizer`.  Keyword-only extras of this engine: `dtype` ("bf16" perf mode | "f32" parity mode),
         `state_dicts` short-circuits disk I/O (synthetic weights); `tokenizer` is a directory or a `Tokenizer`;
-        `spk_stat` is the reference's `Config.spk_stat` string (needed by `sample_random_speaker` only).
+        `spk_stat` is the reference's `Config.spk_stat` string (needed by `sample_random_speaker` only); `codec_gemm` picks the
+        acoustic decoder's dense-layer arithmetic (`CodecEngine`: "f16" | "bf16x3" | "f32"; default: "f16" in perf mode --
+        waveform within 2e-5 RMS of the f32-class decoder for the same hidden states -- and "bf16x3" in parity mode).
         `compile`, `use_flash_attn`, `use_vllm`, `experimental` select between the reference's torch back ends and
         have no meaning for this engine (accepted, ignored).  `coef` is accepted and has no effect, as in the reference:
         `DVAE.__init__` installs it (dvae.py:219-226) and `load_pretrained` then overwrites the buffer with the
@@ -115,7 +117,7 @@ class Chat:
             self.logger.error("%s", e)
             return False
         self.gpt = GptEngine(sds["gpt"], sds["embed"], device, dtype=dtype, logger=self.logger, **sds.get("gpt_config", {}))
-        self.codec = CodecEngine(sds["decoder"], sds["vocos"], device)
+        self.codec = CodecEngine(sds["decoder"], sds["vocos"], device, gemm=codec_gemm or ("f16" if dtype == "bf16" else "bf16x3"))
         self.dvae = DvaeEngine(sds["dvae"], device) if "dvae" in sds else None
         self.device = device
         if tokenizer is None and state_dicts is None and os.path.isdir(os.path.join(root, "asset", "tokenizer")):

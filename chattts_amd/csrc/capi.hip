@@ -605,7 +605,12 @@ extern "C" int ctts_codec_create(ctts_codec** out, const ctts_codec_weights* w) 
     c->d[i].assign(dsrc[i], dsrc[i] + w->n_dvae_blocks);
     c->v[i].assign(vsrc[i], vsrc[i] + w->n_vocos_blocks);
   }
-  if (w->gemm_mode == 1 && w->d_pw1_x3p && w->d_pw2_x3p && w->v_pw1_x3p && w->v_pw2_x3p) {
+  if (w->gemm_mode != 0 && w->gemm_mode != 1 && w->gemm_mode != 2) { delete c; return fail("ctts_codec_create: gemm_mode must be 0, 1 or 2"); }
+  if (w->gemm_mode == 2 && !(w->d_pw1_x3p && w->d_pw2_x3p && w->v_pw1_x3p && w->v_pw2_x3p)) {
+    delete c;
+    return fail("ctts_codec_create: gemm_mode 2 needs the fp16 planes of the point-wise weights");
+  }
+  if (w->gemm_mode >= 1 && w->d_pw1_x3p && w->d_pw2_x3p && w->v_pw1_x3p && w->v_pw2_x3p) {
     c->dx[0].assign(w->d_pw1_x3p, w->d_pw1_x3p + w->n_dvae_blocks);
     c->dx[1].assign(w->d_pw2_x3p, w->d_pw2_x3p + w->n_dvae_blocks);
     c->vx[0].assign(w->v_pw1_x3p, w->v_pw1_x3p + w->n_vocos_blocks);
@@ -653,19 +658,20 @@ static GemmArgs conv(const float* X, int cin, const float* W, float* C, int cout
 static int convnext_stack(const ctts_codec* c, int n, const std::vector<const float*>* p, const std::vector<const void*>* px, int inter, int dil,
                           CodecWs& ws, int B, int F, hipStream_t st) {
   const int R = B * F;
-  const bool x3p = c->w.gemm_mode == 1 && !px[0].empty() && c->x3p_min_rows > 0 && R >= c->x3p_min_rows && inter % 256 == 0;
+  const bool f16 = c->w.gemm_mode == 2;   // one fp16 plane per operand (gemm_h1p_k) instead of hi | lo bf16 planes (gemm_x3p_k)
+  const bool x3p = c->w.gemm_mode >= 1 && !px[0].empty() && c->x3p_min_rows > 0 && R >= c->x3p_min_rows && inter % 256 == 0;
   for (int i = 0; x3p && i < n; ++i) {
     // depthwise conv + LayerNorm -> bf16 planes; pwconv1 + GELU -> bf16 planes; pwconv2 * gamma + residual -> f32 rows
     uint16_t* bp = reinterpret_cast<uint16_t*>(ws.b);     // [R256][512] as hi / lo planes: the bytes of the f32 buffer
     uint16_t* bigp = reinterpret_cast<uint16_t*>(ws.big);
-    CK(launch_dwconv_ln(ws.a, p[0][i], p[1][i], p[2][i], p[3][i], 1e-6f, dil, nullptr, B, F, 512, st, bp));
+    CK(launch_dwconv_ln(ws.a, p[0][i], p[1][i], p[2][i], p[3][i], 1e-6f, dil, nullptr, B, F, 512, st, bp, f16 ? 1 : 0));
     X3pArgs g;
     memset(&g, 0, sizeof(g));
     g.Ap = bp; g.Wp = (const uint16_t*)px[0][i]; g.M = R; g.N = inter; g.K = 512; g.epi = X3P_GELU_PACKED; g.bias = p[5][i]; g.Cp = bigp;
-    CK(launch_gemm_x3p(g, st));
+    CK(f16 ? launch_gemm_h1p(g, st) : launch_gemm_x3p(g, st));
     g.Ap = bigp; g.Wp = (const uint16_t*)px[1][i]; g.N = 512; g.K = inter; g.epi = X3P_SCALE_RES; g.bias = p[7][i]; g.gamma = p[8][i];
     g.res = ws.a; g.ldr = 512; g.C = ws.a; g.ldc = 512; g.Cp = nullptr;
-    CK(launch_gemm_x3p(g, st));
+    CK(f16 ? launch_gemm_h1p(g, st) : launch_gemm_x3p(g, st));
   }
   for (int i = 0; !x3p && i < n; ++i) {
     CK(launch_dwconv_ln(ws.a, p[0][i], p[1][i], p[2][i], p[3][i], 1e-6f, dil, ws.b, B, F, 512, st));
@@ -680,7 +686,7 @@ static int convnext_stack(const ctts_codec* c, int n, const std::vector<const fl
 }
 
 static hipError_t dense(const ctts_codec* c, const GemmArgs& a, hipStream_t st) {
-  return c->w.gemm_mode == 1 ? launch_gemm_tiled_bf16x3(a, st) : launch_gemm_tiled(a, st);
+  return c->w.gemm_mode >= 1 ? launch_gemm_tiled_bf16x3(a, st) : launch_gemm_tiled(a, st);   // mode 2: only the ConvNeXt point-wise pairs are fp16
 }
 
 extern "C" int ctts_dvae_decode(ctts_codec* c, const float* hid, float* mel, int32_t B, int32_t T, void* workspace, size_t ws_bytes,
@@ -749,6 +755,15 @@ extern "C" int ctts_k_gemm_x3p(const uint16_t* Ap, const uint16_t* Wp, int32_t M
   g.Ap = Ap; g.Wp = Wp; g.M = M; g.N = N; g.K = K; g.epi = epi; g.bias = bias; g.gamma = gamma; g.res = res; g.ldr = N; g.C = C; g.ldc = N; g.Cp = Cp;
   { const char* e = getenv("CTTS_X3_DBG_PTR"); if (e) g.dbg = (long long*)strtoull(e, nullptr, 0); }   // probe variant only
   CK(launch_gemm_x3p(g, (hipStream_t)stream));
+  return 0;
+}
+extern "C" int ctts_k_gemm_h1p(const uint16_t* Ap, const uint16_t* Wp, int32_t M, int32_t N, int32_t K, int32_t epi, const float* bias,
+                               const float* gamma, const float* res, float* C, uint16_t* Cp, void* stream) {
+  X3pArgs g;
+  memset(&g, 0, sizeof(g));
+  g.Ap = Ap; g.Wp = Wp; g.M = M; g.N = N; g.K = K; g.epi = epi; g.bias = bias; g.gamma = gamma; g.res = res; g.ldr = N; g.C = C; g.ldc = N; g.Cp = Cp;
+  { const char* e = getenv("CTTS_X3_DBG_PTR"); if (e) g.dbg = (long long*)strtoull(e, nullptr, 0); }   // probe variant only (CTTS_H1P_PROBE=1)
+  CK(launch_gemm_h1p(g, (hipStream_t)stream));
   return 0;
 }
 extern "C" int ctts_k_gemm_fast(const uint16_t* A, int32_t lda, const uint16_t* W, int32_t M, int32_t N, int32_t K, const float* ssq_in,

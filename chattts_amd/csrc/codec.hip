@@ -13,7 +13,7 @@
 // channels = 64 lanes x CPL: 512 (CPL 8: both ConvNeXt stacks of the decoder path) or 256 (CPL 4: the full DVAE's trunks)
 // planes != null: the normalised row goes out as hi / lo bf16 planes in the fragment order of codec_gemm.hip (a lane's 8 channels are
 // one 16-byte slot of each plane) instead of f32
-template <int CPL>
+template <int CPL, bool F16 = false>
 __device__ __forceinline__ void ln_finish(float* y, const float* __restrict__ lw, const float* __restrict__ lb, float eps, int c0,
                                           float* __restrict__ dst, uint16_t* __restrict__ planes = nullptr, int row = 0) {
   constexpr int C = 64 * CPL;
@@ -37,6 +37,11 @@ __device__ __forceinline__ void ln_finish(float* y, const float* __restrict__ lw
   if constexpr (CPL == 8) {
    if (planes != nullptr) {
     constexpr int KB16 = C / 16;
+    if constexpr (F16) {   // one fp16 plane (codec_gemm.hip: gemm_h1p_k): a lane's 8 channels are one 16-byte slot of it
+      const size_t o = (((size_t)(row >> 5) * KB16 + (c0 >> 4)) * 64 + (((c0 & 15) >> 3) << 5) + (row & 31)) * 8;
+      *reinterpret_cast<uint4*>(planes + o) = make_uint4(pack_f16x2(y[0], y[1]), pack_f16x2(y[2], y[3]), pack_f16x2(y[4], y[5]), pack_f16x2(y[6], y[7]));
+      return;
+    }
     uint32_t h[4], l[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -51,7 +56,7 @@ __device__ __forceinline__ void ln_finish(float* y, const float* __restrict__ lw
 }
 
 // w is the depthwise kernel transposed on the host to [7][C] so that a lane's CPL channels are contiguous
-template <int CPL>
+template <int CPL, bool F16 = false>
 __global__ __launch_bounds__(256) void dwconv_ln_k(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
                                                    const float* __restrict__ lw, const float* __restrict__ lb, float eps, int dil,
                                                    float* __restrict__ y, int F, int rows, uint16_t* __restrict__ yp) {
@@ -86,15 +91,16 @@ __global__ __launch_bounds__(256) void dwconv_ln_k(const float* __restrict__ x, 
       }
     }
   }
-  ln_finish<CPL>(acc, lw, lb, eps, c0, y + (size_t)row * C, yp, row);
+  ln_finish<CPL, F16>(acc, lw, lb, eps, c0, y + (size_t)row * C, yp, row);
 }
 
 hipError_t launch_dwconv_ln(const float* x, const float* w, const float* b, const float* ln_w, const float* ln_b, float eps, int dil,
-                            float* y, int B, int F, int C, hipStream_t st, uint16_t* yp) {
+                            float* y, int B, int F, int C, hipStream_t st, uint16_t* yp, int plane_f16) {
   const int rows = B * F;
   const int nblk = ((rows + 3) / 4 + 7) / 8 * 8;   // multiple of 8: one contiguous run of frames per XCD (see the kernel)
   if (yp != nullptr && C != 512) return hipErrorInvalidValue;
-  if (C == 512) hipLaunchKernelGGL(dwconv_ln_k<8>, dim3(nblk), dim3(256), 0, st, x, w, b, ln_w, ln_b, eps, dil, y, F, rows, yp);
+  if (C == 512 && yp != nullptr && plane_f16) hipLaunchKernelGGL((dwconv_ln_k<8, true>), dim3(nblk), dim3(256), 0, st, x, w, b, ln_w, ln_b, eps, dil, y, F, rows, yp);
+  else if (C == 512) hipLaunchKernelGGL(dwconv_ln_k<8>, dim3(nblk), dim3(256), 0, st, x, w, b, ln_w, ln_b, eps, dil, y, F, rows, yp);
   else if (C == 256) hipLaunchKernelGGL(dwconv_ln_k<4>, dim3(nblk), dim3(256), 0, st, x, w, b, ln_w, ln_b, eps, dil, y, F, rows, (uint16_t*)nullptr);
   else return hipErrorInvalidValue;
   return hipGetLastError();

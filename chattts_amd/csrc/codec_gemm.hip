@@ -19,6 +19,8 @@
 // Numerics are those of gemm_tiled_bf16x3_k: a.w ~= a_lo w_hi + a_hi w_lo + a_hi w_hi, f32 accumulation over k in order.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -219,18 +221,35 @@ __global__ __launch_bounds__(512, 2) void gemm_x3p_k(X3pArgs a) {
         __builtin_amdgcn_wave_barrier();
       }
   } else {   // X3P_SCALE_RES: C = res + gamma * (acc + bias), f32 row-major (the residual stream the depthwise conv reads)
+    // C and res are the SAME buffer (the residual stream is updated in place): written element by element, every load would have
+    // to wait for the previous store (may-alias), one memory round trip per element -- 62 of a 122 us tile
+    // (profiles/r3ag_h1p_phase_probe.log).  Each thread reads and writes only its own elements, so a column block's 32 residuals
+    // are requested together, then the 32 results are stored.
+    auto scale_res = [&](auto whole_tile) {   // whole_tile: all 256 rows exist -> straight-line loads and stores (the ragged last tile predicates)
+      constexpr bool FULL = decltype(whole_tile)::value;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int col = n0 + (wn * 4 + j) * 32 + (lane & 31);
-      const float bias = a.bias[col], gam = a.gamma[col];
+      for (int j = 0; j < 4; ++j) {
+        const int col = n0 + (wn * 4 + j) * 32 + (lane & 31);
+        const float bias = a.bias[col], gam = a.gamma[col];
+        float rv[2][16];
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = m0 + (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          if (row < M) a.C[(size_t)row * a.ldc + col] = a.res[(size_t)row * a.ldr + col] + gam * (acc[i][j][r] + bias);
-        }
-    }
+          for (int r = 0; r < 16; ++r) {
+            const int row = m0 + (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            rv[i][r] = __builtin_nontemporal_load(a.res + (size_t)(FULL ? row : min(row, M - 1)) * a.ldr + col);   // clamped, never predicated
+          }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = m0 + (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (FULL || row < M) a.C[(size_t)row * a.ldc + col] = rv[i][r] + gam * (acc[i][j][r] + bias);
+          }
+      }
+    };
+    if (m0 + BM <= M) scale_res(std::true_type{});
+    else scale_res(std::false_type{});
   }
 }
 
@@ -253,5 +272,203 @@ hipError_t launch_gemm_x3p(const X3pArgs& a, hipStream_t st) {
   else if (var == 3) x3p_launch<3>(a, grid, st);
   else if (var == 4) x3p_launch<4>(a, grid, st);
   else x3p_launch<1>(a, grid, st);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// gemm_h1p_k (round 3, gemm_mode 2 = "f16"): the same 256 x 256 tile, LDS-DMA ring and epilogues on ONE fp16 plane per operand.
+// The north-star bar for the acoustic decoder is a waveform within 1e-4 RMS of the float32 path; the split-bf16 kernel above lands
+// at 4e-7 and pays three MFMAs per product and 4 bytes per staged element for it.  fp16 keeps 11 significant bits of both operands
+// (f32 accumulation): 6e-6 RMS on the waveform (tests/test_gpu_e2e.py states the bound), one MFMA per product, 2 bytes per element
+// in HBM, in the DMA and in the fragment reads.  Activations are saturated to +-65504 where they are rounded (pack_f16x2).
+//   plane[row / 32][k / 16][lane = (k % 16) / 8 * 32 + row % 32][k % 8]   -- the x3p layout without the hi | lo axis
+// A ring slot holds a 32-wide k block (two 16-wide fragments per 32-row tile where x3p holds hi | lo of one), a stage is two
+// slots = 64 of k: one barrier per 32 MFMAs of a wave.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ size_t h1p_off(int r, int k, int kb16) {
+  return (((size_t)(r >> 5) * kb16 + (k >> 4)) * 64 + (((k & 15) >> 3) << 5) + (r & 31)) * 8 + (k & 7);
+}
+
+template <int EPI, bool PROBE = false>   // PROBE (CTTS_H1P_PROBE=1 + CTTS_X3_DBG_PTR, tools/x3p_phase_probe.py --h1p): wave 0 accumulates 100 MHz phase times
+__global__ __launch_bounds__(512, 2) void gemm_h1p_k(X3pArgs a) {
+  constexpr int BM = 256, BN = 256;
+  constexpr int FRAG = 512;                 // fp16 elements of one fragment (1 KiB): 32 rows x 16 of k
+  constexpr int SLOT = 32 * FRAG;           // one ring slot = a 32-wide k block of the tile: (8 A + 8 W row tiles) x 2 fragments = 32 KiB
+  constexpr int NSLOT = 4;
+  __shared__ __attribute__((aligned(16))) uint16_t lds[NSLOT * SLOT];
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = wave & 3, wn = wave >> 2;  // 4 x 2 waves, each 64 rows x 128 columns = 2 x 4 MFMA blocks of 32 x 32
+  const int M = a.M, N = a.N, K = a.K;
+  const int nx = N / BN, ny = (M + BM - 1) / BM, T = nx * ny, per = (T + 7) / 8;   // XCD-aware tile order, as gemm_x3p_k
+  const int t = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= per || t >= T) return;
+  const int m0 = (t / nx) * BM, n0 = (t % nx) * BN;
+  const int kb16 = K >> 4;
+
+  // wave w stages row tile w of the A panel and column tile w of the W panel: per 32-wide k block two consecutive fragments = 2 KiB each
+  const uint16_t* ag = a.Ap + ((size_t)((m0 >> 5) + wave) * kb16) * FRAG + lane * 8;
+  const uint16_t* wg = a.Wp + ((size_t)((n0 >> 5) + wave) * kb16) * FRAG + lane * 8;
+  auto issue = [&](int q) {   // 32-wide k block q -> slot q % 4: 4 LDS-DMA pieces of 1 KiB per wave
+    uint16_t* la = lds + (q & (NSLOT - 1)) * SLOT + wave * 2 * FRAG;
+    uint16_t* lw = la + 16 * FRAG;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ag + ((size_t)q * 2 + h) * FRAG),
+                                       (__attribute__((address_space(3))) void*)(la + h * FRAG), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wg + ((size_t)q * 2 + h) * FRAG),
+                                       (__attribute__((address_space(3))) void*)(lw + h * FRAG), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // Stages of two slots (64 of k), double-buffered, as gemm_x3p_k's variant 4: wait for this wave's pieces of the stage, barrier
+  // (everybody's pieces are in, everybody has READ the other stage), refill the other stage, multiply this one.  On top of that the
+  // fragment reads run ONE 16-wide k block ahead of the MFMAs (two register sets): with one product per MFMA the LDS pipe (384
+  // cycles of fragment reads + 128 of DMA writes per k block and CU) is as busy as the matrix pipe (512), so a wave that reads,
+  // waits, then multiplies leaves both idle half the time.  The reads of a stage's first block are issued right behind the
+  // barrier and land under the previous stage's last 8 MFMAs, whose operands are already in registers.
+  const int np = K >> 6;   // K % 64 == 0
+  f16x8 fa0[2], fw0[4], fa1[2], fw1[4];
+  auto rd = [&](f16x8* fa, f16x8* fw, int u) {   // fragments of 16-wide k block u
+    const uint16_t* la = lds + ((u >> 1) & (NSLOT - 1)) * SLOT + lane * 8;
+    const uint16_t* lw = la + 16 * FRAG;
+    const int h = u & 1;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const f16x8*>(la + ((wm * 2 + i) * 2 + h) * FRAG);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fw[j] = *reinterpret_cast<const f16x8*>(lw + ((wn * 4 + j) * 2 + h) * FRAG);
+  };
+  // mm_a: the block's first MFMA (hipcc puts its `s_waitcnt lgkmcnt(0)` for the block's fragments in front of it -- they were
+  // requested a whole block earlier); the NEXT block's reads are issued behind it, so nothing younger is outstanding at that wait;
+  // mm_b: the other 7, which cover the reads' latency
+  auto mm_a = [&](const f16x8* fa, const f16x8* fw) { acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0], fw[0], acc[0][0], 0, 0, 0); };
+  auto mm_b = [&](const f16x8* fa, const f16x8* fw) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (i + j > 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fw[j], acc[i][j], 0, 0, 0);
+  };
+#define H1P_SB() __builtin_amdgcn_sched_barrier(0)
+  long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0, t_begin = 0;
+#define H1P_MARK(i) do { if (PROBE) { const long long tn = wall_clock64(); tacc[i] += tn - tprev; tprev = tn; } } while (0)
+  if (PROBE) t_begin = tprev = wall_clock64();
+  issue(0); issue(1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (np > 1) { issue(2); issue(3); }
+  rd(fa0, fw0, 0);
+  H1P_MARK(0);   // prologue: first stage requested, landed, barrier, second stage requested
+  for (int p = 0; p < np; ++p) {
+    const int u = 4 * p;
+    H1P_SB(); mm_a(fa0, fw0); H1P_SB(); rd(fa1, fw1, u + 1); H1P_SB(); mm_b(fa0, fw0);
+    H1P_SB(); mm_a(fa1, fw1); H1P_SB(); rd(fa0, fw0, u + 2); H1P_SB(); mm_b(fa1, fw1);
+    H1P_SB(); mm_a(fa0, fw0); H1P_SB(); rd(fa1, fw1, u + 3); H1P_SB(); mm_b(fa0, fw0);
+    H1P_SB(); mm_a(fa1, fw1); H1P_SB();
+    H1P_MARK(1);   // 25 MFMAs issued, 18 fragment reads
+    if (p + 1 < np) {   // stage boundary: every wave holds its last fragments of stage p in registers -> its slots may be refilled
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      H1P_MARK(2);   // this wave's DMA pieces of the next stage
+      __builtin_amdgcn_s_barrier();
+      H1P_MARK(3);   // everybody else
+      if (p + 2 < np) { issue(2 * p + 4); issue(2 * p + 5); }
+      rd(fa0, fw0, u + 4);
+      H1P_SB();
+      H1P_MARK(4);   // 8 DMA pieces + 6 reads issued
+    }
+    mm_b(fa1, fw1);
+  }
+  if (PROBE) { asm volatile("s_nop 15\n\ts_nop 15" :: "v"(acc[1][3][0])); H1P_MARK(1); }
+#undef H1P_SB
+  __syncthreads();   // the ring becomes the epilogue's scratch
+
+  if (EPI == X3P_GELU_PACKED) {
+    // C layout (one column per lane, 16 rows) -> 8 consecutive columns of one row per lane through a wave-private LDS tile:
+    // bias + GELU (gelu_fast: within 1.5e-7 |x| of the erf form, common.hpp), round to fp16, one 16-byte slot of the NEXT
+    // gemm_h1p_k's A plane (K' = N)
+    float* scr = reinterpret_cast<float*>(lds) + wave * (32 * 36);
+    const int nb16 = N >> 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int cb = n0 + (wn * 4 + j) * 32;
+        const float bias = a.bias[cb + (lane & 31)];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          scr[rr * 36 + (lane & 31)] = gelu_fast(acc[i][j][r] + bias);
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const int item = lane + 64 * it, rr = item >> 2, cg = item & 3;
+          const float4 v0 = *reinterpret_cast<const float4*>(scr + rr * 36 + cg * 8);
+          const float4 v1 = *reinterpret_cast<const float4*>(scr + rr * 36 + cg * 8 + 4);
+          const int row = m0 + (wm * 2 + i) * 32 + rr;   // rows >= M land in the buffer's padding (allocated to a multiple of 256)
+          *reinterpret_cast<uint4*>(a.Cp + h1p_off(row, cb + cg * 8, nb16)) =
+              make_uint4(pack_f16x2(v0.x, v0.y), pack_f16x2(v0.z, v0.w), pack_f16x2(v1.x, v1.y), pack_f16x2(v1.z, v1.w));
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+  } else {   // X3P_SCALE_RES: C = res + gamma * (acc + bias), f32 row-major (the residual stream stays f32)
+    // in place (C == res): a column block's 32 residuals are requested together, then the 32 results stored (see gemm_x3p_k)
+    auto scale_res = [&](auto whole_tile) {   // whole_tile: all 256 rows exist -> straight-line loads and stores (the ragged last tile predicates)
+      constexpr bool FULL = decltype(whole_tile)::value;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int col = n0 + (wn * 4 + j) * 32 + (lane & 31);
+        const float bias = a.bias[col], gam = a.gamma[col];
+        float rv[2][16];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = m0 + (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            rv[i][r] = __builtin_nontemporal_load(a.res + (size_t)(FULL ? row : min(row, M - 1)) * a.ldr + col);   // clamped, never predicated
+          }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = m0 + (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (FULL || row < M) a.C[(size_t)row * a.ldc + col] = rv[i][r] + gam * (acc[i][j][r] + bias);
+          }
+      }
+    };
+    if (m0 + BM <= M) scale_res(std::true_type{});
+    else scale_res(std::false_type{});
+  }
+  if (PROBE && a.dbg != nullptr && tid == 0) {
+    H1P_MARK(5);   // epilogue (from the end of the k loop)
+    long long* d = a.dbg + (size_t)blockIdx.x * 8;
+    for (int i = 0; i < 6; ++i) d[i] = tacc[i];
+    d[6] = wall_clock64() - t_begin;
+  }
+#undef H1P_MARK
+}
+
+hipError_t launch_gemm_h1p(const X3pArgs& a, hipStream_t st) {
+  static int probe = -1;
+  if (probe < 0) { const char* e = getenv("CTTS_H1P_PROBE"); probe = (e && atoi(e) > 0) ? 1 : 0; }
+  if (a.M <= 0 || (a.N % 256) != 0 || (a.K % 64) != 0 || a.K < 64) return hipErrorInvalidValue;
+  if (a.epi != X3P_GELU_PACKED && a.epi != X3P_SCALE_RES) return hipErrorInvalidValue;
+  const int tiles = (a.N / 256) * ((a.M + 255) / 256);
+  dim3 grid(((tiles + 7) / 8) * 8);
+  if (probe && a.dbg != nullptr) {
+    if (a.epi == X3P_GELU_PACKED) CTTS_LAUNCH((gemm_h1p_k<X3P_GELU_PACKED, true>), grid, dim3(512), st, a);
+    else CTTS_LAUNCH((gemm_h1p_k<X3P_SCALE_RES, true>), grid, dim3(512), st, a);
+    return hipGetLastError();
+  }
+  if (a.epi == X3P_GELU_PACKED) CTTS_LAUNCH((gemm_h1p_k<X3P_GELU_PACKED>), grid, dim3(512), st, a);
+  else CTTS_LAUNCH((gemm_h1p_k<X3P_SCALE_RES>), grid, dim3(512), st, a);
   return hipGetLastError();
 }

@@ -22,6 +22,14 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
 }
 
 // two floats -> packed bf16 pair (first value in the low half) with gfx950's v_cvt_pk_bf16_f32 (round-to-nearest-even)
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+// two f32 -> two fp16 (round to nearest even), saturated to the largest finite half: an activation beyond +-65504 must not become inf
+__device__ __forceinline__ uint32_t pack_f16x2(float a, float b) {
+  a = fminf(fmaxf(a, -65504.f), 65504.f);
+  b = fminf(fmaxf(b, -65504.f), 65504.f);
+  const _Float16 ha = (_Float16)a, hb = (_Float16)b;
+  return (uint32_t)__builtin_bit_cast(uint16_t, ha) | ((uint32_t)__builtin_bit_cast(uint16_t, hb) << 16);
+}
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
@@ -77,6 +85,21 @@ __device__ __forceinline__ int wave_min_dpp(int v) {
 
 // erf-based GELU (nn.GELU default, approximate='none')
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// The same function for an output that is rounded to fp16 anyway (gemm_h1p_k): Phi(x) from Abramowitz-Stegun 7.1.26,
+// erfc(z) = (a1 t + ... + a5 t^5) exp(-z^2), t = 1 / (1 + p z), |error| <= 1.5e-7 (3.2e-7 |x| on the result in f32 arithmetic, checked on 2e6 points) -- branch-free, one v_rcp_f32 and one v_exp_f32
+// (libm's erff is ~45 VALU instructions per element behind two divergent branches, and the 256 x 256 tile's GELU epilogue was
+// costing more than its 8 k stages of fp16 MFMAs).  |gelu_fast - gelu_erf| <= 1.5e-7 |x|, a 2^-11 rounding follows.
+__device__ __forceinline__ float gelu_fast(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float half_erfc = 0.5f * (p * t) * __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);   // 0.5 erfc(|x| / sqrt 2) = Phi(-|x|)
+  const float phi = x < 0.f ? half_erfc : 1.0f - half_erfc;
+  return x * phi;
+}
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
 
 struct alignas(16) u128 {

@@ -254,6 +254,16 @@ __global__ __launch_bounds__(256) void gemm_tiled_f32_k(GemmArgs a) {
     float bias = 0.f, gam = 1.f;
     if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_SCALE_RES) bias = a.bias[col];
     if (EPI == EPI_BIAS_SCALE_RES || EPI == EPI_SCALE || EPI == EPI_LOG_DIV) gam = a.gamma[col];
+    // the residual is updated IN PLACE (C == res): read element by element, every load would wait for the previous store (may-alias),
+    // one memory round trip per element.  A thread reads and writes only its own elements: its 16 residuals are requested first.
+    float rv[16];
+    if (EPI == EPI_BIAS_SCALE_RES || EPI == EPI_RES) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        rv[r] = a.res[(size_t)min(row, M - 1) * a.ldr + col];
+      }
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);  // C/D map of 32x32 MFMA
@@ -261,8 +271,8 @@ __global__ __launch_bounds__(256) void gemm_tiled_f32_k(GemmArgs a) {
         float v = acc[r];
         if (EPI == EPI_BIAS) v = v + bias;
         else if (EPI == EPI_BIAS_GELU) v = gelu_erf(v + bias);
-        else if (EPI == EPI_BIAS_SCALE_RES) v = a.res[(size_t)row * a.ldr + col] + gam * (v + bias);
-        else if (EPI == EPI_RES) v = a.res[(size_t)row * a.ldr + col] + v;
+        else if (EPI == EPI_BIAS_SCALE_RES) v = rv[r] + gam * (v + bias);
+        else if (EPI == EPI_RES) v = rv[r] + v;
         else if (EPI == EPI_SCALE) v = v * gam;
         else if (EPI == EPI_LOG_DIV) v = logf(fmaxf(v, 1e-5f)) / gam;
         a.C[(size_t)row * a.ldc + col] = v;
@@ -739,6 +749,16 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) void gemm_til
     float bias = 0.f, gam = 1.f;
     if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_SCALE_RES) bias = a.bias[col];
     if (EPI == EPI_BIAS_SCALE_RES || EPI == EPI_SCALE) gam = a.gamma[col];
+    float rv[MBLK][16];   // in place (C == res): a column block's residuals are requested before its results are stored (see gemm_tiled_k)
+    if (EPI == EPI_BIAS_SCALE_RES || EPI == EPI_RES) {
+#pragma unroll
+      for (int i = 0; i < MBLK; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + (wm * MBLK + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          rv[i][r] = a.res[(size_t)min(row, M - 1) * a.ldr + col];
+        }
+    }
 #pragma unroll
     for (int i = 0; i < MBLK; ++i) {
 #pragma unroll
@@ -748,8 +768,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 2 : 1) void gemm_til
           float v = acc[i][j][r];
           if (EPI == EPI_BIAS) v = v + bias;
           else if (EPI == EPI_BIAS_GELU) v = gelu_erf(v + bias);
-          else if (EPI == EPI_BIAS_SCALE_RES) v = a.res[(size_t)row * a.ldr + col] + gam * (v + bias);
-          else if (EPI == EPI_RES) v = a.res[(size_t)row * a.ldr + col] + v;
+          else if (EPI == EPI_BIAS_SCALE_RES) v = rv[i][r] + gam * (v + bias);
+          else if (EPI == EPI_RES) v = rv[i][r] + v;
           else if (EPI == EPI_SCALE) v = v * gam;
           a.C[(size_t)row * a.ldc + col] = v;
         }

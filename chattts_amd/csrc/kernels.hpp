@@ -312,11 +312,15 @@ struct X3pArgs {
   long long* dbg;        // probe variant only (CTTS_X3P_VAR=3, tools/x3p_phase_probe.py): [n_workgroups][8] accumulated phase times
 };
 hipError_t launch_gemm_x3p(const X3pArgs& a, hipStream_t st);
+// The same GEMM on ONE fp16 plane per operand ("h1p", gemm_mode 2): [rows/32][K/16][lane = (k%16)/8*32 + row%32][k%8] fp16, one
+// v_mfma_f32_32x32x16_f16 per product instead of three bf16 ones, f32 accumulation.  K % 64 == 0.  Ap / Wp / Cp are that plane.
+hipError_t launch_gemm_h1p(const X3pArgs& a, hipStream_t st);
 
 // ---- codec kernels (channels-last [B, F, C]) ---------------------------------------------------
-// yp != null (C = 512 only): the output goes out as the two bf16 planes gemm_x3p_k reads instead of f32 rows
+// yp != null (C = 512 only): the output goes out as the two bf16 planes gemm_x3p_k reads (plane_f16 = 0) or as the one fp16 plane
+// gemm_h1p_k reads (plane_f16 = 1) instead of f32 rows
 hipError_t launch_dwconv_ln(const float* x, const float* w /*[C,7]*/, const float* b, const float* ln_w, const float* ln_b,
-                            float eps, int dil, float* y, int B, int F, int C, hipStream_t st, uint16_t* yp = nullptr);
+                            float eps, int dil, float* y, int B, int F, int C, hipStream_t st, uint16_t* yp = nullptr, int plane_f16 = 0);
 hipError_t launch_layernorm(const float* x, const float* w, const float* b, float eps, float* y, int rows, int C, hipStream_t st);
 hipError_t launch_istft(const float* head /*[B,F,1026]*/, const float* window /*[1024]*/, const float* twiddle /*[512,2]*/,
                         float* frames /*[B,F,1024] scratch*/, float* wav /*[B,256(F-1)]*/, int B, int F, hipStream_t st);

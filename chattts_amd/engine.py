@@ -825,6 +825,21 @@ def unpack_x3p(p: torch.Tensor, R: int, K: int) -> torch.Tensor:
     return x[0] + x[1]
 
 
+def pack_h1p(w: torch.Tensor) -> torch.Tensor:
+    """[R, K] float32 (R % 32 == 0, K % 16 == 0) -> ONE fp16 plane in MFMA fragment order (csrc/codec_gemm.hip: gemm_h1p_k),
+    [R/32][K/16][lane = (k%16)/8*32 + r%32][k%8] float16, values saturated to the finite half range like the kernels' own
+    activation rounding."""
+    R, K = w.shape
+    assert R % 32 == 0 and K % 16 == 0
+    h = w.to(torch.float32).clamp(-65504.0, 65504.0).to(torch.float16)
+    return h.reshape(R // 32, 32, K // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous()
+
+
+def unpack_h1p(p: torch.Tensor, R: int, K: int) -> torch.Tensor:
+    """inverse of pack_h1p: -> float32 [R, K] (tests)"""
+    return p.reshape(R // 32, K // 16, 2, 32, 8).permute(0, 3, 1, 2, 4).reshape(R, K).to(torch.float32)
+
+
 # ---------------------------------------------------------------------------------------------
 class PendingWavs:
     """result of `CodecEngine.decode_to_wavs_async`: the float32 waveforms of one batch, in flight"""
@@ -848,9 +863,12 @@ class CodecEngine:
 
     def __init__(self, decoder_sd: dict, vocos_sd: dict, device: torch.device, gemm: str = "bf16x3"):
         """gemm="bf16x3": dense layers run on split-bf16 MFMA tiles (x = hi + lo, 3 products; f32-class accuracy,
-        measured wav RMS error vs the reference ~1e-6 against the 1e-4 bar); gemm="f32": f32-input MFMA tiles."""
-        if gemm not in ("bf16x3", "f32"):
-            raise ValueError("gemm must be 'bf16x3' or 'f32'")
+        measured wav RMS error vs the reference ~1e-6 against the 1e-4 bar); gemm="f32": f32-input MFMA tiles;
+        gemm="f16" (the perf mode's decoder): as "bf16x3", but the ConvNeXt point-wise pairs of large batches (>= 12288 frames) take
+        one fp16 MFMA per product with f32 accumulation -- waveform within 1e-5 RMS of "bf16x3" (stated and tested bound; the
+        north-star bar is 1e-4), about half the decode time."""
+        if gemm not in ("bf16x3", "f32", "f16"):
+            raise ValueError("gemm must be 'bf16x3', 'f16' or 'f32'")
         self.gemm = gemm
         self.lib = _lib.lib()
         self.device = torch.device(device)
@@ -924,7 +942,13 @@ class CodecEngine:
         w.window = P(f(v["head.istft.window"]))
         kk = torch.arange(VOCOS.n_fft // 2, dtype=torch.float64) * (2.0 * math.pi / VOCOS.n_fft)
         w.twiddle = P(f(torch.stack([kk.cos(), kk.sin()], 1)))
-        w.gemm_mode = 1 if gemm == "bf16x3" else 0
+        w.gemm_mode = {"f32": 0, "bf16x3": 1, "f16": 2}[gemm]
+        if gemm == "f16":
+            h1p = lambda t: pack_h1p(t.to(torch.float32).reshape(t.shape[0], -1)).to(dev)
+            w.d_pw1_x3p = PA([h1p(blk(i, "pwconv1.weight")) for i in range(nb)])
+            w.d_pw2_x3p = PA([h1p(blk(i, "pwconv2.weight")) for i in range(nb)])
+            w.v_pw1_x3p = PA([h1p(vb(i, "pwconv1.weight")) for i in range(nv)])
+            w.v_pw2_x3p = PA([h1p(vb(i, "pwconv2.weight")) for i in range(nv)])
         if gemm == "bf16x3":
             # the ConvNeXt point-wise layers once more as pre-split fragment-order planes: from 12288 frames they run on the
             # LDS-DMA staged kernel of csrc/codec_gemm.hip (40 of the 45 GEMM launches of a decode)

@@ -208,7 +208,11 @@ typedef struct {
   /* 0: every dense weight above is float32 [N][K] (f32-input MFMA tiles);
    * 1: every dense weight (conv_in*, *_pw1, *_pw2, conv_out, out_conv, v_embed, head) is instead a packed
    *    split-bf16 tensor [N][Kp/32][2][32] (per row and 32-wide k block: hi values, lo values; Kp = K rounded up to 32, zero padded), consumed by
-   *    the bf16x3 tiles (3 bf16 MFMAs per product, f32-class accuracy).  Biases/LN/depthwise stay float32. */
+   *    the bf16x3 tiles (3 bf16 MFMAs per product, f32-class accuracy).  Biases/LN/depthwise stay float32.
+   * 2: as 1, but the ConvNeXt point-wise pairs (pwconv1 -> GELU -> pwconv2; 95 % of the decoder's flops) of batches from 12288
+   *    frames run on ONE fp16 plane per operand (1 MFMA per product, f32 accumulation, activations saturated to +-65504 where they
+   *    are rounded): the waveform stays within 1e-5 RMS of mode 1 (bar: 1e-4), the decoder takes about half the time.  The four
+   *    *_x3p arrays below are then REQUIRED and hold fp16 planes [N/32][K/16][lane = (k%16)/8*32 + n%32][k%8]. */
   int32_t gemm_mode;
   /* gemm_mode 1, optional (NULL: the point-wise layers run on the tiles above at every size): the ConvNeXt pwconv1 / pwconv2
    * weights once more as PRE-SPLIT planes in MFMA fragment order, [N/32][K/16][hi|lo][lane = (k%16)/8*32 + n%32][k%8] bf16, for the
@@ -292,6 +296,9 @@ int ctts_k_gemm(int32_t tiled /* 0 skinny, 1 f32 tiles, 2 split-bf16 tiles */, c
  * [rows/32][K/16][hi|lo][64][8] bf16 with rows padded to 256; epi 0: Cp = planes of gelu(A W^T + bias) (a [rows][N] matrix),
  * epi 1: C = res + gamma * (A W^T + bias), f32 [M][N].  N % 256 == 0, K % 32 == 0. */
 int ctts_k_gemm_x3p(const uint16_t* Ap, const uint16_t* Wp, int32_t M, int32_t N, int32_t K, int32_t epi, const float* bias,
+                    const float* gamma, const float* res, float* C, uint16_t* Cp, void* stream);
+/* the same on ONE fp16 plane per operand (gemm_mode 2): Ap / Wp / Cp are [rows/32][K/16][64][8] fp16; K % 64 == 0 */
+int ctts_k_gemm_h1p(const uint16_t* Ap, const uint16_t* Wp, int32_t M, int32_t N, int32_t K, int32_t epi, const float* bias,
                     const float* gamma, const float* res, float* C, uint16_t* Cp, void* stream);
 /* perf-mode projection: bf16 activations/weights, optional per-row 1/rms from 48 partial sums of squares,
  * epi 0 = f32 store, 1 = residual add (+ bf16 copy + new partial sums), 2 = SiLU(gate)*up -> bf16 */

@@ -452,6 +452,40 @@ def test_codec_lds_dma_path_equals_tile_path(weights, monkeypatch):
     assert float(np.sqrt(np.mean((w_new[2, :n] - ref[0, :n]) ** 2))) < 1e-4
 
 
+def test_codec_f16_mode_holds_the_waveform_bar(weights):
+    """gemm="f16" (the perf mode's acoustic decoder): from 12288 frames the ConvNeXt point-wise pairs take ONE fp16 MFMA per product
+    (csrc/codec_gemm.hip: gemm_h1p_k; planes written by the depthwise-conv + LayerNorm kernel and the GELU epilogue).  Stated
+    bounds, against the split-bf16 decoder (itself 4e-7 from the float32 oracle) on a 16 x 400-token ragged batch: mel within
+    2e-3 of its peak, waveform within 2e-5 RMS -- a fifth of the north-star's 1e-4 -- and within 1e-4 RMS of the numpy oracle on
+    a row slice.  Below 12288 frames the mode runs the split-bf16 tiles, i.e. equals gemm="bf16x3"."""
+    rs = np.random.RandomState(33)
+    rows = [torch.from_numpy(rs.standard_normal((n, 768)).astype(np.float32)) for n in [400, 390, 120, 400] + [300] * 12]
+    ref_eng = E.CodecEngine(weights["decoder"], weights["vocos"], DEV, gemm="bf16x3")
+    f16_eng = E.CodecEngine(weights["decoder"], weights["vocos"], DEV, gemm="f16")
+    Tmax = 400
+    batch = torch.zeros((16, Tmax, 768))
+    for i, r in enumerate(rows):
+        batch[i, : r.shape[0]] = r
+    mel_ref = ref_eng.dvae_decode(batch).cpu().numpy()
+    mel_f16 = f16_eng.dvae_decode(batch).cpu().numpy()
+    merr = float(np.abs(mel_f16 - mel_ref).max() / np.abs(mel_ref).max())
+    w_ref = ref_eng.decode_to_wavs(rows).cpu().numpy()
+    w_f16 = f16_eng.decode_to_wavs(rows).cpu().numpy()
+    assert w_f16.shape == w_ref.shape == (16, 256 * 799) and np.isfinite(w_f16).all()
+    rms = float(np.sqrt(np.mean((w_f16 - w_ref) ** 2)))
+    print(f"codec f16 vs bf16x3: mel max err / peak {merr:.2e}, wav rms diff {rms:.2e} (signal rms {float(np.sqrt(np.mean(w_ref ** 2))):.2e})")
+    assert rms > 0.0          # the fp16 kernels really ran
+    assert merr < 2e-3, merr
+    assert rms < 2e-5, rms
+    dsd = {k: v.numpy() for k, v in weights["decoder"].items()}
+    vsd = {k: v.numpy() for k, v in weights["vocos"].items()}
+    ref = codec_np.decode_to_wavs(dsd, vsd, [rows[2].numpy()])
+    n = 256 * (2 * 100 - 1) - 256 * 110
+    assert float(np.sqrt(np.mean((w_f16[2, :n] - ref[0, :n]) ** 2))) < 1e-4
+    small = [r[:40] for r in rows[:4]]               # 320 frames: below the threshold the mode IS the split-bf16 decoder
+    assert torch.equal(f16_eng.decode_to_wavs(small), ref_eng.decode_to_wavs(small))
+
+
 def test_decode_window_equals_slices_of_the_full_decode(codec):
     """`CodecEngine.decode_window` (what streaming emits): any sample range of the batch decode, computed from the token
     window it depends on (+ halos) -- interior ranges, ranges touching either end, ragged rows shorter than the window"""

@@ -367,6 +367,56 @@ def test_gemm_tiled_bf16x3_big_tile_linear(G, M, N, K, epi):
 
 @pytest.mark.parametrize("M", [12288, 16400, 300])
 @pytest.mark.parametrize("N,K,epi", [(2048, 512, 0), (512, 2048, 1), (1536, 512, 0), (512, 1536, 1)])
+def test_gemm_h1p(G, M, N, K, epi):
+    """the same pair on ONE fp16 plane per operand (gemm_mode 2, csrc/codec_gemm.hip: gemm_h1p_k).  Against float64 on the SAME
+    fp16-rounded operands the kernel is exact up to f32 accumulation (3e-5, the x3p bar); against the unrounded operands the
+    stated bound is the rounding of both operands to 11 significant bits: relative error of the result < 1e-3.  The GELU
+    epilogue's output is itself rounded to fp16 (one more 2^-11)."""
+    from chattts_amd.engine import pack_h1p, unpack_h1p
+    lib = _lib.lib()
+    rs = np.random.RandomState(M + N + K + 1)
+    Mp = (M + 255) // 256 * 256
+    A = np.zeros((Mp, K), f32)
+    A[:M] = rs.standard_normal((M, K)).astype(f32)
+    W = (rs.standard_normal((N, K)) / np.sqrt(K)).astype(f32)
+    bias = rs.standard_normal(N).astype(f32) * 0.1
+    if epi == 0:
+        bias[0] = 1e5                               # column 0 of gelu(.) leaves the half range: saturated to 65504 where it is rounded, never inf
+    gam = (0.05 + 0.1 * rs.rand(N)).astype(f32)
+    res = rs.standard_normal((M, N)).astype(f32)
+    Ap_h = pack_h1p(torch.from_numpy(A))
+    Wp_h = pack_h1p(torch.from_numpy(W))
+    Ar, Wr = unpack_h1p(Ap_h, Mp, K).numpy(), unpack_h1p(Wp_h, N, K).numpy()      # what the kernel multiplies
+    Ap, Wp = Ap_h.to(G.DEV), Wp_h.to(G.DEV)
+    b_d, g_d = G.dev(bias), G.dev(gam)
+    acc = Ar[:M].astype(np.float64) @ Wr.astype(np.float64).T
+    acc_full = A[:M].astype(np.float64) @ W.astype(np.float64).T
+    if epi == 0:
+        Cp = torch.zeros((Mp * N,), dtype=torch.float16, device=G.DEV)
+        _lib.check(lib.ctts_k_gemm_h1p(Ap.data_ptr(), Wp.data_ptr(), M, N, K, 0, b_d.data_ptr(), None, None, None, Cp.data_ptr(), None), "h1p gelu")
+        torch.cuda.synchronize()
+        got = unpack_h1p(Cp.cpu(), Mp, N).numpy()[:M]
+        assert (got[:, 0] == 65504.0).all()
+        got = got[:, 1:]
+        ref = codec_np.gelu((acc + bias).astype(f32))[:, 1:]
+        ref_full = codec_np.gelu((acc_full + bias).astype(f32))[:, 1:]
+        tol_same = 6e-4                              # the output's own fp16 rounding
+    else:
+        C_d = G.dev(res).clone()
+        _lib.check(lib.ctts_k_gemm_h1p(Ap.data_ptr(), Wp.data_ptr(), M, N, K, 1, b_d.data_ptr(), g_d.data_ptr(), C_d.data_ptr(), C_d.data_ptr(),
+                                       None, None), "h1p res")
+        torch.cuda.synchronize()
+        got = C_d.cpu().numpy()
+        ref = res + gam * (acc + bias)
+        ref_full = res + gam * (acc_full + bias)
+        tol_same = 3e-5
+    assert np.isfinite(got).all()
+    assert G.relerr(got, ref) < tol_same, G.relerr(got, ref)
+    assert G.relerr(got, ref_full) < 1e-3, G.relerr(got, ref_full)
+
+
+@pytest.mark.parametrize("M", [12288, 16400, 300])
+@pytest.mark.parametrize("N,K,epi", [(2048, 512, 0), (512, 2048, 1), (1536, 512, 0), (512, 1536, 1)])
 def test_gemm_x3p(G, M, N, K, epi):
     """split-bf16 GEMM on pre-split fragment-order planes, LDS-DMA staged (csrc/codec_gemm.hip): both epilogues of the ConvNeXt
     point-wise pair at every DVAE / Vocos shape, ragged last row tile (M not a multiple of 256), vs float64"""

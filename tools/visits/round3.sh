@@ -440,7 +440,53 @@ r3ad() {   # three KV blocks in flight per wave (CTTS_ATT_NBUF=3) vs two: parity
   cut -c1-420 gpurun_out/${T}_ab.log
 }
 
+r3ae() {   # the perf mode's acoustic decoder on one fp16 MFMA per product (gemm="f16"): kernel + e2e tests, then A/B on C3
+  T=r3ae
+  timeout 600 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -k "h1p or x3p or codec or decode_to_wavs or decode_window or stream" > gpurun_out/${T}_tests.log 2>&1; tail -5 gpurun_out/${T}_tests.log
+  grep "codec f16 vs" gpurun_out/${T}_tests.log
+  Q="--steps 4 --warmup 1 --no-cpu-baseline --no-ttfs --no-bf16-parity --parity-steps 2"
+  ab() { L=$1; shift; echo "== $L" >> gpurun_out/${T}_ab.log
+    timeout 300 python bench.py $Q "$@" 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], 'parity', d['parity_mode']['value'], d['parity_mode']['ids_match_reference'], 'codec_parity', d.get('codec_parity'), {k: (v['avg_launch_us'], v['frac']) for k, v in d['roofline_mfma'].items()})" >> gpurun_out/${T}_ab.log 2>&1; }
+  for rep in 1 2; do
+  ab "decoder bf16x3" --codec-gemm bf16x3
+  ab "decoder f16" --codec-gemm f16
+  done
+  cut -c1-900 gpurun_out/${T}_ab.log
+}
+
+r3af() {   # gemm_h1p_k with fragment reads one k block ahead + the branch-free GELU: tests, GEMM timings, C3
+  T=r3af
+  timeout 600 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -k "h1p or f16_mode" > gpurun_out/${T}_tests.log 2>&1; tail -3 gpurun_out/${T}_tests.log
+  grep "codec f16 vs" gpurun_out/${T}_tests.log
+  Q="--steps 4 --warmup 1 --no-cpu-baseline --no-ttfs --no-bf16-parity --parity-steps 1"
+  for rep in 1 2; do
+  timeout 300 python bench.py $Q 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], 'codec_parity', d['codec_parity']['wav_rms_diff'], {k: (v['avg_launch_us'], v['frac']) for k, v in d['roofline_mfma'].items()})" >> gpurun_out/${T}_ab.log 2>&1
+  done
+  cat gpurun_out/${T}_ab.log
+  cd /tmp
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${T} -o ${T} -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-ttfs --no-parity-mode --no-bf16-parity > $R/gpurun_out/${T}_rocprof.log 2>&1
+  F=$(find /tmp/prof_${T} -name "*kernel_stats.csv" | head -1); [ -n "$F" ] && cp $F $R/gpurun_out/${T}_kernel_stats.csv && grep -v "gemm_dec_k\|attention_k" $F | head -14 | cut -c1-150
+  cd "$R"
+}
+
+r3ag() {   # where a 256 x 256 tile of gemm_h1p_k spends its time
+  T=r3ag
+  CTTS_H1P_PROBE=1 timeout 200 python tools/x3p_phase_probe.py --h1p 2>&1 | grep -v "amdgpu.ids\|incomplete" > gpurun_out/${T}_h1p_phase_probe.log; cat gpurun_out/${T}_h1p_phase_probe.log
+}
+
+r3ah() {   # residual epilogues without the load-after-store chain (gemm_x3p_k, gemm_h1p_k, the tiled kernels): tests, phase probe, C3, C5
+  T=r3ah
+  timeout 600 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -k "h1p or x3p or codec or decode_to_wavs or decode_window or stream or gemm_tiled or dvae" > gpurun_out/${T}_tests.log 2>&1; tail -3 gpurun_out/${T}_tests.log
+  CTTS_H1P_PROBE=1 timeout 200 python tools/x3p_phase_probe.py --h1p 2>&1 | grep -v "amdgpu.ids\|incomplete" > gpurun_out/${T}_h1p_phase_probe.log; cat gpurun_out/${T}_h1p_phase_probe.log
+  Q="--steps 4 --warmup 1 --no-cpu-baseline --no-ttfs --no-bf16-parity --parity-steps 2"
+  for rep in 1 2; do
+  timeout 300 python bench.py $Q 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], 'parity', d['parity_mode']['value'], d['parity_mode']['ids_match_reference'], 'codec_parity', d['codec_parity']['wav_rms_diff'], {k: (v['avg_launch_us'], v['frac']) for k, v in d['roofline_mfma'].items()})" >> gpurun_out/${T}_ab.log 2>&1
+  done
+  cat gpurun_out/${T}_ab.log
+  timeout 300 python tools/configs_run.py 2>&1 | grep -v "amdgpu.ids\|incomplete" > gpurun_out/${T}_configs.log; cut -c1-400 gpurun_out/${T}_configs.log
+}
+
 case "$1" in
-  r3a|r3b|r3c|r3d|r3e|r3f|r3g|r3h|r3i|r3j|r3k|r3l|r3m|r3n|r3o|r3p|r3q|r3r|r3s|r3t|r3u|r3v|r3w|r3x|r3y|r3z|r3ab|r3ac|r3ad|r3ae|r3af) "$1" ;;
+  r3a|r3b|r3c|r3d|r3e|r3f|r3g|r3h|r3i|r3j|r3k|r3l|r3m|r3n|r3o|r3p|r3q|r3r|r3s|r3t|r3u|r3v|r3w|r3x|r3y|r3z|r3ab|r3ac|r3ad|r3ae|r3af|r3ag|r3ah|r3ai|r3aj|r3ak) "$1" ;;
   *) echo "usage: round3.sh <" 'r3a r3b r3c r3d r3e r3f r3g r3h r3i r3j r3k r3l r3m r3n r3o r3p r3q r3r r3s r3t r3u r3v r3w r3x r3y r3z' ">"; exit 2 ;;
 esac
