@@ -289,12 +289,15 @@ __device__ __forceinline__ size_t h1p_off(int r, int k, int kb16) {
   return (((size_t)(r >> 5) * kb16 + (k >> 4)) * 64 + (((k & 15) >> 3) << 5) + (r & 31)) * 8 + (k & 7);
 }
 
-template <int EPI, bool PROBE = false>   // PROBE (CTTS_H1P_PROBE=1 + CTTS_X3_DBG_PTR, tools/x3p_phase_probe.py --h1p): wave 0 accumulates 100 MHz phase times
+// PROBE (CTTS_H1P_PROBE=1 + CTTS_X3_DBG_PTR, tools/x3p_phase_probe.py --h1p): wave 0 accumulates 100 MHz phase times.
+// NS: ring slots.  4 = stages of two slots, one in flight (64 KiB) while the other is multiplied; 5 (CTTS_H1P_RING=5, all 160 KiB of
+// the CU's LDS) = one slot per barrier, FOUR in flight (128 KiB) -- the A/B of "is the loop bound by the fill's latency or by its rate".
+template <int EPI, bool PROBE = false, int NS = 4>
 __global__ __launch_bounds__(512, 2) void gemm_h1p_k(X3pArgs a) {
   constexpr int BM = 256, BN = 256;
   constexpr int FRAG = 512;                 // fp16 elements of one fragment (1 KiB): 32 rows x 16 of k
   constexpr int SLOT = 32 * FRAG;           // one ring slot = a 32-wide k block of the tile: (8 A + 8 W row tiles) x 2 fragments = 32 KiB
-  constexpr int NSLOT = 4;
+  constexpr int NSLOT = NS;
   __shared__ __attribute__((aligned(16))) uint16_t lds[NSLOT * SLOT];
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -310,7 +313,7 @@ __global__ __launch_bounds__(512, 2) void gemm_h1p_k(X3pArgs a) {
   const uint16_t* ag = a.Ap + ((size_t)((m0 >> 5) + wave) * kb16) * FRAG + lane * 8;
   const uint16_t* wg = a.Wp + ((size_t)((n0 >> 5) + wave) * kb16) * FRAG + lane * 8;
   auto issue = [&](int q) {   // 32-wide k block q -> slot q % 4: 4 LDS-DMA pieces of 1 KiB per wave
-    uint16_t* la = lds + (q & (NSLOT - 1)) * SLOT + wave * 2 * FRAG;
+    uint16_t* la = lds + (q % NSLOT) * SLOT + wave * 2 * FRAG;
     uint16_t* lw = la + 16 * FRAG;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -338,7 +341,7 @@ __global__ __launch_bounds__(512, 2) void gemm_h1p_k(X3pArgs a) {
   const int np = K >> 6;   // K % 64 == 0
   f16x8 fa0[2], fw0[4], fa1[2], fw1[4];
   auto rd = [&](f16x8* fa, f16x8* fw, int u) {   // fragments of 16-wide k block u
-    const uint16_t* la = lds + ((u >> 1) & (NSLOT - 1)) * SLOT + lane * 8;
+    const uint16_t* la = lds + ((u >> 1) % NSLOT) * SLOT + lane * 8;
     const uint16_t* lw = la + 16 * FRAG;
     const int h = u & 1;
 #pragma unroll
@@ -361,6 +364,40 @@ __global__ __launch_bounds__(512, 2) void gemm_h1p_k(X3pArgs a) {
   long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0, t_begin = 0;
 #define H1P_MARK(i) do { if (PROBE) { const long long tn = wall_clock64(); tacc[i] += tn - tprev; tprev = tn; } } while (0)
   if (PROBE) t_begin = tprev = wall_clock64();
+  if constexpr (NS != 4) {
+    // one 32-wide slot per barrier, NS - 1 slots in flight behind it.  Waiting for slot t leaves the pieces of the slots issued
+    // after it outstanding: min(nq - 1, t + NS - 2) - t slots x 4 pieces of this wave (vmcnt counts in order).
+    const int nq = K >> 5;
+    auto wait_slot = [&](int t) {
+      const int younger = min(nq - 1, t + NS - 2) - t;
+      if (younger >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else if (younger == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    for (int q = 0; q < NS - 1 && q < nq; ++q) issue(q);
+    wait_slot(0);
+    __builtin_amdgcn_s_barrier();
+    if (NS - 1 < nq) issue(NS - 1);
+    rd(fa0, fw0, 0);
+    H1P_MARK(0);
+    for (int q = 0; q < nq; ++q) {
+      H1P_SB(); mm_a(fa0, fw0); H1P_SB(); rd(fa1, fw1, 2 * q + 1); H1P_SB(); mm_b(fa0, fw0);
+      H1P_SB(); mm_a(fa1, fw1); H1P_SB();
+      H1P_MARK(1);
+      if (q + 1 < nq) {   // slot boundary: this wave's fragments of slot q are in registers -> after the barrier the slot is refilled
+        wait_slot(q + 1);
+        H1P_MARK(2);
+        __builtin_amdgcn_s_barrier();
+        H1P_MARK(3);
+        if (q + NS < nq) issue(q + NS);
+        rd(fa0, fw0, 2 * q + 2);
+        H1P_SB();
+        H1P_MARK(4);
+      }
+      mm_b(fa1, fw1);
+    }
+  } else {
   issue(0); issue(1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -385,6 +422,7 @@ __global__ __launch_bounds__(512, 2) void gemm_h1p_k(X3pArgs a) {
       H1P_MARK(4);   // 8 DMA pieces + 6 reads issued
     }
     mm_b(fa1, fw1);
+  }
   }
   if (PROBE) { asm volatile("s_nop 15\n\ts_nop 15" :: "v"(acc[1][3][0])); H1P_MARK(1); }
 #undef H1P_SB
@@ -457,12 +495,25 @@ __global__ __launch_bounds__(512, 2) void gemm_h1p_k(X3pArgs a) {
 }
 
 hipError_t launch_gemm_h1p(const X3pArgs& a, hipStream_t st) {
-  static int probe = -1;
-  if (probe < 0) { const char* e = getenv("CTTS_H1P_PROBE"); probe = (e && atoi(e) > 0) ? 1 : 0; }
   if (a.M <= 0 || (a.N % 256) != 0 || (a.K % 64) != 0 || a.K < 64) return hipErrorInvalidValue;
   if (a.epi != X3P_GELU_PACKED && a.epi != X3P_SCALE_RES) return hipErrorInvalidValue;
   const int tiles = (a.N / 256) * ((a.M + 255) / 256);
   dim3 grid(((tiles + 7) / 8) * 8);
+  static int probe = -1, ring = 4;
+  if (probe < 0) {
+    const char* e = getenv("CTTS_H1P_PROBE"); probe = (e && atoi(e) > 0) ? 1 : 0;
+    const char* r = getenv("CTTS_H1P_RING"); if (r && atoi(r) == 5) ring = 5;
+  }
+  if (ring == 5) {
+    if (probe && a.dbg != nullptr) {
+      if (a.epi == X3P_GELU_PACKED) CTTS_LAUNCH((gemm_h1p_k<X3P_GELU_PACKED, true, 5>), grid, dim3(512), st, a);
+      else CTTS_LAUNCH((gemm_h1p_k<X3P_SCALE_RES, true, 5>), grid, dim3(512), st, a);
+    } else {
+      if (a.epi == X3P_GELU_PACKED) CTTS_LAUNCH((gemm_h1p_k<X3P_GELU_PACKED, false, 5>), grid, dim3(512), st, a);
+      else CTTS_LAUNCH((gemm_h1p_k<X3P_SCALE_RES, false, 5>), grid, dim3(512), st, a);
+    }
+    return hipGetLastError();
+  }
   if (probe && a.dbg != nullptr) {
     if (a.epi == X3P_GELU_PACKED) CTTS_LAUNCH((gemm_h1p_k<X3P_GELU_PACKED, true>), grid, dim3(512), st, a);
     else CTTS_LAUNCH((gemm_h1p_k<X3P_SCALE_RES, true>), grid, dim3(512), st, a);

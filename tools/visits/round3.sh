@@ -486,6 +486,21 @@ r3ah() {   # residual epilogues without the load-after-store chain (gemm_x3p_k, 
   timeout 300 python tools/configs_run.py 2>&1 | grep -v "amdgpu.ids\|incomplete" > gpurun_out/${T}_configs.log; cut -c1-400 gpurun_out/${T}_configs.log
 }
 
+r3ai() {   # gemm_h1p_k with a 5-slot ring (160 KiB, four 32-wide k blocks in flight) vs the 2 x 2-slot stages: probe, tests, C3
+  T=r3ai
+  for RING in 4 5; do
+    echo "== CTTS_H1P_RING=$RING" >> gpurun_out/${T}_h1p_ring.log
+    CTTS_H1P_RING=$RING CTTS_H1P_PROBE=1 timeout 200 python tools/x3p_phase_probe.py --h1p 2>&1 | grep "^h1p" >> gpurun_out/${T}_h1p_ring.log
+  done
+  CTTS_H1P_RING=5 timeout 400 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -k "h1p or f16_mode" > gpurun_out/${T}_tests_ring5.log 2>&1; tail -2 gpurun_out/${T}_tests_ring5.log
+  Q="--steps 4 --warmup 1 --no-cpu-baseline --no-ttfs --no-bf16-parity --no-parity-mode"
+  for rep in 1 2; do for RING in 4 5; do
+    echo "== CTTS_H1P_RING=$RING" >> gpurun_out/${T}_h1p_ring.log
+    CTTS_H1P_RING=$RING timeout 300 python bench.py $Q 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], {k: (v['avg_launch_us'], v['frac']) for k, v in d['roofline_mfma'].items()})" >> gpurun_out/${T}_h1p_ring.log 2>&1
+  done; done
+  cat gpurun_out/${T}_h1p_ring.log
+}
+
 case "$1" in
   r3a|r3b|r3c|r3d|r3e|r3f|r3g|r3h|r3i|r3j|r3k|r3l|r3m|r3n|r3o|r3p|r3q|r3r|r3s|r3t|r3u|r3v|r3w|r3x|r3y|r3z|r3ab|r3ac|r3ad|r3ae|r3af|r3ag|r3ah|r3ai|r3aj|r3ak) "$1" ;;
   *) echo "usage: round3.sh <" 'r3a r3b r3c r3d r3e r3f r3g r3h r3i r3j r3k r3l r3m r3n r3o r3p r3q r3r r3s r3t r3u r3v r3w r3x r3y r3z' ">"; exit 2 ;;
