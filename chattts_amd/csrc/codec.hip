@@ -23,14 +23,14 @@ __device__ __forceinline__ void ln_finish(float* y, const float* __restrict__ lw
   const float mean = wave_sum(s) * (1.0f / C);
   float v = 0.f;
 #pragma unroll
-  for (int i = 0; i < CPL; ++i) { const float d = y[i] - mean; v += d * d; }
+  for (int i = 0; i < CPL; ++i) { const float d = y[i] - mean; v = fmaf(d, d, v); }   // explicit: the same bits in every kernel this is inlined into
   const float rstd = 1.0f / sqrtf(wave_sum(v) * (1.0f / C) + eps);
 #pragma unroll
   for (int q = 0; q < CPL / 4; ++q) {
     const float4 w = *reinterpret_cast<const float4*>(lw + c0 + 4 * q), b = *reinterpret_cast<const float4*>(lb + c0 + 4 * q);
     float4 o;
-    o.x = (y[4 * q + 0] - mean) * rstd * w.x + b.x; o.y = (y[4 * q + 1] - mean) * rstd * w.y + b.y;
-    o.z = (y[4 * q + 2] - mean) * rstd * w.z + b.z; o.w = (y[4 * q + 3] - mean) * rstd * w.w + b.w;
+    o.x = fmaf((y[4 * q + 0] - mean) * rstd, w.x, b.x); o.y = fmaf((y[4 * q + 1] - mean) * rstd, w.y, b.y);
+    o.z = fmaf((y[4 * q + 2] - mean) * rstd, w.z, b.z); o.w = fmaf((y[4 * q + 3] - mean) * rstd, w.w, b.w);
     if (planes == nullptr) *reinterpret_cast<float4*>(dst + c0 + 4 * q) = o;
     else { y[4 * q] = o.x; y[4 * q + 1] = o.y; y[4 * q + 2] = o.z; y[4 * q + 3] = o.w; }
   }
@@ -94,11 +94,88 @@ __global__ __launch_bounds__(256) void dwconv_ln_k(const float* __restrict__ x, 
   ln_finish<CPL, F16>(acc, lw, lb, eps, c0, y + (size_t)row * C, yp, row);
 }
 
+// Large batches (round 3): the kernel above gives every frame its own wave, so each input row is requested by the 7 waves whose taps
+// touch it -- 0.94 GB of L2 reads per launch at 65,536 frames for 134 MB of input, 130 us where HBM would need 40.  Here a wave walks
+// RUN frames f0, f0 + dil, f0 + 2 dil, ... of one utterance (a run of RUN * dil consecutive frames is shared by `dil` waves, one per
+// phase) and keeps the 7 rows of its current frame in a register ring of 9 (two rows requested ahead): every row is loaded once per
+// wave that needs it (+ 6 / RUN halo), the depthwise weights (56 registers) and the bias once per wave instead of once per frame.
+// Same arithmetic per frame as dwconv_ln_k: acc = bias, taps 0..6 in order (a tap outside [0, F) multiplies a zero row).
+template <int CPL, bool F16>
+__global__ __launch_bounds__(256) void dwconv_ln_run_k(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                                       const float* __restrict__ lw, const float* __restrict__ lb, float eps, int dil,
+                                                       float* __restrict__ y, int F, int B, int runs, uint16_t* __restrict__ yp) {
+  constexpr int C = 64 * CPL;
+  constexpr int RUN = 36, NSL = 9;   // RUN % NSL == 0: the ring indices below are compile-time constants
+  const int per = gridDim.x >> 3;    // XCD-aware order: one contiguous range of (utterance, run, phase) per XCD (see dwconv_ln_k)
+  const int blk = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  const int gw = blk * 4 + (threadIdx.x >> 6);
+  const int wpu = runs * dil;        // waves per utterance
+  if (gw >= B * wpu) return;
+  const int bi = gw / wpu, rem = gw - bi * wpu;
+  const int run = rem / dil, ph = rem - run * dil;
+  const int f0 = run * (RUN * dil) + ph;
+  if (f0 >= F) return;
+  const int lane = threadIdx.x & 63, c0 = lane * CPL;
+  float wt[7][CPL], bias[CPL];
+#pragma unroll
+  for (int q = 0; q < CPL / 4; ++q) {
+    const float4 b0 = *reinterpret_cast<const float4*>(b + c0 + 4 * q);
+    bias[4 * q] = b0.x; bias[4 * q + 1] = b0.y; bias[4 * q + 2] = b0.z; bias[4 * q + 3] = b0.w;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      const float4 w0 = *reinterpret_cast<const float4*>(w + j * C + c0 + 4 * q);
+      wt[j][4 * q] = w0.x; wt[j][4 * q + 1] = w0.y; wt[j][4 * q + 2] = w0.z; wt[j][4 * q + 3] = w0.w;
+    }
+  }
+  const float* xb = x + (size_t)bi * F * C + c0;
+  float s[NSL][CPL];
+  auto ldrow = [&](float* dst, int t_rel) {   // row f0 + dil * t_rel, zeros outside the utterance (Conv1d zero padding)
+    const int r = f0 + dil * t_rel;
+    const bool ok = r >= 0 && r < F;
+    const float* xp = xb + (size_t)min(max(r, 0), F - 1) * C;
+#pragma unroll
+    for (int q = 0; q < CPL / 4; ++q) {
+      const float4 v = *reinterpret_cast<const float4*>(xp + 4 * q);
+      dst[4 * q] = ok ? v.x : 0.f; dst[4 * q + 1] = ok ? v.y : 0.f; dst[4 * q + 2] = ok ? v.z : 0.f; dst[4 * q + 3] = ok ? v.w : 0.f;
+    }
+  };
+  // slot (t + k) % NSL holds row t - 3 + k (k = 0..8): the 7 taps of frame t are k = 0..6, k = 7, 8 are on their way
+#pragma unroll
+  for (int k = 0; k < NSL - 1; ++k) ldrow(s[k], k - 3);
+  for (int t0 = 0; t0 < RUN; t0 += NSL) {
+#pragma unroll
+    for (int u = 0; u < NSL; ++u) {
+      const int t = t0 + u, f = f0 + dil * t;
+      if (f >= F) return;                     // wave-uniform
+      ldrow(s[(u + NSL - 1) % NSL], t + 5);   // row t + 5 = k 8 of this frame
+      float acc[CPL];
+#pragma unroll
+      for (int i = 0; i < CPL; ++i) acc[i] = bias[i];
+#pragma unroll
+      for (int j = 0; j < 7; ++j)
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) acc[i] = fmaf(wt[j][i], s[(u + j) % NSL][i], acc[i]);
+      const int row = bi * F + f;
+      ln_finish<CPL, F16>(acc, lw, lb, eps, c0, y + (size_t)row * C, yp, row);
+    }
+  }
+}
+
 hipError_t launch_dwconv_ln(const float* x, const float* w, const float* b, const float* ln_w, const float* ln_b, float eps, int dil,
                             float* y, int B, int F, int C, hipStream_t st, uint16_t* yp, int plane_f16) {
   const int rows = B * F;
   const int nblk = ((rows + 3) / 4 + 7) / 8 * 8;   // multiple of 8: one contiguous run of frames per XCD (see the kernel)
   if (yp != nullptr && C != 512) return hipErrorInvalidValue;
+  static int run_min = -1;   // CTTS_DWCONV_RUN_MIN_ROWS: frames from which the sliding-window kernel is used (0 = never); below it one wave per frame
+  if (run_min < 0) { const char* e = getenv("CTTS_DWCONV_RUN_MIN_ROWS"); run_min = e ? atoi(e) : 12288; }
+  if (C == 512 && run_min > 0 && rows >= run_min && dil >= 1 && dil <= 4) {
+    const int runs = (F + 36 * dil - 1) / (36 * dil);
+    const int waves = B * runs * dil;
+    const int nb = ((waves + 3) / 4 + 7) / 8 * 8;
+    if (yp != nullptr && plane_f16) hipLaunchKernelGGL((dwconv_ln_run_k<8, true>), dim3(nb), dim3(256), 0, st, x, w, b, ln_w, ln_b, eps, dil, y, F, B, runs, yp);
+    else hipLaunchKernelGGL((dwconv_ln_run_k<8, false>), dim3(nb), dim3(256), 0, st, x, w, b, ln_w, ln_b, eps, dil, y, F, B, runs, yp);
+    return hipGetLastError();
+  }
   if (C == 512 && yp != nullptr && plane_f16) hipLaunchKernelGGL((dwconv_ln_k<8, true>), dim3(nblk), dim3(256), 0, st, x, w, b, ln_w, ln_b, eps, dil, y, F, rows, yp);
   else if (C == 512) hipLaunchKernelGGL(dwconv_ln_k<8>, dim3(nblk), dim3(256), 0, st, x, w, b, ln_w, ln_b, eps, dil, y, F, rows, yp);
   else if (C == 256) hipLaunchKernelGGL(dwconv_ln_k<4>, dim3(nblk), dim3(256), 0, st, x, w, b, ln_w, ln_b, eps, dil, y, F, rows, (uint16_t*)nullptr);

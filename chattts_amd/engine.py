@@ -113,6 +113,13 @@ class GenerationOutputs:          # gpt.py:276-285
         self.hiddens.clear()
 
 
+class RowList(list):
+    """The per-utterance rows of a result (what the reference hands around as a plain list) that are VIEWS of one zero-padded
+    [B, Tmax, ...] tensor, `padded` -- the batch `Chat._decode_to_wavs` would rebuild from them row by row (core.py:525-533).
+    `CodecEngine.decode_to_wavs` takes it as is; any list operation (slicing, copying) yields a plain list and the generic path."""
+    padded: Optional[torch.Tensor] = None
+
+
 class Context:                    # gpt.py:103-111
     def __init__(self):
         self._interrupt = False
@@ -600,6 +607,25 @@ class GptEngine:
             # copies, on the caller's stream behind the poll-time event: the session's buffers are reused by the next
             # call of the same geometry, results must not alias them
             with torch.cuda.stream(caller):
+                if len(L) == 1 and max(L[0].end_snap, default=0) > 0:
+                    # one lane (the default): ONE strided copy per result instead of one clone per row (128 launches for a batch of 64,
+                    # ~1.5 ms of host time between the last decode step and the acoustic decoder); rows are views of the copies, the
+                    # hidden states come zero padded -- the batch the decoder needs (RowList.padded)
+                    ln = L[0]
+                    e, nb = ln.end_snap, ln.hi - ln.lo
+                    Tm = max(e)
+                    caller.wait_event(ln.ev)
+                    ids_all = (ln.ids_buf[:nb, T: T + Tm, 0] if infer_text else ln.ids_buf[:nb, T: T + Tm]).clone()   # gpt.py:297-301
+                    ids = [ids_all[b, : e[b]] for b in range(nb)]
+                    hid = RowList()
+                    if return_hidden:                                                                                 # gpt.py:303-307
+                        e_d = torch.tensor(e, dtype=torch.int32).to(dev, non_blocking=True)
+                        keep = torch.arange(Tm, device=dev, dtype=torch.int32)[None, :] < e_d[:, None]
+                        hid.padded = torch.where(keep[..., None], ln.hiddens[:nb, :Tm], ln.hiddens.new_zeros(()))
+                        hid.extend(hid.padded[b, : e[b]] for b in range(nb))
+                    sess["out_ev"] = torch.cuda.Event()
+                    sess["out_ev"].record(caller)
+                    return GenerationOutputs(ids=ids, attentions=[], hiddens=hid)
                 for ln in L:
                     e = ln.end_snap
                     caller.wait_event(ln.ev)
@@ -1124,6 +1150,10 @@ class CodecEngine:
         longest row, DVAE decode, Vocos decode -> [B, 256(2Tmax-1)] float32 on the device."""
         if len(result_list) == 0:
             return torch.empty((0,), dtype=torch.float32)
+        pad = getattr(result_list, "padded", None)
+        if (pad is not None and pad.dim() == 3 and pad.shape[0] == len(result_list) and pad.shape[2] == GPT.hidden and pad.device == self.device
+                and pad.dtype == torch.float32 and pad.shape[1] == max(int(r.size(0)) for r in result_list)):
+            return self.vocos_decode(self.dvae_decode(pad))      # GptEngine.generate's rows: views of exactly this batch (RowList)
         Tmax = max(int(r.size(0)) for r in result_list)
         batch = torch.zeros((len(result_list), Tmax, GPT.hidden), dtype=torch.float32, device=self.device)
         for i, r in enumerate(result_list):

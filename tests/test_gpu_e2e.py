@@ -380,6 +380,26 @@ def test_codec_vs_reference_golden(codec, golden, name):
     assert rms < 1e-4, rms   # north_star: float32 waveform within 1e-4 RMS (signal rms ~ 3.5e-2)
 
 
+def test_generate_rows_are_views_of_the_padded_batch(gpt_f32, weights):
+    """`GptEngine.generate` hands out its per-utterance rows as views of ONE copy per result (engine.RowList): the hidden rows sit in
+    the zero-padded [B, Tmax, 768] batch `_decode_to_wavs` would rebuild from them (core.py:525-533), which the decoder takes as
+    is.  Same waveform, bit for bit, as the generic path over a plain list of the same rows; ragged lengths (b8)."""
+    outs, _ = run_case(gpt_f32, cases.GEN_CASES["b8"], use_graph=True)
+    out = outs[-1]
+    lens = [int(r.shape[0]) for r in out.hiddens]
+    assert isinstance(out.hiddens, E.RowList) and out.hiddens.padded is not None and len(set(lens)) > 1
+    pad = out.hiddens.padded
+    assert tuple(pad.shape) == (len(lens), max(lens), 768)
+    for b, n in enumerate(lens):
+        assert torch.equal(pad[b, :n], out.hiddens[b]) and not bool(pad[b, n:].any())
+        assert out.ids[b].shape[0] == n and out.ids[b].is_contiguous() and out.hiddens[b].is_contiguous()
+    codec = E.CodecEngine(weights["decoder"], weights["vocos"], DEV)
+    fast = codec.decode_to_wavs(out.hiddens)
+    plain = codec.decode_to_wavs([r.clone() for r in out.hiddens])
+    assert torch.equal(fast, plain)
+    assert torch.equal(codec.decode_to_wavs(out.hiddens[:3]), codec.decode_to_wavs([r.clone() for r in out.hiddens[:3]]))   # a slice is a plain list
+
+
 def test_decode_to_wavs_padding(codec, weights):
     """ragged rows are zero padded like core.py:525-533; compare with the oracle on a larger batch"""
     rs = np.random.RandomState(4)

@@ -826,6 +826,34 @@ def test_dwconv_ln(G, dil):
     assert np.abs(y2.cpu().numpy() - codec_np.layer_norm(x, lw, lb, 1e-6).reshape(B * F, Cc)).max() < 2e-5
 
 
+@pytest.mark.parametrize("dil,B,F", [(1, 13, 1000), (2, 13, 1000), (2, 7, 1900), (1, 200, 70)])
+def test_dwconv_ln_sliding_window(G, dil, B, F):
+    """from 12288 frames the depthwise conv + LayerNorm runs as `dwconv_ln_run_k` (a wave walks 36 frames of one utterance and phase,
+    7 rows in a register ring): ragged run ends, utterances shorter than one run, both dilations, vs the numpy oracle -- and bit
+    for bit the one-wave-per-frame kernel's result (same taps in the same order)."""
+    lib = _lib.lib()
+    rs = np.random.RandomState(dil + F)
+    Cc = 512
+    assert B * F >= 12288
+    x = rs.standard_normal((B, F, Cc)).astype(f32)
+    w = rs.standard_normal((Cc, 1, 7)).astype(f32) * 0.4
+    b = rs.standard_normal(Cc).astype(f32) * 0.1
+    lw = (1 + 0.1 * rs.standard_normal(Cc)).astype(f32)
+    lb = rs.standard_normal(Cc).astype(f32) * 0.1
+    y = torch.empty((B, F, Cc), dtype=torch.float32, device=G.DEV)
+    keep = [G.dev(x), G.dev(np.ascontiguousarray(w[:, 0, :].T)), G.dev(b), G.dev(lw), G.dev(lb)]
+    _lib.check(lib.ctts_k_dwconv_ln(*[k.data_ptr() for k in keep], 1e-6, dil, y.data_ptr(), B, F, None), "dwconv_ln")
+    got = y.cpu().numpy()
+    ref = codec_np.layer_norm(codec_np.dwconv1d_cl(x[:3], w, b, pad=3 * dil, dil=dil), lw, lb, 1e-6)
+    assert np.abs(got[:3] - ref).max() < 2e-5
+    # the small-batch kernel on slices of the same input (below the threshold) must give the same bits
+    for lo in (0, B - 3):
+        ys = torch.empty((3, F, Cc), dtype=torch.float32, device=G.DEV)
+        xs = G.dev(x[lo: lo + 3])
+        _lib.check(lib.ctts_k_dwconv_ln(xs.data_ptr(), *[k.data_ptr() for k in keep[1:]], 1e-6, dil, ys.data_ptr(), 3, F, None), "dwconv_ln small")
+        assert np.array_equal(ys.cpu().numpy(), got[lo: lo + 3])
+
+
 @pytest.mark.parametrize("B,F", [(1, 2), (2, 9), (3, 40)])
 def test_istft(G, B, F):
     import math
