@@ -218,6 +218,7 @@ def main():
     ap.add_argument("--pipeline", action="store_true", help="time the main leg as a software-pipelined queue of batches (batch i's acoustic decode "
                     "overlaps batch i+1's generation); default: one batch after the other, the pipelined figure is reported beside it")
     ap.add_argument("--parity-steps", type=int, default=5, help="timed passes of the f32 parity mode")
+    ap.add_argument("--no-slot-pool", action="store_true", help="skip the continuous-batching leg (serving.SlotPool over 4 batches' worth of requests)")
     ap.add_argument("--codec-gemm", default=None, choices=["f16", "bf16x3", "f32"],
                     help="dense-layer arithmetic of the acoustic decoder in the main leg (default: f16 with --dtype bf16, bf16x3 with f32; "
                          "the parity-mode leg always decodes with bf16x3)")
@@ -385,6 +386,52 @@ def main():
         result["pipelined_queue"] = {"value": round(audio_seconds(stop) * 4 / dtp, 2), "unit": "audio-s/s", "steps": 4, "ms_per_step": round(1000.0 * dtp / 4, 3),
                                      "what": "the acoustic decode + waveform D2H of batch i on the codec engine's side HIP stream while batch i+1 is "
                                              "generated; all waveforms on the host before the clock stops"}
+    if world == 1 and not args.pipeline and not args.no_slot_pool and args.dtype == "bf16":
+        # the same utterances as a QUEUE served by continuous batching (chattts_amd/serving.py): 4 batches' worth of
+        # requests through a pool of `batch` slots -- a request is admitted the moment a slot frees up, so the decode step stays full
+        # instead of thinning out towards the longest row of a fixed batch; finished requests are decoded to audio in groups of
+        # `batch` on the codec engine's side stream.  Reported beside `value`; every request's tokens are those of its isolated
+        # generation at its pool row (tests/test_gpu_e2e.py::test_continuous_batching_equals_isolated_generation).
+        note("continuous batching over a slot pool")
+        from chattts_amd.serving import SlotPool
+        nq = 4
+        pool = SlotPool(gpt, slots=args.batch, cap=48 + args.max_len + 2 + 2 * SlotPool.POLL, hid_cap=args.max_len + 8, manual_seed=42)
+
+        def pool_pass():
+            for k in range(nq):
+                for b in range(ids_t.shape[0]):
+                    m = mask_t[b].bool()
+                    pool.submit((k, b), ids_t[b][m], tm_t[b][m], max_new_token=int(stop[b]) + 1, stop_at=int(stop[b]))
+            done, pend, n_tok = [], [], 0
+            for rid, ids_r, hid_r in pool.run():
+                assert ids_r.shape[0] == int(stop[rid[1]]), "forced length not honoured in the pool"
+                n_tok += int(ids_r.shape[0])
+                done.append(hid_r)
+                if len(done) == args.batch:
+                    pend.append(codec.decode_to_wavs_async(done))
+                    done = []
+            if done:
+                pend.append(codec.decode_to_wavs_async(done))
+            wavs = [p_.result() for p_ in pend]
+            assert all(w.dtype == np.float32 and bool(np.isfinite(w).all()) for w in wavs)
+            return n_tok
+
+        pool_pass()                       # warm-up: graph, workspaces, side-stream buffers
+        barrier()
+        steps0, adm0, t0 = pool.steps, pool.admissions, time.perf_counter()
+        n_tok = pool_pass()
+        torch.cuda.synchronize(dev)
+        dts = time.perf_counter() - t0
+        result["continuous_batching_queue"] = {
+            "value": round(audio_seconds(stop) * nq / dts, 2), "unit": "audio-s/s", "requests": nq * int(ids_t.shape[0]), "slots": args.batch,
+            "wall_ms": round(1e3 * dts, 2), "decode_steps": pool.steps - steps0, "tokens": n_tok,
+            "tokens_per_decode_step": round(n_tok / max(1, pool.steps - steps0), 2), "prefill_groups": pool.admissions - adm0,
+            "what": "serving.SlotPool: %d requests (the C3 utterances x %d) through %d slots, admission every %d decode steps, audio of every "
+                    "group of %d finished requests decoded on the side stream; all waveforms on the host before the clock stops" %
+                    (nq * int(ids_t.shape[0]), nq, args.batch, SlotPool.POLL, args.batch)}
+        pool.close()
+        del pool
+        torch.cuda.empty_cache()
     if world > 1:   # self-diagnosing multi-GPU line: who was slow, what the one collective cost
         rt = rank_times.get("main", [])
         result["ranks"] = {"world": world, "pass_ms_per_rank": rt, "pass_ms_min": min(rt) if rt else None, "pass_ms_max": max(rt) if rt else None,

@@ -26,7 +26,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._sync import wait_stream
+from ._sync import wait_event, wait_stream
 from .config import GPT
 from .engine import GptEngine, gen_logits, plan_from_processors
 from .rng import ExpDraws, penalty_table
@@ -103,9 +103,10 @@ class SlotPool:
         self.st.synchronize()
         _lib.check(self.lib.ctts_gpt_graph_build(self.handle, C.byref(self.dec), self.st.cuda_stream), "ctts_gpt_graph_build")
         self.free: List[int] = list(range(slots))
-        self.active: dict = {}                 # slot -> (_Req, Tg)
+        self.active: dict = {}                 # slot -> (_Req, Tg, first snapshot sequence number that reflects this request)
         self.queue: Deque[_Req] = deque()
         self.steps = 0
+        self.admissions = 0                   # prefill groups so far (bench.py reports it)
         self._keep = None
         self.slot_of: dict = {}               # request id -> slot it ran in (parity tests / tracing)
 
@@ -146,8 +147,9 @@ class SlotPool:
         ids = torch.as_tensor(input_ids).to(torch.int64)
         assert ids.dim() == 2 and ids.shape[1] == GPT.n_vq
         tm = torch.ones(ids.shape[0], dtype=torch.bool) if text_mask is None else torch.as_tensor(text_mask).bool()
-        if ids.shape[0] + max_new_token + 1 > self.cap or max_new_token > self.hid_cap:
-            raise ValueError("request does not fit a slot (prompt + max_new_token vs cap / hid_cap)")
+        # 2 * POLL positions of slack: a request that ends by max_new_token (no EOS) is retired by the HOST, up to two chunks late
+        if ids.shape[0] + max_new_token + 1 + 2 * self.POLL > self.cap or max_new_token > self.hid_cap:
+            raise ValueError("request does not fit a slot (prompt + max_new_token + 2 * POLL vs cap, max_new_token vs hid_cap)")
         self.queue.append(_Req(rid, ids, tm, int(max_new_token), int(stop_at)))
 
     def _admit(self) -> None:
@@ -159,13 +161,14 @@ class SlotPool:
         for r in list(self.queue)[: len(self.free)]:
             t_new = max(Tg, int(r.ids.shape[0]))
             need_new = max(need, r.max_new)
-            if n > 0 and t_new + need_new + 1 > self.cap:
+            if n > 0 and t_new + need_new + 1 + 2 * self.POLL > self.cap:
                 break
             n, Tg, need = n + 1, t_new, need_new
         if n == 0:
             return
-        assert Tg + need + 1 <= self.cap
+        assert Tg + need + 1 + 2 * self.POLL <= self.cap
         reqs = [self.queue.popleft() for _ in range(n)]
+        self.admissions += 1
         slots = [self.free.pop(0) for _ in range(n)]              # lowest free slots first (deterministic)
         ids = torch.zeros((n, Tg, GPT.n_vq), dtype=torch.int64)
         mask = torch.zeros((n, Tg), dtype=torch.bool)
@@ -189,36 +192,67 @@ class SlotPool:
             pre = self._state(B=n, T=Tg, workspace=ws, row_map=rmap, n_active=None)
             _lib.check(self.lib.ctts_gpt_prefill(self.handle, C.byref(pre), emb.data_ptr(), self.st.cuda_stream), "ctts_gpt_prefill")
             self._keep = (ws, emb, rmap, sl)  # stream-ordered: stay alive until the next poll's sync, no extra sync here
+        since = getattr(self, "_snap_seq", 0)      # snapshots enqueued before this admission still show the previous occupant
         for s_, r in zip(slots, reqs):
-            self.active[s_] = (r, Tg)
+            self.active[s_] = (r, Tg, since)
             self.slot_of[r.rid] = s_
 
     # -- main loop --------------------------------------------------------------------------------------------
+    def _snapshot(self):
+        """stream-ordered shader copy of the finish flags + end_idx into one of two pinned blocks, and the event behind it"""
+        if not hasattr(self, "_snaps"):
+            self._snaps = [(torch.empty((5 * self._Sp,), dtype=torch.uint8).pin_memory(), torch.cuda.Event()) for _ in range(2)]
+            self._snap_seq = 0
+        blk, ev = self._snaps[self._snap_seq % 2]
+        _lib.check(self.lib.ctts_copy_bytes(blk.data_ptr(), self.state_blk.data_ptr(), blk.numel(), self.st.cuda_stream), "ctts_copy_bytes")
+        ev.record(self.st)
+        self._snap_seq += 1
+        return self._snap_seq - 1, blk, ev
+
     def run(self) -> Iterator[Tuple[object, torch.Tensor, torch.Tensor]]:
         """Yields (request id, ids [n,4] int64, hiddens [n,768] float32) as requests complete, admitting queued
-        requests into freed slots between decode chunks."""
-        while self.queue or self.active:
+        requests into freed slots between decode chunks.  ONE chunk runs ahead: the next POLL steps are enqueued before the host
+        looks at the previous chunk's flags, so the device never waits for the poll, the admission prefill or the result copies
+        (a freed slot idles for at most two chunks instead of one).  A slot's entry only listens to snapshots enqueued after its
+        admission -- an older one still shows the previous occupant's flag."""
+        pending: Deque = deque()
+        ready: Deque = deque()      # (event behind the result copies, results) of the previous poll
+        while self.queue or self.active or pending:
             self._admit()
-            # requests can already be over after the prefill's sample (EOS at step 0) -> handled by the poll below
             if self.active:
                 _lib.check(self.lib.ctts_gpt_graph_launch(self.handle, self.POLL, self.st.cuda_stream), "ctts_gpt_graph_launch")
                 self.steps += self.POLL
-            if not hasattr(self, "_blk_h"):
-                self._blk_h = torch.empty((5 * self._Sp,), dtype=torch.uint8).pin_memory()
-            _lib.check(self.lib.ctts_copy_bytes(self._blk_h.data_ptr(), self.state_blk.data_ptr(), self._blk_h.numel(), self.st.cuda_stream),
-                       "ctts_copy_bytes")
-            wait_stream(self.st)     # polled, not an interrupt wait (chattts_amd/_sync.py)
-            fin = self._blk_h[: self.S].clone()
-            end = self._blk_h[self._Sp:].view(torch.int32)[: self.S].clone()
-            done = [s for s, (r, _) in self.active.items() if bool(fin[s]) or int(end[s]) >= r.max_new]
-            for s in done:
-                r, Tg = self.active.pop(s)
-                n = min(int(end[s]), r.max_new)
-                with torch.cuda.stream(self.st):
-                    ids = self.ids_buf[s, Tg: Tg + n].clone()
-                    hid = self.hiddens[s, :n].clone()
+                pending.append(self._snapshot())
+            while ready:          # the copies were enqueued in front of the chunk launched just now: the device stays busy while we wait
+                ev_out, outs = ready.popleft()
+                wait_event(ev_out)
+                for o in outs:
+                    yield o
+            if len(pending) < 2 and self.active:
+                continue          # keep one chunk running ahead of the snapshot the host is about to read
+            if not pending:
+                continue
+            seq, blk, ev = pending.popleft()
+            wait_event(ev)        # polled, not an interrupt wait (chattts_amd/_sync.py)
+            fin = blk[: self.S]
+            end = blk[self._Sp:].view(torch.int32)[: self.S]
+            done = [s for s, (r, _, since) in self.active.items() if seq >= since and (bool(fin[s]) or int(end[s]) >= r.max_new)]
+            if not done:
+                continue
+            outs = []
+            with torch.cuda.stream(self.st):
+                for s in done:
+                    r, Tg, _ = self.active.pop(s)
+                    n = min(int(end[s]), r.max_new)
+                    outs.append((r.rid, self.ids_buf[s, Tg: Tg + n].clone(), self.hiddens[s, :n].clone()))
                     self.finish[s] = 1      # a request cut at max_new_token stops costing attention bandwidth
-                wait_stream(self.st)
-                self.free.append(s)
-                self.free.sort()
-                yield r.rid, ids, hid
+                ev_out = torch.cuda.Event()
+                ev_out.record(self.st)
+            ready.append((ev_out, outs))    # handed out after the next chunk has been enqueued; the slots are free now (re-admission
+            self.free.extend(done)          # writes are stream-ordered behind the copies)
+            self.free.sort()
+        while ready:
+            ev_out, outs = ready.popleft()
+            wait_event(ev_out)
+            for o in outs:
+                yield o

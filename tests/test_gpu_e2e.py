@@ -400,6 +400,19 @@ def test_generate_rows_are_views_of_the_padded_batch(gpt_f32, weights):
     assert torch.equal(codec.decode_to_wavs(out.hiddens[:3]), codec.decode_to_wavs([r.clone() for r in out.hiddens[:3]]))   # a slice is a plain list
 
 
+def test_to_host_in_pieces_equals_cpu_numpy(weights):
+    """`CodecEngine.to_host` of a batch's worth of waveforms (>= 16 MB): the bus copy and the copy out of the pinned staging buffer run
+    in 4 overlapped pieces; the result is a fresh array equal to `.cpu().numpy()`, for sizes that do and do not divide evenly"""
+    codec = E.CodecEngine(weights["decoder"], weights["vocos"], DEV)
+    g = torch.Generator(device=DEV).manual_seed(3)
+    for shape in ((64, 261888), (5, 1000016), (3, 700000)):
+        t = torch.randn(shape, device=DEV, generator=g)
+        a = codec.to_host(t)
+        b = codec.to_host(t * 2.0)          # the staging buffer is reused: `a` must not change
+        ref = t.cpu().numpy()
+        assert a.dtype == np.float32 and a.shape == tuple(shape) and np.array_equal(a, ref) and np.array_equal(b, ref * 2.0)
+
+
 def test_decode_to_wavs_padding(codec, weights):
     """ragged rows are zero padded like core.py:525-533; compare with the oracle on a larger batch"""
     rs = np.random.RandomState(4)

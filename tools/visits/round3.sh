@@ -541,7 +541,32 @@ for l in sys.stdin:
   cd "$R"
 }
 
+r3al() {   # bus copy and staging-buffer copy-out overlapped in pieces: test, timeline, C3
+  T=r3al
+  timeout 300 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -k "to_host or rows_are_views or decode_to_wavs" > gpurun_out/${T}_tests.log 2>&1; tail -2 gpurun_out/${T}_tests.log
+  for P in 0 1; do echo "== CTTS_D2H_PIPE=$P" >> gpurun_out/${T}_timeline.log; CTTS_D2H_PIPE=$P timeout 300 python tools/pass_timeline.py 2>&1 | grep -v amdgpu.ids | tail -2 >> gpurun_out/${T}_timeline.log; done
+  cat gpurun_out/${T}_timeline.log
+  Q="--steps 6 --warmup 2 --no-cpu-baseline --no-ttfs --no-bf16-parity --no-parity-mode --no-roofline"
+  for rep in 1 2; do for P in 0 1; do
+    echo "== CTTS_D2H_PIPE=$P" >> gpurun_out/${T}_ab.log
+    CTTS_D2H_PIPE=$P timeout 300 python bench.py $Q 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])" >> gpurun_out/${T}_ab.log 2>&1
+  done; done
+  cat gpurun_out/${T}_ab.log
+}
+
+r3an() {   # SlotPool with one chunk running ahead: parity tests, then the continuous-batching leg of bench.py
+  T=r3an
+  timeout 400 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -k "continuous or slot_pool or device_generator" > gpurun_out/${T}_tests.log 2>&1; tail -3 gpurun_out/${T}_tests.log
+  for rep in 1 2; do
+  timeout 400 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-ttfs --no-bf16-parity --no-parity-mode --no-roofline 2>/dev/null | tail -1 | python -c "
+import sys, json
+d = json.loads(sys.stdin.read())
+print(d['value'], d['ms_per_step']); print(d.get('continuous_batching_queue'))" >> gpurun_out/${T}_pool.log 2>&1
+  done
+  cat gpurun_out/${T}_pool.log
+}
+
 case "$1" in
-  r3a|r3b|r3c|r3d|r3e|r3f|r3g|r3h|r3i|r3j|r3k|r3l|r3m|r3n|r3o|r3p|r3q|r3r|r3s|r3t|r3u|r3v|r3w|r3x|r3y|r3z|r3ab|r3ac|r3ad|r3ae|r3af|r3ag|r3ah|r3ai|r3aj|r3ak) "$1" ;;
+  r3a|r3b|r3c|r3d|r3e|r3f|r3g|r3h|r3i|r3j|r3k|r3l|r3m|r3n|r3o|r3p|r3q|r3r|r3s|r3t|r3u|r3v|r3w|r3x|r3y|r3z|r3ab|r3ac|r3ad|r3ae|r3af|r3ag|r3ah|r3ai|r3aj|r3ak|r3al|r3am|r3an|r3ao|r3ap) "$1" ;;
   *) echo "usage: round3.sh <" 'r3a r3b r3c r3d r3e r3f r3g r3h r3i r3j r3k r3l r3m r3n r3o r3p r3q r3r r3s r3t r3u r3v r3w r3x r3y r3z' ">"; exit 2 ;;
 esac
