@@ -277,7 +277,10 @@ __global__ __launch_bounds__(64 * NW + (PF ? 64 : 0)) void attention_k(const flo
   constexpr int NI = 4;             // load instructions per block and operand (K and V): 8 loads per block in flight,
                                     // and the NEXT block's 8 are issued before the current block is consumed
   constexpr int KB = KPI * NI;      // keys per wave-block: 32 / 16
-  constexpr bool KV_NT = NW > 1;    // decode: every KV byte is read once per step by exactly one workgroup -> non-temporal
+#ifndef CTTS_KV_NT
+#define CTTS_KV_NT 1              // A/B builds: python -m chattts_amd.build --variant kvplain -DCTTS_KV_NT=0 (profiles/r3ap_kv_nt_ab.log)
+#endif
+  constexpr bool KV_NT = NW > 1 && CTTS_KV_NT;    // decode: every KV byte is read once per step by exactly one workgroup -> non-temporal
   __shared__ float sm_m[NW], sm_l[NW], sm_acc[NW][HDIM];
   if (NW > 1) CTTS_PROBE_RETURN();
   if (PF && (threadIdx.x >> 6) == NW) {   // fifth wave: this layer's gate/up weights towards this XCD's L2 (common.hpp), then gone

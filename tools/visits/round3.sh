@@ -566,6 +566,17 @@ print(d['value'], d['ms_per_step']); print(d.get('continuous_batching_queue'))" 
   cat gpurun_out/${T}_pool.log
 }
 
+r3ap() {   # KV loads of the decode attention with and without the non-temporal hint (variant build: -DCTTS_KV_NT=0)
+  T=r3ap
+  Q="--steps 4 --warmup 1 --no-cpu-baseline --no-ttfs --no-bf16-parity --no-parity-mode --no-slot-pool"
+  for rep in 1 2; do for V in nt plain; do
+    echo "== KV loads: $V" >> gpurun_out/${T}_kv_nt_ab.log
+    L=""; [ $V = plain ] && L="$R/chattts_amd/csrc/libchattts_amd_kvplain.so"
+    CTTS_LIB=$L timeout 300 python bench.py $Q 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['avg_launch_us'], d['roofline']['frac'])" >> gpurun_out/${T}_kv_nt_ab.log 2>&1
+  done; done
+  cat gpurun_out/${T}_kv_nt_ab.log
+}
+
 case "$1" in
   r3a|r3b|r3c|r3d|r3e|r3f|r3g|r3h|r3i|r3j|r3k|r3l|r3m|r3n|r3o|r3p|r3q|r3r|r3s|r3t|r3u|r3v|r3w|r3x|r3y|r3z|r3ab|r3ac|r3ad|r3ae|r3af|r3ag|r3ah|r3ai|r3aj|r3ak|r3al|r3am|r3an|r3ao|r3ap) "$1" ;;
   *) echo "usage: round3.sh <" 'r3a r3b r3c r3d r3e r3f r3g r3h r3i r3j r3k r3l r3m r3n r3o r3p r3q r3r r3s r3t r3u r3v r3w r3x r3y r3z' ">"; exit 2 ;;
