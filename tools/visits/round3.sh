@@ -296,7 +296,7 @@ for l in sys.stdin:
   timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline --no-ttfs > gpurun_out/${T}_torchrun_world1.log 2>&1
   echo "torchrun exit $?" >> gpurun_out/${T}_torchrun_world1.log; tail -3 gpurun_out/${T}_torchrun_world1.log | cut -c1-400
   cd /tmp
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${T} -o ${T} -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-ttfs --no-parity-mode --no-bf16-parity > $R/gpurun_out/${T}_rocprof.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${T} -o ${T} -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-ttfs --no-parity-mode --no-bf16-parity --no-slot-pool > $R/gpurun_out/${T}_rocprof.log 2>&1
   F=$(find /tmp/prof_${T} -name "*kernel_stats.csv" | head -1); [ -n "$F" ] && cp $F $R/gpurun_out/${T}_kernel_stats.csv && head -12 $F | cut -c1-120
   cd "$R"
 }
@@ -412,7 +412,7 @@ for l in sys.stdin:
   timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline --no-ttfs > gpurun_out/${T}_torchrun_world1.log 2>&1
   echo "torchrun exit $?" >> gpurun_out/${T}_torchrun_world1.log; tail -1 gpurun_out/${T}_torchrun_world1.log
   cd /tmp
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${T} -o ${T} -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-ttfs --no-parity-mode --no-bf16-parity > $R/gpurun_out/${T}_rocprof.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${T} -o ${T} -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-ttfs --no-parity-mode --no-bf16-parity --no-slot-pool > $R/gpurun_out/${T}_rocprof.log 2>&1
   F=$(find /tmp/prof_${T} -name "*kernel_stats.csv" | head -1); [ -n "$F" ] && cp $F $R/gpurun_out/${T}_kernel_stats.csv && head -6 $F | cut -c1-120
   cd "$R"
 }
@@ -464,7 +464,7 @@ r3af() {   # gemm_h1p_k with fragment reads one k block ahead + the branch-free 
   done
   cat gpurun_out/${T}_ab.log
   cd /tmp
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${T} -o ${T} -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-ttfs --no-parity-mode --no-bf16-parity > $R/gpurun_out/${T}_rocprof.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${T} -o ${T} -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-ttfs --no-parity-mode --no-bf16-parity --no-slot-pool > $R/gpurun_out/${T}_rocprof.log 2>&1
   F=$(find /tmp/prof_${T} -name "*kernel_stats.csv" | head -1); [ -n "$F" ] && cp $F $R/gpurun_out/${T}_kernel_stats.csv && grep -v "gemm_dec_k\|attention_k" $F | head -14 | cut -c1-150
   cd "$R"
 }
@@ -511,7 +511,7 @@ r3aj() {   # sliding-window depthwise conv + LayerNorm for large batches: tests,
   done; done
   cat gpurun_out/${T}_ab.log
   cd /tmp
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${T} -o ${T} -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-ttfs --no-parity-mode --no-bf16-parity > $R/gpurun_out/${T}_rocprof.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${T} -o ${T} -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-ttfs --no-parity-mode --no-bf16-parity --no-slot-pool > $R/gpurun_out/${T}_rocprof.log 2>&1
   F=$(find /tmp/prof_${T} -name "*kernel_stats.csv" | head -1); [ -n "$F" ] && cp $F $R/gpurun_out/${T}_kernel_stats.csv && grep -v "gemm_dec_k\|attention_k" $F | head -12 | cut -c1-150
   cd "$R"
 }
@@ -536,7 +536,7 @@ for l in sys.stdin:
   timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline --no-ttfs > gpurun_out/${T}_torchrun_world1.log 2>&1
   echo "torchrun exit $?" >> gpurun_out/${T}_torchrun_world1.log; tail -1 gpurun_out/${T}_torchrun_world1.log
   cd /tmp
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${T} -o ${T} -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-ttfs --no-parity-mode --no-bf16-parity > $R/gpurun_out/${T}_rocprof.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${T} -o ${T} -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-ttfs --no-parity-mode --no-bf16-parity --no-slot-pool > $R/gpurun_out/${T}_rocprof.log 2>&1
   F=$(find /tmp/prof_${T} -name "*kernel_stats.csv" | head -1); [ -n "$F" ] && cp $F $R/gpurun_out/${T}_kernel_stats.csv && head -6 $F | cut -c1-120
   cd "$R"
 }
@@ -597,7 +597,7 @@ for l in sys.stdin:
   timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline --no-ttfs > gpurun_out/${T}_torchrun_world1.log 2>&1
   echo "torchrun exit $?" >> gpurun_out/${T}_torchrun_world1.log; tail -1 gpurun_out/${T}_torchrun_world1.log
   cd /tmp
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${T} -o ${T} -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-ttfs --no-parity-mode --no-bf16-parity > $R/gpurun_out/${T}_rocprof.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${T} -o ${T} -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-ttfs --no-parity-mode --no-bf16-parity --no-slot-pool > $R/gpurun_out/${T}_rocprof.log 2>&1
   F=$(find /tmp/prof_${T} -name "*kernel_stats.csv" | head -1); [ -n "$F" ] && cp $F $R/gpurun_out/${T}_kernel_stats.csv && head -6 $F | cut -c1-120
   cd "$R"
 }
