@@ -104,6 +104,32 @@ int main() {
     printf("  %3d workgroups: %7.2f us = %5.2f TB/s\n", G, m, a_bytes / m / 1e6);
   }
 
+  // (4) the decode projections' weight fetch in miniature: G workgroups x S bytes, every load in flight at once, latency-bound.
+  //     cold (HBM) vs "warm in the Infinity Cache only" (read before, then 64 MB of other reads through every L2) vs straight after.
+  printf("(4) small latency-bound reads (the shape of a decode projection's weight fetch)\n");
+  {
+    char* B2; const size_t b2 = (size_t)64 << 20; CK(hipMalloc(&B2, b2)); CK(hipMemset(B2, 5, b2));
+    const int b2n = (int)(b2 / seg);
+    struct Shape { const char* name; int G; int S; };
+    const Shape shapes[] = {{"QKV     3.5 MB", 144, 6 * 4096}, {"o_proj  1.2 MB", 48, 6 * 4096}, {"gate/up 9.4 MB", 256, 9 * 4096}, {"down    4.7 MB", 192, 6 * 4096}};
+    for (const Shape& sh : shapes) {
+      double med[3];
+      for (int mode = 0; mode < 3; ++mode) {   // 0 cold, 1 Infinity-Cache-warm, 2 straight after the same read
+        std::vector<double> t;
+        for (int rep = 0; rep < 15; ++rep) {
+          flush();
+          if (mode >= 1) hipLaunchKernelGGL(read_seg, dim3(sh.G), dim3(256), 0, st, (const char*)A, sh.S, sh.G, 0, sink);
+          if (mode == 1) hipLaunchKernelGGL(read_seg, dim3(b2n), dim3(256), 0, st, (const char*)B2, seg, b2n, 0, sink);
+          hipExtLaunchKernelGGL(read_seg, dim3(sh.G), dim3(256), 0, st, e0, e1, 0, (const char*)A, sh.S, sh.G, mode == 1 ? 3 : 0, sink);
+          CK(hipEventSynchronize(e1));
+          float ms; CK(hipEventElapsedTime(&ms, e0, e1)); t.push_back(ms * 1e3);
+        }
+        med[mode] = median(t);
+      }
+      printf("  %s (%3d workgroups x %5d B): cold %.2f us | Infinity-Cache-warm %.2f us | straight after %.2f us\n", sh.name, sh.G, sh.S, med[0], med[1], med[2]);
+    }
+  }
+
   // (2) a dependent chain with and without a concurrent reader on another stream
   float *b0, *b1; CK(hipMalloc(&b0, 16384 * 4)); CK(hipMalloc(&b1, 16384 * 4)); CK(hipMemset(b0, 0, 16384 * 4)); CK(hipMemset(b1, 0, 16384 * 4));
   hipGraph_t g; hipGraphExec_t ge;

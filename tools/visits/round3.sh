@@ -602,4 +602,18 @@ for l in sys.stdin:
   cd "$R"
 }
 
+r3as() {   # o_proj's spare CUs prefetch the layer's gate/up weights into the consumer XCD's L2 (CTTS_PF=32)
+  T=r3as
+  CTTS_PF=32 timeout 300 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -k "packed_decode or bf16_parity or invariance or teacher" > gpurun_out/${T}_tests_pf32.log 2>&1; tail -2 gpurun_out/${T}_tests_pf32.log
+  Q="--steps 4 --warmup 1 --no-cpu-baseline --no-ttfs --no-bf16-parity --no-parity-mode --no-slot-pool"
+  ab() { L=$1; shift; echo "== $L" >> gpurun_out/${T}_ab.log
+    env "$@" timeout 200 python bench.py $Q 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], {k: v['avg_launch_us'] for k, v in d['decode_kernels'].items()})" >> gpurun_out/${T}_ab.log 2>&1; }
+  for rep in 1 2; do
+  ab "off" CTTS_PF=0
+  ab "o_proj + 2 rows of prefetch workgroups -> gate/up" CTTS_PF=32 CTTS_PF_ROWS=2
+  ab "o_proj + 4 rows" CTTS_PF=32 CTTS_PF_ROWS=4
+  done
+  cat gpurun_out/${T}_ab.log
+}
+
 if declare -F "$1" > /dev/null; then "$1"; else echo "usage: round3.sh <visit>   (one of: $(declare -F | awk '{print $3}' | tr '\n' ' '))"; exit 2; fi
