@@ -123,6 +123,20 @@ def test_rope_row_perm_is_a_permutation_pairing_halves():
     assert torch.equal(t[:, :, 8:] - t[:, :, :8], torch.full((12, 4, 8), 32))
 
 
+def test_fp16_plane_packing_matches_the_split_planes_layout():
+    """pack_h1p (the single fp16 plane of gemm_h1p_k) uses the fragment order of pack_x3p's planes without the hi | lo axis: on
+    bf16-representable values the two agree element for element; values beyond the half range saturate; round trip"""
+    from chattts_amd.engine import pack_h1p, pack_x3p, unpack_h1p
+    g = torch.Generator().manual_seed(5)
+    w = torch.randn(96, 64, generator=g).to(torch.bfloat16).to(torch.float32)      # exactly representable in bf16 and (here) in fp16
+    p1, p3 = pack_h1p(w), pack_x3p(w)
+    assert p1.dtype == torch.float16 and tuple(p1.shape) == (3, 4, 2, 32, 8) and tuple(p3.shape) == (3, 4, 2, 2, 32, 8)
+    assert torch.equal(p1.to(torch.float32), p3[:, :, 0].to(torch.float32)) and not bool(p3[:, :, 1].to(torch.float32).any())
+    assert torch.equal(unpack_h1p(p1, 96, 64), w)
+    big = torch.tensor([[1e6, -1e6] + [0.0] * 14] * 32)
+    assert unpack_h1p(pack_h1p(big), 32, 16)[0, :2].tolist() == [65504.0, -65504.0]
+
+
 def test_fragment_packing_round_trips_and_matches_the_kernel_offsets():
     """pack_frag / pack_frag32 (engine.py) against the device-side offset functions they must agree with (csrc/common.hpp
     pk_off / pk32_off, restated here): element (r, c) of a [R, C] matrix lands where the decode kernels look for it"""

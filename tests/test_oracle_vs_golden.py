@@ -158,3 +158,33 @@ def test_torch_port_matches_goldens(golden, weights):
     assert float((mel - torch.from_numpy(golden["codec"]["c24.mel"])).abs().max()) < 1e-4
     wav = torch_port.vocos_decode(weights["vocos"], mel)
     assert float((wav - torch.from_numpy(golden["codec"]["c24.wav"])).pow(2).mean().sqrt()) < 1e-5
+
+
+def test_fp16_pointwise_pairs_stay_inside_the_stated_waveform_bound(weights):
+    """Where the perf-mode decoder's bound comes from (`CodecEngine(gemm="f16")`, csrc/codec_gemm.hip gemm_h1p_k): in the torch
+    restatement of DVAE decode + Vocos, rounding BOTH operands of every ConvNeXt point-wise layer to fp16 (f32 accumulation) moves
+    the waveform by < 1e-5 RMS -- the kernel additionally rounds the GELU output where the restatement rounds the next layer's
+    input (the same values) and is held to 2e-5 on the GPU (tests/test_gpu_e2e.py).  bf16 operands (8 bits) would spend half of
+    the north-star's 1e-4 on this alone."""
+    from oracle import torch_port
+    F = torch.nn.functional
+    hid = torch.from_numpy(np.random.RandomState(0).standard_normal((4, 96, 768)).astype(np.float32))
+    orig = F.linear
+
+    def run(q):
+        def lin(x, w, b=None):
+            if q is not None and x.dim() == 3 and w.shape[0] != 1026:      # the point-wise pairs (not the Vocos head)
+                return orig(q(x), q(w), b)
+            return orig(x, w, b)
+        F.linear = lin
+        try:
+            return torch_port.vocos_decode(weights["vocos"], torch_port.dvae_decode(weights["decoder"], hid))
+        finally:
+            F.linear = orig
+
+    ref = run(None)
+    rms = lambda t: float(t.pow(2).mean().sqrt())
+    e16 = rms(run(lambda t: t.clamp(-65504.0, 65504.0).half().float()) - ref)
+    eb16 = rms(run(lambda t: t.bfloat16().float()) - ref)
+    assert 0.0 < e16 < 1e-5, e16
+    assert eb16 > 3 * e16 and rms(ref) > 1e-2, (eb16, rms(ref))
