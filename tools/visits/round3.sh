@@ -616,4 +616,29 @@ r3as() {   # o_proj's spare CUs prefetch the layer's gate/up weights into the co
   cat gpurun_out/${T}_ab.log
 }
 
+r3at() {   # validation visit on the final tree
+  T=r3at
+  timeout 700 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/${T}_tests.log 2>&1; echo "pytest exit $?" >> gpurun_out/${T}_tests.log; tail -3 gpurun_out/${T}_tests.log
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${T}_smoke.log 2>&1; tail -1 gpurun_out/${T}_smoke.log
+  timeout 500 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${T}_bench.log 2> gpurun_out/${T}_bench.err; echo "bench exit $?" >> gpurun_out/${T}_bench.log
+  tail -2 gpurun_out/${T}_bench.log | python -c "
+import sys, json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d = json.loads(l)
+        print('value', d['value'], 'ms', d['ms_per_step'], 'parity', d['parity_mode']['value'], d['parity_mode']['ids_match_reference'], 'ttfs', d['ttfs_ms_p50'], 'pipelined', d['pipelined_queue']['value']); print('pool', d.get('continuous_batching_queue', {}).get('value'), 'codec_parity', d.get('codec_parity', {}).get('wav_rms_diff'))
+        print('roofline', d['roofline']['frac'], d['roofline']['avg_launch_us'], 'step', d['roofline']['whole_decode_step']['ms_per_step'], d['roofline']['whole_decode_step']['frac'], 'f32 att', d['parity_mode']['roofline']['frac'], d['parity_mode']['decode_ms_per_gpt_step'])
+        print({k: v['avg_launch_us'] for k, v in d['decode_kernels'].items()})
+        print('cpu', d['cpu_baseline']['value'], d['cpu_baseline']['cores'], 'agree', d['bf16_parity']['token_agreement'])
+    else:
+        print(l[:300])
+"
+  timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline --no-ttfs > gpurun_out/${T}_torchrun_world1.log 2>&1
+  echo "torchrun exit $?" >> gpurun_out/${T}_torchrun_world1.log; tail -1 gpurun_out/${T}_torchrun_world1.log
+  cd /tmp
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${T} -o ${T} -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-ttfs --no-parity-mode --no-bf16-parity --no-slot-pool > $R/gpurun_out/${T}_rocprof.log 2>&1
+  F=$(find /tmp/prof_${T} -name "*kernel_stats.csv" | head -1); [ -n "$F" ] && cp $F $R/gpurun_out/${T}_kernel_stats.csv && head -6 $F | cut -c1-120
+  cd "$R"
+}
+
 if declare -F "$1" > /dev/null; then "$1"; else echo "usage: round3.sh <visit>   (one of: $(declare -F | awk '{print $3}' | tr '\n' ' '))"; exit 2; fi
