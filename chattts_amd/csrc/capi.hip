@@ -38,7 +38,6 @@ struct ctts_gpt {
   bool dec_packed = false;     // perf mode (bf16 weights): decode.hip
   bool dec_packed32 = false;   // parity mode (f32 weights): decode32.hip
   bool heads_packed = false;   // heads GEMM on packed f32 operands (decode32.hip), both modes
-  int pf_rows = 2;             // env CTTS_PF_ROWS: grid rows (of 48 workgroups) appended to o_proj for CTTS_PF bit 32
   int pf_mask = 0;             // env CTTS_PF: cross-kernel weight prefetch, bit mask (1 QKV->o_proj, 16 QKV->gate/up, 2 attention->gate/up)
   int temporal_layers = 0;     // env CTTS_W_TEMPORAL_LAYERS: decode weights of layers [0, N) loaded WITHOUT the non-temporal hint (A/B)
   bool pre32_packed = true;    // parity mode: prompt pass on the packed f32 kernels (env CTTS_PRE32_PACKED=0: row-major gemm_skinny_k)
@@ -139,7 +138,6 @@ extern "C" int ctts_gpt_create(ctts_gpt** out, const ctts_gpt_weights* w) {
   { const char* e = getenv("CTTS_FNORM_FUSE"); if (e && atoi(e) == 0) g->fnorm_fuse = false; }
   { const char* e = getenv("CTTS_W_TEMPORAL_LAYERS"); if (e) g->temporal_layers = atoi(e); }
   { const char* e = getenv("CTTS_PF"); if (e) g->pf_mask = atoi(e); }
-  { const char* e = getenv("CTTS_PF_ROWS"); if (e) g->pf_rows = atoi(e) > 0 ? atoi(e) : 2; }
   { const char* e = getenv("CTTS_PRE32_PACKED"); if (e && atoi(e) == 0) g->pre32_packed = false; }
   {
     int dev = 0, cus = 0;
@@ -282,11 +280,7 @@ static int run_step(ctts_gpt* g, const ctts_gen_state* s, int q_per_b, hipStream
     { Prof p(g, 3, st, prof_ok); CK(launch_attention(ws.qkv, kc, vc, kt, cmax, ws.aop, 2, rm, M, st)); }
     d.Ap = ws.aop; d.Wp = (const uint16_t*)g->wo_pk[l]; d.N = HID; d.ssq_in = nullptr; d.epi = FEPI_RES; d.C32 = ws.x; d.ldc = HID;
     d.Cp = ws.xp; d.kch_out = HID / 32; d.ssq_out = ws.ssq;
-    // CTTS_PF bit 32: two extra grid rows of o_proj workgroups (96, on the CUs the 192 working ones leave free) pull this layer's
-    // gate/up weights into the L2 of the XCD that will read them
-    d.pf[0] = (g->pf_mask & 32) ? pf_gu : pf_none; d.pf[1] = pf_none; d.pf_wg_rows = (g->pf_mask & 32) ? g->pf_rows : 0;
     { Prof p(g, 4, st, prof_ok); CK(launch_gemm_dec(d, st)); }
-    d.pf_wg_rows = 0;
     d.Ap = ws.xp; d.Wp = (const uint16_t*)g->wgu_pk[l]; d.N = INTER; d.ssq_in = ws.ssq; d.epi = FEPI_SILU; d.C32 = nullptr;
     d.Cp = ws.actp; d.kch_out = INTER / 32; d.ssq_out = nullptr;
     d.pf[0] = pf_none; d.pf[1] = pf_none; (void)pf_d; (void)pf_next;   // (gate/up has no auxiliary wave: see decode.hip)

@@ -189,26 +189,6 @@ struct PfDesc {
   unsigned tile_bytes;   // contiguous bytes of one weight tile (a multiple of 64)
   unsigned n_tiles;
 };
-// The same by whole WORKGROUPS appended to a launch's grid (round 3, CTTS_PF bit 32: o_proj's spare CUs pull the layer's gate/up
-// weights, the one projection whose 9.4 MB fetch is measurably shorter when it hits -- tools/mall_probe.hip part 4: 5.3 us cold,
-// 3.9 us warm).  Workgroup `id` of the launch runs on XCD id % 8; the n_pf prefetchers are ids first .. first + n_pf - 1 (first and
-// n_pf multiples of 8); tile i of the consumer is read by its workgroup on XCD i % 8.  One dword per 64-byte granule.
-__device__ __forceinline__ void prefetch_weight_tiles_wg(const PfDesc& pf, unsigned tid, unsigned nthr, unsigned id, unsigned first, unsigned n_pf) {
-  if (pf.base == nullptr || n_pf < 8u) return;
-  const unsigned x = id & 7u, q = (id - first) >> 3, nq = n_pf >> 3;
-  if (x >= pf.n_tiles || q >= nq) return;
-  const unsigned nt = (pf.n_tiles - x + 7u) >> 3;      // tiles the consumer reads on XCD x
-  const unsigned gpt = pf.tile_bytes >> 6;             // 64-byte granules per tile
-  const unsigned G = nt * gpt, per = (G + nq - 1u) / nq;
-  const unsigned beg = q * per, end = min(G, beg + per);
-  unsigned sink = 0;
-  for (unsigned g = beg + tid; g < end; g += nthr) {
-    const unsigned ti = g / gpt;
-    const char* p = pf.base + (size_t)(x + 8u * ti) * pf.tile_bytes + ((size_t)(g - ti * gpt) << 6);
-    asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(p) : "memory");
-  }
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink) : : "memory");
-}
 __device__ __forceinline__ void prefetch_weight_tiles(const PfDesc& pf, int lane, unsigned wg, unsigned n_wg) {
   if (pf.base == nullptr) return;
   const unsigned x = wg & 7u, q = wg >> 3;

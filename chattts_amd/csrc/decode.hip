@@ -75,7 +75,7 @@ __device__ __forceinline__ void dec_body(const DecGemmArgs& a, const int M, cons
   const u128* wp = reinterpret_cast<const u128*>(a.Wp) + ((size_t)tile * KCH + wave * nper) * 64 + lane;
   const u128* wp2 = wp + (size_t)(N >> 4) * KCH * 64;  // SILU: the "up" tile of the same columns
   const u128* ap = reinterpret_cast<const u128*>(a.Ap) + ((size_t)mt0 * KCH + wave * nper) * 64 + lane;
-  const bool w_once = a.w_nt && (int)gridDim.y - a.pf_wg_rows == 1;  // a single row group reads W: stream it past the caches
+  const bool w_once = a.w_nt && gridDim.y == 1;  // a single row group reads W: stream it past the caches
 
   f32x4 acc[NACC][NMB];
 #pragma unroll
@@ -229,11 +229,6 @@ void gemm_dec_k(DecGemmArgs a) {
     prefetch_weight_tiles(a.pf[0], threadIdx.x & 63, wg, n_wg);
     prefetch_weight_tiles(a.pf[1], threadIdx.x & 63, wg, n_wg);
   }
-  if (EPI == FEPI_RES && a.pf_wg_rows > 0 && blockIdx.y >= gridDim.y - a.pf_wg_rows) {   // appended workgroups: prefetch only
-    const unsigned first = (gridDim.y - a.pf_wg_rows) * gridDim.x;
-    prefetch_weight_tiles_wg(a.pf[0], threadIdx.x, blockDim.x, blockIdx.y * gridDim.x + blockIdx.x, first, a.pf_wg_rows * gridDim.x);
-    return;
-  }
   const int tile = blockIdx.x, mt0 = blockIdx.y * MBT;
   if (a.dbg && threadIdx.x == 0) a.dbg[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8] = wall_clock64();
   // The weight fragments of the first round do not depend on anything but the kernel arguments: request them before
@@ -254,7 +249,7 @@ void gemm_dec_k(DecGemmArgs a) {
     }
     const u128* wp = reinterpret_cast<const u128*>(a.Wp) + ((size_t)tile * KCH + wave * nper) * 64 + lane;
     const u128* wp2 = wp + (size_t)(a.N >> 4) * KCH * 64;
-    const bool w_once = a.w_nt && (int)gridDim.y - a.pf_wg_rows == 1;
+    const bool w_once = a.w_nt && gridDim.y == 1;
     if (w_once) {
 #pragma unroll
       for (int j = 0; j < DEC_U; ++j) {
@@ -315,7 +310,7 @@ template <int MBT>
 static hipError_t dec_dispatch_k768(const DecGemmArgs& a, hipStream_t st) {
   constexpr int NW = 4;
   const int mt = (a.M + 15) / 16;
-  dim3 grid(a.N / 16, (mt + MBT - 1) / MBT + (a.epi == FEPI_RES ? a.pf_wg_rows : 0));
+  dim3 grid(a.N / 16, (mt + MBT - 1) / MBT);
   const bool scale = a.ssq_in != nullptr;
   if (a.epi == FEPI_QKV_ROPE && scale) CTTS_LAUNCH((gemm_dec_k<MBT, NW, true, FEPI_QKV_ROPE>), grid, dim3(64 * NW + 64), st, a);
   else if (a.epi == FEPI_SILU && scale) CTTS_LAUNCH((gemm_dec_k<MBT, NW, true, FEPI_SILU>), grid, dim3(64 * NW), st, a);
@@ -343,7 +338,6 @@ hipError_t launch_gemm_dec(const DecGemmArgs& a_in, hipStream_t st) {
   }
   a.w_nt = a.force_nt ? (a.force_nt == 2) : nt;
   a.a_early = a_early;
-  if (!(a.epi == FEPI_RES && a.K == 768 && a.pf[0].base != nullptr && (a.N / 16) % 8 == 0)) a.pf_wg_rows = 0;   // o_proj only (48 tiles per grid row)
   if (a.M <= 0 || a.N <= 0 || (a.N & 15) || !(a.K == 768 || a.K == 3072)) return hipErrorInvalidValue;
   if (a.epi == FEPI_RES && a.N != 16 * SSQ_PARTS) return hipErrorInvalidValue;
   if (a.epi == FEPI_QKV_ROPE && (a.N != 2304 || a.K != 768 || !a.desc)) return hipErrorInvalidValue;

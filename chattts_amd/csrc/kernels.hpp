@@ -149,7 +149,6 @@ struct DecGemmArgs {
   int a_early;                  // set by the launcher (CTTS_DEC_A_EARLY): batches of <= 16 rows request their activation tile at entry
   int force_nt;                 // 0: the launcher's policy (CTTS_W_NT); 1: plain (temporal) weight loads; 2: non-temporal (A/B: CTTS_W_TEMPORAL_LAYERS)
   PfDesc pf[2];                 // weights of later launches of the step this launch's auxiliary wave pulls towards L2 (QKV_ROPE, SILU), or {null}
-  int pf_wg_rows;               // RES, K = 768 (o_proj): > 0 = this many extra grid rows of workgroups that only prefetch pf[0] (common.hpp)
   long long* dbg;               // probes only (tools/dec_phase_probe.py): [n_workgroups][8] phase stamps, or null
 };
 hipError_t launch_gemm_dec(const DecGemmArgs& a, hipStream_t st);

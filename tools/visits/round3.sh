@@ -602,7 +602,7 @@ for l in sys.stdin:
   cd "$R"
 }
 
-r3as() {   # o_proj's spare CUs prefetch the layer's gate/up weights into the consumer XCD's L2 (CTTS_PF=32)
+r3as() {   # o_proj's spare CUs prefetch the layer's gate/up weights into the consumer XCD's L2 (CTTS_PF=32: the code of commit 23fb1f2, removed since)
   T=r3as
   CTTS_PF=32 timeout 300 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -k "packed_decode or bf16_parity or invariance or teacher" > gpurun_out/${T}_tests_pf32.log 2>&1; tail -2 gpurun_out/${T}_tests_pf32.log
   Q="--steps 4 --warmup 1 --no-cpu-baseline --no-ttfs --no-bf16-parity --no-parity-mode --no-slot-pool"
