@@ -396,3 +396,8 @@ def test_pmc_summary_maps_the_profiled_kernel_names():
         traffic = json.load(f)
     assert traffic["attention"]["hbm_bytes_per_launch"] > 1e7 and traffic["attention"]["dispatches"] > 1000
     assert traffic["attention_f32"]["hbm_bytes_per_launch"] > 2e7 and traffic["heads_gemm"]["dispatches"] > 100
+    with open(os.path.join(ROOT, "profiles", "r3ak_kernel_stats.csv")) as f:         # the final tree's one-pass profile: decoder kernels too
+        tags = {mod.short(r["Name"]) for r in csv.DictReader(f)} - {None}
+    assert {"attention", "qkv_gemm", "o_proj_gemm", "gate_up_gemm", "down_gemm", "heads_gemm", "sample", "codec_pwconv1_h1p",
+            "codec_pwconv2_h1p", "dwconv_ln_run"} <= tags
+    assert {"codec_pwconv1_h1p", "codec_pwconv2_h1p", "dwconv_ln_run"} <= set(traffic)

@@ -45,8 +45,16 @@ def short(name):
         return "heads_gemm"         # fused final-norm + heads | packed heads | row-major heads
     if "sample_k" in name:
         return "sample"
+    if "dwconv_ln_run_k" in name:
+        return "dwconv_ln_run"      # large batches: a wave walks 36 frames (codec.hip)
     if "dwconv_ln_k" in name:
         return "dwconv_ln"
+    m = re.search(r"gemm_h1p_k<(\d+)", name)
+    if m:
+        return "codec_pwconv1_h1p" if int(m.group(1)) == 0 else "codec_pwconv2_h1p"   # the perf mode's decoder GEMMs (codec_gemm.hip)
+    m = re.search(r"gemm_x3p_k<(\d+)", name)
+    if m:
+        return "codec_pwconv1_x3p" if int(m.group(1)) == 0 else "codec_pwconv2_x3p"
     return None
 
 

@@ -641,4 +641,18 @@ for l in sys.stdin:
   cd "$R"
 }
 
+r3av() {   # PMC traffic of the final tree: --pmc FETCH_SIZE / WRITE_SIZE in separate kernel-trace-only passes, both modes
+  T=r3av
+  rm -f $R/gpurun_out/${T}_pmc_traffic.json
+  cd /tmp
+  for D in bf16 f32; do
+    for C in FETCH_SIZE WRITE_SIZE; do
+    CTTS_SYNC_POLL=1 timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/pmc_${T}_${D}_$C -o ${T}_$C -- python $R/bench.py --dtype $D --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-ttfs --no-parity-mode --no-bf16-parity --no-slot-pool > $R/gpurun_out/${T}_pmc_${D}_$C.log 2>&1
+    done
+    python $R/tools/pmc_summary.py /tmp/pmc_${T}_${D}_FETCH_SIZE /tmp/pmc_${T}_${D}_WRITE_SIZE $R/gpurun_out/${T}_pmc_traffic.json > $R/gpurun_out/${T}_pmc_summary_$D.txt 2>&1
+    head -14 $R/gpurun_out/${T}_pmc_summary_$D.txt | cut -c1-150
+  done
+  cd "$R"
+}
+
 if declare -F "$1" > /dev/null; then "$1"; else echo "usage: round3.sh <visit>   (one of: $(declare -F | awk '{print $3}' | tr '\n' ' '))"; exit 2; fi
