@@ -130,6 +130,29 @@ int main() {
     }
   }
 
+  // (5) what ONE workgroup per CU can pull from the L2s against three per CU (the parity mode's gate/up launch is 768 workgroups of
+  //     144 KB = 3 per CU; a 3-column-tile variant would be 256 workgroups of 336 KB): the same 110 MB in total out of a 19 MB
+  //     (L2 / Infinity Cache resident after the first pass) set, 14 x 16 B per lane in flight per workgroup.
+  printf("(5) 110 MB out of a 19 MB set: workgroups x bytes each (every CU re-reads slices other CUs read too)\n");
+  {
+    struct Shape { int G; int S; };
+    const Shape shapes[] = {{768, 36 * 4096}, {512, 54 * 4096}, {256, 108 * 4096}, {256, 82 * 4096}};
+    const int wn = (int)(w_bytes / 4096);
+    for (const Shape& sh : shapes) {
+      std::vector<double> t;
+      for (int rep = 0; rep < 12; ++rep) {
+        // segment index modulo the set: consecutive workgroups start 144 KB apart and wrap around the 19 MB
+        hipExtLaunchKernelGGL(read_seg, dim3(sh.G), dim3(256), 0, st, e0, e1, 0, (const char*)W, sh.S, (int)(w_bytes / sh.S), 0, sink);
+        CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (rep >= 2) t.push_back(ms * 1e3);
+      }
+      const double m = median(t);
+      printf("  %4d workgroups x %6d B = %6.1f MB: %6.2f us = %5.2f TB/s  (%.0f GB/s per CU)\n", sh.G, sh.S, (double)sh.G * sh.S / 1e6, m,
+             (double)sh.G * sh.S / m / 1e6, (double)sh.G * sh.S / m / 1e3 / 256.0);
+    }
+    (void)wn;
+  }
+
   // (2) a dependent chain with and without a concurrent reader on another stream
   float *b0, *b1; CK(hipMalloc(&b0, 16384 * 4)); CK(hipMalloc(&b1, 16384 * 4)); CK(hipMemset(b0, 0, 16384 * 4)); CK(hipMemset(b1, 0, 16384 * 4));
   hipGraph_t g; hipGraphExec_t ge;
