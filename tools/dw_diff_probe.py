@@ -1,3 +1,5 @@
+"""Where `dwconv_ln_run_k` (sliding window, large batches) and `dwconv_ln_k` (one wave per frame) differ bit for bit: the probe that
+found hipcc contracting the LayerNorm's `v += d * d` in one inlining and not in the other (round 3; now 0 differing elements)."""
 import sys, numpy as np, torch
 sys.path.insert(0, '.')
 from chattts_amd import _lib
