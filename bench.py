@@ -5,8 +5,8 @@ A "step" = one pass of the whole hot path over one batch of synthetic input: pre
 replay) of a 64-utterance mixed-length batch, DVAE + Vocos decode of all 64 rows, and the `.cpu().numpy()` of the float32
 waveforms the reference path ends with (core.py:508-510) -- BASELINE.json configs[2], "batch=64 mixed-length utterances
 ... hipGraph-captured decode, top-p sampling"; the metric is quoted on batch=64.  Inputs (weights, the embedded prompts,
-the Exp(1) draws of the seeded CPU generator) are resident in HBM before the timed region starts; the prompt embedding
-gather (Embed.forward, a2) is outside it (0.1 ms).
+the prompt token ids, the Exp(1) draws of the seeded CPU generator) are resident in HBM before the timed region starts; the prompt
+embedding gather (Embed.forward, a2) is inside it.
 
 One invocation measures BOTH numeric modes on the same workload: `value` is the bf16 perf mode BASELINE.json's configs
 name; `parity_mode` is the f32 mode whose token ids are bit-exact against the reference -- its sha256 over all generated
@@ -200,6 +200,99 @@ def mfma_rooflines(dev) -> dict:
     return out
 
 
+def config_legs_bf16(gpt, codec, dev) -> dict:
+    """BASELINE.json configs[1] (C2: batch 1, 512 speech tokens, bf16, GPT decode + DVAE) and configs[4] (C5: streaming, batch 16,
+    chunked yield schedule with the acoustic decode of every yield) on the engines of the main leg -- the recipes of
+    tools/configs_run.py, so that the driver's own bench record carries every configured workload."""
+    from chattts_amd.core import Chat, InferCodeParams
+    chat = Chat()
+    chat.gpt, chat.codec = gpt, codec
+    out = {}
+
+    def med(fn, reps=3):
+        fn()
+        ts, o = [], None
+        for _ in range(reps):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            o = fn()
+            torch.cuda.synchronize(dev)
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts)), o
+
+    # C2
+    ids, mask, tmask = synth.make_prompts(1, 32, 32, seed=1)
+    a = (torch.from_numpy(ids), torch.from_numpy(mask), torch.from_numpy(tmask))
+    p2 = InferCodeParams(max_new_token=513, manual_seed=42, show_tqdm=False)
+    stop1 = torch.tensor([512], dtype=torch.int32)
+    t_gpt, _ = med(lambda: list(chat.infer_code(*a, p2, stop_at=stop1))[-1])
+    dec_ms, n_steps = gpt.last_stats.get("decode_ms", 0.0), gpt.last_stats.get("steps", 0)
+    t_all, wav = med(lambda: chat.infer_ids(*a, p2, stop_at=stop1))
+    step_ms = dec_ms / max(1, n_steps - 1)
+    # SURVEY 8d bytes of one batch-1 decode step: every weight once + K and V of the visible keys (32-token prompt + i generated)
+    wbytes = gpt.weight_bytes_per_step()
+    kv = float(np.mean([(32 + i) for i in range(1, n_steps)])) * 2 * GPT.n_layers * 768 * 2
+    out["C2"] = {"config": "configs[1]: batch=1, 512 speech tokens, bf16, GPT decode + DVAE + Vocos + waveform on the host",
+                 "wall_ms": round(t_all * 1e3, 2), "gpt_ms": round(t_gpt * 1e3, 2), "decode_ms_per_gpt_step": round(step_ms, 4),
+                 "audio_s": round(audio_seconds([512]), 2), "value": round(audio_seconds([512]) / t_all, 1), "unit": "audio-s/s",
+                 "wav_shape": list(wav.shape),
+                 "roofline_whole_decode_step": {"bound": "hbm", "alg_bytes_per_step": int(wbytes + kv), "achieved": round((wbytes + kv) / (step_ms * 1e-3) / 1e9, 1)
+                                                if step_ms > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                "frac": round((wbytes + kv) / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if step_ms > 0 else None}}
+    # C5
+    ids, mask, tmask = synth.make_prompts(16, 16, 48, seed=2)
+    stop16 = torch.from_numpy(synth.make_stop_lengths(16, 128, 512, seed=2))
+    a = (torch.from_numpy(ids), torch.from_numpy(mask), torch.from_numpy(tmask))
+    p5 = InferCodeParams(max_new_token=int(stop16.max()) + 1, manual_seed=42, show_tqdm=False)
+    ttfs, totals, nchunks = [], [], 0
+    for _ in range(12):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        first, nchunks = None, 0
+        for _chunk in chat.infer_ids_stream(*a, p5, stop_at=stop16):
+            if first is None:
+                first = time.perf_counter() - t0
+            nchunks += 1
+        totals.append(time.perf_counter() - t0)
+        ttfs.append(first)
+    out["C5"] = {"config": "configs[4]: streaming, batch=16, mixed lengths 128..512, the reference's yield schedule (24-token chunks, first audio "
+                           "after 72 tokens), chunked prefill path + DVAE/Vocos of every yield overlapped with the next chunk's generation",
+                 "samples": len(ttfs) - 2, "ttfs_ms_p50": round(1e3 * float(np.median(ttfs[2:])), 2),
+                 "ttfs_ms_p90": round(1e3 * float(np.percentile(ttfs[2:], 90)), 2), "total_ms_p50": round(1e3 * float(np.median(totals[2:])), 1),
+                 "chunks": nchunks, "audio_s": round(audio_seconds(stop16.tolist()), 1),
+                 "value": round(audio_seconds(stop16.tolist()) / float(np.median(totals[2:])), 1), "unit": "audio-s/s"}
+    return out
+
+
+def config_leg_c1(gpt32, codec, dev) -> dict:
+    """BASELINE.json configs[0] (C1: one 16-token sentence, near-greedy decode -- the reference's CPU-runnable case) on the f32 parity
+    engine; token ids compared bit for bit with the reference's own output (tests/golden/generate.npz `c1.ids`)."""
+    from chattts_amd.core import Chat, InferCodeParams
+    chat = Chat()
+    chat.gpt, chat.codec = gpt32, codec
+    ids, mask, tmask = synth.make_prompts(1, 16, 16, seed=0)
+    a = (torch.from_numpy(ids), torch.from_numpy(mask), torch.from_numpy(tmask))
+    p1 = InferCodeParams(top_P=0.005, top_K=1, max_new_token=48, manual_seed=42, show_tqdm=False)
+    chat.infer_ids(*a, p1)
+    ts = []
+    for _ in range(3):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        chat.infer_ids(*a, p1)
+        torch.cuda.synchronize(dev)
+        ts.append(time.perf_counter() - t0)
+    t = float(np.median(ts))
+    o = list(chat.infer_code(*a, p1))[-1]
+    exact = None
+    gp = os.path.join(ROOT, "tests", "golden", "generate.npz")
+    if os.path.exists(gp):
+        exact = bool(np.array_equal(o.ids[0].cpu().numpy(), np.load(gp)["c1.ids"]))
+    n = int(o.ids[0].shape[0])
+    return {"config": "configs[0]: one 16-token sentence, top_K=1 / top_P=0.005 (tests/#511.py parameters), f32 parity mode, GPT + DVAE + Vocos",
+            "wall_ms": round(t * 1e3, 2), "tokens": n, "audio_s": round(audio_seconds([n]), 3), "value": round(audio_seconds([n]) / t, 1),
+            "unit": "audio-s/s", "ids_bit_exact_vs_reference": exact}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -215,6 +308,7 @@ def main():
     ap.add_argument("--no-ttfs", action="store_true")
     ap.add_argument("--no-parity-mode", action="store_true")
     ap.add_argument("--no-bf16-parity", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the BASELINE.json configs[0] / [1] / [4] legs (C1, C2, C5)")
     ap.add_argument("--pipeline", action="store_true", help="time the main leg as a software-pipelined queue of batches (batch i's acoustic decode "
                     "overlaps batch i+1's generation); default: one batch after the other, the pipelined figure is reported beside it")
     ap.add_argument("--parity-steps", type=int, default=5, help="timed passes of the f32 parity mode")
@@ -282,12 +376,12 @@ def main():
     warpers, procs = E.gen_logits(625, 0.7, 20, 1.05)
     temp = torch.tensor([0.3] * 4)
     max_new = int(stop.max()) + 1
-    emb = gpt.embed_prompt(ids_t, tm_t)
-    ids_d, mask_d = ids_t.to(dev), mask_t
+    ids_d, mask_d, tm_d = ids_t.to(dev), mask_t, tm_t.to(dev)   # the prompt ids are resident; Embed.forward (a2) runs INSIDE the clock
 
     def one_pass(eng, use_graph=True, profile_tag=None, decode_audio=True, profile_stride=1, keep_ids=False, teacher=None, keep_hidden=False):
         """generate -> DVAE -> Vocos -> host numpy (the reference path's last op is `.cpu().numpy()`, core.py:508-510)"""
         out = None
+        emb = eng.embed_prompt(ids_d, tm_d)      # a2: Embed.forward (embed.py:52-79)
         for out in eng.generate(emb, ids_d, temp, 625, mask_d, max_new, 0, (*procs, *warpers), return_hidden=True,
                                 manual_seed=42, use_graph=use_graph, stop_at=stop_t, row_offset=wl["row_offset"],
                                 total_rows=wl["total_rows"], profile_tag=profile_tag, profile_stride=profile_stride, lanes=args.lanes,
@@ -309,6 +403,7 @@ def main():
 
     def gpt_pass(eng):
         out = None
+        emb = eng.embed_prompt(ids_d, tm_d)
         for out in eng.generate(emb, ids_d, temp, 625, mask_d, max_new, 0, (*procs, *warpers), return_hidden=True,
                                 manual_seed=42, use_graph=not args.no_graph, stop_at=stop_t, row_offset=wl["row_offset"],
                                 total_rows=wl["total_rows"], lanes=args.lanes):
@@ -361,14 +456,20 @@ def main():
     value = total_audio / dt
     gpt_steps = gpt.last_stats.get("steps", 0)
     decode_ms = gpt.last_stats.get("decode_ms", 0.0)      # host wall of the decode loop of the LAST timed pass
+    # what the timed passes produced, beyond forced lengths and finite audio: the seeded run is deterministic -- two more passes (graph
+    # replay and eager launches) must give the same token ids bit for bit
+    _, _, ids_g = one_pass(gpt, use_graph=not args.no_graph, decode_audio=False, keep_ids=True)
+    _, _, ids_e = one_pass(gpt, use_graph=False, decode_audio=False, keep_ids=True)
+    ids_check = {"ids_sha256": ids_digest(ids_g), "graph_equals_eager": ids_digest(ids_g) == ids_digest(ids_e)}
+    assert ids_check["graph_equals_eager"], "graph replay and eager launches disagree on the sampled token ids"
 
     result = {
         "metric": "audio seconds/sec (RTF), batch=64 per GPU", "value": round(value, 2), "unit": "audio-s/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000.0 * dt / args.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "C3: batch=64/GPU mixed-length (prompts 16-48 tok, outputs U{%d..%d} tok), top-p .7/top-k 20/rep 1.05/"
-                               "temp .3, manual_seed 42, hipGraph decode + DVAE + Vocos + waveform D2H (.cpu().numpy()); prompt "
-                               "embedding gather outside the timed region; %s" % (args.min_len, args.max_len,
+                               "temp .3, manual_seed 42, prompt embedding gather + hipGraph decode + DVAE + Vocos + waveform D2H (.cpu().numpy()); "
+                               "%s" % (args.min_len, args.max_len,
                                "the K batches are software-pipelined: DVAE + Vocos + D2H of batch i on a side HIP stream while batch i+1 is generated"
                                if args.pipeline else "one batch after the other"),
                    "pipelined": bool(args.pipeline),
@@ -377,6 +478,7 @@ def main():
                                                           "bf16x3": ": split-bf16, f32-class", "f32": ": f32 MFMA tiles"}[codec_gemm],
                    "global_batch": Bg, "decode_steps_per_pass": gpt_steps, "parallelism": f"dp{world}", "lanes_per_gpu": args.lanes,
                    "tokens_per_pass": int(stop.sum()), "audio_s_per_pass": round(audio_seconds(stop), 2)},
+        "ids_check": ids_check,
     }
     if world == 1 and not args.pipeline and not args.no_parity_mode:
         # the same workload as a software-pipelined QUEUE of batches (Chat.infer_ids_pipelined / CodecEngine.decode_to_wavs_async):
@@ -522,9 +624,14 @@ def main():
                                  "ids_sha256": got, "golden_sha256": want,
                                  "ids_match_reference": (got == want) if want else None,
                                  "golden": "tests/golden/bench_c3.npz: the reference's GPT.generate on this workload (oracle/make_bench_golden.py)"}
+        result["value_parity_f32"] = result["parity_mode"]["value"]          # the number that meets north_star's bit-exactness
+        result["parity_f32_ids_match_reference"] = result["parity_mode"]["ids_match_reference"]
         if not args.no_roofline:
             roof32, k32 = roofline_leg(gpt32, 4, (3,), steps32, dec32_ms / max(1, steps32 - 1), pmc_key_suffix="_f32")
             result["parity_mode"]["roofline"] = roof32
+        if not args.no_configs:
+            note("config C1 (f32 parity engine)")
+            result.setdefault("configs", {})["C1"] = config_leg_c1(gpt32, codec, dev)
         if codec is not codec_main:
             # the perf mode's decoder (one fp16 MFMA per product) against the parity mode's on the SAME hidden states: this pass's 64 rows
             hs = [torch.from_numpy(h).to(dev) for h in hid32]
@@ -567,8 +674,20 @@ def main():
         roof, kernels = roofline_leg(gpt, es, tags, gpt_steps, decode_ms / max(1, gpt_steps - 1))
         result["roofline"] = roof
         result["decode_kernels"] = kernels
+        ksum = sum(v["avg_launch_us"] * v["launches_per_step"] for v in kernels.values())
+        roof["whole_decode_step"]["sum_kernel_us_per_step"] = round(ksum, 1)
+        roof["whole_decode_step"]["sum_kernel_note"] = ("sum over the step's launches of the per-launch event durations (eager passes); it may exceed "
+                                                        "ms_per_step (graph replay, host wall): per-launch durations overlap their neighbours' "
+                                                        "dispatch, so every per-kernel frac is an upper bound and only the whole-step frac is wall-anchored")
         if world == 1:
             result["roofline_mfma"] = mfma_rooflines(dev)
+
+    # ---- BASELINE.json configs[1] and [4] on the same engines (configs[0] ran on the f32 engine above; [3] is this file under torchrun) ----
+    if rank == 0 and world == 1 and args.dtype == "bf16" and not args.no_configs:
+        note("configs C2 (batch 1) and C5 (streaming)")
+        result.setdefault("configs", {}).update(config_legs_bf16(gpt, codec, dev))
+        result["configs"]["C3"] = "this line's `value` (bf16) and `value_parity_f32`"
+        result["configs"]["C4"] = "bench.py --gpus N under torch.distributed.run: batch 64 x N sharded, ONE RCCL weight broadcast (`ranks`)"
 
     # ---- time to first sample: stream=True with the reference's yield schedule (first audio after 3 x 24 tokens) ----
     if rank == 0 and world == 1 and not args.no_ttfs:
