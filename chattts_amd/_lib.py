@@ -25,6 +25,7 @@ class GptWeights(C.Structure):
         ("emb_text", P), ("head_text", P), ("n_text", C.c_int32),
         ("wqkv_pk", PP), ("wo_pk", PP), ("wgu_pk", PP), ("wd_pk", PP),
         ("heads_pk", P), ("head_text_pk", P),
+        ("wo_hd", PP),
     ]
 
 
@@ -122,6 +123,7 @@ SIGNATURES = {
     "ctts_k_attention": (C.c_int, [P, P, P, I32, I32, P, I32, P, P, I32, P]),
     "ctts_k_attention_prefill": (C.c_int, [P, P, P, I32, P, I32, I32, P, I32, P]),
     "ctts_k_attention_dec": (C.c_int, [P, P, P, I32, P, P, P, I32, P, P, I32, P]),
+    "ctts_k_attention_oproj": (C.c_int, [P, P, P, I32, P, P, P, I32, P, P, P, P, P, P]),
     "ctts_k_embed_codes": (C.c_int, [P, P, I32, P, P, I32, P]),
     "ctts_k_final_norm": (C.c_int, [P, I32, P, F, P, P, I32, P, I32, I32, P]),
     "ctts_k_sample": (C.c_int, [C.POINTER(GenState), P, P]),

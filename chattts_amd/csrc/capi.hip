@@ -35,6 +35,9 @@ struct ctts_gpt {
   ctts_gpt_weights w;
   std::vector<const void*> wqkv, wo, wgu, wd;
   std::vector<const void*> wqkv_pk, wo_pk, wgu_pk, wd_pk;   // fragment-packed copies for the decode step, or empty
+  std::vector<const void*> wo_hd;                           // o_proj per attention head (perf mode), or empty
+  bool qkv_att = false;        // perf mode decode, <= 64 rows: QKV + attention as ONE launch (gpt.hip qkv_attention_k); env CTTS_QKV_ATT=1, OFF by default
+  bool att_oproj = false;      // perf mode decode: o_proj + residual folded into the attention launch (env CTTS_ATT_OPROJ=0: separate launches)
   bool dec_packed = false;     // perf mode (bf16 weights): decode.hip
   bool dec_packed32 = false;   // parity mode (f32 weights): decode32.hip
   bool heads_packed = false;   // heads GEMM on packed f32 operands (decode32.hip), both modes
@@ -63,7 +66,8 @@ struct ctts_gpt {
 
 static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 #define ATT_CUS_MAX 512   // upper bound of compute units the attention split state is sized for
-
+#define QA_LAYERS_MAX 32  // layers the arrival words of the fused QKV + attention launches are sized for
+#define QA_STRIDE 1088    // = HO_STRIDE (decode_dev.hpp): ints between two arrival words
 struct GptWs {
   float *x, *qkv, *ao, *act, *hfin, *logits, *ssq;
   uint16_t* xb;  // bf16 copy of the residual stream (perf mode); ao / act are reused as bf16 buffers there
@@ -76,8 +80,14 @@ struct GptWs {
   float* att_part;    // attention remainder splitting: partials of the split units' pieces, and their arrival counters
   int32_t* att_cnt;
   int32_t* row_map;   // device-side compaction: this step's compact row -> utterance map (written by the step's first kernel)
+  float* rope_cs;     // [Bp][64] cos[32] | sin[32] of every decode row's position, written by the step's first kernel (fused QKV + attention)
+  int32_t* qa_flag;   // fused QKV + attention launches: arrival words [QA_LAYERS_MAX][8 copies][16] (12 heads used), zeroed by the step's first kernel
+  float* op_part;     // attention + o_proj in one launch: [Bp][12][768] partials of the (utterance, head) units ...
+  int32_t* op_cnt;    // ... and the rows' arrival counters, RIGHT BEHIND att_cnt: one memset zeroes both (cnt_bytes)
+  size_t op_part_bytes;
   size_t bytes;
 };
+static size_t cnt_bytes(int B) { return ((size_t)ATT_CUS_MAX + ((size_t)B + 15) / 16 * 16) * sizeof(int32_t); }
 static GptWs carve(void* base, int B, int T) {
   const size_t M = (size_t)B * (T > 1 ? T : 1);
   GptWs w;
@@ -105,7 +115,12 @@ static GptWs carve(void* base, int B, int T) {
   w.rstd = (float*)(p + off); off += align_up(Mp * sizeof(float));
   w.row_map = (int32_t*)(p + off); off += align_up(Bp * sizeof(int32_t));
   w.att_part = (float*)(p + off); off += align_up((size_t)ATT_CUS_MAX * ATT_SPLIT_MAX * 66 * sizeof(float));
-  w.att_cnt = (int32_t*)(p + off); off += align_up((size_t)ATT_CUS_MAX * sizeof(int32_t));
+  w.att_cnt = (int32_t*)(p + off); off += align_up(cnt_bytes(B));
+  w.op_cnt = w.att_cnt + ATT_CUS_MAX;
+  w.op_part_bytes = Bp * NHEAD * HID * sizeof(float);
+  w.op_part = (float*)(p + off); off += align_up(w.op_part_bytes);
+  w.rope_cs = (float*)(p + off); off += align_up(Bp * 64 * sizeof(float));
+  w.qa_flag = (int32_t*)(p + off); off += align_up((size_t)QA_LAYERS_MAX * NHEAD * QA_STRIDE * sizeof(int32_t));
   w.bytes = off;
   return w;
 }
@@ -134,10 +149,21 @@ extern "C" int ctts_gpt_create(ctts_gpt** out, const ctts_gpt_weights* w) {
     g->dec_packed32 = on && w->weight_dtype != CTTS_BF16 && w->kv_dtype != CTTS_BF16;
   }
   { const char* e = getenv("CTTS_DEC_PACKED"); g->heads_packed = w->heads_pk != nullptr && !(e && atoi(e) == 0); }
+  if (w->wo_hd && g->dec_packed) {
+    g->wo_hd.assign(w->wo_hd, w->wo_hd + L);
+    // OFF by default: measured on the C3 bench the fused launch costs what the two launches cost (13.9 us vs 9.07 + 4.87) and the step
+    // gets 26 us SLOWER (profiles/r4b_ab_oproj.log): the 12 -> 1 hand-off through memory is a chain of dependent round trips
+    const char* e = getenv("CTTS_ATT_OPROJ");
+    g->att_oproj = e && atoi(e) == 1;
+  }
   { const char* e = getenv("CTTS_SKIP_FINISHED"); if (e && atoi(e) == 0) g->skip_finished = false; }
   { const char* e = getenv("CTTS_FNORM_FUSE"); if (e && atoi(e) == 0) g->fnorm_fuse = false; }
   { const char* e = getenv("CTTS_W_TEMPORAL_LAYERS"); if (e) g->temporal_layers = atoi(e); }
   { const char* e = getenv("CTTS_PF"); if (e) g->pf_mask = atoi(e); }
+  // OFF by default: measured on the C3 bench the fused launch is worth +0.1 ... +0.8 % (13.9 us against 5.3 + 9.1 us; more prefetch ahead of
+  // the wait LOSES 4 %, none loses 4 %: profiles/r4f_ab_qkv_att_pre.log, r4g_ab_qkv_att_variants.log) -- not enough to make a launch that
+  // spins on device memory the default
+  { const char* e = getenv("CTTS_QKV_ATT"); g->qkv_att = e && atoi(e) == 1; }
   { const char* e = getenv("CTTS_PRE32_PACKED"); if (e && atoi(e) == 0) g->pre32_packed = false; }
   {
     int dev = 0, cus = 0;
@@ -276,11 +302,31 @@ static int run_step(ctts_gpt* g, const ctts_gen_state* s, int q_per_b, hipStream
     d.Ap = ws.xp; d.Wp = (const uint16_t*)g->wqkv_pk[l]; d.N = 3 * HID; d.K = HID; d.ssq_in = ws.ssq; d.epi = FEPI_QKV_ROPE;
     d.C32 = ws.qkv; d.ldc = 3 * HID; d.desc = ws.desc; d.cos_t = g->w.rope_cos; d.sin_t = g->w.rope_sin;
     d.kc = (uint16_t*)kc; d.vc = (uint16_t*)vc; d.cmax = cmax;
-    { Prof p(g, 1, st, prof_ok); CK(launch_gemm_dec(d, st)); }
-    { Prof p(g, 3, st, prof_ok); CK(launch_attention(ws.qkv, kc, vc, kt, cmax, ws.aop, 2, rm, M, st)); }
-    d.Ap = ws.aop; d.Wp = (const uint16_t*)g->wo_pk[l]; d.N = HID; d.ssq_in = nullptr; d.epi = FEPI_RES; d.C32 = ws.x; d.ldc = HID;
-    d.Cp = ws.xp; d.kch_out = HID / 32; d.ssq_out = ws.ssq;
-    { Prof p(g, 4, st, prof_ok); CK(launch_gemm_dec(d, st)); }
+    const bool fuse_qa = g->qkv_att && M <= 64 && kv_layer < ((size_t)1 << 31) && g->w.n_layers <= QA_LAYERS_MAX && g->n_cu == 0 && g->pf_mask == 0 && !(g->att_oproj) && rm.dbg == nullptr;
+    bool need_o = true;   // o_proj + residual as its own launch
+    if (fuse_qa) {   // QKV + attention: one launch (gpt.hip qkv_attention_k)
+      d.ho_flag = ws.qa_flag + (size_t)l * NHEAD * QA_STRIDE; rm.qf_flag = d.ho_flag; d.rope_cs = ws.rope_cs; rm.qf_kv_bytes = (int)kv_layer;
+      Prof p(g, 3, st, prof_ok);
+      CK(launch_qkv_attention(d, kc, vc, cmax, ws.aop, rm, M, st));
+    } else {
+      { Prof p(g, 1, st, prof_ok); CK(launch_gemm_dec(d, st)); }
+      if (g->att_oproj && g->n_cu == 0) {   // attention + o_proj + residual: one launch (gpt.hip attention_k<OPJ>)
+        rm.wo_h = (const uint16_t*)g->wo_hd[l]; rm.op_part = ws.op_part; rm.op_part_bytes = (int)ws.op_part_bytes; rm.op_cnt = ws.op_cnt;
+        rm.x32 = ws.x; rm.xp = ws.xp; rm.ssq = ws.ssq;
+        Prof p(g, 3, st, prof_ok);
+        CK(launch_attention_oproj(ws.qkv, kc, vc, cmax, rm, M, st));
+        need_o = false;
+      } else {
+        Prof p(g, 3, st, prof_ok);
+        CK(launch_attention(ws.qkv, kc, vc, kt, cmax, ws.aop, 2, rm, M, st));
+      }
+    }
+    if (need_o) {
+      d.Ap = ws.aop; d.Wp = (const uint16_t*)g->wo_pk[l]; d.N = HID; d.ssq_in = nullptr; d.epi = FEPI_RES; d.C32 = ws.x; d.ldc = HID;
+      d.Cp = ws.xp; d.kch_out = HID / 32; d.ssq_out = ws.ssq; d.ho_flag = nullptr;
+      Prof p(g, 4, st, prof_ok);
+      CK(launch_gemm_dec(d, st));
+    }
     d.Ap = ws.xp; d.Wp = (const uint16_t*)g->wgu_pk[l]; d.N = INTER; d.ssq_in = ws.ssq; d.epi = FEPI_SILU; d.C32 = nullptr;
     d.Cp = ws.actp; d.kch_out = INTER / 32; d.ssq_out = nullptr;
     d.pf[0] = pf_none; d.pf[1] = pf_none; (void)pf_d; (void)pf_next;   // (gate/up has no auxiliary wave: see decode.hip)
@@ -452,13 +498,13 @@ extern "C" int ctts_gpt_prefill(ctts_gpt* g, const ctts_gen_state* s, const floa
   CttsDeviceGuard dg(stream);
   hipStream_t st = (hipStream_t)stream;
   const GptWs ws = carve(s->workspace, s->B, s->T);
-  CK(hipMemsetAsync(ws.att_cnt, 0, (size_t)ATT_CUS_MAX * sizeof(int32_t), st));   // arrival counters of the attention split
+  CK(hipMemsetAsync(ws.att_cnt, 0, cnt_bytes(s->B), st));   // arrival counters of the attention split
   CK(hipMemcpyAsync(ws.x, emb, (size_t)s->B * s->T * HID * 4, hipMemcpyDeviceToDevice, st));
   if (g->w.weight_dtype == CTTS_BF16) CK(launch_rows_prep(ws.x, ws.xb, ws.ssq, s->B * s->T, st));
   if (run_step(g, s, s->T, st, false)) return -1;
   // arrival counters of the attention split at the place the DECODE steps carve them (one row per utterance), once the
   // prompt-sized buffers above are dead
-  CK(hipMemsetAsync(carve(s->workspace, s->B, 1).att_cnt, 0, (size_t)ATT_CUS_MAX * sizeof(int32_t), st));
+  CK(hipMemsetAsync(carve(s->workspace, s->B, 1).att_cnt, 0, cnt_bytes(s->B), st));
   return 0;
 }
 
@@ -475,7 +521,7 @@ extern "C" int ctts_gpt_prefill_chunk(ctts_gpt* g, const ctts_gen_state* s, cons
   if (run_step(g, s, tc, st, false, t0, last != 0, tc)) return -1;
   // the decode steps carve the workspace for one row per utterance: zero THEIR attention-split arrival counters once the
   // chunk-sized buffers above are dead
-  if (last) CK(hipMemsetAsync(carve(s->workspace, s->B, 1).att_cnt, 0, (size_t)ATT_CUS_MAX * sizeof(int32_t), st));
+  if (last) CK(hipMemsetAsync(carve(s->workspace, s->B, 1).att_cnt, 0, cnt_bytes(s->B), st));
   return 0;
 }
 
@@ -489,7 +535,9 @@ static int decode_body(ctts_gpt* g, const ctts_gen_state* s, hipStream_t st, boo
     const bool dc = dev_compact(g, s);
     StepPrep sp{ws.desc, s->kv_start, g->skip_finished ? s->finish : nullptr, packed ? 1 : 0, (!fast && g->dec_packed32) ? ws.xp32 : nullptr,
                 dc ? ws.row_map : nullptr,
-                dc ? const_cast<int32_t*>(s->n_active) : nullptr, dc ? s->order : nullptr};
+                dc ? const_cast<int32_t*>(s->n_active) : nullptr, dc ? s->order : nullptr,
+                (packed && g->qkv_att) ? ws.rope_cs : nullptr, g->w.rope_cos, g->w.rope_sin,
+                (packed && g->qkv_att) ? ws.qa_flag : nullptr, g->w.n_layers * NHEAD, QA_STRIDE};
     const int32_t* nact0 = (!g->skip_finished && s->row_map == nullptr) ? nullptr : s->n_active;
     uint16_t* xb = fast ? (packed ? ws.xp : ws.xb) : nullptr;
     if (s->infer_text)
@@ -516,7 +564,7 @@ extern "C" int ctts_gpt_graph_build(ctts_gpt* g, const ctts_gen_state* s, void* 
   {  // the decode workspace may never have seen a prefill (slot pools prefill into their own): zero the arrival counters of the
      // attention split once, stream-ordered before anything the graph will run
     const GptWs ws = carve(s->workspace, s->B, 1);
-    CK(hipMemsetAsync(ws.att_cnt, 0, (size_t)ATT_CUS_MAX * sizeof(int32_t), st));
+    CK(hipMemsetAsync(ws.att_cnt, 0, cnt_bytes(s->B), st));
   }
   CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
   const int rc = decode_body(g, s, st, false);
@@ -840,6 +888,16 @@ extern "C" int ctts_k_attention_dec(const float* qkv, const uint16_t* kcache, co
   if (n_cu < 0 || n_cu > ATT_CUS_MAX) return fail("ctts_k_attention_dec: bad n_cu");
   GptRowMap rm{1, nullptr, nullptr, nullptr, n_active, nullptr, reinterpret_cast<const RowDesc*>(desc), part, cnt, n_cu, 0, 0};
   CK(launch_attention(qkv, kcache, vcache, WT_BF16, cmax, out_packed, 2, rm, M, (hipStream_t)stream));
+  return 0;
+}
+extern "C" int ctts_k_attention_oproj(const float* qkv, const uint16_t* kcache, const uint16_t* vcache, int32_t cmax, const uint16_t* wo_hd,
+                                      const int32_t* desc, const int32_t* n_active, int32_t M, float* part, int32_t* cnt, float* x32,
+                                      uint16_t* xp, float* ssq, void* stream) {
+  if (!wo_hd || !desc || !part || !cnt || !x32 || !xp || !ssq || M <= 0) return fail("ctts_k_attention_oproj: bad arguments");
+  GptRowMap rm{1, nullptr, nullptr, nullptr, n_active, nullptr, reinterpret_cast<const RowDesc*>(desc), nullptr, nullptr, 0, 0, 0};
+  rm.wo_h = wo_hd; rm.op_part = part; rm.op_part_bytes = (int)((size_t)((M + 15) / 16 * 16) * NHEAD * HID * sizeof(float)); rm.op_cnt = cnt;
+  rm.x32 = x32; rm.xp = xp; rm.ssq = ssq;
+  CK(launch_attention_oproj(qkv, kcache, vcache, cmax, rm, M, (hipStream_t)stream));
   return 0;
 }
 extern "C" int ctts_k_embed_codes(const float* emb_code, const int64_t* ids_buf, int32_t tcap, const int32_t* len, float* x, int32_t B,

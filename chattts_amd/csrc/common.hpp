@@ -116,6 +116,26 @@ __device__ __forceinline__ u128 load16_nt(const void* p) {
   return r;
 }
 __device__ __forceinline__ u128 load16(const void* p) { return *reinterpret_cast<const u128*>(p); }
+// 16-byte load that is coherent at agent scope (`global_load_dwordx4 ... sc1`): data another workgroup of the SAME launch published with
+// write-through (sc1) stores -- MI355X guide Guideline 16.  Two 8-byte relaxed agent atomics (the widest the builtin lowers to sc1).
+__device__ __forceinline__ u128 load16_sc1(const void* p) {
+  const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
+  const unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  u128 r;
+  r.x = (uint32_t)a; r.y = (uint32_t)(a >> 32); r.z = (uint32_t)b; r.w = (uint32_t)(b >> 32);
+  return r;
+}
+// the XCD this wave runs on (0..7); used for speed only (which copy of a flag to poll), never for correctness
+__device__ __forceinline__ unsigned xcc_id() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  unsigned x;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+  return x;
+#else
+  return 0;
+#endif
+}
 
 // Fragment-packed bf16 operand order of the decode projections (decode.hip): a [rows][C] matrix is stored as
 // [rows/16][C/32][lane = (c%32)/8 * 16 + row%16][c%8], i.e. every (16-row tile, 32-column chunk) is one contiguous KiB in

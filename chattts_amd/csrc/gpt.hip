@@ -6,7 +6,14 @@
 
 #include "common.hpp"
 #include "kernels.hpp"
+#include "decode_dev.hpp"
 
+#ifndef CTTS_QF_DELAY
+#define CTTS_QF_DELAY 8   // s_sleep units before a fused-launch attention unit requests its first keys (lets the QKV tiles' requests go first; A/B: 0 | 8 | 24)
+#endif
+#ifndef CTTS_QF_PRE
+#define CTTS_QF_PRE 1   // blocks of old keys per wave a fused-launch attention unit requests before it waits for its QKV tiles (A/B: 0 | 1 | 2; measured 2: 1344, 1: 1422, separate launches: 1406 audio-s/s, profiles/r4f_ab_qkv_att_pre.log)
+#endif
 #define HID 768
 #define NHEAD 12
 #define HDIM 64
@@ -45,6 +52,14 @@ __device__ __forceinline__ void emit_row(float4 s, int t, float* __restrict__ x_
 
 // The first kernel of a decode step also writes the step's row descriptors (kernels.hpp RowDesc): it walks
 // row_map -> len -> kv_start -> finish once, the 20 QKV epilogues and 20 attention launches behind it start from desc[m].
+// ... and, for the QKV tiles of the fused QKV + attention launch, the RoPE factors of the row's position as one 256-byte row
+// (cos[32] | sin[32]): their epilogue then needs no row -> position -> table chain
+__device__ __forceinline__ void write_rope_cs(const StepPrep& sp, int m, int b, int slot, int t) {
+  if (sp.rope_cs == nullptr || t >= 64) return;
+  const int ks = sp.kv_start[b];
+  const int pos = slot - ks < 0 ? 1 : slot - ks;   // as write_desc
+  sp.rope_cs[(size_t)m * 64 + t] = t < 32 ? sp.cos_t[pos * 32 + t] : sp.sin_t[pos * 32 + t - 32];
+}
 __device__ __forceinline__ void write_desc(const StepPrep& sp, int m, int b, int slot) {
   RowDesc d;
   const int ks = sp.kv_start[b];
@@ -80,6 +95,13 @@ __device__ __forceinline__ int nth_unfinished(const uint8_t* __restrict__ finish
   return found;
 }
 
+// The step's first kernel also zeroes the arrival words of the fused QKV + attention launches of the 20 layers behind it (plain stores:
+// a kernel boundary lies between them and the first atomic).
+__device__ __forceinline__ void step_zero(const StepPrep& sp) {
+  if (sp.zero_p == nullptr) return;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < sp.zero_n; i += gridDim.x * blockDim.x) sp.zero_p[(size_t)i * sp.zero_stride] = 0;
+}
+
 __device__ __forceinline__ uint16_t* xb_row_ptr(uint16_t* xb, int m, int t, int packed) {
   // emit_row adds 4t itself: hand it a base such that base + 4t is where columns 4t..4t+3 of row m live
   if (!xb) return nullptr;
@@ -92,6 +114,7 @@ __global__ __launch_bounds__(192) void embed_codes_k(const float* __restrict__ e
                                                      const int32_t* __restrict__ row_map, const int32_t* __restrict__ n_active,
                                                      StepPrep sp) {
   CTTS_PROBE_RETURN();
+  step_zero(sp);
   const int m = blockIdx.x, t = threadIdx.x;
   int b;
   if (sp.row_map_out != nullptr) {   // device-side compaction: this step's row order comes from the finish flags
@@ -109,6 +132,7 @@ __global__ __launch_bounds__(192) void embed_codes_k(const float* __restrict__ e
   }
   const int slot = len[b] - 1;
   if (sp.desc != nullptr && t == 0) write_desc(sp, m, b, slot);
+  write_rope_cs(sp, m, b, slot, t);
   const int64_t* tok = ids_buf + ((size_t)b * tcap + slot) * NVQ;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -123,7 +147,7 @@ __global__ __launch_bounds__(192) void embed_codes_k(const float* __restrict__ e
 }
 
 static StepPrep prep_or_none(const StepPrep* p) {
-  StepPrep sp{nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr};
+  StepPrep sp{nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 1};
   if (p) sp = *p;
   return sp;
 }
@@ -268,9 +292,16 @@ template <> __device__ __forceinline__ void store_out<bf16_t>(bf16_t* p, float v
 // 500-key context is 4 blocks, and with fewer units than CUs (the last quarter of a C3 batch, every step of C2) nothing else on
 // the CU covers the round trip between them (profiles/r3y_attn_phase_probe.log: 240 units at 430 keys spend 3.0 us behind the
 // first block).  The order in which blocks are consumed is untouched, so the result is the same bit for bit in both modes.
-template <typename KT, int NW, typename OT, bool PKO = false, bool SPLIT = false, bool PF = false, int NBUF = 2>
-__global__ __launch_bounds__(64 * NW + (PF ? 64 : 0)) void attention_k(const float* __restrict__ qkv, const KT* __restrict__ kc,
-                                                       const KT* __restrict__ vc, int cmax, OT* __restrict__ out, GptRowMap rm) {
+//
+// OPJ (round 4; decode, perf mode): o_proj + residual folded into this launch -- see the block behind the merge.
+//
+// QF (round 4; decode, perf mode): the unit runs INSIDE the fused QKV + attention launch (qkv_attention_k below).  Its q row and the
+// newest key / value are written by QKV tiles of the same launch, so it (1) requests its first two blocks of OLD keys (everything
+// below the step's slot: written by earlier launches), (2) waits for its head's arrival word, (3) reads q and the newest K / V row
+// with sc1 loads and goes on as usual; the newest key is consumed last, by the last wave, as a block of its own.
+template <typename KT, int NW, typename OT, bool PKO = false, bool SPLIT = false, bool PF = false, int NBUF = 2, bool OPJ = false, bool QF = false>
+__device__ __forceinline__ void attention_body(const float* __restrict__ qkv, const KT* __restrict__ kc, const KT* __restrict__ vc, int cmax,
+                                               OT* __restrict__ out, const GptRowMap& rm, const int h_in, const int m_in, const int wg_linear) {
   constexpr int DPL = KTraits<KT>::DPL;
   constexpr int LPK = HDIM / DPL;   // lanes per key: 8 (bf16) / 16 (f32)
   constexpr int KPI = 64 / LPK;     // keys per load instruction: 8 / 4
@@ -281,17 +312,24 @@ __global__ __launch_bounds__(64 * NW + (PF ? 64 : 0)) void attention_k(const flo
 #define CTTS_KV_NT 1              // A/B builds: python -m chattts_amd.build --variant kvplain -DCTTS_KV_NT=0 (profiles/r3ap_kv_nt_ab.log)
 #endif
   constexpr bool KV_NT = NW > 1 && CTTS_KV_NT;    // decode: every KV byte is read once per step by exactly one workgroup -> non-temporal
-  __shared__ float sm_m[NW], sm_l[NW], sm_acc[NW][HDIM];
-  if (NW > 1) CTTS_PROBE_RETURN();
+  constexpr int NU = QF ? 2 : 1;   // units per workgroup: the fused launch's workgroups are 8 waves = heads 2p and 2p + 1 of one utterance
+  __shared__ float sm_m_[NU][NW], sm_l_[NU][NW], sm_acc_[NU][NW][HDIM];
+  __shared__ __attribute__((aligned(16))) bf16_t sm_on[OPJ ? HDIM : 8];   // OPJ: the unit's normalised output, bf16
+  __shared__ __attribute__((aligned(16))) float sm_p[OPJ ? HID : 4];      // OPJ: its 768-wide o_proj partial
+  __shared__ int sm_last;
   if (PF && (threadIdx.x >> 6) == NW) {   // fifth wave: this layer's gate/up weights towards this XCD's L2 (common.hpp), then gone
     prefetch_weight_tiles(rm.pf, threadIdx.x & 63, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
     return;
   }
 
-  int h = blockIdx.x, m = blockIdx.y;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int unit = QF ? (int)(threadIdx.x >> 8) : 0;   // which of the workgroup's units this wave belongs to
+  int h = h_in + unit, m = m_in;
+  const int tid = QF ? (int)(threadIdx.x & 255) : (int)threadIdx.x, wave = tid >> 6, lane = tid & 63;   // thread / wave index WITHIN the unit
+  float (&sm_m)[NW] = sm_m_[unit];
+  float (&sm_l)[NW] = sm_l_[unit];
+  float (&sm_acc)[NW][HDIM] = sm_acc_[unit];
   const int kg = lane / LPK, dl = lane % LPK;
-  long long* dbg = (PKO && rm.dbg) ? rm.dbg + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 : nullptr;
+  long long* dbg = (PKO && rm.dbg) ? rm.dbg + (size_t)wg_linear * 8 : nullptr;
 #define ASTAMP(i) do { if (dbg && tid == 0) dbg[i] = wall_clock64(); } while (0)
   ASTAMP(0);
   int n_piece = 1, piece = 0, su = 0;   // SPLIT: pieces of this unit, this workgroup's piece, index among the split units
@@ -342,7 +380,7 @@ __global__ __launch_bounds__(64 * NW + (PF ? 64 : 0)) void attention_k(const flo
   for (int i = 0; i < DPL; ++i) acc[i] = 0.f;
 
   // this workgroup's key range [rbeg, rend): all visible keys, or one of n_piece KPI-aligned pieces of them
-  int rbeg = jlo, rend = slot + 1;
+  int rbeg = jlo, rend = QF ? slot : slot + 1;   // QF: the newest key (this step's) is handled behind the loop
   if (SPLIT && n_piece > 1) {
     const int pper = ((slot + 1 - jlo + n_piece - 1) / n_piece + KPI - 1) / KPI * KPI;
     rbeg = jlo + piece * pper;
@@ -360,21 +398,39 @@ __global__ __launch_bounds__(64 * NW + (PF ? 64 : 0)) void attention_k(const flo
   // makes hipcc branch around every load and wait vmcnt(0) in between (one memory round trip per load).
   // Clamped lanes re-read the last key (an L1 hit) and are masked where they are consumed.
   const int jlast = max(jend - 1, jlo);
+  // QF: buffer loads with 32-bit byte offsets (one VGPR per address instead of two; 16 loads are in flight across the wait, and two
+  // 8-wave workgroups per CU need <= 128 VGPRs); aux 2 = the same non-temporal hint
+  const auto krs = __builtin_amdgcn_make_buffer_rsrc((void*)kc, 0, QF ? rm.qf_kv_bytes : 0, 0x00020000);
+  const auto vrs = __builtin_amdgcn_make_buffer_rsrc((void*)vc, 0, QF ? rm.qf_kv_bytes : 0, 0x00020000);
+  const unsigned ubase = (((unsigned)b * NHEAD + (unsigned)h) * (unsigned)cmax) * (HDIM * (unsigned)sizeof(KT)) + (unsigned)dl * 16u;
   auto load_blk = [&](u128* kr, u128* vr, int j0) {
+    if constexpr (QF) {
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const u32x4_t t = __builtin_amdgcn_raw_buffer_load_b128(krs, ubase + (unsigned)min(j0 + i * KPI + kg, jlast) * (HDIM * (unsigned)sizeof(KT)), 0, 2);
+        kr[i].x = t.x; kr[i].y = t.y; kr[i].z = t.z; kr[i].w = t.w;
+      }
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const u32x4_t t = __builtin_amdgcn_raw_buffer_load_b128(vrs, ubase + (unsigned)min(j0 + i * KPI + kg, jlast) * (HDIM * (unsigned)sizeof(KT)), 0, 2);
+        vr[i].x = t.x; vr[i].y = t.y; vr[i].z = t.z; vr[i].w = t.w;
+      }
+    } else {
 #pragma unroll
     for (int i = 0; i < NI; ++i) kr[i] = KV_NT ? load16_nt(kbase + (size_t)min(j0 + i * KPI + kg, jlast) * HDIM)
                                                : load16(kbase + (size_t)min(j0 + i * KPI + kg, jlast) * HDIM);
 #pragma unroll
     for (int i = 0; i < NI; ++i) vr[i] = KV_NT ? load16_nt(vbase + (size_t)min(j0 + i * KPI + kg, jlast) * HDIM)
                                                : load16(vbase + (size_t)min(j0 + i * KPI + kg, jlast) * HDIM);
+    }
   };
-  auto use_blk = [&](const u128* kr, const u128* vr, int j0) {
+  auto use_blk_e = [&](const u128* kr, const u128* vr, int j0, const int jend_) {
     float s[NI];
     bool ok[NI];
     float bmax = -INFINITY;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      ok[i] = (j0 + i * KPI + kg) < jend;
+      ok[i] = (j0 + i * KPI + kg) < jend_;
       float kf[DPL];
       float d = 0.f;
       unpack16<KT, DPL>(kr[i], kf);
@@ -405,8 +461,71 @@ __global__ __launch_bounds__(64 * NW + (PF ? 64 : 0)) void attention_k(const flo
     }
     mrun = mnew;
   };
+  auto use_blk = [&](const u128* kr, const u128* vr, int j0) { use_blk_e(kr, vr, j0, jend); };
 
   int j = jbeg;
+  if constexpr (QF) {
+#if CTTS_QF_DELAY > 0
+    __builtin_amdgcn_s_sleep(CTTS_QF_DELAY);   // A/B: let the QKV tiles' requests go first
+#endif
+#if CTTS_QF_PRE >= 1
+    load_blk(kA, vA, j);        // old keys on their way before the wait
+#endif
+#if CTTS_QF_PRE == 2
+    load_blk(kB, vB, j + KB);
+#endif
+    if (wave == 0) {
+      // arrivals of this head and launch: its 12 QKV tiles (4 q + 4 k + 4 v column tiles; one arrival per tile, decode_dev.hpp).  The
+      // polls queue behind this wave's own KV requests (vmcnt is in order): nothing is lost, the keys are needed anyway.
+      // BOUNDED spin: a dependency that never arrives must not hang the GPU.
+      const int32_t* fw = rm.qf_flag + h * HO_STRIDE;
+      const long long t0 = wall_clock64();
+      while (__hip_atomic_load(fw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 12) {
+        if (wall_clock64() - t0 > 2000000ll) __builtin_trap();   // 20 ms: abort the launch (the host sees a HIP error), never compute on stale q
+        __builtin_amdgcn_s_sleep(4);
+      }
+    }
+    __syncthreads();   // both units: the pair is done waiting when both heads have arrived
+#if CTTS_QF_PRE == 0
+    load_blk(kA, vA, j);
+#endif
+    const auto qrs = __builtin_amdgcn_make_buffer_rsrc((void*)qkv, 0, rm.qf_rows * 3 * HID * 4, 0x00020000);
+    constexpr int NV = DPL / 4;
+    u32x4_t qv[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) qv[i] = __builtin_amdgcn_raw_buffer_load_b128(qrs, (m * (3 * HID) + h * HDIM + dl * DPL + 4 * i) * 4, 0, 16);
+    u128 kN[1], vN[1];
+    if (wave == NW - 1) {   // the newest key: every lane group reads the same row (one 128-byte line), sc1
+      const u32x4_t tk = __builtin_amdgcn_raw_buffer_load_b128(krs, ubase + (unsigned)slot * (HDIM * (unsigned)sizeof(KT)), 0, 16);
+      const u32x4_t tv = __builtin_amdgcn_raw_buffer_load_b128(vrs, ubase + (unsigned)slot * (HDIM * (unsigned)sizeof(KT)), 0, 16);
+      kN[0].x = tk.x; kN[0].y = tk.y; kN[0].z = tk.z; kN[0].w = tk.w;
+      vN[0].x = tv.x; vN[0].y = tv.y; vN[0].z = tv.z; vN[0].w = tv.w;
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      q[4 * i] = __uint_as_float(qv[i].x); q[4 * i + 1] = __uint_as_float(qv[i].y);
+      q[4 * i + 2] = __uint_as_float(qv[i].z); q[4 * i + 3] = __uint_as_float(qv[i].w);
+    }
+    // the newest key FIRST (its row arrives together with q; consumed before the old blocks, its registers are free again)
+    if (wave == NW - 1) {   // the newest key: every lane group holds the same row, lane group 0 accounts for it
+      float kf[DPL], vf[DPL];
+      float d = 0.f;
+      unpack16<KT, DPL>(kN[0], kf);
+#pragma unroll
+      for (int e = 0; e < DPL; ++e) d = fmaf(q[e], kf[e], d);
+#pragma unroll
+      for (int o = 1; o < LPK; o <<= 1) d += __shfl_xor(d, o, 64);
+      d *= 0.125f;
+      const float mnew = fmaxf(mrun, d);
+      const float alpha = expf(mrun - mnew);   // exp(-inf) = 0 when this wave had no old keys
+      const float p = kg == 0 ? expf(d - mnew) : 0.f;
+      lrun = lrun * alpha + p;
+      unpack16<KT, DPL>(vN[0], vf);
+#pragma unroll
+      for (int e = 0; e < DPL; ++e) acc[e] = fmaf(p, vf[e], acc[e] * alpha);
+      mrun = mnew;
+    }
+  } else {
   load_blk(kA, vA, j);
   {   // q: 16-byte vector loads, issued behind the first block's requests
     constexpr int NV = DPL / 4;
@@ -416,8 +535,24 @@ __global__ __launch_bounds__(64 * NW + (PF ? 64 : 0)) void attention_k(const flo
 #pragma unroll
     for (int i = 0; i < NV; ++i) { q[4 * i] = qv[i].x; q[4 * i + 1] = qv[i].y; q[4 * i + 2] = qv[i].z; q[4 * i + 3] = qv[i].w; }
   }
+  }
   ASTAMP(2);   // first block and q requested
   bool first_blk = true;
+#if CTTS_QF_PRE == 2
+  if constexpr (QF) {   // blocks j and j + KB are already here (or on their way): consume them, restoring the loop's invariant
+    if (j < jend) {
+      __builtin_amdgcn_sched_barrier(0);
+      use_blk(kA, vA, j);
+      j += KB;
+      if (j < jend) {
+        load_blk(kA, vA, j + KB);
+        __builtin_amdgcn_sched_barrier(0);
+        use_blk(kB, vB, j);
+        j += KB;
+      }
+    }
+  }
+#endif
   if (NBUF > 2) {   // ring of three: blocks j + KB and j + 2 KB are on their way while block j is consumed
     load_blk(kB, vB, j + KB);
     while (j < jend) {
@@ -452,6 +587,17 @@ __global__ __launch_bounds__(64 * NW + (PF ? 64 : 0)) void attention_k(const flo
   }
 
   if (dbg) { asm volatile("" :: "v"(lrun)); ASTAMP(4); }   // this wave's keys done
+  // OPJ: this head's slice of o_proj -- Wo[:, 64 h .. 64 h + 63] as [k / 8][column][8] bf16, 96 KB shared by every utterance (L2) --
+  // is requested NOW, behind the wave's last KV block and ahead of the merge: thread t owns columns t, t + 256, t + 512
+  u128 wv[OPJ ? 3 : 1][OPJ ? 8 : 1];
+  if constexpr (OPJ) {
+    const u128* wo = reinterpret_cast<const u128*>(rm.wo_h) + (size_t)h * 8 * HID + tid;
+#pragma unroll
+    for (int jc = 0; jc < 3; ++jc)
+#pragma unroll
+      for (int g8 = 0; g8 < 8; ++g8) wv[jc][g8] = load16(wo + (size_t)g8 * HID + 256 * jc);
+    __builtin_amdgcn_sched_barrier(0);
+  }
   // merge the key groups of this wave (same running max in every lane)
 #pragma unroll
   for (int o = LPK; o < 64; o <<= 1) {
@@ -521,10 +667,89 @@ __global__ __launch_bounds__(64 * NW + (PF ? 64 : 0)) void attention_k(const flo
       }
       if (tid == 0) __hip_atomic_store(rm.sp_cnt + su, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
     }
-    store_out<OT>(PKO ? out + pko_off<OT>(m, h * HDIM + tid) : out + (size_t)m * HID + h * HDIM + tid, o / L);
+    if constexpr (!OPJ) store_out<OT>(PKO ? out + pko_off<OT>(m, h * HDIM + tid) : out + (size_t)m * HID + h * HDIM + tid, o / L);
+    else sm_on[tid] = f32_to_bf16(o / L);   // the same bf16 rounding the o_proj kernel's A operand had
+  }
+  if constexpr (OPJ) {
+    // ---- o_proj + residual inside the attention launch (HF Llama: self_attn.o_proj, examples/onnx/modeling_llama.py:500,557) ----
+    // Every (utterance, head) unit multiplies its 64 outputs by its 64 columns of Wo (bf16 x bf16 -> f32: v_dot2_f32_bf16, k ascending)
+    // and publishes a 768-wide f32 partial WRITE-THROUGH (sc1, MI355X guide Guideline 16 R1); every storing wave drains, one lane
+    // draws a ticket from the row's counter; the unit that draws 11 is the row's last: it reads the 12 partials with sc1 loads,
+    // adds them in head order 0..11 onto the residual (fixed order: deterministic and independent of arrival order), and writes what
+    // the o_proj kernel's epilogue wrote: the f32 residual, its bf16 copy in fragment order, the 48 partial sums of squares.
+    // Replaces one launch per layer (the one at 0.04 of the HBM roof); the counter is left at 0 for the next launch.
+    __syncthreads();
+    float pj[3] = {0.f, 0.f, 0.f};
+    const u128* onv = reinterpret_cast<const u128*>(sm_on);
+#pragma unroll
+    for (int g8 = 0; g8 < 8; ++g8) {
+      const u128 a = onv[g8];   // 8 bf16 outputs, the same address in every lane (LDS broadcast)
+#pragma unroll
+      for (int jc = 0; jc < 3; ++jc) {
+        pj[jc] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, wv[jc][g8].x), __builtin_bit_cast(bf16x2_t, a.x), pj[jc], false);
+        pj[jc] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, wv[jc][g8].y), __builtin_bit_cast(bf16x2_t, a.y), pj[jc], false);
+        pj[jc] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, wv[jc][g8].z), __builtin_bit_cast(bf16x2_t, a.z), pj[jc], false);
+        pj[jc] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, wv[jc][g8].w), __builtin_bit_cast(bf16x2_t, a.w), pj[jc], false);
+      }
+    }
+#pragma unroll
+    for (int jc = 0; jc < 3; ++jc) sm_p[tid + 256 * jc] = pj[jc];
+    __syncthreads();
+    const auto prs = __builtin_amdgcn_make_buffer_rsrc((void*)rm.op_part, 0, rm.op_part_bytes, 0x00020000);
+    if (tid < 192)   // 16-byte write-through stores: columns 4 tid .. 4 tid + 3
+      __builtin_amdgcn_raw_buffer_store_b128(reinterpret_cast<const u32x4_t*>(sm_p)[tid], prs, ((m * NHEAD + h) * HID + 4 * tid) * 4, 0, 16);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave: its partial has left
+    __syncthreads();
+    if (tid == 0) sm_last = __hip_atomic_fetch_add(rm.op_cnt + m, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == NHEAD - 1;
+    __syncthreads();
+    if (!sm_last) return;
+    if (tid == 0) __hip_atomic_store(rm.op_cnt + m, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    if (tid < 192) {
+      u32x4_t pv[NHEAD];
+#pragma unroll
+      for (int hh = 0; hh < NHEAD; ++hh) pv[hh] = __builtin_amdgcn_raw_buffer_load_b128(prs, ((m * NHEAD + hh) * HID + 4 * tid) * 4, 0, 16);
+      float4 sres = *reinterpret_cast<const float4*>(rm.x32 + (size_t)m * HID + 4 * tid);
+#pragma unroll
+      for (int hh = 0; hh < NHEAD; ++hh) {
+        sres.x += __uint_as_float(pv[hh].x); sres.y += __uint_as_float(pv[hh].y);
+        sres.z += __uint_as_float(pv[hh].z); sres.w += __uint_as_float(pv[hh].w);
+      }
+      emit_row(sres, tid, rm.x32 + (size_t)m * HID, xb_row_ptr(rm.xp, m, tid, 1), rm.ssq + (size_t)m * SSQ_PARTS);
+    }
   }
   ASTAMP(5);
 #undef ASTAMP
+}
+
+template <typename KT, int NW, typename OT, bool PKO = false, bool SPLIT = false, bool PF = false, int NBUF = 2, bool OPJ = false>
+__global__ __launch_bounds__(64 * NW + (PF ? 64 : 0)) void attention_k(const float* __restrict__ qkv, const KT* __restrict__ kc,
+                                                       const KT* __restrict__ vc, int cmax, OT* __restrict__ out, GptRowMap rm) {
+  if (NW > 1) CTTS_PROBE_RETURN();
+  attention_body<KT, NW, OT, PKO, SPLIT, PF, NBUF, OPJ, false>(qkv, kc, vc, cmax, out, rm, blockIdx.x, blockIdx.y, blockIdx.y * gridDim.x + blockIdx.x);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused QKV + attention launch (round 4; decode, perf mode, <= 64 rows).  512-thread workgroups: [0, 144) are the QKV tiles of
+// decode_dev.hpp (RMSNorm scale + q/k/v_proj + RoPE + KV append, all rows each, 8 waves splitting K), workgroups 144 + 6 m + p hold the
+// attention units (utterance m, heads 2p and 2p + 1), 4 waves each -- 144 + 6 * 64 = 528 workgroups of <= 128 VGPRs: (almost) all
+// resident at once, which the overlap needs.  The dependency q / newest K,V -> attention is NOT all-to-all: a unit needs the 12 column tiles of its head only, and it
+// has work that does not depend on them -- the requests for its old keys, the first memory round trip of the attention launch
+// (3.0 us from request to first use, profiles/r3y_attn_phase_probe.log).  So the units start WITH the QKV tiles, put two blocks of
+// old keys per wave in flight, and a fifth wave polls the head's arrival word (written behind write-through stores by the QKV tiles'
+// finishing waves, decode_dev.hpp) from wave 0 of each unit; q and the newest key / value are then read with sc1 loads.  Removes one kernel boundary per layer
+// and hides the KV stream's start-up latency behind the QKV tiles' weight stream.  Deadlock-free: QKV tiles have the lowest
+// workgroup ids (dispatched first; and two 8-wave workgroups per CU hold nearly the whole grid), the spin is bounded (20 ms, then trap).
+// Reference ops: HF Llama attention, examples/onnx/modeling_llama.py:415-417,239-256,455-475.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 4) void qkv_attention_k(DecGemmArgs d, const bf16_t* __restrict__ kc, const bf16_t* __restrict__ vc, int cmax,
+                                                          bf16_t* __restrict__ out, GptRowMap rm, int n_qkv) {
+  CTTS_PROBE_RETURN();
+  if ((int)blockIdx.x < n_qkv) {   // QKV tile: 16 columns x all (<= 64) rows, the 8 waves split K (3 chunks of 32 each, one round)
+    gemm_dec_wg<4, 8, true, FEPI_QKV_ROPE, true, 3>(d, blockIdx.x, 0, 1, blockIdx.x, n_qkv);
+    return;
+  }
+  const int u = blockIdx.x - n_qkv;   // (utterance, head pair)
+  attention_body<bf16_t, 4, bf16_t, true, false, false, 2, false, true>(d.C32, kc, vc, cmax, out, rm, 2 * (u % (NHEAD / 2)), u / (NHEAD / 2), blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -750,6 +975,32 @@ hipError_t launch_attention(const float* qkv, const void* kcache, const void* vc
     else { if (decode) ATT(float, 4, float); else ATT(float, 1, float); }
   }
 #undef ATT
+  return hipGetLastError();
+}
+
+hipError_t launch_qkv_attention(const DecGemmArgs& d_in, const void* kcache, const void* vcache, int cmax, void* out_packed, GptRowMap rm, int M,
+                                hipStream_t st) {
+  DecGemmArgs d = d_in;
+  if (rm.q_per_b != 1 || rm.desc == nullptr || M <= 0 || M > 64 || d.M != M || d.epi != FEPI_QKV_ROPE || d.N != 3 * HID || d.K != HID || !d.ssq_in ||
+      !d.desc || !d.ho_flag || rm.qf_flag != d.ho_flag || !d.rope_cs)
+    return hipErrorInvalidValue;
+  static int nt = -1, a_early = 1;
+  if (nt < 0) { const char* e = getenv("CTTS_W_NT"); nt = e ? atoi(e) : 1; const char* e2 = getenv("CTTS_DEC_A_EARLY"); a_early = e2 ? atoi(e2) : 1; }
+  d.w_nt = d.force_nt ? (d.force_nt == 2) : nt;
+  d.a_early = a_early;
+  d.pf[0] = PfDesc{nullptr, 0, 0}; d.pf[1] = PfDesc{nullptr, 0, 0};
+  rm.sp_cus = 0; rm.sp_part = nullptr; rm.sp_cnt = nullptr; rm.pf = PfDesc{nullptr, 0, 0};
+  rm.qf_rows = M;
+  const int n_qkv = 3 * HID / 16;
+  CTTS_LAUNCH(qkv_attention_k, dim3(n_qkv + (NHEAD / 2) * M), dim3(512), st, d, (const bf16_t*)kcache, (const bf16_t*)vcache, cmax, (bf16_t*)out_packed, rm, n_qkv);
+  return hipGetLastError();
+}
+
+hipError_t launch_attention_oproj(const float* qkv, const void* kcache, const void* vcache, int cmax, GptRowMap rm, int M, hipStream_t st) {
+  if (rm.q_per_b != 1 || rm.desc == nullptr || !rm.wo_h || !rm.op_part || !rm.op_cnt || !rm.x32 || !rm.xp || !rm.ssq) return hipErrorInvalidValue;
+  rm.sp_cus = 0; rm.sp_part = nullptr; rm.sp_cnt = nullptr;   // no remainder splitting on this path
+  CTTS_LAUNCH((attention_k<bf16_t, 4, bf16_t, true, false, false, 2, true>), dim3(NHEAD, M), dim3(256), st, qkv, (const bf16_t*)kcache,
+              (const bf16_t*)vcache, cmax, (bf16_t*)nullptr, rm);
   return hipGetLastError();
 }
 
@@ -1139,6 +1390,7 @@ __global__ __launch_bounds__(192) void embed_text_k(const float* __restrict__ em
                                                     uint16_t* __restrict__ xb, float* __restrict__ ssq,
                                                     const int32_t* __restrict__ row_map, const int32_t* __restrict__ n_active,
                                                     StepPrep sp) {
+  step_zero(sp);
   const int m = blockIdx.x, t = threadIdx.x;
   int b;
   if (sp.row_map_out != nullptr) {   // device-side compaction (see embed_codes_k)
@@ -1156,6 +1408,7 @@ __global__ __launch_bounds__(192) void embed_text_k(const float* __restrict__ em
   }
   const int slot = len[b] - 1;
   if (sp.desc != nullptr && t == 0) write_desc(sp, m, b, slot);
+  write_rope_cs(sp, m, b, slot, t);
   int id = (int)ids_buf[((size_t)b * tcap + slot) * NVQ];  // slot 0 (gpt.py:407)
   id = min(max(id, 0), n_text - 1);
   const float4 s = *reinterpret_cast<const float4*>(emb_text + (size_t)id * HID + t * 4);

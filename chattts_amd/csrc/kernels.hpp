@@ -150,6 +150,8 @@ struct DecGemmArgs {
   int force_nt;                 // 0: the launcher's policy (CTTS_W_NT); 1: plain (temporal) weight loads; 2: non-temporal (A/B: CTTS_W_TEMPORAL_LAYERS)
   PfDesc pf[2];                 // weights of later launches of the step this launch's auxiliary wave pulls towards L2 (QKV_ROPE, SILU), or {null}
   long long* dbg;               // probes only (tools/dec_phase_probe.py): [n_workgroups][8] phase stamps, or null
+  const float* rope_cs;         // QKV_ROPE inside the fused QKV + attention launch: [rows][64] cos[32] | sin[32] of each row's position (StepPrep)
+  int32_t* ho_flag;             // QKV_ROPE inside the fused QKV + attention launch: this layer's arrival words, head h at [h * HO_STRIDE]
 };
 hipError_t launch_gemm_dec(const DecGemmArgs& a, hipStream_t st);
 
@@ -220,6 +222,19 @@ struct GptRowMap {
                             // kernel need not read *n_active first (one dependent load less in front of the KV stream)
   PfDesc pf;                // decode, perf mode: the gate/up weights of this layer, pulled towards L2 by a fifth wave per workgroup
   long long* dbg;           // probes only (tools/attn_phase_probe.py, env CTTS_ATT_DBG_PTR): [workgroups][8] phase stamps (100 MHz), or null
+  // decode, perf mode, optional (launch_attention_oproj): o_proj + residual folded into the attention launch
+  const uint16_t* wo_h;     // this layer's o_proj weight per head: [12][8 (k / 8)][768 columns][8] bf16 (engine.py pack_wo_heads)
+  float* op_part;           // [rows][12][768] f32 partials of the (utterance, head) units
+  int op_part_bytes;
+  int32_t* op_cnt;          // [rows] arrival counters, zero between launches (the last arriver resets its counter)
+  float* x32;               // [rows][768] f32 residual stream, updated in place by the row's last arriver
+  uint16_t* xp;             // ... its bf16 copy in the fragment-packed order of decode.hip
+  float* ssq;               // ... and its [rows][48] partial sums of squares
+  // decode, perf mode, inside the fused QKV + attention launch (launch_qkv_attention): this layer's arrival words (head h at
+  // [h * HO_STRIDE], decode_dev.hpp) that the QKV tiles bump, and the rows of the qkv buffer
+  const int32_t* qf_flag;
+  int qf_rows;
+  int qf_kv_bytes;          // bytes of this layer's K (= V) cache: the units address it through a buffer descriptor with 32-bit offsets
 };
 #define ATT_SPLIT_MAX 8
 
@@ -237,6 +252,9 @@ struct StepPrep {
   int32_t* row_map_out;     // [B] or null
   int32_t* n_active_out;    // device scalar or null
   const int32_t* order;     // [B] or null: visiting order of the compaction (permutation of the slots; host: descending context)
+  float* rope_cs; const float* cos_t; const float* sin_t;   // [rows][64] out (cos[32] | sin[32] of the row's position) from the [max_pos][32] tables, or null
+  int32_t* zero_p; int zero_n; int zero_stride;   // zero_n words, zero_stride ints apart, that the step's first kernel zeroes (arrival words
+                                                  // of the fused QKV + attention launches), or null
 };
 hipError_t launch_embed_codes(const float* emb_code /*[4,626,768]*/, const int64_t* ids_buf, int ids_row_stride /*Tcap*/,
                               const int32_t* len, float* x, uint16_t* xb /*null ok*/, float* ssq /*null ok*/, int B,
@@ -250,6 +268,13 @@ hipError_t launch_rope_append(float* qkv /*[M,2304]*/, void* kcache, void* vcach
 hipError_t launch_attention(const float* qkv, const void* kcache, const void* vcache, int kv_wt, int cmax,
                             void* out /*[M,768] f32, or bf16 when out_bf16 (2: bf16 in the packed order of decode.hip)*/, int out_bf16,
                             GptRowMap rm, int M, hipStream_t st);
+// decode, perf mode: attention + o_proj + residual in one launch (rm.wo_h .. rm.ssq set); replaces launch_attention(out_bf16 = 2) and
+// the FEPI_RES launch of o_proj behind it
+hipError_t launch_attention_oproj(const float* qkv, const void* kcache, const void* vcache, int cmax, GptRowMap rm, int M, hipStream_t st);
+// decode, perf mode, M <= 64: QKV (RMSNorm scale + q/k/v_proj + RoPE + KV append) and attention as ONE launch -- the attention units
+// request their old keys while the QKV tiles run and pick q / the newest key up through per-head arrival words (d.ho_flag == rm.qf_flag)
+hipError_t launch_qkv_attention(const DecGemmArgs& d, const void* kcache, const void* vcache, int cmax, void* out_packed, GptRowMap rm, int M,
+                                hipStream_t st);
 hipError_t launch_final_norm(const float* x, int q_per_b, const float* w, float eps, float* hfin /*[B,768]*/,
                              float* hiddens /*[slots,max_new,768]*/, int max_new, const int32_t* len, int T, int B,
                              const int32_t* row_map, const int32_t* n_active, const int32_t* prompt_len, hipStream_t st,

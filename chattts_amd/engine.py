@@ -177,6 +177,13 @@ def pack_frag(w: torch.Tensor) -> torch.Tensor:
     return w.reshape(R // 16, 16, Cc // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous()
 
 
+def pack_wo_heads(wo: torch.Tensor) -> torch.Tensor:
+    """o_proj.weight [768 out, 768 in] (bf16) -> [12 heads][8 (k / 8)][768 out][8] : the slice of Wo one attention head multiplies,
+    laid out so that a wave's 16-byte loads (one output column per lane) are one contiguous KiB (csrc/gpt.hip attention_k<OPJ>)"""
+    assert tuple(wo.shape) == (GPT.hidden, GPT.hidden)
+    return wo.view(GPT.hidden, GPT.n_heads, 8, 8).permute(1, 2, 0, 3).contiguous()
+
+
 def pack_frag32(w: torch.Tensor) -> torch.Tensor:
     """float32 twin of pack_frag for the parity mode (csrc/decode32.hip): [R, C] (R % 16 == 0, C % 16 == 0) ->
     [R/16][C/16][lane = (c%16)/4 * 16 + r%16][c%4], one contiguous KiB per (16-row tile, 16-column chunk) in the lane order of
@@ -273,6 +280,9 @@ class GptEngine:
                 qk_perm = torch.cat([rp, GPT.hidden + rp, 2 * GPT.hidden + torch.arange(GPT.hidden, device=dev)])
                 self.packed[0] = [pack_frag32(t[qk_perm]) for t in self.wqkv]
             self._pk_arrs = [_lib.ptr_array(x) for x in self.packed]
+        # perf mode: o_proj once more, sliced per attention head -- the decode step folds o_proj + residual into the attention launch
+        self.wo_hd = [pack_wo_heads(t) for t in self.wo] if (use_packed and dtype == "bf16") else None
+        self._wo_hd_arr = None if self.wo_hd is None else _lib.ptr_array(self.wo_hd)
 
         def pad16(t):      # zero rows up to a multiple of 16: the padded columns of the last logits tile are never stored
             r = (-t.shape[0]) % 16
@@ -289,6 +299,8 @@ class GptEngine:
         if self._pk_arrs is not None:
             w.wqkv_pk, w.wo_pk, w.wgu_pk, w.wd_pk = [C.cast(a, _lib.PP) for a in self._pk_arrs]
         w.heads_pk, w.head_text_pk = _lib.ptr(self.heads_pk), _lib.ptr(self.head_text_pk)
+        if self._wo_hd_arr is not None:
+            w.wo_hd = C.cast(self._wo_hd_arr, _lib.PP)
         self._w = w
         h = C.c_void_p()
         _lib.check(self.lib.ctts_gpt_create(C.byref(h), C.byref(w)), "ctts_gpt_create")

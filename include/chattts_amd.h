@@ -75,6 +75,11 @@ typedef struct {
    * ([rows/16][768/16][64][4]); both modes (the heads are always f32); bit-identical logits */
   const float* heads_pk;
   const float* head_text_pk;
+  /* optional (NULL: o_proj stays its own launch), perf mode only: o_proj.weight once more, sliced per attention head,
+   * [12 heads][8 (k / 8)][768 output columns][8] bf16 = Wo[column][64 head + 8 (k / 8) + (k % 8)].  With it the decode step folds
+   * o_proj + residual into the attention launch (csrc/gpt.hip attention_k<OPJ>; HF Llama self_attn.o_proj,
+   * examples/onnx/modeling_llama.py:500,557): 83 launches per step instead of 103. */
+  const void* const* wo_hd;
 } ctts_gpt_weights;
 
 /* One generate() call's device state (every array is caller-allocated, device memory). */
@@ -339,6 +344,12 @@ int ctts_k_attention_prefill(const float* qkv, const uint16_t* kcache, const uin
  * remainder splitting of the (utterance, head) units over workgroups (csrc/gpt.hip attention_k); n_cu = 0: one workgroup per unit. */
 int ctts_k_attention_dec(const float* qkv, const uint16_t* kcache, const uint16_t* vcache, int32_t cmax, uint16_t* out_packed,
                          const int32_t* desc, const int32_t* n_active, int32_t M, float* part, int32_t* cnt, int32_t n_cu, void* stream);
+/* The same attention with o_proj + residual folded in (ctts_gpt_weights.wo_hd): wo_hd [12][8][768][8] bf16; part [ceil16(M)][12][768]
+ * f32 scratch; cnt [M] int32, zero (left zero); x32 [M][768] f32 residual, updated in place; xp its bf16 copy in the fragment-packed
+ * order; ssq [M][48] partial sums of squares of the new residual. */
+int ctts_k_attention_oproj(const float* qkv, const uint16_t* kcache, const uint16_t* vcache, int32_t cmax, const uint16_t* wo_hd,
+                           const int32_t* desc, const int32_t* n_active, int32_t M, float* part, int32_t* cnt, float* x32, uint16_t* xp,
+                           float* ssq, void* stream);
 int ctts_k_embed_codes(const float* emb_code, const int64_t* ids_buf, int32_t tcap, const int32_t* len, float* x, int32_t B, void* stream);
 int ctts_k_final_norm(const float* x, int32_t q_per_b, const float* w, float eps, float* hfin, float* hiddens, int32_t max_new,
                       const int32_t* len, int32_t T, int32_t B, void* stream);

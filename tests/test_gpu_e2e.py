@@ -174,6 +174,52 @@ def test_bf16_mode_teacher_forced_drift(gpt_bf16, weights, golden, name, file):
     assert np.mean(last_h) < 2.0 * np.mean(first_h) + 1e-3     # no systematic growth with the step index
 
 
+@pytest.mark.parametrize("env", ["CTTS_QKV_ATT", "CTTS_ATT_OPROJ"])
+def test_opt_in_fused_launches_follow_the_default_path(weights, golden, env, monkeypatch):
+    """The two opt-in launch fusions of the perf mode's decode step (round 4, measured and left OFF by default: profiles/r4*.log) --
+    CTTS_QKV_ATT=1: QKV + attention as one launch whose attention units pick q / the newest key up through per-head arrival words;
+    CTTS_ATT_OPROJ=1: o_proj + residual folded into the attention launch (12 -> 1 hand-off through memory per row) -- against the
+    default launch sequence, both teacher-forced on the reference's golden stream `b8` (left-padded rows, rows finishing at different
+    steps): same forced tokens, hidden states of EVERY step within 5e-3 relative (they differ in summation order only), and the
+    fused engine's own free run repeats itself bit for bit (graph replay == eager launches: the hand-offs are race-free)."""
+    c = cases.GEN_CASES["b8"]
+    ids, mask, tmask = cases.gen_inputs(c)
+    B, n = ids.shape[0], c["max_new"]
+    lens, rows = _golden_rows(golden["generate"], "b8", B)
+    teacher = np.zeros((B, n, 4), np.int64)
+    for b in range(B):
+        teacher[b, : lens[b]] = rows[b]
+        if lens[b] < n:
+            teacher[b, lens[b]] = 625
+    ids_t, mask_t = torch.from_numpy(ids), torch.from_numpy(mask)
+    warpers, procs = E.gen_logits(625, c["top_P"], c["top_K"], c["rep"])
+
+    def run(eng, **kw):
+        emb = eng.embed_prompt(ids_t, torch.from_numpy(tmask))
+        return list(eng.generate(emb, ids_t, torch.tensor(c["temperature"]), 625, mask_t, n, c["min_new"], (*procs, *warpers),
+                                 return_hidden=True, manual_seed=c["manual_seed"], **kw))[-1]
+
+    base = E.GptEngine(weights["gpt"], weights["embed"], DEV, dtype="bf16")
+    ref = run(base, teacher_ids=torch.from_numpy(teacher))
+    ref_h = [h.cpu().numpy().astype(np.float64) for h in ref.hiddens]
+    del base
+    monkeypatch.setenv(env, "1")      # read once, by ctts_gpt_create
+    fused = E.GptEngine(weights["gpt"], weights["embed"], DEV, dtype="bf16")
+    got = run(fused, teacher_ids=torch.from_numpy(teacher))
+    worst = 0.0
+    for b in range(B):
+        assert np.array_equal(got.ids[b].cpu().numpy(), rows[b]), b
+        g = got.hiddens[b].cpu().numpy().astype(np.float64)
+        assert g.shape == ref_h[b].shape
+        worst = max(worst, float((np.abs(g - ref_h[b]).max(1) / np.abs(ref_h[b]).max(1)).max()))
+    assert worst < 5e-3, worst
+    a = run(fused, use_graph=True)
+    b_ = run(fused, use_graph=False)
+    assert all(torch.equal(x, y) for x, y in zip(a.ids, b_.ids))
+    assert all(torch.equal(x, y) for x, y in zip(a.hiddens, b_.hiddens))
+    print(f"{env}=1 vs default, teacher-forced b8: worst relative hidden difference {worst:.2e}")
+
+
 def test_stream_chunks_match_oracle(weights):
     """stream=True (core.py:455-503): every emitted chunk is the next `stream_speed` samples of the ORACLE's decode of
     the prefix the reference would have at that yield (ids bit-exact in f32 mode, waveform within 1e-4 RMS)."""

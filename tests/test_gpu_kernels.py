@@ -664,6 +664,69 @@ def test_attention_decode_remainder_split(G, n_live):
         assert (split[:n_live] != whole[:n_live]).mean() < 0.02
 
 
+@pytest.mark.parametrize("n_live", [1, 5, 16, 17, 45, 64])
+def test_attention_oproj_fused(G, n_live):
+    """decode attention of the perf mode with o_proj + residual folded into the launch (attention_k<OPJ>, ctts_gpt_weights.wo_hd): every
+    (utterance, head) unit multiplies its bf16-rounded output by its 64 columns of Wo, the row's last arriver adds the 12 partials onto
+    the residual in head order and writes x (f32), its bf16 copy in fragment order and the 48 partial sums of squares -- against a
+    float64 reference built from the unfused kernel's own bf16 output; rows beyond the live count / finished rows stay untouched;
+    three launches in a row re-use the partial buffer and the counters; the result does not depend on the arrival order (two runs of
+    the same launch are bit-identical)."""
+    from chattts_amd.engine import pack_wo_heads, unpack_frag
+    lib = _lib.lib()
+    rs = np.random.RandomState(300 + n_live)
+    B, nh, d, H, cmax = 64, 12, 64, 768, 640
+    Bp = 64
+    kc = G.dev(G.bf16_round(rs.standard_normal((B, nh, cmax, d)).astype(f32)), torch.bfloat16)
+    vc = G.dev(G.bf16_round(rs.standard_normal((B, nh, cmax, d)).astype(f32)), torch.bfloat16)
+    wo = G.bf16_round((rs.standard_normal((H, H)) * 0.05).astype(f32))
+    wo_hd = pack_wo_heads(torch.from_numpy(wo).to(torch.bfloat16)).to(G.DEV)
+    part = torch.full((Bp * nh * H,), float("nan"), dtype=torch.float32, device=G.DEV)
+    cnt = torch.zeros((Bp,), dtype=torch.int32, device=G.DEV)
+    na = G.dev(np.array([n_live], np.int32))
+    for rep in range(3):
+        slots_b = rs.permutation(B)[:n_live]
+        jlo = rs.randint(0, 30, size=n_live)
+        slot = np.array([rs.randint(jlo[m] + 1, cmax) if rs.rand() < 0.8 else jlo[m] + rs.randint(0, 12) for m in range(n_live)])
+        desc = np.zeros((Bp, 4), np.int32)
+        desc[:, 0] = -1
+        desc[:n_live, 0], desc[:n_live, 1], desc[:n_live, 2], desc[:n_live, 3] = slots_b, slot, slot - jlo, jlo
+        dead = -1
+        if n_live > 4 and rep == 1:          # a row that finished since the last compaction: its descriptor says -1, nothing is written
+            dead = 2
+            desc[dead, 0] = -1
+        qkv = rs.standard_normal((Bp, 3 * H)).astype(f32)
+        x0 = rs.standard_normal((Bp, H)).astype(f32)
+        q_d, desc_d = G.dev(qkv), G.dev(desc)
+        # the unfused kernel's bf16 attention output = the operand the o_proj sees
+        o = torch.full((Bp * H,), float("nan"), dtype=torch.bfloat16, device=G.DEV)
+        _lib.check(lib.ctts_k_attention_dec(q_d.data_ptr(), kc.data_ptr(), vc.data_ptr(), cmax, o.data_ptr(), desc_d.data_ptr(),
+                                            na.data_ptr(), Bp, None, None, 0, None), "attention_dec")
+        att = unpack_frag(o.float().cpu(), Bp, H).numpy().astype(np.float64)
+        res = []
+        for _ in range(2):
+            x = G.dev(x0.copy())
+            xp = torch.full((Bp * H,), float("nan"), dtype=torch.bfloat16, device=G.DEV)
+            ssq = torch.full((Bp, 48), float("nan"), dtype=torch.float32, device=G.DEV)
+            _lib.check(lib.ctts_k_attention_oproj(q_d.data_ptr(), kc.data_ptr(), vc.data_ptr(), cmax, wo_hd.data_ptr(), desc_d.data_ptr(),
+                                                  na.data_ptr(), Bp, part.data_ptr(), cnt.data_ptr(), x.data_ptr(), xp.data_ptr(),
+                                                  ssq.data_ptr(), None), "attention_oproj")
+            torch.cuda.synchronize()
+            res.append((x.cpu().numpy(), unpack_frag(xp.float().cpu(), Bp, H).numpy(), ssq.cpu().numpy()))
+        assert int(cnt.abs().sum()) == 0
+        (xa, xba, sa), (xb_, xbb, sb) = res
+        live = np.array([m for m in range(n_live) if m != dead], np.int64)
+        gone = np.array([m for m in range(Bp) if m >= n_live or m == dead], np.int64)
+        assert np.array_equal(xa[live], xb_[live]) and np.array_equal(sa[live], sb[live])      # arrival order does not matter
+        want = x0.astype(np.float64) + att @ wo.astype(np.float64).T
+        assert np.abs(xa[live] - want[live]).max() < 2e-4, np.abs(xa[live] - want[live]).max()
+        assert np.array_equal(xba[live], G.bf16_round(xa[live]))                                   # the bf16 copy is the rounded f32 row
+        assert np.abs(sa[live] - (xa[live].astype(np.float64) ** 2).reshape(len(live), 48, 16).sum(-1)).max() < 1e-3
+        assert np.array_equal(xa[gone], x0[gone])                                                  # absent rows: untouched
+        assert np.isnan(sa[gone]).all()
+
+
+
 # ------------------------------------------------------------------------------------------------
 def test_embed_and_final_norm(G):
     lib = _lib.lib()

@@ -17,7 +17,7 @@
 //
 // build:  hipcc --offload-arch=gfx950 -O3 --genco --no-gpu-bundle-output tools/overlap_probe.hip -o tools/overlap_probe.hsaco
 //         hipcc --offload-arch=gfx950 -O3 tools/overlap_probe.hip -lhsa-runtime64 -o tools/overlap_probe.bin
-// run:    tools/overlap_probe.bin tools/overlap_probe.hsaco
+// run:    tools/overlap_probe.bin tools/overlap_probe.hsaco [dev]      (dev: the own queue's kernarg segments live in device memory)
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdint.h>
@@ -192,6 +192,7 @@ static int hsa_load(const char* path, HsaKernel* k, hsa_executable_t* exe_out) {
 }
 
 // One timed run on the HSA queue: REPS * CHAIN dispatch packets + one barrier packet that carries the completion signal.
+static char* g_kdev = nullptr;   // kernarg pool in DEVICE memory (argv[2] == "dev"): the host pool is then only the staging copy
 static int run_hsa(hsa_queue_t* q, const HsaKernel& k, char* kernarg_pool, size_t kernarg_stride, hsa_signal_t done, const Bufs& b, int n_wg,
                    int barrier_bit, int fence_scope, bool counters, int flags, const char* name) {
   if (reset(b)) return 1;
@@ -220,7 +221,7 @@ static int run_hsa(hsa_queue_t* q, const HsaKernel& k, char* kernarg_pool, size_
     body.workgroup_size_x = 256; body.workgroup_size_y = 1; body.workgroup_size_z = 1;
     body.grid_size_x = (uint32_t)n_wg * 256u; body.grid_size_y = 1; body.grid_size_z = 1;
     body.private_segment_size = k.priv; body.group_segment_size = k.group;
-    body.kernel_object = k.object; body.kernarg_address = ka;
+    body.kernel_object = k.object; body.kernarg_address = g_kdev ? (void*)(g_kdev + (size_t)n * kernarg_stride) : (void*)ka;
     body.completion_signal.handle = 0;
     const uint16_t header = (uint16_t)((HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | (barrier_bit << HSA_PACKET_HEADER_BARRIER) |
                                        (fence_scope << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (fence_scope << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE));
@@ -241,6 +242,7 @@ static int run_hsa(hsa_queue_t* q, const HsaKernel& k, char* kernarg_pool, size_
     __atomic_store_n((uint32_t*)p, (uint32_t)header, __ATOMIC_RELEASE);
     ++widx;
   }
+  if (g_kdev) { CK(hipMemcpy(g_kdev, kernarg_pool, (size_t)total * kernarg_stride, hipMemcpyHostToDevice)); CK(hipDeviceSynchronize()); }
   hsa_queue_store_write_index_screlease(q, widx);
   const auto t0 = std::chrono::steady_clock::now();
   hsa_signal_store_screlease(q->doorbell_signal, (hsa_signal_value_t)(widx - 1));
@@ -342,6 +344,8 @@ int main(int argc, char** argv) {
   const size_t stride = ((size_t)k.kernarg + 255) & ~(size_t)255;
   char* kpool = nullptr;
   CK(hipHostMalloc((void**)&kpool, stride * REPS * CHAIN, hipHostMallocDefault));
+  if (argc > 2 && !strcmp(argv[2], "dev")) { CK(hipMalloc((void**)&g_kdev, stride * REPS * CHAIN)); printf("kernarg segments in DEVICE memory\n"); }
+  else printf("kernarg segments in pinned HOST memory\n");
   struct { const char* name; int barrier, fence; bool counters; int flags; const char* what; } modes[] = {
     {"Q1", 1, HSA_FENCE_SCOPE_AGENT, false, 0, "barrier = 1, agent acquire/release fences, plain payload"},
     {"Q1s", 1, HSA_FENCE_SCOPE_AGENT, false, 1, "barrier = 1, agent fences, sc1 payload"},
