@@ -361,6 +361,23 @@ def main():
                  "bytes": int(sum(v.numel() * v.element_size() for sd in sds.values() for v in sd.values())),
                  "what": "ONE RCCL broadcast of the checkpoint from rank 0 at load (flat per-dtype buffers, chattts_amd/dist.py); "
                          "first use of the communicator, so ring set-up is inside the figure"}
+        # the same collective through the library's own C ABI (ctts_broadcast_weights on an RCCL communicator made from the C ABI, what a
+        # host without torch would call): one flat buffer, checked against what torch.distributed delivered; never fatal for the bench
+        try:
+            comm = D.CapiComm(world, rank)
+            probe = next(iter(sds["embed"].values())).reshape(-1)[: 1 << 20].clone().contiguous()
+            want = probe.clone()
+            if rank != 0:
+                probe.zero_()
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            comm.broadcast([probe], root=0)
+            torch.cuda.synchronize(dev)
+            bcast["capi_broadcast"] = {"ok": bool(torch.equal(probe, want)), "bytes": int(probe.numel() * probe.element_size()),
+                                       "ms": round(1e3 * (time.perf_counter() - t1), 3), "entry": "ctts_broadcast_weights (include/chattts_amd.h)"}
+            comm.close()
+        except Exception as exc:   # noqa: BLE001
+            bcast["capi_broadcast"] = {"ok": False, "error": repr(exc)[:200]}
         sds = {n: {k: v.cpu() for k, v in sd.items()} for n, sd in sds.items()}  # the engines repack from host tensors
     else:
         sds = W.synthetic_all()

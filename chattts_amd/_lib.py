@@ -40,7 +40,7 @@ class GenState(C.Structure):
         ("stop_at", P), ("workspace", P), ("workspace_bytes", C.c_size_t), ("row_map", P), ("n_active", P),
         ("cap", C.c_int32), ("hid_cap", C.c_int32), ("kv_batch", C.c_int32), ("q_batch", C.c_int32), ("prompt_len", P),
         ("infer_text", C.c_int32), ("teacher_ids", P), ("sampled_ids", P), ("order", P),
-        ("rng_device", C.c_int32), ("rng_per_step", C.c_int32), ("rng_seed", P),
+        ("rng_device", C.c_int32), ("rng_per_step", C.c_int32), ("rng_seed", P), ("rng_nonce", P),
     ]
 
 
@@ -123,7 +123,12 @@ SIGNATURES = {
     "ctts_k_attention": (C.c_int, [P, P, P, I32, I32, P, I32, P, P, I32, P]),
     "ctts_k_attention_prefill": (C.c_int, [P, P, P, I32, P, I32, I32, P, I32, P]),
     "ctts_k_attention_dec": (C.c_int, [P, P, P, I32, P, P, P, I32, P, P, I32, P]),
+    "ctts_rccl_unique_id": (C.c_int, [P]),
+    "ctts_rccl_comm_create": (C.c_int, [P, I32, P, I32]),
+    "ctts_rccl_comm_destroy": (None, [P]),
+    "ctts_broadcast_weights": (C.c_int, [P, P, I32, P, I32, P]),
     "ctts_k_attention_oproj": (C.c_int, [P, P, P, I32, P, P, P, I32, P, P, P, P, P, P]),
+    "ctts_k_device_guard_probe": (C.c_int, [P, P, P, P, P]),
     "ctts_k_embed_codes": (C.c_int, [P, P, I32, P, P, I32, P]),
     "ctts_k_final_norm": (C.c_int, [P, I32, P, F, P, P, I32, P, I32, I32, P]),
     "ctts_k_sample": (C.c_int, [C.POINTER(GenState), P, P]),

@@ -6,6 +6,10 @@ went from 266 ms to exactly 600 ms per batch with the same binaries, profiles/r3
 stream loop can cost tens of milliseconds.  These helpers POLL the event instead (hipEventQuery reads the completion signal; no
 interrupt involved), yielding the GIL between polls so that worker threads (the Exp(1) feeder of the unseeded host mode) keep running.
 CTTS_SPIN_WAIT=0 restores the blocking calls.
+
+The spin is BOUNDED: a wait that has polled for `SPIN_BUDGET_S` (default 20 ms -- longer than any decode chunk, shorter than a batch's
+acoustic decode) backs off to short timed sleeps, so a long wait (a waveform the side stream is still decoding, several ranks or
+serving threads sharing one CPU quota) does not burn a core per waiter.
 """
 from __future__ import annotations
 
@@ -15,6 +19,7 @@ import time
 import torch
 
 SPIN = os.environ.get("CTTS_SPIN_WAIT", "1") != "0"
+SPIN_BUDGET_S = float(os.environ.get("CTTS_SPIN_BUDGET_MS", "20")) * 1e-3
 
 
 def wait_event(ev) -> None:
@@ -22,8 +27,12 @@ def wait_event(ev) -> None:
     if not SPIN:
         ev.synchronize()
         return
+    t0 = time.perf_counter()
     while not ev.query():
-        time.sleep(0)     # release the GIL; no timed sleep (a 50 us sleep would already be 10 % of a decode step)
+        if time.perf_counter() - t0 < SPIN_BUDGET_S:
+            time.sleep(0)     # release the GIL; no timed sleep (a 50 us sleep would already be 10 % of a decode step)
+        else:
+            time.sleep(2e-4)  # a long wait: stop burning the core (the quota is shared with the feeder thread and the other ranks)
 
 
 def wait_stream(stream: "torch.cuda.Stream") -> None:

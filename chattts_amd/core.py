@@ -206,20 +206,18 @@ class Chat:
         codec engine's side stream while batch i+1 is being generated (`CodecEngine.decode_to_wavs_async`).  Yields one
         np.float32 [B_i, n_i] array per batch, in order, each identical to `infer_ids` of that batch; a batch's result is yielded
         once the NEXT batch's generation has been issued and finished, the last one at the end."""
-        pending = None
+        pending = []        # results not yet handed out, oldest first: a PendingWavs, or None for a batch that produced nothing
         for item in batches:
             a, extra = (item[:3], item[3]) if len(item) == 4 else (item, {})
             last = None
             for last in self.infer_code(*a, params, stream=False, **{**kw, **extra}):
                 pass
-            nxt = None if last is None else self.codec.decode_to_wavs_async(last.hiddens)
-            if pending is not None:
-                yield pending.result()
-            elif pending is None and nxt is None:
-                yield np.zeros((0,), np.float32)
-            pending = nxt
-        if pending is not None:
-            yield pending.result()
+            pending.append(None if last is None else self.codec.decode_to_wavs_async(last.hiddens))
+            while len(pending) > 1:     # exactly ONE item per input batch, in order, also for batches that yielded no output
+                p = pending.pop(0)
+                yield np.zeros((0,), np.float32) if p is None else p.result()
+        for p in pending:
+            yield np.zeros((0,), np.float32) if p is None else p.result()
 
     def _stream_piece(self, hiddens, a: int, b: Optional[int], use_decoder: bool = True) -> np.ndarray:
         """samples [a, b) (b=None: to the end) of the decode of the current prefix (core.py:482-497), from a token window with

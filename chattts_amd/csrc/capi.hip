@@ -1,6 +1,7 @@
 // extern "C" boundary of libchattts_amd.so (declared in include/chattts_amd.h) and the launch
 // sequences of the GPT step / DVAE / Vocos.  No device allocation, no device synchronisation.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -222,6 +223,7 @@ static SampleArgs make_sample_args(const ctts_gen_state* s, const float* logits)
   a.dbg = nullptr;
   { const char* e = getenv("CTTS_SAMPLE_DBG_PTR"); if (e) a.dbg = (long long*)strtoull(e, nullptr, 0); }   // probes only
   a.desc = nullptr; a.rng_device = s->rng_device; a.rng_per_step = s->rng_per_step; a.rng_seed = reinterpret_cast<const unsigned long long*>(s->rng_seed);
+  a.rng_nonce = s->rng_nonce;
   return a;
 }
 
@@ -289,7 +291,8 @@ static int run_step(ctts_gpt* g, const ctts_gen_state* s, int q_per_b, hipStream
     d.M = M; d.eps = g->w.rms_eps; d.n_active = nact;
     d.force_nt = l < g->temporal_layers ? 1 : 0;   // A/B knob: the first N layers' weights with plain loads (candidates for the Infinity Cache)
     // cross-kernel weight prefetch (common.hpp): QKV -> this layer's o_proj; attention -> gate/up; gate/up -> down and the next layer's
-    // QKV (last layer: the heads).  CTTS_PF is a bit mask of the four (default 15, 0 = off)
+    // QKV (last layer: the heads).  CTTS_PF is a bit mask (default 0 = off: every combination measured a net loss,
+    // profiles/r3s_ab_prefetch.log): 1 QKV -> o_proj, 16 QKV -> gate/up, 2 attention -> gate/up
     const PfDesc pf_none{nullptr, 0, 0};
     const PfDesc pf_o{(const char*)g->wo_pk[l], 16u * HID * 2u, HID / 16u};
     const PfDesc pf_gu{(const char*)g->wgu_pk[l], 16u * HID * 2u, 2u * INTER / 16u};
@@ -915,6 +918,25 @@ extern "C" int ctts_k_sample(const ctts_gen_state* s, const float* logits, void*
   CK(launch_sample(make_sample_args(s, logits), (hipStream_t)stream));
   return 0;
 }
+// what CttsDeviceGuard (kernels.hpp) does for `stream` on the calling thread: the device current before, the device that owns the stream,
+// the device current INSIDE the guard, and whether it had to switch (tests: the guard's path runs on a 1-GPU box too)
+extern "C" int ctts_k_device_guard_probe(void* stream, int32_t* before, int32_t* stream_dev, int32_t* inside, int32_t* switched) {
+  if (!before || !stream_dev || !inside || !switched) return fail("ctts_k_device_guard_probe: null argument");
+  int b = -1, in = -1;
+  CK(hipGetDevice(&b));
+  *stream_dev = -1;
+  if (stream != nullptr) { hipDevice_t d; CK(hipStreamGetDevice((hipStream_t)stream, &d)); *stream_dev = (int32_t)d; }
+  {
+    CttsDeviceGuard dg(stream);
+    CK(hipGetDevice(&in));
+    *switched = dg.switched ? 1 : 0;
+  }
+  int after = -1;
+  CK(hipGetDevice(&after));
+  if (after != b) return fail("CttsDeviceGuard did not restore the current device (%d -> %d)", b, after);
+  *before = b; *inside = in;
+  return 0;
+}
 extern "C" int ctts_copy_bytes(void* dst, const void* src, size_t bytes, void* stream) {
   if (!dst || !src || (bytes & 15) || (((uintptr_t)dst | (uintptr_t)src) & 15)) return fail("ctts_copy_bytes: pointers and size must be 16-byte aligned");
   CttsDeviceGuard dg(stream);
@@ -938,5 +960,76 @@ extern "C" int ctts_k_layernorm(const float* x, const float* w, const float* b, 
 extern "C" int ctts_k_istft(const float* head, const float* window, const float* twiddle, float* frames, float* wav, int32_t B,
                             int32_t F, void* stream) {
   CK(launch_istft(head, window, twiddle, frames, wav, B, F, (hipStream_t)stream));
+  return 0;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// The one collective of the path: the weights, broadcast from one rank to the others at load -- RCCL over xGMI.
+// librccl.so is loaded lazily, on the first call, so a single-GPU host needs neither the library nor a communicator.  The engines hold
+// no weight memory of their own (the host allocates every buffer and hands pointers to ctts_*_create), so what is broadcast is the
+// host's list of device buffers, in place, BEFORE the engines are created on the receiving ranks.
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct Rccl {
+  void* lib = nullptr;
+  int (*GetUniqueId)(void*) = nullptr;
+  int (*CommInitRank)(void**, int, ctts_rccl_id, int) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  int (*Broadcast)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  bool tried = false;
+};
+Rccl g_rccl;
+int rccl_load() {
+  if (g_rccl.lib) return 0;
+  if (g_rccl.tried) return fail("librccl.so could not be loaded");
+  g_rccl.tried = true;
+  const char* names[] = {getenv("CTTS_RCCL_LIB"), "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+  for (const char* n : names) {
+    if (!n || !*n) continue;
+    g_rccl.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (g_rccl.lib) break;
+  }
+  if (!g_rccl.lib) return fail("librccl.so not found (dlopen: %s); set CTTS_RCCL_LIB", dlerror());
+  g_rccl.GetUniqueId = (int (*)(void*))dlsym(g_rccl.lib, "ncclGetUniqueId");
+  g_rccl.CommInitRank = (int (*)(void**, int, ctts_rccl_id, int))dlsym(g_rccl.lib, "ncclCommInitRank");
+  g_rccl.CommDestroy = (int (*)(void*))dlsym(g_rccl.lib, "ncclCommDestroy");
+  g_rccl.Broadcast = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(g_rccl.lib, "ncclBroadcast");
+  g_rccl.GetErrorString = (const char* (*)(int))dlsym(g_rccl.lib, "ncclGetErrorString");
+  if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.Broadcast) {
+    dlclose(g_rccl.lib); g_rccl.lib = nullptr;
+    return fail("librccl.so lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclBroadcast");
+  }
+  return 0;
+}
+int rccl_fail(const char* what, int rc) { return fail("%s: %s (%d)", what, g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "RCCL error", rc); }
+}  // namespace
+
+extern "C" int ctts_rccl_unique_id(ctts_rccl_id* out) {
+  if (!out) return fail("ctts_rccl_unique_id: null argument");
+  if (rccl_load()) return -1;
+  const int rc = g_rccl.GetUniqueId(out);
+  return rc == 0 ? 0 : rccl_fail("ncclGetUniqueId", rc);
+}
+extern "C" int ctts_rccl_comm_create(void** comm, int32_t world, const ctts_rccl_id* id, int32_t rank) {
+  if (!comm || !id || world <= 0 || rank < 0 || rank >= world) return fail("ctts_rccl_comm_create: bad arguments");
+  if (rccl_load()) return -1;
+  const int rc = g_rccl.CommInitRank(comm, world, *id, rank);
+  return rc == 0 ? 0 : rccl_fail("ncclCommInitRank", rc);
+}
+extern "C" void ctts_rccl_comm_destroy(void* comm) {
+  if (comm && g_rccl.lib) (void)g_rccl.CommDestroy(comm);
+}
+extern "C" int ctts_broadcast_weights(void* const* bufs, const size_t* bytes, int32_t n, void* comm, int32_t root, void* stream) {
+  if (n < 0 || (n > 0 && (!bufs || !bytes)) || !comm) return fail("ctts_broadcast_weights: bad arguments");
+  if (rccl_load()) return -1;
+  CttsDeviceGuard dg(stream);
+  for (int i = 0; i < n; ++i) {
+    if (bytes[i] == 0) continue;
+    if (!bufs[i]) return fail("ctts_broadcast_weights: buffer %d is null", i);
+    const int rc = g_rccl.Broadcast(bufs[i], bufs[i], bytes[i], /* ncclUint8 */ 1, root, comm, (hipStream_t)stream);   // in place, byte-typed
+    if (rc != 0) return rccl_fail("ncclBroadcast", rc);
+  }
   return 0;
 }

@@ -1088,9 +1088,10 @@ __device__ __forceinline__ float exp1_from_bits(uint32_t x) {
   return -logf(u);
 }
 // the 4 draws of tokens 4 grp .. 4 grp + 3 of global sampling row `grow` at generation step `step`
-__device__ __forceinline__ void device_exp_draws4(unsigned long long seed, int grow, int step, int grp, float (&q)[4]) {
+#define CTTS_RNG_WORD3 0x43545453u   // fourth counter word when the caller gives no per-slot nonce
+__device__ __forceinline__ void device_exp_draws4(unsigned long long seed, int grow, int step, int grp, float (&q)[4], uint32_t w3 = CTTS_RNG_WORD3) {
   uint32_t r[4];
-  philox4x32_10((uint32_t)grp, (uint32_t)grow, (uint32_t)step, 0x43545453u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+  philox4x32_10((uint32_t)grp, (uint32_t)grow, (uint32_t)step, w3, (uint32_t)seed, (uint32_t)(seed >> 32), r);
 #pragma unroll
   for (int i = 0; i < 4; ++i) q[i] = exp1_from_bits(r[i]);
 }
@@ -1138,6 +1139,7 @@ __global__ __launch_bounds__(256) void sample_k(SampleArgs a) {
   const float temp = a.temperature[k];
   const int grow = a.row_offset + b * NVQ + k;    // global sampling row (multi-GPU shards keep the reference's numbering)
   const unsigned long long seed = a.rng_device ? *a.rng_seed : 0ull;
+  const uint32_t w3 = (a.rng_device && a.rng_nonce != nullptr) ? a.rng_nonce[b] : CTTS_RNG_WORD3;
 
   // everything that depends only on (b, k, gen) is requested NOW, in one round: the logits, the Exp(1) draws consumed at the very
   // end, the <= 16 history tokens, the harness hooks
@@ -1168,7 +1170,7 @@ __global__ __launch_bounds__(256) void sample_k(SampleArgs a) {
     for (int s = 0; s < SLOTS; ++s) {
       const int v = s * 64 + lane;
       float q4[4];
-      device_exp_draws4(seed, grow, a.rng_per_step ? gen : 0, v >> 2, q4);
+      device_exp_draws4(seed, grow, a.rng_per_step ? gen : 0, v >> 2, q4, w3);
       qv[s] = q4[v & 3];
     }
   }

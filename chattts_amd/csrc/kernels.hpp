@@ -310,6 +310,7 @@ struct SampleArgs {
   int rng_device;           // 1: Exp(1) draws from the device generator (Philox4x32-10 keyed on rng_seed) instead of `q`
   int rng_per_step;         // device generator: 1 = a fresh draw every step (the reference's manual_seed=None), 0 = the same draw
                             // every step (manual_seed set: the reference re-seeds its generator at every step, gpt.py:504-507)
+  const uint32_t* rng_nonce;            // [slots] or null: per-slot fourth counter word of the device generator (slot pools: bumped per admission)
   const unsigned long long* rng_seed;   // device scalar
   long long* dbg;           // probes only (tools/sample_phase_probe.py, env CTTS_SAMPLE_DBG_PTR): [rows][8] phase stamps (100 MHz), or null
 };

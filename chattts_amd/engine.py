@@ -357,7 +357,8 @@ class GptEngine:
                  total_rows: Optional[int] = None, profile_tag: Optional[int] = None,
                  profile_stride: int = 1, lanes: Optional[int] = None,
                  teacher_ids: Optional[torch.Tensor] = None, prefill_chunk: Optional[int] = None,
-                 return_sampled: bool = False, rng: Optional[str] = None, rng_seed: Optional[int] = None) -> Iterator[GenerationOutputs]:
+                 return_sampled: bool = False, rng: Optional[str] = None, rng_seed: Optional[int] = None,
+                 rng_nonce=None) -> Iterator[GenerationOutputs]:
         """Drop-in for `GPT.generate` (gpt.py:316-337), code mode.  Extra keyword-only arguments:
         `use_graph` (hipGraph replay of the decode step), `stop_at` ([B] int32 forced output lengths,
         benchmark hook), `row_offset`/`total_rows` (this shard's position inside a data-parallel batch:
@@ -376,7 +377,9 @@ class GptEngine:
         CPU generator call, uploaded (rng.py).  "device" draws them inside the sampling kernel (Philox4x32-10, counter = token / global
         row / step; the reference on a GPU device draws from the device generator too, gpt.py:39): with `manual_seed=None` -- the
         reference's DEFAULT -- that removes the ~2 ms per-step host draw + upload; the key is `rng_seed` or, if None, one draw from
-        torch's global CPU generator (so `torch.manual_seed` still makes a run repeatable).  Code mode only."""
+        torch's global CPU generator (so `torch.manual_seed` still makes a run repeatable).  Code mode only.  `rng_nonce` (device generator
+        only; an int or one int per utterance): the fourth word of the generator's counter instead of its constant -- a slot pool gives
+        every admission its own (serving.SlotPool), and passing a request's number here reproduces that request in isolation."""
         if return_attn:
             raise NotImplementedError("return_attn is not supported by the fused attention kernel")
         context = context or Context()
@@ -439,7 +442,7 @@ class GptEngine:
         key = (tuple(bounds), T, max_new, nrow, V, nq, self.dtype, top_p_thr, plan.top_p is not None, int(plan.top_k or 0),
                plan.top_k is not None, int(min_new_token), int(eos_token), int(row_offset), bool(infer_text), stop_at is not None,
                ptab is not None, teacher_ids is not None, bool(return_sampled),
-               None if prefill_chunk is None else int(prefill_chunk), device_rng, manual_seed is None)
+               None if prefill_chunk is None else int(prefill_chunk), device_rng, manual_seed is None, device_rng and rng_nonce is not None)
         sess = self._session if (self._session is not None and self._session["key"] == key) else None
         if sess is None:
             self._session = None     # drop the previous session's buffers before allocating new ones
@@ -475,6 +478,7 @@ class GptEngine:
                     ln.q_d = torch.empty((1,) if device_rng else (nq, Bl * nrow, V), dtype=torch.float32, device=dev)
                     ln.teacher = None if teacher_ids is None else torch.empty((Bl, max_new, nvq), dtype=torch.int64, device=dev)
                     ln.sampled = torch.zeros((Bl, max_new, nvq), dtype=torch.int64, device=dev) if return_sampled else None
+                    ln.nonce = torch.zeros((Bl,), dtype=torch.int32, device=dev) if (device_rng and rng_nonce is not None) else None
                 s = _lib.GenState()
                 s.B, s.T, s.max_new = Bl, T, max_new
                 s.ids_buf, s.len, s.kv_start = ln.ids_buf.data_ptr(), ln.len_d.data_ptr(), ln.kv_start.data_ptr()
@@ -493,6 +497,7 @@ class GptEngine:
                 s.teacher_ids = _lib.ptr(ln.teacher)
                 s.sampled_ids = _lib.ptr(ln.sampled)
                 s.rng_device, s.rng_per_step, s.rng_seed = int(device_rng), int(manual_seed is None), sess["seed"].data_ptr()
+                s.rng_nonce = _lib.ptr(ln.nonce)
                 # compaction order: utterances by descending context = ascending left padding (contexts of a batch differ only by
                 # the static valid prompt length), so the attention grid starts its longest units first.  CTTS_ORDER=0: ascending slot
                 s.order = ln.order.data_ptr() if os.environ.get("CTTS_ORDER", "1") != "0" else None
@@ -523,6 +528,10 @@ class GptEngine:
                 ln.kv_start.copy_(kv_start_all[lo:hi])
                 if ln.stop_d is not None:
                     ln.stop_d.copy_(stop_at[lo:hi].to(torch.int32))
+                if getattr(ln, "nonce", None) is not None:
+                    nz = torch.as_tensor(rng_nonce, dtype=torch.int64).reshape(-1)
+                    nz = nz.expand(B) if nz.numel() == 1 else nz
+                    ln.nonce.copy_(nz[lo:hi].to(torch.int32))
                 if ln.teacher is not None:
                     assert tuple(teacher_ids.shape) == (B, max_new, nvq)
                     ln.teacher.copy_(teacher_ids[lo:hi].to(torch.int64))
@@ -736,7 +745,7 @@ class GptEngine:
                                          use_graph=use_graph, stop_at=stop_at, row_offset=row_offset, total_rows=total_rows,
                                          profile_tag=profile_tag, profile_stride=profile_stride, lanes=lanes,
                                          teacher_ids=teacher_ids, prefill_chunk=prefill_chunk, return_sampled=return_sampled,
-                                         rng=rng, rng_seed=None)
+                                         rng=rng, rng_seed=None, rng_nonce=rng_nonce)
             return  # gpt.py:570: the seeded case yields nothing
 
         graph_ok = use_graph and max_new > 1

@@ -48,8 +48,9 @@ class SlotPool:
                  top_P: Optional[float] = 0.7, top_K: Optional[int] = 20, repetition_penalty: float = 1.05, manual_seed: int = 42,
                  min_new_token: int = 0, eos_token: int = GPT.n_audio - 1, rng: str = "host", rng_seed: Optional[int] = None):
         """`rng="device"`: the Exp(1) draws come from the sampling kernel's own generator (engine.generate's `rng`), which is what
-        makes the reference's DEFAULT `manual_seed=None` servable here: a fresh draw per (request step, pool row) without any
-        per-step host work.  The host stream (`rng="host"`) needs `manual_seed` (one constant tensor per session)."""
+        makes the reference's DEFAULT `manual_seed=None` servable here: a fresh draw per (admission, request step, pool row) without any
+        per-step host work -- every admission gets its own number as the fourth word of the generator's counter, so a request never
+        replays the stream of the slot's previous occupant (`nonce_of[rid]`; `generate(rng_nonce=...)` reproduces it in isolation).  The host stream (`rng="host"`) needs `manual_seed` (one constant tensor per session)."""
         if rng not in ("host", "device"):
             raise ValueError("rng must be 'host' or 'device'")
         if manual_seed is None and rng != "device":
@@ -90,9 +91,15 @@ class SlotPool:
                 seed = int(rng_seed) if rng_seed is not None else (int(manual_seed) if manual_seed is not None
                                                                    else int(torch.randint(0, 2 ** 62, (1,)).item()))
                 self.rng_seed = torch.tensor([seed], dtype=torch.int64, device=dev)
+                # unseeded (manual_seed=None): a request's step index restarts at 0, so the Philox counter (token group, pool row, step)
+                # alone would replay the previous occupant's stream in the same slot.  A per-slot admission number is the fourth counter
+                # word (ctts_gen_state.rng_nonce): every (admission, step, row, token) draws fresh.  Seeded pools keep the constant word --
+                # the reference re-seeds at every step there, the same draw for every request IS its semantics.
+                self.rng_nonce = torch.zeros((slots,), dtype=torch.int32, device=dev) if manual_seed is None else None
             else:
                 self.q = ExpDraws(slots * nvq, GPT.n_audio, manual_seed).step(0).to(dev).reshape(1, slots * nvq, GPT.n_audio).contiguous()
                 self.rng_seed = None
+                self.rng_nonce = None
             self.temp = torch.tensor(list(temperature), dtype=torch.float32, device=dev)
             ptab = penalty_table(plan.penalty)
             self.ptab = None if ptab is None else ptab.to(dev)
@@ -109,6 +116,7 @@ class SlotPool:
         self.admissions = 0                   # prefill groups so far (bench.py reports it)
         self._keep = None
         self.slot_of: dict = {}               # request id -> slot it ran in (parity tests / tracing)
+        self.nonce_of: dict = {}              # request id -> its admission number (device generator, unseeded: ctts_gen_state.rng_nonce)
 
     def close(self):
         if getattr(self, "handle", None):
@@ -140,6 +148,7 @@ class SlotPool:
         s.prompt_len = self.prompt_len.data_ptr()
         s.infer_text = 0
         s.rng_device, s.rng_per_step, s.rng_seed = int(self.device_rng), int(self.rng_per_step), _lib.ptr(self.rng_seed)
+        s.rng_nonce = _lib.ptr(getattr(self, "rng_nonce", None))
         return s
 
     # -- request intake ---------------------------------------------------------------------------------------
@@ -187,6 +196,12 @@ class SlotPool:
             self.finish[sl] = 0
             self.end_idx[sl] = 0
             self.stop_at[sl] = torch.tensor([r.stop_at for r in reqs], dtype=torch.int32, device=dev)
+            if getattr(self, "rng_nonce", None) is not None:
+                self._admit_no = getattr(self, "_admit_no", 0) + n
+                # globally unique admission numbers (never the constant word of a plain generate() call)
+                self.rng_nonce[sl] = torch.arange(self._admit_no - n + 1, self._admit_no + 1, dtype=torch.int32, device=dev)
+                for i, r in enumerate(reqs):
+                    self.nonce_of[r.rid] = self._admit_no - n + 1 + i
             rmap = sl.to(torch.int32)
             ws = torch.empty((self.lib.ctts_gpt_workspace_bytes(n, Tg),), dtype=torch.uint8, device=dev)
             pre = self._state(B=n, T=Tg, workspace=ws, row_map=rmap, n_active=None)

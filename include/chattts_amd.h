@@ -148,6 +148,9 @@ typedef struct {
   int32_t rng_device;
   int32_t rng_per_step;
   const uint64_t* rng_seed;        /* DEVICE scalar (read by the kernel at every step, so a captured graph serves every seed) */
+  const uint32_t* rng_nonce;       /* [slots] or NULL, device generator only: a per-utterance-slot word that replaces the constant fourth Philox
+                                      counter word.  A slot pool bumps it at every ADMISSION, so successive requests in one slot -- whose step
+                                      index restarts at 0 -- do not replay the previous occupant's Exp(1) stream */
 } ctts_gen_state;
 
 int ctts_gpt_create(ctts_gpt** out, const ctts_gpt_weights* w);
@@ -230,6 +233,21 @@ typedef struct {
 int ctts_codec_create(ctts_codec** out, const ctts_codec_weights* w);
 void ctts_codec_destroy(ctts_codec* c);
 size_t ctts_codec_workspace_bytes(int32_t B, int32_t F); /* F = mel frames = 2T */
+/* ------------------------------------------------------------------------------------------------
+ * Multi-GPU: ONE collective, the weight broadcast at load (SURVEY 8b `ctts_broadcast_weights`, 8e; the reference has no data-parallel
+ * mode -- ChatTTS/core.py:458-468 batches inside one call only).  One process per GPU; utterances are sharded in contiguous row blocks
+ * by the host (chattts_amd/dist.py shard_bounds) and never interact, so nothing else crosses GPUs.  librccl.so is dlopen'ed on the
+ * first call (CTTS_RCCL_LIB overrides the name): single-GPU hosts need neither RCCL nor a communicator.  The library owns no weight
+ * memory, so the broadcast is over the HOST'S list of device buffers (the repacked weights it is about to hand to ctts_gpt_create /
+ * ctts_codec_create), in place, byte-typed, one ncclBroadcast per buffer on `stream` -- pack small tensors into a few flat buffers
+ * first: a ring broadcast over xGMI is per-link bound (about 153 GB/s), per-call overhead dominates below ~1 MB.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct { char internal[128]; } ctts_rccl_id;   /* = ncclUniqueId: made by ONE rank, carried to the others by the host's own means */
+int ctts_rccl_unique_id(ctts_rccl_id* out);
+int ctts_rccl_comm_create(void** comm /* ncclComm_t out */, int32_t world, const ctts_rccl_id* id, int32_t rank);   /* ncclCommInitRank on the current device */
+void ctts_rccl_comm_destroy(void* comm);
+int ctts_broadcast_weights(void* const* bufs, const size_t* bytes, int32_t n, void* comm /* ncclComm_t */, int32_t root, void* stream);
+
 /* Shader copy of `bytes` (a multiple of 16; both pointers 16-byte aligned) on `stream`.  `dst` may be PINNED HOST memory (mapped into
  * the device's address space): the float32 waveforms then reach the host -- the `.cpu().numpy()` that ends `Chat._decode_to_wavs`,
  * ChatTTS/core.py:508-510 -- as plain stores over PCIe, without the copy engines. */
@@ -350,6 +368,9 @@ int ctts_k_attention_dec(const float* qkv, const uint16_t* kcache, const uint16_
 int ctts_k_attention_oproj(const float* qkv, const uint16_t* kcache, const uint16_t* vcache, int32_t cmax, const uint16_t* wo_hd,
                            const int32_t* desc, const int32_t* n_active, int32_t M, float* part, int32_t* cnt, float* x32, uint16_t* xp,
                            float* ssq, void* stream);
+/* what the library's per-call device guard does for `stream`: the device current before the call, the one that owns the stream, the one
+ * current inside the guard, whether it switched; fails if the previous device is not restored */
+int ctts_k_device_guard_probe(void* stream, int32_t* before, int32_t* stream_dev, int32_t* inside, int32_t* switched);
 int ctts_k_embed_codes(const float* emb_code, const int64_t* ids_buf, int32_t tcap, const int32_t* len, float* x, int32_t B, void* stream);
 int ctts_k_final_norm(const float* x, int32_t q_per_b, const float* w, float eps, float* hfin, float* hiddens, int32_t max_new,
                       const int32_t* len, int32_t T, int32_t B, void* stream);

@@ -220,6 +220,22 @@ def test_opt_in_fused_launches_follow_the_default_path(weights, golden, env, mon
     print(f"{env}=1 vs default, teacher-forced b8: worst relative hidden difference {worst:.2e}")
 
 
+def test_capi_weight_broadcast_world1():
+    """`ctts_broadcast_weights` (the ONE collective of the path) through the C ABI on a real MI355X: librccl.so is
+    dlopen'ed lazily, a communicator of world size 1 is made from a unique id (`ctts_rccl_unique_id` / `ctts_rccl_comm_create`), and an
+    in-place byte-typed broadcast of two flat weight buffers leaves them unchanged and completes on the caller's stream.  (N > 1 needs
+    a multi-GPU box: bench.py --gpus N checks the same entry point against torch.distributed's broadcast there.)"""
+    from chattts_amd import dist as D
+    comm = D.CapiComm(1, 0)
+    a = torch.arange(1 << 20, dtype=torch.float32, device=DEV)
+    b = torch.full((12345,), 3, dtype=torch.bfloat16, device=DEV)
+    a0, b0 = a.clone(), b.clone()
+    comm.broadcast([a, b, torch.empty(0, device=DEV)], root=0)
+    torch.cuda.synchronize()
+    assert torch.equal(a, a0) and torch.equal(b, b0)
+    comm.close()
+
+
 def test_stream_chunks_match_oracle(weights):
     """stream=True (core.py:455-503): every emitted chunk is the next `stream_speed` samples of the ORACLE's decode of
     the prefix the reference would have at that yield (ids bit-exact in f32 mode, waveform within 1e-4 RMS)."""
@@ -1020,6 +1036,27 @@ def test_interrupt_keeps_tokens_steps_and_outputs_consistent(gpt_f32):
         assert torch.equal(out.ids[b], full.ids[b][:steps])     # an interrupted run is a prefix of the uninterrupted one
 
 
+def test_device_guard_path_on_any_box():
+    """CttsDeviceGuard (csrc/kernels.hpp) -- what every C-ABI entry point wraps its enqueues in -- exercised through its probe on
+    whatever this box has: for a stream of EVERY visible device the guard resolves the owning device, makes it current inside, says
+    whether it had to switch, and restores the caller's device; the null stream changes nothing.  (The two-GPU end-to-end test below is
+    skipped on a 1-GPU box; this one still runs the guard's code there.)"""
+    import ctypes as C
+    from chattts_amd import _lib
+    lib = _lib.lib()
+    cur = torch.cuda.current_device()
+    for d in range(torch.cuda.device_count()):
+        st = torch.cuda.Stream(device=d)
+        o = [C.c_int32(-7) for _ in range(4)]
+        _lib.check(lib.ctts_k_device_guard_probe(st.cuda_stream, *[C.byref(x) for x in o]), "guard probe")
+        before, sdev, inside, switched = [x.value for x in o]
+        assert (before, sdev, inside, switched) == (cur, d, d, int(d != cur))
+        assert torch.cuda.current_device() == cur
+    o = [C.c_int32(-7) for _ in range(4)]
+    _lib.check(lib.ctts_k_device_guard_probe(None, *[C.byref(x) for x in o]), "guard probe (null stream)")
+    assert [x.value for x in o] == [cur, -1, cur, 0]
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
 def test_engines_on_a_non_current_device(weights):
     """Chat.load(device=cuda:1) without torch.cuda.set_device: every C-ABI entry point makes the device that owns the stream it was
@@ -1095,8 +1132,18 @@ def test_device_generator_mode(gpt_f32, weights):
         e1 = gpt_f32.embed_prompt(p_t, torch.ones((1, pid.shape[0]), dtype=torch.bool))
         ref = list(gpt_f32.generate(e1, p_t, torch.tensor([0.3] * 4), 625, None, 40, 0, (*procs, *warpers), manual_seed=None, rng="device",
                                     rng_seed=99, stop_at=torch.tensor([n], dtype=torch.int32), row_offset=4 * pool.slot_of[rid],
-                                    total_rows=4 * S))[-1]
+                                    total_rows=4 * S, rng_nonce=pool.nonce_of[rid]))[-1]
         assert np.array_equal(got[rid], ref.ids[0].cpu().numpy()), rid
+    # every admission draws from its own stream: the same prompt submitted twice (it lands in the same slots again) gives different
+    # tokens the second time, and admission numbers never repeat
+    assert len(set(pool.nonce_of.values())) == len(reqs)
+    first = dict(got)
+    for i, (pid, n) in reqs.items():
+        pool.submit(("again", i), pid, max_new_token=32, stop_at=n)
+    again = {rid: t.cpu().numpy() for rid, t, _ in pool.run()}
+    same_slot = [i for i in reqs if pool.slot_of[("again", i)] == pool.slot_of[i]]
+    assert same_slot, "the replay was meant to reuse slots"
+    assert all(not np.array_equal(again[("again", i)], first[i]) for i in same_slot if reqs[i][1] >= 6)
     pool.close()
 
 

@@ -401,3 +401,38 @@ def test_pmc_summary_maps_the_profiled_kernel_names():
     assert {"attention", "qkv_gemm", "o_proj_gemm", "gate_up_gemm", "down_gemm", "heads_gemm", "sample", "codec_pwconv1_h1p",
             "codec_pwconv2_h1p", "dwconv_ln_run"} <= tags
     assert {"codec_pwconv1_h1p", "codec_pwconv2_h1p", "dwconv_ln_run"} <= set(traffic)
+
+
+def test_pipelined_queue_yields_one_item_per_batch_in_order():
+    """`Chat.infer_ids_pipelined`: exactly one result per input batch, in order -- also when a batch in the middle of the queue produces
+    no output (seeded generation that ends at step 0 yields nothing, gpt.py:570): its empty placeholder must not be dropped, or every
+    later result would be attributed to the wrong batch.  Host logic only: generation and the acoustic decoder are stubbed."""
+    import types
+
+    import numpy as np
+
+    from chattts_amd.core import Chat
+
+    class Pend:
+        def __init__(self, v):
+            self.v = v
+
+        def result(self):
+            return np.full((1, 2), self.v, np.float32)
+
+    chat = Chat.__new__(Chat)
+    chat.codec = types.SimpleNamespace(decode_to_wavs_async=lambda hid: Pend(hid))
+    outs = {"a": 1.0, "b": None, "c": 3.0, "d": None, "e": None, "f": 6.0}
+
+    def infer_code(ids, mask, tmask, params, stream=False, **kw):
+        if outs[ids] is not None:
+            yield types.SimpleNamespace(hiddens=outs[ids])
+
+    chat.infer_code = infer_code
+    got = list(chat.infer_ids_pipelined([(k, None, None) for k in outs]))
+    assert len(got) == len(outs)
+    for g, k in zip(got, outs):
+        if outs[k] is None:
+            assert g.shape == (0,)
+        else:
+            assert g.shape == (1, 2) and float(g[0, 0]) == outs[k]
