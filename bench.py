@@ -551,7 +551,7 @@ def main():
         pool.close()
         del pool
         torch.cuda.empty_cache()
-    if world > 1:   # self-diagnosing multi-GPU line: who was slow, what the one collective cost
+    if dist is not None:   # self-diagnosing multi-GPU line (also under torchrun with one rank): who was slow, what the one collective cost
         rt = rank_times.get("main", [])
         result["ranks"] = {"world": world, "pass_ms_per_rank": rt, "pass_ms_min": min(rt) if rt else None, "pass_ms_max": max(rt) if rt else None,
                            "weight_broadcast": bcast,
