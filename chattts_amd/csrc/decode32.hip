@@ -395,29 +395,35 @@ __global__ __launch_bounds__(256, 3) void gemm_dec32_rms16_k(Dec32Args a) {
   const u128* wp2 = wp + (size_t)(a.N >> 4) * KCH * 64;
   const u128* ap = reinterpret_cast<const u128*>(a.Ap) + ((size_t)mt0 * KCH + wave) * 64 + lane;
   const bool w_once = a.w_nt && gridDim.y == 1;
-  u128 wf[NACC][WU], af[NPER];
-  float4 nw[WU];
-  auto load_w = [&](const int i0) {
+  // Round 4: the weight chunks of a round live in TWO half buffers (HU chunks each, the same registers as one WU-chunk round before);
+  // a half is refilled with the chunks of the round after next as soon as its MFMAs are issued, so the next request is in flight while the
+  // other half is multiplied (before: every round's loads were issued right in front of its own MFMAs -- one exposed L2 round trip per
+  // round).  Chunk order per accumulator is unchanged (ascending): bit-identical.
+  constexpr int HU = WU / 2, NH = NPER / HU;
+  u128 wfh[2][NACC][HU], af[NPER];
+  float4 nwh[2][HU];
+  auto load_h = [&](u128 (&wf)[NACC][HU], float4 (&nw)[HU], const int i0) {
     if (w_once) {
 #pragma unroll
-      for (int j = 0; j < WU; ++j) {
+      for (int j = 0; j < HU; ++j) {
         wf[0][j] = load16_nt(wp + (size_t)(i0 + j) * 256);
         if (NACC == 2) wf[1][j] = load16_nt(wp2 + (size_t)(i0 + j) * 256);
       }
     } else {
 #pragma unroll
-      for (int j = 0; j < WU; ++j) {
+      for (int j = 0; j < HU; ++j) {
         wf[0][j] = load16(wp + (size_t)(i0 + j) * 256);
         if (NACC == 2) wf[1][j] = load16(wp2 + (size_t)(i0 + j) * 256);
       }
     }
 #pragma unroll
-    for (int j = 0; j < WU; ++j) nw[j] = *reinterpret_cast<const float4*>(a.norm_w + ((i0 + j) * 4 + wave) * 16 + g * 4);
+    for (int j = 0; j < HU; ++j) nw[j] = *reinterpret_cast<const float4*>(a.norm_w + ((i0 + j) * 4 + wave) * 16 + g * 4);
   };
   // everything the workgroup can ask for without knowing the live-row count (its row tile's buffer exists either way)
 #pragma unroll
   for (int i = 0; i < NPER; ++i) af[i] = load16(ap + (size_t)i * 256);
-  load_w(0);
+  load_h(wfh[0], nwh[0], 0);
+  load_h(wfh[1], nwh[1], HU);
   const int M = a.n_active ? min(*a.n_active, a.M) : a.M;
   if (m0 >= M) return;
 
@@ -455,12 +461,9 @@ __global__ __launch_bounds__(256, 3) void gemm_dec32_rms16_k(Dec32Args a) {
   f32x4 acc[NACC];
 #pragma unroll
   for (int na = 0; na < NACC; ++na) acc[na] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  auto mul_h = [&](const u128 (&wf)[NACC][HU], const float4 (&nw)[HU], const int i0) {
 #pragma unroll
-  for (int i0 = 0; i0 < NPER; i0 += WU) {
-    if (i0 > 0) load_w(i0);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int j = 0; j < WU; ++j) {
+    for (int j = 0; j < HU; ++j) {
       float4 a0 = *reinterpret_cast<const float4*>(&af[i0 + j]);
       a0.x = nw[j].x * (a0.x * rs); a0.y = nw[j].y * (a0.y * rs); a0.z = nw[j].z * (a0.z * rs); a0.w = nw[j].w * (a0.w * rs);
 #pragma unroll
@@ -474,6 +477,17 @@ __global__ __launch_bounds__(256, 3) void gemm_dec32_rms16_k(Dec32Args a) {
         acc[na] = c;
       }
     }
+  };
+#pragma unroll
+  for (int h = 0; h < NH; h += 2) {
+    __builtin_amdgcn_sched_barrier(0);
+    mul_h(wfh[0], nwh[0], h * HU);
+    __builtin_amdgcn_sched_barrier(0);
+    if (h + 2 < NH) load_h(wfh[0], nwh[0], (h + 2) * HU);   // refill the half just consumed: in flight while the other half is multiplied
+    __builtin_amdgcn_sched_barrier(0);
+    mul_h(wfh[1], nwh[1], (h + 1) * HU);
+    __builtin_amdgcn_sched_barrier(0);
+    if (h + 3 < NH) load_h(wfh[1], nwh[1], (h + 3) * HU);
   }
 
 #pragma unroll
@@ -675,8 +689,18 @@ hipError_t launch_gemm_dec32(const Dec32Args& a_in, hipStream_t st) {
   if (mb == 1 && rms16 && a.norm_w != nullptr && a.K == 768) {
     g_d32_variant = "rms16";
     dim3 grid(a.N / 16, (a.M + 15) / 16), block(256);
-    if (a.epi == EPI_SILU_MUL) CTTS_LAUNCH((gemm_dec32_rms16_k<EPI_SILU_MUL>), grid, block, st, a);
-    else if (a.epi == D32_EPI_QKV_ROPE) CTTS_LAUNCH((gemm_dec32_rms16_k<D32_EPI_QKV_ROPE>), grid, block, st, a);
+    // CTTS_D32_LDS=<bytes> (A/B knob): dynamic LDS the RMSNorm launches declare and never touch -- bounds the workgroups a CU holds at once
+    // (160 KiB / bytes), i.e. staggers the 3 co-resident workgroups that otherwise run their load / MFMA / reduce phases in lockstep
+    static int d32_lds = -1;
+    if (d32_lds < 0) {
+      d32_lds = env_int32("CTTS_D32_LDS", 0);
+      if (d32_lds > 65536) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_dec32_rms16_k<EPI_SILU_MUL>), hipFuncAttributeMaxDynamicSharedMemorySize, d32_lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_dec32_rms16_k<D32_EPI_QKV_ROPE>), hipFuncAttributeMaxDynamicSharedMemorySize, d32_lds);
+      }
+    }
+    if (a.epi == EPI_SILU_MUL) CTTS_LAUNCH_SMEM((gemm_dec32_rms16_k<EPI_SILU_MUL>), grid, block, d32_lds, st, a);
+    else if (a.epi == D32_EPI_QKV_ROPE) CTTS_LAUNCH_SMEM((gemm_dec32_rms16_k<D32_EPI_QKV_ROPE>), grid, block, d32_lds, st, a);
     else if (a.epi == EPI_STORE) CTTS_LAUNCH((gemm_dec32_rms16_k<EPI_STORE>), grid, block, st, a);
     else return hipErrorInvalidValue;
     return hipGetLastError();
