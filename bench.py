@@ -308,6 +308,7 @@ def main():
     ap.add_argument("--no-ttfs", action="store_true")
     ap.add_argument("--no-parity-mode", action="store_true")
     ap.add_argument("--no-bf16-parity", action="store_true")
+    ap.add_argument("--no-ids-check", action="store_true", help="skip the two extra passes that compare graph replay with eager launches (profiler runs)")
     ap.add_argument("--no-configs", action="store_true", help="skip the BASELINE.json configs[0] / [1] / [4] legs (C1, C2, C5)")
     ap.add_argument("--pipeline", action="store_true", help="time the main leg as a software-pipelined queue of batches (batch i's acoustic decode "
                     "overlaps batch i+1's generation); default: one batch after the other, the pipelined figure is reported beside it")
@@ -475,10 +476,12 @@ def main():
     decode_ms = gpt.last_stats.get("decode_ms", 0.0)      # host wall of the decode loop of the LAST timed pass
     # what the timed passes produced, beyond forced lengths and finite audio: the seeded run is deterministic -- two more passes (graph
     # replay and eager launches) must give the same token ids bit for bit
-    _, _, ids_g = one_pass(gpt, use_graph=not args.no_graph, decode_audio=False, keep_ids=True)
-    _, _, ids_e = one_pass(gpt, use_graph=False, decode_audio=False, keep_ids=True)
-    ids_check = {"ids_sha256": ids_digest(ids_g), "graph_equals_eager": ids_digest(ids_g) == ids_digest(ids_e)}
-    assert ids_check["graph_equals_eager"], "graph replay and eager launches disagree on the sampled token ids"
+    ids_check = None
+    if not args.no_ids_check:
+        _, _, ids_g = one_pass(gpt, use_graph=not args.no_graph, decode_audio=False, keep_ids=True)
+        _, _, ids_e = one_pass(gpt, use_graph=False, decode_audio=False, keep_ids=True)
+        ids_check = {"ids_sha256": ids_digest(ids_g), "graph_equals_eager": ids_digest(ids_g) == ids_digest(ids_e)}
+        assert ids_check["graph_equals_eager"], "graph replay and eager launches disagree on the sampled token ids"
 
     result = {
         "metric": "audio seconds/sec (RTF), batch=64 per GPU", "value": round(value, 2), "unit": "audio-s/s",

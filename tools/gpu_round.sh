@@ -26,7 +26,7 @@ for S in $STAGES; do
       tail -3 gpurun_out/${TAG}_bench.log ;;
     prof)
       cd /tmp
-      timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${TAG} -o ${TAG} -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-ttfs --no-parity-mode --no-configs > $R/gpurun_out/${TAG}_rocprof.log 2>&1
+      timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${TAG} -o ${TAG} -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-ttfs --no-parity-mode --no-configs --no-slot-pool --no-ids-check > $R/gpurun_out/${TAG}_rocprof.log 2>&1
       echo "rocprof exit $?" >> $R/gpurun_out/${TAG}_rocprof.log
       find /tmp/prof_${TAG} -name "*stats*.csv" -exec cp {} $R/gpurun_out/ \;
       find /tmp/prof_${TAG} -type f >> $R/gpurun_out/${TAG}_rocprof.log
@@ -34,10 +34,10 @@ for S in $STAGES; do
     pmc)
       cd /tmp
       for C in FETCH_SIZE WRITE_SIZE; do
-        timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/pmc_${TAG}_$C -o ${TAG}_$C -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-ttfs --no-parity-mode --no-configs > $R/gpurun_out/${TAG}_pmc_$C.log 2>&1
+        timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/pmc_${TAG}_$C -o ${TAG}_$C -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-ttfs --no-parity-mode --no-configs --no-slot-pool --no-ids-check > $R/gpurun_out/${TAG}_pmc_$C.log 2>&1
         if ! ls /tmp/pmc_${TAG}_$C/*counter_collection.csv > /dev/null 2>&1; then   # the profiler crashed once under the pinned-memory polls: plain polls
           rm -rf /tmp/pmc_${TAG}_$C
-          CTTS_SYNC_POLL=1 timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/pmc_${TAG}_$C -o ${TAG}_$C -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-ttfs --no-parity-mode --no-configs > $R/gpurun_out/${TAG}_pmc_${C}_retry.log 2>&1
+          CTTS_SYNC_POLL=1 timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/pmc_${TAG}_$C -o ${TAG}_$C -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-ttfs --no-parity-mode --no-configs --no-slot-pool --no-ids-check > $R/gpurun_out/${TAG}_pmc_${C}_retry.log 2>&1
         fi
       done
       python $R/tools/pmc_summary.py /tmp/pmc_${TAG}_FETCH_SIZE /tmp/pmc_${TAG}_WRITE_SIZE $R/gpurun_out/${TAG}_pmc_traffic.json > $R/gpurun_out/${TAG}_pmc_summary.txt 2>&1
