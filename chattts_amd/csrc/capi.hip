@@ -643,7 +643,10 @@ struct ctts_codec {
   ctts_codec_weights w;
   std::vector<const float*> d[9], v[9];
   std::vector<const void*> dx[2], vx[2];   // pwconv1 / pwconv2 as pre-split fragment-order planes (codec_gemm.hip), or empty
-  int x3p_min_rows = 12288;                // frames from which the point-wise layers take the LDS-DMA kernel (env CTTS_X3P_MIN_ROWS, 0 = never)
+  int x3p_min_rows = 1024;                 // frames from which the point-wise layers take the LDS-DMA kernel (env CTTS_X3P_MIN_ROWS, 0 = never).
+                                           // Round 4: 12288 -> 1024 -- the first streamed window of a batch (64 x 144 = 9216 frames; 16 x 144 = 2304)
+                                           // was on the register-staged tiles: TTFS p50 55.3 -> 50.4 ms at batch 64, 44.4 -> 40.1 ms at batch 16,
+                                           // C5 total 252.7 -> 239.4 ms (profiles/r4o_ab_x3p_min_rows.log; 256 measures the same as 1024)
 };
 
 extern "C" int ctts_codec_create(ctts_codec** out, const ctts_codec_weights* w) {

@@ -911,7 +911,7 @@ class CodecEngine:
     def __init__(self, decoder_sd: dict, vocos_sd: dict, device: torch.device, gemm: str = "bf16x3"):
         """gemm="bf16x3": dense layers run on split-bf16 MFMA tiles (x = hi + lo, 3 products; f32-class accuracy,
         measured wav RMS error vs the reference ~1e-6 against the 1e-4 bar); gemm="f32": f32-input MFMA tiles;
-        gemm="f16" (the perf mode's decoder): as "bf16x3", but the ConvNeXt point-wise pairs of large batches (>= 12288 frames) take
+        gemm="f16" (the perf mode's decoder): as "bf16x3", but the ConvNeXt point-wise pairs of batches from 1024 frames take
         one fp16 MFMA per product with f32 accumulation -- waveform within 1e-5 RMS of "bf16x3" (stated and tested bound; the
         north-star bar is 1e-4), about half the decode time."""
         if gemm not in ("bf16x3", "f32", "f16"):

@@ -548,11 +548,11 @@ def test_codec_lds_dma_path_equals_tile_path(weights, monkeypatch):
 
 
 def test_codec_f16_mode_holds_the_waveform_bar(weights):
-    """gemm="f16" (the perf mode's acoustic decoder): from 12288 frames the ConvNeXt point-wise pairs take ONE fp16 MFMA per product
+    """gemm="f16" (the perf mode's acoustic decoder): from 1024 frames (12288 until round 4) the ConvNeXt point-wise pairs take ONE fp16 MFMA per product
     (csrc/codec_gemm.hip: gemm_h1p_k; planes written by the depthwise-conv + LayerNorm kernel and the GELU epilogue).  Stated
     bounds, against the split-bf16 decoder (itself 4e-7 from the float32 oracle) on a 16 x 400-token ragged batch: mel within
     2e-3 of its peak, waveform within 2e-5 RMS -- a fifth of the north-star's 1e-4 -- and within 1e-4 RMS of the numpy oracle on
-    a row slice.  Below 12288 frames the mode runs the split-bf16 tiles, i.e. equals gemm="bf16x3"."""
+    a row slice.  Below 1024 frames the mode runs the split-bf16 tiles, i.e. equals gemm="bf16x3"."""
     rs = np.random.RandomState(33)
     rows = [torch.from_numpy(rs.standard_normal((n, 768)).astype(np.float32)) for n in [400, 390, 120, 400] + [300] * 12]
     ref_eng = E.CodecEngine(weights["decoder"], weights["vocos"], DEV, gemm="bf16x3")
@@ -579,6 +579,11 @@ def test_codec_f16_mode_holds_the_waveform_bar(weights):
     assert float(np.sqrt(np.mean((w_f16[2, :n] - ref[0, :n]) ** 2))) < 1e-4
     small = [r[:40] for r in rows[:4]]               # 320 frames: below the threshold the mode IS the split-bf16 decoder
     assert torch.equal(f16_eng.decode_to_wavs(small), ref_eng.decode_to_wavs(small))
+    # ... so in this mode an utterance's waveform depends on the size of the batch it was decoded in: pinned across the
+    # threshold -- row 2 alone (240 frames: split-bf16 tiles) against row 2 inside the 16-row batch (12800 frames: fp16 planes)
+    alone = f16_eng.decode_to_wavs([rows[2]]).cpu().numpy()[0]
+    n2 = 256 * (2 * 120 - 1) - 256 * 110            # clear of the zero-padded tail's edge effects
+    assert float(np.sqrt(np.mean((alone[:n2] - w_f16[2, :n2]) ** 2))) < 2e-5
 
 
 def test_decode_window_equals_slices_of_the_full_decode(codec):
