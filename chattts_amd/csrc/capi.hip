@@ -290,6 +290,7 @@ static int run_step(ctts_gpt* g, const ctts_gen_state* s, int q_per_b, hipStream
     memset(&d, 0, sizeof(d));
     d.M = M; d.eps = g->w.rms_eps; d.n_active = nact;
     d.force_nt = l < g->temporal_layers ? 1 : 0;   // A/B knob: the first N layers' weights with plain loads (candidates for the Infinity Cache)
+#ifdef CTTS_PF_BUILD
     // cross-kernel weight prefetch (common.hpp): QKV -> this layer's o_proj; attention -> gate/up; gate/up -> down and the next layer's
     // QKV (last layer: the heads).  CTTS_PF is a bit mask (default 0 = off: every combination measured a net loss,
     // profiles/r3s_ab_prefetch.log): 1 QKV -> o_proj, 16 QKV -> gate/up, 2 attention -> gate/up
@@ -301,6 +302,7 @@ static int run_step(ctts_gpt* g, const ctts_gen_state* s, int q_per_b, hipStream
                            : (fuse_fnorm && !s->infer_text) ? PfDesc{(const char*)g->w.heads_pk, 16u * HID * 4u, (NVQ * NAUDIO + 15u) / 16u} : pf_none;
     d.pf[0] = (g->pf_mask & 1) ? pf_o : pf_none; d.pf[1] = (g->pf_mask & 16) ? pf_gu : pf_none;
     rm.pf = (g->pf_mask & 2) ? pf_gu : pf_none;
+#endif
     // RMSNorm scale + QKV + RoPE + KV append
     d.Ap = ws.xp; d.Wp = (const uint16_t*)g->wqkv_pk[l]; d.N = 3 * HID; d.K = HID; d.ssq_in = ws.ssq; d.epi = FEPI_QKV_ROPE;
     d.C32 = ws.qkv; d.ldc = 3 * HID; d.desc = ws.desc; d.cos_t = g->w.rope_cos; d.sin_t = g->w.rope_sin;
@@ -332,7 +334,9 @@ static int run_step(ctts_gpt* g, const ctts_gen_state* s, int q_per_b, hipStream
     }
     d.Ap = ws.xp; d.Wp = (const uint16_t*)g->wgu_pk[l]; d.N = INTER; d.ssq_in = ws.ssq; d.epi = FEPI_SILU; d.C32 = nullptr;
     d.Cp = ws.actp; d.kch_out = INTER / 32; d.ssq_out = nullptr;
+#ifdef CTTS_PF_BUILD
     d.pf[0] = pf_none; d.pf[1] = pf_none; (void)pf_d; (void)pf_next;   // (gate/up has no auxiliary wave: see decode.hip)
+#endif
     { Prof p(g, 5, st, prof_ok); CK(launch_gemm_dec(d, st)); }
     d.Ap = ws.actp; d.Wp = (const uint16_t*)g->wd_pk[l]; d.N = HID; d.K = INTER; d.ssq_in = nullptr; d.epi = FEPI_RES; d.C32 = ws.x;
     d.ldc = HID; d.Cp = ws.xp; d.kch_out = HID / 32; d.ssq_out = ws.ssq;

@@ -197,6 +197,7 @@ __device__ __forceinline__ void wave_rows_rstd_768(const float* const (&rows)[NR
   }
 }
 
+#ifdef CTTS_PF_BUILD   // probe builds only (python -m chattts_amd.build --variant pf -DCTTS_PF_BUILD=1, env CTTS_PF=<mask>): a recorded negative result
 // ---- cross-kernel weight prefetch ------------------------------------------------------------------------------------------
 // A decode step is a chain of short, latency-bound kernels; each projection starts with an HBM round trip for weights that nothing
 // upstream has touched (phase probe: +0.6 ... 1.5 us per launch with cold weights).  The NEXT kernel's weights are known when the
@@ -229,3 +230,4 @@ __device__ __forceinline__ void prefetch_weight_tiles(const PfDesc& pf, int lane
   }
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink) : : "memory");
 }
+#endif   // CTTS_PF_BUILD

@@ -260,10 +260,14 @@ __device__ __forceinline__ void gemm_dec_wg(const DecGemmArgs& a, const int tile
 
   // QKV: the RoPE helper wave (index NW) first pulls weights of later launches of the step towards this XCD's L2 (common.hpp).  An
   // extra wave for this in the gate/up kernel cost that kernel +0.6 us by itself (profiles/r3s_ab_prefetch.log): not there.
+#ifdef CTTS_PF_BUILD
   if (!HO && EPI == FEPI_QKV_ROPE && (threadIdx.x >> 6) == NW) {
     prefetch_weight_tiles(a.pf[0], threadIdx.x & 63, (unsigned)wg_linear, (unsigned)n_wg);
     prefetch_weight_tiles(a.pf[1], threadIdx.x & 63, (unsigned)wg_linear, (unsigned)n_wg);
   }
+#else
+  (void)n_wg;
+#endif
   if (a.dbg && threadIdx.x == 0) a.dbg[(size_t)wg_linear * 8] = wall_clock64();
   // The weight fragments of the first round do not depend on anything but the kernel arguments: request them before
   // the live-row count (a dependent scalar load) is known.  Decode weights are read by one row group (<= 64 live

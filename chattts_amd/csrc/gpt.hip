@@ -317,10 +317,12 @@ __device__ __forceinline__ void attention_body(const float* __restrict__ qkv, co
   __shared__ __attribute__((aligned(16))) bf16_t sm_on[OPJ ? HDIM : 8];   // OPJ: the unit's normalised output, bf16
   __shared__ __attribute__((aligned(16))) float sm_p[OPJ ? HID : 4];      // OPJ: its 768-wide o_proj partial
   __shared__ int sm_last;
+#ifdef CTTS_PF_BUILD
   if (PF && (threadIdx.x >> 6) == NW) {   // fifth wave: this layer's gate/up weights towards this XCD's L2 (common.hpp), then gone
     prefetch_weight_tiles(rm.pf, threadIdx.x & 63, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
     return;
   }
+#endif
 
   const int unit = QF ? (int)(threadIdx.x >> 8) : 0;   // which of the workgroup's units this wave belongs to
   int h = h_in + unit, m = m_in;
@@ -935,8 +937,10 @@ hipError_t launch_attention(const float* qkv, const void* kcache, const void* vc
       // step with it, 0.478 without -- the 16-way LDS merge costs what the shorter stream saves -- and it would make a row's
       // perf-mode bits depend on the batch size.
       CTTS_LAUNCH((attention_k<bf16_t, 16, bf16_t, true>), grid, dim3(1024), st, qkv, (const bf16_t*)kcache, (const bf16_t*)vcache, cmax, (bf16_t*)out, rm);
+#ifdef CTTS_PF_BUILD
     else if (rm.pf.base != nullptr)
       CTTS_LAUNCH_SMEM((attention_k<bf16_t, 4, bf16_t, true, false, true>), grid, dim3(320), att_lds, st, qkv, (const bf16_t*)kcache, (const bf16_t*)vcache, cmax, (bf16_t*)out, rm);
+#endif
     else if (nw_packed == 2)
       CTTS_LAUNCH_SMEM((attention_k<bf16_t, 2, bf16_t, true>), grid, dim3(128), att_lds, st, qkv, (const bf16_t*)kcache, (const bf16_t*)vcache, cmax, (bf16_t*)out, rm);
     else if (nw_packed == 8)
@@ -988,8 +992,7 @@ hipError_t launch_qkv_attention(const DecGemmArgs& d_in, const void* kcache, con
   if (nt < 0) { const char* e = getenv("CTTS_W_NT"); nt = e ? atoi(e) : 1; const char* e2 = getenv("CTTS_DEC_A_EARLY"); a_early = e2 ? atoi(e2) : 1; }
   d.w_nt = d.force_nt ? (d.force_nt == 2) : nt;
   d.a_early = a_early;
-  d.pf[0] = PfDesc{nullptr, 0, 0}; d.pf[1] = PfDesc{nullptr, 0, 0};
-  rm.sp_cus = 0; rm.sp_part = nullptr; rm.sp_cnt = nullptr; rm.pf = PfDesc{nullptr, 0, 0};
+  rm.sp_cus = 0; rm.sp_part = nullptr; rm.sp_cnt = nullptr;
   rm.qf_rows = M;
   const int n_qkv = 3 * HID / 16;
   CTTS_LAUNCH(qkv_attention_k, dim3(n_qkv + (NHEAD / 2) * M), dim3(512), st, d, (const bf16_t*)kcache, (const bf16_t*)vcache, cmax, (bf16_t*)out_packed, rm, n_qkv);

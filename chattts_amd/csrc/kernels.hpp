@@ -148,7 +148,9 @@ struct DecGemmArgs {
   int w_nt;                     // set by the launcher
   int a_early;                  // set by the launcher (CTTS_DEC_A_EARLY): batches of <= 16 rows request their activation tile at entry
   int force_nt;                 // 0: the launcher's policy (CTTS_W_NT); 1: plain (temporal) weight loads; 2: non-temporal (A/B: CTTS_W_TEMPORAL_LAYERS)
+#ifdef CTTS_PF_BUILD
   PfDesc pf[2];                 // weights of later launches of the step this launch's auxiliary wave pulls towards L2 (QKV_ROPE, SILU), or {null}
+#endif
   long long* dbg;               // probes only (tools/dec_phase_probe.py): [n_workgroups][8] phase stamps, or null
   const float* rope_cs;         // QKV_ROPE inside the fused QKV + attention launch: [rows][64] cos[32] | sin[32] of each row's position (StepPrep)
   int32_t* ho_flag;             // QKV_ROPE inside the fused QKV + attention launch: this layer's arrival words, head h at [h * HO_STRIDE]
@@ -220,7 +222,9 @@ struct GptRowMap {
   int slot0;                // prefill: first prompt slot of the chunk this launch covers
   int desc_covers_all;      // decode: desc[] is valid for EVERY row of the grid (absent rows carry b = -1), so the attention
                             // kernel need not read *n_active first (one dependent load less in front of the KV stream)
+#ifdef CTTS_PF_BUILD
   PfDesc pf;                // decode, perf mode: the gate/up weights of this layer, pulled towards L2 by a fifth wave per workgroup
+#endif
   long long* dbg;           // probes only (tools/attn_phase_probe.py, env CTTS_ATT_DBG_PTR): [workgroups][8] phase stamps (100 MHz), or null
   // decode, perf mode, optional (launch_attention_oproj): o_proj + residual folded into the attention launch
   const uint16_t* wo_h;     // this layer's o_proj weight per head: [12][8 (k / 8)][768 columns][8] bf16 (engine.py pack_wo_heads)
