@@ -70,7 +70,7 @@ hipError_t launch_gemm_dec(const DecGemmArgs& a_in, hipStream_t st) {
   }
   a.w_nt = a.force_nt ? (a.force_nt == 2) : nt;
   a.a_early = a_early;
-  if (a.M <= 0 || a.N <= 0 || (a.N & 15) || !(a.K == 768 || a.K == 3072)) return hipErrorInvalidValue;
+  if (a.M <= 0 || a.N <= 0 || (a.N & 15) || !(a.K == 768 || a.K == 1536 || a.K == 3072)) return hipErrorInvalidValue;   // 1536: probes (tools/ogu_probe.py)
   if (a.epi == FEPI_RES && a.N != 16 * SSQ_PARTS) return hipErrorInvalidValue;
   if (a.epi == FEPI_QKV_ROPE && (a.N != 2304 || a.K != 768 || !a.desc)) return hipErrorInvalidValue;
   // Rows per workgroup.  Every workgroup pulls its whole activation tile besides its weight tile, and a CU's load path
@@ -78,7 +78,7 @@ hipError_t launch_gemm_dec(const DecGemmArgs& a_in, hipStream_t st) {
   // o_proj / down_proj have only 48 weight tiles, so 16-row workgroups (192 at 64 rows) keep the CUs busy instead.
   int mb = a.epi == FEPI_QKV_ROPE ? mb_qkv : a.epi == FEPI_SILU ? mb_silu : a.K == 3072 ? mb_down : mb_o;
   if (a.force_mb) mb = a.force_mb;
-  if (a.K == 768) {
+  if (a.K == 768 || a.K == 1536) {
     if (mb == 4) return dec_dispatch_k768<4>(a, st);
     if (mb == 2) return dec_dispatch_k768<2>(a, st);
     return dec_dispatch_k768<1>(a, st);
