@@ -308,6 +308,10 @@ def main():
     ap.add_argument("--no-ttfs", action="store_true")
     ap.add_argument("--no-parity-mode", action="store_true")
     ap.add_argument("--no-bf16-parity", action="store_true")
+    ap.add_argument("--capi-broadcast-check", action="store_true", help="N > 1: also run the weight broadcast's C-ABI entry (ctts_broadcast_weights on a "
+                    "communicator made through the C ABI) on a probe buffer and compare with torch.distributed's result; off by default at N > 1 "
+                    "(a second RCCL bootstrap that no multi-GPU box has exercised yet must not be able to stall the scaling run), always on under "
+                    "torchrun with one rank")
     ap.add_argument("--no-ids-check", action="store_true", help="skip the two extra passes that compare graph replay with eager launches (profiler runs)")
     ap.add_argument("--no-configs", action="store_true", help="skip the BASELINE.json configs[0] / [1] / [4] legs (C1, C2, C5)")
     ap.add_argument("--pipeline", action="store_true", help="time the main leg as a software-pipelined queue of batches (batch i's acoustic decode "
@@ -365,6 +369,8 @@ def main():
         # the same collective through the library's own C ABI (ctts_broadcast_weights on an RCCL communicator made from the C ABI, what a
         # host without torch would call): one flat buffer, checked against what torch.distributed delivered; never fatal for the bench
         try:
+            if world > 1 and not args.capi_broadcast_check:
+                raise RuntimeError("skipped at N > 1 (pass --capi-broadcast-check)")
             comm = D.CapiComm(world, rank)
             probe = next(iter(sds["embed"].values())).reshape(-1)[: 1 << 20].clone().contiguous()
             want = probe.clone()
