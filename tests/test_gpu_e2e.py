@@ -224,7 +224,7 @@ def test_capi_weight_broadcast_world1():
     """`ctts_broadcast_weights` (the ONE collective of the path) through the C ABI on a real MI355X: librccl.so is
     dlopen'ed lazily, a communicator of world size 1 is made from a unique id (`ctts_rccl_unique_id` / `ctts_rccl_comm_create`), and an
     in-place byte-typed broadcast of two flat weight buffers leaves them unchanged and completes on the caller's stream.  (N > 1 needs
-    a multi-GPU box: bench.py --gpus N checks the same entry point against torch.distributed's broadcast there.)"""
+    a multi-GPU box: `bench.py --gpus N --capi-broadcast-check` checks the same entry point against torch.distributed's broadcast there.)"""
     from chattts_amd import dist as D
     comm = D.CapiComm(1, 0)
     a = torch.arange(1 << 20, dtype=torch.float32, device=DEV)
