@@ -13,9 +13,9 @@ name; `parity_mode` is the f32 mode whose token ids are bit-exact against the re
 ids is compared with the reference-generated golden of this very workload (tests/golden/bench_c3.npz,
 oracle/make_bench_golden.py).
 
-N > 1: `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` -- the global batch of 64*N utterances
-is sharded in contiguous row blocks (weak scaling), weights are broadcast once from rank 0 over RCCL, there is no
-collective on the data path.
+N > 1: `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`, or plain `python bench.py --gpus N` (which spawns
+exactly that itself; a world size that is not N is refused) -- the global batch of 64*N utterances is sharded in contiguous row blocks
+(weak scaling), weights are broadcast once from rank 0 over RCCL, there is no collective on the data path.
 
 Prints ONE JSON line on rank 0.
 """
@@ -293,6 +293,124 @@ def config_leg_c1(gpt32, codec, dev) -> dict:
             "unit": "audio-s/s", "ids_bit_exact_vs_reference": exact}
 
 
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` -> `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P
+    bench.py <the same arguments>`; stdout / stderr are the children's own (rank 0 prints the JSON line), the exit code is the launcher's."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cpu_quota() // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    print(f"[bench] --gpus {n} without a launcher: spawning {n} ranks: {' '.join(cmd[1:9])} bench.py ...", file=sys.stderr, flush=True)
+    rc = subprocess.call(cmd, env=env)
+    if rc != 0:
+        print(f"[bench] the {n}-rank run failed (exit {rc}); NO result line is printed for --gpus {n}", file=sys.stderr, flush=True)
+    return rc
+
+
+def capi_broadcast_check(D, sds, world, rank, dev, dist, timeout_s):
+    """The path's one collective through the library's own C ABI (ctts_rccl_unique_id / ctts_rccl_comm_create / ctts_broadcast_weights,
+    include/chattts_amd.h -- what a host without torch would call): a 4 MB probe, compared with what torch.distributed delivered.  The RCCL
+    part runs in a worker thread that is given `timeout_s`; a bootstrap that hangs is reported as such and the run goes on (never fatal).
+    The unique id is exchanged on the main thread (a torch.distributed collective every rank reaches)."""
+    import ctypes as C
+    import threading
+    from chattts_amd import _lib
+    out = {"ok": False, "entry": "ctts_broadcast_weights (include/chattts_amd.h)", "timeout_s": timeout_s}
+    try:
+        lib = _lib.lib()
+        idb = (C.c_char * 128)()
+        if rank == 0:
+            _lib.check(lib.ctts_rccl_unique_id(C.cast(idb, C.c_void_p)), "ctts_rccl_unique_id")
+        box = [bytes(idb)]
+        if world > 1:
+            dist.broadcast_object_list(box, src=0)
+        probe = next(iter(sds["embed"].values())).reshape(-1)[: 1 << 20].clone().contiguous()
+        want = probe.clone()
+        if rank != 0:
+            probe.zero_()
+        torch.cuda.synchronize(dev)
+        res = {}
+
+        def work():
+            try:
+                torch.cuda.set_device(dev)
+                comm = D.CapiComm(world, rank, exchange=lambda _b: box[0])
+                st = torch.cuda.Stream(device=dev)
+                t1 = time.perf_counter()
+                comm.broadcast([probe], root=0, stream=st)
+                st.synchronize()
+                res["ms"] = round(1e3 * (time.perf_counter() - t1), 3)
+                comm.close()
+                res["done"] = True
+            except Exception as exc:   # noqa: BLE001
+                res["error"] = repr(exc)[:200]
+
+        th = threading.Thread(target=work, daemon=True)
+        th.start()
+        th.join(timeout_s)
+        if th.is_alive():
+            out["error"] = f"timed out after {timeout_s} s (the worker thread is left behind; the torch.distributed broadcast above is the one the run uses)"
+        elif "error" in res:
+            out["error"] = res["error"]
+        else:
+            out.update({"ok": bool(torch.equal(probe, want)), "bytes": int(probe.numel() * probe.element_size()), "ms": res.get("ms")})
+    except Exception as exc:   # noqa: BLE001
+        out["error"] = repr(exc)[:200]
+    if world > 1:   # one verdict for the line: every rank's
+        flags = [None] * world
+        dist.all_gather_object(flags, bool(out["ok"]))
+        out["ok_all_ranks"] = bool(all(flags))
+    return out
+
+
+def plumbing_only(args, world, rank, local_rank):
+    """--plumbing-only: everything of an N-rank run that is not the GPU -- rendezvous, contiguous shards of the global batch, the ONE broadcast
+    of the checkpoint (chattts_amd/dist.py; a 2-layer slice of it, the collective is the same), the gathered rank report -- on whatever
+    backend this host has (nccl with GPUs, gloo without).  tests/test_host.py runs `python bench.py --gpus 2 --plumbing-only` here."""
+    import torch.distributed as dist
+    from chattts_amd import dist as D
+    has_gpu = torch.cuda.is_available() and torch.cuda.device_count() > local_rank
+    dev = torch.device("cuda", local_rank) if has_gpu else torch.device("cpu")
+    if world > 1 or "RANK" in os.environ:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if has_gpu:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
+    else:
+        dist = None
+    wl = shard_workload(args.batch, world, rank, args.min_len, args.max_len)
+    fp = None
+    if dist is not None:
+        sds = {"gpt": W.synthetic_gpt(n_layers=2), "embed": W.synthetic_embed()} if rank == 0 else None
+        meta_all = D.weights_meta(2)
+        got = D.broadcast_state_dicts(sds, src=0, device=dev, meta={k: meta_all[k] for k in ("gpt", "embed")})
+        fp = hashlib.sha256(b"".join(got[n][k].cpu().numpy().tobytes() for n in sorted(got) for k in sorted(got[n]))).hexdigest()
+        rows = [None] * world
+        dist.all_gather_object(rows, {"rank": rank, "rows": [int(wl["lo"]), int(wl["hi"])], "weights_sha256": fp, "device": str(dev)})
+        dist.barrier()
+    else:
+        rows = [{"rank": 0, "rows": [int(wl["lo"]), int(wl["hi"])], "weights_sha256": None, "device": str(dev)}]
+    if rank == 0:
+        print(json.dumps({"plumbing_only": True, "metric": None, "value": None, "n_gpus": world, "backend": "nccl" if has_gpu else "gloo",
+                          "global_batch": int(wl["Bg"]), "ranks": {"world": world, "shards": rows,
+                                                                  "weights_equal_on_all_ranks": len({r["weights_sha256"] for r in rows}) == 1,
+                                                                  "rows_cover_global_batch": rows[0]["rows"][0] == 0 and rows[-1]["rows"][1] == int(wl["Bg"])
+                                                                  and all(a["rows"][1] == b["rows"][0] for a, b in zip(rows, rows[1:]))},
+                          "note": "no engine, no timing: rendezvous + sharding + the one weight broadcast only"}), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -308,10 +426,14 @@ def main():
     ap.add_argument("--no-ttfs", action="store_true")
     ap.add_argument("--no-parity-mode", action="store_true")
     ap.add_argument("--no-bf16-parity", action="store_true")
-    ap.add_argument("--capi-broadcast-check", action="store_true", help="N > 1: also run the weight broadcast's C-ABI entry (ctts_broadcast_weights on a "
-                    "communicator made through the C ABI) on a probe buffer and compare with torch.distributed's result; off by default at N > 1 "
-                    "(a second RCCL bootstrap that no multi-GPU box has exercised yet must not be able to stall the scaling run), always on under "
-                    "torchrun with one rank")
+    ap.add_argument("--no-capi-broadcast-check", action="store_true", help="skip the check of the weight broadcast's C-ABI entry (ctts_broadcast_weights on "
+                    "a communicator made through the C ABI: a probe buffer, compared with what torch.distributed delivered).  By default it runs at "
+                    "every N as a BOUNDED attempt (worker thread, --capi-broadcast-timeout seconds): a second RCCL bootstrap may fail or time out, "
+                    "it cannot stall the scaling run")
+    ap.add_argument("--capi-broadcast-timeout", type=float, default=45.0)
+    ap.add_argument("--plumbing-only", action="store_true", help="rendezvous + sharding + the ONE weight broadcast + the rank report, no engine and no "
+                    "timing (gloo on a host without GPUs: what tests/test_host.py runs through this very entry at --gpus 2); prints a line marked "
+                    "\"plumbing_only\": true that no driver can mistake for a measurement")
     ap.add_argument("--no-ids-check", action="store_true", help="skip the two extra passes that compare graph replay with eager launches (profiler runs)")
     ap.add_argument("--no-configs", action="store_true", help="skip the BASELINE.json configs[0] / [1] / [4] legs (C1, C2, C5)")
     ap.add_argument("--pipeline", action="store_true", help="time the main leg as a software-pipelined queue of batches (batch i's acoustic decode "
@@ -330,13 +452,25 @@ def main():
         print("CPU_BASELINE_JSON " + json.dumps(cpu_baseline(W.synthetic_all(), wl["ids"], wl["mask"], wl["tmask"], wl["stop_all"])), flush=True)
         return
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: spawn the N ranks ourselves (one process per GPU under torch.distributed.run,
+        # rendezvous on 127.0.0.1) and relay rank 0's one JSON line -- never time ONE GPU and call it N
+        sys.exit(spawn_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a {world}-rank run as n_gpus={args.gpus}")
     # no host-side pool wider than this rank's share of the CPU quota (the quota is the container's, shared by all ranks)
     torch.set_num_threads(max(1, min(torch.get_num_threads(), host_cpu_quota() // max(1, world))))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.plumbing_only:
+        return plumbing_only(args, world, rank, local_rank)
+    n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if n_dev < max(1, args.gpus if "LOCAL_RANK" in os.environ else 1) or local_rank >= n_dev:
+        raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank} of {args.gpus} but this host shows {n_dev} HIP device(s): the hot path has no "
+                         "CPU fallback (the CPU leg is the oracle's, `cpu_baseline`)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -368,23 +502,10 @@ def main():
                          "first use of the communicator, so ring set-up is inside the figure"}
         # the same collective through the library's own C ABI (ctts_broadcast_weights on an RCCL communicator made from the C ABI, what a
         # host without torch would call): one flat buffer, checked against what torch.distributed delivered; never fatal for the bench
-        try:
-            if world > 1 and not args.capi_broadcast_check:
-                raise RuntimeError("skipped at N > 1 (pass --capi-broadcast-check)")
-            comm = D.CapiComm(world, rank)
-            probe = next(iter(sds["embed"].values())).reshape(-1)[: 1 << 20].clone().contiguous()
-            want = probe.clone()
-            if rank != 0:
-                probe.zero_()
-            torch.cuda.synchronize(dev)
-            t1 = time.perf_counter()
-            comm.broadcast([probe], root=0)
-            torch.cuda.synchronize(dev)
-            bcast["capi_broadcast"] = {"ok": bool(torch.equal(probe, want)), "bytes": int(probe.numel() * probe.element_size()),
-                                       "ms": round(1e3 * (time.perf_counter() - t1), 3), "entry": "ctts_broadcast_weights (include/chattts_amd.h)"}
-            comm.close()
-        except Exception as exc:   # noqa: BLE001
-            bcast["capi_broadcast"] = {"ok": False, "error": repr(exc)[:200]}
+        if args.no_capi_broadcast_check:
+            bcast["capi_broadcast"] = {"ok": None, "skipped": "--no-capi-broadcast-check"}
+        else:
+            bcast["capi_broadcast"] = capi_broadcast_check(D, sds, world, rank, dev, dist, args.capi_broadcast_timeout)
         sds = {n: {k: v.cpu() for k, v in sd.items()} for n, sd in sds.items()}  # the engines repack from host tensors
     else:
         sds = W.synthetic_all()

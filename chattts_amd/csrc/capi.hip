@@ -900,6 +900,21 @@ extern "C" int ctts_k_attention_dec(const float* qkv, const uint16_t* kcache, co
   CK(launch_attention(qkv, kcache, vcache, WT_BF16, cmax, out_packed, 2, rm, M, (hipStream_t)stream));
   return 0;
 }
+// decode attention of either mode on fragment-packed output, straight to launch_attention (kv_dtype CTTS_BF16: bf16 cache, packed bf16 output;
+// CTTS_F32: f32 cache, packed f32 output); `covers_all`: descriptors are valid for all M rows (absent rows carry b = -1) and n_active is not read
+extern "C" int ctts_k_attention_dec2(const float* qkv, const void* kcache, const void* vcache, int32_t kv_dtype, int32_t cmax, void* out_packed,
+                                     const int32_t* desc, const int32_t* n_active, int32_t covers_all, int32_t M, void* stream) {
+  if (!desc || M <= 0) return fail("ctts_k_attention_dec2: bad arguments");
+  GptRowMap rm{1, nullptr, nullptr, nullptr, n_active, nullptr, reinterpret_cast<const RowDesc*>(desc), nullptr, nullptr, 0, 0, covers_all};
+  CK(launch_attention(qkv, kcache, vcache, kv_dtype == CTTS_BF16 ? WT_BF16 : WT_F32, cmax, out_packed, kv_dtype == CTTS_BF16 ? 2 : 3, rm, M,
+                      (hipStream_t)stream));
+  return 0;
+}
+extern "C" int ctts_k_attention_cfg(int32_t persist, int32_t workgroups, int32_t ring) {
+  if (ring > 0 && ring != 2 && ring != 3 && ring != 4) return fail("ctts_k_attention_cfg: ring depth must be 2, 3 or 4");
+  attention_persist_override(persist, workgroups, ring);
+  return 0;
+}
 extern "C" int ctts_k_attention_oproj(const float* qkv, const uint16_t* kcache, const uint16_t* vcache, int32_t cmax, const uint16_t* wo_hd,
                                       const int32_t* desc, const int32_t* n_active, int32_t M, float* part, int32_t* cnt, float* x32,
                                       uint16_t* xp, float* ssq, void* stream) {

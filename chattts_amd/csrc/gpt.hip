@@ -275,6 +275,45 @@ template <typename OT> __device__ __forceinline__ void store_out(OT* p, float v)
 template <> __device__ __forceinline__ void store_out<float>(float* p, float v) { *p = v; }
 template <> __device__ __forceinline__ void store_out<bf16_t>(bf16_t* p, float v) { *p = f32_to_bf16(v); }
 
+// Lane-group reductions of the attention kernels without the LDS crossbar (round 5).  `__shfl_xor` lowers to ds_bpermute_b32 -- an LDS
+// round trip per step, 15 of them in a dependent chain per 32-key block, which a persistent workgroup with ONE wave per SIMD cannot
+// hide.  The DPP forms are plain VALU operands.  Bit-identical to the xor butterfly: the partner of step o = 1, 2 is the same lane
+// (quad_perm); for o = 4 (and 8) all lanes of a quad (half row) already hold the same value, so the mirrored lane's value IS lane ^ o's;
+// IEEE addition commutes.
+#ifndef CTTS_ATT_DPP
+#define CTTS_ATT_DPP 1   // A/B builds: python -m chattts_amd.build --variant nodpp -DCTTS_ATT_DPP=0
+#endif
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+template <int LPK>
+__device__ __forceinline__ float group_sum(float d) {   // sum over the LPK (8 | 16) lanes that share a key, every lane gets it
+#if CTTS_ATT_DPP
+  d += dpp_f<0xB1>(d);    // quad_perm [1,0,3,2] = lane ^ 1
+  d += dpp_f<0x4E>(d);    // quad_perm [2,3,0,1] = lane ^ 2
+  d += dpp_f<0x141>(d);   // row_half_mirror: the other quad of the 8 lanes
+  if (LPK == 16) d += dpp_f<0x140>(d);   // row_mirror: the other half of the row
+#else
+#pragma unroll
+  for (int o = 1; o < LPK; o <<= 1) d += __shfl_xor(d, o, 64);
+#endif
+  return d;
+}
+template <int LPK>
+__device__ __forceinline__ float groups_max(float v) {  // max over the key groups of the wave (v is uniform within a group); exact in any order
+#if CTTS_ATT_DPP
+  if (LPK == 8) v = fmaxf(v, dpp_f<0x140>(v));                                                              // row_mirror: the row's other group
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x142, 0xa, 0xf, false)));  // row_bcast15 -> rows 1, 3
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x143, 0xc, 0xf, false)));  // row_bcast31 -> rows 2, 3
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+#else
+#pragma unroll
+  for (int o = LPK; o < 64; o <<= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+#endif
+}
+
 // SPLIT (decode, perf mode): "remainder splitting".  A (utterance, head) unit streams ctx * 256 bytes of KV and a CU ingests
 // only ~25 GB/s of that, so the kernel lasts as long as the CU with the most units: U = 12 * n_active units on C CUs cost
 // ceil(U / C) units of time although the average CU holds U / C (540 units on 256 CUs: 3 instead of 2.1; below 256 units whole
@@ -438,14 +477,12 @@ __device__ __forceinline__ void attention_body(const float* __restrict__ qkv, co
       unpack16<KT, DPL>(kr[i], kf);
 #pragma unroll
       for (int e = 0; e < DPL; ++e) d = fmaf(q[e], kf[e], d);
-#pragma unroll
-      for (int o = 1; o < LPK; o <<= 1) d += __shfl_xor(d, o, 64);
+      d = group_sum<LPK>(d);
       d *= 0.125f;   // 1/sqrt(64), exact
       s[i] = ok[i] ? d : -INFINITY;
       bmax = fmaxf(bmax, s[i]);
     }
-#pragma unroll
-    for (int o = LPK; o < 64; o <<= 1) bmax = fmaxf(bmax, __shfl_xor(bmax, o, 64));
+    bmax = groups_max<LPK>(bmax);
     // bmax is finite: key j0 (i = 0, kg = 0) is always < jend for a block that is consumed
     const float mnew = fmaxf(mrun, bmax);
     const float alpha = expf(mrun - mnew);  // exp(-inf) = 0 on the first block
@@ -731,6 +768,211 @@ __global__ __launch_bounds__(64 * NW + (PF ? 64 : 0)) void attention_k(const flo
 }
 
 // ------------------------------------------------------------------------------------------------
+// Persistent decode attention (round 5; both modes, packed output).  attention_k launches one workgroup per (utterance, head)
+// unit of the captured batch -- 768 workgroups at batch 64 whether 64 or 6 utterances are still alive -- and a launch of 768
+// workgroups costs ~3 us more than one of 256 on this part before any byte moves (profiles/r4a_overlap_probe.log E rows;
+// attention_k's MINIMUM over a C3 run is 5.9 us).  Here the grid is G <= 256 workgroups of 4 waves -- one per CU -- and workgroup w
+// walks the units w, 2G-1-w, 2G+w, ... ("snake": the rows are ordered by descending context, so a workgroup's long unit of an even
+// round is paired with a short one of the odd round) until the unit index leaves the step's live list (RowDesc.b < 0, or
+// 12 * *n_active).  A unit is computed EXACTLY as attention_k<KT, 4> computes it -- the same split of the visible keys over the 4 waves, the
+// same 32-key (f32: 16-key) blocks in the same order, the same online softmax, the same LDS merge -- so the result is the same bit
+// for bit in both modes; what changes is how the bytes are kept in flight.  One workgroup per CU has only 4 waves to cover the HBM
+// round trip (attention_k had two or three resident workgroups), so every wave runs a RING of D blocks (D - 1 blocks = 8 KB each
+// in flight while one is consumed) over its FLATTENED block sequence: when a unit's last block has been requested the ring goes
+// on with the first blocks of the workgroup's next unit (its descriptor was fetched a unit ahead, its q row rides behind the
+// current unit's blocks), so the merge, the barrier and the store of a unit overlap the next unit's first round trip.
+// The ring is branch-free on the load side: every iteration issues 8 loads; a slot with nothing left to fetch re-reads the
+// last key (L1 hit) and is skipped on the consuming side behind a register touch (hipcc's vmcnt bookkeeping stays exact that way).
+// Reference op: softmax(q K^T / 8 + mask) V of HF Llama attention, examples/onnx/modeling_llama.py:455-475.
+// ------------------------------------------------------------------------------------------------
+template <typename KT, typename OT, int D>
+__global__ __launch_bounds__(256) void attention_persist_k(const float* __restrict__ qkv, const KT* __restrict__ kc, const KT* __restrict__ vc,
+                                                           int cmax, OT* __restrict__ out, const RowDesc* __restrict__ desc, int n_units,
+                                                           const int32_t* __restrict__ n_active) {
+  CTTS_PROBE_RETURN();
+  constexpr int NW = 4;
+  constexpr int DPL = KTraits<KT>::DPL;
+  constexpr int LPK = HDIM / DPL, KPI = 64 / LPK, NI = 4, KB = KPI * NI;
+  __shared__ float sm_m[2][NW], sm_l[2][NW], sm_acc[2][NW][HDIM];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kg = lane / LPK, dl = lane % LPK;
+  const int G = gridDim.x, w = blockIdx.x;
+  if (n_active != nullptr) n_units = min(n_units, *n_active * NHEAD);   // host-compacted batches: descriptors beyond the live count are stale
+  const int n_rounds = (n_units + G - 1) / G;
+  if (n_rounds == 0) return;
+  auto unit_of = [&](int r) { return (r & 1) ? (r + 1) * G - 1 - w : r * G + w; };
+  auto desc_of = [&](int r) { return desc[min(unit_of(r), n_units - 1) / NHEAD]; };
+
+  // ---- issue side: the unit whose blocks are being requested --------------------------------------------------------
+  int ir = -1, im = 0, ih = 0, ij = 0, ijbeg = 0, ijend = 0, ijlast = 0;
+  bool iv = false;
+  const KT* ikb = kc + dl * DPL;
+  const KT* ivb = vc + dl * DPL;
+  RowDesc dpre = desc_of(0);
+  float qn[DPL];
+#pragma unroll
+  for (int e = 0; e < DPL; ++e) qn[e] = 0.f;
+  auto load_qn = [&]() {
+    constexpr int NV = DPL / 4;
+    const float* qp = qkv + (size_t)im * (3 * HID) + ih * HDIM + dl * DPL;
+    float4 qv[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) qv[i] = reinterpret_cast<const float4*>(qp)[i];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { qn[4 * i] = qv[i].x; qn[4 * i + 1] = qv[i].y; qn[4 * i + 2] = qv[i].z; qn[4 * i + 3] = qv[i].w; }
+  };
+  auto advance_issue = [&](bool with_q) {
+    ++ir;
+    const RowDesc d = dpre;
+    const int u = unit_of(ir);
+    if (ir + 1 < n_rounds) dpre = desc_of(ir + 1);
+    iv = u < n_units && d.b >= 0;
+    ijbeg = ijend = ij = 0;
+    if (iv) {
+      im = u / NHEAD;
+      ih = u - im * NHEAD;
+      const int rbeg = d.jlo, rend = d.slot + 1;
+      const int nkeys = max(rend - rbeg, 0);
+      const int per = ((nkeys + NW - 1) / NW + KPI - 1) / KPI * KPI;
+      ijbeg = rbeg + wave * per;
+      ijend = max(min(ijbeg + per, rend), ijbeg);
+      ij = ijbeg;
+      ijlast = max(min(ijbeg + per, rend) - 1, d.jlo);
+      const size_t base = ((size_t)d.b * NHEAD + ih) * cmax * HDIM + dl * DPL;
+      ikb = kc + base;
+      ivb = vc + base;
+      if (with_q) load_qn();
+    }
+  };
+
+  // ---- consuming side ------------------------------------------------------------------------------------------------
+  int cr = -1, cm = 0, ch = 0, cj = 0, cjend = 0, par = 0, nfin = 0;
+  bool cv = false;
+  float q[DPL], acc[DPL], mrun = -INFINITY, lrun = 0.f;
+#pragma unroll
+  for (int e = 0; e < DPL; ++e) { acc[e] = 0.f; q[e] = 0.f; }
+
+  u128 kR[D][NI], vR[D][NI];
+  int sj[D];
+  auto issue = [&](const int s) {
+    if (ij >= ijend && ir == cr && ir + 1 < n_rounds) advance_issue(true);
+    const bool okb = ij < ijend;
+    sj[s] = okb ? ij : -1;
+    const int j0 = ij;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) kR[s][i] = load16_nt(ikb + (size_t)min(j0 + i * KPI + kg, ijlast) * HDIM);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) vR[s][i] = load16_nt(ivb + (size_t)min(j0 + i * KPI + kg, ijlast) * HDIM);
+    if (okb) ij += KB;
+  };
+  auto use_blk = [&](const u128* kr, const u128* vr, const int j0) {   // attention_body's use_blk_e, operation for operation
+    float s[NI];
+    bool ok[NI];
+    float bmax = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      ok[i] = (j0 + i * KPI + kg) < cjend;
+      float kf[DPL];
+      float d = 0.f;
+      unpack16<KT, DPL>(kr[i], kf);
+#pragma unroll
+      for (int e = 0; e < DPL; ++e) d = fmaf(q[e], kf[e], d);
+      d = group_sum<LPK>(d);
+      d *= 0.125f;
+      s[i] = ok[i] ? d : -INFINITY;
+      bmax = fmaxf(bmax, s[i]);
+    }
+    bmax = groups_max<LPK>(bmax);
+    const float mnew = fmaxf(mrun, bmax);
+    const float alpha = expf(mrun - mnew);
+    lrun *= alpha;
+#pragma unroll
+    for (int e = 0; e < DPL; ++e) acc[e] *= alpha;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const float p = expf(s[i] - mnew);
+      lrun += p;
+      float vf[DPL];
+      unpack16<KT, DPL>(vr[i], vf);
+#pragma unroll
+      for (int e = 0; e < DPL; ++e) acc[e] = fmaf(p, vf[e], acc[e]);
+    }
+    mrun = mnew;
+  };
+  auto finish_unit = [&]() {   // attention_body's merge: key groups by shuffles, waves through LDS (double-buffered by unit parity)
+#pragma unroll
+    for (int o = LPK; o < 64; o <<= 1) {
+      lrun += __shfl_xor(lrun, o, 64);
+#pragma unroll
+      for (int e = 0; e < DPL; ++e) acc[e] += __shfl_xor(acc[e], o, 64);
+    }
+    if (kg == 0) {
+      if (dl == 0) { sm_m[par][wave] = mrun; sm_l[par][wave] = lrun; }
+#pragma unroll
+      for (int e = 0; e < DPL; ++e) sm_acc[par][wave][dl * DPL + e] = acc[e];
+    }
+    __syncthreads();
+    if (wave == (nfin & (NW - 1))) {   // the merging wave rotates; lane = output column
+      float M = -INFINITY;
+#pragma unroll
+      for (int x = 0; x < NW; ++x) M = fmaxf(M, sm_m[par][x]);
+      float L = 0.f, o = 0.f;
+#pragma unroll
+      for (int x = 0; x < NW; ++x) {
+        const float sc = (sm_m[par][x] == -INFINITY) ? 0.f : expf(sm_m[par][x] - M);
+        L += sm_l[par][x] * sc;
+        o += sm_acc[par][x][lane] * sc;
+      }
+      store_out<OT>(out + pko_off<OT>(cm, ch * HDIM + lane), o / L);
+    }
+    mrun = -INFINITY; lrun = 0.f;
+#pragma unroll
+    for (int e = 0; e < DPL; ++e) acc[e] = 0.f;
+    par ^= 1;
+    ++nfin;
+  };
+  auto switch_consume = [&]() -> bool {
+    if (cr + 1 >= n_rounds) return false;
+    if (ir == cr) advance_issue(true);
+    ++cr;
+    cv = iv; cm = im; ch = ih; cj = ijbeg; cjend = ijend;
+#pragma unroll
+    for (int e = 0; e < DPL; ++e) q[e] = qn[e];
+    return true;
+  };
+
+  // prologue: round 0's first block, THEN its q (an L2 miss in front of the KV stream costs more than one behind it), then the
+  // rest of the ring
+  advance_issue(false);
+  issue(0);
+  if (iv) load_qn();
+#pragma unroll
+  for (int s = 1; s < D - 1; ++s) issue(s);
+  // No `break` out of the unrolled ring: hipcc routes every such exit through the loop latch, and its vmcnt bookkeeping then drains
+  // the ring at the head of every D-th block.  A workgroup that has run out of units finishes the current turn of the ring on empty
+  // slots instead (<= D - 1 re-reads of its last key).
+  bool live = switch_consume();
+  while (live && cj >= cjend) { if (cv) finish_unit(); live = switch_consume(); }
+  while (live) {
+#pragma unroll
+    for (int p = 0; p < D; ++p) {
+      issue((p + D - 1) % D);
+      __builtin_amdgcn_sched_barrier(0);   // keep the 8 requests ahead of the consumer (hipcc sinks them otherwise)
+      if (sj[p] >= 0) {
+        use_blk(kR[p], vR[p], sj[p]);
+        cj += KB;
+      } else {
+        // an empty slot: nothing to compute, but its (last) load must count as waited-for on this path too -- otherwise hipcc drains the
+        // whole ring before it reuses the slot's registers
+        asm volatile("" ::"v"(vR[p][NI - 1].w));
+      }
+      while (live && cj >= cjend) { if (cv) finish_unit(); live = switch_consume(); }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Fused QKV + attention launch (round 4; decode, perf mode, <= 64 rows).  512-thread workgroups: [0, 144) are the QKV tiles of
 // decode_dev.hpp (RMSNorm scale + q/k/v_proj + RoPE + KV append, all rows each, 8 waves splitting K), workgroups 144 + 6 m + p hold the
 // attention units (utterance m, heads 2p and 2p + 1), 4 waves each -- 144 + 6 * 64 = 528 workgroups of <= 128 VGPRs: (almost) all
@@ -896,6 +1138,28 @@ __global__ __launch_bounds__(256) void attention_prefill_mfma_k(const float* __r
   }
 }
 
+// persistent decode attention: [0] on / off, [1] workgroups, [2] ring depth -- environment at first use, ctts_k_attention_cfg afterwards
+static int att_cfg_[3] = {-1, 0, 4};
+static int att_persist_cfg(int i) {
+  if (att_cfg_[0] < 0) {
+    const char* e = getenv("CTTS_ATT_PERSIST"); att_cfg_[0] = e ? (atoi(e) != 0) : 1;
+    const char* eg = getenv("CTTS_ATT_G"); if (eg) att_cfg_[1] = atoi(eg);
+    const char* ed = getenv("CTTS_ATT_D"); if (ed) att_cfg_[2] = atoi(ed);
+    if (att_cfg_[1] <= 0) {
+      int dev = 0, cus = 256;
+      if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+      att_cfg_[1] = cus > 0 ? cus : 256;
+    }
+  }
+  return att_cfg_[i];
+}
+void attention_persist_override(int persist, int g, int d) {
+  (void)att_persist_cfg(0);
+  if (persist >= 0) att_cfg_[0] = persist != 0;
+  if (g > 0) att_cfg_[1] = g;
+  if (d > 0) att_cfg_[2] = d;
+}
+
 hipError_t launch_attention(const float* qkv, const void* kcache, const void* vcache, int kv_wt, int cmax, void* out, int out_bf16,
                             GptRowMap rm, int M, hipStream_t st) {
   dim3 grid(NHEAD, M);
@@ -925,6 +1189,25 @@ hipError_t launch_attention(const float* qkv, const void* kcache, const void* vc
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_k<bf16_t, 4, bf16_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, att_lds);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_k<float, 4, float, true>), hipFuncAttributeMaxDynamicSharedMemorySize, att_lds);
     }
+  }
+  // round 5: persistent grid (attention_persist_k) for the decode step of both modes.  CTTS_ATT_PERSIST=0: one workgroup per unit
+  // (attention_k); CTTS_ATT_G=<workgroups> (default: the device's CU count), CTTS_ATT_D=2|3|4 KV blocks per wave ring (default 4);
+  // ctts_k_attention_cfg overrides all three (tests, probes)
+  const int persist = att_persist_cfg(0), att_g = att_persist_cfg(1), att_d = att_persist_cfg(2);
+  if (persist && decode && rm.desc != nullptr && (out_bf16 == 2 || out_bf16 == 3) && rm.dbg == nullptr &&
+      !(out_bf16 == 2 && rm.sp_cus > 0 && rm.sp_part != nullptr && rm.sp_cnt != nullptr)) {
+    if ((out_bf16 == 2) != (kv_wt == WT_BF16)) return hipErrorInvalidValue;
+    const int n_units = NHEAD * M;
+    const dim3 pg(min(att_g, n_units));
+    const int32_t* nact = rm.desc_covers_all ? nullptr : rm.n_active;
+#define ATTP(KT, D) CTTS_LAUNCH((attention_persist_k<KT, KT, D>), pg, dim3(256), st, qkv, (const KT*)kcache, (const KT*)vcache, cmax, (KT*)out, rm.desc, n_units, nact)
+    if (out_bf16 == 2) {
+      if (att_d == 2) ATTP(bf16_t, 2); else if (att_d == 3) ATTP(bf16_t, 3); else ATTP(bf16_t, 4);
+    } else {
+      if (att_d == 2) ATTP(float, 2); else if (att_d == 3) ATTP(float, 3); else ATTP(float, 4);
+    }
+#undef ATTP
+    return hipGetLastError();
   }
   if (out_bf16 == 2) {   // decode, perf mode: bf16 output in the fragment-packed order the o_proj kernel of decode.hip reads
     if (!decode || kv_wt != WT_BF16) return hipErrorInvalidValue;

@@ -362,6 +362,16 @@ int ctts_k_attention_prefill(const float* qkv, const uint16_t* kcache, const uin
  * remainder splitting of the (utterance, head) units over workgroups (csrc/gpt.hip attention_k); n_cu = 0: one workgroup per unit. */
 int ctts_k_attention_dec(const float* qkv, const uint16_t* kcache, const uint16_t* vcache, int32_t cmax, uint16_t* out_packed,
                          const int32_t* desc, const int32_t* n_active, int32_t M, float* part, int32_t* cnt, int32_t n_cu, void* stream);
+/* Decode attention of EITHER mode the way the decode step launches it (round 5): kv_dtype CTTS_BF16 = bf16 cache, bf16 output in the
+ * fragment-packed order of csrc/decode.hip; CTTS_F32 = f32 cache, f32 output in the packed order of csrc/decode32.hip.  covers_all != 0:
+ * desc is valid for all M rows (absent rows carry slot -1) and n_active is not read.  Runs the persistent grid (csrc/gpt.hip
+ * attention_persist_k: <= one workgroup per CU walking the live (utterance, head) units) unless ctts_k_attention_cfg / CTTS_ATT_PERSIST=0
+ * selected one workgroup per unit (attention_k); both give the same bits.  Reference op: examples/onnx/modeling_llama.py:455-475. */
+int ctts_k_attention_dec2(const float* qkv, const void* kcache, const void* vcache, int32_t kv_dtype, int32_t cmax, void* out_packed,
+                          const int32_t* desc, const int32_t* n_active, int32_t covers_all, int32_t M, void* stream);
+/* tests / probes: decode attention launch shape of this process -- persist 0 | 1 (< 0: keep), workgroups of the persistent grid (<= 0:
+ * keep; default = the device's CU count), KV blocks per wave ring 2 | 3 | 4 (<= 0: keep; default 4).  Never changes a result bit. */
+int ctts_k_attention_cfg(int32_t persist, int32_t workgroups, int32_t ring);
 /* The same attention with o_proj + residual folded in (ctts_gpt_weights.wo_hd): wo_hd [12][8][768][8] bf16; part [ceil16(M)][12][768]
  * f32 scratch; cnt [M] int32, zero (left zero); x32 [M][768] f32 residual, updated in place; xp its bf16 copy in the fragment-packed
  * order; ssq [M][48] partial sums of squares of the new residual. */

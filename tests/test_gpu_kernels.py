@@ -664,6 +664,78 @@ def test_attention_decode_remainder_split(G, n_live):
         assert (split[:n_live] != whole[:n_live]).mean() < 0.02
 
 
+@pytest.mark.parametrize("mode", ["bf16", "f32"])
+@pytest.mark.parametrize("n_live", [1, 5, 22, 43, 64])
+def test_attention_decode_persistent_grid(G, mode, n_live):
+    """round 5: the decode step's attention on a persistent grid (attention_persist_k: G workgroups walk the live (utterance, head)
+    units in snake order, a ring of 2 / 3 / 4 KV blocks per wave that runs on into the workgroup's next unit) against the float64
+    softmax(q K^T / 8 + mask) V reference (examples/onnx/modeling_llama.py:455-475), and BIT-IDENTICAL to one workgroup per unit
+    (attention_k) for every grid size and ring depth -- descriptors that cover all rows (absent rows b = -1, as the decode step writes
+    them), a host-compacted batch (n_active bounds the list, stale descriptors behind it), a finished row in the middle of the list,
+    contexts of 1 key, rows that must stay untouched."""
+    from chattts_amd.engine import unpack_frag, unpack_frag32
+    lib = _lib.lib()
+    rs = np.random.RandomState(500 + n_live + (7 if mode == "f32" else 0))
+    B, nh, d, H, cmax, Bp = 64, 12, 64, 768, 560, 64
+    bf = mode == "bf16"
+    kv_t = torch.bfloat16 if bf else torch.float32
+    Kc = rs.standard_normal((B, nh, cmax, d)).astype(f32)
+    Vc = rs.standard_normal((B, nh, cmax, d)).astype(f32)
+    if bf:
+        Kc, Vc = G.bf16_round(Kc), G.bf16_round(Vc)
+    kc, vc = G.dev(Kc, kv_t), G.dev(Vc, kv_t)
+    unpack = unpack_frag if bf else unpack_frag32
+    try:
+        for rep, covers_all in enumerate((1, 0, 1)):
+            slots_b = rs.permutation(B)[:n_live]
+            jlo = rs.randint(0, 30, size=n_live)
+            slot = np.array([rs.randint(jlo[m] + 1, cmax) if rs.rand() < 0.8 else jlo[m] + rs.randint(0, 12) for m in range(n_live)])
+            order = np.argsort(-(slot - jlo), kind="stable")               # descending context, as the decode step orders its rows
+            slots_b, jlo, slot = slots_b[order], jlo[order], slot[order]
+            desc = np.zeros((Bp, 4), np.int32)
+            desc[:, 0] = -1 if covers_all else rs.randint(0, B, size=Bp)    # host-compacted: stale but plausible rows behind n_active
+            desc[:, 1] = rs.randint(0, cmax, size=Bp)
+            desc[:n_live, 0], desc[:n_live, 1], desc[:n_live, 2], desc[:n_live, 3] = slots_b, slot, slot - jlo, jlo
+            dead = -1
+            if rep == 2 and n_live >= 5:                                    # a row that finished since the last compaction
+                dead = n_live // 2
+                desc[dead, 0] = -1
+            qkv = rs.standard_normal((Bp, 3 * H)).astype(f32)
+            q_d, desc_d = G.dev(qkv), G.dev(desc)
+            na = G.dev(np.array([n_live], np.int32))
+
+            def run(persist, g, ring):
+                _lib.check(lib.ctts_k_attention_cfg(persist, g, ring), "attention_cfg")
+                o = torch.full((Bp * H,), float("nan"), dtype=kv_t, device=G.DEV)
+                _lib.check(lib.ctts_k_attention_dec2(q_d.data_ptr(), kc.data_ptr(), vc.data_ptr(), _lib.BF16 if bf else _lib.F32, cmax,
+                                                     o.data_ptr(), desc_d.data_ptr(), None if covers_all else na.data_ptr(), covers_all,
+                                                     Bp, None), "attention_dec2")
+                torch.cuda.synchronize()
+                return unpack(o.float().cpu(), Bp, H).numpy()
+
+            unit = run(0, 0, 0)
+            live = [m for m in range(n_live) if m != dead]
+            ref = np.zeros((Bp, H))
+            for m in live:
+                b = slots_b[m]
+                q = qkv[m, :H].reshape(nh, d).astype(np.float64)
+                Kb, Vb = Kc[b, :, jlo[m]: slot[m] + 1].astype(np.float64), Vc[b, :, jlo[m]: slot[m] + 1].astype(np.float64)
+                sc = np.einsum("hd,hjd->hj", q, Kb) * 0.125
+                pr = np.exp(sc - sc.max(-1, keepdims=True))
+                pr /= pr.sum(-1, keepdims=True)
+                ref[m] = np.einsum("hj,hjd->hd", pr, Vb).reshape(H)
+            untouched = [m for m in range(Bp) if m not in live]
+            assert np.isfinite(unit[live]).all() and np.isnan(unit[untouched]).all()
+            assert np.abs(unit[live] - ref[live]).max() < (1.5e-2 if bf else 2e-5)
+            for g, ring in ((256, 4), (256, 2), (256, 3), (7, 4), (100, 3), (1, 2), (768, 4), (331, 4)):
+                got = run(1, g, ring)
+                assert np.isnan(got[untouched]).all(), (g, ring)
+                assert np.array_equal(got[live], unit[live]), (g, ring, np.abs(got[live] - unit[live]).max())
+    finally:
+        ncu = torch.cuda.get_device_properties(0).multi_processor_count
+        _lib.check(lib.ctts_k_attention_cfg(1, ncu, 4), "attention_cfg")     # back to the shipped default
+
+
 @pytest.mark.parametrize("n_live", [1, 5, 16, 17, 45, 64])
 def test_attention_oproj_fused(G, n_live):
     """decode attention of the perf mode with o_proj + residual folded into the launch (attention_k<OPJ>, ctts_gpt_weights.wo_hd): every

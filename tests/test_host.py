@@ -377,6 +377,50 @@ def test_two_rank_bench_sharding_path_equals_the_unsharded_batch():
         assert np.array_equal(a, b)
 
 
+def _run_bench(*argv, env_drop=("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")):
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in env_drop}
+    env["HIP_VISIBLE_DEVICES"] = ""        # this test is about the launcher: no GPU, whatever the box has
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py"), *argv], env=env, capture_output=True, text=True, timeout=600)
+
+
+def test_bench_gpus_2_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher in the command: the entry spawns two ranks itself; with
+    --plumbing-only they rendezvous on gloo here, shard the 128-utterance global batch in contiguous blocks and end up with the same
+    broadcast weights -- `ranks.world == 2` on the one line rank 0 prints."""
+    import json
+    r = _run_bench("--gpus", "2", "--plumbing-only")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["plumbing_only"] is True and j["value"] is None            # cannot be mistaken for a measurement
+    assert j["n_gpus"] == 2 and j["ranks"]["world"] == 2 and j["global_batch"] == 128
+    assert [s["rows"] for s in j["ranks"]["shards"]] == [[0, 64], [64, 128]]
+    assert j["ranks"]["weights_equal_on_all_ranks"] and j["ranks"]["rows_cover_global_batch"]
+
+
+def test_bench_gpus_2_without_gpus_fails_loudly_about_the_gpu():
+    """... and the real thing on a box without GPUs: both spawned ranks say which GPU they miss, the launcher exits non-zero and NO
+    result line is printed -- never a 1-rank number labelled n_gpus = 2."""
+    r = _run_bench("--gpus", "2", "--steps", "1", "--warmup", "0")
+    assert r.returncode != 0
+    assert not any(ln.startswith("{") for ln in r.stdout.splitlines()), r.stdout
+    assert "needs GPU 1 of 2" in r.stderr and "needs GPU 0 of 2" in r.stderr and "no CPU fallback" in r.stderr
+    assert "NO result line is printed for --gpus 2" in r.stderr
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "refusing to report a 1-rank run as n_gpus=8" in r.stderr
+
+
 def test_pmc_summary_maps_the_profiled_kernel_names():
     """tools/pmc_summary.py maps rocprofv3 kernel names to bench.py's tags by substring; the committed kernel-stat CSV of the
     round must still resolve to every tag bench.py's roofline leg can ask for (catches template-argument drift)."""
