@@ -101,6 +101,7 @@ SIGNATURES = {
     "ctts_codec_destroy": (None, [P]),
     "ctts_codec_workspace_bytes": (SZ, [I32, I32]),
     "ctts_copy_bytes": (C.c_int, [P, P, SZ, P]),
+    "ctts_float_to_int16": (C.c_int, [P, P, P, I32, C.c_int64, C.c_int64, I32, I32, F, P, P]),
     "ctts_dvae_decode": (C.c_int, [P, P, P, I32, I32, P, SZ, P]),
     "ctts_vocos_decode": (C.c_int, [P, P, P, I32, I32, P, SZ, P]),
     "ctts_dvae_create": (C.c_int, [PP, C.POINTER(DvaeWeights)]),

@@ -959,6 +959,13 @@ extern "C" int ctts_k_device_guard_probe(void* stream, int32_t* before, int32_t*
   *before = b; *inside = in;
   return 0;
 }
+extern "C" int ctts_float_to_int16(const float* wav, int16_t* pcm, uint8_t* keep_bits, int32_t rows, int64_t n, int64_t ld, int32_t per_row,
+                                   int32_t product, float keep_thr, uint32_t* peak, void* stream) {
+  if (!wav || !pcm || !peak || rows < 0 || n < 0 || ld < n || (product != 0 && product != 1)) return fail("ctts_float_to_int16: bad arguments");
+  CttsDeviceGuard dg(stream);
+  CK(launch_float_to_int16(wav, n, ld, rows, per_row != 0, product, keep_thr, peak, pcm, keep_bits, (hipStream_t)stream));
+  return 0;
+}
 extern "C" int ctts_copy_bytes(void* dst, const void* src, size_t bytes, void* stream) {
   if (!dst || !src || (bytes & 15) || (((uintptr_t)dst | (uintptr_t)src) & 15)) return fail("ctts_copy_bytes: pointers and size must be 16-byte aligned");
   CttsDeviceGuard dg(stream);

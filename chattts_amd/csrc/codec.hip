@@ -290,3 +290,63 @@ hipError_t launch_copy16(const void* src, void* dst, size_t bytes, hipStream_t s
   hipLaunchKernelGGL(copy16_k, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, st, (const u128*)src, (u128*)dst, n16);
   return hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------------
+// float32 waveform -> 16-bit PCM on the device (round 5; SURVEY 8f-3, /root/reference/tools/audio/np.py:7-11 `float_to_int16`):
+//     am = 32767 * 32768 // (int(ceil(max |x|)) * 32768);   out = (x * am).astype(int16)      (truncation toward zero)
+// The peak is taken over the whole [rows, n] array (how examples/cmd/stream.py:44 applies it to a streamed block) or per row (one call
+// per utterance: examples/web/funcs.py:206-209, tools/audio/pcm.py:29).  The product is formed the way the reference's RUNTIME forms it:
+// the function is numba-jitted, and numba types `float32[:] * int64` as float64 -- exact for |am| < 2^15 -- (`product` 0); `product` 1
+// is what plain NumPy >= 2 does with the same source line (python int = weak scalar: a float32 product, rounded BEFORE the truncation).
+// Optionally also writes one bit per sample, |x| > keep_thr: the mask of `wav[np.abs(wav) > 1e-5]` (core.py:262-265), so that the
+// silence strip of Chat.infer can run on the int16 samples -- the waveform then leaves the GPU at 2 bytes + 1 bit per sample, not 4 bytes.
+// An all-zero input gives zeros (the reference divides by zero there).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void absmax_rows_k(const float* __restrict__ x, long long n, long long ld, int per_row, unsigned* __restrict__ peak) {
+  const int row = blockIdx.y;
+  const float* xr = x + (size_t)row * ld;
+  unsigned m = 0;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+    m = max(m, __float_as_uint(xr[i]) & 0x7fffffffu);   // |x| as an unsigned: the IEEE order of non-negative floats
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+  if ((threadIdx.x & 63) == 0 && m != 0) atomicMax(peak + (per_row ? row : 0), m);
+}
+__global__ __launch_bounds__(256) void pcm16_k(const float* __restrict__ x, long long n, long long ld, int per_row, int product,
+                                               const unsigned* __restrict__ peak, float keep_thr, int16_t* __restrict__ out,
+                                               uint8_t* __restrict__ keep) {
+  const int row = blockIdx.y;
+  const float pk = __uint_as_float(peak[per_row ? row : 0]);
+  const long long c = (long long)ceilf(pk);
+  const long long am = c > 0 ? (32767ll * 32768ll) / (c * 32768ll) : 0;
+  const float* xr = x + (size_t)row * ld;
+  int16_t* orow = out + (size_t)row * n;
+  const long long nb = (n + 7) >> 3;                     // groups of 8 samples = 16 bytes of PCM = one byte of mask
+  for (long long gi = (long long)blockIdx.x * 256 + threadIdx.x; gi < nb; gi += (long long)gridDim.x * 256) {
+    unsigned bits = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const long long i = gi * 8 + e;
+      if (i < n) {
+        const float v = xr[i];
+        const int q = product == 0 ? (int)((double)v * (double)am) : (int)(v * (float)am);
+        orow[i] = (int16_t)q;
+        if (fabsf(v) > keep_thr) bits |= 0x80u >> e;      // np.packbits order: first sample in the top bit
+      }
+    }
+    if (keep != nullptr) keep[(size_t)row * nb + gi] = (uint8_t)bits;
+  }
+}
+hipError_t launch_float_to_int16(const float* wav, long long n, long long ld, int rows, int per_row, int product, float keep_thr,
+                                 unsigned* peak, int16_t* pcm, uint8_t* keep, hipStream_t st) {
+  if (rows <= 0 || n <= 0) return hipSuccess;
+  hipError_t e = hipMemsetAsync(peak, 0, sizeof(unsigned) * (per_row ? rows : 1), st);
+  if (e != hipSuccess) return e;
+  const long long per_blk = 256ll * 16;
+  const unsigned gx = (unsigned)min((n + per_blk - 1) / per_blk, 1024ll);
+  hipLaunchKernelGGL(absmax_rows_k, dim3(gx, rows), dim3(256), 0, st, wav, n, ld, per_row, peak);
+  const long long nb = (n + 7) >> 3;
+  const unsigned gx2 = (unsigned)min((nb + 255) / 256, 2048ll);
+  hipLaunchKernelGGL(pcm16_k, dim3(gx2, rows), dim3(256), 0, st, wav, n, ld, per_row, product, (const unsigned*)peak, keep_thr, pcm, keep);
+  return hipGetLastError();
+}

@@ -356,6 +356,9 @@ hipError_t launch_layernorm(const float* x, const float* w, const float* b, floa
 hipError_t launch_istft(const float* head /*[B,F,1026]*/, const float* window /*[1024]*/, const float* twiddle /*[512,2]*/,
                         float* frames /*[B,F,1024] scratch*/, float* wav /*[B,256(F-1)]*/, int B, int F, hipStream_t st);
 
+// float32 waveform [rows][ld] (n samples per row) -> int16 PCM [rows][n] (+ optional keep mask [rows][ceil(n/8)]): tools/audio/np.py:7-11
+hipError_t launch_float_to_int16(const float* wav, long long n, long long ld, int rows, int per_row, int product, float keep_thr,
+                                 unsigned* peak, int16_t* pcm, uint8_t* keep, hipStream_t st);
 hipError_t launch_copy16(const void* src, void* dst, size_t bytes, hipStream_t st);   // shader copy (dst may be pinned host memory)
 
 // ---- full DVAE: mel front end + GFSQ (dvae.hip) ------------------------------------------------

@@ -1056,6 +1056,27 @@ class CodecEngine:
         _lib.check(self.lib.ctts_vocos_decode(self.handle, mel.data_ptr(), wav.data_ptr(), B, F, ws.data_ptr(), n, st), "ctts_vocos_decode")
         return wav
 
+    def float_to_int16(self, wav: torch.Tensor, per_row: bool = True, product: str = "f64", keep_thr: Optional[float] = None):
+        """`float_to_int16` of the reference's back end (tools/audio/np.py:7-11) ON THE DEVICE, before the waveform crosses PCIe: wav
+        [B, n] float32 (any row stride) -> (pcm [B, n] int16, keep) with am = 32767 * 32768 // (ceil(peak) * 32768) and truncation toward
+        zero.  per_row: a peak per utterance (one call per utterance, examples/web/funcs.py:206-209) -- False: ONE peak over the block
+        (the function applied to a [B, n] array, examples/cmd/stream.py:44).  product "f64": the reference's numba runtime (exact product),
+        "f32": plain NumPy's reading of the same line.  keep_thr: also return the packed mask |x| > keep_thr ([B, ceil(n/8)] uint8,
+        np.packbits order) -- the selector of Chat.infer's silence strip (core.py:262-265) -- else None.  Bit-exact against the reference
+        function (tests/test_backend.py)."""
+        assert wav.dim() == 2 and wav.dtype == torch.float32 and wav.is_cuda and (wav.shape[1] == 0 or wav.stride(1) == 1)
+        B, n = int(wav.shape[0]), int(wav.shape[1])
+        pcm = torch.empty((B, n), dtype=torch.int16, device=wav.device)
+        keep = torch.empty((B, (n + 7) // 8), dtype=torch.uint8, device=wav.device) if keep_thr is not None else None
+        if B == 0 or n == 0:
+            return pcm, keep
+        peak = torch.empty((B,), dtype=torch.int32, device=wav.device)
+        st = torch.cuda.current_stream(wav.device).cuda_stream
+        _lib.check(self.lib.ctts_float_to_int16(wav.data_ptr(), pcm.data_ptr(), _lib.ptr(keep), B, n, int(wav.stride(0)) if B > 1 else n,
+                                                1 if per_row else 0, {"f64": 0, "f32": 1}[product], float(keep_thr or 0.0), peak.data_ptr(), st),
+                   "ctts_float_to_int16")
+        return pcm, keep
+
     # receptive field of one output sample, in mel frames either side: ISTFT 4 overlapping frames; Vocos embed k7 + 8 ConvNeXt
     # blocks k7 = 27; DVAE conv_in k3 + k3, 12 ConvNeXt blocks k7 dilation 2, out_conv k3 = 75 (dvae.py:145-161, config.py:83-121)
     HALO_FRAMES = 27 + 75

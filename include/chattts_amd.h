@@ -248,6 +248,15 @@ int ctts_rccl_comm_create(void** comm /* ncclComm_t out */, int32_t world, const
 void ctts_rccl_comm_destroy(void* comm);
 int ctts_broadcast_weights(void* const* bufs, const size_t* bytes, int32_t n, void* comm /* ncclComm_t */, int32_t root, void* stream);
 
+/* float32 waveform -> 16-bit PCM on the device: replaces `float_to_int16` (/root/reference/tools/audio/np.py:7-11) behind Chat.infer --
+ * am = 32767 * 32768 // (int(ceil(max |x|)) * 32768); pcm = (x * am) truncated toward zero.  wav: [rows] rows of n samples, ld floats apart;
+ * pcm: [rows][n] int16; per_row 0: ONE peak over the whole array (the function applied to a [B, n] block, examples/cmd/stream.py:44),
+ * 1: a peak per row (one call per utterance: examples/web/funcs.py:206-209, tools/audio/pcm.py:29); product 0: the float64 product of the
+ * reference's numba-jitted runtime, 1: the float32 product plain NumPy >= 2 forms from the same source line; keep_bits: NULL, or
+ * [rows][ceil(n / 8)] bytes in np.packbits order, bit = |x| > keep_thr (the mask of Chat.infer's silence strip, core.py:262-265); peak:
+ * [rows] uint32 device scratch.  An all-zero input gives zeros (the reference divides by zero).  Stream-ordered, two launches. */
+int ctts_float_to_int16(const float* wav, int16_t* pcm, uint8_t* keep_bits, int32_t rows, int64_t n, int64_t ld, int32_t per_row,
+                        int32_t product, float keep_thr, uint32_t* peak, void* stream);
 /* Shader copy of `bytes` (a multiple of 16; both pointers 16-byte aligned) on `stream`.  `dst` may be PINNED HOST memory (mapped into
  * the device's address space): the float32 waveforms then reach the host -- the `.cpu().numpy()` that ends `Chat._decode_to_wavs`,
  * ChatTTS/core.py:508-510 -- as plain stores over PCIe, without the copy engines. */

@@ -100,3 +100,105 @@ def codec_inputs(c):
     if c["B"] > 1:
         hid[1, c["T"] * 2 // 3:] = 0  # a shorter row zero-padded like core.py:525-533
     return hid
+
+
+# ---- acoustic decoder at BASELINE sizes (tests/golden/codec_big.npz) -----------------------------------------------------------
+# Inputs are the REFERENCE's own GPT hidden states: contiguous runs of `c2.hid0` (tests/golden/generate_big.npz: the 512 final-norm
+# rows of the reference's 512-step C2 generation), not random normals -- so nothing but the golden outputs has to be stored.
+#   c2size  : BASELINE configs[1] -- 1 x 512 tokens = 1024 frames: the size from which the point-wise ConvNeXt pairs take the LDS-DMA
+#             kernels (gemm_x3p_k / gemm_h1p_k, ctts_codec.x3p_min_rows)
+#   r16x400 : 16 ragged rows (128..400 tokens, one of them 400) zero-padded to 400 like core.py:525-533 = 12800 frames: the size from
+#             which the dense layers take the 256 x 256 split-bf16 tile and the depthwise conv the sliding-window kernel (>= 12288)
+CODEC_BIG_CASES = {
+    "c2size": dict(B=1, T=512, seed=None),
+    "r16x400": dict(B=16, T=400, seed=3),
+}
+CODEC_BIG_MEL_STRIDE = 4     # the golden keeps mel frames f = (b + 4 k) ...: every 4th frame, phase = row index (all rows, all phases)
+CODEC_BIG_WAV_STRIDE = 16    # ... and every 16th waveform sample, phase = row index
+
+
+def codec_big_inputs(c, hid0: np.ndarray):
+    """hid0: generate_big.npz['c2.hid0'] [512, 768] f32.  Returns (hid [B, T, 768] f32, lens [B])."""
+    assert hid0.shape == (512, 768)
+    if c["seed"] is None:
+        return hid0[None, : c["T"]].astype(f32).copy(), np.array([c["T"]], np.int64)
+    rs = np.random.RandomState(200 + c["seed"])
+    lens = rs.randint(128, c["T"] + 1, size=c["B"]).astype(np.int64)
+    lens[rs.randint(c["B"])] = c["T"]
+    hid = np.zeros((c["B"], c["T"], 768), f32)
+    for b in range(c["B"]):
+        off = rs.randint(0, 512 - lens[b] + 1)
+        hid[b, : lens[b]] = hid0[off: off + lens[b]]
+    return hid, lens
+
+
+def codec_big_subsample(mel: np.ndarray, wav: np.ndarray):
+    """what the golden stores of a case's outputs (mel [B,100,F], wav [B,N]): strided samples whose phase walks with the row, plus
+    float64 block sums that cover every element (mel: 32-frame blocks, wav: 2048-sample blocks)"""
+    B, _, F = mel.shape
+    N = wav.shape[1]
+    ms, ws = CODEC_BIG_MEL_STRIDE, CODEC_BIG_WAV_STRIDE
+    mel_s = np.stack([mel[b][:, (b % ms)::ms][:, : F // ms] for b in range(B)])
+    wav_s = np.stack([wav[b][(b % ws)::ws][: N // ws] for b in range(B)])
+    nbm, nbw = F // 32, N // 2048
+    mel_blk = mel[:, :, : nbm * 32].astype(np.float64).reshape(B, 100, nbm, 32).sum(-1)
+    wav_blk = wav[:, : nbw * 2048].astype(np.float64).reshape(B, nbw, 2048).sum(-1)
+    wav_sq = (wav[:, : nbw * 2048].astype(np.float64) ** 2).reshape(B, nbw, 2048).sum(-1)
+    return dict(mel_s=mel_s, wav_s=wav_s, mel_blk=mel_blk, wav_blk=wav_blk, wav_sq=wav_sq,
+                mel_peak=np.array([np.abs(mel).max()], np.float64), wav_rms=np.array([np.sqrt(np.mean(wav.astype(np.float64) ** 2))]))
+
+
+# ---- host / device back end (tests/golden/backend.npz): float_to_int16 and ChatStreamer ------------------------------------------
+def pcm_inputs():
+    """waveforms for the float_to_int16 goldens: name -> float32 array (1-D = one utterance, 2-D = a [B, n] block).  Covers a peak below 1
+    (scale 32767), above 1 (ceil 2: scale 16383) and above 2, exact +-peak samples, values around the 1e-5 strip threshold, zeros
+    inside, a length that is not a multiple of 8, and products that sit within an ulp of an integer."""
+    rs = np.random.RandomState(77)
+    out = {}
+    a = (rs.standard_normal(10007) * 0.11).astype(f32)
+    a[100], a[200], a[300:310] = 0.73, -0.73, 0.0
+    out["utt_quiet"] = a
+    b = (rs.standard_normal(8192) * 0.35).astype(f32)
+    b[5], b[6] = 1.5, -1.25
+    out["utt_peak2"] = b
+    c = (rs.standard_normal((4, 6001)) * np.array([[0.2], [0.02], [1e-5], [0.0]])).astype(f32)
+    c[0, 17] = 0.999999
+    out["block4"] = c
+    d = (np.arange(1, 4097, dtype=np.float64) / 32767.0).astype(f32)          # x * 32767 within rounding of the integers 1..4096
+    d = np.concatenate([d, -d, np.nextafter(d, f32(0)), np.nextafter(d, f32(2))]).astype(f32)
+    out["integers"] = d
+    e = (rs.standard_normal(3000) * 0.9).astype(f32)
+    e[0] = 2.5
+    out["utt_peak3"] = e
+    return out
+
+
+def stream_chunks(name: str):
+    """chunk sequences like Chat.infer(stream=True) yields them ([B, n] float32, utterances that have finished are silent from then on)
+    for the ChatStreamer goldens"""
+    rs = np.random.RandomState({"three": 5, "one": 6, "late": 7}[name])
+    if name == "one":        # a single utterance, chunks shorter than a block
+        return [(rs.standard_normal((1, n)) * 0.2).astype(f32) for n in (3000, 3000, 3000, 12000, 500, 7000)]
+    if name == "three":      # three utterances of different lengths: 0 ends first, then 2, then 1
+        ends = [30000, 90000, 55000]
+        chunks, pos = [], 0
+        for n in [12000] * 8 + [7000]:
+            ch = (rs.standard_normal((3, n)) * 0.15).astype(f32)
+            for b, e in enumerate(ends):
+                k = max(0, min(n, e - pos))
+                ch[b, k:] = 0.0
+            chunks.append(ch)
+            pos += n
+        return chunks
+    # "late": utterance 0 silent from the start, a silent chunk in the middle, a tail that stays under the block size
+    chunks = []
+    for i, n in enumerate((9000, 9000, 4000, 9000, 2500, 2500)):
+        ch = (rs.standard_normal((2, n)) * 0.3).astype(f32)
+        ch[0] = 0.0
+        if i == 2:
+            ch[:] = 0.0
+        chunks.append(ch)
+    return chunks
+
+
+STREAM_CASES = ("three", "one", "late")

@@ -105,6 +105,27 @@ def golden_codec(sds):
     np.savez_compressed(os.path.join(OUT, "codec.npz"), **out)
 
 
+def golden_codec_big(sds):
+    """BASELINE-size acoustic goldens: mel from the reference's own DVAE class (ChatTTS/model/dvae.py:276-297), waveform
+    from oracle/torch_port.vocos_decode, inputs = the reference GPT's hidden states (cases.codec_big_inputs)."""
+    dec = ref_harness.build_decoder(sds)
+    hid0 = np.load(os.path.join(OUT, "generate_big.npz"))["c2.hid0"]
+    out = {}
+    for name, c in cases.CODEC_BIG_CASES.items():
+        t0 = time.time()
+        hid, lens = cases.codec_big_inputs(c, hid0)
+        with torch.inference_mode():
+            mel = dec(torch.from_numpy(hid).permute(0, 2, 1).contiguous())  # core.py:519-535 layout (B,768,T)
+            wav = ref_harness.torch_vocos_decode(sds["vocos"], mel)
+        sub = cases.codec_big_subsample(mel.numpy(), wav.numpy())
+        for k, v in sub.items():
+            out[f"{name}.{k}"] = v
+        out[name + ".lens"] = lens
+        out[name + ".hid_sha256"] = np.array(W.fingerprint({"h": torch.from_numpy(hid)}))
+        print(name, tuple(mel.shape), tuple(wav.shape), "mel peak", float(sub["mel_peak"][0]), "wav rms", float(sub["wav_rms"][0]), f"{time.time() - t0:.1f}s")
+    np.savez_compressed(os.path.join(OUT, "codec_big.npz"), **out)
+
+
 def main():
     assert ref_harness.available(), "/root/reference is required to generate goldens"
     os.makedirs(OUT, exist_ok=True)
@@ -132,6 +153,8 @@ def main():
         golden_codec(sds)
     if "text" in which:
         golden_text(sds)
+    if "codec_big" in which:   # needs generate_big.npz ("big") to exist: its c2.hid0 is the input
+        golden_codec_big(sds)
 
 
 if __name__ == "__main__":

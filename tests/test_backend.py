@@ -1,0 +1,105 @@
+"""Back end of the path against the reference's own code run on the same inputs (tests/golden/backend.npz,
+oracle/make_backend_goldens.py): `float_to_int16` (tools/audio/np.py:7-11) on the host and -- `-m gpu` -- on the device, `ChatStreamer`
+(examples/cmd/stream.py:9-145) block for block, `Chat.infer(..., pcm16=True)`.  Bit-exact bars: integer / byte work."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from chattts_amd import audio
+from chattts_amd.streamer import ChatStreamer
+from oracle import cases
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "backend.npz")
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(GOLD)
+
+
+@pytest.mark.parametrize("product", ["f64", "f32"])
+def test_host_float_to_int16_equals_the_reference_function(gold, product):
+    """every sample of every case: the reference function's own output, for the arithmetic of its numba runtime (float64 product) and
+    for plain NumPy's reading of the same line (float32 product); the two do differ (4608 samples of the `integers` case)"""
+    for name, x in cases.pcm_inputs().items():
+        got = audio.float_to_int16(x, product)
+        assert got.dtype == np.int16 and got.shape == x.shape
+        assert np.array_equal(got, gold[f"pcm.{name}.{product}"]), (name, int((got != gold[f"pcm.{name}.{product}"]).sum()))
+    assert (gold["pcm.integers.f32"] != gold["pcm.integers.f64"]).sum() > 1000
+    assert not audio.float_to_int16(np.zeros(100, np.float32)).any()          # the reference divides by zero here
+    assert audio.pcm_scale(0.3) == 32767 and audio.pcm_scale(1.5) == 16383 and audio.pcm_scale(2.5) == 10922
+
+
+def _digest(blocks, as_float):
+    raw = b"".join(np.ascontiguousarray(b, dtype="<f4").tobytes() for b in blocks) if as_float else b"".join(blocks)
+    return hashlib.sha256(raw).hexdigest()
+
+
+@pytest.mark.parametrize("name", cases.STREAM_CASES)
+def test_chat_streamer_equals_the_reference_class(gold, name):
+    """the reference's ChatStreamer fed the same chunk sequence: the same PCM16 byte blocks in the same order with the same boundaries
+    (three utterances ending at different times; one utterance in sub-block chunks; a silent first utterance, a silent chunk, a
+    leftover under the block size), for both product arithmetics, and the float pieces of output_format=None"""
+    for product in ("f64", "f32"):
+        blocks = list(ChatStreamer(product=product).generate(iter(cases.stream_chunks(name)), output_format="PCM16_byte"))
+        key = f"stream.{name}.{product}.bytes"
+        assert all(isinstance(b, bytes) for b in blocks)
+        assert [len(b) for b in blocks] == gold[key + ".lens"].tolist()
+        if key in gold.files:
+            assert np.array_equal(np.frombuffer(b"".join(blocks), np.uint8), gold[key])
+        assert _digest(blocks, False) == str(gold[key + ".sha256"])
+    pieces = list(ChatStreamer().generate(iter(cases.stream_chunks(name)), output_format=None))
+    assert [len(p) for p in pieces] == gold[f"stream.{name}.f64.float.lens"].tolist()
+    assert _digest(pieces, True) == str(gold[f"stream.{name}.f64.float.sha256"])
+    ints = list(ChatStreamer().generate(iter(cases.stream_chunks(name)), output_format="PCM16"))
+    assert all(p.dtype == np.int16 for p in ints)
+    assert _digest([p.astype("<i2").tobytes() for p in ints], False) == str(gold[f"stream.{name}.f64.bytes.sha256"])
+
+
+def test_chat_streamer_edge_inputs():
+    """no chunks, only silent chunks, an empty chunk: nothing is yielded (the reference raises on the first and the last)"""
+    s = ChatStreamer()
+    assert list(s.generate(iter([]), "PCM16_byte")) == []
+    assert list(s.generate(iter([np.zeros((2, 500), np.float32)] * 3), "PCM16_byte")) == []
+    assert list(s.generate(iter([np.zeros((2, 0), np.float32)]), "PCM16_byte")) == []
+
+
+def test_wav_bytes_round_trip():
+    import io
+    import wave
+    x = cases.pcm_inputs()["utt_quiet"]
+    with wave.open(io.BytesIO(audio.pcm_to_wav_bytes(x)), "rb") as wf:
+        assert (wf.getnchannels(), wf.getsampwidth(), wf.getframerate(), wf.getnframes()) == (1, 2, 24000, x.size)
+        assert np.array_equal(np.frombuffer(wf.readframes(x.size), "<i2"), audio.float_to_int16(x))
+
+
+# ---- device ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("product", ["f64", "f32"])
+def test_device_float_to_int16_equals_the_reference_function(gold, weights, product):
+    """ctts_float_to_int16 (csrc/codec.hip absmax_rows_k + pcm16_k) through CodecEngine.float_to_int16: np.array_equal with the reference
+    function's output on every case -- one peak over a block (`per_row=False`, the function applied to a 2-D array) and a peak per row
+    (one call per utterance); the keep mask equals |x| > 1e-5; a strided view (a window of a wider buffer) converts like its copy."""
+    from chattts_amd import engine as E
+    dev = torch.device("cuda:0")
+    codec = E.CodecEngine(weights["decoder"], weights["vocos"], dev)
+    for name, x in cases.pcm_inputs().items():
+        x2 = x if x.ndim == 2 else x[None]
+        pcm, keep = codec.float_to_int16(torch.from_numpy(x2).to(dev), per_row=False, product=product, keep_thr=1e-5)
+        want = gold[f"pcm.{name}.{product}"].reshape(x2.shape)
+        assert pcm.dtype == torch.int16 and np.array_equal(pcm.cpu().numpy(), want), (name, int((pcm.cpu().numpy() != want).sum()))
+        bits = np.unpackbits(keep.cpu().numpy(), axis=1)[:, : x2.shape[1]].astype(bool)
+        assert np.array_equal(bits, np.abs(x2) > np.float32(1e-5))
+        rows, _ = codec.float_to_int16(torch.from_numpy(x2).to(dev), per_row=True, product=product)
+        for b in range(x2.shape[0]):
+            assert np.array_equal(rows[b].cpu().numpy(), audio.float_to_int16(x2[b], product)), (name, b)
+    wide = torch.from_numpy(cases.pcm_inputs()["block4"]).to(dev)
+    view = wide[:, 1001:5000]
+    a, _ = codec.float_to_int16(view, per_row=True, product=product)
+    b, _ = codec.float_to_int16(view.contiguous(), per_row=True, product=product)
+    assert not view.is_contiguous() and torch.equal(a, b)
+    z, _ = codec.float_to_int16(torch.zeros((2, 77), device=dev), per_row=True)
+    assert not bool(z.any())

@@ -11,6 +11,7 @@ pytestmark = pytest.mark.gpu
 
 from chattts_amd import engine as E  # noqa: E402
 from chattts_amd import synth  # noqa: E402
+from chattts_amd import weights as W  # noqa: E402
 from oracle import cases, codec_np, generate_np, llama_np  # noqa: E402
 
 DEV = torch.device("cuda:0")
@@ -440,6 +441,42 @@ def test_codec_vs_reference_golden(codec, golden, name):
     rms = float(np.sqrt(np.mean((wav - ref) ** 2)))
     print(f"codec[{codec.gemm}] {name}: mel max err {merr:.2e}, wav rms err {rms:.2e}")
     assert rms < 1e-4, rms   # north_star: float32 waveform within 1e-4 RMS (signal rms ~ 3.5e-2)
+
+
+@pytest.mark.parametrize("gemm", ["bf16x3", "f16", "f32"])
+@pytest.mark.parametrize("name", list(cases.CODEC_BIG_CASES))
+def test_codec_baseline_sizes_vs_reference_golden(weights, golden, name, gemm):
+    """The acoustic decoder AT THE SIZES THE BENCH RUNS IT, against the reference itself: inputs are the reference
+    GPT's own hidden states (runs of generate_big.npz c2.hid0), mel is the output of the reference's DVAE class
+    (ChatTTS/model/dvae.py:276-297), the waveform that of oracle/torch_port.vocos_decode on it (tests/golden/codec_big.npz,
+    oracle/make_goldens.py codec_big).  c2size = 1 x 512 tokens (1024 frames: gemm_x3p_k / gemm_h1p_k, the LDS-DMA point-wise pairs);
+    r16x400 = 16 ragged rows zero-padded to 400 tokens (12800 frames: 256 x 256 split-bf16 tiles, dwconv_ln_run_k).  Every dense-layer
+    mode is compared DIRECTLY -- no HIP-vs-HIP step: strided samples whose phase walks with the row (every 4th mel frame, every 16th
+    waveform sample) and float64 block sums over every element.  Bars: mel within 1e-4 of its peak and waveform within 1e-4 RMS
+    (north_star) for the f32-class modes; gemm="f16" (one fp16 MFMA per product): mel within 2e-3 of its peak, waveform within 2e-5 RMS
+    -- measured 1.3e-5, a fifth of the bar."""
+    c = cases.CODEC_BIG_CASES[name]
+    Gd = golden["codec_big"]
+    hid, lens = cases.codec_big_inputs(c, golden["generate_big"]["c2.hid0"])
+    assert np.array_equal(lens, Gd[name + ".lens"])
+    assert W.fingerprint({"h": torch.from_numpy(hid)}) == str(Gd[name + ".hid_sha256"])     # the input the reference saw, bit for bit
+    eng = E.CodecEngine(weights["decoder"], weights["vocos"], DEV, gemm=gemm)
+    mel = eng.dvae_decode(torch.from_numpy(hid))                 # [B, 2T, 100]
+    wav = eng.vocos_decode(mel).cpu().numpy()                    # [B, 256 (2T - 1)]
+    got = cases.codec_big_subsample(mel.cpu().numpy().transpose(0, 2, 1), wav)
+    peak, wrms = float(Gd[name + ".mel_peak"][0]), float(Gd[name + ".wav_rms"][0])
+    merr = float(np.abs(got["mel_s"] - Gd[name + ".mel_s"]).max()) / peak
+    rms = float(np.sqrt(np.mean((got["wav_s"].astype(np.float64) - Gd[name + ".wav_s"]) ** 2)))
+    # block sums: every mel bin of every 32-frame block, every 2048-sample block of the waveform (a wrong tile / row / tail shows here even
+    # if the strided samples miss it); |sum of n errors| <= n * max error
+    mblk = float(np.abs(got["mel_blk"] - Gd[name + ".mel_blk"]).max()) / (32 * peak)
+    wblk = float(np.abs(got["wav_blk"] - Gd[name + ".wav_blk"]).max()) / 2048
+    wsq = float(np.abs(np.sqrt(got["wav_sq"] / 2048) - np.sqrt(Gd[name + ".wav_sq"] / 2048)).max())
+    print(f"codec[{gemm}] {name}: mel max err / peak {merr:.2e} (block mean {mblk:.2e}), wav rms err {rms:.2e} (block mean {wblk:.2e}, "
+          f"block rms {wsq:.2e}; signal rms {wrms:.2e})")
+    mel_bar, wav_bar = (2e-3, 2e-5) if gemm == "f16" else (1e-4, 1e-4)
+    assert merr < mel_bar and mblk < mel_bar, (merr, mblk)
+    assert rms < wav_bar and wblk < wav_bar and wsq < wav_bar, (rms, wblk, wsq)
 
 
 def test_generate_rows_are_views_of_the_padded_batch(gpt_f32, weights):

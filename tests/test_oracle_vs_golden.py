@@ -131,6 +131,32 @@ def test_codec(golden, weights, name):
     assert wav.shape == ref.shape and rms < 1e-4, rms  # north_star bar: float32 waveform within 1e-4 RMS
 
 
+def test_codec_baseline_size_golden(golden, weights):
+    """tests/golden/codec_big.npz (the reference's DVAE class + oracle/torch_port.vocos_decode on the reference GPT's own hidden states, at
+    the sizes the bench decodes): the input recipe reproduces the exact arrays the reference saw (sha256), and the numpy oracle holds the
+    same bars on the 1 x 512-token case (the 16 x 400 case is the GPU tests': minutes of numpy here)."""
+    from chattts_amd import weights as W
+    Gd = golden["codec_big"]
+    hid0 = golden["generate_big"]["c2.hid0"]
+    for name, c in cases.CODEC_BIG_CASES.items():
+        hid, lens = cases.codec_big_inputs(c, hid0)
+        assert np.array_equal(lens, Gd[name + ".lens"]) and hid.shape == (c["B"], c["T"], 768)
+        assert W.fingerprint({"h": torch.from_numpy(hid)}) == str(Gd[name + ".hid_sha256"])
+        assert all(not hid[b, lens[b]:].any() for b in range(c["B"]))             # zero padding behind a short row (core.py:525-533)
+    name = "c2size"
+    hid, _ = cases.codec_big_inputs(cases.CODEC_BIG_CASES[name], hid0)
+    dsd = {k: v.numpy() for k, v in weights["decoder"].items()}
+    vsd = {k: v.numpy() for k, v in weights["vocos"].items()}
+    mel = codec_np.dvae_decode(dsd, hid)                       # [B, 2T, 100]
+    wav = codec_np.vocos_decode(vsd, mel)
+    got = cases.codec_big_subsample(mel.transpose(0, 2, 1), wav)
+    peak = float(Gd[name + ".mel_peak"][0])
+    assert np.abs(got["mel_s"] - Gd[name + ".mel_s"]).max() < 1e-4 * peak
+    assert np.sqrt(np.mean((got["wav_s"].astype(np.float64) - Gd[name + ".wav_s"]) ** 2)) < 1e-4
+    assert np.abs(got["mel_blk"] - Gd[name + ".mel_blk"]).max() < 32 * 1e-4 * peak
+    assert np.abs(got["wav_blk"] - Gd[name + ".wav_blk"]).max() < 2048 * 1e-4
+
+
 def test_torch_port_matches_goldens(golden, weights):
     """oracle/torch_port.py (bench.py's CPU baseline: HF LlamaModel + DynamicCache + transformers' warpers under
     torch/MKL) reproduces the reference's golden token ids, and its DVAE / Vocos restatements the reference-class mel
