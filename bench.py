@@ -445,6 +445,8 @@ def main():
                          "the parity-mode leg always decodes with bf16x3)")
     ap.add_argument("--lanes", type=int, default=1, help="concurrent decode lanes (HIP streams) the batch is cut into")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) run the CPU baseline leg alone and print its JSON")
+    ap.add_argument("--cold-start-only", choices=["plain", "prewarmed"], default=None,
+                    help="(internal) a FRESH process: load, optionally Chat.warm the workload's geometry, then time the first streamed chunk")
     args = ap.parse_args()
 
     if args.cpu_baseline_only:   # child process of the main run (no GPU use): see cpu_baseline_guarded()
@@ -452,6 +454,8 @@ def main():
         print("CPU_BASELINE_JSON " + json.dumps(cpu_baseline(W.synthetic_all(), wl["ids"], wl["mask"], wl["tmask"], wl["stop_all"])), flush=True)
         return
 
+    if args.cold_start_only:
+        return cold_start_child(args)
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -766,13 +770,33 @@ def main():
         result["parity_mode"] = {"dtype": "f32", "value": round(audio_seconds(stop) * args.parity_steps / dt32, 2), "unit": "audio-s/s",
                                  "steps": args.parity_steps, "warmup": 1, "ms_per_step": round(1000.0 * dt32 / args.parity_steps, 3),
                                  "decode_ms_per_gpt_step": round(dec32_ms / max(1, steps32 - 1), 4),
-                                 "kernels": "decode projections on fragment-packed f32 operands (csrc/decode32.hip), operation order of "
-                                            "the row-major f32 kernels kept bit for bit; acoustic decoder gemm=bf16x3 (4e-7 RMS from the f32 oracle)",
+                                 "kernels": ("decode projections on SPLIT-bf16 operands (csrc/decode32x.hip: hi | lo bf16 planes, three bf16 MFMAs per "
+                                             "product, f32 accumulation; f32 KV cache, f32 attention, f32 heads + sampling)" if gpt32.x3 is not None else
+                                             "decode projections on fragment-packed f32 operands (csrc/decode32.hip), operation order of the row-major "
+                                             "f32 kernels kept bit for bit") + "; acoustic decoder gemm=bf16x3 (4e-7 RMS from the f32 oracle)",
                                  "ids_sha256": got, "golden_sha256": want,
                                  "ids_match_reference": (got == want) if want else None,
                                  "golden": "tests/golden/bench_c3.npz: the reference's GPT.generate on this workload (oracle/make_bench_golden.py)"}
         result["value_parity_f32"] = result["parity_mode"]["value"]          # the number that meets north_star's bit-exactness
         result["parity_f32_ids_match_reference"] = result["parity_mode"]["ids_match_reference"]
+        if gpt32.x3 is not None:
+            # ... and the same leg on the f32 MFMA kernels (CTTS_D32_EXACT=1, the fallback the split-bf16 decode step is measured against)
+            note("parity mode, f32 MFMA projections (CTTS_D32_EXACT=1): 2 timed passes")
+            os.environ["CTTS_D32_EXACT"] = "1"
+            try:
+                gpt32e = E.GptEngine(sds["gpt"], sds["embed"], dev, dtype="f32")
+            finally:
+                os.environ.pop("CTTS_D32_EXACT", None)
+            dte = timed(gpt32e, 2, 1)
+            stepse, dece_ms = gpt32e.last_stats.get("steps", 0), gpt32e.last_stats.get("decode_ms", 0.0)
+            _, _, rows_e = one_pass(gpt32e, decode_audio=False, keep_ids=True)
+            result["parity_mode"]["exact_f32_mfma"] = {"value": round(audio_seconds(stop) * 2 / dte, 2), "unit": "audio-s/s", "steps": 2,
+                                                       "ms_per_step": round(1000.0 * dte / 2, 3),
+                                                       "decode_ms_per_gpt_step": round(dece_ms / max(1, stepse - 1), 4),
+                                                       "ids_match_reference": (ids_digest(rows_e) == want) if want else None,
+                                                       "kernels": "csrc/decode32.hip (v_mfma_f32_16x16x4_f32), CTTS_D32_EXACT=1"}
+            del gpt32e
+            torch.cuda.empty_cache()
         if not args.no_roofline:
             roof32, k32 = roofline_leg(gpt32, 4, (3,), steps32, dec32_ms / max(1, steps32 - 1), pmc_key_suffix="_f32")
             result["parity_mode"]["roofline"] = roof32
@@ -853,6 +877,12 @@ def main():
                 break
         result["ttfs_ms_p50"] = round(1000.0 * float(np.median(ttfs[1:])), 2)
         result["ttfs_samples"] = len(ttfs) - 1
+        # what `ttfs_ms_p50` hides: the FIRST request of a process (session allocation, graph capture + instantiation, first replays,
+        # code objects, decoder workspace, pinned buffers) -- a fresh process each, with and without Chat.load(..., warm=...)
+        note("cold start (two fresh processes)")
+        result["ttfs_cold"] = {m: cold_start_guarded(args, m) for m in ("plain", "prewarmed")}
+        result["ttfs_ms_cold"] = result["ttfs_cold"]["plain"].get("first_chunk_ms")
+        result["ttfs_ms_cold_prewarmed"] = result["ttfs_cold"]["prewarmed"].get("first_chunk_ms")
 
     # ---- same-box CPU baseline: torch/MKL restatement on the reference's own stack (HF LlamaModel + DynamicCache) ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -871,6 +901,56 @@ def generate_heads(embed_sd) -> np.ndarray:
     return np.concatenate([W.fold_weight_norm(embed_sd[f"head_code.{k}.parametrizations.weight.original0"].float(),
                                               embed_sd[f"head_code.{k}.parametrizations.weight.original1"].float()).numpy()
                            for k in range(GPT.n_vq)], 0).astype(np.float32)
+
+
+def cold_start_child(args):
+    """--cold-start-only: this process has done nothing on the GPU yet.  Load the engines (weights resident: that is `Chat.load`), optionally
+    pre-warm the workload's geometry, then time ONE request to its first streamed chunk on the host (the reference's yield schedule:
+    first audio after 3 x 24 tokens) -- and a second one, for the warm figure of the same process."""
+    from chattts_amd.core import Chat, InferCodeParams
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    torch.set_num_threads(max(1, min(torch.get_num_threads(), host_cpu_quota())))
+    wl = shard_workload(args.batch, 1, 0, args.min_len, args.max_len)
+    ids_t, mask_t, tm_t = torch.from_numpy(wl["ids"]), torch.from_numpy(wl["mask"]), torch.from_numpy(wl["tmask"])
+    stop_t = torch.from_numpy(wl["stop"])
+    params = InferCodeParams(max_new_token=int(wl["stop_all"].max()) + 1, manual_seed=42, show_tqdm=False)
+    kw = dict(stop_at=stop_t, row_offset=wl["row_offset"], total_rows=wl["total_rows"])
+    sds = W.synthetic_all()
+    chat = Chat()
+    t0 = time.perf_counter()
+    assert chat.load(state_dicts=sds, device=dev, dtype=args.dtype)
+    torch.cuda.synchronize(dev)
+    load_ms = 1e3 * (time.perf_counter() - t0)
+    warm_ms = None
+    if args.cold_start_only == "prewarmed":
+        warm_ms = 1e3 * chat.warm(ids_t.shape[0], ids_t.shape[1], params, **kw)
+    out = []
+    for _ in range(2):
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for _chunk in chat.infer_ids_stream(ids_t, mask_t, tm_t, params, **kw):
+            out.append(1e3 * (time.perf_counter() - t1))
+            break
+    print("COLD_START_JSON " + json.dumps({"mode": args.cold_start_only, "first_chunk_ms": round(out[0], 2), "second_request_ms": round(out[1], 2),
+                                           "load_ms": round(load_ms, 1), "warm_ms": None if warm_ms is None else round(warm_ms, 1),
+                                           "what": "fresh process; first streamed chunk of the C3 batch on the host, after Chat.load"
+                                                   + (" + Chat.warm of this geometry" if warm_ms is not None else "")}), flush=True)
+
+
+def cold_start_guarded(args, mode: str, limit_s: float = 240.0):
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--cold-start-only", mode, "--batch", str(args.batch), "--min-len", str(args.min_len),
+           "--max-len", str(args.max_len), "--dtype", args.dtype]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=limit_s, env=env)
+        for line in out.stdout.splitlines():
+            if line.startswith("COLD_START_JSON "):
+                return json.loads(line[len("COLD_START_JSON "):])
+        return {"first_chunk_ms": None, "error": "cold-start child printed no result: " + (out.stderr or "")[-300:]}
+    except subprocess.TimeoutExpired:
+        return {"first_chunk_ms": None, "error": f"cold-start child exceeded {limit_s:.0f} s and was stopped"}
 
 
 def cpu_baseline_guarded(args, limit_s: float = 150.0):

@@ -26,6 +26,7 @@ class GptWeights(C.Structure):
         ("wqkv_pk", PP), ("wo_pk", PP), ("wgu_pk", PP), ("wd_pk", PP),
         ("heads_pk", P), ("head_text_pk", P),
         ("wo_hd", PP),
+        ("wqkv_x3", PP), ("wo_x3", PP), ("wgu_x3", PP), ("wd_x3", PP),
     ]
 
 
@@ -117,6 +118,7 @@ SIGNATURES = {
     "ctts_k_gemm_fast": (C.c_int, [P, I32, P, I32, I32, I32, P, F, I32, P, I32, P, I32, P, P]),
     "ctts_k_qkv_rope": (C.c_int, [P, P, I32, P, F, P, P, P, I32, P, P, I32, P, P, I32, P]),
     "ctts_k_gemm_dec": (C.c_int, [P, P, I32, I32, I32, P, P, F, I32, P, I32, P, I32, P, I32, P]),
+    "ctts_k_gemm_dec32x": (C.c_int, [P, C.c_int64, P, C.c_int64, I32, I32, I32, P, P, I32, F, I32, P, I32, P, I32, P, C.c_int64, I32, P, I32, P]),
     "ctts_k_dec32_last_variant": (C.c_char_p, []),
     "ctts_k_gemm_dec32": (C.c_int, [P, P, I32, I32, I32, P, P, I32, P, F, I32, P, I32, P, I32, P, I32, I32, I32, P]),
     "ctts_k_rows_prep": (C.c_int, [P, P, P, I32, P]),

@@ -17,14 +17,28 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libchattts_amd.so")
-SOURCES = ["gemm.hip", "decode.hip", "decode32.hip", "prefill.hip", "prefill32.hip", "gpt.hip", "codec.hip", "codec_gemm.hip", "dvae.hip", "capi.hip"]
+SOURCES = ["gemm.hip", "decode.hip", "decode32.hip", "decode32x.hip", "prefill.hip", "prefill32.hip", "gpt.hip", "codec.hip", "codec_gemm.hip", "dvae.hip", "capi.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result"]
 HEADERS = [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "kernels.hpp"), os.path.join(CSRC, "decode_dev.hpp"),
            os.path.join(HERE, "..", "include", "chattts_amd.h")]
 
 
-def _digest(src: str, flags) -> str:
+_TOOLCHAIN = {}
+
+
+def _toolchain(hipcc: str) -> bytes:
+    """`hipcc --version`: part of every object's digest, so a toolchain upgrade rebuilds"""
+    if hipcc not in _TOOLCHAIN:
+        try:
+            _TOOLCHAIN[hipcc] = subprocess.run([hipcc, "--version"], capture_output=True, timeout=60).stdout
+        except (OSError, subprocess.SubprocessError):
+            _TOOLCHAIN[hipcc] = b"unknown"
+    return _TOOLCHAIN[hipcc]
+
+
+def _digest(src: str, flags, hipcc: str = "") -> str:
     h = hashlib.sha256()
+    h.update(_toolchain(hipcc) if hipcc else b"")
     for p in (src, *HEADERS):
         with open(p, "rb") as fh:
             h.update(fh.read())
@@ -62,7 +76,7 @@ def build(force: bool = False, verbose: bool = True, variant: str = "", defines=
         src = os.path.join(CSRC, s)
         obj = os.path.join(odir, s.replace(".hip", ".o"))
         objs.append(obj)
-        dg = _digest(src, flags)
+        dg = _digest(src, flags, hipcc)
         if force or not os.path.exists(obj) or _stamp(obj) != dg:
             jobs.append((src, obj, dg))
 
@@ -78,11 +92,16 @@ def build(force: bool = False, verbose: bool = True, variant: str = "", defines=
     if jobs:
         with ThreadPoolExecutor(max_workers=min(len(jobs), max(1, (os.cpu_count() or 2) - 1), 10)) as pool:
             list(pool.map(compile_one, jobs))
-    if force or jobs or not os.path.exists(lib):
+    # the library carries the digests of the objects it was linked from (csrc/<lib>.sha): an interrupted or failed link after a
+    # successful compile leaves a stale library that the next build must not take for current
+    want = hashlib.sha256("\n".join(_stamp(o) for o in objs).encode()).hexdigest()
+    if force or jobs or not os.path.exists(lib) or _stamp(lib) != want:
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", lib]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+        with open(lib + ".sha", "w") as fh:
+            fh.write(want)
         if not variant:
             with open(os.path.join(CSRC, ".built_on"), "w") as fh:
                 fh.write(socket.gethostname())

@@ -23,6 +23,7 @@ import numpy as np
 import torch
 
 from . import weights as W
+from .audio import float_to_int16
 from .config import GPT
 from .dvae import DvaeEngine
 from .engine import CodecEngine, Context, GenerationOutputs, GptEngine, gen_logits
@@ -87,7 +88,8 @@ class Chat:
     def load(self, source: str = "local", force_redownload: bool = False, compile: bool = False, custom_path: Optional[str] = None,
              device: Optional[torch.device] = None, coef=None, use_flash_attn: bool = False, use_vllm: bool = False,
              experimental: bool = False, *, dtype: str = "bf16", state_dicts: Optional[dict] = None,
-             tokenizer: Union[None, str, Tokenizer] = None, spk_stat: Optional[str] = None, codec_gemm: Optional[str] = None) -> bool:
+             tokenizer: Union[None, str, Tokenizer] = None, spk_stat: Optional[str] = None, codec_gemm: Optional[str] = None,
+             warm=None) -> bool:
         """`Chat.load` with the reference's positional parameters and defaults (core.py:137-148), for `source="local"` /
         `"custom"` (assets already on disk; there is no network path here, `"huggingface"` returns False): the four
         hot-path safetensors files under `custom_path` (default: the working directory, like the reference's "local"
@@ -96,6 +98,7 @@ class Chat:
         `spk_stat` is the reference's `Config.spk_stat` string (needed by `sample_random_speaker` only); `codec_gemm` picks the
         acoustic decoder's dense-layer arithmetic (`CodecEngine`: "f16" | "bf16x3" | "f32"; default: "f16" in perf mode --
         waveform within 2e-5 RMS of the f32-class decoder for the same hidden states -- and "bf16x3" in parity mode).
+        `warm=(B, T)` or `(B, T, InferCodeParams)`: pay the first request's cold start at load time instead (see `Chat.warm`).
         `compile`, `use_flash_attn`, `use_vllm`, `experimental` select between the reference's torch back ends and
         have no meaning for this engine (accepted, ignored).  `coef` is accepted and has no effect, as in the reference:
         `DVAE.__init__` installs it (dvae.py:219-226) and `load_pretrained` then overwrites the buffer with the
@@ -126,7 +129,42 @@ class Chat:
             self.tokenizer = tokenizer if isinstance(tokenizer, Tokenizer) else Tokenizer(tokenizer)
         if spk_stat is not None:
             self.speaker = Speaker(GPT.hidden, spk_stat, torch.device("cpu"))
+        if warm is not None:
+            self.warm(*warm)
         return True
+
+    def warm(self, batch: int, prompt_len: int, params: Optional["Chat.InferCodeParams"] = None, stream: bool = True, **kw) -> float:
+        """Pre-warm the engine for one geometry -- `batch` utterances, prompts padded to `prompt_len` tokens, the sampling constants
+        and `max_new_token` of `params` (default: InferCodeParams()) -- so that the FIRST request of that shape finds what a second one
+        would: the generation session (KV cache, token / hidden-state buffers: 2.3 GB at batch 64 x 2048 new tokens), the captured and
+        instantiated decode graphs with their first replays behind them, the acoustic decoder's workspace and the pinned staging buffers
+        (profiles/r4u_ttfs_probe.log: first audio of a fresh engine after 280 ms, 32-51 ms from the second call on).  Runs the real path
+        on a synthetic prompt up to its first streamed chunk and interrupts it (core.py:272-273); a request of another shape still
+        benefits from the allocator's cached blocks and the decoder's buffers (`kw`: the extra keywords the requests will pass to
+        `infer_code`, e.g. a `stop_at` tensor -- the session is keyed on their presence).  The reference has no counterpart: its first call pays
+        torch's lazy initialisation the same way (core.py:137-163 loads weights only).  Returns the seconds it took."""
+        import time
+        assert self.has_loaded()
+        t0 = time.perf_counter()
+        params = params or Chat.InferCodeParams(show_tqdm=False)
+        ids = torch.ones((batch, prompt_len, GPT.n_vq), dtype=torch.int64)
+        attn = torch.ones((batch, prompt_len), dtype=torch.bool)
+        was = self.context.get()
+        self.context.set(False)
+        try:
+            n = 0
+            for out in self.infer_code(ids, attn, torch.ones((batch, prompt_len), dtype=torch.bool), params, stream=stream, **kw):
+                n += 1
+                if out is not None and len(out.hiddens) and max(int(h.shape[0]) for h in out.hiddens) > 0 and self.codec is not None:
+                    if stream:
+                        self._stream_piece(out.hiddens, 0, params.stream_speed)      # window decode + staging buffers
+                    else:
+                        self.decode_to_wavs(out.hiddens)
+                self.context.set(True)          # one chunk is enough: the generator stops at its next poll
+        finally:
+            self.context.set(was)
+        torch.cuda.synchronize(self.device)
+        return time.perf_counter() - t0
 
     def unload(self):               # core.py:165-174
         self.gpt = None
@@ -190,6 +228,25 @@ class Chat:
             return self.codec.to_host(self.codec.decode_to_wavs(result_list))
         return self.codec.to_host(self.codec.vocos_decode(self.dvae.decode_codes(result_list)))
 
+    def decode_to_pcm16(self, result_list: List[torch.Tensor], use_decoder: bool = True, strip: bool = True,
+                        product: str = "f64") -> List[np.ndarray]:
+        """`_decode_to_wavs` followed by what the reference's callers do with every waveform -- the sample-level silence strip of
+        core.py:262-265 and `float_to_int16` (tools/audio/np.py:7-11; examples/web/funcs.py:209, tools/audio/pcm.py:29), one peak per
+        utterance -- with the conversion ON THE DEVICE: the batch crosses PCIe as int16 + one mask bit per sample instead of float32.
+        Returns one int16 array per utterance, equal to `float_to_int16(wav[np.abs(wav) > 1e-5])` bit for bit (the strip only removes
+        samples that are far below one count, so the peak -- hence the scale -- is that of the unstripped row)."""
+        assert self.has_loaded(use_decoder)
+        if len(result_list) == 0:
+            return []
+        wav = self.codec.decode_to_wavs(result_list) if use_decoder else self.codec.vocos_decode(self.dvae.decode_codes(result_list))
+        pcm, keep = self.codec.float_to_int16(wav, per_row=True, product=product, keep_thr=1e-5 if strip else None)
+        pcm_h = self.codec.to_host(pcm)
+        if not strip:
+            return [pcm_h[b] for b in range(pcm_h.shape[0])]
+        keep_h = self.codec.to_host(keep)
+        n = pcm_h.shape[1]
+        return [pcm_h[b][np.unpackbits(keep_h[b])[:n].astype(bool)] for b in range(pcm_h.shape[0])]
+
     def infer_ids(self, input_ids, attention_mask, text_mask, params: InferCodeParams = InferCodeParams(), **kw) -> np.ndarray:
         """non-stream `Chat._infer` body for one batch (core.py:469-481, split_text=False, skip_refine_text=True),
         BEFORE the sample-level silence strip of core.py:258-270."""
@@ -219,7 +276,7 @@ class Chat:
         for p in pending:
             yield np.zeros((0,), np.float32) if p is None else p.result()
 
-    def _stream_piece(self, hiddens, a: int, b: Optional[int], use_decoder: bool = True) -> np.ndarray:
+    def _stream_piece(self, hiddens, a: int, b: Optional[int], use_decoder: bool = True, pcm16: bool = False) -> np.ndarray:
         """samples [a, b) (b=None: to the end) of the decode of the current prefix (core.py:482-497), from a token window with
         halos instead of the whole prefix (`CodecEngine.decode_window`); `incremental_stream=False` restores the reference's
         full re-decode per yield"""
@@ -227,9 +284,13 @@ class Chat:
         total = 256 * (2 * Tn - 1) if use_decoder else None
         if not use_decoder or not self.incremental_stream:
             wavs = self.decode_to_wavs(hiddens, use_decoder)
-            return wavs[:, a: wavs.shape[1] if b is None else min(b, wavs.shape[1])]
+            piece = wavs[:, a: wavs.shape[1] if b is None else min(b, wavs.shape[1])]
+            return np.stack([float_to_int16(r) for r in piece]) if (pcm16 and piece.shape[1]) else piece
         hi = total if b is None else min(b, total)
-        return self.codec.to_host(self.codec.decode_window(hiddens, a, hi))
+        win = self.codec.decode_window(hiddens, a, hi)
+        if pcm16 and win.shape[1] > 0:     # every row by its own peak -- float_to_int16(chunk[b]), examples/web/funcs.py:203-206 -- on the device
+            return self.codec.to_host(self.codec.float_to_int16(win, per_row=True)[0])
+        return self.codec.to_host(win)
 
     def infer_ids_stream(self, input_ids, attention_mask, text_mask, params: InferCodeParams = InferCodeParams(), **kw):
         """stream=True body of `Chat._infer` for one batch (core.py:455-503): every `stream_batch` live steps the
@@ -310,9 +371,13 @@ class Chat:
 
     def infer(self, text, stream=False, lang=None, skip_refine_text=False, refine_text_only=False, use_decoder=True,
               do_text_normalization=True, do_homophone_replacement=True, split_text=True, max_split_batch=4,
-              params_refine_text: RefineTextParams = RefineTextParams(), params_infer_code: InferCodeParams = InferCodeParams()):
+              params_refine_text: RefineTextParams = RefineTextParams(), params_infer_code: InferCodeParams = InferCodeParams(),
+              *, pcm16: bool = False):
         """core.py:208-270: `List[np.ndarray]` (one stripped waveform per text, or ONE concatenated waveform when
-        `split_text`), a generator of `np.ndarray [B, n]` chunks when `stream`, the refined text when `refine_text_only`."""
+        `split_text`), a generator of `np.ndarray [B, n]` chunks when `stream`, the refined text when `refine_text_only`.
+        `pcm16=True` (keyword-only, not in the reference): the same results as 16-bit PCM -- what the reference's callers get from
+        `float_to_int16` (tools/audio/np.py:7-11) on each returned waveform / on each row of each streamed chunk, computed on the
+        device so that half the bytes cross PCIe: `infer(t, pcm16=True)[i] == float_to_int16(infer(t)[i])` bit for bit."""
         self.context.set(False)
         if split_text and isinstance(text, str):
             if "\n" in text:
@@ -323,17 +388,22 @@ class Chat:
         if len(text) == 0:
             return []
         res_gen = self._infer(text, stream, lang, skip_refine_text, refine_text_only, use_decoder, do_text_normalization,
-                              do_homophone_replacement, split_text, max_split_batch, params_refine_text, params_infer_code)
+                              do_homophone_replacement, split_text, max_split_batch, params_refine_text, params_infer_code,
+                              pcm16=pcm16 and not refine_text_only and not (split_text and not stream))
         if stream:
             return res_gen
         if refine_text_only:
             return next(res_gen)
+        if pcm16 and not split_text:
+            return [w for wavs in res_gen for w in wavs]          # already stripped and converted, utterance by utterance, on the device
         thr = np.float32(1e-5)
         stripped = [wav[np.abs(wav) > thr] for wavs in res_gen for wav in wavs]   # sample-level strip, also mid-utterance
+        if pcm16:      # split_text: ONE concatenated waveform, hence one peak over all sentences -- converted on the host
+            return [float_to_int16(np.concatenate(stripped))]
         return [np.concatenate(stripped)] if split_text else stripped
 
     def _infer(self, text, stream, lang, skip_refine_text, refine_text_only, use_decoder, do_text_normalization,
-               do_homophone_replacement, split_text, max_split_batch, params_refine_text, params_infer_code):
+               do_homophone_replacement, split_text, max_split_batch, params_refine_text, params_infer_code, pcm16: bool = False):
         """core.py:395-503 (generator)."""
         assert self.has_loaded(use_decoder=use_decoder)
         if not isinstance(text, list):
@@ -365,7 +435,8 @@ class Chat:
             last = None
             for result in self._infer_code(batch, stream, self.device, use_decoder, params_infer_code):
                 if not stream:
-                    wavs = self.decode_to_wavs(result.hiddens if use_decoder else result.ids, use_decoder)
+                    src = result.hiddens if use_decoder else result.ids
+                    wavs = self.decode_to_pcm16(src, use_decoder) if pcm16 else self.decode_to_wavs(src, use_decoder)
                     result.destroy()
                     yield wavs
                     continue
@@ -376,11 +447,13 @@ class Chat:
                 if pass_batch_count <= params_infer_code.pass_first_n_batches:
                     continue     # the reference decodes these yields and drops the audio (core.py:482-490)
                 piece = self._stream_piece(result.hiddens if use_decoder else result.ids, length,
-                                           length + params_infer_code.stream_speed, use_decoder)
+                                           length + params_infer_code.stream_speed, use_decoder, pcm16)
                 length += piece.shape[1]
                 yield piece
             if stream and last is not None:
                 new_wavs = self._stream_piece(last.hiddens if use_decoder else last.ids, length, None, use_decoder)
                 last.destroy()
                 keep_cols = np.sum(np.abs(new_wavs) > 1e-5, axis=0) > 0
-                yield new_wavs[:, keep_cols]
+                tail = new_wavs[:, keep_cols]
+                # the last chunk is filtered by columns on the float samples first (core.py:500-503): converted on the host, row by row
+                yield np.stack([float_to_int16(r) for r in tail]) if (pcm16 and tail.shape[1]) else tail

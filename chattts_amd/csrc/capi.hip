@@ -37,8 +37,10 @@ struct ctts_gpt {
   std::vector<const void*> wqkv, wo, wgu, wd;
   std::vector<const void*> wqkv_pk, wo_pk, wgu_pk, wd_pk;   // fragment-packed copies for the decode step, or empty
   std::vector<const void*> wo_hd;                           // o_proj per attention head (perf mode), or empty
+  std::vector<const void*> wqkv_x3, wo_x3, wgu_x3, wd_x3;   // parity mode: hi | lo bf16 planes in fragment order (decode32x.hip), or empty
+  bool dec_x3 = false;         // parity mode decode on split-bf16 operands (env CTTS_D32_EXACT=1: the f32 MFMA kernels of decode32.hip)
   bool qkv_att = false;        // perf mode decode, <= 64 rows: QKV + attention as ONE launch (gpt.hip qkv_attention_k); env CTTS_QKV_ATT=1, OFF by default
-  bool att_oproj = false;      // perf mode decode: o_proj + residual folded into the attention launch (env CTTS_ATT_OPROJ=0: separate launches)
+  bool att_oproj = false;      // perf mode decode: o_proj + residual folded into the attention launch -- OPT-IN, env CTTS_ATT_OPROJ=1 (default: separate launches)
   bool dec_packed = false;     // perf mode (bf16 weights): decode.hip
   bool dec_packed32 = false;   // parity mode (f32 weights): decode32.hip
   bool heads_packed = false;   // heads GEMM on packed f32 operands (decode32.hip), both modes
@@ -68,7 +70,7 @@ struct ctts_gpt {
 static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 #define ATT_CUS_MAX 512   // upper bound of compute units the attention split state is sized for
 #define QA_LAYERS_MAX 32  // layers the arrival words of the fused QKV + attention launches are sized for
-#define QA_STRIDE 1088    // = HO_STRIDE (decode_dev.hpp): ints between two arrival words
+#define QA_STRIDE HO_STRIDE   // kernels.hpp: ints between two arrival words
 struct GptWs {
   float *x, *qkv, *ao, *act, *hfin, *logits, *ssq;
   uint16_t* xb;  // bf16 copy of the residual stream (perf mode); ao / act are reused as bf16 buffers there
@@ -82,7 +84,7 @@ struct GptWs {
   int32_t* att_cnt;
   int32_t* row_map;   // device-side compaction: this step's compact row -> utterance map (written by the step's first kernel)
   float* rope_cs;     // [Bp][64] cos[32] | sin[32] of every decode row's position, written by the step's first kernel (fused QKV + attention)
-  int32_t* qa_flag;   // fused QKV + attention launches: arrival words [QA_LAYERS_MAX][8 copies][16] (12 heads used), zeroed by the step's first kernel
+  int32_t* qa_flag;   // fused QKV + attention launches: arrival words [QA_LAYERS_MAX][12 heads], QA_STRIDE ints apart, zeroed by the step's first kernel
   float* op_part;     // attention + o_proj in one launch: [Bp][12][768] partials of the (utterance, head) units ...
   int32_t* op_cnt;    // ... and the rows' arrival counters, RIGHT BEHIND att_cnt: one memset zeroes both (cnt_bytes)
   size_t op_part_bytes;
@@ -150,6 +152,14 @@ extern "C" int ctts_gpt_create(ctts_gpt** out, const ctts_gpt_weights* w) {
     g->dec_packed32 = on && w->weight_dtype != CTTS_BF16 && w->kv_dtype != CTTS_BF16;
   }
   { const char* e = getenv("CTTS_DEC_PACKED"); g->heads_packed = w->heads_pk != nullptr && !(e && atoi(e) == 0); }
+  if (w->wqkv_x3 && w->wo_x3 && w->wgu_x3 && w->wd_x3 && g->dec_packed32) {
+    g->wqkv_x3.assign(w->wqkv_x3, w->wqkv_x3 + L);
+    g->wo_x3.assign(w->wo_x3, w->wo_x3 + L);
+    g->wgu_x3.assign(w->wgu_x3, w->wgu_x3 + L);
+    g->wd_x3.assign(w->wd_x3, w->wd_x3 + L);
+    const char* e = getenv("CTTS_D32_EXACT");
+    g->dec_x3 = !(e && atoi(e) == 1);
+  }
   if (w->wo_hd && g->dec_packed) {
     g->wo_hd.assign(w->wo_hd, w->wo_hd + L);
     // OFF by default: measured on the C3 bench the fused launch costs what the two launches cost (13.9 us vs 9.07 + 4.87) and the step
@@ -368,7 +378,41 @@ static int run_step(ctts_gpt* g, const ctts_gen_state* s, int q_per_b, hipStream
     f.C32 = ws.x; f.ldc = HID; f.Cb = ws.xb; f.ldcb = HID; f.ssq_out = ws.ssq;
     { Prof p(g, 6, st, prof_ok); CK(launch_gemm_fast(f, st)); }
   }
-  const bool packed32 = !fast && dec && g->dec_packed32;   // parity mode decode step on fragment-packed f32 operands (decode32.hip)
+  // parity mode decode step on SPLIT-bf16 operands (decode32x.hip): hi | lo planes in the buffers the f32 kernels use for their packed
+  // operands (same bytes: 2 planes x 2 B), the heads' packed f32 operand in ws.hfinp
+  const bool x3 = !fast && dec && g->dec_packed32 && g->dec_x3;
+  const size_t Bp16 = ((size_t)M + 15) / 16 * 16;
+  for (int l = 0; x3 && l < g->w.n_layers; ++l) {
+    void* kc = (char*)s->kcache + kv_layer * l;
+    void* vc = (char*)s->vcache + kv_layer * l;
+    uint16_t* xpx = reinterpret_cast<uint16_t*>(ws.xp32);
+    uint16_t* aopx = reinterpret_cast<uint16_t*>(ws.aop32);
+    uint16_t* actx = reinterpret_cast<uint16_t*>(ws.actp32);
+    Dec32xArgs d;
+    memset(&d, 0, sizeof(d));
+    d.M = M; d.eps = g->w.rms_eps; d.n_active = nact;
+    // RMSNorm (gain folded into the weights, 1 / rms on the accumulator) + QKV + RoPE + KV append
+    d.Ap = xpx; d.a_plane = Bp16 * HID; d.Wp = (const uint16_t*)g->wqkv_x3[l]; d.w_plane = (size_t)3 * HID * HID; d.N = 3 * HID; d.K = HID;
+    d.rms = 1; d.X = ws.x; d.ldx = HID; d.epi = D32_EPI_QKV_ROPE; d.C = ws.qkv; d.ldc = 3 * HID; d.desc = ws.desc;
+    d.cos_t = g->w.rope_cos; d.sin_t = g->w.rope_sin; d.kc = (float*)kc; d.vc = (float*)vc; d.cmax = cmax;
+    { Prof p(g, 1, st, prof_ok); CK(launch_gemm_dec32x(d, st)); }
+    rm.x3_plane = Bp16 * HID;
+    { Prof p(g, 3, st, prof_ok); CK(launch_attention(ws.qkv, kc, vc, kt, cmax, aopx, 4, rm, M, st)); }
+    // o_proj + residual
+    d.Ap = aopx; d.a_plane = Bp16 * HID; d.Wp = (const uint16_t*)g->wo_x3[l]; d.w_plane = (size_t)HID * HID; d.N = HID; d.rms = 0; d.X = nullptr;
+    d.epi = EPI_RES; d.C = ws.x; d.ldc = HID; d.res = ws.x; d.ldr = HID; d.Cp = xpx; d.c_plane = Bp16 * HID; d.kch_out = HID / 32;
+    { Prof p(g, 4, st, prof_ok); CK(launch_gemm_dec32x(d, st)); }
+    // RMSNorm + gate/up + SiLU*up
+    d.Ap = xpx; d.a_plane = Bp16 * HID; d.Wp = (const uint16_t*)g->wgu_x3[l]; d.w_plane = (size_t)2 * INTER * HID; d.N = INTER; d.rms = 1; d.X = ws.x;
+    d.epi = EPI_SILU_MUL; d.C = nullptr; d.res = nullptr; d.Cp = actx; d.c_plane = Bp16 * INTER; d.kch_out = INTER / 32;
+    { Prof p(g, 5, st, prof_ok); CK(launch_gemm_dec32x(d, st)); }
+    // down_proj + residual (last layer: also the packed f32 rows the fused final-norm + heads launch reads)
+    d.Ap = actx; d.a_plane = Bp16 * INTER; d.Wp = (const uint16_t*)g->wd_x3[l]; d.w_plane = (size_t)HID * INTER; d.N = HID; d.K = INTER; d.rms = 0;
+    d.X = nullptr; d.epi = EPI_RES; d.C = ws.x; d.ldc = HID; d.res = ws.x; d.ldr = HID; d.Cp = xpx; d.c_plane = Bp16 * HID; d.kch_out = HID / 32;
+    d.Cp32 = (fuse_fnorm && l == g->w.n_layers - 1) ? ws.hfinp : nullptr; d.kch32_out = HID / 16;
+    { Prof p(g, 6, st, prof_ok); CK(launch_gemm_dec32x(d, st)); }
+  }
+  const bool packed32 = !fast && dec && g->dec_packed32 && !x3;   // parity mode decode step on fragment-packed f32 operands (decode32.hip)
   for (int l = 0; packed32 && l < g->w.n_layers; ++l) {
     void* kc = (char*)s->kcache + kv_layer * l;
     void* vc = (char*)s->vcache + kv_layer * l;
@@ -427,7 +471,7 @@ static int run_step(ctts_gpt* g, const ctts_gen_state* s, int q_per_b, hipStream
     d.C = ws.x; d.ldc = HID; d.res = ws.x; d.ldr = HID; d.Cp = ws.xp32; d.kch_out = HID / 16;
     CK(launch_gemm_pre32(d, nullptr, st));
   }
-  for (int l = 0; !fast && !packed32 && !pre32 && l < g->w.n_layers; ++l) {
+  for (int l = 0; !fast && !packed32 && !pre32 && !x3 && l < g->w.n_layers; ++l) {
     void* kc = (char*)s->kcache + kv_layer * l;
     void* vc = (char*)s->vcache + kv_layer * l;
     GemmArgs a;
@@ -458,7 +502,7 @@ static int run_step(ctts_gpt* g, const ctts_gen_state* s, int q_per_b, hipStream
     const int nlog = s->infer_text ? g->w.n_text : NVQ * NAUDIO;
     Dec32Args d;
     memset(&d, 0, sizeof(d));
-    d.Ap = ws.xp32; d.Wp = s->infer_text ? g->w.head_text_pk : g->w.heads_pk; d.M = B; d.N = (nlog + 15) / 16 * 16; d.K = HID; d.n_active = nact;
+    d.Ap = x3 ? ws.hfinp : ws.xp32; d.Wp = s->infer_text ? g->w.head_text_pk : g->w.heads_pk; d.M = B; d.N = (nlog + 15) / 16 * 16; d.K = HID; d.n_active = nact;
     d.epi = EPI_STORE; d.C = ws.logits; d.ldc = nlog; d.n_cols = nlog;
     d.fnorm = 1; d.norm_w = g->w.norm; d.eps = g->w.rms_eps; d.desc = ws.desc; d.hid = s->hiddens; d.hid_cap = s->hid_cap ? s->hid_cap : s->max_new;
     d.T = s->T; d.prompt_len = s->prompt_len;
@@ -540,13 +584,17 @@ static int decode_body(ctts_gpt* g, const ctts_gen_state* s, hipStream_t st, boo
   { Prof p(g, 0, st, prof_ok); const bool fast = g->w.weight_dtype == CTTS_BF16;
     const bool packed = fast && g->dec_packed;
     const bool dc = dev_compact(g, s);
-    StepPrep sp{ws.desc, s->kv_start, g->skip_finished ? s->finish : nullptr, packed ? 1 : 0, (!fast && g->dec_packed32) ? ws.xp32 : nullptr,
+    const bool x3 = !fast && g->dec_packed32 && g->dec_x3;   // split-bf16 parity mode: the residual rows as hi | lo planes (decode32x.hip)
+    StepPrep sp{ws.desc, s->kv_start, g->skip_finished ? s->finish : nullptr, (packed || x3) ? 1 : 0, (!fast && g->dec_packed32 && !x3) ? ws.xp32 : nullptr,
                 dc ? ws.row_map : nullptr,
                 dc ? const_cast<int32_t*>(s->n_active) : nullptr, dc ? s->order : nullptr,
-                (packed && g->qkv_att) ? ws.rope_cs : nullptr, g->w.rope_cos, g->w.rope_sin,
-                (packed && g->qkv_att) ? ws.qa_flag : nullptr, g->w.n_layers * NHEAD, QA_STRIDE};
+                (packed && g->qkv_att && g->w.n_layers <= QA_LAYERS_MAX) ? ws.rope_cs : nullptr, g->w.rope_cos, g->w.rope_sin,
+                // the arrival words are sized for QA_LAYERS_MAX layers: the same predicate as `fuse_qa` in run_step (a deeper model
+                // never takes the fused launch and must not zero past the carve either)
+                (packed && g->qkv_att && g->w.n_layers <= QA_LAYERS_MAX) ? ws.qa_flag : nullptr, g->w.n_layers * NHEAD, QA_STRIDE};
     const int32_t* nact0 = (!g->skip_finished && s->row_map == nullptr) ? nullptr : s->n_active;
-    uint16_t* xb = fast ? (packed ? ws.xp : ws.xb) : nullptr;
+    uint16_t* xb = fast ? (packed ? ws.xp : ws.xb) : x3 ? reinterpret_cast<uint16_t*>(ws.xp32) : nullptr;
+    if (x3) sp.xb_lo_plane = ((size_t)s->B + 15) / 16 * 16 * HID;
     if (s->infer_text)
       CK(launch_embed_text(g->w.emb_text, g->w.n_text, s->ids_buf, s->cap ? s->cap : s->T + s->max_new, s->len, ws.x, xb,
                            fast ? ws.ssq : nullptr, s->B, s->row_map, nact0, st, &sp));
@@ -866,6 +914,18 @@ extern "C" int ctts_k_gemm_dec32(const float* Ap, const float* Wp, int32_t M, in
   d.Ap = Ap; d.Wp = Wp; d.M = M; d.N = N; d.K = K; d.n_active = n_active; d.X = X; d.ldx = ldx; d.norm_w = norm_w; d.eps = eps; d.epi = epi;
   d.C = C; d.ldc = ldc; d.res = res; d.ldr = ldr; d.Cp = Cp; d.kch_out = kch_out; d.force_mb = force_mb;
   CK(launch_gemm_dec32(d, (hipStream_t)stream));
+  return 0;
+}
+extern "C" int ctts_k_gemm_dec32x(const uint16_t* Ap, int64_t a_plane, const uint16_t* Wp, int64_t w_plane, int32_t M, int32_t N, int32_t K,
+                                  const int32_t* n_active, const float* X, int32_t ldx, float eps, int32_t epi, float* C, int32_t ldc,
+                                  const float* res, int32_t ldr, uint16_t* Cp, int64_t c_plane, int32_t kch_out, float* Cp32, int32_t force_mb,
+                                  void* stream) {
+  Dec32xArgs d;
+  memset(&d, 0, sizeof(d));
+  d.Ap = Ap; d.a_plane = (size_t)a_plane; d.Wp = Wp; d.w_plane = (size_t)w_plane; d.M = M; d.N = N; d.K = K; d.n_active = n_active;
+  d.rms = X != nullptr; d.X = X; d.ldx = ldx; d.eps = eps; d.epi = epi; d.C = C; d.ldc = ldc; d.res = res; d.ldr = ldr;
+  d.Cp = Cp; d.c_plane = (size_t)c_plane; d.kch_out = kch_out; d.Cp32 = Cp32; d.kch32_out = N / 16; d.force_mb = force_mb;
+  CK(launch_gemm_dec32x(d, (hipStream_t)stream));
   return 0;
 }
 extern "C" const char* ctts_k_dec32_last_variant(void) { return dec32_last_variant(); }

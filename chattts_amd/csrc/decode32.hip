@@ -33,6 +33,39 @@
 #include "common.hpp"
 #include "kernels.hpp"
 
+// The four v_mfma_f32_16x16x4_f32 steps of one 16-wide k chunk.  Probe builds (python -m chattts_amd.build --variant emux3
+// -DCTTS_D32_EMU_X3=1, tools/x3_sensitivity_probe.py): the ARITHMETIC of split-bf16 operands emulated on the f32 matrix pipe -- both
+// operands rounded to hi + lo bf16 planes (16-17 significant bits), the product taken without its lo * lo term, i.e. exactly what
+// three bf16 MFMAs on those planes would sum -- to price VERDICT r4 item 4 (do the reference's token ids survive it?) before any
+// kernel is written.
+#ifndef CTTS_D32_EMU_X3
+#define CTTS_D32_EMU_X3 0
+#endif
+__device__ __forceinline__ f32x4 mfma4_f32(const float4 a, const float4 b, f32x4 c) {
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, c, 0, 0, 0);
+  return c;
+}
+#if CTTS_D32_EMU_X3
+__device__ __forceinline__ void x3_split(const float x, float& s, float& lo) {
+  const float hi = bf16_to_f32(f32_to_bf16(x));
+  lo = bf16_to_f32(f32_to_bf16(x - hi));
+  s = hi + lo;   // exact: 16 significant bits
+}
+__device__ __forceinline__ f32x4 mfma4_proj(const float4 a, const float4 b, f32x4 c) {
+  float4 as, al, bs, bl;
+  x3_split(a.x, as.x, al.x); x3_split(a.y, as.y, al.y); x3_split(a.z, as.z, al.z); x3_split(a.w, as.w, al.w);
+  x3_split(b.x, bs.x, bl.x); x3_split(b.y, bs.y, bl.y); x3_split(b.z, bs.z, bl.z); x3_split(b.w, bs.w, bl.w);
+  c = mfma4_f32(as, bs, c);
+  al.x = -al.x; al.y = -al.y; al.z = -al.z; al.w = -al.w;
+  return mfma4_f32(al, bl, c);     // - lo * lo: the term three bf16 MFMAs never form
+}
+#else
+__device__ __forceinline__ f32x4 mfma4_proj(const float4 a, const float4 b, f32x4 c) { return mfma4_f32(a, b, c); }
+#endif
+
 constexpr int D32_U = 6;   // k chunks of 16 per wave and round: D32_U * (NACC + NMB) 16-byte loads in flight per lane
 
 template <int NMB, int MBT, bool RMS, int EPI>
@@ -165,10 +198,7 @@ __device__ __forceinline__ void dec32_body(const Dec32Args& a, const int M, cons
         for (int na = 0; na < NACC; ++na) {
           const float4 b = *reinterpret_cast<const float4*>(&wf[na][j]);
           f32x4 c = acc[na][mb];
-          c = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b.x, c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b.y, c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b.z, c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b.w, c, 0, 0, 0);
+          c = mfma4_proj(a0, b, c);
           acc[na][mb] = c;
         }
       }
@@ -330,10 +360,7 @@ __global__ __launch_bounds__(256) void gemm_dec32_m16_k(Dec32Args a) {
       for (int na = 0; na < NACC; ++na) {
         const float4 b = *reinterpret_cast<const float4*>(&s.w[na][j]);
         f32x4 c = acc[na];
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b.x, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b.y, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b.z, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b.w, c, 0, 0, 0);
+        c = mfma4_proj(a0, b, c);
         acc[na] = c;
       }
     }
@@ -470,10 +497,7 @@ __global__ __launch_bounds__(256, 3) void gemm_dec32_rms16_k(Dec32Args a) {
       for (int na = 0; na < NACC; ++na) {
         const float4 b = *reinterpret_cast<const float4*>(&wf[na][j]);
         f32x4 c = acc[na];
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b.x, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b.y, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b.z, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b.w, c, 0, 0, 0);
+        c = mfma4_proj(a0, b, c);
         acc[na] = c;
       }
     }

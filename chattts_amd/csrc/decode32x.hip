@@ -1,0 +1,298 @@
+// Decode-step projections of the GPT path in the float32 PARITY mode on SPLIT-bf16 operands (round 5).
+//
+// Reference op: the four nn.Linear calls of a HF Llama decoder layer reached from /root/reference/ChatTTS/model/gpt.py:419-427
+// (in-tree twin /root/reference/examples/onnx/modeling_llama.py:415-417 q/k/v_proj, :500 o_proj, :293 gate/up/down) with the
+// RMSNorm of :76-84 as prologue and the residual add / SiLU(gate)*up as epilogue -- float32 in the reference.
+//
+// Why: the parity mode (token ids bit-identical to the reference's CPU run) multiplied on v_mfma_f32_16x16x4_f32 -- 256 flop per
+// clock and CU, a sixteenth of the bf16 rate: 7.7 us of matrix-pipe time per layer at batch 64 before a byte of latency
+// (decode32.hip).  Here every operand is held as TWO bf16 planes, x = hi + lo with hi = bf16(x), lo = bf16(x - hi)
+// (16-17 significant bits), and a product is three bf16 MFMAs, lo*hi + hi*lo + hi*hi, accumulated in float32 (the lo*lo term, 2^-18
+// of the product, is dropped) -- the arithmetic the acoustic decoder's dense layers have used since round 1 (codec_gemm.hip).  The
+// bytes are the float32 bytes (2 x 2 instead of 4 per value), the matrix pipe runs at 3/16 of the f32 cost.
+//
+// Parity: NOT bit-identical to gemm_dec32_k; the bar of this mode is "the reference's token ids on every golden".  Priced before it
+// was built: the same arithmetic EMULATED inside the f32 kernels (build variant emux3, decode32.hip mfma4_proj) reproduces the
+// reference's ids on the bench workload's 85,752 draws and on every reference-generated golden (profiles/r5d_x3_emulation.log); the
+// e2e goldens run in this mode (tests/test_gpu_e2e.py) and bench.py's parity leg compares its sha256 with the reference's.
+// CTTS_D32_EXACT=1 keeps the f32 MFMA kernels.
+//
+// Layout: a plane is the bf16 fragment order of decode.hip, [rows/16][K/32][lane = (k%32)/8 * 16 + row%16][k%8]: one contiguous KiB
+// per (16-row tile, 32-wide k chunk) in exactly the lane order v_mfma_f32_16x16x32_bf16 wants; the lo plane lies `plane` elements
+// behind the hi plane.  Weights are split once at load (engine.py pack_frag_x3) with the RMSNorm gain folded in (W' = W diag(g), as
+// the perf mode does): x g / rms . W = (x . W') / rms, so the activations reach the matrix core un-normalised and the row's 1 / rms
+// -- taken from the float32 residual rows in gemm_skinny_k's order (common.hpp wave_rows_rstd_768), the same bits the f32 kernels
+// use -- scales the accumulator.  Activations are split by their producers: embed_codes_k, attention_k (x3p_t output), the RES /
+// SILU epilogues below.
+//
+// One kernel body, as decode32.hip's generic one: a workgroup = 16 output columns x (16 NMB) rows, its 4 waves split K into
+// contiguous quarters, all loads of a round are issued before the first MFMA, the K partials meet in LDS and are added in the fixed
+// order ((w0 + w1) + w2) + w3.
+#include <stdlib.h>
+
+#include "common.hpp"
+#include "kernels.hpp"
+
+template <int MBT> struct DxU { static constexpr int v = MBT == 1 ? 6 : 3; };   // k chunks of 32 per wave and round, by the KERNEL's row tiles (known before the live-row count)
+
+__device__ __forceinline__ void x3_store(uint16_t* __restrict__ hi_at, const size_t plane, const float v) {
+  const bf16_t h = f32_to_bf16(v);
+  hi_at[0] = h;
+  hi_at[plane] = f32_to_bf16(v - bf16_to_f32(h));
+}
+
+template <int NMB, int MBT, bool RMS, int EPI>
+__device__ __forceinline__ void dec32x_body(const Dec32xArgs& a, const int M, const int tile, const int mt0,
+                                            u128 (&wh)[(EPI == EPI_SILU_MUL) ? 2 : 1][DxU<MBT>::v], u128 (&wl)[(EPI == EPI_SILU_MUL) ? 2 : 1][DxU<MBT>::v],
+                                            float (*red)[(EPI == EPI_SILU_MUL) ? 2 : 1][MBT][64][4], float* rstd_s) {
+  constexpr int NACC = (EPI == EPI_SILU_MUL) ? 2 : 1;
+  constexpr int U = DxU<MBT>::v;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 15, g = lane >> 4;
+  const int n0 = tile * 16, m0 = mt0 * 16;
+  const int N = a.N, K = a.K, KCH = K >> 5;
+
+  constexpr int PPW = NMB >= 3 ? 4 : NMB;
+  constexpr int NF = NMB >= 3 ? NMB : 4;
+  const int fmb = (wave * PPW) >> 2, fr0 = (wave * PPW) & 3;   // meaningful for wave < NF
+  float pre0[PPW];  // RES: residual, requested before the operand loads
+#pragma unroll
+  for (int q = 0; q < PPW; ++q) pre0[q] = 0.f;
+  if (EPI == EPI_RES && wave < NF) {
+#pragma unroll
+    for (int q = 0; q < PPW; ++q) {
+      const int row = min(m0 + 16 * fmb + 4 * g + fr0 + q, M - 1);
+      pre0[q] = a.res[(size_t)row * a.ldr + n0 + li];
+    }
+  }
+  // QKV_ROPE tiles (weight rows permuted by the loader, engine.py rope_row_perm): see decode32.hip
+  const int sect = n0 / 768, hcol = n0 % 768, head = hcol >> 6, t4 = (hcol & 63) >> 4;
+  const int dlo = 8 * t4 + (li & 7);
+  RowDesc rd[PPW];
+  float rc[PPW], rsn[PPW];
+  if (EPI == D32_EPI_QKV_ROPE && wave < NF) {
+#pragma unroll
+    for (int q = 0; q < PPW; ++q) {
+      rd[q] = a.desc[min(m0 + 16 * fmb + 4 * g + fr0 + q, M - 1)];
+      rc[q] = a.cos_t[rd[q].pos * 32 + dlo];
+      rsn[q] = a.sin_t[rd[q].pos * 32 + dlo];
+    }
+  }
+
+  const int nper = KCH / 4;   // chunks per wave (launcher guarantees nper % U == 0); wave w owns the contiguous quarter w
+  const u128* wp = reinterpret_cast<const u128*>(a.Wp) + ((size_t)tile * KCH + wave * nper) * 64 + lane;
+  const u128* wp2 = wp + (size_t)(N >> 4) * KCH * 64;  // SILU_MUL: the "up" tile of the same columns
+  const u128* ap = reinterpret_cast<const u128*>(a.Ap) + ((size_t)mt0 * KCH + wave * nper) * 64 + lane;
+  const size_t wpl = a.w_plane >> 3, apl = a.a_plane >> 3;   // plane strides in 16-byte units
+  const bool w_once = a.w_nt && gridDim.y == 1;
+  u128 ah[NMB][U], al[NMB][U];
+  auto load_a = [&](const int i) {
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        ah[mb][j] = load16(ap + ((size_t)mb * KCH + i + j) * 64);
+        al[mb][j] = load16(ap + apl + ((size_t)mb * KCH + i + j) * 64);
+      }
+  };
+  load_a(0);   // before the prologue's row loads: the statistics cost no extra round trip
+  if (RMS) {
+    // 1 / rms of the 16 NMB rows, gemm_skinny_k's arithmetic (the same bits the f32 kernels use): K = 768 only
+#pragma unroll
+    for (int r0 = 0; r0 < 16 * NMB; r0 += 16) {
+      const float* rows[4];
+      float rstd[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) rows[q] = a.X + (size_t)min(m0 + r0 + wave + 4 * q, M - 1) * a.ldx;
+      wave_rows_rstd_768<4>(rows, a.eps, lane, rstd);
+      if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rstd_s[r0 + wave + 4 * q] = rstd[q];
+      }
+    }
+  }
+
+  f32x4 acc[NACC][NMB];
+#pragma unroll
+  for (int na = 0; na < NACC; ++na)
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb) acc[na][mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int i = 0; i < nper; i += U) {
+    if (i > 0) {   // the first round's weight fragments were requested at kernel entry (before *n_active was known)
+      if (w_once) {
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+          wh[0][j] = load16_nt(wp + (size_t)(i + j) * 64);
+          wl[0][j] = load16_nt(wp + wpl + (size_t)(i + j) * 64);
+          if (NACC == 2) { wh[1][j] = load16_nt(wp2 + (size_t)(i + j) * 64); wl[1][j] = load16_nt(wp2 + wpl + (size_t)(i + j) * 64); }
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+          wh[0][j] = load16(wp + (size_t)(i + j) * 64);
+          wl[0][j] = load16(wp + wpl + (size_t)(i + j) * 64);
+          if (NACC == 2) { wh[1][j] = load16(wp2 + (size_t)(i + j) * 64); wl[1][j] = load16(wp2 + wpl + (size_t)(i + j) * 64); }
+        }
+      }
+      load_a(i);
+    }
+    // every load of the round in flight before the first MFMA (hipcc otherwise sinks each load next to its use)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < U; ++j)
+#pragma unroll
+      for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+        for (int na = 0; na < NACC; ++na) {
+          f32x4 c = acc[na][mb];   // small terms first
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&al[mb][j]), *reinterpret_cast<const bf16x8*>(&wh[na][j]), c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&ah[mb][j]), *reinterpret_cast<const bf16x8*>(&wl[na][j]), c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&ah[mb][j]), *reinterpret_cast<const bf16x8*>(&wh[na][j]), c, 0, 0, 0);
+          acc[na][mb] = c;
+        }
+  }
+
+#pragma unroll
+  for (int na = 0; na < NACC; ++na)
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb) *reinterpret_cast<f32x4*>(&red[wave][na][mb][lane][0]) = acc[na][mb];
+  __syncthreads();   // (also publishes rstd_s)
+  if (wave >= NF) return;
+
+  float t[4][NACC][PPW];   // the 4 waves' partials of this wave's outputs
+#pragma unroll
+  for (int w = 0; w < 4; ++w)
+#pragma unroll
+    for (int na = 0; na < NACC; ++na) {
+      if constexpr (PPW == 4) {
+        *reinterpret_cast<f32x4*>(t[w][na]) = *reinterpret_cast<const f32x4*>(&red[w][na][fmb][lane][0]);
+      } else if constexpr (PPW == 2) {
+        *reinterpret_cast<float2*>(t[w][na]) = *reinterpret_cast<const float2*>(&red[w][na][fmb][lane][fr0]);
+      } else {
+        t[w][na][0] = red[w][na][fmb][lane][fr0];
+      }
+    }
+
+  const int col = n0 + li;
+#pragma unroll
+  for (int q = 0; q < PPW; ++q) {
+    const int rloc = 16 * fmb + 4 * g + fr0 + q;   // C/D map of the 16x16 MFMA: col = lane & 15, row = 4 (lane >> 4) + reg
+    const int row = m0 + rloc;
+    float v = ((t[0][0][q] + t[1][0][q]) + t[2][0][q]) + t[3][0][q];   // fixed order
+    float u = 0.f;
+    if (EPI == EPI_SILU_MUL) u = ((t[0][NACC - 1][q] + t[1][NACC - 1][q]) + t[2][NACC - 1][q]) + t[3][NACC - 1][q];
+    if (RMS) {
+      const float rs = rstd_s[rloc];
+      v *= rs;
+      u *= rs;
+    }
+    if (EPI == EPI_SILU_MUL) v = silu_f(v) * u;
+    else if (EPI == EPI_RES) v = pre0[q] + v;
+    if (EPI == D32_EPI_QKV_ROPE) {   // q -> roped, qkv buffer; k -> roped, KV cache; v -> KV cache  (rope_append_k, gpt.hip)
+      const float other = __shfl_xor(v, 8, 64);   // every lane of the wave is here (rows are skipped below, not above)
+      const bool hi = li >= 8;
+      const float roped = hi ? rope_hi(other, v, rc[q], rsn[q]) : rope_lo(v, other, rc[q], rsn[q]);
+      const int d = dlo + (hi ? 32 : 0);
+      if (row < M && rd[q].b >= 0) {
+        const size_t cbase = (((size_t)rd[q].b * 12 + head) * a.cmax + rd[q].slot) * 64;
+        if (sect == 0) a.C[(size_t)row * a.ldc + head * 64 + d] = roped;
+        else if (sect == 1) a.kc[cbase + d] = roped;
+        else a.vc[cbase + (hcol & 63) + li] = v;
+      }
+      continue;
+    }
+    if (row >= M) continue;
+    if (EPI == EPI_RES) a.C[(size_t)row * a.ldc + col] = v;
+    if (a.Cp != nullptr) x3_store(a.Cp + pk_off(row, col, a.kch_out), a.c_plane, v);
+    if (EPI == EPI_RES && a.Cp32 != nullptr) a.Cp32[pk32_off(row, col, a.kch32_out)] = v;
+  }
+}
+
+template <int MBT, bool RMS, int EPI>
+__global__ __launch_bounds__(256) void gemm_dec32x_k(Dec32xArgs a) {
+  constexpr int NACC = (EPI == EPI_SILU_MUL) ? 2 : 1;
+  constexpr int U = DxU<MBT>::v;
+  __shared__ __attribute__((aligned(16))) float red[4][NACC][MBT][64][4];
+  __shared__ float rstd_s[16 * MBT];
+  CTTS_PROBE_RETURN();
+
+  const int tile = blockIdx.x, mt0 = blockIdx.y * MBT;
+  // the weight fragments of the first round depend on nothing but the kernel arguments: request them before the live-row count (a
+  // dependent scalar load) is known
+  u128 wh[NACC][U], wl[NACC][U];
+  {
+    const int KCH = a.K >> 5, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nper = KCH / 4;
+    const u128* wp = reinterpret_cast<const u128*>(a.Wp) + ((size_t)tile * KCH + wave * nper) * 64 + lane;
+    const u128* wp2 = wp + (size_t)(a.N >> 4) * KCH * 64;
+    const size_t wpl = a.w_plane >> 3;
+    if (a.w_nt && gridDim.y == 1) {
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        wh[0][j] = load16_nt(wp + (size_t)j * 64); wl[0][j] = load16_nt(wp + wpl + (size_t)j * 64);
+        if (NACC == 2) { wh[1][j] = load16_nt(wp2 + (size_t)j * 64); wl[1][j] = load16_nt(wp2 + wpl + (size_t)j * 64); }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        wh[0][j] = load16(wp + (size_t)j * 64); wl[0][j] = load16(wp + wpl + (size_t)j * 64);
+        if (NACC == 2) { wh[1][j] = load16(wp2 + (size_t)j * 64); wl[1][j] = load16(wp2 + wpl + (size_t)j * 64); }
+      }
+    }
+  }
+  const int M = a.n_active ? min(*a.n_active, a.M) : a.M;   // live (compact) rows
+  if (mt0 * 16 >= M) return;
+  const int nmb = min(MBT, (M - mt0 * 16 + 15) >> 4);
+  if constexpr (MBT == 1) {
+    dec32x_body<1, MBT, RMS, EPI>(a, M, tile, mt0, wh, wl, red, rstd_s);
+  } else if constexpr (MBT == 2) {
+    if (nmb == 1) dec32x_body<1, MBT, RMS, EPI>(a, M, tile, mt0, wh, wl, red, rstd_s);
+    else dec32x_body<2, MBT, RMS, EPI>(a, M, tile, mt0, wh, wl, red, rstd_s);
+  } else {
+    if (nmb == 1) dec32x_body<1, MBT, RMS, EPI>(a, M, tile, mt0, wh, wl, red, rstd_s);
+    else if (nmb == 2) dec32x_body<2, MBT, RMS, EPI>(a, M, tile, mt0, wh, wl, red, rstd_s);
+    else if (nmb == 3) dec32x_body<3, MBT, RMS, EPI>(a, M, tile, mt0, wh, wl, red, rstd_s);
+    else dec32x_body<4, MBT, RMS, EPI>(a, M, tile, mt0, wh, wl, red, rstd_s);
+  }
+}
+
+static int env_i(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
+template <int MBT>
+static hipError_t dec32x_dispatch(const Dec32xArgs& a, hipStream_t st) {
+  const int mt = (a.M + 15) / 16;
+  dim3 grid(a.N / 16, (mt + MBT - 1) / MBT), block(256);
+  if (a.epi == EPI_RES && !a.rms) CTTS_LAUNCH((gemm_dec32x_k<MBT, false, EPI_RES>), grid, block, st, a);
+  else if (a.epi == EPI_SILU_MUL && a.rms) CTTS_LAUNCH((gemm_dec32x_k<MBT, true, EPI_SILU_MUL>), grid, block, st, a);
+  else if (a.epi == D32_EPI_QKV_ROPE && a.rms) CTTS_LAUNCH((gemm_dec32x_k<MBT, true, D32_EPI_QKV_ROPE>), grid, block, st, a);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+hipError_t launch_gemm_dec32x(const Dec32xArgs& a_in, hipStream_t st) {
+  Dec32xArgs a = a_in;
+  static int nt = -1, mb_qkv = 4, mb_silu = 4, mb_o = 1, mb_down = 1;
+  if (nt < 0) {
+    nt = env_i("CTTS_W_NT", 1);
+    // rows per workgroup (A/B knobs): the matrix pipe is no longer what these launches cost, so the RMSNorm launches take all <= 64 rows
+    // per weight tile (one pass over the weights, as the perf mode does), o / down (48 weight tiles) stay 16-row workgroups
+    mb_qkv = env_i("CTTS_D32X_MB_QKV", 4); mb_silu = env_i("CTTS_D32X_MB_SILU", 4);
+    mb_o = env_i("CTTS_D32X_MB_O", 1); mb_down = env_i("CTTS_D32X_MB_DOWN", 1);
+  }
+  a.w_nt = nt;
+  // K: chunks of 32, 4 waves, rounds of 6 (3) chunks
+  if (a.M <= 0 || a.N <= 0 || (a.N & 15) || a.K % (32 * 4 * 6) != 0 || !a.Ap || !a.Wp || (a.a_plane & 7) || (a.w_plane & 7) || (a.c_plane & 7))
+    return hipErrorInvalidValue;
+  if (a.rms && (a.X == nullptr || (a.ldx & 3) || a.K != 768)) return hipErrorInvalidValue;
+  if (a.epi == D32_EPI_QKV_ROPE && (a.N != 2304 || a.K != 768 || !a.desc || !a.kc || !a.vc || !a.C)) return hipErrorInvalidValue;
+  if (a.epi == EPI_RES && (!a.res || !a.C)) return hipErrorInvalidValue;
+  if (a.epi == EPI_SILU_MUL && !a.Cp) return hipErrorInvalidValue;
+  int mb = a.epi == EPI_SILU_MUL ? mb_silu : a.epi == EPI_RES ? (a.K > 768 ? mb_down : mb_o) : mb_qkv;
+  if (a.force_mb) mb = a.force_mb;
+  if (mb >= 4) return dec32x_dispatch<4>(a, st);
+  if (mb == 2) return dec32x_dispatch<2>(a, st);
+  return dec32x_dispatch<1>(a, st);
+}

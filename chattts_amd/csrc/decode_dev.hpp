@@ -5,9 +5,7 @@
 #include "common.hpp"
 #include "kernels.hpp"
 
-// arrival words of the fused QKV + attention launch: one int per (layer, head), HO_STRIDE ints apart (4 KiB + 256 B: neighbouring
-// words on different memory channels -- they are polled by every attention unit of the head)
-constexpr int HO_STRIDE = 1088;
+// (HO_STRIDE, the spacing of the fused QKV + attention launch's arrival words, lives in kernels.hpp: capi.hip carves the buffer with it)
 constexpr int DEC_U = 6;  // k-chunks of 32 per wave and round: DEC_U * (NACC + NMB) 16-byte loads in flight per lane
 
 template <int NMB, int MBT, int NW, bool SCALE, int EPI, bool HO = false, int U_ = DEC_U>

@@ -34,13 +34,19 @@ __device__ __forceinline__ bool row_absent(const int32_t* n_active, int m) { ret
 // emit one residual-stream row: f32, optional bf16 copy, optional 48 partial sums of squares
 // (thread t owns columns 4t..4t+3; a partial covers 16 columns = 4 consecutive threads)
 __device__ __forceinline__ void emit_row(float4 s, int t, float* __restrict__ x_row, uint16_t* __restrict__ xb_row,
-                                         float* __restrict__ ssq_row, float* __restrict__ xp32_at = nullptr) {
+                                         float* __restrict__ ssq_row, float* __restrict__ xp32_at = nullptr, size_t lo_plane = 0) {
   if (x_row) *reinterpret_cast<float4*>(x_row + t * 4) = s;
   if (xp32_at) *reinterpret_cast<float4*>(xp32_at) = s;   // columns 4t..4t+3 are one lane's 16 bytes of the packed f32 order
   if (xb_row) {
     ushort4 o;
     o.x = f32_to_bf16(s.x); o.y = f32_to_bf16(s.y); o.z = f32_to_bf16(s.z); o.w = f32_to_bf16(s.w);
     *reinterpret_cast<ushort4*>(xb_row + t * 4) = o;   // columns 4t..4t+3 share one 8-column group in either layout
+    if (lo_plane) {   // split-bf16 parity mode (decode32x.hip): the lo plane, lo = bf16(x - hi), lo_plane elements behind the hi plane
+      ushort4 l;
+      l.x = f32_to_bf16(s.x - bf16_to_f32(o.x)); l.y = f32_to_bf16(s.y - bf16_to_f32(o.y));
+      l.z = f32_to_bf16(s.z - bf16_to_f32(o.z)); l.w = f32_to_bf16(s.w - bf16_to_f32(o.w));
+      *reinterpret_cast<ushort4*>(xb_row + lo_plane + t * 4) = l;
+    }
   }
   if (ssq_row) {
     float q = (s.x * s.x + s.y * s.y) + (s.z * s.z + s.w * s.w);
@@ -143,7 +149,7 @@ __global__ __launch_bounds__(192) void embed_codes_k(const float* __restrict__ e
     if (k == 0) s = v; else { s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
   }
   emit_row(s, t, x + (size_t)m * HID, xb_row_ptr(xb, m, t, sp.xb_packed), ssq ? ssq + (size_t)m * SSQ_PARTS : nullptr,
-           sp.xp32 ? sp.xp32 + pk32_off(m, 4 * t, HID / 16) : nullptr);
+           sp.xp32 ? sp.xp32 + pk32_off(m, 4 * t, HID / 16) : nullptr, sp.xb_lo_plane);
 }
 
 static StepPrep prep_or_none(const StepPrep* p) {
@@ -271,9 +277,23 @@ template <> __device__ __forceinline__ void unpack16<bf16_t, 8>(const u128& r, f
 template <typename OT> __device__ __forceinline__ size_t pko_off(int m, int c);
 template <> __device__ __forceinline__ size_t pko_off<bf16_t>(int m, int c) { return pk_off(m, c, HID / 32); }
 template <> __device__ __forceinline__ size_t pko_off<float>(int m, int c) { return pk32_off(m, c, HID / 16); }
+// split-bf16 parity mode (decode32x.hip): the attention output as hi / lo bf16 planes in decode.hip's fragment order
+struct x3p_t { uint16_t v; };
+template <> __device__ __forceinline__ size_t pko_off<x3p_t>(int m, int c) { return pk_off(m, c, HID / 32); }
 template <typename OT> __device__ __forceinline__ void store_out(OT* p, float v);
+template <> __device__ __forceinline__ void store_out<x3p_t>(x3p_t* p, float v) { p->v = f32_to_bf16(v); }   // (never the packed path's store)
+// packed store of one output element: row m, column c
+template <typename OT> __device__ __forceinline__ void store_pko(OT* out, int m, int c, float v, size_t);
+template <> __device__ __forceinline__ void store_pko<x3p_t>(x3p_t* out, int m, int c, float v, size_t plane) {
+  uint16_t* p = reinterpret_cast<uint16_t*>(out) + pk_off(m, c, HID / 32);
+  const bf16_t h = f32_to_bf16(v);
+  p[0] = h;
+  p[plane] = f32_to_bf16(v - bf16_to_f32(h));
+}
 template <> __device__ __forceinline__ void store_out<float>(float* p, float v) { *p = v; }
 template <> __device__ __forceinline__ void store_out<bf16_t>(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+template <> __device__ __forceinline__ void store_pko<float>(float* out, int m, int c, float v, size_t) { out[pko_off<float>(m, c)] = v; }
+template <> __device__ __forceinline__ void store_pko<bf16_t>(bf16_t* out, int m, int c, float v, size_t) { out[pko_off<bf16_t>(m, c)] = f32_to_bf16(v); }
 
 // Lane-group reductions of the attention kernels without the LDS crossbar (round 5).  `__shfl_xor` lowers to ds_bpermute_b32 -- an LDS
 // round trip per step, 15 of them in a dependent chain per 32-key block, which a persistent workgroup with ONE wave per SIMD cannot
@@ -706,7 +726,10 @@ __device__ __forceinline__ void attention_body(const float* __restrict__ qkv, co
       }
       if (tid == 0) __hip_atomic_store(rm.sp_cnt + su, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
     }
-    if constexpr (!OPJ) store_out<OT>(PKO ? out + pko_off<OT>(m, h * HDIM + tid) : out + (size_t)m * HID + h * HDIM + tid, o / L);
+    if constexpr (!OPJ) {
+      if constexpr (PKO) store_pko<OT>(out, m, h * HDIM + tid, o / L, rm.x3_plane);
+      else store_out<OT>(out + (size_t)m * HID + h * HDIM + tid, o / L);
+    }
     else sm_on[tid] = f32_to_bf16(o / L);   // the same bf16 rounding the o_proj kernel's A operand had
   }
   if constexpr (OPJ) {
@@ -788,7 +811,7 @@ __global__ __launch_bounds__(64 * NW + (PF ? 64 : 0)) void attention_k(const flo
 template <typename KT, typename OT, int D>
 __global__ __launch_bounds__(256) void attention_persist_k(const float* __restrict__ qkv, const KT* __restrict__ kc, const KT* __restrict__ vc,
                                                            int cmax, OT* __restrict__ out, const RowDesc* __restrict__ desc, int n_units,
-                                                           const int32_t* __restrict__ n_active) {
+                                                           const int32_t* __restrict__ n_active, size_t x3_plane) {
   CTTS_PROBE_RETURN();
   constexpr int NW = 4;
   constexpr int DPL = KTraits<KT>::DPL;
@@ -924,7 +947,7 @@ __global__ __launch_bounds__(256) void attention_persist_k(const float* __restri
         L += sm_l[par][x] * sc;
         o += sm_acc[par][x][lane] * sc;
       }
-      store_out<OT>(out + pko_off<OT>(cm, ch * HDIM + lane), o / L);
+      store_pko<OT>(out, cm, ch * HDIM + lane, o / L, x3_plane);
     }
     mrun = -INFINITY; lrun = 0.f;
 #pragma unroll
@@ -1194,17 +1217,19 @@ hipError_t launch_attention(const float* qkv, const void* kcache, const void* vc
   // (attention_k); CTTS_ATT_G=<workgroups> (default: the device's CU count), CTTS_ATT_D=2|3|4 KV blocks per wave ring (default 4);
   // ctts_k_attention_cfg overrides all three (tests, probes)
   const int persist = att_persist_cfg(0), att_g = att_persist_cfg(1), att_d = att_persist_cfg(2);
-  if (persist && decode && rm.desc != nullptr && (out_bf16 == 2 || out_bf16 == 3) && rm.dbg == nullptr &&
+  if (persist && decode && rm.desc != nullptr && (out_bf16 == 2 || out_bf16 == 3 || out_bf16 == 4) && rm.dbg == nullptr &&
       !(out_bf16 == 2 && rm.sp_cus > 0 && rm.sp_part != nullptr && rm.sp_cnt != nullptr)) {
-    if ((out_bf16 == 2) != (kv_wt == WT_BF16)) return hipErrorInvalidValue;
+    if ((out_bf16 == 2) != (kv_wt == WT_BF16) || (out_bf16 == 4 && rm.x3_plane == 0)) return hipErrorInvalidValue;
     const int n_units = NHEAD * M;
     const dim3 pg(min(att_g, n_units));
     const int32_t* nact = rm.desc_covers_all ? nullptr : rm.n_active;
-#define ATTP(KT, D) CTTS_LAUNCH((attention_persist_k<KT, KT, D>), pg, dim3(256), st, qkv, (const KT*)kcache, (const KT*)vcache, cmax, (KT*)out, rm.desc, n_units, nact)
+#define ATTP(KT, OT, D) CTTS_LAUNCH((attention_persist_k<KT, OT, D>), pg, dim3(256), st, qkv, (const KT*)kcache, (const KT*)vcache, cmax, (OT*)out, rm.desc, n_units, nact, rm.x3_plane)
     if (out_bf16 == 2) {
-      if (att_d == 2) ATTP(bf16_t, 2); else if (att_d == 3) ATTP(bf16_t, 3); else ATTP(bf16_t, 4);
+      if (att_d == 2) ATTP(bf16_t, bf16_t, 2); else if (att_d == 3) ATTP(bf16_t, bf16_t, 3); else ATTP(bf16_t, bf16_t, 4);
+    } else if (out_bf16 == 3) {
+      if (att_d == 2) ATTP(float, float, 2); else if (att_d == 3) ATTP(float, float, 3); else ATTP(float, float, 4);
     } else {
-      if (att_d == 2) ATTP(float, 2); else if (att_d == 3) ATTP(float, 3); else ATTP(float, 4);
+      if (att_d == 2) ATTP(float, x3p_t, 2); else if (att_d == 3) ATTP(float, x3p_t, 3); else ATTP(float, x3p_t, 4);
     }
 #undef ATTP
     return hipGetLastError();
@@ -1239,6 +1264,11 @@ hipError_t launch_attention(const float* qkv, const void* kcache, const void* vc
   if (out_bf16 == 3 && !decode) {   // prefill, f32 parity mode: one wave per (row, head), output in the packed f32 order
     if (kv_wt == WT_BF16) return hipErrorInvalidValue;
     CTTS_LAUNCH((attention_k<float, 1, float, true>), grid, dim3(64), st, qkv, (const float*)kcache, (const float*)vcache, cmax, (float*)out, rm);
+    return hipGetLastError();
+  }
+  if (out_bf16 == 4) {   // decode, split-bf16 parity mode: f32 KV cache, output as hi / lo bf16 planes in decode.hip's fragment order
+    if (!decode || kv_wt == WT_BF16 || rm.x3_plane == 0) return hipErrorInvalidValue;
+    CTTS_LAUNCH_SMEM((attention_k<float, 4, x3p_t, true>), grid, dim3(256), att_lds, st, qkv, (const float*)kcache, (const float*)vcache, cmax, (x3p_t*)out, rm);
     return hipGetLastError();
   }
   if (out_bf16 == 3) {   // decode, f32 parity mode: f32 output in the fragment-packed order o_proj of decode32.hip reads
@@ -1701,7 +1731,7 @@ __global__ __launch_bounds__(192) void embed_text_k(const float* __restrict__ em
   id = min(max(id, 0), n_text - 1);
   const float4 s = *reinterpret_cast<const float4*>(emb_text + (size_t)id * HID + t * 4);
   emit_row(s, t, x + (size_t)m * HID, xb_row_ptr(xb, m, t, sp.xb_packed), ssq ? ssq + (size_t)m * SSQ_PARTS : nullptr,
-           sp.xp32 ? sp.xp32 + pk32_off(m, 4 * t, HID / 16) : nullptr);
+           sp.xp32 ? sp.xp32 + pk32_off(m, 4 * t, HID / 16) : nullptr, sp.xb_lo_plane);
 }
 
 hipError_t launch_embed_text(const float* emb_text, int n_text, const int64_t* ids_buf, int tcap, const int32_t* len, float* x,

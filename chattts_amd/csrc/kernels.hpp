@@ -44,6 +44,10 @@ extern thread_local hipEvent_t ctts_prof_start, ctts_prof_stop;
 
 enum { WT_F32 = 0, WT_BF16 = 1 };
 
+// arrival words of the fused QKV + attention launch (decode_dev.hpp, gpt.hip qkv_attention_k): one int per (layer, head), HO_STRIDE ints
+// apart (4 KiB + 256 B: neighbouring words on different memory channels -- they are polled by every attention unit of the head)
+constexpr int HO_STRIDE = 1088;
+
 // ---- GEMM  C[M,N] = epi( pro(A)[M,K] * W[N,K]^T ) ------------------------------------------
 enum GemmEpi {
   EPI_STORE = 0,       // C = acc
@@ -195,6 +199,24 @@ hipError_t launch_gemm_dec32(const Dec32Args& a, hipStream_t st);
 // rstd [M]: 1 / rms per row (launch_rows_rstd32) when a.norm_w is set.  epi: D32_EPI_QKV_ROPE | EPI_RES | EPI_SILU_MUL.
 hipError_t launch_rows_rstd32(const float* X, int ldx, int M, float eps, float* rstd, hipStream_t st);
 hipError_t launch_gemm_pre32(const Dec32Args& a, const float* rstd, hipStream_t st);
+// decode32x.hip: the same four projections on SPLIT-bf16 operands (x = hi + lo bf16 planes, three bf16 MFMAs per product, f32 accumulation;
+// RMSNorm gain folded into the weights, 1 / rms applied to the accumulator).  Planes are in decode.hip's fragment order (pk_off).
+struct Dec32xArgs {
+  const uint16_t* Ap; size_t a_plane;   // activations, hi plane [ceil(M/16)][K/32][64][8] bf16; the lo plane a_plane ELEMENTS behind it
+  const uint16_t* Wp; size_t w_plane;   // weights likewise, [N/16 (SILU_MUL: gate tiles then up tiles)][K/32][64][8]
+  int M, N, K;                          // M = rows the buffers hold; live rows = *n_active
+  const int32_t* n_active;
+  int rms; const float* X; int ldx; float eps;   // RMSNorm launches (K = 768): the rows, row-major f32, for 1 / rms (gemm_skinny_k's arithmetic)
+  int epi;                              // D32_EPI_QKV_ROPE | EPI_RES | EPI_SILU_MUL
+  float* C; int ldc;                    // RES: the new residual rows (row-major f32); QKV_ROPE: the qkv buffer
+  const float* res; int ldr;
+  uint16_t* Cp; size_t c_plane; int kch_out;   // the output as planes for the next projection (kch_out = its columns / 32), or null
+  float* Cp32; int kch32_out;           // RES, optional: packed f32 copy (pk32_off, kch32_out = columns / 16): the heads' operand
+  const RowDesc* desc; const float* cos_t; const float* sin_t; float* kc; float* vc; int cmax;   // QKV_ROPE, as Dec32Args
+  int force_mb;                         // tests only
+  int w_nt;                             // set by the launcher
+};
+hipError_t launch_gemm_dec32x(const Dec32xArgs& a, hipStream_t st);
 const char* dec32_last_variant();   // "rms16" | "m16" | "generic": the kernel the calling thread's last launch picked (tests)
 
 // ---- GPT step kernels -------------------------------------------------------------------------
@@ -239,6 +261,7 @@ struct GptRowMap {
   const int32_t* qf_flag;
   int qf_rows;
   int qf_kv_bytes;          // bytes of this layer's K (= V) cache: the units address it through a buffer descriptor with 32-bit offsets
+  size_t x3_plane;          // decode, split-bf16 parity mode (out mode 4): elements between the hi and the lo plane of the packed output
 };
 #define ATT_SPLIT_MAX 8
 
@@ -259,6 +282,7 @@ struct StepPrep {
   float* rope_cs; const float* cos_t; const float* sin_t;   // [rows][64] out (cos[32] | sin[32] of the row's position) from the [max_pos][32] tables, or null
   int32_t* zero_p; int zero_n; int zero_stride;   // zero_n words, zero_stride ints apart, that the step's first kernel zeroes (arrival words
                                                   // of the fused QKV + attention launches), or null
+  size_t xb_lo_plane;       // split-bf16 parity mode: with a packed `xb`, ALSO write the lo plane (x - bf16(x)) this many elements behind it; 0 = no
 };
 hipError_t launch_embed_codes(const float* emb_code /*[4,626,768]*/, const int64_t* ids_buf, int ids_row_stride /*Tcap*/,
                               const int32_t* len, float* x, uint16_t* xb /*null ok*/, float* ssq /*null ok*/, int B,

@@ -177,6 +177,21 @@ def pack_frag(w: torch.Tensor) -> torch.Tensor:
     return w.reshape(R // 16, 16, Cc // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous()
 
 
+def pack_frag_x3(w: torch.Tensor) -> torch.Tensor:
+    """float32 [R, C] -> the SPLIT-bf16 planes of csrc/decode32x.hip: [2][R/16][C/32][64][8] bf16, plane 0 = hi = bf16(w), plane 1 = lo =
+    bf16(w - hi) (w = hi + lo to 16-17 significant bits), each plane in pack_frag's fragment order.  Three bf16 MFMAs (lo*hi + hi*lo +
+    hi*hi, f32 accumulation) then stand for one float32 product."""
+    w = w.to(torch.float32)
+    hi = w.to(torch.bfloat16)
+    lo = (w - hi.to(torch.float32)).to(torch.bfloat16)
+    return torch.stack([pack_frag(hi), pack_frag(lo)], 0).contiguous()
+
+
+def unpack_frag_x3(p: torch.Tensor, R: int, Cc: int) -> torch.Tensor:
+    """planes -> float32 hi + lo (tests)"""
+    return unpack_frag(p[0].float(), R, Cc) + unpack_frag(p[1].float(), R, Cc)
+
+
 def pack_wo_heads(wo: torch.Tensor) -> torch.Tensor:
     """o_proj.weight [768 out, 768 in] (bf16) -> [12 heads][8 (k / 8)][768 out][8] : the slice of Wo one attention head multiplies,
     laid out so that a wave's 16-byte loads (one output column per lane) are one contiguous KiB (csrc/gpt.hip attention_k<OPJ>)"""
@@ -280,8 +295,17 @@ class GptEngine:
                 qk_perm = torch.cat([rp, GPT.hidden + rp, 2 * GPT.hidden + torch.arange(GPT.hidden, device=dev)])
                 self.packed[0] = [pack_frag32(t[qk_perm]) for t in self.wqkv]
             self._pk_arrs = [_lib.ptr_array(x) for x in self.packed]
+        # parity mode, decode step on split-bf16 operands (csrc/decode32x.hip): the four matrices once more as hi | lo bf16 planes (the
+        # float32 bytes again), the RMSNorm gains folded in before the split; CTTS_D32_EXACT=1 skips them (f32 MFMA kernels)
+        self.x3, self._x3_arrs = None, None
+        if use_packed and dtype != "bf16" and os.environ.get("CTTS_D32_EXACT") != "1":
+            gain = lambda w_, g_: w_.float() * g_.float()[None, :]
+            self.x3 = [[pack_frag_x3(gain(t[qk_perm], g_)) for t, g_ in zip(self.wqkv, self.ln1)], [pack_frag_x3(t) for t in self.wo],
+                       [pack_frag_x3(gain(t, g_)) for t, g_ in zip(self.wgu, self.ln2)], [pack_frag_x3(t) for t in self.wd]]
+            self._x3_arrs = [_lib.ptr_array(x) for x in self.x3]
         # perf mode: o_proj once more, sliced per attention head -- the decode step folds o_proj + residual into the attention launch
-        self.wo_hd = [pack_wo_heads(t) for t in self.wo] if (use_packed and dtype == "bf16") else None
+        # a second, per-head copy of every o_proj (23.6 MB of bf16) only for the opt-in fused attention + o_proj launch (CTTS_ATT_OPROJ=1)
+        self.wo_hd = [pack_wo_heads(t) for t in self.wo] if (use_packed and dtype == "bf16" and os.environ.get("CTTS_ATT_OPROJ") == "1") else None
         self._wo_hd_arr = None if self.wo_hd is None else _lib.ptr_array(self.wo_hd)
 
         def pad16(t):      # zero rows up to a multiple of 16: the padded columns of the last logits tile are never stored
@@ -301,6 +325,8 @@ class GptEngine:
         w.heads_pk, w.head_text_pk = _lib.ptr(self.heads_pk), _lib.ptr(self.head_text_pk)
         if self._wo_hd_arr is not None:
             w.wo_hd = C.cast(self._wo_hd_arr, _lib.PP)
+        if self._x3_arrs is not None:
+            w.wqkv_x3, w.wo_x3, w.wgu_x3, w.wd_x3 = [C.cast(a, _lib.PP) for a in self._x3_arrs]
         self._w = w
         h = C.c_void_p()
         _lib.check(self.lib.ctts_gpt_create(C.byref(h), C.byref(w)), "ctts_gpt_create")
@@ -1114,10 +1140,11 @@ class CodecEngine:
         t = t.contiguous()
         n = t.numel()
         if n == 0:
-            return np.zeros(tuple(t.shape), dtype=np.float32)
-        buf = getattr(self, "_pinned", None)
-        if buf is None or buf.numel() < n or buf.dtype != t.dtype:
-            buf = self._pinned = torch.empty(((n + 3) // 4 * 4,), dtype=t.dtype).pin_memory()
+            return np.zeros(tuple(t.shape), dtype={torch.int16: np.int16, torch.uint8: np.uint8}.get(t.dtype, np.float32))
+        pins = self.__dict__.setdefault("_pinned", {})     # one grow-only staging buffer per element type (float32 waveforms, int16 PCM, uint8 masks)
+        buf = pins.get(t.dtype)
+        if buf is None or buf.numel() < n:
+            buf = pins[t.dtype] = torch.empty(((n + 15) // 16 * 16,), dtype=t.dtype).pin_memory()
         view = buf[:n].view(t.shape)
         nbytes = n * t.element_size()
         if nbytes >= (16 << 20) and nbytes % 64 == 0 and t.data_ptr() % 16 == 0 and os.environ.get("CTTS_D2H_PIPE", "1") != "0":

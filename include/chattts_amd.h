@@ -76,10 +76,20 @@ typedef struct {
   const float* heads_pk;
   const float* head_text_pk;
   /* optional (NULL: o_proj stays its own launch), perf mode only: o_proj.weight once more, sliced per attention head,
-   * [12 heads][8 (k / 8)][768 output columns][8] bf16 = Wo[column][64 head + 8 (k / 8) + (k % 8)].  With it the decode step folds
-   * o_proj + residual into the attention launch (csrc/gpt.hip attention_k<OPJ>; HF Llama self_attn.o_proj,
-   * examples/onnx/modeling_llama.py:500,557): 83 launches per step instead of 103. */
+   * [12 heads][8 (k / 8)][768 output columns][8] bf16 = Wo[column][64 head + 8 (k / 8) + (k % 8)].  With it AND the environment
+   * variable CTTS_ATT_OPROJ=1 the decode step folds o_proj + residual into the attention launch (csrc/gpt.hip attention_k<OPJ>; HF Llama
+   * self_attn.o_proj, examples/onnx/modeling_llama.py:500,557): 83 launches per step instead of 103.  OPT-IN: measured slower than the
+   * two launches (profiles/r4b_ab_oproj.log), so by default the pointer is ignored and o_proj stays its own launch. */
   const void* const* wo_hd;
+  /* optional (NULL: the f32 MFMA kernels of csrc/decode32.hip), parity mode only, together with the *_pk copies above: the same four
+   * matrices as SPLIT-bf16 planes for the decode step (csrc/decode32x.hip) -- [2 planes: hi = bf16(w), lo = bf16(w - hi)][N/16][K/32][64][8]
+   * bf16, the bf16 fragment order above per plane; wqkv_x3 / wgu_x3 carry the RMSNorm gain of ln1 / ln2 (w' = w * gain[k], folded BEFORE
+   * the split) and the q / k row permutation of wqkv_pk.  Three bf16 MFMAs per product instead of f32 MFMA at a sixteenth of the rate; the
+   * reference's token ids hold on every golden (tests/test_gpu_e2e.py); the environment variable CTTS_D32_EXACT=1 ignores the planes. */
+  const void* const* wqkv_x3;
+  const void* const* wo_x3;
+  const void* const* wgu_x3;
+  const void* const* wd_x3;
 } ctts_gpt_weights;
 
 /* One generate() call's device state (every array is caller-allocated, device memory). */
@@ -353,6 +363,15 @@ int ctts_k_gemm_dec32(const float* Ap, const float* Wp, int32_t M, int32_t N, in
                       const float* norm_w, float eps, int32_t epi, float* C, int32_t ldc, const float* res, int32_t ldr, float* Cp,
                       int32_t kch_out, int32_t force_mb, int32_t n_cols /* epi 0: columns of C that exist (N padded to 16), 0 = N */,
                       void* stream);
+/* The same projections on SPLIT-bf16 operands (csrc/decode32x.hip; ctts_gpt_weights.wqkv_x3 ...): Ap / Wp = hi planes in the bf16 fragment order
+ * ([rows/16][K/32][64][8]), the lo planes a_plane / w_plane ELEMENTS behind them; three bf16 MFMAs per product (lo*hi + hi*lo + hi*hi), f32
+ * accumulation.  X != NULL (K = 768): RMSNorm launch -- 1 / rms of the rows of X (row-major f32, gemm_skinny_k's arithmetic) scales the
+ * accumulator, the gain is expected folded into W.  epi 1 = C = res + acc (row-major f32), Cp = its planes (c_plane elements apart, kch_out =
+ * N / 32) and optionally Cp32 = its packed f32 copy; epi 2 = SiLU(gate) * up -> Cp planes (W = gate tiles then up tiles).  Reference ops:
+ * examples/onnx/modeling_llama.py:293,415-417,500. */
+int ctts_k_gemm_dec32x(const uint16_t* Ap, int64_t a_plane, const uint16_t* Wp, int64_t w_plane, int32_t M, int32_t N, int32_t K,
+                       const int32_t* n_active, const float* X, int32_t ldx, float eps, int32_t epi, float* C, int32_t ldc, const float* res,
+                       int32_t ldr, uint16_t* Cp, int64_t c_plane, int32_t kch_out, float* Cp32, int32_t force_mb, void* stream);
 /* which decode32 kernel the calling thread's last ctts_k_gemm_dec32 / decode step picked: "rms16" | "m16" | "generic" (all bit-identical) */
 const char* ctts_k_dec32_last_variant(void);
 int ctts_k_rows_prep(const float* x32, uint16_t* xb, float* ssq, int32_t M, void* stream);

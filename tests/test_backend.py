@@ -103,3 +103,38 @@ def test_device_float_to_int16_equals_the_reference_function(gold, weights, prod
     assert not view.is_contiguous() and torch.equal(a, b)
     z, _ = codec.float_to_int16(torch.zeros((2, 77), device=dev), per_row=True)
     assert not bool(z.any())
+
+
+@pytest.mark.gpu
+def test_chat_infer_pcm16_equals_float_to_int16_of_infer(weights):
+    """`Chat.infer(..., pcm16=True)` (the conversion + the silence strip on the device, int16 + mask bits over PCIe) against the float path
+    followed by the reference's host function: non-stream per utterance, stream per row of every chunk -- np.array_equal."""
+    from chattts_amd.core import Chat
+    dev = torch.device("cuda:0")
+    gold_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    with open(os.path.join(gold_dir, "spk_stat.txt"), encoding="utf-8") as f:
+        spk_stat = f.read()
+    chat = Chat()
+    assert chat.load(state_dicts=weights, device=dev, dtype="f32", tokenizer=os.path.join(gold_dir, "tokenizer"), spk_stat=spk_stat)
+    torch.manual_seed(11)
+    spk = chat.sample_random_speaker()
+    texts = ["What is [uv_break]your favorite english food?[laugh][lbreak]", "hello world"]
+
+    def params(n):
+        return Chat.InferCodeParams(spk_emb=spk, max_new_token=n, min_new_token=n - 7, manual_seed=7, show_tqdm=False, stream_batch=8,
+                                    stream_speed=3000, pass_first_n_batches=1)
+    f32 = chat.infer(list(texts), skip_refine_text=True, split_text=False, params_infer_code=params(40))
+    pcm = chat.infer(list(texts), skip_refine_text=True, split_text=False, params_infer_code=params(40), pcm16=True)
+    assert len(pcm) == len(f32) == 2
+    for a, b in zip(pcm, f32):
+        assert a.dtype == np.int16 and a.shape == b.shape and np.array_equal(a, audio.float_to_int16(b))
+    chunks_f = list(chat.infer(list(texts), stream=True, skip_refine_text=True, split_text=False, params_infer_code=params(40)))
+    chunks_p = list(chat.infer(list(texts), stream=True, skip_refine_text=True, split_text=False, params_infer_code=params(40), pcm16=True))
+    assert len(chunks_f) == len(chunks_p) >= 3
+    for cf, cp in zip(chunks_f, chunks_p):
+        assert cp.shape == cf.shape
+        if cf.shape[1]:
+            assert cp.dtype == np.int16 and all(np.array_equal(cp[b], audio.float_to_int16(cf[b])) for b in range(cf.shape[0]))
+    # ... and the streamer over the float chunks is the reference's byte stream for ONE listener (its conversion is per collected block)
+    blocks = list(ChatStreamer(base_block_size=2000).generate(iter(chunks_f), "PCM16_byte"))
+    assert blocks and all(isinstance(b, bytes) and len(b) % 2 == 0 for b in blocks)

@@ -17,9 +17,20 @@ from oracle import cases, codec_np, generate_np, llama_np  # noqa: E402
 DEV = torch.device("cuda:0")
 
 
-@pytest.fixture(scope="module")
-def gpt_f32(weights):
-    return E.GptEngine(weights["gpt"], weights["embed"], DEV, dtype="f32")
+@pytest.fixture(scope="module", params=["x3", "exact"])
+def gpt_f32(weights, request):
+    """the parity mode, both arithmetics of its decode projections: "x3" = split-bf16 planes, three bf16 MFMAs per product
+    (csrc/decode32x.hip, the default), "exact" = f32 MFMA on packed f32 operands (csrc/decode32.hip, CTTS_D32_EXACT=1).  Every
+    reference-generated golden must hold in BOTH: the bar is the reference's token ids, not either kernel's bits."""
+    import os
+    if request.param == "exact":
+        os.environ["CTTS_D32_EXACT"] = "1"
+    try:
+        eng = E.GptEngine(weights["gpt"], weights["embed"], DEV, dtype="f32")
+    finally:
+        os.environ.pop("CTTS_D32_EXACT", None)
+    assert (eng.x3 is not None) == (request.param == "x3")
+    return eng
 
 
 @pytest.fixture(scope="module")
@@ -385,6 +396,7 @@ def test_packed_f32_decode_is_bit_identical_to_row_major(weights, monkeypatch):
     """parity mode: the decode step on fragment-packed f32 operands (csrc/decode32.hip) keeps the operation order of the
     row-major kernels the goldens were established with -> identical token ids AND bit-identical hidden states"""
     c = cases.GEN_CASES["b8"]
+    monkeypatch.setenv("CTTS_D32_EXACT", "1")     # (the default decode step runs the split-bf16 kernels of decode32x.hip: same ids, other bits)
     packed = E.GptEngine(weights["gpt"], weights["embed"], DEV, dtype="f32")
     outs_p, _ = run_case(packed, c, use_graph=True)
     monkeypatch.setenv("CTTS_DEC_PACKED", "0")
@@ -621,6 +633,31 @@ def test_codec_f16_mode_holds_the_waveform_bar(weights):
     alone = f16_eng.decode_to_wavs([rows[2]]).cpu().numpy()[0]
     n2 = 256 * (2 * 120 - 1) - 256 * 110            # clear of the zero-padded tail's edge effects
     assert float(np.sqrt(np.mean((alone[:n2] - w_f16[2, :n2]) ** 2))) < 2e-5
+
+
+def test_codec_f16_mode_threshold_straddle(weights, golden):
+    """gemm="f16" on both sides of the frame count from which the point-wise pairs take the fp16 kernels (ctts_codec.x3p_min_rows = 1024;
+    ADVICE r4): 8 utterances x 64 tokens = 1024 frames run gemm_h1p_k, 8 x 63 = 1008 frames run the split-bf16 tiles -- i.e. equal
+    gemm="bf16x3" bit for bit -- and the fp16 side stays within the mode's stated 2e-5 RMS of the f32-class decoder; a STREAMED window
+    (decode_window: 8 x 55 tokens = 880 frames, below the threshold) of a batch whose full decode is above it (8 x 100 = 1600 frames)
+    differs from the slice of the full decode by the same bound.  Inputs: the reference GPT's own hidden states (c2.hid0)."""
+    hid0 = torch.from_numpy(golden["generate_big"]["c2.hid0"])
+    f16 = E.CodecEngine(weights["decoder"], weights["vocos"], DEV, gemm="f16")
+    ref = E.CodecEngine(weights["decoder"], weights["vocos"], DEV, gemm="bf16x3")
+    rows64 = [hid0[40 * i: 40 * i + 64].clone() for i in range(8)]
+    rows63 = [r[:63] for r in rows64]
+    w63_f, w63_r = f16.decode_to_wavs(rows63), ref.decode_to_wavs(rows63)
+    assert torch.equal(w63_f, w63_r)                                          # 1008 frames: the mode IS the split-bf16 decoder
+    w64_f, w64_r = f16.decode_to_wavs(rows64).cpu().numpy(), ref.decode_to_wavs(rows64).cpu().numpy()
+    rms = float(np.sqrt(np.mean((w64_f - w64_r) ** 2)))
+    assert 0.0 < rms < 2e-5, rms                                              # 1024 frames: the fp16 kernels ran, within the stated bound
+    rows100 = [hid0[30 * i: 30 * i + 100].clone() for i in range(8)]
+    full = f16.decode_to_wavs(rows100).cpu().numpy()                          # 1600 frames: fp16 path
+    n = 256 * 4                                                               # halo 102 frames -> a 55-token window = 880 frames < 1024
+    win = f16.decode_window(rows100, 0, n).cpu().numpy()                      # its first samples from that window: split-bf16 path
+    d = float(np.sqrt(np.mean((win - full[:, :n]) ** 2)))
+    print(f"codec f16 threshold: 1024 frames vs bf16x3 {rms:.2e} RMS; streamed window (tiles) vs full decode (fp16) {d:.2e} RMS")
+    assert d < 2e-5, d
 
 
 def test_decode_window_equals_slices_of_the_full_decode(codec):

@@ -227,6 +227,74 @@ def test_gemm_dec32_bit_identical(G, M, n_act, force_mb):
 
 
 @pytest.mark.parametrize("force_mb", [0, 1, 2, 4])
+@pytest.mark.parametrize("M,n_act", [(64, None), (64, 37), (16, None), (5, None), (33, 20), (48, 48)])
+def test_gemm_dec32x_split_bf16(G, M, n_act, force_mb):
+    """parity-mode decode projections on SPLIT-bf16 operands (csrc/decode32x.hip: hi | lo bf16 planes, three bf16 MFMAs per product,
+    f32 accumulation) for the o_proj / gate-up / down shapes of a layer: (a) against the float64 value of EXACTLY what the kernel is
+    defined to compute -- (hi+lo)(hi+lo) - lo*lo over the split operands, 1 / rms from the f32 rows, residual / SiLU epilogue --
+    within f32 accumulation noise; (b) within 2e-5 (relative to the output's scale) of the float64 product of the UNSPLIT operands:
+    the 2^-17-class operand error the mode is priced on; the output planes re-assemble to the row-major result; partial row tiles,
+    a device-side live-row count, rows beyond it untouched."""
+    from chattts_amd.engine import pack_frag, pack_frag_x3, unpack_frag, unpack_frag32
+    lib = _lib.lib()
+    rs = np.random.RandomState(M * 13 + (n_act or 0) + force_mb)
+    Mp = (M + 15) // 16 * 16
+    live = M if n_act is None else n_act
+    na_d = None if n_act is None else G.dev(np.array([n_act], np.int32))
+
+    def split(a):
+        t = torch.from_numpy(a)
+        hi = t.to(torch.bfloat16)
+        lo = (t - hi.float()).to(torch.bfloat16)
+        return hi, lo
+
+    for N, K, epi, rms in [(768, 768, 1, False), (3072, 768, 2, True), (768, 3072, 1, False)]:
+        A = (rs.standard_normal((M, K)) * (2.0 if rms else 1.0)).astype(f32)
+        nrows = 2 * N if epi == 2 else N
+        Wm = (rs.standard_normal((nrows, K)) * 0.03).astype(f32)
+        res = rs.standard_normal((M, N)).astype(f32) if epi == 1 else None
+        Apad = np.full((Mp, K), np.nan, f32)          # pad rows = NaN: they must never reach a live output
+        Apad[:M] = A
+        ah, al = split(Apad)
+        planes_a = torch.stack([pack_frag(ah), pack_frag(al)], 0).contiguous().to(G.DEV)
+        planes_w = pack_frag_x3(torch.from_numpy(Wm)).to(G.DEV)
+        Cc = torch.full((M, N), float("nan"), dtype=torch.float32, device=G.DEV)
+        Cp = torch.full((2, Mp * N), float("nan"), dtype=torch.float32, device=G.DEV).to(torch.bfloat16)
+        Cp32 = torch.full((Mp * N,), float("nan"), dtype=torch.float32, device=G.DEV) if epi == 1 else None
+        A_d = G.dev(A)
+        res_d = None if res is None else G.dev(res)
+        _lib.check(lib.ctts_k_gemm_dec32x(planes_a.data_ptr(), Mp * K, planes_w.data_ptr(), nrows * K, M, N, K, _lib.ptr(na_d),
+                                          A_d.data_ptr() if rms else None, K, 1e-6, epi, Cc.data_ptr() if epi == 1 else None, N,
+                                          _lib.ptr(res_d), N, Cp.data_ptr(), Mp * N, N // 32, _lib.ptr(Cp32), force_mb, None), "dec32x")
+        torch.cuda.synchronize()
+        # float64 models
+        a_h, a_l = (x.float().numpy().astype(np.float64)[:live] for x in split(A))
+        w_h, w_l = (x.float().numpy().astype(np.float64) for x in split(Wm))
+        exact = (a_h + a_l) @ (w_h + w_l).T - a_l @ w_l.T          # what three MFMAs sum
+        full = A[:live].astype(np.float64) @ Wm.astype(np.float64).T
+        if rms:
+            rstd = 1.0 / np.sqrt((A[:live].astype(np.float64) ** 2).mean(1, keepdims=True) + 1e-6)
+            exact, full = exact * rstd, full * rstd
+        if epi == 2:
+            sil = lambda v: v / (1.0 + np.exp(-v))
+            exact, full = sil(exact[:, :N]) * exact[:, N:], sil(full[:, :N]) * full[:, N:]
+        else:
+            exact, full = exact + res[:live], full + res[:live]
+        got_planes = unpack_frag(Cp[0].float().cpu(), Mp, N).numpy().astype(np.float64) + unpack_frag(Cp[1].float().cpu(), Mp, N).numpy()
+        scale = np.abs(full).max()
+        if epi == 1:
+            got = Cc.cpu().numpy()
+            assert np.isnan(got[live:]).all()                       # rows beyond the live count are not written
+            assert np.abs(got[:live] - exact).max() < 5e-6 * scale, (N, K, np.abs(got[:live] - exact).max() / scale)
+            assert np.abs(got[:live] - full).max() < 2e-5 * scale, (N, K, np.abs(got[:live] - full).max() / scale)
+            assert np.array_equal(unpack_frag32(Cp32.cpu(), Mp, N).numpy()[:live], got[:live])
+            assert np.abs(got_planes[:live] - got[:live]).max() < 2e-5 * scale      # planes hold the row to 16-17 bits
+        else:
+            assert np.abs(got_planes[:live] - exact).max() < 2e-5 * scale, (N, K, np.abs(got_planes[:live] - exact).max() / scale)
+        assert np.isnan(got_planes[live:M]).all()
+
+
+@pytest.mark.parametrize("force_mb", [0, 1, 2, 4])
 @pytest.mark.parametrize("decode", [False, True, "tiled", "tiled128"])
 def test_qkv_rope_fused(G, force_mb, decode):
     """perf-mode fused RMSNorm-scale + QKV + RoPE + KV append vs numpy (natural weight order); "tiled": a prompt-sized
