@@ -393,21 +393,24 @@ static int run_step(ctts_gpt* g, const ctts_gen_state* s, int q_per_b, hipStream
     d.M = M; d.eps = g->w.rms_eps; d.n_active = nact;
     // RMSNorm (gain folded into the weights, 1 / rms on the accumulator) + QKV + RoPE + KV append
     d.Ap = xpx; d.a_plane = Bp16 * HID; d.Wp = (const uint16_t*)g->wqkv_x3[l]; d.w_plane = (size_t)3 * HID * HID; d.N = 3 * HID; d.K = HID;
-    d.rms = 1; d.X = ws.x; d.ldx = HID; d.epi = D32_EPI_QKV_ROPE; d.C = ws.qkv; d.ldc = 3 * HID; d.desc = ws.desc;
+    d.rms = 1; d.X = ws.x; d.ldx = HID; d.ssq_in = ws.ssq; d.rope_cs = ws.rope_cs; d.epi = D32_EPI_QKV_ROPE; d.C = ws.qkv; d.ldc = 3 * HID; d.desc = ws.desc;
     d.cos_t = g->w.rope_cos; d.sin_t = g->w.rope_sin; d.kc = (float*)kc; d.vc = (float*)vc; d.cmax = cmax;
     { Prof p(g, 1, st, prof_ok); CK(launch_gemm_dec32x(d, st)); }
     rm.x3_plane = Bp16 * HID;
     { Prof p(g, 3, st, prof_ok); CK(launch_attention(ws.qkv, kc, vc, kt, cmax, aopx, 4, rm, M, st)); }
     // o_proj + residual
     d.Ap = aopx; d.a_plane = Bp16 * HID; d.Wp = (const uint16_t*)g->wo_x3[l]; d.w_plane = (size_t)HID * HID; d.N = HID; d.rms = 0; d.X = nullptr;
+    d.ssq_in = nullptr; d.ssq_out = ws.ssq;
     d.epi = EPI_RES; d.C = ws.x; d.ldc = HID; d.res = ws.x; d.ldr = HID; d.Cp = xpx; d.c_plane = Bp16 * HID; d.kch_out = HID / 32;
     { Prof p(g, 4, st, prof_ok); CK(launch_gemm_dec32x(d, st)); }
     // RMSNorm + gate/up + SiLU*up
     d.Ap = xpx; d.a_plane = Bp16 * HID; d.Wp = (const uint16_t*)g->wgu_x3[l]; d.w_plane = (size_t)2 * INTER * HID; d.N = INTER; d.rms = 1; d.X = ws.x;
+    d.ssq_in = ws.ssq; d.ssq_out = nullptr;
     d.epi = EPI_SILU_MUL; d.C = nullptr; d.res = nullptr; d.Cp = actx; d.c_plane = Bp16 * INTER; d.kch_out = INTER / 32;
     { Prof p(g, 5, st, prof_ok); CK(launch_gemm_dec32x(d, st)); }
     // down_proj + residual (last layer: also the packed f32 rows the fused final-norm + heads launch reads)
     d.Ap = actx; d.a_plane = Bp16 * INTER; d.Wp = (const uint16_t*)g->wd_x3[l]; d.w_plane = (size_t)HID * INTER; d.N = HID; d.K = INTER; d.rms = 0;
+    d.ssq_in = nullptr; d.ssq_out = ws.ssq;
     d.X = nullptr; d.epi = EPI_RES; d.C = ws.x; d.ldc = HID; d.res = ws.x; d.ldr = HID; d.Cp = xpx; d.c_plane = Bp16 * HID; d.kch_out = HID / 32;
     d.Cp32 = (fuse_fnorm && l == g->w.n_layers - 1) ? ws.hfinp : nullptr; d.kch32_out = HID / 16;
     { Prof p(g, 6, st, prof_ok); CK(launch_gemm_dec32x(d, st)); }
@@ -588,7 +591,7 @@ static int decode_body(ctts_gpt* g, const ctts_gen_state* s, hipStream_t st, boo
     StepPrep sp{ws.desc, s->kv_start, g->skip_finished ? s->finish : nullptr, (packed || x3) ? 1 : 0, (!fast && g->dec_packed32 && !x3) ? ws.xp32 : nullptr,
                 dc ? ws.row_map : nullptr,
                 dc ? const_cast<int32_t*>(s->n_active) : nullptr, dc ? s->order : nullptr,
-                (packed && g->qkv_att && g->w.n_layers <= QA_LAYERS_MAX) ? ws.rope_cs : nullptr, g->w.rope_cos, g->w.rope_sin,
+                ((packed && g->qkv_att && g->w.n_layers <= QA_LAYERS_MAX) || x3) ? ws.rope_cs : nullptr, g->w.rope_cos, g->w.rope_sin,
                 // the arrival words are sized for QA_LAYERS_MAX layers: the same predicate as `fuse_qa` in run_step (a deeper model
                 // never takes the fused launch and must not zero past the carve either)
                 (packed && g->qkv_att && g->w.n_layers <= QA_LAYERS_MAX) ? ws.qa_flag : nullptr, g->w.n_layers * NHEAD, QA_STRIDE};
@@ -597,9 +600,9 @@ static int decode_body(ctts_gpt* g, const ctts_gen_state* s, hipStream_t st, boo
     if (x3) sp.xb_lo_plane = ((size_t)s->B + 15) / 16 * 16 * HID;
     if (s->infer_text)
       CK(launch_embed_text(g->w.emb_text, g->w.n_text, s->ids_buf, s->cap ? s->cap : s->T + s->max_new, s->len, ws.x, xb,
-                           fast ? ws.ssq : nullptr, s->B, s->row_map, nact0, st, &sp));
+                           (fast || x3) ? ws.ssq : nullptr, s->B, s->row_map, nact0, st, &sp));
     else
-      CK(launch_embed_codes(g->w.emb_code, s->ids_buf, s->cap ? s->cap : s->T + s->max_new, s->len, ws.x, xb, fast ? ws.ssq : nullptr, s->B,
+      CK(launch_embed_codes(g->w.emb_code, s->ids_buf, s->cap ? s->cap : s->T + s->max_new, s->len, ws.x, xb, (fast || x3) ? ws.ssq : nullptr, s->B,
                             s->row_map, nact0, st, &sp)); }
   return run_step(g, s, 1, st, prof_ok, 0, true, 1);
 }
@@ -919,11 +922,12 @@ extern "C" int ctts_k_gemm_dec32(const float* Ap, const float* Wp, int32_t M, in
 extern "C" int ctts_k_gemm_dec32x(const uint16_t* Ap, int64_t a_plane, const uint16_t* Wp, int64_t w_plane, int32_t M, int32_t N, int32_t K,
                                   const int32_t* n_active, const float* X, int32_t ldx, float eps, int32_t epi, float* C, int32_t ldc,
                                   const float* res, int32_t ldr, uint16_t* Cp, int64_t c_plane, int32_t kch_out, float* Cp32, int32_t force_mb,
-                                  void* stream) {
+                                  const float* ssq_in, float* ssq_out, void* stream) {
   Dec32xArgs d;
   memset(&d, 0, sizeof(d));
+  d.ssq_in = ssq_in; d.ssq_out = ssq_out;
   d.Ap = Ap; d.a_plane = (size_t)a_plane; d.Wp = Wp; d.w_plane = (size_t)w_plane; d.M = M; d.N = N; d.K = K; d.n_active = n_active;
-  d.rms = X != nullptr; d.X = X; d.ldx = ldx; d.eps = eps; d.epi = epi; d.C = C; d.ldc = ldc; d.res = res; d.ldr = ldr;
+  d.rms = X != nullptr || ssq_in != nullptr; d.X = X; d.ldx = ldx; d.eps = eps; d.epi = epi; d.C = C; d.ldc = ldc; d.res = res; d.ldr = ldr;
   d.Cp = Cp; d.c_plane = (size_t)c_plane; d.kch_out = kch_out; d.Cp32 = Cp32; d.kch32_out = N / 16; d.force_mb = force_mb;
   CK(launch_gemm_dec32x(d, (hipStream_t)stream));
   return 0;

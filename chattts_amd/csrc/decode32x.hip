@@ -33,7 +33,19 @@
 #include "common.hpp"
 #include "kernels.hpp"
 
-template <int MBT> struct DxU { static constexpr int v = MBT == 1 ? 6 : 3; };   // k chunks of 32 per wave and round, by the KERNEL's row tiles (known before the live-row count)
+// k chunks of 32 per wave and round, by the KERNEL's row tiles and K (both known before the live-row count).  The rounds are not
+// double-buffered -- every round is one exposed memory round trip -- so a workgroup takes its whole quarter of K in ONE round wherever the
+// registers allow: 6 chunks at K = 768 (16-row workgroups: 24-36 16-byte loads in flight per lane; 64-row workgroups: up to 72, 404
+// VGPRs, one workgroup per CU, which is all a 144- / 192-tile launch has anyway), 24 chunks at K = 3072 for the 16-row workgroups of
+// down_proj (96 loads, 400 VGPRs, 192 workgroups).  Measured (profiles/r5i_ab_x3_rounds.log, parity leg of the bench): 3 -> 6 chunks for
+// the 64-row RMSNorm launches 995 -> 1016 audio-s/s, 12 -> 24 for down 978 -> 986.
+#ifndef CTTS_D32X_U3072
+#define CTTS_D32X_U3072 24   // A/B builds: python -m chattts_amd.build --variant u12 -DCTTS_D32X_U3072=12
+#endif
+#ifndef CTTS_D32X_UW
+#define CTTS_D32X_UW 6       // ... --variant uw3 -DCTTS_D32X_UW=3: two rounds at K = 768 for the 32- / 64-row workgroups
+#endif
+template <int MBT, int KT> struct DxU { static constexpr int v = MBT == 1 ? (KT == 3072 ? CTTS_D32X_U3072 : 6) : (KT == 3072 ? 3 : CTTS_D32X_UW); };
 
 __device__ __forceinline__ void x3_store(uint16_t* __restrict__ hi_at, const size_t plane, const float v) {
   const bf16_t h = f32_to_bf16(v);
@@ -41,45 +53,23 @@ __device__ __forceinline__ void x3_store(uint16_t* __restrict__ hi_at, const siz
   hi_at[plane] = f32_to_bf16(v - bf16_to_f32(h));
 }
 
-template <int NMB, int MBT, bool RMS, int EPI>
+template <int NMB, int MBT, int KT, bool RMS, int EPI>
 __device__ __forceinline__ void dec32x_body(const Dec32xArgs& a, const int M, const int tile, const int mt0,
-                                            u128 (&wh)[(EPI == EPI_SILU_MUL) ? 2 : 1][DxU<MBT>::v], u128 (&wl)[(EPI == EPI_SILU_MUL) ? 2 : 1][DxU<MBT>::v],
+                                            u128 (&wh)[(EPI == EPI_SILU_MUL) ? 2 : 1][DxU<MBT, KT>::v], u128 (&wl)[(EPI == EPI_SILU_MUL) ? 2 : 1][DxU<MBT, KT>::v],
                                             float (*red)[(EPI == EPI_SILU_MUL) ? 2 : 1][MBT][64][4], float* rstd_s) {
   constexpr int NACC = (EPI == EPI_SILU_MUL) ? 2 : 1;
-  constexpr int U = DxU<MBT>::v;
+  constexpr int U = DxU<MBT, KT>::v;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int li = lane & 15, g = lane >> 4;
   const int n0 = tile * 16, m0 = mt0 * 16;
-  const int N = a.N, K = a.K, KCH = K >> 5;
+  const int N = a.N;
+  constexpr int KCH = KT >> 5;
 
   constexpr int PPW = NMB >= 3 ? 4 : NMB;
   constexpr int NF = NMB >= 3 ? NMB : 4;
   const int fmb = (wave * PPW) >> 2, fr0 = (wave * PPW) & 3;   // meaningful for wave < NF
-  float pre0[PPW];  // RES: residual, requested before the operand loads
-#pragma unroll
-  for (int q = 0; q < PPW; ++q) pre0[q] = 0.f;
-  if (EPI == EPI_RES && wave < NF) {
-#pragma unroll
-    for (int q = 0; q < PPW; ++q) {
-      const int row = min(m0 + 16 * fmb + 4 * g + fr0 + q, M - 1);
-      pre0[q] = a.res[(size_t)row * a.ldr + n0 + li];
-    }
-  }
-  // QKV_ROPE tiles (weight rows permuted by the loader, engine.py rope_row_perm): see decode32.hip
-  const int sect = n0 / 768, hcol = n0 % 768, head = hcol >> 6, t4 = (hcol & 63) >> 4;
-  const int dlo = 8 * t4 + (li & 7);
-  RowDesc rd[PPW];
-  float rc[PPW], rsn[PPW];
-  if (EPI == D32_EPI_QKV_ROPE && wave < NF) {
-#pragma unroll
-    for (int q = 0; q < PPW; ++q) {
-      rd[q] = a.desc[min(m0 + 16 * fmb + 4 * g + fr0 + q, M - 1)];
-      rc[q] = a.cos_t[rd[q].pos * 32 + dlo];
-      rsn[q] = a.sin_t[rd[q].pos * 32 + dlo];
-    }
-  }
 
-  const int nper = KCH / 4;   // chunks per wave (launcher guarantees nper % U == 0); wave w owns the contiguous quarter w
+  constexpr int nper = KCH / 4;   // chunks per wave (nper % U == 0); wave w owns the contiguous quarter w
   const u128* wp = reinterpret_cast<const u128*>(a.Wp) + ((size_t)tile * KCH + wave * nper) * 64 + lane;
   const u128* wp2 = wp + (size_t)(N >> 4) * KCH * 64;  // SILU_MUL: the "up" tile of the same columns
   const u128* ap = reinterpret_cast<const u128*>(a.Ap) + ((size_t)mt0 * KCH + wave * nper) * 64 + lane;
@@ -95,9 +85,53 @@ __device__ __forceinline__ void dec32x_body(const Dec32xArgs& a, const int M, co
         al[mb][j] = load16(ap + apl + ((size_t)mb * KCH + i + j) * 64);
       }
   };
-  load_a(0);   // before the prologue's row loads: the statistics cost no extra round trip
-  if (RMS) {
-    // 1 / rms of the 16 NMB rows, gemm_skinny_k's arithmetic (the same bits the f32 kernels use): K = 768 only
+  // Every load the workgroup can issue is requested here, up front, and none depends on another: the activation fragments of the first
+  // round (the weights' were requested at kernel entry), then the small operands of the prologue / epilogue -- residual, row
+  // descriptors, RoPE factors, the rows' partial sums of squares.  One memory round trip, not a chain of them.
+  load_a(0);
+  float pre0[PPW];  // RES: residual
+#pragma unroll
+  for (int q = 0; q < PPW; ++q) pre0[q] = 0.f;
+  if (EPI == EPI_RES && wave < NF) {
+#pragma unroll
+    for (int q = 0; q < PPW; ++q) {
+      const int row = min(m0 + 16 * fmb + 4 * g + fr0 + q, M - 1);
+      pre0[q] = a.res[(size_t)row * a.ldr + n0 + li];
+    }
+  }
+  // QKV_ROPE tiles (weight rows permuted by the loader, engine.py rope_row_perm): see decode32.hip.  The RoPE factors come from the
+  // per-row table the step's first kernel wrote (StepPrep.rope_cs: cos[32] | sin[32] of the row's position -- the same table entries
+  // a.cos_t[pos * 32 + d] would deliver, without the row -> position -> table chain), or through the descriptor when there is none.
+  const int sect = n0 / 768, hcol = n0 % 768, head = hcol >> 6, t4 = (hcol & 63) >> 4;
+  const int dlo = 8 * t4 + (li & 7);
+  RowDesc rd[PPW];
+  float rc[PPW], rsn[PPW];
+  if (EPI == D32_EPI_QKV_ROPE && wave < NF) {
+#pragma unroll
+    for (int q = 0; q < PPW; ++q) {
+      const int row = min(m0 + 16 * fmb + 4 * g + fr0 + q, M - 1);
+      rd[q] = a.desc[row];
+      if (a.rope_cs != nullptr) {
+        rc[q] = a.rope_cs[(size_t)row * 64 + dlo];
+        rsn[q] = a.rope_cs[(size_t)row * 64 + 32 + dlo];
+      } else {
+        rc[q] = a.cos_t[rd[q].pos * 32 + dlo];
+        rsn[q] = a.sin_t[rd[q].pos * 32 + dlo];
+      }
+    }
+  }
+  // RMSNorm launches: 1 / rms of the workgroup's rows.  With `ssq_in` (the decode step): from the 48 partial sums of squares per row
+  // the producers of the residual stream left (embed_codes_k, the RES epilogue below) -- 4 threads x 12 partials per row, as decode.hip;
+  // without (tests): from the float32 rows themselves, gemm_skinny_k's arithmetic.
+  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0;
+  const int srow = tid >> 2, spart = tid & 3;
+  if (RMS && a.ssq_in != nullptr && srow < 16 * NMB) {
+    const float* sp = a.ssq_in + (size_t)min(m0 + srow, M - 1) * SSQ_PARTS + spart * 12;
+    s0 = *reinterpret_cast<const float4*>(sp);
+    s1 = *reinterpret_cast<const float4*>(sp + 4);
+    s2 = *reinterpret_cast<const float4*>(sp + 8);
+  }
+  if (RMS && a.ssq_in == nullptr) {
 #pragma unroll
     for (int r0 = 0; r0 < 16 * NMB; r0 += 16) {
       const float* rows[4];
@@ -153,6 +187,12 @@ __device__ __forceinline__ void dec32x_body(const Dec32xArgs& a, const int M, co
         }
   }
 
+  if (RMS && a.ssq_in != nullptr) {
+    float sq = (((s0.x + s0.y) + (s0.z + s0.w)) + ((s1.x + s1.y) + (s1.z + s1.w))) + ((s2.x + s2.y) + (s2.z + s2.w));
+    sq += __shfl_xor(sq, 1, 64);
+    sq += __shfl_xor(sq, 2, 64);
+    if (spart == 0 && srow < 16 * NMB) rstd_s[srow] = 1.0f / sqrtf(sq / 768.0f + a.eps);
+  }
 #pragma unroll
   for (int na = 0; na < NACC; ++na)
 #pragma unroll
@@ -202,6 +242,14 @@ __device__ __forceinline__ void dec32x_body(const Dec32xArgs& a, const int M, co
       }
       continue;
     }
+    if (EPI == EPI_RES && a.ssq_out != nullptr) {   // this tile's share of the new row's sum of squares (every lane of the wave is here)
+      float sq = row < M ? v * v : 0.f;
+      sq += __shfl_xor(sq, 1, 64);
+      sq += __shfl_xor(sq, 2, 64);
+      sq += __shfl_xor(sq, 4, 64);
+      sq += __shfl_xor(sq, 8, 64);
+      if (li == 0 && row < M) a.ssq_out[(size_t)row * SSQ_PARTS + tile] = sq;
+    }
     if (row >= M) continue;
     if (EPI == EPI_RES) a.C[(size_t)row * a.ldc + col] = v;
     if (a.Cp != nullptr) x3_store(a.Cp + pk_off(row, col, a.kch_out), a.c_plane, v);
@@ -209,10 +257,10 @@ __device__ __forceinline__ void dec32x_body(const Dec32xArgs& a, const int M, co
   }
 }
 
-template <int MBT, bool RMS, int EPI>
+template <int MBT, int KT, bool RMS, int EPI>
 __global__ __launch_bounds__(256) void gemm_dec32x_k(Dec32xArgs a) {
   constexpr int NACC = (EPI == EPI_SILU_MUL) ? 2 : 1;
-  constexpr int U = DxU<MBT>::v;
+  constexpr int U = DxU<MBT, KT>::v;
   __shared__ __attribute__((aligned(16))) float red[4][NACC][MBT][64][4];
   __shared__ float rstd_s[16 * MBT];
   CTTS_PROBE_RETURN();
@@ -222,7 +270,8 @@ __global__ __launch_bounds__(256) void gemm_dec32x_k(Dec32xArgs a) {
   // dependent scalar load) is known
   u128 wh[NACC][U], wl[NACC][U];
   {
-    const int KCH = a.K >> 5, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nper = KCH / 4;
+    constexpr int KCH = KT >> 5, nper = KCH / 4;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const u128* wp = reinterpret_cast<const u128*>(a.Wp) + ((size_t)tile * KCH + wave * nper) * 64 + lane;
     const u128* wp2 = wp + (size_t)(a.N >> 4) * KCH * 64;
     const size_t wpl = a.w_plane >> 3;
@@ -244,15 +293,15 @@ __global__ __launch_bounds__(256) void gemm_dec32x_k(Dec32xArgs a) {
   if (mt0 * 16 >= M) return;
   const int nmb = min(MBT, (M - mt0 * 16 + 15) >> 4);
   if constexpr (MBT == 1) {
-    dec32x_body<1, MBT, RMS, EPI>(a, M, tile, mt0, wh, wl, red, rstd_s);
+    dec32x_body<1, MBT, KT, RMS, EPI>(a, M, tile, mt0, wh, wl, red, rstd_s);
   } else if constexpr (MBT == 2) {
-    if (nmb == 1) dec32x_body<1, MBT, RMS, EPI>(a, M, tile, mt0, wh, wl, red, rstd_s);
-    else dec32x_body<2, MBT, RMS, EPI>(a, M, tile, mt0, wh, wl, red, rstd_s);
+    if (nmb == 1) dec32x_body<1, MBT, KT, RMS, EPI>(a, M, tile, mt0, wh, wl, red, rstd_s);
+    else dec32x_body<2, MBT, KT, RMS, EPI>(a, M, tile, mt0, wh, wl, red, rstd_s);
   } else {
-    if (nmb == 1) dec32x_body<1, MBT, RMS, EPI>(a, M, tile, mt0, wh, wl, red, rstd_s);
-    else if (nmb == 2) dec32x_body<2, MBT, RMS, EPI>(a, M, tile, mt0, wh, wl, red, rstd_s);
-    else if (nmb == 3) dec32x_body<3, MBT, RMS, EPI>(a, M, tile, mt0, wh, wl, red, rstd_s);
-    else dec32x_body<4, MBT, RMS, EPI>(a, M, tile, mt0, wh, wl, red, rstd_s);
+    if (nmb == 1) dec32x_body<1, MBT, KT, RMS, EPI>(a, M, tile, mt0, wh, wl, red, rstd_s);
+    else if (nmb == 2) dec32x_body<2, MBT, KT, RMS, EPI>(a, M, tile, mt0, wh, wl, red, rstd_s);
+    else if (nmb == 3) dec32x_body<3, MBT, KT, RMS, EPI>(a, M, tile, mt0, wh, wl, red, rstd_s);
+    else dec32x_body<4, MBT, KT, RMS, EPI>(a, M, tile, mt0, wh, wl, red, rstd_s);
   }
 }
 
@@ -265,9 +314,10 @@ template <int MBT>
 static hipError_t dec32x_dispatch(const Dec32xArgs& a, hipStream_t st) {
   const int mt = (a.M + 15) / 16;
   dim3 grid(a.N / 16, (mt + MBT - 1) / MBT), block(256);
-  if (a.epi == EPI_RES && !a.rms) CTTS_LAUNCH((gemm_dec32x_k<MBT, false, EPI_RES>), grid, block, st, a);
-  else if (a.epi == EPI_SILU_MUL && a.rms) CTTS_LAUNCH((gemm_dec32x_k<MBT, true, EPI_SILU_MUL>), grid, block, st, a);
-  else if (a.epi == D32_EPI_QKV_ROPE && a.rms) CTTS_LAUNCH((gemm_dec32x_k<MBT, true, D32_EPI_QKV_ROPE>), grid, block, st, a);
+  if (a.epi == EPI_RES && !a.rms && a.K == 768) CTTS_LAUNCH((gemm_dec32x_k<MBT, 768, false, EPI_RES>), grid, block, st, a);
+  else if (a.epi == EPI_RES && !a.rms && a.K == 3072) CTTS_LAUNCH((gemm_dec32x_k<MBT, 3072, false, EPI_RES>), grid, block, st, a);
+  else if (a.epi == EPI_SILU_MUL && a.rms && a.K == 768) CTTS_LAUNCH((gemm_dec32x_k<MBT, 768, true, EPI_SILU_MUL>), grid, block, st, a);
+  else if (a.epi == D32_EPI_QKV_ROPE && a.rms && a.K == 768) CTTS_LAUNCH((gemm_dec32x_k<MBT, 768, true, D32_EPI_QKV_ROPE>), grid, block, st, a);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }
@@ -277,16 +327,18 @@ hipError_t launch_gemm_dec32x(const Dec32xArgs& a_in, hipStream_t st) {
   static int nt = -1, mb_qkv = 4, mb_silu = 4, mb_o = 1, mb_down = 1;
   if (nt < 0) {
     nt = env_i("CTTS_W_NT", 1);
-    // rows per workgroup (A/B knobs): the matrix pipe is no longer what these launches cost, so the RMSNorm launches take all <= 64 rows
-    // per weight tile (one pass over the weights, as the perf mode does), o / down (48 weight tiles) stay 16-row workgroups
+    // rows per workgroup (A/B knobs; profiles/r5h_ab_x3_mb.log, r5i_ab_x3_rounds.log): the RMSNorm launches take all <= 64 rows per weight
+    // tile -- every weight fragment crosses L2 -> CU once instead of once per row tile (16-row workgroups: 110 MB of operand traffic per
+    // gate/up launch for 19 MB of weights) --, o / down (48 weight tiles) stay 16-row workgroups (2 rows per workgroup: 906 vs 981)
     mb_qkv = env_i("CTTS_D32X_MB_QKV", 4); mb_silu = env_i("CTTS_D32X_MB_SILU", 4);
     mb_o = env_i("CTTS_D32X_MB_O", 1); mb_down = env_i("CTTS_D32X_MB_DOWN", 1);
   }
   a.w_nt = nt;
   // K: chunks of 32, 4 waves, rounds of 6 (3) chunks
-  if (a.M <= 0 || a.N <= 0 || (a.N & 15) || a.K % (32 * 4 * 6) != 0 || !a.Ap || !a.Wp || (a.a_plane & 7) || (a.w_plane & 7) || (a.c_plane & 7))
+  if (a.M <= 0 || a.N <= 0 || (a.N & 15) || (a.K != 768 && a.K != 3072) || !a.Ap || !a.Wp || (a.a_plane & 7) || (a.w_plane & 7) || (a.c_plane & 7))
     return hipErrorInvalidValue;
-  if (a.rms && (a.X == nullptr || (a.ldx & 3) || a.K != 768)) return hipErrorInvalidValue;
+  if (a.rms && a.K != 768) return hipErrorInvalidValue;
+  if (a.rms && a.ssq_in == nullptr && (a.X == nullptr || (a.ldx & 3))) return hipErrorInvalidValue;
   if (a.epi == D32_EPI_QKV_ROPE && (a.N != 2304 || a.K != 768 || !a.desc || !a.kc || !a.vc || !a.C)) return hipErrorInvalidValue;
   if (a.epi == EPI_RES && (!a.res || !a.C)) return hipErrorInvalidValue;
   if (a.epi == EPI_SILU_MUL && !a.Cp) return hipErrorInvalidValue;

@@ -206,7 +206,11 @@ struct Dec32xArgs {
   const uint16_t* Wp; size_t w_plane;   // weights likewise, [N/16 (SILU_MUL: gate tiles then up tiles)][K/32][64][8]
   int M, N, K;                          // M = rows the buffers hold; live rows = *n_active
   const int32_t* n_active;
-  int rms; const float* X; int ldx; float eps;   // RMSNorm launches (K = 768): the rows, row-major f32, for 1 / rms (gemm_skinny_k's arithmetic)
+  int rms; const float* X; int ldx; float eps;   // RMSNorm launches (K = 768): 1 / rms of the rows scales the accumulator -- from ssq_in, else from
+                                                 // the rows themselves (row-major f32, gemm_skinny_k's arithmetic)
+  const float* ssq_in;                  // RMSNorm launches: [rows][48] partial sums of squares of the rows (one per 16 columns), or null
+  float* ssq_out;                       // RES: the same for the new residual rows, or null
+  const float* rope_cs;                 // QKV_ROPE: [rows][64] cos[32] | sin[32] of each row's position (StepPrep.rope_cs), or null (cos_t / sin_t via desc)
   int epi;                              // D32_EPI_QKV_ROPE | EPI_RES | EPI_SILU_MUL
   float* C; int ldc;                    // RES: the new residual rows (row-major f32); QKV_ROPE: the qkv buffer
   const float* res; int ldr;

@@ -366,12 +366,14 @@ int ctts_k_gemm_dec32(const float* Ap, const float* Wp, int32_t M, int32_t N, in
 /* The same projections on SPLIT-bf16 operands (csrc/decode32x.hip; ctts_gpt_weights.wqkv_x3 ...): Ap / Wp = hi planes in the bf16 fragment order
  * ([rows/16][K/32][64][8]), the lo planes a_plane / w_plane ELEMENTS behind them; three bf16 MFMAs per product (lo*hi + hi*lo + hi*hi), f32
  * accumulation.  X != NULL (K = 768): RMSNorm launch -- 1 / rms of the rows of X (row-major f32, gemm_skinny_k's arithmetic) scales the
- * accumulator, the gain is expected folded into W.  epi 1 = C = res + acc (row-major f32), Cp = its planes (c_plane elements apart, kch_out =
+ * accumulator, the gain is expected folded into W; ssq_in != NULL instead: [rows][48] partial sums of squares of the rows (one per 16 columns, what
+ * the decode step's producers leave); ssq_out (epi 1): the same partials of the NEW rows.  epi 1 = C = res + acc (row-major f32), Cp = its planes (c_plane elements apart, kch_out =
  * N / 32) and optionally Cp32 = its packed f32 copy; epi 2 = SiLU(gate) * up -> Cp planes (W = gate tiles then up tiles).  Reference ops:
  * examples/onnx/modeling_llama.py:293,415-417,500. */
 int ctts_k_gemm_dec32x(const uint16_t* Ap, int64_t a_plane, const uint16_t* Wp, int64_t w_plane, int32_t M, int32_t N, int32_t K,
                        const int32_t* n_active, const float* X, int32_t ldx, float eps, int32_t epi, float* C, int32_t ldc, const float* res,
-                       int32_t ldr, uint16_t* Cp, int64_t c_plane, int32_t kch_out, float* Cp32, int32_t force_mb, void* stream);
+                       int32_t ldr, uint16_t* Cp, int64_t c_plane, int32_t kch_out, float* Cp32, int32_t force_mb, const float* ssq_in,
+                       float* ssq_out, void* stream);
 /* which decode32 kernel the calling thread's last ctts_k_gemm_dec32 / decode step picked: "rms16" | "m16" | "generic" (all bit-identical) */
 const char* ctts_k_dec32_last_variant(void);
 int ctts_k_rows_prep(const float* x32, uint16_t* xb, float* ssq, int32_t M, void* stream);

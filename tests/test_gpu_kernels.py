@@ -263,9 +263,14 @@ def test_gemm_dec32x_split_bf16(G, M, n_act, force_mb):
         Cp32 = torch.full((Mp * N,), float("nan"), dtype=torch.float32, device=G.DEV) if epi == 1 else None
         A_d = G.dev(A)
         res_d = None if res is None else G.dev(res)
+        # RMSNorm launches: 1 / rms from the rows themselves (even seeds) or from 48 partial sums of squares per row (odd: the decode step's way)
+        via_ssq = rms and (M + force_mb) % 2 == 1
+        ssq_in = G.dev((A.reshape(M, 48, 16).astype(np.float64) ** 2).sum(-1).astype(f32)) if via_ssq else None
+        ssq_out = torch.full((M, 48), float("nan"), dtype=torch.float32, device=G.DEV) if epi == 1 else None
         _lib.check(lib.ctts_k_gemm_dec32x(planes_a.data_ptr(), Mp * K, planes_w.data_ptr(), nrows * K, M, N, K, _lib.ptr(na_d),
-                                          A_d.data_ptr() if rms else None, K, 1e-6, epi, Cc.data_ptr() if epi == 1 else None, N,
-                                          _lib.ptr(res_d), N, Cp.data_ptr(), Mp * N, N // 32, _lib.ptr(Cp32), force_mb, None), "dec32x")
+                                          A_d.data_ptr() if (rms and not via_ssq) else None, K, 1e-6, epi, Cc.data_ptr() if epi == 1 else None, N,
+                                          _lib.ptr(res_d), N, Cp.data_ptr(), Mp * N, N // 32, _lib.ptr(Cp32), force_mb, _lib.ptr(ssq_in),
+                                          _lib.ptr(ssq_out), None), "dec32x")
         torch.cuda.synchronize()
         # float64 models
         a_h, a_l = (x.float().numpy().astype(np.float64)[:live] for x in split(A))
@@ -289,6 +294,9 @@ def test_gemm_dec32x_split_bf16(G, M, n_act, force_mb):
             assert np.abs(got[:live] - full).max() < 2e-5 * scale, (N, K, np.abs(got[:live] - full).max() / scale)
             assert np.array_equal(unpack_frag32(Cp32.cpu(), Mp, N).numpy()[:live], got[:live])
             assert np.abs(got_planes[:live] - got[:live]).max() < 2e-5 * scale      # planes hold the row to 16-17 bits
+            sq = ssq_out.cpu().numpy()
+            want_sq = (got[:live].astype(np.float64).reshape(live, 48, 16) ** 2).sum(-1)
+            assert np.abs(sq[:live] - want_sq).max() < 1e-5 * want_sq.max() and np.isnan(sq[live:]).all()
         else:
             assert np.abs(got_planes[:live] - exact).max() < 2e-5 * scale, (N, K, np.abs(got_planes[:live] - exact).max() / scale)
         assert np.isnan(got_planes[live:M]).all()
