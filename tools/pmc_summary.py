@@ -41,6 +41,10 @@ def short(name):
             return "gate_up_gemm"
         if epi == 1:
             return "o_proj_gemm" if nw == 4 else "down_gemm"
+    m = re.search(r"gemm_dec32x_k<(\d+), (\d+), (true|false), (\d+)>", name)
+    if m:                           # parity mode, split-bf16 decode projections (decode32x.hip): <MBT, K, RMS, EPI>
+        kt, epi = int(m.group(2)), int(m.group(4))
+        return {100: "qkv_gemm_f32", 2: "gate_up_gemm_f32"}.get(epi, "o_proj_gemm_f32" if kt == 768 else "down_gemm_f32")
     if "gemm_dec32_fnorm16_k" in name or "gemm_dec32_m16_k<768, 0>" in name or "gemm_skinny_k<float" in name:
         return "heads_gemm"         # fused final-norm + heads | packed heads | row-major heads
     if "sample_k" in name:
