@@ -320,6 +320,31 @@ __device__ __forceinline__ float group_sum(float d) {   // sum over the LPK (8 |
 #endif
   return d;
 }
+// x + its partners at lane ^ o for o = LPK, 2 LPK, ... 32 (the merge of a wave's key groups), in the xor butterfly's order and with its bits:
+// o = 8 is a rotation by 8 inside the 16-lane row (DPP row_ror:8), o = 16 / 32 swap rows / halves between two copies of the register
+// (v_permlane16_swap_b32 / v_permlane32_swap_b32, gfx950) -- no LDS round trip.  9 values x 3 steps at the end of every unit.
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+template <int LPK>
+__device__ __forceinline__ float groups_sum(float x, const int lane) {
+#if CTTS_ATT_DPP
+  if (LPK == 8) x += dpp_f<0x128>(x);   // row_ror:8 = lane ^ 8 within the row
+  {
+    const unsigned xi = __float_as_uint(x);
+    const u32x2_t r = __builtin_amdgcn_permlane16_swap(xi, xi, false, false);   // .x = [r0 r0 r2 r2], .y = [r1 r1 r3 r3]
+    x += __uint_as_float((lane & 16) ? r.x : r.y);
+  }
+  {
+    const unsigned xi = __float_as_uint(x);
+    const u32x2_t r = __builtin_amdgcn_permlane32_swap(xi, xi, false, false);   // .x = [lo lo], .y = [hi hi]
+    x += __uint_as_float((lane & 32) ? r.x : r.y);
+  }
+  return x;
+#else
+#pragma unroll
+  for (int o = LPK; o < 64; o <<= 1) x += __shfl_xor(x, o, 64);
+  return x;
+#endif
+}
 template <int LPK>
 __device__ __forceinline__ float groups_max(float v) {  // max over the key groups of the wave (v is uniform within a group); exact in any order
 #if CTTS_ATT_DPP
@@ -658,12 +683,9 @@ __device__ __forceinline__ void attention_body(const float* __restrict__ qkv, co
     __builtin_amdgcn_sched_barrier(0);
   }
   // merge the key groups of this wave (same running max in every lane)
+  lrun = groups_sum<LPK>(lrun, lane);
 #pragma unroll
-  for (int o = LPK; o < 64; o <<= 1) {
-    lrun += __shfl_xor(lrun, o, 64);
-#pragma unroll
-    for (int e = 0; e < DPL; ++e) acc[e] += __shfl_xor(acc[e], o, 64);
-  }
+  for (int e = 0; e < DPL; ++e) acc[e] = groups_sum<LPK>(acc[e], lane);
   if (NW == 1) {
     if (kg == 0) {
       const float inv = 1.0f / lrun;
@@ -924,12 +946,9 @@ __global__ __launch_bounds__(256) void attention_persist_k(const float* __restri
     mrun = mnew;
   };
   auto finish_unit = [&]() {   // attention_body's merge: key groups by shuffles, waves through LDS (double-buffered by unit parity)
+    lrun = groups_sum<LPK>(lrun, lane);
 #pragma unroll
-    for (int o = LPK; o < 64; o <<= 1) {
-      lrun += __shfl_xor(lrun, o, 64);
-#pragma unroll
-      for (int e = 0; e < DPL; ++e) acc[e] += __shfl_xor(acc[e], o, 64);
-    }
+    for (int e = 0; e < DPL; ++e) acc[e] = groups_sum<LPK>(acc[e], lane);
     if (kg == 0) {
       if (dl == 0) { sm_m[par][wave] = mrun; sm_l[par][wave] = lrun; }
 #pragma unroll
