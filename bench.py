@@ -639,6 +639,34 @@ def main():
         result["pipelined_queue"] = {"value": round(audio_seconds(stop) * 4 / dtp, 2), "unit": "audio-s/s", "steps": 4, "ms_per_step": round(1000.0 * dtp / 4, 3),
                                      "what": "the acoustic decode + waveform D2H of batch i on the codec engine's side HIP stream while batch i+1 is "
                                              "generated; all waveforms on the host before the clock stops"}
+    if world == 1 and not args.pipeline and not args.no_parity_mode:
+        # the same passes ending in 16-bit PCM instead of float32: float_to_int16 (tools/audio/np.py:7-11, what every caller of the reference
+        # does next) + the silence strip's mask ON THE DEVICE, int16 + 1 bit per sample over PCIe (Chat.decode_to_pcm16).  Beside `value`,
+        # which stays the reference's float32 `.cpu().numpy()`.
+        note("pcm16 output leg")
+        def pcm_pass():
+            emb = gpt.embed_prompt(ids_d, tm_d)
+            out = None
+            for out in gpt.generate(emb, ids_d, temp, 625, mask_d, max_new, 0, (*procs, *warpers), return_hidden=True, manual_seed=42,
+                                    use_graph=not args.no_graph, stop_at=stop_t, row_offset=wl["row_offset"], total_rows=wl["total_rows"]):
+                pass
+            wav = codec.decode_to_wavs(out.hiddens)
+            pcm, keep = codec.float_to_int16(wav, per_row=True, keep_thr=1e-5)
+            return codec.to_host(pcm), codec.to_host(keep), wav
+        pcm_pass()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            pcm_h, keep_h, wav_d = pcm_pass()
+        torch.cuda.synchronize(dev)
+        dtq = time.perf_counter() - t0
+        from chattts_amd import audio as _audio
+        w0 = wav_d[0].cpu().numpy()
+        result["pcm16_output"] = {"value": round(audio_seconds(stop) * 3 / dtq, 2), "unit": "audio-s/s", "steps": 3, "ms_per_step": round(1000.0 * dtq / 3, 3),
+                                  "d2h_bytes_per_pass": int(pcm_h.nbytes + keep_h.nbytes), "d2h_bytes_float32_path": int(pcm_h.size * 4),
+                                  "row0_equals_host_float_to_int16": bool(np.array_equal(pcm_h[0], _audio.float_to_int16(w0))),
+                                  "what": "generate + DVAE + Vocos + float_to_int16 (per utterance) + silence-strip mask on the device, int16 + mask to the host"}
+        del pcm_h, keep_h, wav_d
     if world == 1 and not args.pipeline and not args.no_slot_pool and args.dtype == "bf16":
         # the same utterances as a QUEUE served by continuous batching (chattts_amd/serving.py): 4 batches' worth of
         # requests through a pool of `batch` slots -- a request is admitted the moment a slot frees up, so the decode step stays full

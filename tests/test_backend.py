@@ -138,3 +138,27 @@ def test_chat_infer_pcm16_equals_float_to_int16_of_infer(weights):
     # ... and the streamer over the float chunks is the reference's byte stream for ONE listener (its conversion is per collected block)
     blocks = list(ChatStreamer(base_block_size=2000).generate(iter(chunks_f), "PCM16_byte"))
     assert blocks and all(isinstance(b, bytes) and len(b) % 2 == 0 for b in blocks)
+
+
+@pytest.mark.gpu
+def test_chat_warm_hands_the_first_request_a_ready_session(weights):
+    """`Chat.warm(B, T, params)` / `Chat.load(..., warm=...)`: the first real request of that geometry reuses the session the warm-up
+    built (same buffers, graph already instantiated) and yields exactly what an un-warmed engine yields; the interrupt flag the warm-up
+    used is restored."""
+    from chattts_amd import synth
+    from chattts_amd.core import Chat, InferCodeParams
+    dev = torch.device("cuda:0")
+    ids, mask, tmask = synth.make_prompts(4, 7, 12, seed=3)
+    a = (torch.from_numpy(ids), torch.from_numpy(mask), torch.from_numpy(tmask))
+    p = InferCodeParams(max_new_token=40, min_new_token=40, manual_seed=5, show_tqdm=False, stream_batch=8, stream_speed=3000, pass_first_n_batches=1)
+    cold = Chat()
+    assert cold.load(state_dicts=weights, device=dev, dtype="bf16")
+    want = list(cold.infer_ids_stream(*a, p))
+    warm = Chat()
+    assert warm.load(state_dicts=weights, device=dev, dtype="bf16", warm=(4, ids.shape[1], p))
+    sess = warm.gpt._session
+    assert sess is not None and sess["graph"] and not warm.context.get()
+    got = list(warm.infer_ids_stream(*a, p))
+    assert warm.gpt._session is sess                         # not rebuilt: the request found its geometry
+    assert len(got) == len(want) >= 3 and all(np.array_equal(x, y) for x, y in zip(got, want))
+    assert warm.warm(4, ids.shape[1], p) < 5.0               # idempotent, and cheap the second time
