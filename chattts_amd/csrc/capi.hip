@@ -968,9 +968,10 @@ extern "C" int ctts_k_attention_dec(const float* qkv, const uint16_t* kcache, co
 // CTTS_F32: f32 cache, packed f32 output); `covers_all`: descriptors are valid for all M rows (absent rows carry b = -1) and n_active is not read
 extern "C" int ctts_k_attention_dec2(const float* qkv, const void* kcache, const void* vcache, int32_t kv_dtype, int32_t cmax, void* out_packed,
                                      const int32_t* desc, const int32_t* n_active, int32_t covers_all, int32_t M, void* stream) {
-  if (!desc || M <= 0) return fail("ctts_k_attention_dec2: bad arguments");
+  if (!desc || M <= 0 || kv_dtype < 0 || kv_dtype > 2) return fail("ctts_k_attention_dec2: bad arguments");
   GptRowMap rm{1, nullptr, nullptr, nullptr, n_active, nullptr, reinterpret_cast<const RowDesc*>(desc), nullptr, nullptr, 0, 0, covers_all};
-  CK(launch_attention(qkv, kcache, vcache, kv_dtype == CTTS_BF16 ? WT_BF16 : WT_F32, cmax, out_packed, kv_dtype == CTTS_BF16 ? 2 : 3, rm, M,
+  if (kv_dtype == 2) rm.x3_plane = ((size_t)M + 15) / 16 * 16 * HID;   // f32 cache, output as hi | lo bf16 planes (the split-bf16 parity mode)
+  CK(launch_attention(qkv, kcache, vcache, kv_dtype == CTTS_BF16 ? WT_BF16 : WT_F32, cmax, out_packed, kv_dtype == CTTS_BF16 ? 2 : kv_dtype == 2 ? 4 : 3, rm, M,
                       (hipStream_t)stream));
   return 0;
 }

@@ -393,7 +393,8 @@ int ctts_k_attention_prefill(const float* qkv, const uint16_t* kcache, const uin
 int ctts_k_attention_dec(const float* qkv, const uint16_t* kcache, const uint16_t* vcache, int32_t cmax, uint16_t* out_packed,
                          const int32_t* desc, const int32_t* n_active, int32_t M, float* part, int32_t* cnt, int32_t n_cu, void* stream);
 /* Decode attention of EITHER mode the way the decode step launches it (round 5): kv_dtype CTTS_BF16 = bf16 cache, bf16 output in the
- * fragment-packed order of csrc/decode.hip; CTTS_F32 = f32 cache, f32 output in the packed order of csrc/decode32.hip.  covers_all != 0:
+ * fragment-packed order of csrc/decode.hip; CTTS_F32 = f32 cache, f32 output in the packed order of csrc/decode32.hip; 2 = f32 cache, output as
+ * hi | lo bf16 planes in decode.hip's order, the lo plane ceil16(M) * 768 elements behind (the split-bf16 parity mode, csrc/decode32x.hip).  covers_all != 0:
  * desc is valid for all M rows (absent rows carry slot -1) and n_active is not read.  Runs the persistent grid (csrc/gpt.hip
  * attention_persist_k: <= one workgroup per CU walking the live (utterance, head) units) unless ctts_k_attention_cfg / CTTS_ATT_PERSIST=0
  * selected one workgroup per unit (attention_k); both give the same bits.  Reference op: examples/onnx/modeling_llama.py:455-475. */

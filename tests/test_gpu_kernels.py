@@ -791,6 +791,19 @@ def test_attention_decode_persistent_grid(G, mode, n_live):
 
             unit = run(0, 0, 0)
             live = [m for m in range(n_live) if m != dead]
+            if not bf:     # the split-bf16 parity mode's output: the SAME f32 result, stored as hi = bf16(o), lo = bf16(o - hi) planes
+                for persist in (0, 1):
+                    _lib.check(lib.ctts_k_attention_cfg(persist, 256, 4), "attention_cfg")
+                    pl = torch.full((2, Bp * H), float("nan"), dtype=torch.float32, device=G.DEV).to(torch.bfloat16)
+                    _lib.check(lib.ctts_k_attention_dec2(q_d.data_ptr(), kc.data_ptr(), vc.data_ptr(), 2, cmax, pl.data_ptr(), desc_d.data_ptr(),
+                                                         None if covers_all else na.data_ptr(), covers_all, Bp, None), "attention_dec2 planes")
+                    torch.cuda.synchronize()
+                    hi = unpack_frag(pl[0].float().cpu(), Bp, H)
+                    lo = unpack_frag(pl[1].float().cpu(), Bp, H)
+                    o32 = torch.from_numpy(unit)
+                    want_hi = o32.to(torch.bfloat16).float()
+                    want_lo = (o32 - want_hi).to(torch.bfloat16).float()
+                    assert torch.equal(hi[live], want_hi[live]) and torch.equal(lo[live], want_lo[live]), persist
             ref = np.zeros((Bp, H))
             for m in live:
                 b = slots_b[m]
