@@ -95,6 +95,8 @@ SIGNATURES = {
     "ctts_gpt_decode_step": (C.c_int, [P, C.POINTER(GenState), P]),
     "ctts_gpt_graph_build": (C.c_int, [P, C.POINTER(GenState), P]),
     "ctts_gpt_graph_launch": (C.c_int, [P, I32, P]),
+    "ctts_gpt_graph_build_rows": (C.c_int, [P, C.POINTER(GenState), I32, P]),
+    "ctts_gpt_graph_launch_rows": (C.c_int, [P, I32, I32, P]),
     "ctts_gpt_graph_destroy": (None, [P]),
     "ctts_gpt_profile_begin": (C.c_int, [P, I32, I32, I32]),
     "ctts_gpt_profile_end": (C.c_int, [P, C.POINTER(I32), C.POINTER(C.c_double)]),

@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <map>
 #include <vector>
 
 #include "../../include/chattts_amd.h"
@@ -55,6 +56,11 @@ struct ctts_gpt {
   // multi_steps steps instead of one per step
   hipGraph_t graph_multi = nullptr;
   hipGraphExec_t exec_multi = nullptr;
+  // round 5: the same step captured for a BOUND on the live rows (ctts_gpt_graph_build_rows): every grid of the step is sized for `rows`
+  // compact rows instead of B -- the attention launch loses its dead workgroups (12 per finished utterance), the 16-row projections their
+  // dead row tiles.  Nothing else changes: the kernels still read the live count, so a bound that is merely >= it gives the same bits.
+  struct RowsGraph { hipGraph_t graph = nullptr, gm = nullptr; hipGraphExec_t exec = nullptr, exec_multi = nullptr; };
+  std::map<int, RowsGraph> rows_graphs;
   int multi_steps = 1;
   // profiling (eager decode only)
   int prof_tag = -1;
@@ -195,6 +201,13 @@ extern "C" void ctts_gpt_graph_destroy(ctts_gpt* g) {
   if (g->graph) { (void)hipGraphDestroy(g->graph); g->graph = nullptr; }
   if (g->exec_multi) { (void)hipGraphExecDestroy(g->exec_multi); g->exec_multi = nullptr; }
   if (g->graph_multi) { (void)hipGraphDestroy(g->graph_multi); g->graph_multi = nullptr; }
+  for (auto& kv : g->rows_graphs) {
+    if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+    if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
+    if (kv.second.exec_multi) (void)hipGraphExecDestroy(kv.second.exec_multi);
+    if (kv.second.gm) (void)hipGraphDestroy(kv.second.gm);
+  }
+  g->rows_graphs.clear();
 }
 
 extern "C" void ctts_gpt_destroy(ctts_gpt* g) {
@@ -268,9 +281,12 @@ static bool dev_compact(const ctts_gpt* g, const ctts_gen_state* s) {
 
 // the 20-layer body + heads + sampling over M = B * q_per_b rows
 static int run_step(ctts_gpt* g, const ctts_gen_state* s, int q_per_b, hipStream_t st, bool prof_ok, int slot0 = 0, bool heads = true,
-                    int ws_T = 0) {
+                    int ws_T = 0, int rows = 0) {
   const GptWs ws = carve(s->workspace, s->B, ws_T ? ws_T : s->T);
-  const int B = s->B, M = B * q_per_b, cmax = s->cap ? s->cap : s->T + s->max_new;
+  // `rows` (decode only): a bound on the live compact rows this step can have -- grids and M are sized for it instead of B (buffer
+  // geometry, the KV cache's batch stride above all, stays B's)
+  const int B = s->B, Bh = (q_per_b == 1 && rows > 0 && rows < s->B) ? rows : s->B, M = q_per_b == 1 ? Bh : B * q_per_b;
+  const int cmax = s->cap ? s->cap : s->T + s->max_new;
   const int wt = g->w.weight_dtype, kt = g->w.kv_dtype;
   const size_t kv_layer = (size_t)(s->kv_batch ? s->kv_batch : B) * NHEAD * cmax * HDIM * (kt == CTTS_BF16 ? 2 : 4);
   const bool dec = q_per_b == 1;
@@ -505,7 +521,7 @@ static int run_step(ctts_gpt* g, const ctts_gen_state* s, int q_per_b, hipStream
     const int nlog = s->infer_text ? g->w.n_text : NVQ * NAUDIO;
     Dec32Args d;
     memset(&d, 0, sizeof(d));
-    d.Ap = x3 ? ws.hfinp : ws.xp32; d.Wp = s->infer_text ? g->w.head_text_pk : g->w.heads_pk; d.M = B; d.N = (nlog + 15) / 16 * 16; d.K = HID; d.n_active = nact;
+    d.Ap = x3 ? ws.hfinp : ws.xp32; d.Wp = s->infer_text ? g->w.head_text_pk : g->w.heads_pk; d.M = Bh; d.N = (nlog + 15) / 16 * 16; d.K = HID; d.n_active = nact;
     d.epi = EPI_STORE; d.C = ws.logits; d.ldc = nlog; d.n_cols = nlog;
     d.fnorm = 1; d.norm_w = g->w.norm; d.eps = g->w.rms_eps; d.desc = ws.desc; d.hid = s->hiddens; d.hid_cap = s->hid_cap ? s->hid_cap : s->max_new;
     d.T = s->T; d.prompt_len = s->prompt_len;
@@ -513,7 +529,7 @@ static int run_step(ctts_gpt* g, const ctts_gen_state* s, int q_per_b, hipStream
     CK(launch_gemm_dec32(d, st));
   } else {
   { Prof p(g, 7, st, prof_ok);
-    CK(launch_final_norm(ws.x, q_per_b, g->w.norm, g->w.rms_eps, ws.hfin, s->hiddens, s->hid_cap ? s->hid_cap : s->max_new, s->len, s->T, B, rmap,
+    CK(launch_final_norm(ws.x, q_per_b, g->w.norm, g->w.rms_eps, ws.hfin, s->hiddens, s->hid_cap ? s->hid_cap : s->max_new, s->len, s->T, Bh, rmap,
                          nact, s->prompt_len, st, ws.hfinp)); }
   {
     const int nlog = s->infer_text ? g->w.n_text : NVQ * NAUDIO;   // gpt.py:439-440 text head | :441-454 four code heads
@@ -521,7 +537,7 @@ static int run_step(ctts_gpt* g, const ctts_gen_state* s, int q_per_b, hipStream
     if (g->heads_packed && hpk != nullptr) {   // same arithmetic as the row-major kernel below, operands in fragment order
       Dec32Args d;
       memset(&d, 0, sizeof(d));
-      d.Ap = ws.hfinp; d.Wp = hpk; d.M = B; d.N = (nlog + 15) / 16 * 16; d.K = HID; d.n_active = nact; d.epi = EPI_STORE;
+      d.Ap = ws.hfinp; d.Wp = hpk; d.M = Bh; d.N = (nlog + 15) / 16 * 16; d.K = HID; d.n_active = nact; d.epi = EPI_STORE;
       d.C = ws.logits; d.ldc = nlog; d.n_cols = nlog;
       Prof p(g, 8, st, prof_ok);
       CK(launch_gemm_dec32(d, st));
@@ -529,7 +545,7 @@ static int run_step(ctts_gpt* g, const ctts_gen_state* s, int q_per_b, hipStream
     GemmArgs a;
     memset(&a, 0, sizeof(a));
     a.taps = 1;
-    a.A = ws.hfin; a.lda = HID; a.W = s->infer_text ? g->w.head_text : g->w.heads; a.C = ws.logits; a.ldc = nlog; a.M = B; a.N = nlog;
+    a.A = ws.hfin; a.lda = HID; a.W = s->infer_text ? g->w.head_text : g->w.heads; a.C = ws.logits; a.ldc = nlog; a.M = Bh; a.N = nlog;
     a.K = HID; a.wt = WT_F32; a.epi = EPI_STORE; a.n_active = nact;
     Prof p(g, 8, st, prof_ok);
     CK(launch_gemm_skinny(a, st));
@@ -539,6 +555,7 @@ static int run_step(ctts_gpt* g, const ctts_gen_state* s, int q_per_b, hipStream
   {
     Prof p(g, 9, st, prof_ok);
     SampleArgs sa = make_sample_args(s, ws.logits);
+    sa.B = Bh;   // (the grid; q_rows keeps the batch geometry)
     sa.row_map = rmap; sa.n_active = nact;
     if (dec && dev_compact(g, s)) sa.desc = ws.desc;   // one load instead of the n_active -> row_map -> len chain
     if (s->infer_text) CK(launch_sample_text(sa, g->w.n_text, st));
@@ -582,7 +599,7 @@ extern "C" int ctts_gpt_prefill_chunk(ctts_gpt* g, const ctts_gen_state* s, cons
 // The decode step carves the workspace for ONE row per utterance (ctts_gpt_workspace_bytes(B, 1)) whatever the prompt length was: a
 // caller that prefills in chunks of tc slots needs max(bytes(B, tc), bytes(B, 1)), not bytes(B, T).  Nothing in the workspace
 // survives from the prefill into the decode steps (all generation state lives in ctts_gen_state's own arrays).
-static int decode_body(ctts_gpt* g, const ctts_gen_state* s, hipStream_t st, bool prof_ok) {
+static int decode_body(ctts_gpt* g, const ctts_gen_state* s, hipStream_t st, bool prof_ok, int rows = 0) {
   const GptWs ws = carve(s->workspace, s->B, 1);
   { Prof p(g, 0, st, prof_ok); const bool fast = g->w.weight_dtype == CTTS_BF16;
     const bool packed = fast && g->dec_packed;
@@ -597,20 +614,45 @@ static int decode_body(ctts_gpt* g, const ctts_gen_state* s, hipStream_t st, boo
                 (packed && g->qkv_att && g->w.n_layers <= QA_LAYERS_MAX) ? ws.qa_flag : nullptr, g->w.n_layers * NHEAD, QA_STRIDE};
     const int32_t* nact0 = (!g->skip_finished && s->row_map == nullptr) ? nullptr : s->n_active;
     uint16_t* xb = fast ? (packed ? ws.xp : ws.xb) : x3 ? reinterpret_cast<uint16_t*>(ws.xp32) : nullptr;
-    if (x3) sp.xb_lo_plane = ((size_t)s->B + 15) / 16 * 16 * HID;
+    if (x3) sp.xb_lo_plane = ((size_t)((rows > 0 && rows < s->B) ? rows : s->B) + 15) / 16 * 16 * HID;   // = run_step's plane stride for this bound
     if (s->infer_text)
       CK(launch_embed_text(g->w.emb_text, g->w.n_text, s->ids_buf, s->cap ? s->cap : s->T + s->max_new, s->len, ws.x, xb,
                            (fast || x3) ? ws.ssq : nullptr, s->B, s->row_map, nact0, st, &sp));
     else
       CK(launch_embed_codes(g->w.emb_code, s->ids_buf, s->cap ? s->cap : s->T + s->max_new, s->len, ws.x, xb, (fast || x3) ? ws.ssq : nullptr, s->B,
                             s->row_map, nact0, st, &sp)); }
-  return run_step(g, s, 1, st, prof_ok, 0, true, 1);
+  return run_step(g, s, 1, st, prof_ok, 0, true, 1, rows);
 }
 
 extern "C" int ctts_gpt_decode_step(ctts_gpt* g, const ctts_gen_state* s, void* stream) {
   if (check_state(g, s, 1)) return -1;
   CttsDeviceGuard dg(stream);
   return decode_body(g, s, (hipStream_t)stream, true);
+}
+
+// captures decode_body (rows bound `rows`, 0 = the whole batch) as a 1-step graph and as a graph of g->multi_steps steps
+static int capture_graphs(ctts_gpt* g, const ctts_gen_state* s, hipStream_t st, int rows, hipGraph_t* graph, hipGraphExec_t* exec, hipGraph_t* gm,
+                          hipGraphExec_t* exec_multi) {
+  CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+  const int rc = decode_body(g, s, st, false, rows);
+  hipGraph_t gr = nullptr;
+  hipError_t e = hipStreamEndCapture(st, &gr);
+  if (rc != 0) { if (gr) (void)hipGraphDestroy(gr); return -1; }
+  if (e != hipSuccess) return fail("hipStreamEndCapture: %s", hipGetErrorString(e));
+  *graph = gr;
+  CK(hipGraphInstantiate(exec, gr, nullptr, nullptr, 0));
+  if (g->multi_steps > 1) {
+    CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    int rc2 = 0;
+    for (int i = 0; i < g->multi_steps && rc2 == 0; ++i) rc2 = decode_body(g, s, st, false, rows);
+    hipGraph_t g2 = nullptr;
+    hipError_t e3 = hipStreamEndCapture(st, &g2);
+    if (rc2 != 0) { if (g2) (void)hipGraphDestroy(g2); return -1; }
+    if (e3 != hipSuccess) return fail("hipStreamEndCapture (multi-step graph): %s", hipGetErrorString(e3));
+    *gm = g2;
+    CK(hipGraphInstantiate(exec_multi, g2, nullptr, nullptr, 0));
+  }
+  return 0;
 }
 
 extern "C" int ctts_gpt_graph_build(ctts_gpt* g, const ctts_gen_state* s, void* stream) {
@@ -624,30 +666,26 @@ extern "C" int ctts_gpt_graph_build(ctts_gpt* g, const ctts_gen_state* s, void* 
     const GptWs ws = carve(s->workspace, s->B, 1);
     CK(hipMemsetAsync(ws.att_cnt, 0, cnt_bytes(s->B), st));
   }
-  CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-  const int rc = decode_body(g, s, st, false);
-  hipGraph_t graph = nullptr;
-  hipError_t e = hipStreamEndCapture(st, &graph);
-  if (rc != 0) { if (graph) (void)hipGraphDestroy(graph); return -1; }
-  if (e != hipSuccess) return fail("hipStreamEndCapture: %s", hipGetErrorString(e));
-  g->graph = graph;
-  CK(hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0));
   // default 8 steps per launch of the multi-step graph: +0.5 % on the C3 bench over one hipGraphLaunch per step
   // (profiles/r3b_ab_fnorm_graphsteps.log: 1325 -> 1331-1334 audio-s/s with 8, 1328-1331 with 16)
   { const char* e2 = getenv("CTTS_GRAPH_STEPS"); g->multi_steps = e2 ? atoi(e2) : 8; }
-  if (g->multi_steps > 1 && g->multi_steps <= 64) {
-    CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-    int rc2 = 0;
-    for (int i = 0; i < g->multi_steps && rc2 == 0; ++i) rc2 = decode_body(g, s, st, false);
-    hipGraph_t gm = nullptr;
-    hipError_t e3 = hipStreamEndCapture(st, &gm);
-    if (rc2 != 0) { if (gm) (void)hipGraphDestroy(gm); return -1; }
-    if (e3 != hipSuccess) return fail("hipStreamEndCapture (multi-step graph): %s", hipGetErrorString(e3));
-    g->graph_multi = gm;
-    CK(hipGraphInstantiate(&g->exec_multi, g->graph_multi, nullptr, nullptr, 0));
-  } else {
-    g->multi_steps = 1;
-  }
+  if (g->multi_steps < 1 || g->multi_steps > 64) g->multi_steps = 1;
+  return capture_graphs(g, s, st, 0, &g->graph, &g->exec, &g->graph_multi, &g->exec_multi);
+}
+
+// The same step for a bound on the live rows (see ctts_gpt::rows_graphs).  Needs ctts_gpt_graph_build of the same state first (it owns the
+// geometry; ctts_gpt_graph_build / _destroy drop every bounded graph too).  rows >= B: nothing to build (the plain graph is that graph).
+extern "C" int ctts_gpt_graph_build_rows(ctts_gpt* g, const ctts_gen_state* s, int32_t rows, void* stream) {
+  if (check_state(g, s, 1)) return -1;
+  if (!g->exec) return fail("ctts_gpt_graph_build_rows: build the plain graph first");
+  if (rows <= 0) return fail("ctts_gpt_graph_build_rows: bad bound");
+  if (rows >= s->B || g->rows_graphs.count(rows)) return 0;
+  CttsDeviceGuard dg(stream);
+  hipStream_t st = (hipStream_t)stream;
+  if (st == nullptr) return fail("graph capture needs a non-default stream");
+  ctts_gpt::RowsGraph rg;
+  if (capture_graphs(g, s, st, rows, &rg.graph, &rg.exec, &rg.gm, &rg.exec_multi)) return -1;
+  g->rows_graphs[rows] = rg;
   return 0;
 }
 
@@ -657,6 +695,19 @@ extern "C" int ctts_gpt_graph_launch(ctts_gpt* g, int32_t n_steps, void* stream)
   int left = n_steps;
   while (g->exec_multi && left >= g->multi_steps) { CK(hipGraphLaunch(g->exec_multi, (hipStream_t)stream)); left -= g->multi_steps; }
   for (int i = 0; i < left; ++i) CK(hipGraphLaunch(g->exec, (hipStream_t)stream));
+  return 0;
+}
+
+// n_steps replays of the step captured for the bound `rows` (the caller guarantees live rows <= rows for all of them; rows >= B or a
+// bound that was never built: the plain graph)
+extern "C" int ctts_gpt_graph_launch_rows(ctts_gpt* g, int32_t n_steps, int32_t rows, void* stream) {
+  if (!g || !g->exec) return fail("no captured graph");
+  auto it = g->rows_graphs.find(rows);
+  if (rows <= 0 || it == g->rows_graphs.end()) return ctts_gpt_graph_launch(g, n_steps, stream);
+  CttsDeviceGuard dg(stream);
+  int left = n_steps;
+  while (it->second.exec_multi && left >= g->multi_steps) { CK(hipGraphLaunch(it->second.exec_multi, (hipStream_t)stream)); left -= g->multi_steps; }
+  for (int i = 0; i < left; ++i) CK(hipGraphLaunch(it->second.exec, (hipStream_t)stream));
   return 0;
 }
 

@@ -541,6 +541,7 @@ class GptEngine:
             lo, hi = ln.lo, ln.hi
             Bl = hi - lo
             ln.done, ln.end_snap = False, None
+            ln.live_ub = Bl      # upper bound of the lane's live utterances: what the last collected finish poll saw (flags only go up)
             with torch.cuda.stream(ln.st):
                 if sess.get("out_ev") is not None:
                     ln.st.wait_event(sess["out_ev"])   # the previous call's result copies have read these buffers
@@ -717,6 +718,7 @@ class GptEngine:
             ln.ev = ev
             ln.end_snap = end_h.tolist()
             ln.done = bool(fin_h.all())
+            ln.live_ub = (ln.hi - ln.lo) - int(fin_h.sum())
             return fin_h.clone()
 
         def poll(ln):
@@ -733,7 +735,19 @@ class GptEngine:
                     if ln.done:
                         continue
                     if graph_ok:
-                        _lib.check(lib.ctts_gpt_graph_launch(ln.handle, k, ln.st.cuda_stream), "ctts_gpt_graph_launch")
+                        # opt-in: the step captured for a BOUND on the live rows (16-row buckets below the batch; include/chattts_amd.h
+                        # ctts_gpt_graph_build_rows): finished utterances then cost no workgroups at all.  The bound is what the last
+                        # COLLECTED poll saw -- one or two chunks old, and finish flags only go up -- so it holds for every step enqueued
+                        # here; the kernels read the exact live count themselves, the bits do not depend on the bound.
+                        Bl_ = ln.hi - ln.lo
+                        rows = (max(ln.live_ub, 1) + 15) // 16 * 16 if rows_graphs else Bl_
+                        if rows < Bl_:
+                            if rows not in sess.setdefault("rows_built", [set() for _ in L])[L.index(ln)]:
+                                _lib.check(lib.ctts_gpt_graph_build_rows(ln.handle, C.byref(ln.s), rows, ln.st.cuda_stream), "ctts_gpt_graph_build_rows")
+                                sess["rows_built"][L.index(ln)].add(rows)
+                            _lib.check(lib.ctts_gpt_graph_launch_rows(ln.handle, k, rows, ln.st.cuda_stream), "ctts_gpt_graph_launch_rows")
+                        else:
+                            _lib.check(lib.ctts_gpt_graph_launch(ln.handle, k, ln.st.cuda_stream), "ctts_gpt_graph_launch")
                     else:
                         for _ in range(k):
                             _lib.check(lib.ctts_gpt_decode_step(ln.handle, C.byref(ln.s), ln.st.cuda_stream), "ctts_gpt_decode_step")
@@ -775,10 +789,15 @@ class GptEngine:
             return  # gpt.py:570: the seeded case yields nothing
 
         graph_ok = use_graph and max_new > 1
+        # OPT-IN (CTTS_GRAPH_ROWS=1): measured on the C3 bench it changes nothing -- 1399-1406 vs 1403-1413 audio-s/s, parity mode 1011-1031
+        # vs 1021-1037 (profiles/r5o_ab_graph_rows.log): like the persistent attention grid, it removes workgroups that were not what the
+        # step was waiting for.  Default: every chunk on the batch-sized graph.
+        rows_graphs = os.environ.get("CTTS_GRAPH_ROWS", "0") == "1"
         if graph_ok and not sess["graph"]:
             for ln in L:
                 _lib.check(lib.ctts_gpt_graph_build(ln.handle, C.byref(ln.s), ln.st.cuda_stream), "ctts_gpt_graph_build")
             sess["graph"] = True
+            sess["rows_built"] = [set() for _ in L]     # (graph_build dropped whatever bounded graphs the handle had)
         if profile_tag is not None:
             _lib.check(lib.ctts_gpt_profile_begin(L[0].handle, int(profile_tag), 4096, int(profile_stride)), "profile_begin")
 

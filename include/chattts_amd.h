@@ -182,6 +182,16 @@ int ctts_gpt_decode_step(ctts_gpt* g, const ctts_gen_state* s, void* stream);
  * same executable graph is replayed for every step), then replay it n times */
 int ctts_gpt_graph_build(ctts_gpt* g, const ctts_gen_state* s, void* stream);
 int ctts_gpt_graph_launch(ctts_gpt* g, int32_t n_steps, void* stream);
+/* Round 5: the same captured step for a BOUND on the live rows.  The decode step's grids are sized for the batch B the state describes --
+ * 12 attention workgroups and one row of every 16-row projection tile per utterance, finished or not (a finished row's workgroups leave
+ * at their first load).  ctts_gpt_graph_build_rows captures the step once more with every grid sized for `rows` < B compact rows; the
+ * kernels still read the device-side live count, so ANY bound >= it replays to the same bits as the plain graph.  A host that polls the
+ * finish flags anyway (they only ever go up) launches the smallest bound it knows to hold: ctts_gpt_graph_launch_rows(g, n, rows, stream).
+ * Needs ctts_gpt_graph_build first; build / destroy of the plain graph drop the bounded ones.  MEASURED: no gain on the C3 bench (the dead
+ * workgroups were not what the step waits for, profiles/r5o_ab_graph_rows.log) -- the Python engine uses it only with CTTS_GRAPH_ROWS=1.  No reference counterpart (the reference steps
+ * every row until the last one is done, gpt.py:512-518,592). */
+int ctts_gpt_graph_build_rows(ctts_gpt* g, const ctts_gen_state* s, int32_t rows, void* stream);
+int ctts_gpt_graph_launch_rows(ctts_gpt* g, int32_t n_steps, int32_t rows, void* stream);
 void ctts_gpt_graph_destroy(ctts_gpt* g);
 
 /* Per-kernel timing of one launch site (tag) of the eager decode step, for bench.py's roofline leg: the

@@ -408,6 +408,44 @@ def test_packed_f32_decode_is_bit_identical_to_row_major(weights, monkeypatch):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+def test_bounded_row_graphs_replay_to_the_same_bits(weights, dtype, monkeypatch):
+    """round 5, opt-in (CTTS_GRAPH_ROWS=1; measured no gain, profiles/r5o_ab_graph_rows.log): chunks of decode steps are replayed from the
+    graph captured for a BOUND on the live rows (16-row buckets; ctts_gpt_graph_build_rows) once finish polls have seen utterances leave -- the grids shrink, the kernels still read the exact live
+    count.  c3w (64 utterances, 20 of them hitting EOS at different steps) and a batch in which most rows finish early: token ids AND
+    hidden states torch.equal to the batch-sized graph (CTTS_GRAPH_ROWS=0), bounded graphs really used, a second call reuses them."""
+    outs = {}
+    for rows in ("1", "0"):
+        monkeypatch.setenv("CTTS_GRAPH_ROWS", rows)
+        eng = E.GptEngine(weights["gpt"], weights["embed"], DEV, dtype=dtype)
+        res = []
+        for name, stop in (("c3w", None), ("c3w", "early")):
+            c = dict(cases.BIG_CASES[name])
+            ids, mask, tmask = cases.gen_inputs(c)
+            B = ids.shape[0]
+            ids_t, mask_t, tm_t = torch.from_numpy(ids), torch.from_numpy(mask), torch.from_numpy(tmask)
+            emb = eng.embed_prompt(ids_t, tm_t)
+            warpers, procs = E.gen_logits(625, c["top_P"], c["top_K"], c["rep"])
+            kw = {}
+            n = c["max_new"]
+            if stop == "early":      # 50 of the 64 rows are forced to stop within the first chunks: bounds 64 -> 32 -> 16
+                n = 96
+                st = np.full(B, 90, np.int32)
+                st[:50] = 3 + (np.arange(50) % 30)
+                kw["stop_at"] = torch.from_numpy(st)
+            for rep in range(2):
+                out = list(eng.generate(emb, ids_t, torch.tensor(c["temperature"]), 625, mask_t, n, c["min_new"], (*procs, *warpers),
+                                        return_hidden=True, manual_seed=c["manual_seed"], **kw))[-1]
+            res.append(([t.clone() for t in out.ids], [h.clone() for h in out.hiddens]))
+            built = eng._session.get("rows_built", [set()])[0]
+            if stop == "early":
+                assert (len(built) >= 2 and max(built) < 64) if rows == "1" else (len(built) == 0), (rows, built)
+        outs[rows] = res
+        del eng
+    for (ia, ha), (ib, hb) in zip(outs["1"], outs["0"]):
+        assert all(torch.equal(x, y) for x, y in zip(ia, ib)) and all(torch.equal(x, y) for x, y in zip(ha, hb))
+
+
 def test_attention_split_in_the_engine(weights, golden, monkeypatch):
     """the whole decode step with and without the attention remainder splitting, teacher-forced on the same token stream
     (the c3w batch: 64 utterances whose number drops as they finish, so the split geometry changes from step to step):
