@@ -39,13 +39,9 @@
 // VGPRs, one workgroup per CU, which is all a 144- / 192-tile launch has anyway), 24 chunks at K = 3072 for the 16-row workgroups of
 // down_proj (96 loads, 400 VGPRs, 192 workgroups).  Measured (profiles/r5i_ab_x3_rounds.log, parity leg of the bench): 3 -> 6 chunks for
 // the 64-row RMSNorm launches 995 -> 1016 audio-s/s, 12 -> 24 for down 978 -> 986.
-#ifndef CTTS_D32X_U3072
-#define CTTS_D32X_U3072 24   // A/B builds: python -m chattts_amd.build --variant u12 -DCTTS_D32X_U3072=12
-#endif
-#ifndef CTTS_D32X_UW
-#define CTTS_D32X_UW 6       // ... --variant uw3 -DCTTS_D32X_UW=3: two rounds at K = 768 for the 32- / 64-row workgroups
-#endif
-template <int MBT, int KT> struct DxU { static constexpr int v = MBT == 1 ? (KT == 3072 ? CTTS_D32X_U3072 : 6) : (KT == 3072 ? 3 : CTTS_D32X_UW); };
+// (one round everywhere by default: chunks per wave and round = (K / 32) / waves; only the wide workgroups at K = 3072 -- not a shipped
+// choice -- keep rounds of 3)
+template <int MBT, int KT, int NW> struct DxU { static constexpr int v = (MBT > 1 && KT == 3072) ? 3 : (KT / 32) / NW; };
 
 __device__ __forceinline__ void x3_store(uint16_t* __restrict__ hi_at, const size_t plane, const float v) {
   const bf16_t h = f32_to_bf16(v);
@@ -53,12 +49,12 @@ __device__ __forceinline__ void x3_store(uint16_t* __restrict__ hi_at, const siz
   hi_at[plane] = f32_to_bf16(v - bf16_to_f32(h));
 }
 
-template <int NMB, int MBT, int KT, bool RMS, int EPI>
+template <int NMB, int MBT, int KT, bool RMS, int EPI, int NW>
 __device__ __forceinline__ void dec32x_body(const Dec32xArgs& a, const int M, const int tile, const int mt0,
-                                            u128 (&wh)[(EPI == EPI_SILU_MUL) ? 2 : 1][DxU<MBT, KT>::v], u128 (&wl)[(EPI == EPI_SILU_MUL) ? 2 : 1][DxU<MBT, KT>::v],
+                                            u128 (&wh)[(EPI == EPI_SILU_MUL) ? 2 : 1][DxU<MBT, KT, NW>::v], u128 (&wl)[(EPI == EPI_SILU_MUL) ? 2 : 1][DxU<MBT, KT, NW>::v],
                                             float (*red)[(EPI == EPI_SILU_MUL) ? 2 : 1][MBT][64][4], float* rstd_s) {
   constexpr int NACC = (EPI == EPI_SILU_MUL) ? 2 : 1;
-  constexpr int U = DxU<MBT, KT>::v;
+  constexpr int U = DxU<MBT, KT, NW>::v;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int li = lane & 15, g = lane >> 4;
   const int n0 = tile * 16, m0 = mt0 * 16;
@@ -69,7 +65,7 @@ __device__ __forceinline__ void dec32x_body(const Dec32xArgs& a, const int M, co
   constexpr int NF = NMB >= 3 ? NMB : 4;
   const int fmb = (wave * PPW) >> 2, fr0 = (wave * PPW) & 3;   // meaningful for wave < NF
 
-  constexpr int nper = KCH / 4;   // chunks per wave (nper % U == 0); wave w owns the contiguous quarter w
+  constexpr int nper = KCH / NW;   // chunks per wave (nper % U == 0); wave w owns the contiguous share w of K
   const u128* wp = reinterpret_cast<const u128*>(a.Wp) + ((size_t)tile * KCH + wave * nper) * 64 + lane;
   const u128* wp2 = wp + (size_t)(N >> 4) * KCH * 64;  // SILU_MUL: the "up" tile of the same columns
   const u128* ap = reinterpret_cast<const u128*>(a.Ap) + ((size_t)mt0 * KCH + wave * nper) * 64 + lane;
@@ -131,7 +127,7 @@ __device__ __forceinline__ void dec32x_body(const Dec32xArgs& a, const int M, co
     s1 = *reinterpret_cast<const float4*>(sp + 4);
     s2 = *reinterpret_cast<const float4*>(sp + 8);
   }
-  if (RMS && a.ssq_in == nullptr) {
+  if (RMS && a.ssq_in == nullptr && wave < 4) {
 #pragma unroll
     for (int r0 = 0; r0 < 16 * NMB; r0 += 16) {
       const float* rows[4];
@@ -200,9 +196,9 @@ __device__ __forceinline__ void dec32x_body(const Dec32xArgs& a, const int M, co
   __syncthreads();   // (also publishes rstd_s)
   if (wave >= NF) return;
 
-  float t[4][NACC][PPW];   // the 4 waves' partials of this wave's outputs
+  float t[NW][NACC][PPW];   // the NW waves' partials of this wave's outputs
 #pragma unroll
-  for (int w = 0; w < 4; ++w)
+  for (int w = 0; w < NW; ++w)
 #pragma unroll
     for (int na = 0; na < NACC; ++na) {
       if constexpr (PPW == 4) {
@@ -219,9 +215,14 @@ __device__ __forceinline__ void dec32x_body(const Dec32xArgs& a, const int M, co
   for (int q = 0; q < PPW; ++q) {
     const int rloc = 16 * fmb + 4 * g + fr0 + q;   // C/D map of the 16x16 MFMA: col = lane & 15, row = 4 (lane >> 4) + reg
     const int row = m0 + rloc;
-    float v = ((t[0][0][q] + t[1][0][q]) + t[2][0][q]) + t[3][0][q];   // fixed order
-    float u = 0.f;
-    if (EPI == EPI_SILU_MUL) u = ((t[0][NACC - 1][q] + t[1][NACC - 1][q]) + t[2][NACC - 1][q]) + t[3][NACC - 1][q];
+    float v = t[0][0][q], u = 0.f;   // fixed order: ((w0 + w1) + w2) + ...
+#pragma unroll
+    for (int w = 1; w < NW; ++w) v += t[w][0][q];
+    if (EPI == EPI_SILU_MUL) {
+      u = t[0][NACC - 1][q];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) u += t[w][NACC - 1][q];
+    }
     if (RMS) {
       const float rs = rstd_s[rloc];
       v *= rs;
@@ -257,11 +258,11 @@ __device__ __forceinline__ void dec32x_body(const Dec32xArgs& a, const int M, co
   }
 }
 
-template <int MBT, int KT, bool RMS, int EPI>
-__global__ __launch_bounds__(256) void gemm_dec32x_k(Dec32xArgs a) {
+template <int MBT, int KT, bool RMS, int EPI, int NW>
+__global__ __launch_bounds__(64 * NW) void gemm_dec32x_k(Dec32xArgs a) {
   constexpr int NACC = (EPI == EPI_SILU_MUL) ? 2 : 1;
-  constexpr int U = DxU<MBT, KT>::v;
-  __shared__ __attribute__((aligned(16))) float red[4][NACC][MBT][64][4];
+  constexpr int U = DxU<MBT, KT, NW>::v;
+  __shared__ __attribute__((aligned(16))) float red[NW][NACC][MBT][64][4];
   __shared__ float rstd_s[16 * MBT];
   CTTS_PROBE_RETURN();
 
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(256) void gemm_dec32x_k(Dec32xArgs a) {
   // dependent scalar load) is known
   u128 wh[NACC][U], wl[NACC][U];
   {
-    constexpr int KCH = KT >> 5, nper = KCH / 4;
+    constexpr int KCH = KT >> 5, nper = KCH / NW;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const u128* wp = reinterpret_cast<const u128*>(a.Wp) + ((size_t)tile * KCH + wave * nper) * 64 + lane;
     const u128* wp2 = wp + (size_t)(a.N >> 4) * KCH * 64;
@@ -293,15 +294,15 @@ __global__ __launch_bounds__(256) void gemm_dec32x_k(Dec32xArgs a) {
   if (mt0 * 16 >= M) return;
   const int nmb = min(MBT, (M - mt0 * 16 + 15) >> 4);
   if constexpr (MBT == 1) {
-    dec32x_body<1, MBT, KT, RMS, EPI>(a, M, tile, mt0, wh, wl, red, rstd_s);
+    dec32x_body<1, MBT, KT, RMS, EPI, NW>(a, M, tile, mt0, wh, wl, red, rstd_s);
   } else if constexpr (MBT == 2) {
-    if (nmb == 1) dec32x_body<1, MBT, KT, RMS, EPI>(a, M, tile, mt0, wh, wl, red, rstd_s);
-    else dec32x_body<2, MBT, KT, RMS, EPI>(a, M, tile, mt0, wh, wl, red, rstd_s);
+    if (nmb == 1) dec32x_body<1, MBT, KT, RMS, EPI, NW>(a, M, tile, mt0, wh, wl, red, rstd_s);
+    else dec32x_body<2, MBT, KT, RMS, EPI, NW>(a, M, tile, mt0, wh, wl, red, rstd_s);
   } else {
-    if (nmb == 1) dec32x_body<1, MBT, KT, RMS, EPI>(a, M, tile, mt0, wh, wl, red, rstd_s);
-    else if (nmb == 2) dec32x_body<2, MBT, KT, RMS, EPI>(a, M, tile, mt0, wh, wl, red, rstd_s);
-    else if (nmb == 3) dec32x_body<3, MBT, KT, RMS, EPI>(a, M, tile, mt0, wh, wl, red, rstd_s);
-    else dec32x_body<4, MBT, KT, RMS, EPI>(a, M, tile, mt0, wh, wl, red, rstd_s);
+    if (nmb == 1) dec32x_body<1, MBT, KT, RMS, EPI, NW>(a, M, tile, mt0, wh, wl, red, rstd_s);
+    else if (nmb == 2) dec32x_body<2, MBT, KT, RMS, EPI, NW>(a, M, tile, mt0, wh, wl, red, rstd_s);
+    else if (nmb == 3) dec32x_body<3, MBT, KT, RMS, EPI, NW>(a, M, tile, mt0, wh, wl, red, rstd_s);
+    else dec32x_body<4, MBT, KT, RMS, EPI, NW>(a, M, tile, mt0, wh, wl, red, rstd_s);
   }
 }
 
@@ -310,21 +311,21 @@ static int env_i(const char* name, int dflt) {
   return e ? atoi(e) : dflt;
 }
 
-template <int MBT>
+template <int MBT, int NW>
 static hipError_t dec32x_dispatch(const Dec32xArgs& a, hipStream_t st) {
   const int mt = (a.M + 15) / 16;
-  dim3 grid(a.N / 16, (mt + MBT - 1) / MBT), block(256);
-  if (a.epi == EPI_RES && !a.rms && a.K == 768) CTTS_LAUNCH((gemm_dec32x_k<MBT, 768, false, EPI_RES>), grid, block, st, a);
-  else if (a.epi == EPI_RES && !a.rms && a.K == 3072) CTTS_LAUNCH((gemm_dec32x_k<MBT, 3072, false, EPI_RES>), grid, block, st, a);
-  else if (a.epi == EPI_SILU_MUL && a.rms && a.K == 768) CTTS_LAUNCH((gemm_dec32x_k<MBT, 768, true, EPI_SILU_MUL>), grid, block, st, a);
-  else if (a.epi == D32_EPI_QKV_ROPE && a.rms && a.K == 768) CTTS_LAUNCH((gemm_dec32x_k<MBT, 768, true, D32_EPI_QKV_ROPE>), grid, block, st, a);
+  dim3 grid(a.N / 16, (mt + MBT - 1) / MBT), block(64 * NW);
+  if (a.epi == EPI_RES && !a.rms && a.K == 768) CTTS_LAUNCH((gemm_dec32x_k<MBT, 768, false, EPI_RES, NW>), grid, block, st, a);
+  else if (a.epi == EPI_RES && !a.rms && a.K == 3072) CTTS_LAUNCH((gemm_dec32x_k<MBT, 3072, false, EPI_RES, NW>), grid, block, st, a);
+  else if (a.epi == EPI_SILU_MUL && a.rms && a.K == 768) CTTS_LAUNCH((gemm_dec32x_k<MBT, 768, true, EPI_SILU_MUL, NW>), grid, block, st, a);
+  else if (a.epi == D32_EPI_QKV_ROPE && a.rms && a.K == 768) CTTS_LAUNCH((gemm_dec32x_k<MBT, 768, true, D32_EPI_QKV_ROPE, NW>), grid, block, st, a);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }
 
 hipError_t launch_gemm_dec32x(const Dec32xArgs& a_in, hipStream_t st) {
   Dec32xArgs a = a_in;
-  static int nt = -1, mb_qkv = 4, mb_silu = 4, mb_o = 1, mb_down = 1;
+  static int nt = -1, mb_qkv = 4, mb_silu = 4, mb_o = 1, mb_down = 1, nw_qkv = 8, nw_silu = 8, nw_o = 4, nw_down = 8;
   if (nt < 0) {
     nt = env_i("CTTS_W_NT", 1);
     // rows per workgroup (A/B knobs; profiles/r5h_ab_x3_mb.log, r5i_ab_x3_rounds.log): the RMSNorm launches take all <= 64 rows per weight
@@ -332,6 +333,9 @@ hipError_t launch_gemm_dec32x(const Dec32xArgs& a_in, hipStream_t st) {
     // gate/up launch for 19 MB of weights) --, o / down (48 weight tiles) stay 16-row workgroups (2 rows per workgroup: 906 vs 981)
     mb_qkv = env_i("CTTS_D32X_MB_QKV", 4); mb_silu = env_i("CTTS_D32X_MB_SILU", 4);
     mb_o = env_i("CTTS_D32X_MB_O", 1); mb_down = env_i("CTTS_D32X_MB_DOWN", 1);
+    // waves per workgroup (4 | 8): with 8 a wave requests half as many chunks and twice as many waves have requests in flight
+    // (profiles/r5s_ab_x3_nw.log, parity leg: 4 waves everywhere 1011-1021 audio-s/s; QKV + gate/up on 8: 1023-1046; + down: 1026-1052; + o: no change)
+    nw_qkv = env_i("CTTS_D32X_NW_QKV", 8); nw_silu = env_i("CTTS_D32X_NW_SILU", 8); nw_o = env_i("CTTS_D32X_NW_O", 4); nw_down = env_i("CTTS_D32X_NW_DOWN", 8);
   }
   a.w_nt = nt;
   // K: chunks of 32, 4 waves, rounds of 6 (3) chunks
@@ -343,8 +347,19 @@ hipError_t launch_gemm_dec32x(const Dec32xArgs& a_in, hipStream_t st) {
   if (a.epi == EPI_RES && (!a.res || !a.C)) return hipErrorInvalidValue;
   if (a.epi == EPI_SILU_MUL && !a.Cp) return hipErrorInvalidValue;
   int mb = a.epi == EPI_SILU_MUL ? mb_silu : a.epi == EPI_RES ? (a.K > 768 ? mb_down : mb_o) : mb_qkv;
-  if (a.force_mb) mb = a.force_mb;
-  if (mb >= 4) return dec32x_dispatch<4>(a, st);
-  if (mb == 2) return dec32x_dispatch<2>(a, st);
-  return dec32x_dispatch<1>(a, st);
+  int nw = a.epi == EPI_SILU_MUL ? nw_silu : a.epi == EPI_RES ? (a.K > 768 ? nw_down : nw_o) : nw_qkv;
+  if (a.force_mb) { mb = a.force_mb & 7; nw = (a.force_mb & 16) ? 16 : (a.force_mb & 8) ? 8 : 4; }   // tests: rows per workgroup in the low bits, +8 = eight waves, +16 = sixteen (down_proj, 16 rows)
+  if (nw == 16 && a.epi == EPI_RES && !a.rms && a.K == 3072 && mb == 1) {   // down_proj only: 16 waves x 6 chunks, as the perf mode's down_proj
+    dim3 grid(a.N / 16, (a.M + 15) / 16), block(1024);
+    CTTS_LAUNCH((gemm_dec32x_k<1, 3072, false, EPI_RES, 16>), grid, block, st, a);
+    return hipGetLastError();
+  }
+  if (nw >= 8) {
+    if (mb >= 4) return dec32x_dispatch<4, 8>(a, st);
+    if (mb == 2) return dec32x_dispatch<2, 8>(a, st);
+    return dec32x_dispatch<1, 8>(a, st);
+  }
+  if (mb >= 4) return dec32x_dispatch<4, 4>(a, st);
+  if (mb == 2) return dec32x_dispatch<2, 4>(a, st);
+  return dec32x_dispatch<1, 4>(a, st);
 }

@@ -377,7 +377,8 @@ int ctts_k_gemm_dec32(const float* Ap, const float* Wp, int32_t M, int32_t N, in
  * ([rows/16][K/32][64][8]), the lo planes a_plane / w_plane ELEMENTS behind them; three bf16 MFMAs per product (lo*hi + hi*lo + hi*hi), f32
  * accumulation.  X != NULL (K = 768): RMSNorm launch -- 1 / rms of the rows of X (row-major f32, gemm_skinny_k's arithmetic) scales the
  * accumulator, the gain is expected folded into W; ssq_in != NULL instead: [rows][48] partial sums of squares of the rows (one per 16 columns, what
- * the decode step's producers leave); ssq_out (epi 1): the same partials of the NEW rows.  epi 1 = C = res + acc (row-major f32), Cp = its planes (c_plane elements apart, kch_out =
+ * the decode step's producers leave); ssq_out (epi 1): the same partials of the NEW rows.  force_mb: 0 = the launcher's choice, else rows per
+ * workgroup / 16 (1 | 2 | 4), + 8 for eight instead of four waves.  epi 1 = C = res + acc (row-major f32), Cp = its planes (c_plane elements apart, kch_out =
  * N / 32) and optionally Cp32 = its packed f32 copy; epi 2 = SiLU(gate) * up -> Cp planes (W = gate tiles then up tiles).  Reference ops:
  * examples/onnx/modeling_llama.py:293,415-417,500. */
 int ctts_k_gemm_dec32x(const uint16_t* Ap, int64_t a_plane, const uint16_t* Wp, int64_t w_plane, int32_t M, int32_t N, int32_t K,

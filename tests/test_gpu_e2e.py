@@ -377,19 +377,38 @@ def test_bf16_mode_runs_and_tracks_f32(gpt_bf16, golden):
     assert rel < 5e-2
 
 
-def test_packed_decode_equals_row_major_decode(weights, monkeypatch):
-    """perf mode: the decode step on fragment-packed operands (csrc/decode.hip) multiplies the same bf16 values with the
-    same per-wave k split as the row-major kernels it replaces -> identical token ids, hidden states equal to rounding"""
+def test_packed_decode_equals_row_major_decode(weights, golden, monkeypatch):
+    """perf mode: the decode step on fragment-packed operands (csrc/decode.hip) multiplies the same bf16 values as the row-major kernels
+    it replaces.  Until round 4 both split K over 4 waves the same way and free-running token ids were identical; since round 5 the packed
+    QKV / gate-up launches split K over 8 waves (another order of the f32 partial sums), so the two engines are compared the way the perf
+    mode is bounded anywhere else: TEACHER-FORCED on the reference's token stream (b8), hidden states of every step within bf16 rounding
+    noise of each other (measured 2e-3 relative; asserted 1e-2), and -- with CTTS_DEC_NW-independent arithmetic -- the f32 twin of this
+    test stays bit-identical."""
     c = cases.GEN_CASES["b8"]
-    packed = E.GptEngine(weights["gpt"], weights["embed"], DEV, dtype="bf16")
-    outs_p, _ = run_case(packed, c, use_graph=True)
-    monkeypatch.setenv("CTTS_DEC_PACKED", "0")
-    plain = E.GptEngine(weights["gpt"], weights["embed"], DEV, dtype="bf16")
-    outs_r, _ = run_case(plain, c, use_graph=True)
-    for a, b in zip(outs_p[0].ids, outs_r[0].ids):
-        assert torch.equal(a, b)
-    for a, b in zip(outs_p[0].hiddens, outs_r[0].hiddens):
-        assert float((a - b).abs().max()) < 1e-4
+    Gd = golden["generate"]
+    ids, mask, tmask = cases.gen_inputs(c)
+    B, n = ids.shape[0], c["max_new"]
+    lens, rows = _golden_rows(Gd, "b8", B)
+    teacher = np.zeros((B, n, 4), np.int64)
+    for b in range(B):
+        teacher[b, : lens[b]] = rows[b]
+        if lens[b] < n:
+            teacher[b, lens[b]] = 625
+    ids_t, mask_t = torch.from_numpy(ids), torch.from_numpy(mask)
+    warpers, procs = E.gen_logits(625, c["top_P"], c["top_K"], c["rep"])
+    hid = []
+    for packed in ("1", "0"):
+        monkeypatch.setenv("CTTS_DEC_PACKED", packed)
+        eng = E.GptEngine(weights["gpt"], weights["embed"], DEV, dtype="bf16")
+        emb = eng.embed_prompt(ids_t, torch.from_numpy(tmask))
+        out = list(eng.generate(emb, ids_t, torch.tensor(c["temperature"]), 625, mask_t, n, c["min_new"], (*procs, *warpers),
+                                return_hidden=True, manual_seed=c["manual_seed"], teacher_ids=torch.from_numpy(teacher)))[-1]
+        assert [int(t.shape[0]) for t in out.ids] == lens.tolist()
+        hid.append([h.cpu().numpy() for h in out.hiddens])
+        del eng
+    worst = max(float(np.abs(a - b).max() / np.abs(b).max()) for a, b in zip(*hid) if len(a))
+    print(f"packed vs row-major bf16 decode, teacher-forced b8: worst hidden rel diff {worst:.3e}")
+    assert worst < 1e-2
 
 
 def test_packed_f32_decode_is_bit_identical_to_row_major(weights, monkeypatch):

@@ -226,7 +226,7 @@ def test_gemm_dec32_bit_identical(G, M, n_act, force_mb):
             assert np.isnan(got_p[live:M]).all()
 
 
-@pytest.mark.parametrize("force_mb", [0, 1, 2, 4])
+@pytest.mark.parametrize("force_mb", [0, 1, 2, 4, 9, 10, 12, 17])  # rows per workgroup (x 16); + 8: eight waves split K instead of four; 17: sixteen (down_proj only, else eight)
 @pytest.mark.parametrize("M,n_act", [(64, None), (64, 37), (16, None), (5, None), (33, 20), (48, 48)])
 def test_gemm_dec32x_split_bf16(G, M, n_act, force_mb):
     """parity-mode decode projections on SPLIT-bf16 operands (csrc/decode32x.hip: hi | lo bf16 planes, three bf16 MFMAs per product,

@@ -32,7 +32,7 @@ def short(name):
         return "attention_f32"      # parity mode (f32 KV cache): bench.py's parity_mode.roofline
     if "attention_k" in name:
         return "attention"
-    m = re.search(r"gemm_(dec|fast)_k<(\d+), (\d+), (true|false), (\d+)>", name)
+    m = re.search(r"gemm_(dec|fast)_k<(\d+), (\d+), (true|false), (\d+)(?:, \d+)?>", name)   # (<MBT, NW, SCALE, EPI[, U]>: U since round 5)
     if m:
         nw, epi = int(m.group(3)), int(m.group(5))
         if epi == 3:
@@ -41,8 +41,8 @@ def short(name):
             return "gate_up_gemm"
         if epi == 1:
             return "o_proj_gemm" if nw == 4 else "down_gemm"
-    m = re.search(r"gemm_dec32x_k<(\d+), (\d+), (true|false), (\d+)>", name)
-    if m:                           # parity mode, split-bf16 decode projections (decode32x.hip): <MBT, K, RMS, EPI>
+    m = re.search(r"gemm_dec32x_k<(\d+), (\d+), (true|false), (\d+)(?:, \d+)?>", name)
+    if m:                           # parity mode, split-bf16 decode projections (decode32x.hip): <MBT, K, RMS, EPI[, NW]>
         kt, epi = int(m.group(2)), int(m.group(4))
         return {100: "qkv_gemm_f32", 2: "gate_up_gemm_f32"}.get(epi, "o_proj_gemm_f32" if kt == 768 else "down_gemm_f32")
     if "gemm_dec32_fnorm16_k" in name or "gemm_dec32_m16_k<768, 0>" in name or "gemm_skinny_k<float" in name:
