@@ -73,6 +73,28 @@ BIG_CASES = {
 }
 
 
+# ---- the sampling-parameter space and batch widths beyond one GPU's share (tests/golden/generate_params.npz) ----------------------
+# Everything `Chat.InferCodeParams` lets a caller turn (core.py:195-206 -> gen_logits, processors.py:36-58): no top-k / no top-p
+# warper at all, top_K below min_tokens_to_keep, a wide nucleus at temperature 1, strong / no repetition penalty -- and a batch of
+# 160 utterances = 640 sampling rows: the reference's own run of a batch wider than 64 rows per GPU, whose rows >= 625 get NO
+# repetition penalty (processors.py:24-27); the engine must reproduce that through its GLOBAL row numbering, on one GPU and from a
+# shard (SURVEY 8e caveats 1-2).
+PARAM_CASES = {
+    "wide160": dict(B=160, t_min=8, t_max=16, pseed=11, temperature=[0.3] * 4, top_P=0.7, top_K=20, rep=1.3,
+                    max_new=24, min_new=4, manual_seed=42, keep_hidden_rows=[0, 156, 159], keep_logit_steps=[]),
+    "hot": dict(B=5, t_min=10, t_max=18, pseed=12, temperature=[1.0, 0.9, 0.8, 0.7], top_P=0.95, top_K=50, rep=1.2,
+                max_new=48, min_new=0, manual_seed=3, keep_hidden_rows=[4], keep_logit_steps=[0, 47]),
+    "k2": dict(B=3, t_min=9, t_max=13, pseed=13, temperature=[0.5] * 4, top_P=0.3, top_K=2, rep=1.0,
+               max_new=32, min_new=2, manual_seed=11, keep_hidden_rows=[1], keep_logit_steps=[0]),
+    "ponly": dict(B=2, t_min=12, t_max=12, pseed=14, temperature=[0.3] * 4, top_P=0.5, top_K=None, rep=1.0,
+                  max_new=32, min_new=0, manual_seed=5, keep_hidden_rows=[0], keep_logit_steps=[0]),
+    "konly": dict(B=4, t_min=6, t_max=20, pseed=15, temperature=[0.6] * 4, top_P=None, top_K=8, rep=1.3,
+                  max_new=32, min_new=0, manual_seed=6, keep_hidden_rows=[3], keep_logit_steps=[0]),
+    "nowarp": dict(B=2, t_min=8, t_max=10, pseed=16, temperature=[0.2] * 4, top_P=None, top_K=None, rep=1.05,
+                   max_new=24, min_new=0, manual_seed=8, keep_hidden_rows=[1], keep_logit_steps=[0]),
+}
+
+
 # refine-text mode (core.py:665-751 defaults: temperature 0.7, top_P 0.7, top_K 20, repetition_penalty 1.0)
 TEXT_EOS = 21000  # stands in for tokenizer.eos_token ([Ebreak]); any id works with synthetic weights
 TEXT_CASES = {

@@ -149,6 +149,8 @@ def main():
         golden_generate(sds)
     if "big" in which:   # BASELINE-size cases (C3 at B = 64, C2 at 512 steps): separate file, ~2 min of reference CPU time
         golden_generate(sds, cases.BIG_CASES, "generate_big.npz")
+    if "params" in which:   # the sampling-parameter space + a 160-utterance batch (rows >= 625): ~1 min of reference CPU time
+        golden_generate(sds, cases.PARAM_CASES, "generate_params.npz")
     if "codec" in which:
         golden_codec(sds)
     if "text" in which:

@@ -98,6 +98,55 @@ def test_generate_baseline_sizes_bit_exact(gpt_f32, golden, name):
         assert err < 2e-4, (b, err)
 
 
+@pytest.mark.parametrize("use_graph", [False, True])
+@pytest.mark.parametrize("name", list(cases.PARAM_CASES))
+def test_generate_parameter_space_bit_exact(gpt_f32, golden, name, use_graph):
+    """tests/golden/generate_params.npz, the reference's own runs over what `InferCodeParams` lets a caller turn: no top-k / no
+    top-p warper at all, top_K = 2 (below min_tokens_to_keep = 3), a wide nucleus (0.95 / 50) at temperatures up to 1.0, repetition
+    penalty 1.0 (no processor) / 1.2 / 1.3 -- and `wide160`: 160 utterances in ONE batch (2.5x a GPU's share of C4; 64 + 64 + 32-row
+    projection tiles, 640 sampling rows of which rows >= 625 get no repetition penalty, processors.py:24-27).  Token ids bit-exact."""
+    c = cases.PARAM_CASES[name]
+    Gd = golden["generate_params"]
+    outs, emb = run_case(gpt_f32, c, use_graph=use_graph)
+    out = outs[-1]
+    assert np.array_equal(emb[0].cpu().numpy(), Gd[name + ".emb_row0"])
+    lens = np.array([int(t.shape[0]) for t in out.ids])
+    got = np.concatenate([t.cpu().numpy() for t in out.ids], 0)
+    want_lens, want = Gd[name + ".lens"], Gd[name + ".ids"]
+    assert np.array_equal(lens, want_lens), (lens, want_lens)
+    assert np.array_equal(got, want), f"{int((got != want).any(1).sum())} of {len(want)} token rows differ"
+    for b in c["keep_hidden_rows"]:
+        err = np.abs(out.hiddens[b].cpu().numpy() - Gd[name + f".hid{b}"]).max()
+        assert err < 2e-4, (b, err)
+
+
+def test_wide_batch_tail_shard_keeps_the_global_row_quirk(gpt_f32, golden):
+    """SURVEY 8e caveats 1-2 against the reference itself: utterances [128, 160) of `wide160` generated ALONE, as the last rank of a
+    five-way split would (row_offset = 512 of total_rows = 640), equal the same utterances of the reference's unsharded run --
+    including utterances 156..158, whose sampling rows >= 625 the reference does not penalise (that the golden discriminates the quirk --
+    penalising those rows changes utterances 156, 157 and 158 -- is shown on the oracle, tests/test_oracle_vs_golden.py)."""
+    c = cases.PARAM_CASES["wide160"]
+    Gd = golden["generate_params"]
+    lens, rows = _golden_rows(Gd, "wide160", c["B"])
+    outs, _ = run_case(gpt_f32, c, use_graph=True, rows=slice(128, 160))
+    for i, b in enumerate(range(128, 160)):
+        assert np.array_equal(outs[-1].ids[i].cpu().numpy(), rows[b]), b
+
+
+def test_wide_batch_bf16_rows_do_not_depend_on_the_batch(gpt_bf16):
+    """perf mode at 160 utterances in one batch: an utterance's tokens do not depend on which others share the batch -- the first
+    and the last 32 of `wide160` generated as shards (same global row numbering) give the tokens they get inside the batch of 160.
+    (32 utterances keep the prompt on the kernels the 160 use -- >= 256 prompt rows; below that the prompt runs on the small-batch
+    kernels, whose bf16 sums are ordered differently: bf16 results are batch-invariant per kernel family, f32 results everywhere.)"""
+    c = cases.PARAM_CASES["wide160"]
+    full, _ = run_case(gpt_bf16, c, use_graph=True)
+    assert len(full[-1].ids) == 160
+    for sl in (slice(0, 32), slice(128, 160)):
+        part, _ = run_case(gpt_bf16, c, use_graph=True, rows=sl)
+        for i, b in enumerate(range(sl.start, sl.stop)):
+            assert torch.equal(part[-1].ids[i], full[-1].ids[b]), b
+
+
 def test_bench_workload_f32_equals_reference_golden(gpt_f32):
     """the workload bench.py times (C3: 64 utterances, prompts 16-48 tokens, forced lengths U{128..512}, 513 steps, contexts
     up to 560 keys) in parity mode: every one of the 21,438 generated token rows equals the reference's own run of this

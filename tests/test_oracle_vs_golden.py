@@ -31,11 +31,18 @@ def np_model(weights):
     return llama, esd, generate_np.fold_heads(esd)
 
 
-@pytest.mark.parametrize("name", list(cases.GEN_CASES))
+def _pow(rep):
+    pt = rng.penalty_table(rep)      # None when the reference builds no penalty processor (processors.py:49: rep == 1)
+    return None if pt is None else pt.numpy()
+
+
+@pytest.mark.parametrize("name", list(cases.GEN_CASES) + [n for n in cases.PARAM_CASES if n != "wide160"])
 def test_generate(golden, np_model, name):
+    """GEN_CASES + the sampling-parameter space (generate_params.npz: no top-k / no top-p warper, top_K below
+    min_tokens_to_keep, a wide nucleus at temperature 1, repetition penalty 1.0 / 1.2 / 1.3)"""
     llama, esd, heads = np_model
-    c = cases.GEN_CASES[name]
-    G = golden["generate"]
+    c = cases.GEN_CASES[name] if name in cases.GEN_CASES else cases.PARAM_CASES[name]
+    G = golden["generate" if name in cases.GEN_CASES else "generate_params"]
     ids, mask, tmask = cases.gen_inputs(c)
     emb = generate_np.embed_prompt(esd, ids, tmask)
     assert np.array_equal(emb[0], G[name + ".emb_row0"])
@@ -46,7 +53,7 @@ def test_generate(golden, np_model, name):
     res = generate_np.generate(
         llama, esd, heads, emb, ids, mask, temperature=np.array(c["temperature"], np.float32),
         draw_q=lambda i: draws.step(i).numpy(), top_p=c["top_P"], top_k=c["top_K"],
-        pow_table=rng.penalty_table(c["rep"]).numpy(), max_new_token=c["max_new"], min_new_token=c["min_new"],
+        pow_table=_pow(c["rep"]), max_new_token=c["max_new"], min_new_token=c["min_new"],
         keep_logits=True)
     lens = np.array([r.shape[0] for r in res.ids])
     assert np.array_equal(lens, G[name + ".lens"])
@@ -92,6 +99,64 @@ def test_generate_baseline_sizes_prefix(golden, np_model, name, k):
     for b in c["keep_hidden_rows"]:
         n = min(k, lens[b])
         assert np.abs(res.hiddens[b][:n] - G[name + f".hid{b}"][:n]).max() < 2e-4
+
+
+def test_generate_wide_batch_prefix(golden, np_model):
+    """generate_params.npz `wide160`: the reference's own run of 160 utterances = 640 sampling rows, of which rows >= 625
+    (utterance 156 from its 2nd codebook on) get no repetition penalty (processors.py:24-27).  The oracle reproduces the first 6
+    steps of all 160 rows bit-exactly (rows finish from step 4 on); the full 24 steps run on the GPU side."""
+    llama, esd, heads = np_model
+    c, k = cases.PARAM_CASES["wide160"], 6
+    G = golden["generate_params"]
+    ids, mask, tmask = cases.gen_inputs(c)
+    emb = generate_np.embed_prompt(esd, ids, tmask)
+    assert np.array_equal(emb[0], G["wide160.emb_row0"])
+    B = ids.shape[0]
+    draws = rng.ExpDraws(B * 4, 626, c["manual_seed"])
+    res = generate_np.generate(
+        llama, esd, heads, emb, ids, mask, temperature=np.array(c["temperature"], np.float32),
+        draw_q=lambda i: draws.step(i).numpy(), top_p=c["top_P"], top_k=c["top_K"],
+        pow_table=_pow(c["rep"]), max_new_token=k, min_new_token=min(c["min_new"], k))
+    lens = G["wide160.lens"]
+    off = np.concatenate([[0], np.cumsum(lens)])
+    for b in range(B):
+        want = G["wide160.ids"][off[b]: off[b + 1]][:k]
+        assert np.array_equal(res.ids[b][: len(want)], want), b
+        assert len(res.ids[b]) == min(lens[b], k), (b, len(res.ids[b]), lens[b])
+    for b in c["keep_hidden_rows"]:
+        n = min(k, lens[b])
+        assert np.abs(res.hiddens[b][:n] - G[f"wide160.hid{b}"][:n]).max() < 2e-4
+
+
+def test_wide_batch_golden_discriminates_the_row_quirk(golden, np_model, monkeypatch):
+    """utterances [152, 160) of `wide160`, all 24 steps, as a shard (row_offset 608 of 640 sampling rows): equal to the reference's
+    unsharded run with the "rows >= 625 are not penalised" quirk keyed on the global row -- and, with the quirk switched off
+    (every row penalised), utterances 156..158 come out different: the golden does pin the quirk, not just tolerate it."""
+    llama, esd, heads = np_model
+    c = cases.PARAM_CASES["wide160"]
+    G = golden["generate_params"]
+    ids, mask, tmask = cases.gen_inputs(c)
+    sl = slice(152, 160)
+    emb = generate_np.embed_prompt(esd, ids[sl], tmask[sl])
+    lens = G["wide160.lens"]
+    off = np.concatenate([[0], np.cumsum(lens)])
+    want = [G["wide160.ids"][off[b]: off[b + 1]] for b in range(152, 160)]
+
+    def run():
+        draws = rng.ExpDraws(640, 626, c["manual_seed"])
+        return generate_np.generate(
+            llama, esd, heads, emb, ids[sl], mask[sl], temperature=np.array(c["temperature"], np.float32),
+            draw_q=lambda i: draws.step(i).numpy()[608:], top_p=c["top_P"], top_k=c["top_K"], pow_table=_pow(c["rep"]),
+            max_new_token=c["max_new"], min_new_token=c["min_new"], row_offset=608).ids
+
+    got = run()
+    assert all(np.array_equal(g, w) for g, w in zip(got, want))
+    orig = sampling_np.repetition_penalty
+    monkeypatch.setattr(sampling_np, "repetition_penalty",
+                        lambda history, x, pow_table, max_input_ids, past_window, row_offset=0: orig(history, x, pow_table, 10 ** 9, past_window, row_offset))
+    got = run()
+    differ = [152 + i for i, (g, w) in enumerate(zip(got, want)) if not (len(g) == len(w) and np.array_equal(g, w))]
+    assert differ == [156, 157, 158], differ
 
 
 @pytest.mark.parametrize("name", list(cases.TEXT_CASES))
