@@ -95,6 +95,17 @@ PARAM_CASES = {
 }
 
 
+# ---- GPT.generate(stream=True): the yield schedule of gpt.py:579-589 (tests/golden/generate_stream.npz) -----------------------
+# a yield whenever the count of steps with any unfinished row is a multiple of `stream_batch`, every row cut at its own end_idx,
+# plus the final yield (a duplicate when the last step was a multiple).  GEN_CASES entries + the stream_batch to run them with.
+GEN_STREAM_CASES = {
+    "b8_s24": ("b8", 24),          # the default stream_batch; rows finish between yields
+    "b8_s5": ("b8", 5),            # 12 yields + final; not a divisor of max_new = 64
+    "unseeded_s7": ("unseeded", 7),   # global-generator draws, stream_batch not aligned with anything
+    "c1_s16": ("c1", 16),          # 48 steps = 3 x 16: the final yield repeats the third
+}
+
+
 # refine-text mode (core.py:665-751 defaults: temperature 0.7, top_P 0.7, top_K 20, repetition_penalty 1.0)
 TEXT_EOS = 21000  # stands in for tokenizer.eos_token ([Ebreak]); any id works with synthetic weights
 TEXT_CASES = {

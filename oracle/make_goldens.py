@@ -71,6 +71,28 @@ def golden_generate(sds, which=None, fname="generate.npz"):
     np.savez_compressed(os.path.join(OUT, fname), **out)
 
 
+def golden_stream(sds):
+    """every yield of the reference's GPT.generate(stream=True): per yield the length of every row's ids / hidden rows, and the ids
+    of the yield themselves as one concatenated array (rows in order)"""
+    embed, gpt = ref_harness.build_gpt(sds)
+    out = {}
+    for name, (base, sb) in cases.GEN_STREAM_CASES.items():
+        c = cases.GEN_CASES[base]
+        ids, mask, tmask = cases.gen_inputs(c)
+        if c["manual_seed"] is None:
+            torch.manual_seed(c["global_seed"])
+        ys = []
+        ref_harness.run_generate(
+            embed, gpt, ids, mask, tmask, temperature=c["temperature"], top_P=c["top_P"], top_K=c["top_K"],
+            repetition_penalty=c["rep"], max_new_token=c["max_new"], min_new_token=c["min_new"],
+            manual_seed=c["manual_seed"], stream=True, stream_batch=sb, yields=ys)
+        out[name + ".lens"] = np.array([[r.shape[0] for r in y[0]] for y in ys], np.int64)         # [yields, B]
+        out[name + ".hid_lens"] = np.array([y[1] for y in ys], np.int64)
+        out[name + ".ids"] = np.concatenate([r for y in ys for r in y[0]], 0)
+        print(name, "yields", len(ys), out[name + ".lens"].tolist())
+    np.savez_compressed(os.path.join(OUT, "generate_stream.npz"), **out)
+
+
 def golden_text(sds):
     embed, gpt = ref_harness.build_gpt(sds)
     out = {}
@@ -151,6 +173,8 @@ def main():
         golden_generate(sds, cases.BIG_CASES, "generate_big.npz")
     if "params" in which:   # the sampling-parameter space + a 160-utterance batch (rows >= 625): ~1 min of reference CPU time
         golden_generate(sds, cases.PARAM_CASES, "generate_params.npz")
+    if "stream" in which:   # the yield schedule of GPT.generate(stream=True)
+        golden_stream(sds)
     if "codec" in which:
         golden_codec(sds)
     if "text" in which:

@@ -90,8 +90,9 @@ def build_gpt(sds: dict):
 
 def run_generate(embed, gpt, input_ids, attention_mask, text_mask, *, temperature, top_P, top_K,
                  repetition_penalty, max_new_token, min_new_token, manual_seed, extra_processors=(),
-                 capture_logits=False, infer_text=False, eos_token=None):
-    """`Chat._infer_code` from `gen_logits` on (core.py:580-658), minus tokenizer/speaker."""
+                 capture_logits=False, infer_text=False, eos_token=None, stream=False, stream_batch=24, yields=None):
+    """`Chat._infer_code` from `gen_logits` on (core.py:580-658), minus tokenizer/speaker.  With `stream=True` every yield of
+    gpt.py:579-589 is appended to the list `yields` as (ids per row, hidden rows per row) copies; the return value is the last one."""
     m = ref_modules()
     ids = torch.from_numpy(input_ids)
     am = torch.from_numpy(attention_mask)
@@ -113,10 +114,11 @@ def run_generate(embed, gpt, input_ids, attention_mask, text_mask, *, temperatur
     for out in gpt.generate(
         emb, ids, temperature=torch.tensor(temperature), eos_token=eos_token, attention_mask=am,
         max_new_token=max_new_token, min_new_token=min_new_token, logits_processors=tuple(plist),
-        infer_text=infer_text, return_hidden=True, stream=False, show_tqdm=False, ensure_non_empty=True,
-        manual_seed=manual_seed,
+        infer_text=infer_text, return_hidden=True, stream=stream, show_tqdm=False, ensure_non_empty=True,
+        stream_batch=stream_batch, manual_seed=manual_seed,
     ):
-        pass
+        if yields is not None:
+            yields.append(([r.clone().numpy() for r in out.ids], [int(h.shape[0]) for h in out.hiddens]))
     if out is None:
         return None, emb.numpy(), cap
     return out, emb.numpy(), cap

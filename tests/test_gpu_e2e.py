@@ -371,6 +371,33 @@ def test_lanes_do_not_change_results(gpt_f32, golden):
     assert gpt_f32.last_stats["lanes"] == 3
 
 
+@pytest.mark.parametrize("use_graph", [False, True])
+@pytest.mark.parametrize("name", list(cases.GEN_STREAM_CASES))
+def test_stream_yields_equal_the_reference(gpt_f32, golden, name, use_graph):
+    """tests/golden/generate_stream.npz: EVERY yield of the reference's GPT.generate(stream=True) (gpt.py:579-589) -- how many there
+    are, where each row is cut (its own end_idx: finished rows stop growing), the ids inside, the number of hidden rows -- for
+    stream_batch 24 (default), 5 (not a divisor of max_new), 7 with the unseeded global-generator draws, and 16 where the final
+    yield repeats the last streamed one.  Copies are taken at yield time, as a consumer would see them."""
+    base, sb = cases.GEN_STREAM_CASES[name]
+    c = cases.GEN_CASES[base]
+    Gd = golden["generate_stream"]
+    ids, mask, tmask = cases.gen_inputs(c)
+    ids_t, mask_t = torch.from_numpy(ids), torch.from_numpy(mask)
+    emb = gpt_f32.embed_prompt(ids_t, torch.from_numpy(tmask))
+    warpers, procs = E.gen_logits(625, c["top_P"], c["top_K"], c["rep"])
+    if c["manual_seed"] is None:
+        torch.manual_seed(c["global_seed"])
+    lens, hid_lens, rows = [], [], []
+    for out in gpt_f32.generate(emb, ids_t, torch.tensor(c["temperature"]), 625, mask_t, c["max_new"], c["min_new"], (*procs, *warpers),
+                                return_hidden=True, stream=True, stream_batch=sb, manual_seed=c["manual_seed"], use_graph=use_graph):
+        lens.append([int(t.shape[0]) for t in out.ids])
+        hid_lens.append([int(h.shape[0]) for h in out.hiddens])
+        rows += [t.cpu().numpy().copy() for t in out.ids]
+    assert np.array_equal(np.array(lens), Gd[name + ".lens"]), (lens, Gd[name + ".lens"].tolist())
+    assert np.array_equal(np.array(hid_lens), Gd[name + ".hid_lens"])
+    assert np.array_equal(np.concatenate(rows, 0), Gd[name + ".ids"])
+
+
 def test_stream_yield_schedule(gpt_f32):
     c = dict(cases.GEN_CASES["c1"])
     outs, _ = run_case(gpt_f32, c, use_graph=True, stream=True)
