@@ -106,6 +106,21 @@ GEN_STREAM_CASES = {
 }
 
 
+# ---- "unexpected end at index" (gpt.py:527-570, tests/golden/generate_regen.npz) ----------------------------------------------
+# a row draws EOS at the very first step (min_new_token = 0, temperature 1, no warpers; the seed was searched for on the reference):
+#   unseeded: the reference throws the attempt away and calls itself again -- the global generator has moved on by the one [rows, 626]
+#             draw of the failed step 0, so the second attempt sees different draws;
+#   seeded  : the reference logs the warning and RETURNS WITHOUT YIELDING anything (gpt.py:570).
+REGEN_CASES = {
+    "regen57": dict(B=6, t_min=8, t_max=14, pseed=21, temperature=[1.0] * 4, top_P=None, top_K=None, rep=1.05,
+                    max_new=16, min_new=0, manual_seed=None, global_seed=57),
+    "regen195": dict(B=6, t_min=8, t_max=14, pseed=21, temperature=[1.0] * 4, top_P=None, top_K=None, rep=1.05,
+                     max_new=16, min_new=0, manual_seed=None, global_seed=195),
+    "seeded57": dict(B=6, t_min=8, t_max=14, pseed=21, temperature=[1.0] * 4, top_P=None, top_K=None, rep=1.05,
+                     max_new=16, min_new=0, manual_seed=57),
+}
+
+
 # refine-text mode (core.py:665-751 defaults: temperature 0.7, top_P 0.7, top_K 20, repetition_penalty 1.0)
 TEXT_EOS = 21000  # stands in for tokenizer.eos_token ([Ebreak]); any id works with synthetic weights
 TEXT_CASES = {

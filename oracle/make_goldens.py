@@ -93,6 +93,31 @@ def golden_stream(sds):
     np.savez_compressed(os.path.join(OUT, "generate_stream.npz"), **out)
 
 
+def golden_regen(sds):
+    """the step-0 EOS path: how many times the reference ran step 0 (`attempts`), what it finally returned (nothing, when seeded),
+    and where it left torch's global generator (three uniforms drawn right after)"""
+    embed, gpt = ref_harness.build_gpt(sds)
+    out = {}
+    for name, c in cases.REGEN_CASES.items():
+        ids, mask, tmask = cases.gen_inputs(c)
+        torch.manual_seed(c.get("global_seed", 999))
+        res, emb, cap = ref_harness.run_generate(
+            embed, gpt, ids, mask, tmask, temperature=c["temperature"], top_P=c["top_P"], top_K=c["top_K"],
+            repetition_penalty=c["rep"], max_new_token=c["max_new"], min_new_token=c["min_new"],
+            manual_seed=c["manual_seed"], capture_logits=True)
+        out[name + ".rand_after"] = torch.rand(3).numpy()
+        out[name + ".yielded"] = np.array([res is not None])
+        if res is not None:
+            out[name + ".lens"] = np.array([r.shape[0] for r in res.ids], dtype=np.int64)
+            out[name + ".ids"] = np.concatenate([r.numpy() for r in res.ids], 0)
+            out[name + ".attempts"] = np.array([len(cap) - int(out[name + ".lens"].max()) + 1])
+        else:
+            out[name + ".attempts"] = np.array([len(cap)])
+        print(name, "yielded", res is not None, "spy calls", len(cap), "attempts", int(out[name + ".attempts"][0]),
+              out.get(name + ".lens", np.array([])).tolist())
+    np.savez_compressed(os.path.join(OUT, "generate_regen.npz"), **out)
+
+
 def golden_text(sds):
     embed, gpt = ref_harness.build_gpt(sds)
     out = {}
@@ -173,6 +198,8 @@ def main():
         golden_generate(sds, cases.BIG_CASES, "generate_big.npz")
     if "params" in which:   # the sampling-parameter space + a 160-utterance batch (rows >= 625): ~1 min of reference CPU time
         golden_generate(sds, cases.PARAM_CASES, "generate_params.npz")
+    if "regen" in which:    # the "unexpected end at index" / regenerate path
+        golden_regen(sds)
     if "stream" in which:   # the yield schedule of GPT.generate(stream=True)
         golden_stream(sds)
     if "codec" in which:

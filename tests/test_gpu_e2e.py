@@ -398,6 +398,33 @@ def test_stream_yields_equal_the_reference(gpt_f32, golden, name, use_graph):
     assert np.array_equal(np.concatenate(rows, 0), Gd[name + ".ids"])
 
 
+@pytest.mark.parametrize("use_graph", [False, True])
+@pytest.mark.parametrize("name", list(cases.REGEN_CASES))
+def test_unexpected_end_at_step0_follows_the_reference(gpt_f32, golden, name, use_graph):
+    """tests/golden/generate_regen.npz: a row draws EOS at the very first step (gpt.py:527-570).  Unseeded, the reference discards the
+    attempt and calls itself again with the global generator one [rows, 626] draw further on -- the engine's second attempt must see
+    exactly those draws (ids bit-exact) and leave the generator where the reference leaves it; seeded, the reference warns and yields
+    NOTHING, and so does the engine (and neither touches the global generator)."""
+    c = cases.REGEN_CASES[name]
+    Gd = golden["generate_regen"]
+    ids, mask, tmask = cases.gen_inputs(c)
+    ids_t, mask_t = torch.from_numpy(ids), torch.from_numpy(mask)
+    emb = gpt_f32.embed_prompt(ids_t, torch.from_numpy(tmask))
+    warpers, procs = E.gen_logits(625, c["top_P"], c["top_K"], c["rep"])
+    torch.manual_seed(c.get("global_seed", 999))
+    outs = list(gpt_f32.generate(emb, ids_t, torch.tensor(c["temperature"]), 625, mask_t, c["max_new"], c["min_new"], (*procs, *warpers),
+                                 return_hidden=True, manual_seed=c["manual_seed"], use_graph=use_graph))
+    after = torch.rand(3).numpy()
+    assert np.array_equal(after, Gd[name + ".rand_after"])
+    if not bool(Gd[name + ".yielded"][0]):
+        assert outs == []
+        return
+    assert len(outs) == 1
+    assert np.array_equal(np.array([int(t.shape[0]) for t in outs[0].ids]), Gd[name + ".lens"])
+    assert np.array_equal(np.concatenate([t.cpu().numpy() for t in outs[0].ids], 0), Gd[name + ".ids"])
+    assert [int(h.shape[0]) for h in outs[0].hiddens] == Gd[name + ".lens"].tolist()
+
+
 def test_stream_yield_schedule(gpt_f32):
     c = dict(cases.GEN_CASES["c1"])
     outs, _ = run_case(gpt_f32, c, use_graph=True, stream=True)
