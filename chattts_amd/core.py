@@ -287,6 +287,8 @@ class Chat:
             piece = wavs[:, a: wavs.shape[1] if b is None else min(b, wavs.shape[1])]
             return np.stack([float_to_int16(r) for r in piece]) if (pcm16 and piece.shape[1]) else piece
         hi = total if b is None else min(b, total)
+        if hi <= a:     # a window that starts past the end of this prefix (a later split batch, see `_infer`): nothing to decode
+            return np.zeros((len(hiddens), 0), np.int16 if pcm16 else np.float32)
         win = self.codec.decode_window(hiddens, a, hi)
         if pcm16 and win.shape[1] > 0:     # every row by its own peak -- float_to_int16(chunk[b]), examples/web/funcs.py:203-206 -- on the device
             return self.codec.to_host(self.codec.float_to_int16(win, per_row=True)[0])
@@ -446,9 +448,12 @@ class Chat:
                 pass_batch_count += 1
                 if pass_batch_count <= params_infer_code.pass_first_n_batches:
                     continue     # the reference decodes these yields and drops the audio (core.py:482-490)
-                piece = self._stream_piece(result.hiddens if use_decoder else result.ids, length,
-                                           length + params_infer_code.stream_speed, use_decoder, pcm16)
-                length += piece.shape[1]
+                src = result.hiddens if use_decoder else result.ids
+                piece = self._stream_piece(src, length, length + params_infer_code.stream_speed, use_decoder, pcm16)
+                # core.py:491-496: `b = a + stream_speed`, clamped to the width of THIS decode, becomes the new `length` -- also when
+                # that is BELOW `a`: `length` and `pass_batch_count` are not reset between split batches, so the first yields of a
+                # later batch (a short prefix again) are empty and pull `length` back (tests/test_host_flow.py, stream_split_batches)
+                length = min(length + params_infer_code.stream_speed, 256 * (2 * max(int(r.size(0)) for r in src) - 1))
                 yield piece
             if stream and last is not None:
                 new_wavs = self._stream_piece(last.hiddens if use_decoder else last.ids, length, None, use_decoder)
