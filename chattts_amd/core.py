@@ -206,12 +206,12 @@ class Chat:
             params.stream_batch, params.manual_seed, self.context, **shard_kw)
 
     def refine_text_ids(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, text_mask: torch.Tensor, eos_token: int,
-                        params: RefineTextParams = RefineTextParams(), **kw) -> GenerationOutputs:
+                        params: RefineTextParams = RefineTextParams(), num_code: int = GPT.n_text, **kw) -> GenerationOutputs:
         """`Chat._refine_text` from `gen_logits` on (core.py:682-751): the same generator in text mode
         (`infer_text=True`: text embedding, 21178-way text head, tokens replicated over the 4 slots); `eos_token`
         is `tokenizer.eos_token` ([Ebreak]).  Returns `GenerationOutputs` whose `ids[b]` is the 1-D refined token row."""
         assert self.has_loaded()
-        warpers, procs = gen_logits(GPT.n_text, params.top_P, params.top_K, params.repetition_penalty)
+        warpers, procs = gen_logits(num_code, params.top_P, params.top_K, params.repetition_penalty)   # core.py:682-687: len(tokenizer)
         emb = self.gpt.embed_prompt(input_ids, text_mask)
         return next(self.gpt.generate(
             emb, input_ids, torch.tensor([params.temperature]), eos_token, attention_mask, params.max_new_token,
@@ -369,7 +369,7 @@ class Chat:
         if not isinstance(text, list):
             text = [text]
         ids, attn, tmask = self.tokenizer.encode(Speaker.decorate_text_prompts(text, params.prompt), GPT.n_vq)
-        return self.refine_text_ids(ids, attn, tmask, self.tokenizer.eos_token, params)
+        return self.refine_text_ids(ids, attn, tmask, self.tokenizer.eos_token, params, num_code=self.tokenizer.len)
 
     def infer(self, text, stream=False, lang=None, skip_refine_text=False, refine_text_only=False, use_decoder=True,
               do_text_normalization=True, do_homophone_replacement=True, split_text=True, max_split_batch=4,

@@ -169,3 +169,74 @@ def call_infer(chat, sc: dict, code_params, refine_params):
     desc["spk_smp_after"] = code_params.spk_smp
     desc["txt_smp_after"] = code_params.txt_smp
     return desc, arrays
+
+
+# ---- the argument side of engine seam #1: what `Chat._infer_code` / `Chat._refine_text` hand to `GPT.generate` ----------------------
+# (oracle/make_seam_goldens.py runs the reference's two methods unmodified -- real reference Tokenizer on the synthetic vocabulary of
+# tests/golden/tokenizer, real reference Speaker and Embed -- with a recorder in place of `GPT.generate`; tests/test_seam_args.py does the
+# same with chattts_amd.core.Chat and a recorder in place of the engine.)  "$SPK" / "$SMP" are replaced by the speaker / audio-prompt strings
+# of tests/golden/frontend.json (`speaker.sample_str`, `speaker.prompt_str`).
+GENERATE_ARGS = ("emb", "inputs_ids", "temperature", "eos_token", "attention_mask", "max_new_token", "min_new_token", "logits_processors",
+                 "infer_text", "return_attn", "return_hidden", "stream", "show_tqdm", "ensure_non_empty", "stream_batch", "manual_seed", "context")
+
+SEAM_CODE_SCENARIOS = {
+    "defaults_one_text": dict(text=["what is your favorite english food?"], stream=False, return_hidden=True, params={}),
+    "string_not_list": dict(text="hello world", stream=False, return_hidden=False, params=dict(prompt="[speed_2]")),
+    "speaker_three_texts": dict(text=["chat tts test string [laugh] like that", "你好", "the time of day"], stream=True, return_hidden=True,
+                                params=dict(prompt="[speed_3]", spk_emb="$SPK", temperature=[0.1, 0.2, 0.4, 0.8], top_P=None, top_K=5,
+                                            repetition_penalty=1.0, max_new_token=100, min_new_token=5, manual_seed=7, stream_batch=12,
+                                            ensure_non_empty=False, show_tqdm=False)),
+    "audio_prompt": dict(text=["hello world", "四川美食确实以辣闻名"], stream=False, return_hidden=True,
+                         params=dict(spk_smp="$SMP", txt_smp="sample text", top_P=0.9, top_K=None, repetition_penalty=1.3, temperature=0.0003)),
+    "speaker_and_audio_prompt": dict(text=["hot water"], stream=False, return_hidden=True,
+                                     params=dict(spk_emb="$SPK", spk_smp="$SMP", txt_smp="the way", max_new_token=17)),
+}
+
+SEAM_REFINE_SCENARIOS = {
+    "defaults": dict(text=["what is your favorite food", "你好"], params={}),
+    "custom": dict(text="hello world", params=dict(prompt="[oral_2][laugh_0][break_6]", top_P=0.5, top_K=10, temperature=0.5, repetition_penalty=1.2,
+                                                   max_new_token=77, min_new_token=3, manual_seed=11, show_tqdm=False, ensure_non_empty=False)),
+}
+
+
+def describe_processors(procs) -> list:
+    """class-agnostic description of a logits-processor chain: the reference's objects (transformers' warpers, processors.py:8-35) and
+    this package's descriptors expose the same numbers under these attribute names"""
+    out = []
+    for p in procs:
+        if hasattr(p, "top_p"):
+            out.append(["top_p", float(p.top_p), int(p.min_tokens_to_keep)])
+        elif hasattr(p, "top_k"):
+            # transformers' TopKLogitsWarper stores max(top_k, min_tokens_to_keep) as `top_k`; the descriptor keeps both numbers
+            out.append(["top_k", max(int(p.top_k), int(getattr(p, "min_tokens_to_keep", 0)))])
+        elif hasattr(p, "penalty"):
+            out.append(["penalty", float(p.penalty), int(p.max_input_ids), int(p.past_window)])
+        else:
+            out.append(["?", type(p).__name__])
+    return out
+
+
+def describe_generate_call(real_generate, args, kwargs) -> dict:
+    """positional + keyword arguments of one generate call, bound to the signature of the REAL function the recorder stands in for
+    (its defaults fill what the caller left out) -> {name: JSON-able value} over the reference's 17 parameters; tensors by shape / dtype /
+    values, the embedding by checksum"""
+    import hashlib
+    import inspect
+    ba = inspect.signature(real_generate).bind(None, *args, **kwargs)
+    ba.apply_defaults()
+    out = {}
+    for k in GENERATE_ARGS:
+        v = ba.arguments[k]
+        if k == "context":
+            out[k] = "context" if v is not None else None
+        elif k == "logits_processors":
+            out[k] = describe_processors(v)
+        elif k == "emb":
+            a = v.detach().cpu().numpy()
+            out[k] = {"shape": list(a.shape), "dtype": str(a.dtype), "sha256": hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest(),
+                      "abs_sum": float(np.abs(a).sum(dtype=np.float64))}
+        elif isinstance(v, torch.Tensor):
+            out[k] = {"shape": list(v.shape), "dtype": str(v.dtype).replace("torch.", ""), "values": v.detach().cpu().tolist()}
+        else:
+            out[k] = v
+    return out
