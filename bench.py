@@ -739,11 +739,13 @@ def main():
         """HIP start/stop events of sampled launches (hipExtLaunchKernel, on the launch stream; events created without the
         system-scope fence, so the dispatch timestamps are the ones rocprofv3's kernel trace reads) in EAGER passes of the SAME
         workload: every 5th launch of the tag over all decode steps."""
-        per_tag = {}
+        per_tag, att_samples = {}, (None, 1)
         for tag in tags:
             calls = GPT.n_layers if tag in (1, 3, 4, 5, 6) else 1
             one_pass(eng, use_graph=False, profile_tag=tag, profile_stride=1 if calls == 1 else 5, decode_audio=False)
             per_tag[tag] = eng.last_stats.get("profile", (0, 0.0))
+            if tag == 3:
+                att_samples = (eng.last_stats.get("profile_samples_ms"), 1 if calls == 1 else 5)
         per_tag = {t: v for t, v in per_tag.items() if v[0] > 0}   # e.g. final_norm: fused into the heads launch on the packed decode path
         calls_per_step = {t: (GPT.n_layers if t in (1, 3, 4, 5, 6) else 1) for t in per_tag}
         avg_us = {t: 1e3 * per_tag[t][1] / max(1, per_tag[t][0]) for t in per_tag}
@@ -769,6 +771,26 @@ def main():
                 "clock": "HIP start/stop events of the dispatch (hipExtLaunchKernel, no system-scope fence), every 5th launch of the "
                          "kernel over all decode steps of an eager pass of the workload; cross-check: profiles/ *_kernel_stats.csv "
                          "(rocprofv3 --kernel-trace --stats of this command)"}
+        if TAGS[dom] == "attention" and att_samples[0] is not None and len(att_samples[0]) >= 64:
+            # duration = fixed + bytes / bandwidth, least squares over the timed launches: sample j is the (j * stride)-th attention launch
+            # after the prompt, i.e. layer (j * stride) % 20 of decode step 1 + (j * stride) // 20, whose KV bytes are known exactly
+            ms, stride = att_samples
+            j = np.arange(len(ms)) * stride
+            stp = 1 + j // GPT.n_layers
+            ok = stp < n_steps
+            byt = np.array([((valid_prompt + i) * (st_ >= i)).sum() * 2 * 768 * es_ + int((st_ >= i).sum()) * 768 * (4 + es_) for i in stp[ok]], np.float64)
+            us = ms[ok].astype(np.float64) * 1e3
+            A = np.stack([np.ones_like(byt), byt], 1)
+            (c0, c1), res, *_ = np.linalg.lstsq(A, us, rcond=None)
+            ss_tot = float(((us - us.mean()) ** 2).sum())
+            r2 = 1.0 - float(((us - A @ np.array([c0, c1])) ** 2).sum()) / ss_tot if ss_tot > 0 else None
+            roof["fit"] = {"fixed_us": round(float(c0), 2), "marginal_GBps": round(1e-3 / float(c1), 1) if c1 > 0 else None,
+                           "marginal_frac_of_peak": round(1e-3 / float(c1) / HBM_PEAK_GBS, 4) if c1 > 0 else None, "r2": round(r2, 4) if r2 is not None else None,
+                           "launches": int(ok.sum()), "bytes_min": int(byt.min()), "bytes_max": int(byt.max()),
+                           "what": "least squares of per-launch duration on per-launch algorithmic bytes over the decode steps of the pass "
+                                   "(contexts and live rows change from step to step): duration = fixed_us + bytes / marginal bandwidth -- "
+                                   "the part of a launch that scales with the KV it streams, and the part that does not (dispatch, ramp, "
+                                   "the cross-wave merge, the tail)"}
         step_bytes = decode_step_bytes(es_, valid_prompt, st_, n_steps)
         roof["whole_decode_step"] = {
             "alg_bytes_per_step": int(step_bytes), "ms_per_step": round(step_ms, 4),

@@ -99,6 +99,7 @@ SIGNATURES = {
     "ctts_gpt_graph_launch_rows": (C.c_int, [P, I32, I32, P]),
     "ctts_gpt_graph_destroy": (None, [P]),
     "ctts_gpt_profile_begin": (C.c_int, [P, I32, I32, I32]),
+    "ctts_gpt_profile_samples": (C.c_int, [P, C.POINTER(C.c_float), I32, C.POINTER(I32)]),
     "ctts_gpt_profile_end": (C.c_int, [P, C.POINTER(I32), C.POINTER(C.c_double)]),
     "ctts_codec_create": (C.c_int, [PP, C.POINTER(CodecWeights)]),
     "ctts_codec_destroy": (None, [P]),

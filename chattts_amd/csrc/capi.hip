@@ -729,6 +729,17 @@ extern "C" int ctts_gpt_profile_begin(ctts_gpt* g, int32_t tag, int32_t max_samp
   return 0;
 }
 
+extern "C" int ctts_gpt_profile_samples(ctts_gpt* g, float* ms_out, int32_t cap, int32_t* n_samples) {
+  if (!g || !ms_out || cap < 0) return fail("bad profile_samples args");
+  const int n = g->prof_n < cap ? g->prof_n : cap;
+  for (int i = 0; i < n; ++i) {
+    CK(hipEventSynchronize(g->ev1[i]));
+    CK(hipEventElapsedTime(&ms_out[i], g->ev0[i], g->ev1[i]));
+  }
+  if (n_samples) *n_samples = n;
+  return 0;
+}
+
 extern "C" int ctts_gpt_profile_end(ctts_gpt* g, int32_t* n_samples, double* total_ms) {
   if (!g) return fail("null engine");
   double tot = 0.0;

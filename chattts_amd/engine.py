@@ -858,6 +858,9 @@ class GptEngine:
                     break
             if profile_tag is not None:
                 n_s, tot = C.c_int32(0), C.c_double(0.0)
+                buf = (C.c_float * 4096)()
+                _lib.check(lib.ctts_gpt_profile_samples(L[0].handle, buf, 4096, C.byref(n_s)), "profile_samples")
+                self.last_stats["profile_samples_ms"] = np.ctypeslib.as_array(buf)[: int(n_s.value)].copy()
                 _lib.check(lib.ctts_gpt_profile_end(L[0].handle, C.byref(n_s), C.byref(tot)), "profile_end")
                 self.last_stats["profile"] = (int(n_s.value), float(tot.value))
         finally:

@@ -198,6 +198,9 @@ void ctts_gpt_graph_destroy(ctts_gpt* g);
  * launch goes through hipExtLaunchKernel with start/stop events (dispatch timestamps, as rocprofv3 reads them).
  * tags: 0 embed, 1 qkv, 2 rope_append, 3 attention, 4 o_proj, 5 gate_up, 6 down, 7 final_norm, 8 heads, 9 sample */
 int ctts_gpt_profile_begin(ctts_gpt* g, int32_t tag, int32_t max_samples, int32_t stride /* time every stride-th launch */);
+/* the individual durations (ms) of the launches timed since profile_begin, in launch order (sample j = the (j * stride)-th launch of the
+ * tag); call before profile_end, which resets them.  bench.py fits duration = fixed + bytes / bandwidth over them. */
+int ctts_gpt_profile_samples(ctts_gpt* g, float* ms_out, int32_t cap, int32_t* n_samples);
 int ctts_gpt_profile_end(ctts_gpt* g, int32_t* n_samples, double* total_ms);
 
 /* ------------------------------------------------------------------------------------------------
