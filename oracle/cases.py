@@ -142,6 +142,16 @@ CODEC_CASES = {
 }
 
 
+# ragged rows through the reference's own `Chat._decode_to_wavs` (core.py:513-539: zero padding to the longest row, [T, 768] -> [768, T],
+# decoder, vocos) -- codec.npz `ragged.wav`
+RAGGED_LENS = (40, 17, 33, 1)
+
+
+def ragged_rows():
+    rs = np.random.RandomState(4)
+    return [rs.standard_normal((n, 768)).astype(f32) for n in RAGGED_LENS]
+
+
 def codec_inputs(c):
     rs = np.random.RandomState(100 + c["seed"])
     hid = rs.standard_normal((c["B"], c["T"], 768)).astype(f32)

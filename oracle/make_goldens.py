@@ -149,6 +149,22 @@ def golden_codec(sds):
         out[name + ".mel"] = mel.numpy()  # [B, 100, 2T]
         out[name + ".wav"] = wav.numpy()  # [B, 256(2T-1)]
         print(name, mel.shape, wav.shape, "wav rms", float(wav.pow(2).mean().sqrt()))
+    # the reference's own Chat._decode_to_wavs (core.py:513-539, unmodified) on ragged rows; its `self.decoder` is the reference DVAE, its
+    # `self.vocos` the torch restatement (the package is absent)
+    from oracle import make_host_goldens as MH
+
+    class _V:
+        def decode(self, spec):
+            return ref_harness.torch_vocos_decode(sds["vocos"], spec)
+
+    Chat = MH.ref_chat_class()
+    chat = Chat.__new__(Chat)
+    chat.decoder, chat.vocos, chat.device = dec, _V(), torch.device("cpu")
+    rows = [torch.from_numpy(r) for r in cases.ragged_rows()]
+    wav = chat._decode_to_wavs(rows, True)
+    assert rows == []          # core.py:534 `del_all(result_list)`: the reference EMPTIES the caller's list
+    out["ragged.wav"] = np.asarray(wav)
+    print("ragged", out["ragged.wav"].shape, out["ragged.wav"].dtype)
     np.savez_compressed(os.path.join(OUT, "codec.npz"), **out)
 
 

@@ -684,11 +684,14 @@ def test_to_host_in_pieces_equals_cpu_numpy(weights):
         assert a.dtype == np.float32 and a.shape == tuple(shape) and np.array_equal(a, ref) and np.array_equal(b, ref * 2.0)
 
 
-def test_decode_to_wavs_padding(codec, weights):
-    """ragged rows are zero padded like core.py:525-533; compare with the oracle on a larger batch"""
-    rs = np.random.RandomState(4)
-    rows = [rs.standard_normal((n, 768)).astype(np.float32) for n in (40, 17, 33, 1)]
+def test_decode_to_wavs_padding(codec, weights, golden):
+    """ragged rows are zero padded like core.py:525-533; compare with the oracle on a larger batch, and with what the reference's own
+    `Chat._decode_to_wavs` (run unmodified over the reference DVAE, codec.npz `ragged.wav`) returns for these rows"""
+    rows = cases.ragged_rows()
     wav = codec.decode_to_wavs([torch.from_numpy(r) for r in rows]).cpu().numpy()
+    gold = golden["codec"]["ragged.wav"]
+    assert wav.shape == gold.shape and wav.dtype == gold.dtype
+    assert float(np.sqrt(np.mean((wav - gold) ** 2))) < 1e-4
     dsd = {k: v.numpy() for k, v in weights["decoder"].items()}
     vsd = {k: v.numpy() for k, v in weights["vocos"].items()}
     ref = codec_np.decode_to_wavs(dsd, vsd, rows)

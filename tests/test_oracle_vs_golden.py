@@ -196,6 +196,17 @@ def test_codec(golden, weights, name):
     assert wav.shape == ref.shape and rms < 1e-4, rms  # north_star bar: float32 waveform within 1e-4 RMS
 
 
+def test_decode_to_wavs_ragged_vs_the_reference_method(golden, weights):
+    """codec.npz `ragged.wav`: the reference's own `Chat._decode_to_wavs` (core.py:513-539, run unmodified: zero padding to the longest row,
+    [T, 768] -> [768, T], reference DVAE, vocos restatement) on rows of 40 / 17 / 33 / 1 tokens; the oracle's restatement of that method"""
+    dsd = {k: v.numpy() for k, v in weights["decoder"].items()}
+    vsd = {k: v.numpy() for k, v in weights["vocos"].items()}
+    wav = codec_np.decode_to_wavs(dsd, vsd, cases.ragged_rows())
+    ref = golden["codec"]["ragged.wav"]
+    assert wav.shape == ref.shape == (4, 256 * (2 * 40 - 1)) and wav.dtype == ref.dtype
+    assert float(np.sqrt(np.mean((wav - ref) ** 2))) < 1e-6
+
+
 def test_codec_baseline_size_golden(golden, weights):
     """tests/golden/codec_big.npz (the reference's DVAE class + oracle/torch_port.vocos_decode on the reference GPT's own hidden states, at
     the sizes the bench decodes): the input recipe reproduces the exact arrays the reference saw (sha256), and the numpy oracle holds the
