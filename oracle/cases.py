@@ -121,6 +121,31 @@ REGEN_CASES = {
 }
 
 
+# ---- a seeded random sweep over everything GPT.generate's caller can turn (tests/golden/generate_sweep.npz: ids only) ------------------
+def sweep_cases(n: int = 40, seed: int = 2025):
+    """deterministic list of GEN_CASES-shaped dicts: batch widths around the 16-row tile edges, one-token prompts, max_new_token = 1,
+    min_new_token above max_new_token, top_K in {None, 1, 2, 3, ..., above the vocabulary}, top_P from 0.1 to 0.99 or absent, temperatures
+    from 0.05 to 1.5 per codebook, repetition penalties below / at / above 1, seeded and unseeded"""
+    rs = np.random.RandomState(seed)
+    out = {}
+    for i in range(n):
+        B = int(rs.choice([1, 2, 3, 5, 7, 9, 16, 17, 33]))
+        t_min = int(rs.randint(1, 13))
+        t_max = t_min + int(rs.randint(0, 21))
+        max_new = int(rs.choice([1, 2, 3, 8, 17, 24, 40]))
+        seeded = bool(rs.rand() < 0.75)
+        c = dict(B=B, t_min=t_min, t_max=t_max, pseed=100 + i,
+                 temperature=[float(rs.choice([0.05, 0.3, 0.7, 1.0, 1.5])) for _ in range(4)],
+                 top_P=[None, 0.1, 0.5, 0.7, 0.9, 0.99][int(rs.randint(6))],
+                 top_K=[None, 1, 2, 3, 5, 20, 100, 700][int(rs.randint(8))],
+                 rep=float(rs.choice([1.0, 1.05, 1.2, 2.0, 0.9])),
+                 max_new=max_new, min_new=int(rs.randint(0, max_new + 3)),
+                 manual_seed=int(rs.randint(1, 10 ** 6)) if seeded else None, global_seed=int(rs.randint(1, 10 ** 6)),
+                 keep_hidden_rows=[], keep_logit_steps=[])
+        out[f"s{i:02d}"] = c
+    return out
+
+
 # refine-text mode (core.py:665-751 defaults: temperature 0.7, top_P 0.7, top_K 20, repetition_penalty 1.0)
 TEXT_EOS = 21000  # stands in for tokenizer.eos_token ([Ebreak]); any id works with synthetic weights
 TEXT_CASES = {

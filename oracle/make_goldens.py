@@ -118,6 +118,28 @@ def golden_regen(sds):
     np.savez_compressed(os.path.join(OUT, "generate_regen.npz"), **out)
 
 
+def golden_sweep(sds):
+    """cases.sweep_cases() through the reference: ids only (+ whether anything was yielded, + the global generator's position after)"""
+    embed, gpt = ref_harness.build_gpt(sds)
+    out = {}
+    t0 = time.time()
+    for name, c in cases.sweep_cases().items():
+        ids, mask, tmask = cases.gen_inputs(c)
+        torch.manual_seed(c["global_seed"])
+        res, emb, cap = ref_harness.run_generate(
+            embed, gpt, ids, mask, tmask, temperature=c["temperature"], top_P=c["top_P"], top_K=c["top_K"],
+            repetition_penalty=c["rep"], max_new_token=c["max_new"], min_new_token=c["min_new"], manual_seed=c["manual_seed"])
+        out[name + ".rand_after"] = torch.rand(2).numpy()
+        out[name + ".yielded"] = np.array([res is not None])
+        if res is not None:
+            out[name + ".lens"] = np.array([r.shape[0] for r in res.ids], dtype=np.int16)
+            out[name + ".ids"] = np.concatenate([r.numpy() for r in res.ids], 0).astype(np.int16)
+        print(name, {k: c[k] for k in ("B", "t_min", "t_max", "top_P", "top_K", "rep", "max_new", "min_new", "manual_seed")},
+              "yielded", res is not None, "" if res is None else out[name + ".lens"].tolist()[:8])
+    print(f"sweep: {time.time() - t0:.1f}s")
+    np.savez_compressed(os.path.join(OUT, "generate_sweep.npz"), **out)
+
+
 def golden_text(sds):
     embed, gpt = ref_harness.build_gpt(sds)
     out = {}
@@ -214,6 +236,8 @@ def main():
         golden_generate(sds, cases.BIG_CASES, "generate_big.npz")
     if "params" in which:   # the sampling-parameter space + a 160-utterance batch (rows >= 625): ~1 min of reference CPU time
         golden_generate(sds, cases.PARAM_CASES, "generate_params.npz")
+    if "sweep" in which:    # 40 seeded random configurations, ids only
+        golden_sweep(sds)
     if "regen" in which:    # the "unexpected end at index" / regenerate path
         golden_regen(sds)
     if "stream" in which:   # the yield schedule of GPT.generate(stream=True)

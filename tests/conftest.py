@@ -34,4 +34,4 @@ def weights():
 
 @pytest.fixture(scope="session")
 def golden():
-    return {n: np.load(os.path.join(GOLDEN, n + ".npz")) for n in ("sampling", "generate", "generate_big", "generate_params", "generate_stream", "generate_regen", "codec", "codec_big", "text")}
+    return {n: np.load(os.path.join(GOLDEN, n + ".npz")) for n in ("sampling", "generate", "generate_big", "generate_params", "generate_stream", "generate_regen", "generate_sweep", "codec", "codec_big", "text")}

@@ -120,6 +120,32 @@ def test_generate_parameter_space_bit_exact(gpt_f32, golden, name, use_graph):
         assert err < 2e-4, (b, err)
 
 
+def test_random_sweep_equals_the_reference(gpt_f32, golden):
+    """tests/golden/generate_sweep.npz: 40 seeded random configurations (cases.sweep_cases) run by the reference itself -- batch widths
+    1..33 around the 16-row tile edges, one-token prompts, max_new_token = 1, min_new_token above max_new_token, top_K from 1 to above the
+    vocabulary or absent, top_P 0.1..0.99 or absent, per-codebook temperatures 0.05..1.5, repetition penalties 0.9 / 1 / 1.05 / 1.2 / 2,
+    seeded and unseeded.  Token ids bit-exact in every one, and the global generator left where the reference leaves it."""
+    Gd = golden["generate_sweep"]
+    bad = []
+    for name, c in cases.sweep_cases().items():
+        ids, mask, tmask = cases.gen_inputs(c)
+        ids_t, mask_t = torch.from_numpy(ids), torch.from_numpy(mask)
+        emb = gpt_f32.embed_prompt(ids_t, torch.from_numpy(tmask))
+        warpers, procs = E.gen_logits(625, c["top_P"], c["top_K"], c["rep"])
+        torch.manual_seed(c["global_seed"])
+        outs = list(gpt_f32.generate(emb, ids_t, torch.tensor(c["temperature"]), 625, mask_t, c["max_new"], c["min_new"], (*procs, *warpers),
+                                     return_hidden=True, manual_seed=c["manual_seed"], use_graph=(int(name[1:]) % 2 == 0)))
+        after = torch.rand(2).numpy()
+        ok = np.array_equal(after, Gd[name + ".rand_after"]) and (len(outs) == 1) == bool(Gd[name + ".yielded"][0])
+        if ok and outs:
+            lens = np.array([int(t.shape[0]) for t in outs[0].ids])
+            got = np.concatenate([t.cpu().numpy() for t in outs[0].ids], 0)
+            ok = np.array_equal(lens, Gd[name + ".lens"].astype(np.int64)) and np.array_equal(got, Gd[name + ".ids"].astype(np.int64))
+        if not ok:
+            bad.append((name, {k: c[k] for k in ("B", "t_min", "t_max", "top_P", "top_K", "rep", "max_new", "min_new", "manual_seed")}))
+    assert not bad, bad
+
+
 def test_wide_batch_tail_shard_keeps_the_global_row_quirk(gpt_f32, golden):
     """SURVEY 8e caveats 1-2 against the reference itself: utterances [128, 160) of `wide160` generated ALONE, as the last rank of a
     five-way split would (row_offset = 512 of total_rows = 640), equal the same utterances of the reference's unsharded run --

@@ -101,6 +101,30 @@ def test_generate_baseline_sizes_prefix(golden, np_model, name, k):
         assert np.abs(res.hiddens[b][:n] - G[name + f".hid{b}"][:n]).max() < 2e-4
 
 
+def test_generate_random_sweep_subset(golden, np_model):
+    """generate_sweep.npz (40 seeded random configurations through the reference): the numpy oracle on the cheap ones (at most 60
+    row-steps each; all 40 run on the GPU side) -- bit-exact ids incl. top_K above the vocabulary, repetition penalties below 1,
+    min_new_token above max_new_token, one-token prompts"""
+    llama, esd, heads = np_model
+    G = golden["generate_sweep"]
+    n = 0
+    for name, c in cases.sweep_cases().items():
+        if c["B"] * c["max_new"] > 60 or not bool(G[name + ".yielded"][0]):
+            continue
+        ids, mask, tmask = cases.gen_inputs(c)
+        B = ids.shape[0]
+        torch.manual_seed(c["global_seed"])
+        draws = rng.ExpDraws(B * 4, 626, c["manual_seed"])
+        res = generate_np.generate(
+            llama, esd, heads, generate_np.embed_prompt(esd, ids, tmask), ids, mask, temperature=np.array(c["temperature"], np.float32),
+            draw_q=lambda i: draws.step(i).numpy(), top_p=c["top_P"], top_k=c["top_K"], pow_table=_pow(c["rep"]),
+            max_new_token=c["max_new"], min_new_token=c["min_new"])
+        assert np.array_equal(np.array([r.shape[0] for r in res.ids]), G[name + ".lens"].astype(np.int64)), name
+        assert np.array_equal(np.concatenate(res.ids, 0), G[name + ".ids"].astype(np.int64)), name
+        n += 1
+    assert n >= 15
+
+
 def test_generate_wide_batch_prefix(golden, np_model):
     """generate_params.npz `wide160`: the reference's own run of 160 utterances = 640 sampling rows, of which rows >= 625
     (utterance 156 from its 2nd codebook on) get no repetition penalty (processors.py:24-27).  The oracle reproduces the first 6
