@@ -146,6 +146,24 @@ def sweep_cases(n: int = 40, seed: int = 2025):
     return out
 
 
+def text_sweep_cases(n: int = 12, seed: int = 2026):
+    """the same for refine-text mode (infer_text=True: one sampling row per utterance over the 21178-way text head, repetition penalty 1 --
+    the only value the reference's text mode can run with)"""
+    rs = np.random.RandomState(seed)
+    out = {}
+    for i in range(n):
+        t_min = int(rs.randint(1, 10))
+        max_new = int(rs.choice([1, 2, 5, 12, 20]))
+        seeded = bool(rs.rand() < 0.75)
+        out[f"t{i:02d}"] = dict(B=int(rs.choice([1, 2, 3, 6, 17])), t_min=t_min, t_max=t_min + int(rs.randint(0, 12)), pseed=300 + i,
+                                temperature=[float(rs.choice([0.1, 0.7, 1.0, 1.3]))],
+                                top_P=[None, 0.2, 0.7, 0.95][int(rs.randint(4))], top_K=[None, 1, 2, 20, 500, 30000][int(rs.randint(6))],
+                                rep=1.0, max_new=max_new, min_new=int(rs.randint(0, max_new + 2)),
+                                manual_seed=int(rs.randint(1, 10 ** 6)) if seeded else None, global_seed=int(rs.randint(1, 10 ** 6)),
+                                keep_hidden_rows=[], keep_logit_steps=[])
+    return out
+
+
 # refine-text mode (core.py:665-751 defaults: temperature 0.7, top_P 0.7, top_K 20, repetition_penalty 1.0)
 TEXT_EOS = 21000  # stands in for tokenizer.eos_token ([Ebreak]); any id works with synthetic weights
 TEXT_CASES = {

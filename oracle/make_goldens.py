@@ -123,17 +123,19 @@ def golden_sweep(sds):
     embed, gpt = ref_harness.build_gpt(sds)
     out = {}
     t0 = time.time()
-    for name, c in cases.sweep_cases().items():
+    for name, c in {**cases.sweep_cases(), **cases.text_sweep_cases()}.items():
+        text = name.startswith("t")
         ids, mask, tmask = cases.gen_inputs(c)
         torch.manual_seed(c["global_seed"])
         res, emb, cap = ref_harness.run_generate(
             embed, gpt, ids, mask, tmask, temperature=c["temperature"], top_P=c["top_P"], top_K=c["top_K"],
-            repetition_penalty=c["rep"], max_new_token=c["max_new"], min_new_token=c["min_new"], manual_seed=c["manual_seed"])
+            repetition_penalty=c["rep"], max_new_token=c["max_new"], min_new_token=c["min_new"], manual_seed=c["manual_seed"],
+            **(dict(infer_text=True, eos_token=cases.TEXT_EOS) if text else {}))
         out[name + ".rand_after"] = torch.rand(2).numpy()
         out[name + ".yielded"] = np.array([res is not None])
         if res is not None:
             out[name + ".lens"] = np.array([r.shape[0] for r in res.ids], dtype=np.int16)
-            out[name + ".ids"] = np.concatenate([r.numpy() for r in res.ids], 0).astype(np.int16)
+            out[name + ".ids"] = np.concatenate([r.numpy().reshape(-1) if text else r.numpy() for r in res.ids], 0).astype(np.int16)
         print(name, {k: c[k] for k in ("B", "t_min", "t_max", "top_P", "top_K", "rep", "max_new", "min_new", "manual_seed")},
               "yielded", res is not None, "" if res is None else out[name + ".lens"].tolist()[:8])
     print(f"sweep: {time.time() - t0:.1f}s")

@@ -127,14 +127,16 @@ def test_random_sweep_equals_the_reference(gpt_f32, golden):
     seeded and unseeded.  Token ids bit-exact in every one, and the global generator left where the reference leaves it."""
     Gd = golden["generate_sweep"]
     bad = []
-    for name, c in cases.sweep_cases().items():
+    for name, c in {**cases.sweep_cases(), **cases.text_sweep_cases()}.items():
+        text = name.startswith("t")      # + 12 refine-text configurations (one row per utterance over the 21178-way head, top_K up to 30000)
         ids, mask, tmask = cases.gen_inputs(c)
         ids_t, mask_t = torch.from_numpy(ids), torch.from_numpy(mask)
         emb = gpt_f32.embed_prompt(ids_t, torch.from_numpy(tmask))
-        warpers, procs = E.gen_logits(625, c["top_P"], c["top_K"], c["rep"])
+        warpers, procs = E.gen_logits(21178 if text else 625, c["top_P"], c["top_K"], c["rep"])
         torch.manual_seed(c["global_seed"])
-        outs = list(gpt_f32.generate(emb, ids_t, torch.tensor(c["temperature"]), 625, mask_t, c["max_new"], c["min_new"], (*procs, *warpers),
-                                     return_hidden=True, manual_seed=c["manual_seed"], use_graph=(int(name[1:]) % 2 == 0)))
+        outs = list(gpt_f32.generate(emb, ids_t, torch.tensor(c["temperature"]), cases.TEXT_EOS if text else 625, mask_t, c["max_new"],
+                                     c["min_new"], (*procs, *warpers), infer_text=text, return_hidden=True, manual_seed=c["manual_seed"],
+                                     use_graph=(int(name[1:]) % 2 == 0)))
         after = torch.rand(2).numpy()
         ok = np.array_equal(after, Gd[name + ".rand_after"]) and (len(outs) == 1) == bool(Gd[name + ".yielded"][0])
         if ok and outs:
