@@ -99,6 +99,25 @@ CODE_TEXTS = [
 ]
 
 
+def norm_sweep_cases(n: int = 120, seed: int = 31):
+    """seeded random strings over everything norm.py looks at: ASCII / CJK letters (incl. the keys of the homophone map), digits, both
+    punctuation families and the characters its tables rewrite, control tags (whole, unclosed, nested), brackets, whitespace runs,
+    characters outside every accepted range; random (do_text_normalization, do_homophone_replacement, lang)"""
+    rs = np.random.RandomState(seed)
+    pools = [list("abcdefghijklmnopqrstuvwxyzABCDEFXYZ"), list("0123456789"), list("四川美食辣面圆糕甜腻你好选择比如水汤蛋"),
+             list(",.!?;:'\"-_()<>{}#%&*+=/~`@$^|\\"), list("，。！？；：、（）《》【】“”‘’—…·"), [" ", "  ", "\t", "\n"],
+             ["[uv_break]", "[laugh]", "[lbreak]", "[speed_5]", "[oral_2]", "[break_6]", "[", "]", "[[x]", "[unclosed"],
+             ["é", "ß", "ø", "Ω", "я", "あ", "한", "😀", "\u200b", "１２", "ＡＢ"]]
+    weights = np.array([6, 2, 6, 3, 3, 2, 2, 1], np.float64)
+    weights /= weights.sum()
+    out = []
+    for _ in range(n):
+        k = int(rs.randint(1, 30))
+        t = "".join(str(rs.choice(pools[int(rs.choice(len(pools), p=weights))])) for _ in range(k))
+        out.append((t, bool(rs.rand() < 0.8), bool(rs.rand() < 0.7), [None, None, "en", "zh"][int(rs.randint(4))]))
+    return out
+
+
 def main():
     tok_dir = build_tokenizer(os.path.join(GOLD, "tokenizer"))
     tokm, spkm, normm, cfgm = ref_frontend()
@@ -114,6 +133,8 @@ def main():
     nz = normm.Normalizer(hpath)
     nz.register("en", lambda s: s.replace("100%", "one hundred percent"))
     out["norm"] = [{"in": t, "tn": tn, "hp": hp, "lang": lang, "out": nz(t, tn, hp, lang)} for t, tn, hp, lang in NORM_CASES]
+
+    out["norm_sweep"] = [{"in": t, "tn": tn, "hp": hp, "lang": lang, "out": nz(t, tn, hp, lang)} for t, tn, hp, lang in norm_sweep_cases()]
 
     T = tokm.Tokenizer(tok_dir)
     if not hasattr(T._tokenizer, "encode_plus"):
@@ -133,6 +154,25 @@ def main():
                         "prompt": None if prompt is None else prompt.tolist(), "ids": ids.tolist(), "attn": attn.tolist(),
                         "tmask": tmask.to(torch.int64).tolist(), "decoded": T.decode(ids[..., 0])})
     out["encode"] = enc
+    # seeded random batches: 1..6 texts of 0..12 vocabulary words / CJK characters / control tokens / unknown words, random prompt string,
+    # optional speaker embedding and audio-code prompt (1..40 frames)
+    rs = np.random.RandomState(17)
+    vocab_like = WORDS + ZH + CONTROL + PUNCT + ["zzzqq", "Ünknown", "12", " "]
+    sweep = []
+    for i in range(30):
+        texts = ["".join(str(rs.choice(vocab_like)) + ("" if rs.rand() < 0.3 else " ") for _ in range(int(rs.randint(0, 13))))
+                 for _ in range(int(rs.randint(1, 7)))]
+        spk_emb = None if rs.rand() < 0.5 else "x"
+        with_prompt = bool(rs.rand() < 0.4)
+        txt_smp = "sample text" if (with_prompt and rs.rand() < 0.7) else None
+        prm = ["", "[speed_5]", "[oral_2][laugh_0][break_6]"][int(rs.randint(3))]
+        deco = S.decorate_code_prompts(list(texts), prm, txt_smp, spk_emb)
+        prompt = torch.from_numpy(rs.randint(0, 626, (4, int(rs.randint(1, 41)))).astype(np.int32)) if with_prompt else None
+        ids, attn, tmask = T.encode(deco, 4, prompt=prompt)
+        sweep.append({"texts": texts, "spk_emb": spk_emb, "txt_smp": txt_smp, "prompt_str": prm, "decorated": deco,
+                      "prompt": None if prompt is None else prompt.tolist(), "ids": ids.tolist(), "attn": attn.tolist(),
+                      "tmask": tmask.to(torch.int64).tolist(), "decoded": T.decode(ids[..., 0])})
+    out["encode_sweep"] = sweep
     deco = S.decorate_text_prompts(["what is your favorite food", "你好"], "[oral_2][laugh_0][break_6]")
     ids, attn, tmask = T.encode(deco, 4)
     out["refine"] = {"decorated": deco, "ids": ids.tolist(), "attn": attn.tolist(), "tmask": tmask.to(torch.int64).tolist()}

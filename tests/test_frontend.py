@@ -70,6 +70,17 @@ def test_normalizer_matches_reference(gold):
     assert F.Normalizer()("你好", True, True) == "你好"        # no map file: homophone step is a no-op
 
 
+def test_normalizer_random_sweep_matches_reference(gold):
+    """frontend.json `norm_sweep`: 120 seeded random strings (ASCII / CJK letters incl. the homophone keys, digits, both punctuation
+    families, control tags whole / unclosed / nested, whitespace runs, characters outside every accepted range) with random flags through
+    the reference's Normalizer (oracle/make_frontend_goldens.norm_sweep_cases)"""
+    nz = F.Normalizer(os.path.join(GOLD, "homophones_small.json"))
+    nz.register("en", lambda s: s.replace("100%", "one hundred percent"))
+    bad = [(c["in"], c["tn"], c["hp"], c["lang"], c["out"], nz(c["in"], c["tn"], c["hp"], c["lang"])) for c in gold["norm_sweep"]
+           if nz(c["in"], c["tn"], c["hp"], c["lang"]) != c["out"]]
+    assert not bad, bad[:5]
+
+
 def test_split_and_combine_tags():
     t, g = F.split_tags("a[x]b[y]")
     assert (t, g) == (["a", "b"], ["[x]", "[y]"])
@@ -97,6 +108,18 @@ def test_tokenizer_encode_matches_reference(gold, tok):
     r = gold["refine"]
     ids, attn, tmask = tok.encode(r["decorated"], 4)
     assert ids.tolist() == r["ids"] and attn.tolist() == r["attn"] and tmask.to(torch.int64).tolist() == r["tmask"]
+
+
+def test_tokenizer_encode_random_sweep_matches_reference(gold, tok):
+    """frontend.json `encode_sweep`: 30 seeded random batches (1..6 texts of vocabulary words / CJK characters / control tokens / unknown
+    words, empty texts, random prompt strings, optional speaker embedding and audio-code prompt of 1..40 frames) decorated and encoded by
+    the reference's Speaker / Tokenizer: decoration, ids, left padding, masks and the decoded strings"""
+    for e in gold["encode_sweep"]:
+        assert F.Speaker.decorate_code_prompts(list(e["texts"]), e["prompt_str"], e["txt_smp"], e["spk_emb"]) == e["decorated"]
+        prompt = None if e["prompt"] is None else torch.tensor(e["prompt"], dtype=torch.int32)
+        ids, attn, tmask = tok.encode(e["decorated"], 4, prompt=prompt)
+        assert ids.tolist() == e["ids"] and attn.tolist() == e["attn"] and tmask.to(torch.int64).tolist() == e["tmask"], e["texts"]
+        assert tok.decode(ids[..., 0]) == e["decoded"]
 
 
 def test_reference_test_655_round_trip(tok):
