@@ -95,6 +95,15 @@ PARAM_CASES = {
 }
 
 
+# ---- `InferCodeParams.max_new_token`'s default, 2048 (core.py:197), in full (tests/golden/generate_max.npz) ----------------------------
+# batch 2 (one row left-padded), EOS masked to the last step: 2048 autoregressive steps, contexts up to 2088 keys -- the longest
+# generation the reference's defaults allow; ~10 min of reference CPU time (its DynamicCache re-concatenates the KV every step)
+MAX_CASES = {
+    "max2048": dict(B=2, t_min=24, t_max=40, pseed=31, temperature=[0.3] * 4, top_P=0.7, top_K=20, rep=1.05,
+                    max_new=2048, min_new=2048, manual_seed=42, keep_hidden_rows=[], keep_logit_steps=[]),
+}
+
+
 # ---- GPT.generate(stream=True): the yield schedule of gpt.py:579-589 (tests/golden/generate_stream.npz) -----------------------
 # a yield whenever the count of steps with any unfinished row is a multiple of `stream_batch`, every row cut at its own end_idx,
 # plus the final yield (a duplicate when the last step was a multiple).  GEN_CASES entries + the stream_batch to run them with.

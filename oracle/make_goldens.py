@@ -238,6 +238,8 @@ def main():
         golden_generate(sds, cases.BIG_CASES, "generate_big.npz")
     if "params" in which:   # the sampling-parameter space + a 160-utterance batch (rows >= 625): ~1 min of reference CPU time
         golden_generate(sds, cases.PARAM_CASES, "generate_params.npz")
+    if "max" in which:      # 2048 steps: ~10 min
+        golden_generate(sds, cases.MAX_CASES, "generate_max.npz")
     if "sweep" in which:    # 40 seeded random configurations, ids only
         golden_sweep(sds)
     if "regen" in which:    # the "unexpected end at index" / regenerate path

@@ -120,6 +120,23 @@ def test_generate_parameter_space_bit_exact(gpt_f32, golden, name, use_graph):
         assert err < 2e-4, (b, err)
 
 
+def test_generate_default_max_new_token_bit_exact(gpt_f32):
+    """tests/golden/generate_max.npz: `InferCodeParams.max_new_token`'s default (2048, core.py:197) generated in full by the reference --
+    two utterances (one left-padded), EOS masked to the last step, contexts up to 2088 keys.  All 2 x 2048 token rows bit-exact (graph
+    replay): no f32 summation-order difference anywhere in 20 layers x 2048 steps of attention over a growing cache flips a draw."""
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "generate_max.npz")
+    Gd = np.load(path)
+    c = cases.MAX_CASES["max2048"]
+    outs, emb = run_case(gpt_f32, c, use_graph=True)
+    out = outs[-1]
+    assert np.array_equal(emb[0].cpu().numpy(), Gd["max2048.emb_row0"])
+    assert [int(t.shape[0]) for t in out.ids] == Gd["max2048.lens"].tolist() == [2048, 2048]
+    got = np.concatenate([t.cpu().numpy() for t in out.ids], 0)
+    want = Gd["max2048.ids"]
+    assert np.array_equal(got, want), f"first differing token row: {int(np.argmax((got != want).any(1)))} of {len(want)}"
+
+
 def test_random_sweep_equals_the_reference(gpt_f32, golden):
     """tests/golden/generate_sweep.npz: 40 seeded random configurations (cases.sweep_cases) run by the reference itself -- batch widths
     1..33 around the 16-row tile edges, one-token prompts, max_new_token = 1, min_new_token above max_new_token, top_K from 1 to above the

@@ -101,6 +101,23 @@ def test_generate_baseline_sizes_prefix(golden, np_model, name, k):
         assert np.abs(res.hiddens[b][:n] - G[name + f".hid{b}"][:n]).max() < 2e-4
 
 
+def test_generate_max_prefix(np_model):
+    """generate_max.npz (the reference's run of the default max_new_token = 2048): the oracle reproduces its first 10 steps (the other
+    2038 are the GPU side's)"""
+    import os
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "generate_max.npz"))
+    llama, esd, heads = np_model
+    c, k = cases.MAX_CASES["max2048"], 10
+    ids, mask, tmask = cases.gen_inputs(c)
+    draws = rng.ExpDraws(ids.shape[0] * 4, 626, c["manual_seed"])
+    res = generate_np.generate(
+        llama, esd, heads, generate_np.embed_prompt(esd, ids, tmask), ids, mask, temperature=np.array(c["temperature"], np.float32),
+        draw_q=lambda i: draws.step(i).numpy(), top_p=c["top_P"], top_k=c["top_K"], pow_table=_pow(c["rep"]), max_new_token=k, min_new_token=k)
+    off = np.concatenate([[0], np.cumsum(G["max2048.lens"])])
+    for b in range(ids.shape[0]):
+        assert np.array_equal(res.ids[b], G["max2048.ids"][off[b]: off[b] + k]), b
+
+
 def test_generate_random_sweep_subset(golden, np_model):
     """generate_sweep.npz (40 seeded random configurations through the reference): the numpy oracle on the cheap ones (at most 60
     row-steps each; all 40 run on the GPU side) -- bit-exact ids incl. top_K above the vocabulary, repetition penalties below 1,
