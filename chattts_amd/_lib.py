@@ -131,6 +131,7 @@ SIGNATURES = {
     "ctts_k_attention_dec": (C.c_int, [P, P, P, I32, P, P, P, I32, P, P, I32, P]),
     "ctts_k_attention_dec2": (C.c_int, [P, P, P, I32, I32, P, P, P, I32, I32, P]),
     "ctts_k_attention_cfg": (C.c_int, [I32, I32, I32]),
+    "ctts_k_attention_heads_per_wg": (C.c_int, [I32]),
     "ctts_rccl_unique_id": (C.c_int, [P]),
     "ctts_rccl_comm_create": (C.c_int, [P, I32, P, I32]),
     "ctts_rccl_comm_destroy": (None, [P]),

@@ -1042,6 +1042,11 @@ extern "C" int ctts_k_attention_cfg(int32_t persist, int32_t workgroups, int32_t
   attention_persist_override(persist, workgroups, ring);
   return 0;
 }
+extern "C" int ctts_k_attention_heads_per_wg(int32_t hpw) {
+  if (hpw != 1 && hpw != 2 && hpw != 3 && hpw != 4) return fail("ctts_k_attention_heads_per_wg: 1, 2, 3 or 4");
+  attention_hpw_override(hpw);
+  return 0;
+}
 extern "C" int ctts_k_attention_oproj(const float* qkv, const uint16_t* kcache, const uint16_t* vcache, int32_t cmax, const uint16_t* wo_hd,
                                       const int32_t* desc, const int32_t* n_active, int32_t M, float* part, int32_t* cnt, float* x32,
                                       uint16_t* xp, float* ssq, void* stream) {

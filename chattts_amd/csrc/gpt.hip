@@ -383,7 +383,7 @@ __device__ __forceinline__ float groups_max(float v) {  // max over the key grou
 // newest key / value are written by QKV tiles of the same launch, so it (1) requests its first two blocks of OLD keys (everything
 // below the step's slot: written by earlier launches), (2) waits for its head's arrival word, (3) reads q and the newest K / V row
 // with sc1 loads and goes on as usual; the newest key is consumed last, by the last wave, as a block of its own.
-template <typename KT, int NW, typename OT, bool PKO = false, bool SPLIT = false, bool PF = false, int NBUF = 2, bool OPJ = false, bool QF = false>
+template <typename KT, int NW, typename OT, bool PKO = false, bool SPLIT = false, bool PF = false, int NBUF = 2, bool OPJ = false, bool QF = false, int HPW = 1>
 __device__ __forceinline__ void attention_body(const float* __restrict__ qkv, const KT* __restrict__ kc, const KT* __restrict__ vc, int cmax,
                                                OT* __restrict__ out, const GptRowMap& rm, const int h_in, const int m_in, const int wg_linear) {
   constexpr int DPL = KTraits<KT>::DPL;
@@ -396,7 +396,8 @@ __device__ __forceinline__ void attention_body(const float* __restrict__ qkv, co
 #define CTTS_KV_NT 1              // A/B builds: python -m chattts_amd.build --variant kvplain -DCTTS_KV_NT=0 (profiles/r3ap_kv_nt_ab.log)
 #endif
   constexpr bool KV_NT = NW > 1 && CTTS_KV_NT;    // decode: every KV byte is read once per step by exactly one workgroup -> non-temporal
-  constexpr int NU = QF ? 2 : 1;   // units per workgroup: the fused launch's workgroups are 8 waves = heads 2p and 2p + 1 of one utterance
+  constexpr int NU = QF ? 2 : HPW;   // units per workgroup: the fused launch's workgroups are 8 waves = heads 2p and 2p + 1 of one utterance;
+                                     // HPW > 1 (attention_hpw_k): HPW consecutive heads of one utterance, NW waves each (same length: uniform barriers)
   __shared__ float sm_m_[NU][NW], sm_l_[NU][NW], sm_acc_[NU][NW][HDIM];
   __shared__ __attribute__((aligned(16))) bf16_t sm_on[OPJ ? HDIM : 8];   // OPJ: the unit's normalised output, bf16
   __shared__ __attribute__((aligned(16))) float sm_p[OPJ ? HID : 4];      // OPJ: its 768-wide o_proj partial
@@ -408,9 +409,9 @@ __device__ __forceinline__ void attention_body(const float* __restrict__ qkv, co
   }
 #endif
 
-  const int unit = QF ? (int)(threadIdx.x >> 8) : 0;   // which of the workgroup's units this wave belongs to
+  const int unit = (QF || HPW > 1) ? (int)(threadIdx.x / (64 * NW)) : 0;   // which of the workgroup's units this wave belongs to
   int h = h_in + unit, m = m_in;
-  const int tid = QF ? (int)(threadIdx.x & 255) : (int)threadIdx.x, wave = tid >> 6, lane = tid & 63;   // thread / wave index WITHIN the unit
+  const int tid = (QF || HPW > 1) ? (int)(threadIdx.x % (64 * NW)) : (int)threadIdx.x, wave = tid >> 6, lane = tid & 63;   // thread / wave index WITHIN the unit
   float (&sm_m)[NW] = sm_m_[unit];
   float (&sm_l)[NW] = sm_l_[unit];
   float (&sm_acc)[NW][HDIM] = sm_acc_[unit];
@@ -812,6 +813,17 @@ __global__ __launch_bounds__(64 * NW + (PF ? 64 : 0)) void attention_k(const flo
   attention_body<KT, NW, OT, PKO, SPLIT, PF, NBUF, OPJ, false>(qkv, kc, vc, cmax, out, rm, blockIdx.x, blockIdx.y, blockIdx.y * gridDim.x + blockIdx.x);
 }
 
+// HPW heads of one utterance per workgroup (round 5 A/B, CTTS_ATT_HPW=2|3|4; ctts_k_attention_heads_per_wg): the SAME 4-wave unit,
+// arithmetic and bits as attention_k<KT, 4>, but 12 / HPW workgroups of 4 HPW waves per utterance instead of 12 of 4 -- the question is
+// whether a launch's fixed cost (5.0 us by bench.py's roofline.fit; an empty 768-workgroup stage measures 5.1 us, a 192-workgroup one
+// 2.6) follows the number of WORKGROUPS dispatched or the number of waves.  The heads of one utterance have the same context, so the
+// units of a workgroup run the same number of blocks and meet at the merge's barrier together.
+template <typename KT, typename OT, int HPW>
+__global__ __launch_bounds__(256 * HPW) void attention_hpw_k(const float* __restrict__ qkv, const KT* __restrict__ kc, const KT* __restrict__ vc, int cmax,
+                                                              OT* __restrict__ out, GptRowMap rm) {
+  attention_body<KT, 4, OT, true, false, false, 2, false, false, HPW>(qkv, kc, vc, cmax, out, rm, blockIdx.x * HPW, blockIdx.y, blockIdx.y * gridDim.x + blockIdx.x);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Persistent decode attention (round 5; both modes, packed output).  attention_k launches one workgroup per (utterance, head)
 // unit of the captured batch -- 768 workgroups at batch 64 whether 64 or 6 utterances are still alive -- and a launch of 768
@@ -1181,6 +1193,16 @@ __global__ __launch_bounds__(256) void attention_prefill_mfma_k(const float* __r
 }
 
 // persistent decode attention: [0] on / off, [1] workgroups, [2] ring depth -- environment at first use, ctts_k_attention_cfg afterwards
+static int att_hpw_ = -1;   // heads per workgroup of the decode attention (attention_hpw_k): CTTS_ATT_HPW at first use, ctts_k_attention_heads_per_wg afterwards
+static int att_hpw_cfg() {
+  if (att_hpw_ < 0) {
+    const char* e = getenv("CTTS_ATT_HPW");
+    const int v = e ? atoi(e) : 1;
+    att_hpw_ = (v == 2 || v == 3 || v == 4) ? v : 1;
+  }
+  return att_hpw_;
+}
+void attention_hpw_override(int hpw) { att_hpw_ = (hpw == 2 || hpw == 3 || hpw == 4) ? hpw : 1; }
 static int att_cfg_[3] = {-1, 0, 4};
 static int att_persist_cfg(int i) {
   if (att_cfg_[0] < 0) {
@@ -1251,6 +1273,18 @@ hipError_t launch_attention(const float* qkv, const void* kcache, const void* vc
       if (att_d == 2) ATTP(float, x3p_t, 2); else if (att_d == 3) ATTP(float, x3p_t, 3); else ATTP(float, x3p_t, 4);
     }
 #undef ATTP
+    return hipGetLastError();
+  }
+  const int hpw = att_hpw_cfg();
+  if (hpw > 1 && decode && rm.desc != nullptr && (out_bf16 == 2 || out_bf16 == 3 || out_bf16 == 4) && rm.dbg == nullptr &&
+      !(out_bf16 == 2 && rm.sp_cus > 0 && rm.sp_part != nullptr && rm.sp_cnt != nullptr)) {
+    if ((out_bf16 == 2) != (kv_wt == WT_BF16) || (out_bf16 == 4 && rm.x3_plane == 0)) return hipErrorInvalidValue;
+    const dim3 hg(NHEAD / hpw, M), hb(256 * hpw);
+#define ATTH(KT, OT, H) CTTS_LAUNCH((attention_hpw_k<KT, OT, H>), hg, hb, st, qkv, (const KT*)kcache, (const KT*)vcache, cmax, (OT*)out, rm)
+    if (out_bf16 == 2) { if (hpw == 2) ATTH(bf16_t, bf16_t, 2); else if (hpw == 3) ATTH(bf16_t, bf16_t, 3); else ATTH(bf16_t, bf16_t, 4); }
+    else if (out_bf16 == 3) { if (hpw == 2) ATTH(float, float, 2); else if (hpw == 3) ATTH(float, float, 3); else ATTH(float, float, 4); }
+    else { if (hpw == 2) ATTH(float, x3p_t, 2); else if (hpw == 3) ATTH(float, x3p_t, 3); else ATTH(float, x3p_t, 4); }
+#undef ATTH
     return hipGetLastError();
   }
   if (out_bf16 == 2) {   // decode, perf mode: bf16 output in the fragment-packed order the o_proj kernel of decode.hip reads

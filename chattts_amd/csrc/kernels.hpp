@@ -298,6 +298,7 @@ hipError_t launch_prefill_prep32(const float* x, float* xp32, RowDesc* desc, int
 hipError_t launch_rope_append(float* qkv /*[M,2304]*/, void* kcache, void* vcache, int kv_wt, int cmax,
                               const float* cos_tab, const float* sin_tab /*[max_pos,32]*/, GptRowMap rm, int M, hipStream_t st);
 void attention_persist_override(int persist, int g, int d);   // tests / probes: < 0 (<= 0) leaves a field as it is
+void attention_hpw_override(int hpw);   // heads of one utterance per decode-attention workgroup: 1 (default) | 2 | 3 | 4
 hipError_t launch_attention(const float* qkv, const void* kcache, const void* vcache, int kv_wt, int cmax,
                             void* out /*[M,768] f32, or bf16 when out_bf16 (2: bf16 in the packed order of decode.hip)*/, int out_bf16,
                             GptRowMap rm, int M, hipStream_t st);

@@ -417,6 +417,9 @@ int ctts_k_attention_dec2(const float* qkv, const void* kcache, const void* vcac
 /* tests / probes: decode attention launch shape of this process -- persist 0 | 1 (< 0: keep), workgroups of the persistent grid (<= 0:
  * keep; default = the device's CU count), KV blocks per wave ring 2 | 3 | 4 (<= 0: keep; default 4).  Never changes a result bit. */
 int ctts_k_attention_cfg(int32_t persist, int32_t workgroups, int32_t ring);
+/* round 5 A/B: `hpw` consecutive heads of one utterance per decode-attention workgroup (1 = the shipped grid of one workgroup per (utterance,
+ * head); 2 | 3 | 4: the same 4-wave units, 12 / hpw workgroups of 4 hpw waves per utterance -- bit-identical output; env CTTS_ATT_HPW). */
+int ctts_k_attention_heads_per_wg(int32_t hpw);
 /* The same attention with o_proj + residual folded in (ctts_gpt_weights.wo_hd): wo_hd [12][8][768][8] bf16; part [ceil16(M)][12][768]
  * f32 scratch; cnt [M] int32, zero (left zero); x32 [M][768] f32 residual, updated in place; xp its bf16 copy in the fragment-packed
  * order; ssq [M][48] partial sums of squares of the new residual. */

@@ -820,9 +820,26 @@ def test_attention_decode_persistent_grid(G, mode, n_live):
                 got = run(1, g, ring)
                 assert np.isnan(got[untouched]).all(), (g, ring)
                 assert np.array_equal(got[live], unit[live]), (g, ring, np.abs(got[live] - unit[live]).max())
+            # 2 / 3 / 4 heads of one utterance per workgroup (attention_hpw_k): the same units, the same bits, a third / a quarter of the workgroups
+            for hpw in (2, 3, 4):
+                _lib.check(lib.ctts_k_attention_heads_per_wg(hpw), "heads_per_wg")
+                got = run(0, 0, 0)
+                assert np.isnan(got[untouched]).all(), hpw
+                assert np.array_equal(got[live], unit[live]), (hpw, np.abs(got[live] - unit[live]).max())
+                if not bf:
+                    pl = torch.full((2, Bp * H), float("nan"), dtype=torch.float32, device=G.DEV).to(torch.bfloat16)
+                    _lib.check(lib.ctts_k_attention_dec2(q_d.data_ptr(), kc.data_ptr(), vc.data_ptr(), 2, cmax, pl.data_ptr(), desc_d.data_ptr(),
+                                                         None if covers_all else na.data_ptr(), covers_all, Bp, None), "attention_dec2 planes")
+                    torch.cuda.synchronize()
+                    o32 = torch.from_numpy(unit)
+                    want_hi = o32.to(torch.bfloat16).float()
+                    assert torch.equal(unpack_frag(pl[0].float().cpu(), Bp, H)[live], want_hi[live])
+                    assert torch.equal(unpack_frag(pl[1].float().cpu(), Bp, H)[live], (o32 - want_hi).to(torch.bfloat16).float()[live])
+            _lib.check(lib.ctts_k_attention_heads_per_wg(1), "heads_per_wg")
     finally:
         ncu = torch.cuda.get_device_properties(0).multi_processor_count
-        _lib.check(lib.ctts_k_attention_cfg(1, ncu, 4), "attention_cfg")     # back to the shipped default
+        _lib.check(lib.ctts_k_attention_cfg(0, ncu, 4), "attention_cfg")     # back to the shipped default: one workgroup per unit
+        _lib.check(lib.ctts_k_attention_heads_per_wg(1), "heads_per_wg")
 
 
 @pytest.mark.parametrize("n_live", [1, 5, 16, 17, 45, 64])
