@@ -140,6 +140,38 @@ SCENARIOS = {
     "stream_short_never_passes": dict(text=["k"], stream=True, split_text=False, skip_refine_text=True, pass_first_n_batches=9),
 }
 
+def _random_scenarios(n: int = 40, seed: int = 7):
+    """seeded random calls of Chat.infer: 0..7 sentences as a list / newline string / regex-split string, every flag, window sizes from
+    a few hundred samples to larger than any waveform, 0..4 passed batches, split batches of 1..4"""
+    rs = np.random.RandomState(seed)
+    words = ["alpha", "beta", "gamma", "delta", "epsilon", "zeta", "eta", "theta", "iota", "kappa", "lambda", "mu", "中文", "句子", "x"]
+    out = {}
+    for i in range(n):
+        k = int(rs.randint(0, 8))
+        sents = [" ".join(str(rs.choice(words)) for _ in range(int(rs.randint(1, 6)))) + f" {i}.{j}" for j in range(k)]
+        form = int(rs.randint(3))
+        split = bool(rs.rand() < 0.5)
+        if form == 0 or not split:
+            text = sents if (k != 1 or rs.rand() < 0.5) else sents[0]
+        elif form == 1:
+            text = "\n".join(sents)
+        else:
+            text = "".join(t + (". " if rs.rand() < 0.5 else "。") for t in sents)
+        sc = dict(text=text, split_text=split, skip_refine_text=bool(rs.rand() < 0.7), stream=bool(rs.rand() < 0.5),
+                  use_decoder=bool(rs.rand() < 0.8), max_split_batch=int(rs.randint(1, 5)))
+        if not sc["skip_refine_text"] and rs.rand() < 0.3:
+            sc["refine_text_only"] = True
+        if sc["stream"]:
+            sc["stream_speed"] = int(rs.choice([500, 3000, 12000, 24000, 10 ** 6]))
+            sc["pass_first_n_batches"] = int(rs.randint(0, 5))
+        if rs.rand() < 0.3:
+            sc["spk_smp"], sc["txt_smp"] = "GIVEN", "given text"
+        out[f"rand{i:02d}"] = sc
+    return out
+
+
+SCENARIOS.update(_random_scenarios())
+
 INFER_KEYS = ("stream", "lang", "skip_refine_text", "refine_text_only", "use_decoder", "do_text_normalization", "do_homophone_replacement",
               "split_text", "max_split_batch")
 CODE_PARAM_KEYS = ("spk_smp", "txt_smp", "stream_speed", "pass_first_n_batches")
