@@ -286,6 +286,22 @@ def pcm_inputs():
 def stream_chunks(name: str):
     """chunk sequences like Chat.infer(stream=True) yields them ([B, n] float32, utterances that have finished are silent from then on)
     for the ChatStreamer goldens"""
+    if name.startswith("rnd"):   # seeded random: 1..4 utterances ending at random times (silent afterwards), 1..12 chunks of 100..30000
+        rs = np.random.RandomState(900 + int(name[3:]))   # samples, some chunks silent for everybody, some utterances silent throughout
+        B, n_chunks = int(rs.randint(1, 5)), int(rs.randint(1, 13))
+        widths = [int(rs.choice([100, 700, 3000, 12000, 12001, 24000, 30000])) for _ in range(n_chunks)]
+        total = sum(widths)
+        ends = [0 if rs.rand() < 0.15 else int(rs.randint(1, total + 1)) for _ in range(B)]
+        chunks, pos = [], 0
+        for n in widths:
+            ch = (rs.standard_normal((B, n)) * float(rs.choice([0.05, 0.3, 1.2]))).astype(f32)
+            for b, e in enumerate(ends):
+                ch[b, max(0, min(n, e - pos)):] = 0.0
+            if rs.rand() < 0.15:
+                ch[:] = 0.0
+            chunks.append(ch)
+            pos += n
+        return chunks
     rs = np.random.RandomState({"three": 5, "one": 6, "late": 7}[name])
     if name == "one":        # a single utterance, chunks shorter than a block
         return [(rs.standard_normal((1, n)) * 0.2).astype(f32) for n in (3000, 3000, 3000, 12000, 500, 7000)]
@@ -311,4 +327,4 @@ def stream_chunks(name: str):
     return chunks
 
 
-STREAM_CASES = ("three", "one", "late")
+STREAM_CASES = ("three", "one", "late") + tuple(f"rnd{i}" for i in range(16))

@@ -74,15 +74,22 @@ def main():
         Streamer = ref_streamer(fn)
         for name in cases.STREAM_CASES:
             for fmt in ("PCM16_byte", None):
-                with contextlib.redirect_stdout(io.StringIO()):        # the class prints its progress
-                    blocks = list(Streamer().generate(iter(cases.stream_chunks(name)), output_format=fmt))
                 key = f"stream.{name}.{prod}.{'bytes' if fmt else 'float'}"
+                try:
+                    with contextlib.redirect_stdout(io.StringIO()):        # the class prints its progress
+                        blocks = list(Streamer().generate(iter(cases.stream_chunks(name)), output_format=fmt))
+                except (UnboundLocalError, ValueError, IndexError) as exc:
+                    # the reference class crashes on some sequences (e.g. `is_keep_next` unbound when the first chunk is silent for everybody,
+                    # stream.py:124): recorded as such -- the port's behaviour there is its own (tests/test_backend.py)
+                    out[key + ".raises"] = np.array(type(exc).__name__)
+                    print(key, "reference raises", type(exc).__name__)
+                    continue
                 if not fmt and prod == "f32":
                     continue          # no conversion in this format: one golden is enough
                 raw = b"".join(blocks) if fmt else b"".join(np.ascontiguousarray(b, dtype="<f4").tobytes() for b in blocks)
                 out[key + ".sha256"] = np.array(hashlib.sha256(raw).hexdigest())     # the blocks, concatenated, byte for byte
                 out[key + ".lens"] = np.array([len(b) for b in blocks], np.int64)    # ... and where each one ends
-                if fmt and name != "three":
+                if fmt and name in ("one", "late"):
                     out[key] = np.frombuffer(raw, dtype=np.uint8)                    # the small cases also in full (a failing test can show where)
                 print(key, len(blocks), "blocks", out[key + ".lens"].tolist()[:12])
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "backend.npz"), **out)

@@ -42,7 +42,14 @@ def _digest(blocks, as_float):
 def test_chat_streamer_equals_the_reference_class(gold, name):
     """the reference's ChatStreamer fed the same chunk sequence: the same PCM16 byte blocks in the same order with the same boundaries
     (three utterances ending at different times; one utterance in sub-block chunks; a silent first utterance, a silent chunk, a
-    leftover under the block size), for both product arithmetics, and the float pieces of output_format=None"""
+    leftover under the block size; 16 seeded random sequences of 1..4 utterances, 1..12 chunks of 100..30000 samples), for both product
+    arithmetics, and the float pieces of output_format=None"""
+    if f"stream.{name}.f64.bytes.raises" in gold.files:
+        # seeded random sequences on which the reference class itself crashes (`is_keep_next` unbound, stream.py:124, when the first
+        # chunk is silent for every utterance): the port must not -- what it yields there is its own behaviour, not pinned
+        for fmt in ("PCM16_byte", "PCM16", None):
+            list(ChatStreamer().generate(iter(cases.stream_chunks(name)), output_format=fmt))
+        return
     for product in ("f64", "f32"):
         blocks = list(ChatStreamer(product=product).generate(iter(cases.stream_chunks(name)), output_format="PCM16_byte"))
         key = f"stream.{name}.{product}.bytes"
