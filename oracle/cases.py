@@ -217,6 +217,10 @@ def gen_inputs(c):
 CODEC_CASES = {
     "c24": dict(B=2, T=24, seed=0),
     "c1x5": dict(B=1, T=5, seed=1),   # shorter than the receptive field: edge handling
+    # round 5: the short end -- one token (2 mel frames, a 256-sample waveform: every convolution is all padding), 2 / 3 / 4 tokens, lengths
+    # around the dilated kernels' reach, odd batches with a zero-padded second row
+    "s1x1": dict(B=1, T=1, seed=11), "s1x2": dict(B=1, T=2, seed=12), "s2x3": dict(B=2, T=3, seed=13), "s3x4": dict(B=3, T=4, seed=14),
+    "s1x7": dict(B=1, T=7, seed=15), "s4x9": dict(B=4, T=9, seed=16), "s2x13": dict(B=2, T=13, seed=17), "s3x33": dict(B=3, T=33, seed=18),
 }
 
 
