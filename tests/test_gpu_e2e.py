@@ -868,6 +868,26 @@ def test_codec_f16_mode_threshold_straddle(weights, golden):
     assert d < 2e-5, d
 
 
+def test_decode_window_vs_the_reference_decode(codec, golden):
+    """streamed windows against the REFERENCE's decode of the whole utterance (codec_big.npz `c2size`: the reference's DVAE class + the vocos
+    restatement on the reference GPT's own 512 hidden states; the golden keeps every 16th waveform sample): windows at the start, in the
+    interior (token window + halos only: 12000 samples need ~126 of the 512 tokens), and at the end -- each within the 1e-4 RMS bar of the
+    samples the reference produced for that range"""
+    Gd = golden["codec_big"]
+    hid, _ = cases.codec_big_inputs(cases.CODEC_BIG_CASES["c2size"], golden["generate_big"]["c2.hid0"])
+    rows = [torch.from_numpy(hid[0]).to(DEV)]
+    ref_s = Gd["c2size.wav_s"][0]                  # samples 0, 16, 32, ... of row 0
+    total = 256 * (2 * 512 - 1)
+    st = cases.CODEC_BIG_WAV_STRIDE
+    for lo, hi in [(0, 12000), (12000, 24000), (100000, 112000), (200000, 212000), (131072, 131072 + 500), (total - 9000, total)]:
+        got = codec.decode_window(rows, lo, hi).cpu().numpy()[0]
+        assert got.shape == (hi - lo,)
+        p = np.arange((lo + st - 1) // st * st, hi, st)
+        p = p[p // st < ref_s.shape[0]]
+        err = got[p - lo] - ref_s[p // st]
+        assert float(np.sqrt(np.mean(err ** 2))) < 1e-4, (lo, hi, float(np.sqrt(np.mean(err ** 2))))
+
+
 def test_decode_window_equals_slices_of_the_full_decode(codec):
     """`CodecEngine.decode_window` (what streaming emits): any sample range of the batch decode, computed from the token
     window it depends on (+ halos) -- interior ranges, ranges touching either end, ragged rows shorter than the window"""
