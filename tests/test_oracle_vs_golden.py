@@ -303,6 +303,29 @@ def test_torch_port_matches_goldens(golden, weights):
     assert float((wav - torch.from_numpy(golden["codec"]["c24.wav"])).pow(2).mean().sqrt()) < 1e-5
 
 
+@pytest.mark.parametrize("name", ["hot", "k2", "ponly", "konly", "nowarp"])
+def test_torch_port_matches_the_parameter_space_goldens(golden, weights, name):
+    """the CPU baseline's port (oracle/torch_port.py: what bench.py times on the host cores) on the reference's sampling-parameter goldens
+    (generate_params.npz): no top-k / no top-p warper, top_K below min_tokens_to_keep, a wide nucleus at temperature 1, penalties 1 / 1.2 / 1.3"""
+    from oracle import torch_port
+    c = cases.PARAM_CASES[name]
+    ids, mask, tmask = cases.gen_inputs(c)
+    esd = weights["embed"]
+    emb = torch.from_numpy(generate_np.embed_prompt({k: v.numpy() for k, v in esd.items()}, ids, tmask))
+    llama = torch_port.build_llama(weights["gpt"])
+    n = min(16, c["max_new"])
+    got, hid, end_idx = torch_port.generate(llama, esd, emb, torch.from_numpy(ids), torch.from_numpy(mask), temperature=c["temperature"],
+                                            top_P=c["top_P"], top_K=c["top_K"], repetition_penalty=c["rep"], max_new_token=n,
+                                            min_new_token=min(n, c["min_new"]), manual_seed=c["manual_seed"])
+    G = golden["generate_params"]
+    lens = G[name + ".lens"]
+    off = np.concatenate([[0], np.cumsum(lens)])
+    for b in range(ids.shape[0]):
+        want = G[name + ".ids"][off[b]: off[b + 1]][:n]
+        assert np.array_equal(got[b, : len(want)].numpy(), want), b
+        assert int(end_idx[b]) == min(lens[b], n)
+
+
 def test_fp16_pointwise_pairs_stay_inside_the_stated_waveform_bound(weights):
     """Where the perf-mode decoder's bound comes from (`CodecEngine(gemm="f16")`, csrc/codec_gemm.hip gemm_h1p_k): in the torch
     restatement of DVAE decode + Vocos, rounding BOTH operands of every ConvNeXt point-wise layer to fp16 (f32 accumulation) moves
