@@ -101,6 +101,60 @@ def test_generate_baseline_sizes_prefix(golden, np_model, name, k):
         assert np.abs(res.hiddens[b][:n] - G[name + f".hid{b}"][:n]).max() < 2e-4
 
 
+@pytest.mark.parametrize("name", list(cases.REGEN_CASES))
+def test_generate_step0_eos_paths(golden, np_model, name):
+    """generate_regen.npz: a row draws EOS at step 0 (gpt.py:527-570).  Seeded: the oracle stops after that step with nothing to yield, like
+    the reference.  Unseeded: the reference discards the attempt and calls itself again -- the oracle run twice over ONE stream of
+    global-generator draws (the second run starts one [rows, 626] draw further on) gives the reference's final ids, and leaves the generator
+    where the reference left it."""
+    llama, esd, heads = np_model
+    c = cases.REGEN_CASES[name]
+    G = golden["generate_regen"]
+    ids, mask, tmask = cases.gen_inputs(c)
+    emb = generate_np.embed_prompt(esd, ids, tmask)
+    torch.manual_seed(c.get("global_seed", 999))
+    attempts, res = 0, None
+    while True:
+        attempts += 1
+        draws = rng.ExpDraws(ids.shape[0] * 4, 626, c["manual_seed"])
+        res = generate_np.generate(llama, esd, heads, emb, ids, mask, temperature=np.array(c["temperature"], np.float32),
+                                   draw_q=lambda i: draws.step(i).numpy(), top_p=c["top_P"], top_k=c["top_K"], pow_table=_pow(c["rep"]),
+                                   max_new_token=c["max_new"], min_new_token=c["min_new"])
+        if res.ids or c["manual_seed"] is not None:
+            break
+        assert res.steps == 1 and attempts < 4
+    assert attempts == int(G[name + ".attempts"][0])
+    assert np.array_equal(torch.rand(3).numpy(), G[name + ".rand_after"])
+    if not bool(G[name + ".yielded"][0]):
+        assert res.ids == [] and res.steps == 1
+        return
+    assert np.array_equal(np.array([r.shape[0] for r in res.ids]), G[name + ".lens"])
+    assert np.array_equal(np.concatenate(res.ids, 0), G[name + ".ids"])
+
+
+def test_stream_golden_is_consistent_with_the_batch_golden(golden):
+    """generate_stream.npz against generate.npz (two separate runs of the reference): the FINAL yield of every streamed case is the
+    non-streamed result of the same case, and every earlier yield is a per-row prefix of it, cut at min(row length, yield step)"""
+    S, Gn = golden["generate_stream"], golden["generate"]
+    for name, (base, sb) in cases.GEN_STREAM_CASES.items():
+        lens, ids = S[name + ".lens"], S[name + ".ids"]
+        fin_lens = Gn[base + ".lens"]
+        off_f = np.concatenate([[0], np.cumsum(fin_lens)])
+        final_rows = [Gn[base + ".ids"][off_f[b]: off_f[b + 1]] for b in range(len(fin_lens))]
+        assert np.array_equal(lens[-1], fin_lens), name
+        pos = 0
+        for y in range(lens.shape[0]):
+            for b, n in enumerate(lens[y]):
+                assert n <= fin_lens[b] and np.array_equal(ids[pos: pos + n], final_rows[b][:n]), (name, y, b)
+                pos += n
+            if y < lens.shape[0] - 1 or lens.shape[0] == 1:
+                pass
+        assert pos == ids.shape[0]
+        streamed = lens[:-1] if lens.shape[0] > 1 else lens[:0]
+        for y in range(streamed.shape[0]):      # a streamed yield comes after (y + 1) * stream_batch steps with a live row
+            assert streamed[y].max() == (y + 1) * sb, (name, y)
+
+
 def test_generate_max_prefix(np_model):
     """generate_max.npz (the reference's run of the default max_new_token = 2048): the oracle reproduces its first 10 steps (the other
     2038 are the GPU side's)"""
