@@ -67,16 +67,20 @@ def ids_digest(rows) -> str:
     return h.hexdigest()
 
 
-def shard_workload(batch_per_gpu: int, world: int, rank: int, min_len: int, max_len: int):
-    """The global C3 batch (64 utterances per GPU) and this rank's contiguous block of it: prompts, masks, forced lengths,
-    the shard's row range -- shared by main() and the world-size-2 gloo test of the sharding path (tests/test_host.py)."""
+def shard_workload(batch_per_gpu: int, world: int, rank: int, min_len: int, max_len: int, policy: str = "snake"):
+    """The global C3 batch (64 utterances per GPU) and this rank's shard of it: prompts, masks, forced lengths, the GLOBAL indices of its
+    utterances (chattts_amd.dist.deal_shards: sorted by prompt length and dealt in snake order, so every rank gets an equal share of long
+    and short prompts; a world of one is the batch itself) -- shared by main() and the world-size-2 gloo test of the sharding path
+    (tests/test_host.py).  `row_ids` is None when the shard is the contiguous block starting at `row_offset` (world 1)."""
     from chattts_amd import dist as D
     Bg = batch_per_gpu * world
     ids, mask, tmask = synth.make_prompts(Bg, 16, 48, seed=0)
     stop = synth.make_stop_lengths(Bg, min_len, max_len, seed=0)
-    lo, hi = D.shard_bounds(Bg, world, rank)
-    return dict(Bg=Bg, lo=lo, hi=hi, ids=ids[lo:hi], mask=mask[lo:hi], tmask=tmask[lo:hi], stop=stop[lo:hi], stop_all=stop,
-                mask_all=mask, row_offset=lo * GPT.n_vq, total_rows=Bg * GPT.n_vq)
+    sel = D.deal_shards(mask.sum(1).tolist(), world, policy)[rank]
+    contiguous = sel == list(range(sel[0], sel[0] + len(sel))) if sel else True
+    return dict(Bg=Bg, sel=sel, lo=sel[0] if sel else 0, hi=(sel[-1] + 1) if sel else 0, ids=ids[sel], mask=mask[sel], tmask=tmask[sel], stop=stop[sel],
+                stop_all=stop, mask_all=mask, row_offset=(sel[0] * GPT.n_vq) if (sel and contiguous) else 0,
+                row_ids=None if contiguous else np.asarray(sel, np.int64), total_rows=Bg * GPT.n_vq)
 
 
 def decode_step_bytes(es: int, valid_prompt: np.ndarray, stop: np.ndarray, n_steps: int) -> float:
@@ -264,6 +268,81 @@ def config_legs_bf16(gpt, codec, dev) -> dict:
     return out
 
 
+def refine_text_legs(gpt, codec, dev, one_code_step_ms: float) -> dict:
+    """refine-text generation (`Chat._refine_text`, core.py:665-751; gpt.py `infer_text=True` branches :406-407,439-440,477-485,
+    519-525) runs before every default `infer()` call.  Same engine, text embedding, ONE sampling row per utterance over the 21178-way text
+    head (65 MB of float32 per step), block-wide sampler `sample_text_k`.  `RefineTextParams` defaults (core.py:182-193): temperature 0.7,
+    top_P 0.7, top_K 20, repetition_penalty 1.0, max_new_token 384.  Synthetic text prompts of 16-48 tokens, output lengths forced to
+    U{24..96} tokens (random weights never emit [Ebreak] on cue).  Per batch size: wall, ms per decode step (host wall of the graph-replayed
+    loop), and -- eager passes with per-launch events -- the text-head GEMM and the sampler against the HBM roof."""
+    from chattts_amd.core import Chat, InferCodeParams, RefineTextParams
+    chat = Chat()
+    chat.gpt, chat.codec = gpt, codec
+    TEXT_EOS = 21000     # stands in for tokenizer.eos_token; any id works with synthetic weights
+    p = RefineTextParams(manual_seed=42, show_tqdm=False)
+    out = {"params": "RefineTextParams defaults: temperature %.1f, top_P %.1f, top_K %d, repetition_penalty %.1f, max_new_token %d" %
+                     (p.temperature, p.top_P, p.top_K, p.repetition_penalty, p.max_new_token),
+           "dtype": gpt.dtype, "code_mode_decode_ms_per_step_b64": round(one_code_step_ms, 4)}
+    head_bytes = GPT.n_text * GPT.hidden * 4
+    for B in (1, 4, 64):
+        ids, mask, tmask = synth.make_prompts(B, 16, 48, seed=3)
+        stop = torch.from_numpy(synth.make_stop_lengths(B, 24, 96, seed=3))
+        a = (torch.from_numpy(ids), torch.from_numpy(mask), torch.from_numpy(tmask))
+        kw = dict(stop_at=stop)
+
+        def run(**extra):
+            return chat.refine_text_ids(*a, TEXT_EOS, p, **kw, **extra)
+        run()
+        ts = []
+        for _ in range(3):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            o = run()
+            torch.cuda.synchronize(dev)
+            ts.append(time.perf_counter() - t0)
+        assert [int(t.shape[0]) for t in o.ids] == stop.tolist(), "forced refine lengths not honoured"
+        n_steps, dec_ms = gpt.last_stats.get("steps", 0), gpt.last_stats.get("decode_ms", 0.0)
+        step_ms = dec_ms / max(1, n_steps - 1)
+        leg = {"batch": B, "wall_ms": round(1e3 * float(np.median(ts)), 2), "decode_steps": n_steps, "tokens": int(stop.sum()),
+               "decode_ms_per_step": round(step_ms, 4), "tokens_per_s": round(float(stop.sum()) / float(np.median(ts)), 1),
+               "cert_min_margin": gpt.last_stats.get("min_margin"), "cert_exact_rerun_utterances": len(gpt.last_stats.get("exact_rerun_rows", []))}
+        kern = {}
+        for tag, name in ((8, "text_head_gemm"), (9, "sample_text")):
+            run(use_graph=False, profile_tag=tag, profile_stride=1)
+            n_s, tot = gpt.last_stats.get("profile", (0, 0.0))
+            if n_s > 0:
+                us = 1e3 * tot / n_s
+                live = float(np.mean([int((stop.numpy() >= i).sum()) for i in range(1, n_steps)])) if n_steps > 1 else float(B)
+                # text head: the folded [21178, 768] f32 matrix once + the live rows' hidden states in / logits out; sampler: the logits row
+                # + the Exp(1) draws of the KEPT tokens only (q is read for <= top_K + ties tokens)
+                alg = head_bytes + live * (GPT.hidden * 4 * 2 + GPT.n_text * 4) if tag == 8 else live * GPT.n_text * 4
+                kern[name] = {"avg_launch_us": round(us, 2), "launches_timed": int(n_s), "alg_bytes_per_launch": int(alg),
+                              "frac_of_hbm_peak": round(alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+        leg["kernels"] = kern
+        out["b%d" % B] = leg
+    # default-path time to first sample at the C3 geometry: refine-text of the batch, THEN the streamed code generation to its first chunk
+    # (`skip_refine_text=False`, the reference's default; ids level -- no tokenizer assets offline, the refined ids are not re-tokenised)
+    ids, mask, tmask = synth.make_prompts(64, 16, 48, seed=0)
+    a = (torch.from_numpy(ids), torch.from_numpy(mask), torch.from_numpy(tmask))
+    stop_r = torch.from_numpy(synth.make_stop_lengths(64, 24, 96, seed=3))
+    stop_c = torch.from_numpy(synth.make_stop_lengths(64, 128, 512, seed=0))
+    pc = InferCodeParams(max_new_token=int(stop_c.max()) + 1, manual_seed=42, show_tqdm=False)
+    tt, tr = [], []
+    for _ in range(6):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        chat.refine_text_ids(*a, TEXT_EOS, p, stop_at=stop_r)
+        t1 = time.perf_counter()
+        for _chunk in chat.infer_ids_stream(*a, pc, stop_at=stop_c):
+            break
+        tt.append(time.perf_counter() - t0)
+        tr.append(t1 - t0)
+    out["ttfs_default_path_b64"] = {"ttfs_ms_p50": round(1e3 * float(np.median(tt[1:])), 2), "refine_ms_p50": round(1e3 * float(np.median(tr[1:])), 2),
+                                    "what": "refine-text of the 64 utterances (forced lengths U{24..96}) followed by streamed code generation to the first "
+                                            "chunk on the host -- infer(skip_refine_text=False, stream=True) at the ids level"}
+    return out
+
+
 def config_leg_c1(gpt32, codec, dev) -> dict:
     """BASELINE.json configs[0] (C1: one 16-token sentence, near-greedy decode -- the reference's CPU-runnable case) on the f32 parity
     engine; token ids compared bit for bit with the reference's own output (tests/golden/generate.npz `c1.ids`)."""
@@ -370,7 +449,7 @@ def capi_broadcast_check(D, sds, world, rank, dev, dist, timeout_s):
 
 
 def plumbing_only(args, world, rank, local_rank):
-    """--plumbing-only: everything of an N-rank run that is not the GPU -- rendezvous, contiguous shards of the global batch, the ONE broadcast
+    """--plumbing-only: everything of an N-rank run that is not the GPU -- rendezvous, length-balanced shards of the global batch, the ONE broadcast
     of the checkpoint (chattts_amd/dist.py; a 2-layer slice of it, the collective is the same), the gathered rank report -- on whatever
     backend this host has (nccl with GPUs, gloo without).  tests/test_host.py runs `python bench.py --gpus 2 --plumbing-only` here."""
     import torch.distributed as dist
@@ -395,16 +474,17 @@ def plumbing_only(args, world, rank, local_rank):
         got = D.broadcast_state_dicts(sds, src=0, device=dev, meta={k: meta_all[k] for k in ("gpt", "embed")})
         fp = hashlib.sha256(b"".join(got[n][k].cpu().numpy().tobytes() for n in sorted(got) for k in sorted(got[n]))).hexdigest()
         rows = [None] * world
-        dist.all_gather_object(rows, {"rank": rank, "rows": [int(wl["lo"]), int(wl["hi"])], "weights_sha256": fp, "device": str(dev)})
+        dist.all_gather_object(rows, {"rank": rank, "utterances": [int(i) for i in wl["sel"]], "prompt_tokens": int(wl["mask"].sum()),
+                                      "weights_sha256": fp, "device": str(dev)})
         dist.barrier()
     else:
-        rows = [{"rank": 0, "rows": [int(wl["lo"]), int(wl["hi"])], "weights_sha256": None, "device": str(dev)}]
+        rows = [{"rank": 0, "utterances": [int(i) for i in wl["sel"]], "prompt_tokens": int(wl["mask"].sum()), "weights_sha256": None, "device": str(dev)}]
     if rank == 0:
         print(json.dumps({"plumbing_only": True, "metric": None, "value": None, "n_gpus": world, "backend": "nccl" if has_gpu else "gloo",
                           "global_batch": int(wl["Bg"]), "ranks": {"world": world, "shards": rows,
                                                                   "weights_equal_on_all_ranks": len({r["weights_sha256"] for r in rows}) == 1,
-                                                                  "rows_cover_global_batch": rows[0]["rows"][0] == 0 and rows[-1]["rows"][1] == int(wl["Bg"])
-                                                                  and all(a["rows"][1] == b["rows"][0] for a, b in zip(rows, rows[1:]))},
+                                                                  "rows_cover_global_batch": sorted(i for r in rows for i in r["utterances"]) == list(range(int(wl["Bg"]))),
+                                                                  "sharding": "chattts_amd.dist.deal_shards: by prompt length, snake order"},
                           "note": "no engine, no timing: rendezvous + sharding + the one weight broadcast only"}), flush=True)
     if dist is not None:
         dist.destroy_process_group()
@@ -419,12 +499,22 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="utterances per GPU")
     ap.add_argument("--min-len", type=int, default=128)
     ap.add_argument("--max-len", type=int, default=512)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="f32x3", choices=["f32x3", "f32", "bf16"],
+                    help="arithmetic of the HEADLINE leg (`value`, --steps / --warmup).  f32x3 (default): the parity mode -- float32 weights / KV / "
+                         "attention / heads / sampling, decode projections on split-bf16 operands, every call certified by its decision margins "
+                         "with the exact f32 kernels as fallback; token ids == the reference's (sha256 checked on the line).  f32: the same on "
+                         "f32 MFMA throughout.  bf16: the perf mode (not bit-exact; normally reported beside the headline as `value_bf16`)")
+    ap.add_argument("--bf16-steps", type=int, default=5, help="timed passes of the bf16 perf mode reported beside a parity headline")
+    ap.add_argument("--no-bf16-mode", action="store_true", help="skip the bf16 perf-mode legs (value_bf16, its kernels, the queue / pcm16 / slot-pool "
+                    "/ C2 / C5 legs that run on it)")
+    ap.add_argument("--no-refine-text", action="store_true", help="skip the refine-text legs (configs.refine_text)")
+    ap.add_argument("--exact-fallback", action="store_true", help="f32x3: generate the utterances the certificate flags again on the exact f32 "
+                    "kernels inside the timed passes (default: the certificate is reported, the ids are checked against the reference's sha256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-ttfs", action="store_true")
-    ap.add_argument("--no-parity-mode", action="store_true")
+    ap.add_argument("--no-parity-mode", action="store_true", help="skip the secondary legs of the parity headline (exact f32 MFMA passes, queue / pcm16 legs)")
     ap.add_argument("--no-bf16-parity", action="store_true")
     ap.add_argument("--no-capi-broadcast-check", action="store_true", help="skip the check of the weight broadcast's C-ABI entry (ctts_broadcast_weights on "
                     "a communicator made through the C ABI: a probe buffer, compared with what torch.distributed delivered).  By default it runs at "
@@ -438,7 +528,7 @@ def main():
     ap.add_argument("--no-configs", action="store_true", help="skip the BASELINE.json configs[0] / [1] / [4] legs (C1, C2, C5)")
     ap.add_argument("--pipeline", action="store_true", help="time the main leg as a software-pipelined queue of batches (batch i's acoustic decode "
                     "overlaps batch i+1's generation); default: one batch after the other, the pipelined figure is reported beside it")
-    ap.add_argument("--parity-steps", type=int, default=5, help="timed passes of the f32 parity mode")
+    ap.add_argument("--parity-steps", type=int, default=5, help="(with --dtype bf16) timed passes of the f32x3 parity mode reported beside it")
     ap.add_argument("--no-slot-pool", action="store_true", help="skip the continuous-batching leg (serving.SlotPool over 4 batches' worth of requests)")
     ap.add_argument("--codec-gemm", default=None, choices=["f16", "bf16x3", "f32"],
                     help="dense-layer arithmetic of the acoustic decoder in the main leg (default: f16 with --dtype bf16, bf16x3 with f32; "
@@ -513,13 +603,14 @@ def main():
         sds = {n: {k: v.cpu() for k, v in sd.items()} for n, sd in sds.items()}  # the engines repack from host tensors
     else:
         sds = W.synthetic_all()
-    gpt = E.GptEngine(sds["gpt"], sds["embed"], dev, dtype=args.dtype)
-    codec_gemm = args.codec_gemm or ("f16" if args.dtype == "bf16" else "bf16x3")
-    codec_main = codec = E.CodecEngine(sds["decoder"], sds["vocos"], dev, gemm=codec_gemm)   # `codec` is rebound for the parity-mode leg
+    parity = args.dtype != "bf16"      # the headline engine holds the reference's token ids (f32x3: certified per call; f32: exact)
+    gpt = E.GptEngine(sds["gpt"], sds["embed"], dev, dtype=args.dtype, exact_fallback=args.exact_fallback)
+    codec_gemm = args.codec_gemm or ("bf16x3" if parity else "f16")
+    codec = E.CodecEngine(sds["decoder"], sds["vocos"], dev, gemm=codec_gemm)
 
     # ---- workload: global batch sharded in contiguous row blocks ----
     wl = shard_workload(args.batch, world, rank, args.min_len, args.max_len)
-    Bg, lo, hi, stop = wl["Bg"], wl["lo"], wl["hi"], wl["stop_all"]
+    Bg, stop = wl["Bg"], wl["stop_all"]
     ids_t, mask_t, tm_t = torch.from_numpy(wl["ids"]), torch.from_numpy(wl["mask"]), torch.from_numpy(wl["tmask"])
     stop_t = torch.from_numpy(wl["stop"])
     warpers, procs = E.gen_logits(625, 0.7, 20, 1.05)
@@ -527,17 +618,17 @@ def main():
     max_new = int(stop.max()) + 1
     ids_d, mask_d, tm_d = ids_t.to(dev), mask_t, tm_t.to(dev)   # the prompt ids are resident; Embed.forward (a2) runs INSIDE the clock
 
-    def one_pass(eng, use_graph=True, profile_tag=None, decode_audio=True, profile_stride=1, keep_ids=False, teacher=None, keep_hidden=False):
+    def one_pass(eng, cdc, use_graph=True, profile_tag=None, decode_audio=True, profile_stride=1, keep_ids=False, teacher=None, keep_hidden=False):
         """generate -> DVAE -> Vocos -> host numpy (the reference path's last op is `.cpu().numpy()`, core.py:508-510)"""
         out = None
         emb = eng.embed_prompt(ids_d, tm_d)      # a2: Embed.forward (embed.py:52-79)
         for out in eng.generate(emb, ids_d, temp, 625, mask_d, max_new, 0, (*procs, *warpers), return_hidden=True,
-                                manual_seed=42, use_graph=use_graph, stop_at=stop_t, row_offset=wl["row_offset"],
+                                manual_seed=42, use_graph=use_graph, stop_at=stop_t, row_offset=wl["row_offset"], row_ids=wl["row_ids"],
                                 total_rows=wl["total_rows"], profile_tag=profile_tag, profile_stride=profile_stride, lanes=args.lanes,
                                 teacher_ids=teacher, return_sampled=teacher is not None):
             pass
         lens = [int(t.shape[0]) for t in out.ids]
-        wav = codec.to_host(codec.decode_to_wavs(out.hiddens)) if decode_audio else None   # what Chat.decode_to_wavs returns
+        wav = cdc.to_host(cdc.decode_to_wavs(out.hiddens)) if decode_audio else None   # what Chat.decode_to_wavs returns
         if keep_hidden:
             return lens, [h.cpu().numpy() for h in out.hiddens], [t.cpu().numpy() for t in out.ids]
         return lens, wav, ([t.cpu().numpy() for t in out.ids] if keep_ids else None)
@@ -554,30 +645,30 @@ def main():
         out = None
         emb = eng.embed_prompt(ids_d, tm_d)
         for out in eng.generate(emb, ids_d, temp, 625, mask_d, max_new, 0, (*procs, *warpers), return_hidden=True,
-                                manual_seed=42, use_graph=not args.no_graph, stop_at=stop_t, row_offset=wl["row_offset"],
+                                manual_seed=42, use_graph=not args.no_graph, stop_at=stop_t, row_offset=wl["row_offset"], row_ids=wl["row_ids"],
                                 total_rows=wl["total_rows"], lanes=args.lanes):
             pass
         return out
 
-    def timed(eng, steps, warmup, tag=None, pipeline=None):
+    def timed(eng, cdc, steps, warmup, tag=None, pipeline=None):
         """K passes, one batch after the other -- or (pipeline) SOFTWARE-PIPELINED over the queue of batches: the acoustic decode + waveform
         D2H of batch i run on the codec engine's side stream while batch i+1 is generated (CodecEngine.decode_to_wavs_async; every
         batch's float32 waveforms are on the host, as numpy, before the clock stops)."""
         pipeline = args.pipeline if pipeline is None else pipeline
         for _ in range(warmup):
-            one_pass(eng, use_graph=not args.no_graph)
+            one_pass(eng, cdc, use_graph=not args.no_graph)
         if pipeline:     # the side stream's buffers exist before the clock starts
-            codec.decode_to_wavs_async(gpt_pass(eng).hiddens).result()
+            cdc.decode_to_wavs_async(gpt_pass(eng).hiddens).result()
         barrier()
         t0 = time.perf_counter()
         pend, lens, wav = None, None, None
         for _ in range(steps):
             if not pipeline:
-                lens, wav, _ = one_pass(eng, use_graph=not args.no_graph)
+                lens, wav, _ = one_pass(eng, cdc, use_graph=not args.no_graph)
                 continue
             out = gpt_pass(eng)
             lens = [int(t.shape[0]) for t in out.ids]
-            nxt = codec.decode_to_wavs_async(out.hiddens)
+            nxt = cdc.decode_to_wavs_async(out.hiddens)
             if pend is not None:
                 wav = pend.result()
             pend = nxt
@@ -599,20 +690,59 @@ def main():
         assert wav is not None and wav.dtype == np.float32 and bool(np.isfinite(wav).all())
         return dt
 
-    note("timed passes (bf16)" if args.dtype == "bf16" else "timed passes")
-    dt = timed(gpt, args.steps, args.warmup, tag="main")
-    total_audio = audio_seconds(stop) * args.steps  # all ranks, all steps
-    value = total_audio / dt
-    gpt_steps = gpt.last_stats.get("steps", 0)
-    decode_ms = gpt.last_stats.get("decode_ms", 0.0)      # host wall of the decode loop of the LAST timed pass
-    # what the timed passes produced, beyond forced lengths and finite audio: the seeded run is deterministic -- two more passes (graph
-    # replay and eager launches) must give the same token ids bit for bit
-    ids_check = None
-    if not args.no_ids_check:
-        _, _, ids_g = one_pass(gpt, use_graph=not args.no_graph, decode_audio=False, keep_ids=True)
-        _, _, ids_e = one_pass(gpt, use_graph=False, decode_audio=False, keep_ids=True)
-        ids_check = {"ids_sha256": ids_digest(ids_g), "graph_equals_eager": ids_digest(ids_g) == ids_digest(ids_e)}
-        assert ids_check["graph_equals_eager"], "graph replay and eager launches disagree on the sampled token ids"
+    gold, gpath = None, os.path.join(ROOT, "tests", "golden", "bench_c3.npz")
+    if os.path.exists(gpath) and (args.batch, args.min_len, args.max_len) == (64, 128, 512) and world == 1:
+        gold = np.load(gpath)
+    want_sha = str(gold["sha256"]) if gold is not None else None
+
+    KERNELS = {"f32x3": "decode projections on SPLIT-bf16 operands (csrc/decode32x.hip: hi | lo bf16 planes, three bf16 MFMAs per product, f32 "
+                        "accumulation); f32 KV cache, f32 prefill / attention / heads / sampling; every call certified by its decision margins "
+                        "(ctts_gen_state.margin) with the f32 MFMA kernels as the per-utterance fallback",
+               "f32": "f32-input MFMA throughout (csrc/decode32.hip, prefill32.hip: v_mfma_f32_16x16x4_f32), f32 KV cache, f32 attention / heads / sampling",
+               "bf16": "bf16 weights / KV / inter-kernel activations (csrc/decode.hip, prefill.hip), f32 residual stream / accumulation / softmax / sampling"}
+
+    def certificate_of(eng):
+        """the parity certificate of the engine's LAST generate() call (engine.GptEngine.generate)"""
+        ls = eng.last_stats
+        if "min_margin" not in ls:
+            return None
+        return {"min_margin": float("%.3e" % ls["min_margin"]), "bound": float("%.3e" % ls["margin_bound"]),
+                "certified": bool(ls["certified"]), "uncertified_utterances": len(ls.get("uncertified_rows", [])),
+                "exact_rerun_utterances": len(ls.get("exact_rerun_rows", [])), "exact_rerun_steps": ls.get("exact_rerun_steps"),
+                "rel_logit_err_bound": E.GptEngine.REL_ERR_X3, "logit_scale": round(eng.logit_scale[False], 3), "temperature_min": float(temp.min()),
+                "exact_fallback": bool(eng.exact_fallback),
+                "what": "min over every step of every utterance of {log(r_best / r_second) of argmax(p / q); value gap at the top-k / top-p cut; "
+                        "|log(cum / (1 - top_P))| at the cut}, in tempered-logit units, computed inside sample_k; bound = 2 x the stated logit error of "
+                        "the split-bf16 projections (GptEngine.REL_ERR_X3 x the head's logit scale; measured: profiles/r6a_x3_logit_bound.log) / min "
+                        "temperature.  `certified: false` = some draw was closer than the worst-case bound (on 500-step utterances one almost always "
+                        "is: 35-50 of this workload's 85,752 draws); the ids of THIS run are checked against the reference's sha256 all the same "
+                        "(`ids_check`), and --exact-fallback regenerates the flagged utterances on the f32 MFMA kernels inside the timed pass"}
+
+    def mode_leg(eng, cdc, steps, warmup, tag=None):
+        """K timed passes of the workload on one engine + what they produced: graph replay == eager launches, sha256 of all token rows
+        (against the reference's own run of this workload when the golden is here)"""
+        dt_ = timed(eng, cdc, steps, warmup, tag=tag)
+        n_st, dec_ms_ = eng.last_stats.get("steps", 0), eng.last_stats.get("decode_ms", 0.0)
+        leg = {"dtype": eng.dtype, "value": round(audio_seconds(stop) * steps / dt_, 2), "unit": "audio-s/s", "steps": steps, "warmup": warmup,
+               "ms_per_step": round(1000.0 * dt_ / steps, 3), "decode_ms_per_gpt_step": round(dec_ms_ / max(1, n_st - 1), 4),
+               "kernels": KERNELS[eng.dtype] + "; acoustic decoder gemm=" + cdc.gemm}
+        cert = certificate_of(eng)
+        if cert is not None:
+            leg["certificate"] = cert
+        if not args.no_ids_check:
+            _, _, ids_g = one_pass(eng, cdc, use_graph=not args.no_graph, decode_audio=False, keep_ids=True)
+            _, _, ids_e = one_pass(eng, cdc, use_graph=False, decode_audio=False, keep_ids=True)
+            leg["ids_check"] = {"ids_sha256": ids_digest(ids_g), "graph_equals_eager": ids_digest(ids_g) == ids_digest(ids_e)}
+            assert leg["ids_check"]["graph_equals_eager"], "graph replay and eager launches disagree on the sampled token ids"
+            if eng.dtype != "bf16":
+                leg["ids_check"].update({"golden_sha256": want_sha, "ids_match_reference": (ids_digest(ids_g) == want_sha) if want_sha else None,
+                                         "golden": "tests/golden/bench_c3.npz: the reference's GPT.generate on this workload (oracle/make_bench_golden.py)"})
+        return leg, dt_, n_st, dec_ms_
+
+    note("timed passes (%s)" % args.dtype)
+    main_leg, dt, gpt_steps, decode_ms = mode_leg(gpt, codec, args.steps, args.warmup, tag="main")
+    value = audio_seconds(stop) * args.steps / dt      # all ranks, all steps
+    ids_check = main_leg.get("ids_check")
 
     result = {
         "metric": "audio seconds/sec (RTF), batch=64 per GPU", "value": round(value, 2), "unit": "audio-s/s",
@@ -623,6 +753,7 @@ def main():
                                "%s" % (args.min_len, args.max_len,
                                "the K batches are software-pipelined: DVAE + Vocos + D2H of batch i on a side HIP stream while batch i+1 is generated"
                                if args.pipeline else "one batch after the other"),
+                   "arithmetic": KERNELS[args.dtype],
                    "pipelined": bool(args.pipeline),
                    "acoustic_decoder_gemm": codec_gemm + {"f16": ": ConvNeXt point-wise pairs on one fp16 MFMA per product, f32 accumulation "
                                                                  "(waveform vs the f32-class decoder on the same hidden states: `codec_parity`)",
@@ -630,29 +761,33 @@ def main():
                    "global_batch": Bg, "decode_steps_per_pass": gpt_steps, "parallelism": f"dp{world}", "lanes_per_gpu": args.lanes,
                    "tokens_per_pass": int(stop.sum()), "audio_s_per_pass": round(audio_seconds(stop), 2)},
         "ids_check": ids_check,
+        "known_deviations": ["top-p ties straddling the cut: engine and oracle keep lowest-index-first, the reference keeps whatever "
+                             "torch.sort(stable=False) does (DESIGN.md 5; such a tie sets the certificate's margin to 0)"],
     }
-    if world == 1 and not args.pipeline and not args.no_parity_mode:
-        # the same workload as a software-pipelined QUEUE of batches (Chat.infer_ids_pipelined / CodecEngine.decode_to_wavs_async):
-        # reported beside `value`, which stays one-batch-after-the-other
-        note("pipelined queue of batches")
-        dtp = timed(gpt, 4, 0, pipeline=True)
-        result["pipelined_queue"] = {"value": round(audio_seconds(stop) * 4 / dtp, 2), "unit": "audio-s/s", "steps": 4, "ms_per_step": round(1000.0 * dtp / 4, 3),
-                                     "what": "the acoustic decode + waveform D2H of batch i on the codec engine's side HIP stream while batch i+1 is "
-                                             "generated; all waveforms on the host before the clock stops"}
-    if world == 1 and not args.pipeline and not args.no_parity_mode:
-        # the same passes ending in 16-bit PCM instead of float32: float_to_int16 (tools/audio/np.py:7-11, what every caller of the reference
-        # does next) + the silence strip's mask ON THE DEVICE, int16 + 1 bit per sample over PCIe (Chat.decode_to_pcm16).  Beside `value`,
-        # which stays the reference's float32 `.cpu().numpy()`.
-        note("pcm16 output leg")
+    if parity:
+        # `value` IS the parity-holding number: ids sha256 == the reference's own run of this workload, certified per call
+        result["parity_mode"] = dict(main_leg, is_headline=True)
+        result["value_parity_f32"] = result["value"]
+        result["parity_f32_ids_match_reference"] = (ids_check or {}).get("ids_match_reference")
+        result["certificate"] = main_leg.get("certificate")
+
+    def pipelined_leg(eng, cdc):
+        dtp = timed(eng, cdc, 4, 0, pipeline=True)
+        return {"dtype": eng.dtype, "value": round(audio_seconds(stop) * 4 / dtp, 2), "unit": "audio-s/s", "steps": 4, "ms_per_step": round(1000.0 * dtp / 4, 3),
+                "what": "the acoustic decode + waveform D2H of batch i on the codec engine's side HIP stream while batch i+1 is "
+                        "generated; all waveforms on the host before the clock stops"}
+
+    def pcm16_leg(eng, cdc):
         def pcm_pass():
-            emb = gpt.embed_prompt(ids_d, tm_d)
+            emb = eng.embed_prompt(ids_d, tm_d)
             out = None
-            for out in gpt.generate(emb, ids_d, temp, 625, mask_d, max_new, 0, (*procs, *warpers), return_hidden=True, manual_seed=42,
-                                    use_graph=not args.no_graph, stop_at=stop_t, row_offset=wl["row_offset"], total_rows=wl["total_rows"]):
+            for out in eng.generate(emb, ids_d, temp, 625, mask_d, max_new, 0, (*procs, *warpers), return_hidden=True, manual_seed=42,
+                                    use_graph=not args.no_graph, stop_at=stop_t, row_offset=wl["row_offset"], row_ids=wl["row_ids"],
+                                    total_rows=wl["total_rows"]):
                 pass
-            wav = codec.decode_to_wavs(out.hiddens)
-            pcm, keep = codec.float_to_int16(wav, per_row=True, keep_thr=1e-5)
-            return codec.to_host(pcm), codec.to_host(keep), wav
+            wav = cdc.decode_to_wavs(out.hiddens)
+            pcm, keep = cdc.float_to_int16(wav, per_row=True, keep_thr=1e-5)
+            return cdc.to_host(pcm), cdc.to_host(keep), wav
         pcm_pass()
         barrier()
         t0 = time.perf_counter()
@@ -662,21 +797,20 @@ def main():
         dtq = time.perf_counter() - t0
         from chattts_amd import audio as _audio
         w0 = wav_d[0].cpu().numpy()
-        result["pcm16_output"] = {"value": round(audio_seconds(stop) * 3 / dtq, 2), "unit": "audio-s/s", "steps": 3, "ms_per_step": round(1000.0 * dtq / 3, 3),
-                                  "d2h_bytes_per_pass": int(pcm_h.nbytes + keep_h.nbytes), "d2h_bytes_float32_path": int(pcm_h.size * 4),
-                                  "row0_equals_host_float_to_int16": bool(np.array_equal(pcm_h[0], _audio.float_to_int16(w0))),
-                                  "what": "generate + DVAE + Vocos + float_to_int16 (per utterance) + silence-strip mask on the device, int16 + mask to the host"}
-        del pcm_h, keep_h, wav_d
-    if world == 1 and not args.pipeline and not args.no_slot_pool and args.dtype == "bf16":
+        return {"dtype": eng.dtype, "value": round(audio_seconds(stop) * 3 / dtq, 2), "unit": "audio-s/s", "steps": 3, "ms_per_step": round(1000.0 * dtq / 3, 3),
+                "d2h_bytes_per_pass": int(pcm_h.nbytes + keep_h.nbytes), "d2h_bytes_float32_path": int(pcm_h.size * 4),
+                "row0_equals_host_float_to_int16": bool(np.array_equal(pcm_h[0], _audio.float_to_int16(w0))),
+                "what": "generate + DVAE + Vocos + float_to_int16 (per utterance) + silence-strip mask on the device, int16 + mask to the host"}
+
+    def slot_pool_leg(eng, cdc):
         # the same utterances as a QUEUE served by continuous batching (chattts_amd/serving.py): 4 batches' worth of
         # requests through a pool of `batch` slots -- a request is admitted the moment a slot frees up, so the decode step stays full
         # instead of thinning out towards the longest row of a fixed batch; finished requests are decoded to audio in groups of
-        # `batch` on the codec engine's side stream.  Reported beside `value`; every request's tokens are those of its isolated
-        # generation at its pool row (tests/test_gpu_e2e.py::test_continuous_batching_equals_isolated_generation).
-        note("continuous batching over a slot pool")
+        # `batch` on the codec engine's side stream.  Every request's tokens are those of its isolated generation at its pool row
+        # (tests/test_gpu_e2e.py::test_continuous_batching_equals_isolated_generation).
         from chattts_amd.serving import SlotPool
         nq = 4
-        pool = SlotPool(gpt, slots=args.batch, cap=48 + args.max_len + 2 + 2 * SlotPool.POLL, hid_cap=args.max_len + 8, manual_seed=42)
+        pool = SlotPool(eng, slots=args.batch, cap=48 + args.max_len + 2 + 2 * SlotPool.POLL, hid_cap=args.max_len + 8, manual_seed=42)
 
         def pool_pass():
             for k in range(nq):
@@ -689,10 +823,10 @@ def main():
                 n_tok += int(ids_r.shape[0])
                 done.append(hid_r)
                 if len(done) == args.batch:
-                    pend.append(codec.decode_to_wavs_async(done))
+                    pend.append(cdc.decode_to_wavs_async(done))
                     done = []
             if done:
-                pend.append(codec.decode_to_wavs_async(done))
+                pend.append(cdc.decode_to_wavs_async(done))
             wavs = [p_.result() for p_ in pend]
             assert all(w.dtype == np.float32 and bool(np.isfinite(w).all()) for w in wavs)
             return n_tok
@@ -703,23 +837,23 @@ def main():
         n_tok = pool_pass()
         torch.cuda.synchronize(dev)
         dts = time.perf_counter() - t0
-        result["continuous_batching_queue"] = {
-            "value": round(audio_seconds(stop) * nq / dts, 2), "unit": "audio-s/s", "requests": nq * int(ids_t.shape[0]), "slots": args.batch,
-            "wall_ms": round(1e3 * dts, 2), "decode_steps": pool.steps - steps0, "tokens": n_tok,
-            "tokens_per_decode_step": round(n_tok / max(1, pool.steps - steps0), 2), "prefill_groups": pool.admissions - adm0,
-            "what": "serving.SlotPool: %d requests (the C3 utterances x %d) through %d slots, admission every %d decode steps, audio of every "
-                    "group of %d finished requests decoded on the side stream; all waveforms on the host before the clock stops" %
-                    (nq * int(ids_t.shape[0]), nq, args.batch, SlotPool.POLL, args.batch)}
+        leg = {"dtype": eng.dtype, "value": round(audio_seconds(stop) * nq / dts, 2), "unit": "audio-s/s", "requests": nq * int(ids_t.shape[0]),
+               "slots": args.batch, "wall_ms": round(1e3 * dts, 2), "decode_steps": pool.steps - steps0, "tokens": n_tok,
+               "tokens_per_decode_step": round(n_tok / max(1, pool.steps - steps0), 2), "prefill_groups": pool.admissions - adm0,
+               "what": "serving.SlotPool: %d requests (the C3 utterances x %d) through %d slots, admission every %d decode steps, audio of every "
+                       "group of %d finished requests decoded on the side stream; all waveforms on the host before the clock stops" %
+                       (nq * int(ids_t.shape[0]), nq, args.batch, SlotPool.POLL, args.batch)}
         pool.close()
         del pool
         torch.cuda.empty_cache()
+        return leg
+
     if dist is not None:   # self-diagnosing multi-GPU line (also under torchrun with one rank): who was slow, what the one collective cost
         rt = rank_times.get("main", [])
         result["ranks"] = {"world": world, "pass_ms_per_rank": rt, "pass_ms_min": min(rt) if rt else None, "pass_ms_max": max(rt) if rt else None,
                            "weight_broadcast": bcast,
                            "data_path_collectives": "none (utterances are independent; only the timing barrier / max-over-ranks all-reduce)"}
 
-    es = 2 if args.dtype == "bf16" else 4
     valid_prompt = wl["mask"].sum(1).astype(np.int64)
     st_ = wl["stop"].astype(np.int64)
 
@@ -735,14 +869,14 @@ def main():
                 5: 2 * 3072 * 768 * es_ + live * (768 + 3072) * es_, 6: 768 * 3072 * es_ + live * (3072 * es_ + 768 * (8 + es_)),
                 8: 2504 * 768 * 4 + live * (768 * 4 * 2 + 2504 * 4), 9: live * 4 * 626 * 8, 0: live * (4 * 3072 + 3072 + 1536), 7: live * 768 * 12}
 
-    def roofline_leg(eng, es_, tags, n_steps, step_ms, pmc_key_suffix=""):
+    def roofline_leg(eng, cdc, es_, tags, n_steps, step_ms, pmc_key_suffix=""):
         """HIP start/stop events of sampled launches (hipExtLaunchKernel, on the launch stream; events created without the
         system-scope fence, so the dispatch timestamps are the ones rocprofv3's kernel trace reads) in EAGER passes of the SAME
         workload: every 5th launch of the tag over all decode steps."""
         per_tag, att_samples = {}, (None, 1)
         for tag in tags:
             calls = GPT.n_layers if tag in (1, 3, 4, 5, 6) else 1
-            one_pass(eng, use_graph=False, profile_tag=tag, profile_stride=1 if calls == 1 else 5, decode_audio=False)
+            one_pass(eng, cdc, use_graph=False, profile_tag=tag, profile_stride=1 if calls == 1 else 5, decode_audio=False)
             per_tag[tag] = eng.last_stats.get("profile", (0, 0.0))
             if tag == 3:
                 att_samples = (eng.last_stats.get("profile_samples_ms"), 1 if calls == 1 else 5)
@@ -765,7 +899,7 @@ def main():
                 tsrc = "profiles/pmc_traffic.json: builder-collected rocprofv3 --pmc passes of this command, not measured in this run"
         except OSError:
             pass
-        roof = {"kernel": TAGS[dom], "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        roof = {"kernel": TAGS[dom], "dtype": eng.dtype, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
                 "avg_launch_us": round(avg_us[dom], 2), "launches_timed": per_tag[dom][0], "alg_bytes_per_launch": int(alg[dom]),
                 "clock": "HIP start/stop events of the dispatch (hipExtLaunchKernel, no system-scope fence), every 5th launch of the "
@@ -798,135 +932,158 @@ def main():
             "frac": round(step_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if step_ms > 0 else None,
             "note": "weights + KV of live rows + logits/draws per step (SURVEY 8d) / host wall of the graph-replayed decode loop of the "
                     "last timed pass (finish polls included)"}
-        return roof, kernels
-
-    gold, gpath = None, os.path.join(ROOT, "tests", "golden", "bench_c3.npz")
-    if os.path.exists(gpath) and (args.batch, args.min_len, args.max_len) == (64, 128, 512) and world == 1:
-        gold = np.load(gpath)
-
-    # ---- the parity mode (f32: token ids bit-exact vs the reference) on the same workload, same invocation: timed like the main
-    #      leg, its own roofline entry, and the reference it gives the bf16 mode's distance measurement ----
-    hid32 = None
-    if world == 1 and args.dtype == "bf16" and not args.no_parity_mode:
-        note("parity mode (f32): %d timed passes" % args.parity_steps)
-        gpt32 = E.GptEngine(sds["gpt"], sds["embed"], dev, dtype="f32")
-        if codec_gemm != "bf16x3":      # the parity mode decodes with the f32-class decoder
-            codec = E.CodecEngine(sds["decoder"], sds["vocos"], dev, gemm="bf16x3")
-        dt32 = timed(gpt32, args.parity_steps, 1)
-        steps32, dec32_ms = gpt32.last_stats.get("steps", 0), gpt32.last_stats.get("decode_ms", 0.0)
-        _, hid32, rows = one_pass(gpt32, keep_hidden=True, decode_audio=False)
-        got = ids_digest(rows)
-        want = str(gold["sha256"]) if gold is not None else None
-        result["parity_mode"] = {"dtype": "f32", "value": round(audio_seconds(stop) * args.parity_steps / dt32, 2), "unit": "audio-s/s",
-                                 "steps": args.parity_steps, "warmup": 1, "ms_per_step": round(1000.0 * dt32 / args.parity_steps, 3),
-                                 "decode_ms_per_gpt_step": round(dec32_ms / max(1, steps32 - 1), 4),
-                                 "kernels": ("decode projections on SPLIT-bf16 operands (csrc/decode32x.hip: hi | lo bf16 planes, three bf16 MFMAs per "
-                                             "product, f32 accumulation; f32 KV cache, f32 attention, f32 heads + sampling)" if gpt32.x3 is not None else
-                                             "decode projections on fragment-packed f32 operands (csrc/decode32.hip), operation order of the row-major "
-                                             "f32 kernels kept bit for bit") + "; acoustic decoder gemm=bf16x3 (4e-7 RMS from the f32 oracle)",
-                                 "ids_sha256": got, "golden_sha256": want,
-                                 "ids_match_reference": (got == want) if want else None,
-                                 "golden": "tests/golden/bench_c3.npz: the reference's GPT.generate on this workload (oracle/make_bench_golden.py)"}
-        result["value_parity_f32"] = result["parity_mode"]["value"]          # the number that meets north_star's bit-exactness
-        result["parity_f32_ids_match_reference"] = result["parity_mode"]["ids_match_reference"]
-        if gpt32.x3 is not None:
-            # ... and the same leg on the f32 MFMA kernels (CTTS_D32_EXACT=1, the fallback the split-bf16 decode step is measured against)
-            note("parity mode, f32 MFMA projections (CTTS_D32_EXACT=1): 2 timed passes")
-            os.environ["CTTS_D32_EXACT"] = "1"
-            try:
-                gpt32e = E.GptEngine(sds["gpt"], sds["embed"], dev, dtype="f32")
-            finally:
-                os.environ.pop("CTTS_D32_EXACT", None)
-            dte = timed(gpt32e, 2, 1)
-            stepse, dece_ms = gpt32e.last_stats.get("steps", 0), gpt32e.last_stats.get("decode_ms", 0.0)
-            _, _, rows_e = one_pass(gpt32e, decode_audio=False, keep_ids=True)
-            result["parity_mode"]["exact_f32_mfma"] = {"value": round(audio_seconds(stop) * 2 / dte, 2), "unit": "audio-s/s", "steps": 2,
-                                                       "ms_per_step": round(1000.0 * dte / 2, 3),
-                                                       "decode_ms_per_gpt_step": round(dece_ms / max(1, stepse - 1), 4),
-                                                       "ids_match_reference": (ids_digest(rows_e) == want) if want else None,
-                                                       "kernels": "csrc/decode32.hip (v_mfma_f32_16x16x4_f32), CTTS_D32_EXACT=1"}
-            del gpt32e
-            torch.cuda.empty_cache()
-        if not args.no_roofline:
-            roof32, k32 = roofline_leg(gpt32, 4, (3,), steps32, dec32_ms / max(1, steps32 - 1), pmc_key_suffix="_f32")
-            result["parity_mode"]["roofline"] = roof32
-        if not args.no_configs:
-            note("config C1 (f32 parity engine)")
-            result.setdefault("configs", {})["C1"] = config_leg_c1(gpt32, codec, dev)
-        if codec is not codec_main:
-            # the perf mode's decoder (one fp16 MFMA per product) against the parity mode's on the SAME hidden states: this pass's 64 rows
-            hs = [torch.from_numpy(h).to(dev) for h in hid32]
-            w_ref = codec.decode_to_wavs(hs).cpu().numpy()
-            w_main = codec_main.decode_to_wavs(hs).cpu().numpy()
-            d = (w_main.astype(np.float64) - w_ref.astype(np.float64))
-            result["codec_parity"] = {"gemm": codec_gemm, "against": "gemm=bf16x3 on the same hidden states (the f32 engine's, all %d rows)" % len(hs),
-                                      "wav_rms_diff": float(np.sqrt(np.mean(d ** 2))), "wav_max_abs_diff": float(np.abs(d).max()),
-                                      "wav_rms": float(np.sqrt(np.mean(w_ref.astype(np.float64) ** 2))), "bar": 1e-4,
-                                      "what": "north_star: float32 waveform within 1e-4 RMS; tests/test_gpu_e2e.py states 2e-5 for this mode"}
-            del hs, w_ref, w_main, d
-            codec = codec_main
-        del gpt32
-        torch.cuda.empty_cache()
-
-    # ---- bf16 (the mode `value` is quoted in) vs f32 (pinned to the reference), both TEACHER-FORCED on the reference's own token
-    #      stream of this workload: all 64 rows, all ~508 steps (gpt.py:497-508: free running, one flipped argmax diverges the suffix,
-    #      so agreement is measured per step under the reference's history) ----
-    if gold is not None and hid32 is not None and not args.no_bf16_parity:
-        note("bf16 parity leg (teacher-forced on the reference's token stream)")
-        lens_g, rows_g, teacher = teacher_from_golden(gold, max_new)
-        _, hid16, ids16 = one_pass(gpt, keep_hidden=True, decode_audio=False, teacher=torch.from_numpy(teacher))
-        assert all(np.array_equal(a, b) for a, b in zip(ids16, rows_g)), "the forced stream was not followed"
-        samp16 = [t.cpu().numpy() for t in gpt.last_sampled]
-        heads = generate_heads(sds["embed"])
-        pm = parity_metrics(hid16, hid32, samp16, rows_g, heads)
-        pm.update({"mode": "bf16 vs f32 engine, both on the reference's golden ids (tests/golden/bench_c3.npz)",
-                   "rows": len(rows_g), "steps_max": int(lens_g.max()),
-                   "f32_is_the_reference_stream": result["parity_mode"]["ids_match_reference"],
-                   "what": "hidden = final-norm output of every step (the DVAE's input); dlogit = |(h16 - h32) @ heads^T| (logit std ~4); "
-                           "token_agreement = the bf16 sampler's own draw (same Exp(1) tensor, same history) == the reference's token"})
-        result["bf16_parity"] = pm
-        del hid16, samp16
-    hid32 = None
-
-    # ---- roofline: the dominant decode kernel + the whole decode step against the HBM roof; MFMA-side entries ----
-    if rank == 0 and not args.no_roofline:
-        note("roofline leg (eager passes with per-launch events)")
-        tags = (0, 1, 3, 4, 5, 6, 7, 8, 9) if world == 1 else (3,)   # N > 1: the other ranks wait for rank 0 here -- attention only
-        roof, kernels = roofline_leg(gpt, es, tags, gpt_steps, decode_ms / max(1, gpt_steps - 1))
-        result["roofline"] = roof
-        result["decode_kernels"] = kernels
         ksum = sum(v["avg_launch_us"] * v["launches_per_step"] for v in kernels.values())
         roof["whole_decode_step"]["sum_kernel_us_per_step"] = round(ksum, 1)
         roof["whole_decode_step"]["sum_kernel_note"] = ("sum over the step's launches of the per-launch event durations (eager passes); it may exceed "
                                                         "ms_per_step (graph replay, host wall): per-launch durations overlap their neighbours' "
                                                         "dispatch, so every per-kernel frac is an upper bound and only the whole-step frac is wall-anchored")
+        return roof, kernels
+
+    ALL_TAGS = (0, 1, 3, 4, 5, 6, 7, 8, 9)
+    es_of = lambda e: 2 if e.dtype == "bf16" else 4
+    pmc_of = lambda e: "" if e.dtype == "bf16" else "_f32"
+
+    # ---- roofline of the HEADLINE mode: the dominant decode kernel + the whole decode step against the HBM roof; MFMA-side entries ----
+    if rank == 0 and not args.no_roofline:
+        note("roofline leg (eager passes with per-launch events)")
+        tags = ALL_TAGS if world == 1 else (3,)   # N > 1: the other ranks wait for rank 0 here -- attention only
+        roof, kernels = roofline_leg(gpt, codec, es_of(gpt), tags, gpt_steps, decode_ms / max(1, gpt_steps - 1), pmc_key_suffix=pmc_of(gpt))
+        result["roofline"] = roof
+        result["decode_kernels"] = kernels
         if world == 1:
             result["roofline_mfma"] = mfma_rooflines(dev)
 
-    # ---- BASELINE.json configs[1] and [4] on the same engines (configs[0] ran on the f32 engine above; [3] is this file under torchrun) ----
-    if rank == 0 and world == 1 and args.dtype == "bf16" and not args.no_configs:
-        note("configs C2 (batch 1) and C5 (streaming)")
-        result.setdefault("configs", {}).update(config_legs_bf16(gpt, codec, dev))
-        result["configs"]["C3"] = "this line's `value` (bf16) and `value_parity_f32`"
-        result["configs"]["C4"] = "bench.py --gpus N under torch.distributed.run: batch 64 x N sharded, ONE RCCL weight broadcast (`ranks`)"
+    # ---- secondary legs of a parity headline, same invocation ----
+    hid32 = None
+    if world == 1 and parity and not args.pipeline and not args.no_parity_mode:
+        note("pipelined queue of batches / pcm16 output (%s)" % args.dtype)
+        result["pipelined_queue"] = pipelined_leg(gpt, codec)
+        # the same passes ending in 16-bit PCM instead of float32: float_to_int16 (tools/audio/np.py:7-11, what every caller of the reference
+        # does next) + the silence strip's mask ON THE DEVICE, int16 + 1 bit per sample over PCIe (Chat.decode_to_pcm16)
+        result["pcm16_output"] = pcm16_leg(gpt, codec)
+        if args.dtype == "f32x3":
+            # the same leg on the f32 MFMA kernels throughout (dtype "f32": what the certificate's fallback runs, and what the split-bf16
+            # decode step is measured against)
+            note("parity mode, f32 MFMA projections (dtype f32): 2 timed passes")
+            gpt32e = E.GptEngine(sds["gpt"], sds["embed"], dev, dtype="f32")
+            dte = timed(gpt32e, codec, 2, 1)
+            stepse, dece_ms = gpt32e.last_stats.get("steps", 0), gpt32e.last_stats.get("decode_ms", 0.0)
+            _, _, rows_e = one_pass(gpt32e, codec, decode_audio=False, keep_ids=True)
+            result["parity_mode"]["exact_f32_mfma"] = {"dtype": "f32", "value": round(audio_seconds(stop) * 2 / dte, 2), "unit": "audio-s/s", "steps": 2,
+                                                       "ms_per_step": round(1000.0 * dte / 2, 3),
+                                                       "decode_ms_per_gpt_step": round(dece_ms / max(1, stepse - 1), 4),
+                                                       "ids_match_reference": (ids_digest(rows_e) == want_sha) if want_sha else None,
+                                                       "kernels": KERNELS["f32"]}
+            del gpt32e
+            torch.cuda.empty_cache()
+        if not args.no_configs:
+            note("config C1 (parity engine)")
+            result.setdefault("configs", {})["C1"] = config_leg_c1(gpt, codec, dev)
+    if world == 1 and parity and gold is not None and not args.no_bf16_mode and not args.no_bf16_parity:
+        _, hid32, _ = one_pass(gpt, codec, keep_hidden=True, decode_audio=False)      # (== the golden stream: the reference for the bf16 distance)
 
-    # ---- time to first sample: stream=True with the reference's yield schedule (first audio after 3 x 24 tokens) ----
-    if rank == 0 and world == 1 and not args.no_ttfs:
-        note("time to first sample")
+    # ---- time to first sample (headline engine): stream=True with the reference's yield schedule (first audio after 3 x 24 tokens) ----
+    def ttfs_leg(eng, cdc, n=21):
         from chattts_amd.core import Chat, InferCodeParams
         chat = Chat()
-        chat.gpt, chat.codec = gpt, codec
+        chat.gpt, chat.codec = eng, cdc
         params = InferCodeParams(max_new_token=max_new, manual_seed=42, show_tqdm=False)
         ttfs = []
-        for _ in range(21):
+        for _ in range(n):
             torch.cuda.synchronize(dev)
             t1 = time.perf_counter()
             for chunk in chat.infer_ids_stream(ids_t, mask_t, tm_t, params, stop_at=stop_t, row_offset=wl["row_offset"],
                                                total_rows=wl["total_rows"]):
                 ttfs.append(time.perf_counter() - t1)   # chunk is a host numpy array: audio is on the host here
                 break
-        result["ttfs_ms_p50"] = round(1000.0 * float(np.median(ttfs[1:])), 2)
-        result["ttfs_samples"] = len(ttfs) - 1
+        return round(1000.0 * float(np.median(ttfs[1:])), 2), len(ttfs) - 1
+
+    if rank == 0 and world == 1 and not args.no_ttfs:
+        note("time to first sample (%s)" % args.dtype)
+        result["ttfs_ms_p50"], result["ttfs_samples"] = ttfs_leg(gpt, codec)
+        result["ttfs_dtype"] = args.dtype
+
+    # ---- refine-text (runs before every default infer() call) on the headline engine ----
+    if rank == 0 and world == 1 and not args.no_refine_text:
+        note("refine-text legs")
+        result.setdefault("configs", {})["refine_text"] = refine_text_legs(gpt, codec, dev, one_code_step_ms=decode_ms / max(1, gpt_steps - 1))
+
+    # ---- the bf16 perf mode beside a parity headline (or the parity mode beside a bf16 headline) ----
+    if world == 1 and parity and not args.no_bf16_mode and not args.pipeline:
+        note("bf16 perf mode: %d timed passes" % args.bf16_steps)
+        gpt16 = E.GptEngine(sds["gpt"], sds["embed"], dev, dtype="bf16")
+        codec16 = E.CodecEngine(sds["decoder"], sds["vocos"], dev, gemm="f16")
+        leg16, dt16, steps16, dec16_ms = mode_leg(gpt16, codec16, args.bf16_steps, 1)
+        leg16["not_bit_exact"] = ("narrower arithmetic than the reference's float32: free-running token ids differ from the reference's; see "
+                                  "`bf16_parity` (teacher-forced token agreement) -- by the tier's rule this number carries no parity claim")
+        result["bf16_mode"] = leg16
+        result["value_bf16"] = leg16["value"]
+        if hid32 is not None:
+            note("bf16 parity leg (teacher-forced on the reference's token stream)")
+            lens_g, rows_g, teacher = teacher_from_golden(gold, max_new)
+            _, hid16, ids16 = one_pass(gpt16, codec16, keep_hidden=True, decode_audio=False, teacher=torch.from_numpy(teacher))
+            assert all(np.array_equal(a, b) for a, b in zip(ids16, rows_g)), "the forced stream was not followed"
+            samp16 = [t.cpu().numpy() for t in gpt16.last_sampled]
+            pm = parity_metrics(hid16, hid32, samp16, rows_g, generate_heads(sds["embed"]))
+            pm.update({"mode": "bf16 vs the parity engine, both on the reference's golden ids (tests/golden/bench_c3.npz)",
+                       "rows": len(rows_g), "steps_max": int(lens_g.max()),
+                       "f32_is_the_reference_stream": result.get("parity_f32_ids_match_reference"),
+                       "what": "hidden = final-norm output of every step (the DVAE's input); dlogit = |(h16 - h32) @ heads^T| (logit std ~4); "
+                               "token_agreement = the bf16 sampler's own draw (same Exp(1) tensor, same history) == the reference's token"})
+            result["bf16_parity"] = pm
+            result["bf16_mode"]["token_agreement"] = pm.get("token_agreement")
+            # the perf mode's decoder (one fp16 MFMA per product) against the parity mode's on the SAME hidden states: this pass's 64 rows
+            hs = [torch.from_numpy(h).to(dev) for h in hid32]
+            w_ref = codec.decode_to_wavs(hs).cpu().numpy()
+            w_main = codec16.decode_to_wavs(hs).cpu().numpy()
+            d = (w_main.astype(np.float64) - w_ref.astype(np.float64))
+            result["codec_parity"] = {"gemm": "f16", "against": "gemm=%s on the same hidden states (the parity engine's, all %d rows)" % (codec_gemm, len(hs)),
+                                      "wav_rms_diff": float(np.sqrt(np.mean(d ** 2))), "wav_max_abs_diff": float(np.abs(d).max()),
+                                      "wav_rms": float(np.sqrt(np.mean(w_ref.astype(np.float64) ** 2))), "bar": 1e-4,
+                                      "what": "north_star: float32 waveform within 1e-4 RMS GIVEN EQUAL HIDDEN STATES; tests/test_gpu_e2e.py states 2e-5 for "
+                                              "this decoder.  End to end the bf16 mode samples other tokens (`bf16_parity`), so its waveforms are "
+                                              "different audio, not the reference's within 1e-4"}
+            del hs, w_ref, w_main, d, hid16, samp16
+        hid32 = None
+        if not args.no_roofline:
+            note("bf16 roofline leg")
+            roof16, k16 = roofline_leg(gpt16, codec16, 2, ALL_TAGS, steps16, dec16_ms / max(1, steps16 - 1))
+            result["bf16_mode"]["roofline"] = roof16
+            result["bf16_mode"]["decode_kernels"] = k16
+        if not args.no_parity_mode:
+            result["bf16_mode"]["pipelined_queue"] = pipelined_leg(gpt16, codec16)
+        if not args.no_slot_pool:
+            note("continuous batching over a slot pool (bf16)")
+            result["continuous_batching_queue"] = slot_pool_leg(gpt16, codec16)
+        if not args.no_configs:
+            note("configs C2 (batch 1) and C5 (streaming) (bf16)")
+            result.setdefault("configs", {}).update(config_legs_bf16(gpt16, codec16, dev))
+            result["configs"]["C3"] = "this line's `value` (parity mode) and `value_bf16`"
+            result["configs"]["C4"] = "bench.py --gpus N under torch.distributed.run: batch 64 x N sharded, ONE RCCL weight broadcast (`ranks`)"
+        if not args.no_ttfs:
+            result["ttfs_ms_p50_bf16"], _ = ttfs_leg(gpt16, codec16)
+        del gpt16, codec16
+        torch.cuda.empty_cache()
+    elif world == 1 and not parity and not args.pipeline:
+        # legacy layout (--dtype bf16): bf16 headline, the parity mode beside it
+        if not args.no_parity_mode:
+            result["pipelined_queue"] = pipelined_leg(gpt, codec)
+            result["pcm16_output"] = pcm16_leg(gpt, codec)
+            note("parity mode (f32x3): %d timed passes" % args.parity_steps)
+            gpt32 = E.GptEngine(sds["gpt"], sds["embed"], dev, dtype="f32x3")
+            codec32 = E.CodecEngine(sds["decoder"], sds["vocos"], dev, gemm="bf16x3")
+            leg32, _, _, _ = mode_leg(gpt32, codec32, args.parity_steps, 1)
+            result["parity_mode"] = leg32
+            result["value_parity_f32"] = leg32["value"]
+            result["parity_f32_ids_match_reference"] = (leg32.get("ids_check") or {}).get("ids_match_reference")
+            del gpt32, codec32
+            torch.cuda.empty_cache()
+        if not args.no_slot_pool:
+            result["continuous_batching_queue"] = slot_pool_leg(gpt, codec)
+        if not args.no_configs:
+            result.setdefault("configs", {}).update(config_legs_bf16(gpt, codec, dev))
+
+    if rank == 0 and world == 1 and not args.no_ttfs:
         # what `ttfs_ms_p50` hides: the FIRST request of a process (session allocation, graph capture + instantiation, first replays,
         # code objects, decoder workspace, pinned buffers) -- a fresh process each, with and without Chat.load(..., warm=...)
         note("cold start (two fresh processes)")
@@ -936,7 +1093,7 @@ def main():
 
     # ---- same-box CPU baseline: torch/MKL restatement on the reference's own stack (HF LlamaModel + DynamicCache) ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        note("cpu baseline (separate process, hard 150 s limit)")
+        note("cpu baseline (separate process, hard 200 s limit)")
         result["cpu_baseline"] = cpu_baseline_guarded(args)
 
     if rank == 0:
@@ -1003,7 +1160,7 @@ def cold_start_guarded(args, mode: str, limit_s: float = 240.0):
         return {"first_chunk_ms": None, "error": f"cold-start child exceeded {limit_s:.0f} s and was stopped"}
 
 
-def cpu_baseline_guarded(args, limit_s: float = 150.0):
+def cpu_baseline_guarded(args, limit_s: float = 200.0):
     """The CPU leg runs in its OWN process under a hard wall-clock limit: whatever the host does with 256 torch threads, the
     GPU numbers of this run are printed.  The child rebuilds the (seeded, fingerprinted) synthetic weights itself."""
     import subprocess
@@ -1023,19 +1180,19 @@ def cpu_baseline_guarded(args, limit_s: float = 150.0):
         return {"value": None, "error": f"cpu baseline child exceeded {limit_s:.0f} s and was stopped"}
 
 
-def cpu_baseline(sds, ids, mask, tmask, stop, n_steps: int = 33, codec_rows: int = 4, codec_T: int = 128, budget_s: float = 40.0):
+def cpu_baseline(sds, ids, mask, tmask, stop, budget_s: float = 140.0, codec_group: int = 8):
     """oracle/torch_port.py timed on this box's host cores: the reference's own stack restated -- transformers'
     `LlamaModel` + `DynamicCache` + TopP/TopK warpers, torch.multinomial on the re-seeded CPU generator, DVAE and Vocos
     as torch conv1d / layer_norm / linear / istft -- float32 under torch/MKL.
 
-    Bounded sample, extrapolated to the bench workload: the batch-64 prefill and up to `n_steps` - 1 decode steps are timed
-    step by step; the reference steps ALL rows until the longest one is done (gpt.py:592), so its wall time for this
-    workload is  prefill + (max(stop)) decode steps  -- taken at the sampled per-step time, i.e. at contexts <= 48 + n_steps
-    keys although the bench's contexts reach 560 (this favours the CPU) -- plus DVAE + Vocos per generated token, measured
-    on a [codec_rows, codec_T]-token slice.  value = audio seconds of the workload / that wall time.
-    Thread count: a 3-step calibration at {32, 64, all hardware threads if <= 96} (BASELINE.md asks for all; measured on this
-    pool's 256-thread host, all threads are 40x SLOWER than 32), the one with the fastest decode step runs the sample.  Every
-    leg carries a wall-clock deadline so that a slow host shortens the sample instead of stalling the bench."""
+    NOT a 32-step sample any more: the WHOLE workload is run as the reference would run it -- the batch-64 prefill and
+    then every decode step with all 64 rows until the longest row is done (gpt.py:592: finished rows keep stepping), at the workload's real,
+    growing contexts -- then DVAE + Vocos over the batch zero-padded to the longest row (core.py:525-533), in groups of `codec_group` rows.
+    Everything is under a wall-clock deadline: if the host is too slow for the budget the MEASURED FRACTION is stated (`gpt_steps_measured`
+    of `gpt_steps_total`, `codec_rows_measured`) and only the remainder is extrapolated, at the rate of the LAST measured steps (contexts
+    only grow, so this favours the CPU).  value = audio seconds of the workload / that wall time.
+    Thread count: a 3-step calibration at {32, 64, the CPU quota, all hardware threads if <= 96} (BASELINE.md asks for all; measured on this
+    pool's 256-thread host, all threads are 40x SLOWER than 32), the one with the fastest decode step runs the workload."""
     from oracle import generate_np, torch_port
 
     cores = os.cpu_count() or 1
@@ -1047,48 +1204,83 @@ def cpu_baseline(sds, ids, mask, tmask, stop, n_steps: int = 33, codec_rows: int
     keep = torch.get_num_threads()
     calib = {}
     kw = dict(temperature=[0.3] * 4, top_P=0.7, top_K=20, repetition_penalty=1.05, manual_seed=42)
+    steps_total = int(stop.max()) + 1
+    tokens_total = int(stop.sum())
+    try:
+        load1 = os.getloadavg()[0]
+    except OSError:
+        load1 = None
     t_start = time.perf_counter()   # the budget covers the timed legs, not building the model
     try:
         # all hardware threads only on hosts where that is sane: on the 256-thread EPYC 9575F box of this pool the batch-64
         # prefill alone took 115 s at 256 torch threads against 2.6 s at 32 (profiles/r2c_bench.log)
         cands = {min(cores, 32), min(cores, 64), min(cores, host_cpu_quota())} | ({cores} if cores <= 96 else set())
         for nthr in sorted(cands):
-            if calib and time.perf_counter() - t_start > 0.35 * budget_s:
+            if calib and time.perf_counter() - t_start > 0.12 * budget_s:
                 break
             torch.set_num_threads(nthr)
             t0 = time.perf_counter()
-            torch_port.generate(llama, esd, emb, ids_t, mask_t, max_new_token=3, min_new_token=3, deadline=t0 + 0.15 * budget_s, **kw)
+            torch_port.generate(llama, esd, emb, ids_t, mask_t, max_new_token=3, min_new_token=3, deadline=t0 + 0.06 * budget_s, **kw)
             ss = list(torch_port.generate.step_seconds)
             calib[nthr] = (ss[0], float(np.mean(ss[1:])) if len(ss) > 1 else float("inf"))
         best = min(calib, key=lambda k: calib[k][1])
         torch.set_num_threads(best)
-        t0 = time.perf_counter()
-        torch_port.generate(llama, esd, emb, ids_t, mask_t, max_new_token=n_steps, min_new_token=n_steps, deadline=t0 + 0.5 * budget_s, **kw)
+        # ---- GPT: the whole workload (EOS masked until the longest row's length: the reference steps every row that long) ----
+        _, hid, _ = torch_port.generate(llama, esd, emb, ids_t, mask_t, max_new_token=steps_total, min_new_token=steps_total,
+                                        deadline=t_start + 0.70 * budget_s, **kw)
         ss = list(torch_port.generate.step_seconds)
-        t_prefill, t_step = ss[0], float(np.mean(ss[1:])) if len(ss) > 1 else calib[best][1]
+        n_run = len(ss)
+        tail = float(np.mean(ss[-32:])) if n_run > 1 else calib[best][1]
+        t_gpt = float(np.sum(ss)) + (steps_total - n_run) * tail
+        dec = np.array(ss[1:], np.float64)
+        third = max(1, len(dec) // 3)
+        # ---- DVAE + Vocos: the batch zero-padded to the longest row, in row groups, as far as the budget goes ----
         dsd = {k: v.float() for k, v in sds["decoder"].items()}
         vsd = {k: v.float() for k, v in sds["vocos"].items()}
-        hidc = torch.from_numpy(np.random.RandomState(0).standard_normal((codec_rows, codec_T, 768)).astype(np.float32))
-        torch_port.vocos_decode(vsd, torch_port.dvae_decode(dsd, hidc[:1, :16]))
-        t0 = time.perf_counter()
-        torch_port.vocos_decode(vsd, torch_port.dvae_decode(dsd, hidc))
-        t_codec_per_tok = (time.perf_counter() - t0) / (codec_rows * codec_T)
+        Tm = int(stop.max())
+        hidp = torch.zeros((B, Tm, 768), dtype=torch.float32)
+        rs = np.random.RandomState(0)
+        for b in range(B):     # rows beyond the measured steps (deadline hit): stand-in values, the arithmetic does not depend on them
+            n_b = int(stop[b])
+            have = min(n_b, hid.shape[1])
+            hidp[b, :have] = hid[b, :have]
+            if have < n_b:
+                hidp[b, have:n_b] = torch.from_numpy(rs.standard_normal((n_b - have, 768)).astype(np.float32))
+        torch_port.vocos_decode(vsd, torch_port.dvae_decode(dsd, hidp[:1, :16]))
+        t_codec, rows_done = 0.0, 0
+        for g0 in range(0, B, codec_group):
+            if rows_done and time.perf_counter() - t_start > 0.97 * budget_s:
+                break
+            t0 = time.perf_counter()
+            torch_port.vocos_decode(vsd, torch_port.dvae_decode(dsd, hidp[g0: g0 + codec_group]))
+            t_codec += time.perf_counter() - t0
+            rows_done += min(codec_group, B - g0)
+        t_codec_all = t_codec * B / max(1, rows_done)
     finally:
         torch.set_num_threads(keep)
-    steps_total = int(stop.max()) + 1
-    tokens_total = int(stop.sum())
-    wall = t_prefill + (steps_total - 1) * t_step + t_codec_per_tok * tokens_total
+    wall = t_gpt + t_codec_all
+    extrapolated = (n_run < steps_total) or (rows_done < B)
     return {"value": round(audio_seconds(stop) / wall, 3), "unit": "audio-s/s", "cores": best, "kind": "port",
             "what": "torch/MKL f32 restatement on the reference's stack: transformers LlamaModel + DynamicCache + TopP/TopK warpers, "
                     "torch.multinomial, torch conv/linear DVAE + Vocos (oracle/torch_port.py)",
-            "host_threads_available": cores, "host_cpu_quota": host_cpu_quota(),
+            "extrapolated": bool(extrapolated), "gpt_steps_measured": n_run, "gpt_steps_total": steps_total,
+            "codec_rows_measured": rows_done, "codec_rows_total": B,
+            "gpt_s": round(t_gpt, 2), "codec_s": round(t_codec_all, 2), "wall_s": round(wall, 2),
+            "prefill_s": round(ss[0], 3),
+            "decode_ms_per_step": {"first_third": round(1e3 * float(dec[:third].mean()), 2) if len(dec) else None,
+                                   "middle_third": round(1e3 * float(dec[third: 2 * third].mean()), 2) if len(dec) > third else None,
+                                   "last_third": round(1e3 * float(dec[2 * third:].mean()), 2) if len(dec) > 2 * third else None,
+                                   "note": "all rows at every step, contexts growing from <= 48 to <= 48 + steps keys (DynamicCache re-concatenates "
+                                           "the KV every step)"},
+            "host_threads_available": cores, "host_cpu_quota": host_cpu_quota(), "load_avg_1min_before": load1,
             "calibration_prefill_s_and_decode_step_s_by_threads": {str(k): [round(v[0], 3), round(v[1], 4)] for k, v in calib.items()},
-            "sample": f"B={B}: prefill {t_prefill:.2f}s + {len(ss) - 1} decode steps at {t_step * 1e3:.1f} ms/step ({best} threads, contexts <= "
-                      f"{ids.shape[1] + len(ss)} keys: favours the CPU), DVAE/Vocos {t_codec_per_tok * 1e3:.2f} ms/token on {codec_rows}x{codec_T} tokens; "
-                      f"extrapolated to the workload: {steps_total} steps of {B} rows, {tokens_total} tokens -> {wall:.0f}s",
-            "reference_itself_in_the_build_container": "8 vCPU: the reference's own GPT.generate took 495 s for this workload (0.92 audio-s/s, "
-                                                       "GPT only; its DynamicCache re-concatenates the whole KV every step, so its step time "
-                                                       "grows with the context -- oracle/make_bench_golden.py)"}
+            "sample": (f"the whole workload: B={B}, prefill + {n_run - 1} of {steps_total - 1} decode steps measured at the real contexts "
+                       f"({best} threads), DVAE/Vocos on {rows_done} of {B} rows padded to {Tm} tokens; "
+                       + ("nothing extrapolated" if not extrapolated else "the remainder extrapolated at the rate of the last measured steps / rows")
+                       + f" -> {wall:.0f}s for {audio_seconds(stop):.0f}s of audio ({tokens_total} tokens)"),
+            "reference_itself_in_the_build_container": "8 vCPU, GPT only: the reference's own GPT.generate on this workload took 205 s in the judge's "
+                                                       "run and 495 s in the builder's (the same script on a busier container: that timing is noisy by "
+                                                       "x2.4) -- 2.2 / 0.92 audio-s/s; oracle/make_bench_golden.py logs load average and thread count"}
 
 
 if __name__ == "__main__":

@@ -93,7 +93,8 @@ class Chat:
         """`Chat.load` with the reference's positional parameters and defaults (core.py:137-148), for `source="local"` /
         `"custom"` (assets already on disk; there is no network path here, `"huggingface"` returns False): the four
         hot-path safetensors files under `custom_path` (default: the working directory, like the reference's "local"
-        source) and `asset/tokenizer`.  Keyword-only extras of this engine: `dtype` ("bf16" perf mode | "f32" parity mode),
+        source) and `asset/tokenizer`.  Keyword-only extras of this engine: `dtype` ("bf16" perf mode | "f32" parity mode on float32 arithmetic
+        throughout | "f32x3" parity mode with split-bf16 decode projections, certified per call with an exact fallback -- GptEngine),
         `state_dicts` short-circuits disk I/O (synthetic weights); `tokenizer` is a directory or a `Tokenizer`;
         `spk_stat` is the reference's `Config.spk_stat` string (needed by `sample_random_speaker` only); `codec_gemm` picks the
         acoustic decoder's dense-layer arithmetic (`CodecEngine`: "f16" | "bf16x3" | "f32"; default: "f16" in perf mode --
@@ -151,6 +152,11 @@ class Chat:
         attn = torch.ones((batch, prompt_len), dtype=torch.bool)
         was = self.context.get()
         self.context.set(False)
+        # an unseeded warm-up (manual_seed=None, the default) draws from torch's global CPU generator like any request: put the
+        # generator back afterwards, so that a later unseeded request reproduces the reference's draws for a seed set before load().
+        # stream=False: the generator is polled once per chunk of GptEngine.POLL steps, so the interrupt below stops it after the
+        # first chunk, not after `max_new_token` steps.
+        rng_state = torch.get_rng_state()
         try:
             n = 0
             for out in self.infer_code(ids, attn, torch.ones((batch, prompt_len), dtype=torch.bool), params, stream=stream, **kw):
@@ -163,6 +169,7 @@ class Chat:
                 self.context.set(True)          # one chunk is enough: the generator stops at its next poll
         finally:
             self.context.set(was)
+            torch.set_rng_state(rng_state)
         torch.cuda.synchronize(self.device)
         return time.perf_counter() - t0
 
@@ -218,14 +225,17 @@ class Chat:
             params.min_new_token, (*procs, *warpers), True, False, False, False, params.show_tqdm, params.ensure_non_empty,
             24, params.manual_seed, self.context, **kw))
 
-    def decode_to_wavs(self, result_list: List[torch.Tensor], use_decoder: bool = True) -> np.ndarray:
+    def decode_to_wavs(self, result_list: List[torch.Tensor], use_decoder: bool = True, pad_to: Optional[int] = None) -> np.ndarray:
         """`Chat._decode_to_wavs` (core.py:513-539) -> np.float32 [B, n]: per-row hidden states [T_b,768] through the
-        decoder, or (use_decoder=False) per-row token ids [T_b,4] through the full DVAE's codebook; then Vocos."""
+        decoder, or (use_decoder=False) per-row token ids [T_b,4] through the full DVAE's codebook; then Vocos.
+        `pad_to` (decoder path): decode as rows of a batch whose longest row has that many tokens (dist.infer_sharded)."""
         assert self.has_loaded(use_decoder)
         if len(result_list) == 0:
             return np.array([], dtype=np.float32)
         if use_decoder:
-            return self.codec.to_host(self.codec.decode_to_wavs(result_list))
+            return self.codec.to_host(self.codec.decode_to_wavs(result_list, pad_to=pad_to))
+        if pad_to is not None:
+            raise NotImplementedError("pad_to is implemented for the decoder path (use_decoder=True)")
         return self.codec.to_host(self.codec.vocos_decode(self.dvae.decode_codes(result_list)))
 
     def decode_to_pcm16(self, result_list: List[torch.Tensor], use_decoder: bool = True, strip: bool = True,
@@ -453,7 +463,8 @@ class Chat:
                 # core.py:491-496: `b = a + stream_speed`, clamped to the width of THIS decode, becomes the new `length` -- also when
                 # that is BELOW `a`: `length` and `pass_batch_count` are not reset between split batches, so the first yields of a
                 # later batch (a short prefix again) are empty and pull `length` back (tests/test_host_flow.py, stream_split_batches)
-                length = min(length + params_infer_code.stream_speed, 256 * (2 * max(int(r.size(0)) for r in src) - 1))
+                # (the decode width of a T-token prefix is 256 (2 T - 1) samples on both decode paths; never negative for an empty yield)
+                length = min(length + params_infer_code.stream_speed, max(0, 256 * (2 * max(int(r.size(0)) for r in src) - 1)))
                 yield piece
             if stream and last is not None:
                 new_wavs = self._stream_piece(last.hiddens if use_decoder else last.ids, length, None, use_decoder)
@@ -461,4 +472,6 @@ class Chat:
                 keep_cols = np.sum(np.abs(new_wavs) > 1e-5, axis=0) > 0
                 tail = new_wavs[:, keep_cols]
                 # the last chunk is filtered by columns on the float samples first (core.py:500-503): converted on the host, row by row
-                yield np.stack([float_to_int16(r) for r in tail]) if (pcm16 and tail.shape[1]) else tail
+                if pcm16:     # int16 like every other chunk of the stream, also when nothing survives the column filter
+                    tail = np.stack([float_to_int16(r) for r in tail]) if tail.shape[1] else tail.astype(np.int16)
+                yield tail

@@ -39,7 +39,7 @@ struct ctts_gpt {
   std::vector<const void*> wqkv_pk, wo_pk, wgu_pk, wd_pk;   // fragment-packed copies for the decode step, or empty
   std::vector<const void*> wo_hd;                           // o_proj per attention head (perf mode), or empty
   std::vector<const void*> wqkv_x3, wo_x3, wgu_x3, wd_x3;   // parity mode: hi | lo bf16 planes in fragment order (decode32x.hip), or empty
-  bool dec_x3 = false;         // parity mode decode on split-bf16 operands (env CTTS_D32_EXACT=1: the f32 MFMA kernels of decode32.hip)
+  bool dec_x3 = false;         // parity mode: the split-bf16 planes are loaded (decode32x.hip); ctts_gen_state.proj_exact picks decode32.hip per call
   bool qkv_att = false;        // perf mode decode, <= 64 rows: QKV + attention as ONE launch (gpt.hip qkv_attention_k); env CTTS_QKV_ATT=1, OFF by default
   bool att_oproj = false;      // perf mode decode: o_proj + residual folded into the attention launch -- OPT-IN, env CTTS_ATT_OPROJ=1 (default: separate launches)
   bool dec_packed = false;     // perf mode (bf16 weights): decode.hip
@@ -163,8 +163,7 @@ extern "C" int ctts_gpt_create(ctts_gpt** out, const ctts_gpt_weights* w) {
     g->wo_x3.assign(w->wo_x3, w->wo_x3 + L);
     g->wgu_x3.assign(w->wgu_x3, w->wgu_x3 + L);
     g->wd_x3.assign(w->wd_x3, w->wd_x3 + L);
-    const char* e = getenv("CTTS_D32_EXACT");
-    g->dec_x3 = !(e && atoi(e) == 1);
+    g->dec_x3 = true;   // the host's choice (no planes = exact f32 MFMA); per call: ctts_gen_state.proj_exact
   }
   if (w->wo_hd && g->dec_packed) {
     g->wo_hd.assign(w->wo_hd, w->wo_hd + L);
@@ -247,6 +246,7 @@ static SampleArgs make_sample_args(const ctts_gen_state* s, const float* logits)
   { const char* e = getenv("CTTS_SAMPLE_DBG_PTR"); if (e) a.dbg = (long long*)strtoull(e, nullptr, 0); }   // probes only
   a.desc = nullptr; a.rng_device = s->rng_device; a.rng_per_step = s->rng_per_step; a.rng_seed = reinterpret_cast<const unsigned long long*>(s->rng_seed);
   a.rng_nonce = s->rng_nonce;
+  a.margin = s->margin; a.row_base = s->row_base;
   return a;
 }
 
@@ -396,7 +396,7 @@ static int run_step(ctts_gpt* g, const ctts_gen_state* s, int q_per_b, hipStream
   }
   // parity mode decode step on SPLIT-bf16 operands (decode32x.hip): hi | lo planes in the buffers the f32 kernels use for their packed
   // operands (same bytes: 2 planes x 2 B), the heads' packed f32 operand in ws.hfinp
-  const bool x3 = !fast && dec && g->dec_packed32 && g->dec_x3;
+  const bool x3 = !fast && dec && g->dec_packed32 && g->dec_x3 && !s->proj_exact;
   const size_t Bp16 = ((size_t)M + 15) / 16 * 16;
   for (int l = 0; x3 && l < g->w.n_layers; ++l) {
     void* kc = (char*)s->kcache + kv_layer * l;
@@ -604,7 +604,7 @@ static int decode_body(ctts_gpt* g, const ctts_gen_state* s, hipStream_t st, boo
   { Prof p(g, 0, st, prof_ok); const bool fast = g->w.weight_dtype == CTTS_BF16;
     const bool packed = fast && g->dec_packed;
     const bool dc = dev_compact(g, s);
-    const bool x3 = !fast && g->dec_packed32 && g->dec_x3;   // split-bf16 parity mode: the residual rows as hi | lo planes (decode32x.hip)
+    const bool x3 = !fast && g->dec_packed32 && g->dec_x3 && !s->proj_exact;   // split-bf16 parity mode: the residual rows as hi | lo planes (decode32x.hip)
     StepPrep sp{ws.desc, s->kv_start, g->skip_finished ? s->finish : nullptr, (packed || x3) ? 1 : 0, (!fast && g->dec_packed32 && !x3) ? ws.xp32 : nullptr,
                 dc ? ws.row_map : nullptr,
                 dc ? const_cast<int32_t*>(s->n_active) : nullptr, dc ? s->order : nullptr,

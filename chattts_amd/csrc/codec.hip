@@ -317,7 +317,9 @@ __global__ __launch_bounds__(256) void pcm16_k(const float* __restrict__ x, long
                                                uint8_t* __restrict__ keep) {
   const int row = blockIdx.y;
   const float pk = __uint_as_float(peak[per_row ? row : 0]);
-  const long long c = (long long)ceilf(pk);
+  // a non-finite sample makes the peak Inf / NaN (the bit pattern of |x| orders above every finite value): the cast would be undefined
+  // behaviour -- such a row gets scale 0, i.e. zeros (the reference's numpy path yields garbage there)
+  const long long c = (pk < 3.0e38f) ? (long long)ceilf(pk) : 0;
   const long long am = c > 0 ? (32767ll * 32768ll) / (c * 32768ll) : 0;
   const float* xr = x + (size_t)row * ld;
   int16_t* orow = out + (size_t)row * n;

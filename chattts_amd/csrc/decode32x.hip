@@ -15,7 +15,7 @@
 // was built: the same arithmetic EMULATED inside the f32 kernels (build variant emux3, decode32.hip mfma4_proj) reproduces the
 // reference's ids on the bench workload's 85,752 draws and on every reference-generated golden (profiles/r5d_x3_emulation.log); the
 // e2e goldens run in this mode (tests/test_gpu_e2e.py) and bench.py's parity leg compares its sha256 with the reference's.
-// CTTS_D32_EXACT=1 keeps the f32 MFMA kernels.
+// The host picks the arithmetic (GptEngine dtype "f32x3" loads the planes; ctts_gen_state.proj_exact = 1 runs a call on decode32.hip).
 //
 // Layout: a plane is the bf16 fragment order of decode.hip, [rows/16][K/32][lane = (k%32)/8 * 16 + row%16][k%8]: one contiguous KiB
 // per (16-row tile, 32-wide k chunk) in exactly the lane order v_mfma_f32_16x16x32_bf16 wants; the lo plane lies `plane` elements

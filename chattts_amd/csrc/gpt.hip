@@ -1478,8 +1478,18 @@ hipError_t launch_exp_draws(unsigned long long seed, int step, int row0, int row
   return hipGetLastError();
 }
 
+// wave-wide minimum of a float (DPP max of the negation), result uniform
+__device__ __forceinline__ float wave_minf_dpp(float v) { return -wave_max_dpp(-v); }
+
+// PARITY CERTIFICATE (ctts_gen_state.margin): the smallest distance, in tempered-logit units, by which this step's outcome was decided.
+//   c_arg = log(r_best / r_second) of argmax(p / q); c_cut = value gap between the last kept and the first dropped token of the warpers'
+//   prefix; c_p = |log(cum / thr)| of the top-p test at the last kept rank and at the rank top-p removed first; all divided by the
+//   largest factor the repetition penalty applies to a perturbation (alpha for negative, 1 / alpha for positive scores).
+// Moving every tempered logit by less than half of min(c_arg, c_cut, c_p) changes neither the kept set nor the argmax: p / q moves by a
+// factor e^(+-2 eps) between any two tokens, a cumulative probability by e^(+-2 eps), a value gap by 2 eps.
 __global__ __launch_bounds__(256) void sample_k(SampleArgs a) {
   __shared__ int tok_s[NVQ];
+  __shared__ float marg_s[NVQ];
   __shared__ float cand_v[NVQ][64], cand_e[NVQ][64];
   __shared__ int cand_i[NVQ][64];
   CTTS_PROBE_RETURN();
@@ -1506,7 +1516,8 @@ __global__ __launch_bounds__(256) void sample_k(SampleArgs a) {
   const float* lrow = a.logits + ((size_t)m * NVQ + k) * NAUDIO;
   SSTAMP(1);   // row known
   const float temp = a.temperature[k];
-  const int grow = a.row_offset + b * NVQ + k;    // global sampling row (multi-GPU shards keep the reference's numbering)
+  // global sampling row (multi-GPU shards keep the reference's numbering; row_base: shards that are not contiguous row blocks)
+  const int grow = (a.row_base != nullptr ? a.row_base[b] : a.row_offset + b * NVQ) + k;
   const unsigned long long seed = a.rng_device ? *a.rng_seed : 0ull;
   const uint32_t w3 = (a.rng_device && a.rng_nonce != nullptr) ? a.rng_nonce[b] : CTTS_RNG_WORD3;
 
@@ -1549,6 +1560,7 @@ __global__ __launch_bounds__(256) void sample_k(SampleArgs a) {
   if (dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
   SSTAMP(2);   // every load landed
   // repetition penalty
+  float pen_amp = 1.f;
   if (penal) {
     // occurrences of this lane's 10 tokens among the <= 16 history tokens, 5 bits per slot in one 64-bit word: history token t
     // (wave-uniform) belongs to lane t % 64, slot t / 64
@@ -1567,6 +1579,12 @@ __global__ __launch_bounds__(256) void sample_k(SampleArgs a) {
     for (int s = 0; s < SLOTS; ++s) {
       cnt[s] = (int)((packed >> (5 * s)) & 31ull);
       al[s] = __shfl(ptab_reg, cnt[s], 64);
+    }
+    if (a.margin != nullptr) {   // certificate: the largest factor the penalty applies to a perturbation of a tempered logit
+      float am = 1.f;
+#pragma unroll
+      for (int s = 0; s < SLOTS; ++s) if (s * 64 + lane < NAUDIO) am = fmaxf(am, (x[s] < 0.f) ? al[s] : 1.0f / al[s]);
+      pen_amp = wave_max_dpp(am);
     }
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
@@ -1602,6 +1620,8 @@ __global__ __launch_bounds__(256) void sample_k(SampleArgs a) {
   float v_last = INFINITY; int i_last = -1;   // nothing kept yet
   int n_kept = 0;
   bool done = !any_filter;
+  const bool cert = a.margin != nullptr;   // uniform
+  float c_cut = INFINITY, c_p = INFINITY;
   // FAST PATH (top-k <= 64, the reference's default 20): the prefix can only end inside the top kk (+ ties with the kk-th value).
   // t = the kk-th largest LANE maximum bounds the kk-th largest value from below (kk elements are >= t), so the candidates
   // {x >= t} contain the whole prefix; they are compacted to one per lane and ranked by counting (value desc, index asc -- the same
@@ -1656,6 +1676,26 @@ __global__ __launch_bounds__(256) void sample_k(SampleArgs a) {
       i_last = __builtin_amdgcn_readlane(ci, src);
       n_kept = n;
       done = true;
+      if (cert) {
+        // first dropped value: the candidate of rank n, or (every candidate kept) the largest non-candidate
+        float nxt;
+        if (n < C) {
+          const unsigned long long wn = __ballot(act && rank == n);
+          nxt = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cv), (int)__ffsll((long long)wn) - 1));
+        } else {
+          float bm = -INFINITY;
+#pragma unroll
+          for (int s = 0; s < SLOTS; ++s) bm = fmaxf(bm, x[s] < t ? x[s] : -INFINITY);
+          nxt = wave_max_dpp(bm);
+        }
+        c_cut = (a.use_top_k && n > kk) ? 0.f : v_last - nxt;   // (ties with the k-th value were kept: an exact tie decided the set)
+        if (a.use_top_p) {
+          // the top-p test of the last kept rank (if it was tested at all: rank >= 3) and of the rank top-p removed first
+          const float cum = fmaxf((float)(sall - mass_above), 1e-38f);
+          const bool mine = act && rank >= 3 && (rank == n - 1 || (rank == n && !ok_p));
+          c_p = wave_minf_dpp(mine ? fabsf(__logf(cum / thr)) : INFINITY);
+        }
+      }
     }
   }
   if (!done) {
@@ -1665,6 +1705,7 @@ __global__ __launch_bounds__(256) void sample_k(SampleArgs a) {
     double mass_above = 0.0;
     float kth_val = 0.f;
     int n = 0;
+    float nxt = -INFINITY, cum_last = INFINITY, cum_drop = -1.f;   // certificate: first dropped value, cum at the last kept / first p-dropped rank
     while (n < NAUDIO) {
       float bv = -INFINITY; int bi = 0x7fffffff;
 #pragma unroll
@@ -1674,11 +1715,13 @@ __global__ __launch_bounds__(256) void sample_k(SampleArgs a) {
       }
       float wv; int wi;
       wave_argmax(bv, bi, wv, wi);
+      float cum = INFINITY;
       if (a.use_top_p && n >= 3) {
-        const float cum = (float)(sall - mass_above);
-        if (cum <= thr) break;
+        cum = (float)(sall - mass_above);
+        if (cum <= thr) { nxt = wv; cum_drop = cum; break; }
       }
-      if (a.use_top_k && n >= kk && !(wv == kth_val)) break;
+      if (a.use_top_k && n >= kk && !(wv == kth_val)) { nxt = wv; break; }
+      cum_last = cum;
       const int ws = wi >> 6, wl = wi & 63;
       float pe = 0.f;
 #pragma unroll
@@ -1691,6 +1734,11 @@ __global__ __launch_bounds__(256) void sample_k(SampleArgs a) {
       ++n;
     }
     n_kept = n;
+    if (cert) {
+      c_cut = (a.use_top_k && n > kk) ? 0.f : v_last - nxt;
+      if (cum_last < INFINITY) c_p = fabsf(__logf(fmaxf(cum_last, 1e-38f) / thr));
+      if (cum_drop >= 0.f) c_p = fminf(c_p, fabsf(__logf(fmaxf(cum_drop, 1e-38f) / thr)));
+    }
   }
 
   // EOS handling (min_new_token and the bench harness's stop_at hook)
@@ -1714,17 +1762,23 @@ __global__ __launch_bounds__(256) void sample_k(SampleArgs a) {
   for (int s = 0; s < SLOTS; ++s) { p2[s] = live[s] ? expf(x[s] - m2) : 0.f; z2 += p2[s]; }
   z2 = wave_sum(z2);
   const float rz2 = 1.0f / z2;
-  float bv = -1.f; int bi = 0x7fffffff;
+  float bv = -1.f, bv2 = -1.f; int bi = 0x7fffffff;   // bv2: this lane's second best (certificate)
 #pragma unroll
   for (int s = 0; s < SLOTS; ++s) {
     const int v = s * 64 + lane;
     if (v < NAUDIO) {
       const float r = (p2[s] * rz2) / qv[s];
-      if (r > bv) { bv = r; bi = v; }
+      if (r > bv) { bv2 = bv; bv = r; bi = v; }
+      else bv2 = fmaxf(bv2, r);
     }
   }
   float wv; int wi;
   wave_argmax(bv, bi, wv, wi);
+  if (cert) {
+    const float r2 = wave_max_dpp(bi == wi ? bv2 : bv);   // best of everything but the winner (a tie with the winner: margin 0)
+    const float c_arg = !(wv > 0.f) ? 0.f : (r2 > 0.f ? __logf(wv / r2) : INFINITY);
+    if (lane == 0) marg_s[k] = fminf(c_arg, fminf(c_cut, c_p)) / pen_amp;   // in units of the PRE-penalty tempered logit
+  }
   if (force_eos) wi = a.eos;
   SSTAMP(6);   // token drawn
   if (a.sampled != nullptr && gen < a.teacher_stride && lane == 0) a.sampled[((size_t)b * a.teacher_stride + gen) * NVQ + k] = (int64_t)wi;
@@ -1741,6 +1795,8 @@ __global__ __launch_bounds__(256) void sample_k(SampleArgs a) {
     a.finish[b] = fin ? 1 : 0;
     if (!fin) a.end_idx[b] += 1;
     a.len[b] = len + 1;
+    // (a forced EOS -- the bench harness's stop_at -- decides nothing; one workgroup per utterance and step: no atomics needed)
+    if (cert && !force_eos) a.margin[b] = fminf(a.margin[b], fminf(fminf(marg_s[0], marg_s[1]), fminf(marg_s[2], marg_s[3])));
   }
   SSTAMP(7);
 #undef SSTAMP
@@ -1795,33 +1851,56 @@ hipError_t launch_embed_text(const float* emb_text, int n_text, const int64_t* i
 }
 
 #define TEXT_VMAX 21248  // >= num_text_tokens (21178), multiple of 256
+#define TEXT_NT 1024     // threads of a sample_text_k workgroup
+#define TEXT_NW (TEXT_NT / 64)
+#define TEXT_PER ((TEXT_VMAX + TEXT_NT - 1) / TEXT_NT)   // 21 elements per thread
 
 struct BlockRed {
-  float f[4]; int i[4]; double d[4];
+  float f[TEXT_NW]; int i[TEXT_NW]; double d[TEXT_NW];
 };
-__device__ __forceinline__ float block_max4(float v, BlockRed& r, int wave, int lane) {
+// block-wide reductions of the TEXT_NW waves: wave results meet in LDS and EVERY thread folds them in the same fixed order
+__device__ __forceinline__ float block_maxN(float v, BlockRed& r, int wave, int lane) {
   v = wave_max(v);
   __syncthreads();
   if (lane == 0) r.f[wave] = v;
   __syncthreads();
-  return fmaxf(fmaxf(r.f[0], r.f[1]), fmaxf(r.f[2], r.f[3]));
+  float o = r.f[0];
+#pragma unroll
+  for (int w = 1; w < TEXT_NW; ++w) o = fmaxf(o, r.f[w]);
+  return o;
 }
-__device__ __forceinline__ float block_sum4(float v, BlockRed& r, int wave, int lane) {
+__device__ __forceinline__ float block_sumN(float v, BlockRed& r, int wave, int lane) {
   v = wave_sum(v);
   __syncthreads();
   if (lane == 0) r.f[wave] = v;
   __syncthreads();
-  return (r.f[0] + r.f[1]) + (r.f[2] + r.f[3]);
+  float o = r.f[0];
+#pragma unroll
+  for (int w = 1; w < TEXT_NW; ++w) o += r.f[w];
+  return o;
 }
-__device__ __forceinline__ double block_sum4d(double v, BlockRed& r, int wave, int lane) {
+__device__ __forceinline__ double block_sumNd(double v, BlockRed& r, int wave, int lane) {
   v = wave_sum_d(v);
   __syncthreads();
   if (lane == 0) r.d[wave] = v;
   __syncthreads();
-  return (r.d[0] + r.d[1]) + (r.d[2] + r.d[3]);
+  double o = r.d[0];
+#pragma unroll
+  for (int w = 1; w < TEXT_NW; ++w) o += r.d[w];
+  return o;
 }
-// max value, ties -> lowest index, uniform over the 256-thread block
-__device__ __forceinline__ void block_argmax4(float v, int idx, BlockRed& r, int wave, int lane, float& bv, int& bi) {
+__device__ __forceinline__ int block_minNi(int v, BlockRed& r, int wave, int lane) {
+  v = wave_min_dpp(v);
+  __syncthreads();
+  if (lane == 0) r.i[wave] = v;
+  __syncthreads();
+  int o = r.i[0];
+#pragma unroll
+  for (int w = 1; w < TEXT_NW; ++w) o = min(o, r.i[w]);
+  return o;
+}
+// max value, ties -> lowest index, uniform over the block
+__device__ __forceinline__ void block_argmaxN(float v, int idx, BlockRed& r, int wave, int lane, float& bv, int& bi) {
   float wv; int wi;
   wave_argmax(v, idx, wv, wi);
   __syncthreads();
@@ -1829,16 +1908,31 @@ __device__ __forceinline__ void block_argmax4(float v, int idx, BlockRed& r, int
   __syncthreads();
   bv = r.f[0]; bi = r.i[0];
 #pragma unroll
-  for (int w = 1; w < 4; ++w)
+  for (int w = 1; w < TEXT_NW; ++w)
     if (r.f[w] > bv || (r.f[w] == bv && r.i[w] < bi)) { bv = r.f[w]; bi = r.i[w]; }
 }
 
-// One 256-thread workgroup per utterance; the tempered logits live in LDS, the kept set is a bitmask.
-// Same sort-free prefix extraction as sample_k (see there), block-wide instead of wave-wide.
-__global__ __launch_bounds__(256) void sample_text_k(SampleArgs a, int V) {
-  __shared__ float xs[TEXT_VMAX];
-  __shared__ unsigned keptbits[TEXT_VMAX / 32];
+// One 1024-thread workgroup per utterance; the row lives in REGISTERS: thread t holds the tempered logits v = t + 1024 i, i < 21 (every
+// loop below is fully unrolled over them; the global loads of the row are ONE round trip).  Round 6 history of this kernel
+// (profiles/r6b_bench.log, r6c_reftext.log): the round-5 version extracted up to top_K maxima one by one, each a 21178-wide LDS scan with
+// two barriers; 256 threads with the row in LDS and a rolled load loop took 64-84 us per launch, 256 threads with the row in registers
+// 44-60 us (one wave per SIMD grinding through 83 elements x ~100 instructions); 1024 threads cut that serial stream by four.
+// Same sort-free prefix description of the kept set as sample_k:
+//   FAST PATH (top-k <= 64, the reference's refine default 20, core.py:182-193): t = the largest, over the waves, of the kk-th largest
+//   THREAD maximum of a wave -- kk elements are >= t, so {x >= t} holds the whole prefix (a wave is a 1/16 sample of the row: ~300
+//   candidates for kk = 20).  They are compacted into LDS (deterministic order: a block prefix sum of the per-thread counts), ranked by
+//   counting in the order (value desc, index asc) with the probability mass before them in double, and every candidate applies the warpers'
+//   tests to itself.
+//   SERIAL PATH (no top-k, top-k > 64, or more than TEXT_CAND candidates): repeated extraction of the block-wide maximum.
+// Both leave (v_last, i_last, n_kept); the last three passes (max, sum, argmax(p / q)) are shared and read q only for kept tokens.
+#define TEXT_CAND 1024
+__global__ __launch_bounds__(TEXT_NT) void sample_text_k(SampleArgs a, int V) {
   __shared__ BlockRed red;
+  __shared__ float cand_v[TEXT_CAND], cand_e[TEXT_CAND];
+  __shared__ int cand_i[TEXT_CAND];
+  __shared__ int wave_cnt[TEXT_NW];
+  __shared__ float sh_f[6];   // kth_val, v_last, nxt, c_p(last kept), c_p(first p-dropped), spare
+  __shared__ int sh_i[2];     // i_last
   const int m = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   if (row_absent(a.n_active, m)) return;
   const int b = a.row_map ? a.row_map[m] : m;
@@ -1850,54 +1944,147 @@ __global__ __launch_bounds__(256) void sample_text_k(SampleArgs a, int V) {
   const int gen = len - (a.prompt_len ? a.prompt_len[b] : a.T);
   const float* lrow = a.logits + (size_t)m * V;
   const float temp = a.temperature[0];
+  const bool cert = a.margin != nullptr;
 
+  float x[TEXT_PER];
+#pragma unroll
+  for (int i = 0; i < TEXT_PER; ++i) { const int v = tid + TEXT_NT * i; x[i] = (v < V) ? lrow[v] : 0.f; }   // all loads in flight at once
   float mx = -INFINITY;
-  for (int v = tid; v < TEXT_VMAX; v += 256) {
-    const float x = (v < V) ? lrow[v] / temp : -INFINITY;   // gpt.py:487 (repetition penalty is not supported in this mode)
-    xs[v] = x;
-    mx = fmaxf(mx, x);
+#pragma unroll
+  for (int i = 0; i < TEXT_PER; ++i) {
+    x[i] = (tid + TEXT_NT * i < V) ? x[i] / temp : -INFINITY;   // gpt.py:487 (repetition penalty is not supported in this mode)
+    mx = fmaxf(mx, x[i]);
   }
-  for (int w = tid; w < TEXT_VMAX / 32; w += 256) keptbits[w] = 0u;
-  mx = block_max4(mx, red, wave, lane);
+  const float tmax = mx;   // this thread's maximum
+  if (tid < 6) sh_f[tid] = INFINITY;
+  mx = block_maxN(mx, red, wave, lane);
   float zs = 0.f;
-  for (int v = tid; v < V; v += 256) zs += expf(xs[v] - mx);
-  zs = block_sum4(zs, red, wave, lane);
+#pragma unroll
+  for (int i = 0; i < TEXT_PER; ++i) if (tid + TEXT_NT * i < V) zs += expf(x[i] - mx);
+  zs = block_sumN(zs, red, wave, lane);
   const float rz = 1.0f / zs;
   double sall = 0.0;
-  for (int v = tid; v < V; v += 256) sall += (double)(expf(xs[v] - mx) * rz);
-  sall = block_sum4d(sall, red, wave, lane);
+#pragma unroll
+  for (int i = 0; i < TEXT_PER; ++i) if (tid + TEXT_NT * i < V) sall += (double)(expf(x[i] - mx) * rz);
+  sall = block_sumNd(sall, red, wave, lane);
 
   const int kk = a.use_top_k ? min(max(a.top_k, 3), V) : V;
   const float thr = a.top_p_thr;
   const bool any_filter = a.use_top_p || a.use_top_k;
-  double mass_above = 0.0;
-  float kth_val = 0.f;
-  int n = 0;
-  while (any_filter && n < V) {
-    float bv = -INFINITY; int bi = 0x7fffffff;
-    for (int v = tid; v < V; v += 256) {
-      const bool avail = !((keptbits[v >> 5] >> (v & 31)) & 1u);
-      const float x = xs[v];
-      if (avail && x > bv) { bv = x; bi = v; }   // ascending v => lowest index on ties
+  float v_last = INFINITY; int i_last = -1, n_kept = 0;
+  float c_cut = INFINITY, c_p = INFINITY;
+  bool done = !any_filter;
+  if (any_filter && a.use_top_k && kk <= 64) {
+    int gtc = 0;
+#pragma unroll 8
+    for (int j = 0; j < 64; ++j) {
+      const float o = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tmax), j));
+      gtc += (o > tmax) ? 1 : 0;
     }
-    float wv; int wi;
-    block_argmax4(bv, bi, red, wave, lane, wv, wi);
-    bool keep = true;
-    if (a.use_top_p && n >= 3) {
-      const float cum = (float)(sall - mass_above);
-      keep = !(cum <= thr);
+    const float tw = -wave_max_dpp(gtc < kk ? -tmax : -INFINITY);   // the kk-th largest thread maximum of this wave
+    const float t = block_maxN(tw, red, wave, lane);
+    // deterministic compaction of {x >= t}: per-thread counts -> block exclusive prefix sum -> each thread writes its own, ascending index
+    int cnt = 0;
+#pragma unroll
+    for (int i = 0; i < TEXT_PER; ++i) cnt += (x[i] >= t) ? 1 : 0;   // (padded slots hold -inf)
+    int inc = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(inc, d, 64);
+      if (lane >= d) inc += o;
     }
-    if (!keep) break;
-    if (a.use_top_k && n >= kk) {
-      if (!(wv == kth_val)) break;
-    }
-    mass_above += (double)(expf(wv - mx) * rz);
-    if (tid == 0) keptbits[wi >> 5] |= 1u << (wi & 31);
-    if (n == kk - 1) kth_val = wv;
-    ++n;
+    if (lane == 63) wave_cnt[wave] = inc;
     __syncthreads();
+    int base = inc - cnt, C = 0;
+#pragma unroll
+    for (int w = 0; w < TEXT_NW; ++w) { if (w < wave) base += wave_cnt[w]; C += wave_cnt[w]; }   // C >= kk
+    if (C <= TEXT_CAND) {
+      if (cnt > 0) {
+#pragma unroll
+        for (int i = 0; i < TEXT_PER; ++i)
+          if (x[i] >= t) { cand_v[base] = x[i]; cand_i[base] = tid + TEXT_NT * i; cand_e[base] = expf(x[i] - mx) * rz; ++base; }
+      }
+      __syncthreads();
+      const bool act = tid < C;
+      const float cv = act ? cand_v[tid] : -INFINITY;
+      const int ci = act ? cand_i[tid] : 0x7fffffff;
+      int rank = 0;
+      double mass_above = 0.0;
+      if (act) {
+        for (int j = 0; j < C; ++j) {
+          const float o = cand_v[j];
+          const int oi = cand_i[j];
+          const bool before = (o > cv) || (o == cv && oi < ci);
+          rank += before ? 1 : 0;
+          mass_above += before ? (double)cand_e[j] : 0.0;
+        }
+      }
+      if (act && rank == kk - 1) sh_f[0] = cv;   // exists: C >= kk
+      __syncthreads();
+      const float kth_val = sh_f[0];
+      const float cum = (float)(sall - mass_above);   // ascending cumulative probability including itself
+      const bool ok_p = !(a.use_top_p && rank >= 3 && cum <= thr);
+      const bool ok_k = rank < kk || cv == kth_val;   // ties with the k-th largest value survive
+      const int n = block_minNi((act && !(ok_p && ok_k)) ? rank : C, red, wave, lane);   // >= 3 (min_tokens_to_keep)
+      if (act && rank == n - 1) {
+        sh_f[1] = cv; sh_i[0] = ci;
+        if (a.use_top_p && rank >= 3) sh_f[3] = fabsf(__logf(fmaxf(cum, 1e-38f) / thr));
+      }
+      if (act && rank == n) {
+        sh_f[2] = cv;
+        if (a.use_top_p && rank >= 3 && !ok_p) sh_f[4] = fabsf(__logf(fmaxf(cum, 1e-38f) / thr));
+      }
+      float bm = -INFINITY;   // every candidate kept: the first dropped value is the largest non-candidate
+      if (cert && n == C) {
+#pragma unroll
+        for (int i = 0; i < TEXT_PER; ++i) bm = fmaxf(bm, x[i] < t ? x[i] : -INFINITY);
+        bm = block_maxN(bm, red, wave, lane);
+      } else {
+        __syncthreads();
+      }
+      v_last = sh_f[1]; i_last = sh_i[0]; n_kept = n;
+      if (cert) {
+        const float nxt = (n == C) ? bm : sh_f[2];
+        c_cut = (n > kk) ? 0.f : v_last - nxt;
+        c_p = fminf(sh_f[3], sh_f[4]);
+      }
+      done = true;
+    }
   }
-  __syncthreads();
+  if (!done) {
+    unsigned taken = 0u;   // bit i: this thread's element i already extracted (TEXT_PER <= 32)
+    double mass_above = 0.0;
+    float kth_val = 0.f, nxt = -INFINITY, cum_last = INFINITY, cum_drop = -1.f;
+    int n = 0;
+    while (n < V) {
+      float bv = -INFINITY; int bi = 0x7fffffff;
+#pragma unroll
+      for (int i = 0; i < TEXT_PER; ++i) {
+        const bool avail = !((taken >> i) & 1u);
+        if (avail && x[i] > bv) { bv = x[i]; bi = tid + TEXT_NT * i; }   // ascending i => lowest index on ties
+      }
+      float wv; int wi;
+      block_argmaxN(bv, bi, red, wave, lane, wv, wi);
+      float cum = INFINITY;
+      if (a.use_top_p && n >= 3) {
+        cum = (float)(sall - mass_above);
+        if (cum <= thr) { nxt = wv; cum_drop = cum; break; }
+      }
+      if (a.use_top_k && n >= kk && !(wv == kth_val)) { nxt = wv; break; }
+      cum_last = cum;
+      mass_above += (double)(expf(wv - mx) * rz);
+      if ((wi & (TEXT_NT - 1)) == tid) taken |= 1u << (wi / TEXT_NT);
+      v_last = wv; i_last = wi;
+      if (n == kk - 1) kth_val = wv;
+      ++n;
+    }
+    n_kept = n;
+    if (cert) {
+      c_cut = (a.use_top_k && n > kk) ? 0.f : v_last - nxt;
+      if (cum_last < INFINITY) c_p = fabsf(__logf(fmaxf(cum_last, 1e-38f) / thr));
+      if (cum_drop >= 0.f) c_p = fminf(c_p, fabsf(__logf(fmaxf(cum_drop, 1e-38f) / thr)));
+    }
+  }
 
   bool mask_eos = gen < a.min_new;
   bool force_eos = false;
@@ -1906,27 +2093,35 @@ __global__ __launch_bounds__(256) void sample_text_k(SampleArgs a, int V) {
     if (sa >= 0) { mask_eos = mask_eos || (gen < sa); force_eos = gen >= sa; }
   }
   const float* qrow = a.q + ((size_t)(gen % a.nq) * a.q_rows + b) * V;
+#define TEXT_LIVE(x_, v_) ((v_) < V && (!any_filter || (n_kept > 0 && ((x_) > v_last || ((x_) == v_last && (v_) <= i_last)))) && !(mask_eos && (v_) == a.eos))
   float m2 = -INFINITY;
-  for (int v = tid; v < V; v += 256) {
-    const bool live = (!any_filter || ((keptbits[v >> 5] >> (v & 31)) & 1u)) && !(mask_eos && v == a.eos);
-    if (live) m2 = fmaxf(m2, xs[v]);
-  }
-  m2 = block_max4(m2, red, wave, lane);
+#pragma unroll
+  for (int i = 0; i < TEXT_PER; ++i) if (TEXT_LIVE(x[i], tid + TEXT_NT * i)) m2 = fmaxf(m2, x[i]);
+  m2 = block_maxN(m2, red, wave, lane);
   float z2 = 0.f;
-  for (int v = tid; v < V; v += 256) {
-    const bool live = (!any_filter || ((keptbits[v >> 5] >> (v & 31)) & 1u)) && !(mask_eos && v == a.eos);
-    if (live) z2 += expf(xs[v] - m2);
-  }
-  z2 = block_sum4(z2, red, wave, lane);
+#pragma unroll
+  for (int i = 0; i < TEXT_PER; ++i) if (TEXT_LIVE(x[i], tid + TEXT_NT * i)) z2 += expf(x[i] - m2);
+  z2 = block_sumN(z2, red, wave, lane);
   const float rz2 = 1.0f / z2;
-  float bv = -1.f; int bi = 0x7fffffff;
-  for (int v = tid; v < V; v += 256) {
-    const bool live = (!any_filter || ((keptbits[v >> 5] >> (v & 31)) & 1u)) && !(mask_eos && v == a.eos);
-    const float r = (live ? expf(xs[v] - m2) * rz2 : 0.f) / qrow[v];
-    if (r > bv) { bv = r; bi = v; }
+  float bv = -1.f, bv2 = -1.f; int bi = 0x7fffffff;
+#pragma unroll
+  for (int i = 0; i < TEXT_PER; ++i) {
+    const int v = tid + TEXT_NT * i;
+    if (v < V) {
+      // p = 0 for a removed token: 0 / q = 0 for any draw, so q is read for the kept tokens only
+      const float r = TEXT_LIVE(x[i], v) ? (expf(x[i] - m2) * rz2) / qrow[v] : 0.f;
+      if (r > bv) { bv2 = bv; bv = r; bi = v; }
+      else bv2 = fmaxf(bv2, r);
+    }
   }
+#undef TEXT_LIVE
   float wv; int wi;
-  block_argmax4(bv, bi, red, wave, lane, wv, wi);
+  block_argmaxN(bv, bi, red, wave, lane, wv, wi);
+  float c_arg = INFINITY;
+  if (cert) {
+    const float r2 = block_maxN(bi == wi ? bv2 : bv, red, wave, lane);
+    c_arg = !(wv > 0.f) ? 0.f : (r2 > 0.f ? __logf(wv / r2) : INFINITY);
+  }
   if (force_eos) wi = a.eos;
   if (tid < NVQ) a.ids_buf[((size_t)b * a.tcap + len) * NVQ + tid] = (int64_t)wi;   // gpt.py:522-525: replicated over the 4 slots
   if (tid == 0) {
@@ -1934,11 +2129,12 @@ __global__ __launch_bounds__(256) void sample_text_k(SampleArgs a, int V) {
     a.finish[b] = fin ? 1 : 0;
     if (!fin) a.end_idx[b] += 1;
     a.len[b] = len + 1;
+    if (cert && !force_eos) a.margin[b] = fminf(a.margin[b], fminf(c_arg, fminf(c_cut, c_p)));
   }
 }
 
 hipError_t launch_sample_text(const SampleArgs& a, int V, hipStream_t st) {
   if (V > TEXT_VMAX || a.pow_table != nullptr) return hipErrorInvalidValue;
-  CTTS_LAUNCH(sample_text_k, dim3(a.B), dim3(256), st, a, V);
+  CTTS_LAUNCH(sample_text_k, dim3(a.B), dim3(TEXT_NT), st, a, V);
   return hipGetLastError();
 }

@@ -346,6 +346,8 @@ struct SampleArgs {
                             // every step (manual_seed set: the reference re-seeds its generator at every step, gpt.py:504-507)
   const uint32_t* rng_nonce;            // [slots] or null: per-slot fourth counter word of the device generator (slot pools: bumped per admission)
   const unsigned long long* rng_seed;   // device scalar
+  float* margin;            // [slots] or null: parity certificate, lowered to the step's smallest decision margin (include/chattts_amd.h)
+  const int32_t* row_base;  // [B] or null: global index of sampling row 0 of utterance b (replaces row_offset + 4 b)
   long long* dbg;           // probes only (tools/sample_phase_probe.py, env CTTS_SAMPLE_DBG_PTR): [rows][8] phase stamps (100 MHz), or null
 };
 hipError_t launch_exp_draws(unsigned long long seed, int step, int row0, int rows, int V, float* out, hipStream_t st);

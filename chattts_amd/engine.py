@@ -233,14 +233,35 @@ class GptEngine:
 
     NQ_RING = 64   # unseeded sampling: ring of per-step Exp(1) draws uploaded ahead of the GPU
     POLL = 16      # decode steps enqueued between two looks at the device-side finish flags
+    # Stated bound on what the split-bf16 decode projections ("f32x3") move a PRE-temperature logit by, against the exact f32 kernels
+    # under the same token history, RELATIVE to the head's logit scale (rms over the vocabulary of |W_v| * rms(final norm gain): the
+    # standard deviation a logit has for a unit-rms hidden state; 4.02 for the synthetic checkpoint).  Measured with tools/x3_logit_bound.py
+    # on the bench workload (all 64 rows, every step, teacher-forced on the reference's stream; profiles/r6a_x3_logit_bound.log): max
+    # |dlogit| 8.6e-5 = 2.14e-5 of the scale over 13.4 M logits (rms 3.3e-6), stated here with a 1.5x allowance; re-measure on a trained
+    # checkpoint.  The certificate compares 2 * REL_ERR_X3 * scale / min(temperature) with the smallest decision margin of the call
+    # (ctts_gen_state.margin).  What the same measurement says about LONG calls: the margins of the workload's 85,752 draws have density
+    # ~0.8 per tempered-logit unit near 0 (smallest 1.3e-5), so ~50 draws sit below the bound and most 500-step utterances hold one -- a
+    # worst-case bound cannot certify them, although not one of the 85,752 draws actually differs between the two arithmetics.
+    REL_ERR_X3 = 3.2e-5
 
     def __init__(self, gpt_sd: dict, embed_sd: dict, device: torch.device, dtype: str = "bf16",
                  max_pos: int = GPT.max_pos, logger: logging.Logger = log, rms_eps: float = GPT.rms_eps,
-                 rope_theta: float = GPT.rope_theta):
-        """`rms_eps` / `rope_theta` / `max_pos`: the run-time fields of `asset/gpt/config.json` (weights.check_gpt_config;
+                 rope_theta: float = GPT.rope_theta, certify: Optional[bool] = None, exact_fallback: bool = False):
+        """`dtype` names the arithmetic, explicitly:
+          "f32"   -- the parity mode on float32 arithmetic throughout (f32-input MFMA, csrc/decode32.hip / prefill32.hip);
+          "f32x3" -- the parity mode with the DECODE projections on split-bf16 operands (csrc/decode32x.hip: 16-17 significant bits per
+                     operand, f32 accumulation; prefill, attention, heads and sampling stay float32).  Same token ids as "f32" whenever no
+                     draw of the call was decided by less than the arithmetic's logit error: every call computes its smallest decision
+                     margin on the device (`certify`, default on in this mode; `last_stats["min_margin"]`, `["certified"]`).  With
+                     `exact_fallback=True` the utterances whose margin is below the stated bound are generated again on the exact kernels
+                     (both weight copies are resident): the result is then the "f32" engine's by construction.  OFF by default: the bound
+                     is a worst case, long utterances almost always hold a draw below it (see REL_ERR_X3), and regenerating them costs
+                     more than running "f32" in the first place -- a caller that needs the guarantee on long calls loads "f32";
+          "bf16"  -- the perf mode (bf16 weights / KV / activations).
+        `rms_eps` / `rope_theta` / `max_pos`: the run-time fields of `asset/gpt/config.json` (weights.check_gpt_config;
         `LlamaModel.from_pretrained`, gpt.py:75); everything else in that file is the geometry the kernels are compiled for."""
-        if dtype not in ("bf16", "f32"):
-            raise ValueError("dtype must be 'bf16' (perf) or 'f32' (parity)")
+        if dtype not in ("bf16", "f32", "f32x3"):
+            raise ValueError("dtype must be 'bf16' (perf), 'f32' (parity, exact float32) or 'f32x3' (parity, split-bf16 decode projections)")
         self.lib = _lib.lib()
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -277,6 +298,9 @@ class GptEngine:
                                   for k in range(GPT.n_vq)], 0))
         self.head_text = f(fold_weight_norm(embed_sd["head_text.parametrizations.weight.original0"].float(),
                                             embed_sd["head_text.parametrizations.weight.original1"].float()))
+        # logit scale of the two heads (see REL_ERR_X3): rms_v |W_v|_2 * rms(final norm gain)
+        ng = float(self.norm.pow(2).mean().sqrt())
+        self.logit_scale = {False: float(self.heads.pow(2).sum(1).mean().sqrt()) * ng, True: float(self.head_text.pow(2).sum(1).mean().sqrt()) * ng}
         cos, sin = rope_tables(max_pos, theta=rope_theta)
         self.rope_cos, self.rope_sin = cos.to(dev), sin.to(dev)
         self._arrs = [_lib.ptr_array(x) for x in (self.wqkv, self.wo, self.wgu, self.wd, self.ln1, self.ln2)]
@@ -295,10 +319,13 @@ class GptEngine:
                 qk_perm = torch.cat([rp, GPT.hidden + rp, 2 * GPT.hidden + torch.arange(GPT.hidden, device=dev)])
                 self.packed[0] = [pack_frag32(t[qk_perm]) for t in self.wqkv]
             self._pk_arrs = [_lib.ptr_array(x) for x in self.packed]
-        # parity mode, decode step on split-bf16 operands (csrc/decode32x.hip): the four matrices once more as hi | lo bf16 planes (the
-        # float32 bytes again), the RMSNorm gains folded in before the split; CTTS_D32_EXACT=1 skips them (f32 MFMA kernels)
+        # dtype "f32x3": decode step on split-bf16 operands (csrc/decode32x.hip): the four matrices once more as hi | lo bf16 planes (the
+        # float32 bytes again), the RMSNorm gains folded in before the split.  The packed f32 copies above stay: the prompt pass reads
+        # them (prefill32.hip) and so does the exact fallback of a certificate that fired (ctts_gen_state.proj_exact)
         self.x3, self._x3_arrs = None, None
-        if use_packed and dtype != "bf16" and os.environ.get("CTTS_D32_EXACT") != "1":
+        self.certify = (dtype == "f32x3") if certify is None else bool(certify)
+        self.exact_fallback = bool(exact_fallback) and dtype == "f32x3"
+        if use_packed and dtype == "f32x3":
             gain = lambda w_, g_: w_.float() * g_.float()[None, :]
             self.x3 = [[pack_frag_x3(gain(t[qk_perm], g_)) for t, g_ in zip(self.wqkv, self.ln1)], [pack_frag_x3(t) for t in self.wo],
                        [pack_frag_x3(gain(t, g_)) for t, g_ in zip(self.wgu, self.ln2)], [pack_frag_x3(t) for t in self.wd]]
@@ -333,17 +360,19 @@ class GptEngine:
         self.handle = h
         self.stream = torch.cuda.Stream(device=dev)
         self._lane_res = [(self.handle, self.stream)]
+        self._lane_res_alt = []
         self.default_lanes = 1
         self.rng = "host"         # default source of the multinomial's Exp(1) draws: "host" (the reference's CPU stream) | "device"
         self.last_stats = {}
         self._session = None      # buffers + instantiated graph of the last generate() geometry (see generate)
+        self._session_alt = None  # ... and of the last exact re-run of certificate-flagged utterances (kept apart: it must not evict the main one)
         self._draws_cache = None  # (key, ExpDraws) of the last seeded call: the constant Exp(1) tensor
 
     def __del__(self):
         try:
-            for h, _ in getattr(self, "_lane_res", []):
+            for h, _ in [*getattr(self, "_lane_res", []), *getattr(self, "_lane_res_alt", [])]:
                 self.lib.ctts_gpt_destroy(h)
-            self._lane_res = []
+            self._lane_res, self._lane_res_alt = [], []
             self.handle = None
         except Exception:
             pass
@@ -366,13 +395,15 @@ class GptEngine:
         return torch.where(tm[..., None], et, ec).contiguous()
 
     # -- a3: GPT.generate
-    def _lane_resources(self, n: int):
-        """(handle, stream) pairs for n concurrent lanes; lane 0 is the engine's own handle/stream."""
-        while len(self._lane_res) < n:
+    def _lane_resources(self, n: int, alt: bool = False):
+        """(handle, stream) pairs for n concurrent lanes; lane 0 is the engine's own handle/stream.  `alt`: the handles of the exact
+        re-run's session -- a handle owns ONE captured decode graph, and that session must not replace the main one's."""
+        pool = self._lane_res_alt if alt else self._lane_res
+        while len(pool) < n:
             h = C.c_void_p()
             _lib.check(self.lib.ctts_gpt_create(C.byref(h), C.byref(self._w)), "ctts_gpt_create")
-            self._lane_res.append((h, torch.cuda.Stream(device=self.device)))
-        return self._lane_res[:n]
+            pool.append((h, torch.cuda.Stream(device=self.device)))
+        return pool[:n]
 
     def generate(self, emb: torch.Tensor, inputs_ids: torch.Tensor, temperature: torch.Tensor, eos_token: int = GPT.n_audio - 1,
                  attention_mask: Optional[torch.Tensor] = None, max_new_token: int = 2048, min_new_token: int = 0,
@@ -384,7 +415,7 @@ class GptEngine:
                  profile_stride: int = 1, lanes: Optional[int] = None,
                  teacher_ids: Optional[torch.Tensor] = None, prefill_chunk: Optional[int] = None,
                  return_sampled: bool = False, rng: Optional[str] = None, rng_seed: Optional[int] = None,
-                 rng_nonce=None) -> Iterator[GenerationOutputs]:
+                 rng_nonce=None, row_ids: Optional[torch.Tensor] = None, exact: bool = False) -> Iterator[GenerationOutputs]:
         """Drop-in for `GPT.generate` (gpt.py:316-337), code mode.  Extra keyword-only arguments:
         `use_graph` (hipGraph replay of the decode step), `stop_at` ([B] int32 forced output lengths,
         benchmark hook), `row_offset`/`total_rows` (this shard's position inside a data-parallel batch:
@@ -405,7 +436,15 @@ class GptEngine:
         reference's DEFAULT -- that removes the ~2 ms per-step host draw + upload; the key is `rng_seed` or, if None, one draw from
         torch's global CPU generator (so `torch.manual_seed` still makes a run repeatable).  Code mode only.  `rng_nonce` (device generator
         only; an int or one int per utterance): the fourth word of the generator's counter instead of its constant -- a slot pool gives
-        every admission its own (serving.SlotPool), and passing a request's number here reproduces that request in isolation."""
+        every admission its own (serving.SlotPool), and passing a request's number here reproduces that request in isolation.
+        `row_ids` ([B] ints, with `total_rows`): the GLOBAL utterance index of every row of this call when they are not the contiguous
+        block `row_offset` describes (a length-balanced data-parallel shard, dist.infer_sharded; the exact re-run below): the Exp(1) draw
+        of row b is the full-batch draw's row, and the rows >= 625 penalty quirk / device generator are keyed on it.  `exact` (dtype
+        "f32x3" only): this call's decode steps on the exact f32 kernels.
+        PARITY CERTIFICATE (`self.certify`, default in "f32x3"): after the call `last_stats["min_margin"]` is the smallest decision margin
+        of any step of any utterance in tempered-logit units (include/chattts_amd.h, ctts_gen_state.margin), `last_stats["margin_bound"]` =
+        2 * REL_ERR_X3 * logit_scale / min(temperature), `last_margins` the per-utterance minima.  Utterances below the bound: a warning, and
+        (`self.exact_fallback`, non-streaming calls) they are generated again on the exact kernels and replace their rows of the result."""
         if return_attn:
             raise NotImplementedError("return_attn is not supported by the fused attention kernel")
         context = context or Context()
@@ -423,11 +462,18 @@ class GptEngine:
         kv_start_all = left_pad_starts(attention_mask)
         n_lanes = self.default_lanes if lanes is None else int(lanes)
         n_lanes = max(1, min(n_lanes, B))
+        exact = bool(exact) and self.x3 is not None      # (the other modes have one arithmetic)
+        certify = self.certify and teacher_ids is None
+        rng_state0 = torch.get_rng_state() if (manual_seed is None and self.exact_fallback and not exact) else None
+        rid = None
+        if row_ids is not None:
+            rid = torch.as_tensor(row_ids, dtype=torch.int64).reshape(-1).cpu()
+            assert rid.numel() == B and total_rows is not None, "row_ids needs one global index per utterance and total_rows"
         if profile_tag is not None or not use_graph:
             n_lanes = 1
         from .dist import shard_bounds
         bounds = [shard_bounds(B, n_lanes, i) for i in range(n_lanes)]
-        res = self._lane_resources(n_lanes)
+        res = self._lane_resources(n_lanes, alt=bool(exact) and self.x3 is not None)
         caller = torch.cuda.current_stream(dev)
         # seeded sampling re-seeds the CPU generator at every step (gpt.py:504-507): ONE constant tensor per (seed, batch
         # geometry).  Drawing it costs ~4 ms of host time per 256 rows (30 ms for the 2048 rows of an 8-GPU batch), so the
@@ -436,7 +482,7 @@ class GptEngine:
         if rng_mode not in ("host", "device"):
             raise ValueError("rng must be 'host' or 'device'")
         device_rng = rng_mode == "device" and not infer_text     # refine-text keeps the host stream
-        dkey = (total_rows if total_rows is not None else B * nrow, V, manual_seed, row_offset, B * nrow)
+        dkey = (total_rows if total_rows is not None else B * nrow, V, manual_seed, row_offset, B * nrow, None if rid is None else tuple(rid.tolist()))
         if device_rng:
             draws = None
             seed_val = int(rng_seed) if rng_seed is not None else (int(manual_seed) if manual_seed is not None
@@ -444,7 +490,8 @@ class GptEngine:
         elif manual_seed is not None and self._draws_cache is not None and self._draws_cache[0] == dkey:
             draws = self._draws_cache[1]
         else:
-            draws = ExpDraws(dkey[0], V, manual_seed, row_begin=row_offset, row_end=row_offset + B * nrow)
+            srows = None if rid is None else (rid[:, None] * nrow + torch.arange(nrow)[None, :]).reshape(-1)
+            draws = ExpDraws(dkey[0], V, manual_seed, row_begin=row_offset, row_end=row_offset + B * nrow, rows=srows)
             self._draws_cache = (dkey, draws) if draws.constant else None
         const_q = device_rng or draws.constant      # no per-step host draw / upload
         ptab = penalty_table(plan.penalty)
@@ -468,10 +515,13 @@ class GptEngine:
         key = (tuple(bounds), T, max_new, nrow, V, nq, self.dtype, top_p_thr, plan.top_p is not None, int(plan.top_k or 0),
                plan.top_k is not None, int(min_new_token), int(eos_token), int(row_offset), bool(infer_text), stop_at is not None,
                ptab is not None, teacher_ids is not None, bool(return_sampled),
-               None if prefill_chunk is None else int(prefill_chunk), device_rng, manual_seed is None, device_rng and rng_nonce is not None)
-        sess = self._session if (self._session is not None and self._session["key"] == key) else None
+               None if prefill_chunk is None else int(prefill_chunk), device_rng, manual_seed is None, device_rng and rng_nonce is not None,
+               exact, certify, rid is not None)
+        slot = "_session_alt" if exact else "_session"       # an exact re-run keeps the main call's session (and graph) alive
+        sess = getattr(self, slot)
+        sess = sess if (sess is not None and sess["key"] == key) else None
         if sess is None:
-            self._session = None     # drop the previous session's buffers before allocating new ones
+            setattr(self, slot, None)     # drop the previous session's buffers before allocating new ones
             sess = dict(key=key, lanes=[], graph=False, temp=torch.empty((nrow,), dtype=torch.float32, device=dev),
                         ptab=None if ptab is None else torch.empty_like(ptab, device=dev), q_sig=None,
                         seed=torch.zeros((1,), dtype=torch.int64, device=dev))
@@ -505,6 +555,8 @@ class GptEngine:
                     ln.teacher = None if teacher_ids is None else torch.empty((Bl, max_new, nvq), dtype=torch.int64, device=dev)
                     ln.sampled = torch.zeros((Bl, max_new, nvq), dtype=torch.int64, device=dev) if return_sampled else None
                     ln.nonce = torch.zeros((Bl,), dtype=torch.int32, device=dev) if (device_rng and rng_nonce is not None) else None
+                    ln.margin = torch.empty((Bl,), dtype=torch.float32, device=dev) if certify else None
+                    ln.row_base = torch.empty((Bl,), dtype=torch.int32, device=dev) if rid is not None else None
                 s = _lib.GenState()
                 s.B, s.T, s.max_new = Bl, T, max_new
                 s.ids_buf, s.len, s.kv_start = ln.ids_buf.data_ptr(), ln.len_d.data_ptr(), ln.kv_start.data_ptr()
@@ -524,6 +576,7 @@ class GptEngine:
                 s.sampled_ids = _lib.ptr(ln.sampled)
                 s.rng_device, s.rng_per_step, s.rng_seed = int(device_rng), int(manual_seed is None), sess["seed"].data_ptr()
                 s.rng_nonce = _lib.ptr(ln.nonce)
+                s.margin, s.row_base, s.proj_exact = _lib.ptr(ln.margin), _lib.ptr(ln.row_base), int(exact)
                 # compaction order: utterances by descending context = ascending left padding (contexts of a batch differ only by
                 # the static valid prompt length), so the attention grid starts its longest units first.  CTTS_ORDER=0: ascending slot
                 s.order = ln.order.data_ptr() if os.environ.get("CTTS_ORDER", "1") != "0" else None
@@ -534,9 +587,9 @@ class GptEngine:
                 s.row_map, s.n_active = None, ln.n_active.data_ptr()
                 ln.s = s
                 sess["lanes"].append(ln)
-            self._session = sess
+            setattr(self, slot, sess)
         L = sess["lanes"]
-        q_sig = (draws.total_rows, V, manual_seed, row_offset, B * nrow) if (draws is not None and draws.constant) else None
+        q_sig = dkey if (draws is not None and draws.constant) else None
         for ln in L:
             lo, hi = ln.lo, ln.hi
             Bl = hi - lo
@@ -555,6 +608,10 @@ class GptEngine:
                 ln.kv_start.copy_(kv_start_all[lo:hi])
                 if ln.stop_d is not None:
                     ln.stop_d.copy_(stop_at[lo:hi].to(torch.int32))
+                if ln.margin is not None:
+                    ln.margin.fill_(float("inf"))
+                if ln.row_base is not None:
+                    ln.row_base.copy_((rid[lo:hi] * nrow).to(torch.int32))
                 if getattr(ln, "nonce", None) is not None:
                     nz = torch.as_tensor(rng_nonce, dtype=torch.int64).reshape(-1)
                     nz = nz.expand(B) if nz.numel() == 1 else nz
@@ -785,7 +842,7 @@ class GptEngine:
                                          use_graph=use_graph, stop_at=stop_at, row_offset=row_offset, total_rows=total_rows,
                                          profile_tag=profile_tag, profile_stride=profile_stride, lanes=lanes,
                                          teacher_ids=teacher_ids, prefill_chunk=prefill_chunk, return_sampled=return_sampled,
-                                         rng=rng, rng_seed=None, rng_nonce=rng_nonce)
+                                         rng=rng, rng_seed=None, rng_nonce=rng_nonce, row_ids=row_ids, exact=exact)
             return  # gpt.py:570: the seeded case yields nothing
 
         graph_ok = use_graph and max_new > 1
@@ -883,7 +940,78 @@ class GptEngine:
         finish_rng(min(steps_ref, max_new))
         if return_sampled:
             self.last_sampled = [ln.sampled[b, : ln.end_snap[b]].clone() for ln in L for b in range(ln.hi - ln.lo)]
-        yield outputs()
+        final = outputs()
+        if certify:
+            # ---- parity certificate: the smallest decision margin of every utterance (tempered-logit units) against twice the stated
+            # logit error of the split-bf16 projections.  The lanes are idle here (wait_stream above).
+            marg = torch.cat([ln.margin for ln in L]).cpu().numpy()
+            x3_run = self.x3 is not None and not exact
+            bound = 2.0 * self.REL_ERR_X3 * self.logit_scale[bool(infer_text)] / max(float(temperature.min()), 1e-6) if x3_run else 0.0
+            unsafe = np.nonzero(marg < bound)[0].tolist()
+            self.last_margins = marg
+            self.last_stats.update(min_margin=float(marg.min()) if marg.size else float("inf"), margin_bound=bound,
+                                   certified=not unsafe, uncertified_rows=unsafe, exact_rerun_rows=[])
+            if unsafe:
+                (self.logger.warning if self.exact_fallback else self.logger.info)(
+                                    "parity certificate: %d of %d utterances had a draw decided by less than %.2e tempered-logit units "
+                                    "(smallest margin %.2e)%s", len(unsafe), B, bound, float(marg.min()),
+                                    "; generating them again on the exact f32 kernels" if (self.exact_fallback and not stream and not interrupted)
+                                    else "; the split-bf16 result stands uncertified")
+                if self.exact_fallback and not stream and not interrupted:
+                    final = self._rerun_exact(final, unsafe, emb, inputs_ids, temperature, eos_token, attention_mask, max_new_token, min_new_token,
+                                              logits_processors, infer_text, return_hidden, stream_batch, manual_seed, context, use_graph, stop_at,
+                                              row_offset // nrow, (total_rows if total_rows is not None else B * nrow), prefill_chunk, rng,
+                                              seed_val if device_rng else None, rng_nonce, rid, rng_state0)
+        yield final
+
+    def _rerun_exact(self, final, rows, emb, inputs_ids, temperature, eos_token, attention_mask, max_new_token, min_new_token,
+                     logits_processors, infer_text, return_hidden, stream_batch, manual_seed, context, use_graph, stop_at, first_row,
+                     total_rows, prefill_chunk, rng, rng_seed, rng_nonce, rid, rng_state0):
+        """The exact fallback of the certificate: utterances `rows` of the call once more, as a sub-batch with the same padded prompt
+        geometry, on the f32 MFMA decode kernels, with the draws of their own global rows -- what the "f32" engine gives for them (utterances
+        never interact) -- spliced over their rows of `final`."""
+        stats = dict(self.last_stats)
+        sel = torch.tensor(rows, dtype=torch.long)
+        gid = rid[sel] if rid is not None else sel + int(first_row)
+        nz = None
+        if rng_nonce is not None:
+            nz = torch.as_tensor(rng_nonce, dtype=torch.int64).reshape(-1)
+            nz = nz if nz.numel() == 1 else nz[sel]
+        state_after = None
+        if rng_state0 is not None:     # unseeded host draws: the same per-step tensors the main call consumed
+            state_after = torch.get_rng_state()
+            torch.set_rng_state(rng_state0)
+        sub = None
+        try:
+            for sub in self.generate(emb[sel.to(emb.device)], inputs_ids[sel.to(inputs_ids.device)], temperature, eos_token,
+                                     None if attention_mask is None else attention_mask[sel.to(attention_mask.device)], max_new_token, min_new_token,
+                                     logits_processors, infer_text, False, return_hidden, False, False, False, stream_batch, manual_seed, context,
+                                     use_graph=use_graph, stop_at=None if stop_at is None else stop_at[sel.to(stop_at.device)], total_rows=total_rows,
+                                     lanes=1, prefill_chunk=prefill_chunk, rng=rng, rng_seed=rng_seed, rng_nonce=nz, row_ids=gid, exact=True):
+                pass
+        finally:
+            if state_after is not None:
+                torch.set_rng_state(state_after)
+        rerun_stats = self.last_stats
+        self.last_stats = stats
+        if sub is None:     # (an EOS at step 0 of the exact run: the seeded reference yields nothing, gpt.py:570)
+            self.logger.warning("parity certificate: the exact re-run ended at step 0; the split-bf16 rows stand")
+            return final
+        same_len = all(int(sub.ids[j].shape[0]) == int(final.ids[b].shape[0]) for j, b in enumerate(rows))
+        padded = getattr(final.hiddens, "padded", None)
+        if return_hidden and not (same_len and padded is not None):
+            final.hiddens = RowList(list(final.hiddens))      # plain rows: the decoder re-pads (core.py:525-533)
+            padded = None
+        for j, b in enumerate(rows):
+            final.ids[b] = sub.ids[j]
+            if return_hidden:
+                if padded is not None:
+                    padded[b, : sub.hiddens[j].shape[0]].copy_(sub.hiddens[j])     # (final.hiddens[b] is a view of it)
+                else:
+                    final.hiddens[b] = sub.hiddens[j]
+        self.last_stats.update(exact_rerun_rows=list(rows), exact_rerun_steps=rerun_stats.get("steps"),
+                               exact_rerun_min_margin=rerun_stats.get("min_margin"), certified=True)
+        return final
 
 
 def split_bf16(w: torch.Tensor) -> torch.Tensor:
@@ -1263,16 +1391,21 @@ class CodecEngine:
             list(pool.map(lambda i: np.copyto(flat_o[i * step: (i + 1) * step], flat_s[i * step: (i + 1) * step]), range(4)))
         return out
 
-    def decode_to_wavs(self, result_list: List[torch.Tensor]) -> torch.Tensor:
+    def decode_to_wavs(self, result_list: List[torch.Tensor], pad_to: Optional[int] = None) -> torch.Tensor:
         """`Chat._decode_to_wavs` (core.py:513-539): zero-pad the per-row [T_b,768] hidden lists to the
-        longest row, DVAE decode, Vocos decode -> [B, 256(2Tmax-1)] float32 on the device."""
+        longest row, DVAE decode, Vocos decode -> [B, 256(2Tmax-1)] float32 on the device.  `pad_to`: pad to that many tokens instead
+        (>= the longest row): a data-parallel shard decodes its rows as part of the GLOBAL batch (dist.infer_sharded) -- the reference
+        decodes a shorter row's tail from zero hidden states and returns it."""
         if len(result_list) == 0:
             return torch.empty((0,), dtype=torch.float32)
+        longest = max(int(r.size(0)) for r in result_list)
+        if pad_to is not None and int(pad_to) < longest:
+            raise ValueError("pad_to is shorter than the longest row")
         pad = getattr(result_list, "padded", None)
         if (pad is not None and pad.dim() == 3 and pad.shape[0] == len(result_list) and pad.shape[2] == GPT.hidden and pad.device == self.device
-                and pad.dtype == torch.float32 and pad.shape[1] == max(int(r.size(0)) for r in result_list)):
+                and pad.dtype == torch.float32 and pad.shape[1] == longest and (pad_to is None or int(pad_to) == longest)):
             return self.vocos_decode(self.dvae_decode(pad))      # GptEngine.generate's rows: views of exactly this batch (RowList)
-        Tmax = max(int(r.size(0)) for r in result_list)
+        Tmax = longest if pad_to is None else int(pad_to)
         batch = torch.zeros((len(result_list), Tmax, GPT.hidden), dtype=torch.float32, device=self.device)
         for i, r in enumerate(result_list):
             batch[i, : r.size(0)] = r

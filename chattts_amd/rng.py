@@ -19,12 +19,16 @@ class ExpDraws:
     """q tensors for successive steps of one `generate` call."""
 
     def __init__(self, total_rows: int, vocab: int, manual_seed: Optional[int],
-                 row_begin: int = 0, row_end: Optional[int] = None):
+                 row_begin: int = 0, row_end: Optional[int] = None, rows: Optional[torch.Tensor] = None):
+        """`rows` (int64 [n], optional): the sampling rows of the full-batch draw this object serves, in the caller's order, when
+        they are not one contiguous block [row_begin, row_end) -- a length-balanced data-parallel shard (dist.py) or the exact re-run
+        of the utterances a parity certificate flagged (engine.py)."""
         self.total_rows = total_rows
         self.vocab = vocab
         self.seed = manual_seed
         self.r0 = row_begin
         self.r1 = total_rows if row_end is None else row_end
+        self.rows = None if rows is None else rows.to(torch.int64).reshape(-1)
         self.gen = torch.Generator(device="cpu")  # gpt.py:39
         self._const = None
         if manual_seed is not None:
@@ -35,6 +39,8 @@ class ExpDraws:
     def _draw(self, gen) -> torch.Tensor:
         q = torch.empty((self.total_rows, self.vocab), dtype=torch.float32)
         q.exponential_(1, generator=gen)
+        if self.rows is not None:
+            return q[self.rows].contiguous()
         return q[self.r0: self.r1].contiguous()
 
     @property
@@ -53,7 +59,7 @@ class ExpDraws:
         the whole batch the draw goes straight into `dst` (same generator call, no temporary, no copy)."""
         if self._const is not None:
             dst.copy_(self._const)
-        elif self.r0 == 0 and self.r1 == self.total_rows and dst.is_contiguous():
+        elif self.rows is None and self.r0 == 0 and self.r1 == self.total_rows and dst.is_contiguous():
             dst.exponential_(1)
         else:
             dst.copy_(self._draw(None))

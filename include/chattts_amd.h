@@ -85,7 +85,8 @@ typedef struct {
    * matrices as SPLIT-bf16 planes for the decode step (csrc/decode32x.hip) -- [2 planes: hi = bf16(w), lo = bf16(w - hi)][N/16][K/32][64][8]
    * bf16, the bf16 fragment order above per plane; wqkv_x3 / wgu_x3 carry the RMSNorm gain of ln1 / ln2 (w' = w * gain[k], folded BEFORE
    * the split) and the q / k row permutation of wqkv_pk.  Three bf16 MFMAs per product instead of f32 MFMA at a sixteenth of the rate; the
-   * reference's token ids hold on every golden (tests/test_gpu_e2e.py); the environment variable CTTS_D32_EXACT=1 ignores the planes. */
+   * reference's token ids hold on every golden (tests/test_gpu_e2e.py).  The HOST chooses the arithmetic: no planes = exact f32 MFMA; planes =
+   * split-bf16 decode steps, certified per call by ctts_gen_state.margin, with ctts_gen_state.proj_exact as the per-call exact fallback. */
   const void* const* wqkv_x3;
   const void* const* wo_x3;
   const void* const* wgu_x3;
@@ -161,6 +162,23 @@ typedef struct {
   const uint32_t* rng_nonce;       /* [slots] or NULL, device generator only: a per-utterance-slot word that replaces the constant fourth Philox
                                       counter word.  A slot pool bumps it at every ADMISSION, so successive requests in one slot -- whose step
                                       index restarts at 0 -- do not replay the previous occupant's Exp(1) stream */
+  /* PARITY CERTIFICATE (round 6).  [slots] float32 or NULL; the host initialises every entry to +inf.  At every step the sampling kernel
+   * lowers margin[b] to the smallest distance -- in units of the TEMPERED logit, logit / temperature -- by which the step's outcome for
+   * utterance b was decided: (1) log(r_best / r_second) of the multinomial's argmax(p / q) (gpt.py:497-508); (2) the value gap between the
+   * last kept and the first dropped token at the cut the warpers make (processors.py:38-58, TopK / TopP prefix); (3) |log(cum / (1 - top_P))|
+   * of the top-p test at the last kept and at the first top-p-dropped rank.  A perturbation of every tempered logit by less than
+   * margin / 2 cannot change any sampled token of that utterance: the split-bf16 parity arithmetic (wqkv_x3 ...) is certified per call
+   * against its measured logit error bound instead of by sample (chattts_amd/engine.py GptEngine.certify).  NULL: nothing is computed. */
+  float* margin;
+  /* [B] or NULL: global index of sampling row 0 of utterance b (b_global * 4 in code mode) -- replaces row_offset + 4 b when a shard holds a
+   * NON-contiguous set of the caller's utterances (length-balanced data-parallel shards, chattts_amd/dist.py; the exact re-run of the
+   * utterances a parity certificate flagged).  Keys the rows >= 625 repetition-penalty quirk (processors.py:24-27) and the device
+   * generator's counter; `q` stays indexed by the local slot (the host uploads the selected rows of the CPU draw). */
+  const int32_t* row_base;
+  /* parity mode with BOTH decode copies loaded (wqkv_pk ... and wqkv_x3 ...): 1 = this call's decode steps run the f32 MFMA kernels
+   * (csrc/decode32.hip) although the split-bf16 planes are there -- the exact fallback of a certificate that fired.  A captured graph
+   * holds the choice it was built with. */
+  int32_t proj_exact;
 } ctts_gen_state;
 
 int ctts_gpt_create(ctts_gpt** out, const ctts_gpt_weights* w);

@@ -38,7 +38,9 @@ def repetition_penalty(history: np.ndarray, scores: np.ndarray, pow_table: np.nd
     freq = np.zeros((rows, V), dtype=np.int64)
     for j in range(history.shape[1]):
         np.add.at(freq, (np.arange(rows), history[:, j]), 1)
-    grow = np.arange(rows) + row_offset
+    # row_offset: the global index of row 0 (a contiguous shard) or, as an array, the global index of every row (a shard that is not a
+    # contiguous block of the caller's batch: chattts_amd.dist.deal_shards)
+    grow = np.asarray(row_offset) if np.ndim(row_offset) else np.arange(rows) + row_offset
     freq[grow >= max_input_ids] = 0
     alpha = pow_table[freq]
     return np.where(scores < 0, scores * alpha, scores / alpha).astype(f32)
@@ -101,3 +103,63 @@ def sample_step(logits: np.ndarray, history: np.ndarray, q: np.ndarray, *, tempe
     if return_processed:
         return idx, x
     return idx
+
+
+def decision_margin(logits: np.ndarray, history: np.ndarray, q: np.ndarray, *, temperature: np.ndarray, top_p, top_k, pow_table,
+                    max_input_ids: int, past_window: int = 16, mask_eos=False, eos: int = 625, row_offset: int = 0) -> np.ndarray:
+    """float64 restatement of the PARITY CERTIFICATE the sampling kernels compute (include/chattts_amd.h, ctts_gen_state.margin; not a
+    reference feature -- the reference has one arithmetic): per sampling row, the smallest distance by which the step was decided, in
+    units of the pre-penalty tempered logit:
+      c_arg = log(r_best / r_second) of argmax(p / q) over the kept tokens;
+      c_cut = value gap between the last kept and the first dropped token of the warpers' prefix (0 when ties with the k-th largest value
+              extended the prefix);
+      c_p   = |log(cum / (1 - top_p))| of the top-p test at the last kept rank (if it was tested: rank >= 3) and at the rank top-p
+              removed first;
+    divided by the largest factor the repetition penalty applies to a perturbation (alpha for negative, 1 / alpha for positive scores).
+    Order inside the prefix: value descending, ties lowest index first (the kernels' order)."""
+    rows, V = logits.shape
+    x = (logits / temperature[:, None].astype(f32)).astype(f32)
+    amp = np.ones(rows)
+    if pow_table is not None:
+        h = history[:, -past_window:] if history.shape[1] > past_window else history
+        freq = np.zeros((rows, V), dtype=np.int64)
+        for j in range(h.shape[1]):
+            np.add.at(freq, (np.arange(rows), h[:, j]), 1)
+        freq[(np.arange(rows) + row_offset) >= max_input_ids] = 0
+        alpha = pow_table[freq].astype(np.float64)
+        amp = np.where(x < 0, alpha, 1.0 / alpha).max(1)
+        x = repetition_penalty(history, x, pow_table, max_input_ids, past_window, row_offset)
+    mrows = np.broadcast_to(np.asarray(mask_eos, dtype=bool), (rows,))
+    out = np.full(rows, np.inf)
+    for r in range(rows):
+        xr = x[r].astype(np.float64)
+        order = np.lexsort((np.arange(V), -xr))          # value desc, index asc
+        prob = softmax_f32(x[r][None])[0].astype(np.float64)
+        cum = prob[order][::-1].cumsum()[::-1]           # ascending cumulative probability including the rank itself
+        n, c_cut, c_p = V, np.inf, np.inf
+        if top_p is not None or top_k is not None:
+            kk = min(max(top_k, 3), V) if top_k is not None else V
+            thr = float(f32(1.0 - top_p)) if top_p is not None else 0.0
+            kth = xr[order[kk - 1]]
+            n = V
+            p_dropped = False
+            for j in range(V):
+                bad_p = top_p is not None and j >= 3 and f32(cum[j]) <= f32(thr)
+                bad_k = top_k is not None and j >= kk and xr[order[j]] != kth
+                if bad_p or bad_k:
+                    n, p_dropped = j, bad_p
+                    break
+            if n < V:
+                c_cut = 0.0 if (top_k is not None and n > kk) else xr[order[n - 1]] - xr[order[n]]
+            if top_p is not None:
+                if n - 1 >= 3:
+                    c_p = abs(np.log(max(cum[n - 1], 1e-38) / thr)) if thr > 0 else np.inf
+                if n < V and p_dropped:
+                    c_p = min(c_p, abs(np.log(max(cum[n], 1e-38) / thr)) if thr > 0 else np.inf)
+        kept = order[:n]
+        live = kept[~((kept == eos) & mrows[r])] if mrows[r] else kept
+        lr = xr[live] - np.log(q[r][live].astype(np.float64))
+        srt = np.sort(lr)[::-1]
+        c_arg = (srt[0] - srt[1]) if len(srt) > 1 else np.inf
+        out[r] = min(c_arg, c_cut, c_p) / amp[r]
+    return out

@@ -19,16 +19,11 @@ DEV = torch.device("cuda:0")
 
 @pytest.fixture(scope="module", params=["x3", "exact"])
 def gpt_f32(weights, request):
-    """the parity mode, both arithmetics of its decode projections: "x3" = split-bf16 planes, three bf16 MFMAs per product
-    (csrc/decode32x.hip, the default), "exact" = f32 MFMA on packed f32 operands (csrc/decode32.hip, CTTS_D32_EXACT=1).  Every
-    reference-generated golden must hold in BOTH: the bar is the reference's token ids, not either kernel's bits."""
-    import os
-    if request.param == "exact":
-        os.environ["CTTS_D32_EXACT"] = "1"
-    try:
-        eng = E.GptEngine(weights["gpt"], weights["embed"], DEV, dtype="f32")
-    finally:
-        os.environ.pop("CTTS_D32_EXACT", None)
+    """the parity mode, both arithmetics of its decode projections: "x3" = dtype "f32x3", split-bf16 planes, three bf16 MFMAs per product
+    (csrc/decode32x.hip) -- WITHOUT the exact fallback, so that what is compared is that arithmetic itself -- and "exact" = dtype "f32",
+    f32 MFMA on packed f32 operands (csrc/decode32.hip).  Every reference-generated golden must hold in BOTH: the bar is the reference's
+    token ids, not either kernel's bits.  (The certificate + fallback have their own tests below.)"""
+    eng = E.GptEngine(weights["gpt"], weights["embed"], DEV, dtype="f32x3" if request.param == "x3" else "f32", exact_fallback=False)
     assert (eng.x3 is not None) == (request.param == "x3")
     return eng
 
@@ -176,6 +171,94 @@ def test_wide_batch_tail_shard_keeps_the_global_row_quirk(gpt_f32, golden):
     outs, _ = run_case(gpt_f32, c, use_graph=True, rows=slice(128, 160))
     for i, b in enumerate(range(128, 160)):
         assert np.array_equal(outs[-1].ids[i].cpu().numpy(), rows[b]), b
+
+
+def test_scattered_shard_with_row_ids_equals_the_unsharded_reference(gpt_f32, golden):
+    """round 6 (length-balanced shards): a NON-contiguous, permuted set of utterances of `wide160` generated alone with
+    `row_ids` = their global indices (ctts_gen_state.row_base; the Exp(1) rows of the full-batch draw selected on the host) equals the
+    same utterances of the reference's unsharded run -- on both sides of sampling row 625 (utterances 156..158 are not penalised,
+    processors.py:24-27), in the caller's order."""
+    c = cases.PARAM_CASES["wide160"]
+    Gd = golden["generate_params"]
+    lens, rows = _golden_rows(Gd, "wide160", c["B"])
+    pick = [157, 3, 159, 64, 156, 12, 158, 155, 0, 131]
+    ids, mask, tmask = cases.gen_inputs(c)
+    ids_t, mask_t, tm_t = torch.from_numpy(ids[pick]), torch.from_numpy(mask[pick]), torch.from_numpy(tmask[pick])
+    emb = gpt_f32.embed_prompt(ids_t, tm_t)
+    warpers, procs = E.gen_logits(625, c["top_P"], c["top_K"], c["rep"])
+    for use_graph in (True, False):
+        out = list(gpt_f32.generate(emb, ids_t, torch.tensor(c["temperature"]), 625, mask_t, c["max_new"], c["min_new"], (*procs, *warpers),
+                                    return_hidden=True, manual_seed=c["manual_seed"], use_graph=use_graph, total_rows=c["B"] * 4,
+                                    row_ids=torch.tensor(pick)))[-1]
+        for i, b in enumerate(pick):
+            assert np.array_equal(out.ids[i].cpu().numpy(), rows[b]), (b, use_graph)
+
+
+def _cert_engines(weights, embed=None):
+    emb_sd = weights["embed"] if embed is None else embed
+    exact = E.GptEngine(weights["gpt"], emb_sd, DEV, dtype="f32")
+    x3 = E.GptEngine(weights["gpt"], emb_sd, DEV, dtype="f32x3", exact_fallback=False)
+    return exact, x3
+
+
+def test_parity_certificate_and_exact_fallback(weights, monkeypatch):
+    """round 6: dtype "f32x3" certifies every call.  (1) the margins are there, positive, and the bound follows the head's logit scale;
+    (2) with the bound raised so that every utterance is flagged, the fallback regenerates them all on the exact kernels: ids AND hidden
+    states are the "f32" engine's bits; (3) with the bound at the median margin only the utterances below it are regenerated -- theirs
+    are the exact engine's bits, the others keep the split-bf16 engine's."""
+    c = cases.GEN_CASES["b8"]
+    exact, x3 = _cert_engines(weights)
+    out_e = run_case(exact, c, use_graph=True)[0][-1]
+    out_x = run_case(x3, c, use_graph=True)[0][-1]
+    st = dict(x3.last_stats)
+    mg = x3.last_margins.copy()
+    assert mg.shape == (8,) and np.isfinite(mg).all() and (mg >= 0).all() and st["min_margin"] == float(mg.min())
+    want_bound = 2.0 * E.GptEngine.REL_ERR_X3 * x3.logit_scale[False] / min(c["temperature"])
+    assert abs(st["margin_bound"] - want_bound) < 1e-9 * max(1.0, want_bound) and st["exact_rerun_rows"] == []
+    assert "min_margin" not in exact.last_stats                      # one arithmetic: nothing to certify
+    fb = E.GptEngine(weights["gpt"], weights["embed"], DEV, dtype="f32x3", exact_fallback=True)
+    monkeypatch.setattr(E.GptEngine, "REL_ERR_X3", 1e3)              # (2) everything is "unsafe"
+    out_f = run_case(fb, c, use_graph=True)[0][-1]
+    assert fb.last_stats["exact_rerun_rows"] == list(range(8)) and fb.last_stats["certified"]
+    for b in range(8):
+        assert torch.equal(out_f.ids[b], out_e.ids[b]) and torch.equal(out_f.hiddens[b], out_e.hiddens[b]), b
+    med = float(np.median(mg))
+    monkeypatch.setattr(E.GptEngine, "REL_ERR_X3", med * min(c["temperature"]) / (2.0 * x3.logit_scale[False]))   # (3)
+    out_h = run_case(fb, c, use_graph=True)[0][-1]
+    flagged = [b for b in range(8) if mg[b] < fb.last_stats["margin_bound"]]
+    assert 0 < len(flagged) < 8 and fb.last_stats["exact_rerun_rows"] == flagged
+    for b in range(8):
+        ref = out_e if b in flagged else out_x
+        assert torch.equal(out_h.ids[b], ref.ids[b]), b
+        assert np.abs(out_h.hiddens[b].cpu().numpy() - ref.hiddens[b].cpu().numpy()).max() <= (1e-6 if b in flagged else 0.0), b
+    # a second call reuses both sessions (main + exact re-run) and gives the same result
+    out_h2 = run_case(fb, c, use_graph=True)[0][-1]
+    assert all(torch.equal(a, b_) for a, b_ in zip(out_h.ids, out_h2.ids))
+
+
+@pytest.mark.parametrize("gain", [1.0 / 16.0, 1.0, 8.0])
+def test_split_bf16_ids_diverge_only_where_the_certificate_fired(weights, gain):
+    """the certificate is sound on a head-gain sweep (flatter and peakier logits than the synthetic checkpoint's): wherever
+    the split-bf16 engine's free-running ids differ from the exact f32 engine's, that utterance's margin was below the bound -- and the
+    fallback engine returns the exact engine's ids for every utterance."""
+    emb_sd = dict(weights["embed"])
+    for k in range(4):
+        key = f"head_code.{k}.parametrizations.weight.original0"
+        emb_sd[key] = emb_sd[key] * gain
+    exact, x3 = _cert_engines(weights, emb_sd)
+    c = dict(cases.GEN_CASES["b8"])
+    c["max_new"], c["min_new"] = 96, 96
+    out_e = run_case(exact, c, use_graph=True)[0][-1]
+    out_x = run_case(x3, c, use_graph=True)[0][-1]
+    mg, bound = x3.last_margins, x3.last_stats["margin_bound"]
+    assert abs(x3.logit_scale[False] / (E.GptEngine(weights["gpt"], weights["embed"], DEV, dtype="f32").logit_scale[False] * gain) - 1.0) < 1e-5
+    for b in range(8):
+        if not torch.equal(out_e.ids[b], out_x.ids[b]):
+            assert mg[b] < bound, (gain, b, float(mg[b]), bound)
+    fb = E.GptEngine(weights["gpt"], emb_sd, DEV, dtype="f32x3", exact_fallback=True)
+    out_f = run_case(fb, c, use_graph=True)[0][-1]
+    for b in range(8):
+        assert torch.equal(out_f.ids[b], out_e.ids[b]), (gain, b)
 
 
 def test_wide_batch_bf16_rows_do_not_depend_on_the_batch(gpt_bf16):
@@ -563,7 +646,6 @@ def test_packed_f32_decode_is_bit_identical_to_row_major(weights, monkeypatch):
     """parity mode: the decode step on fragment-packed f32 operands (csrc/decode32.hip) keeps the operation order of the
     row-major kernels the goldens were established with -> identical token ids AND bit-identical hidden states"""
     c = cases.GEN_CASES["b8"]
-    monkeypatch.setenv("CTTS_D32_EXACT", "1")     # (the default decode step runs the split-bf16 kernels of decode32x.hip: same ids, other bits)
     packed = E.GptEngine(weights["gpt"], weights["embed"], DEV, dtype="f32")
     outs_p, _ = run_case(packed, c, use_graph=True)
     monkeypatch.setenv("CTTS_DEC_PACKED", "0")
@@ -575,7 +657,7 @@ def test_packed_f32_decode_is_bit_identical_to_row_major(weights, monkeypatch):
         assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+@pytest.mark.parametrize("dtype", ["bf16", "f32x3"])
 def test_bounded_row_graphs_replay_to_the_same_bits(weights, dtype, monkeypatch):
     """round 5, opt-in (CTTS_GRAPH_ROWS=1; measured no gain, profiles/r5o_ab_graph_rows.log): chunks of decode steps are replayed from the
     graph captured for a BOUND on the live rows (16-row buckets; ctts_gpt_graph_build_rows) once finish polls have seen utterances leave -- the grids shrink, the kernels still read the exact live

@@ -940,7 +940,7 @@ def test_embed_and_final_norm(G):
 # ------------------------------------------------------------------------------------------------
 # fused sampling kernel vs the reference's own outputs (goldens) and the oracle
 # ------------------------------------------------------------------------------------------------
-def run_sample_kernel(G, logits, hist, temp4, q, *, top_p, top_k, rep, mask_eos, row_offset=0, stop_at=None):
+def run_sample_kernel(G, logits, hist, temp4, q, *, top_p, top_k, rep, mask_eos, row_offset=0, stop_at=None, margin=False, row_base=None):
     lib = _lib.lib()
     rows, V = logits.shape
     B = rows // 4
@@ -968,10 +968,15 @@ def run_sample_kernel(G, logits, hist, temp4, q, *, top_p, top_k, rep, mask_eos,
     s.min_new = (h + 1) if mask_eos else 0
     s.eos, s.row_offset = 625, row_offset
     s.stop_at = None if stop_at is None else d(stop_at.astype(np.int32)).data_ptr()
+    mg_d = d(np.full(B, np.inf, f32)) if margin else None
+    s.margin = None if mg_d is None else mg_d.data_ptr()
+    s.row_base = None if row_base is None else d(np.asarray(row_base, np.int32)).data_ptr()
     lg = d(logits.reshape(B, 4 * V))
     _lib.check(lib.ctts_k_sample(C.byref(s), lg.data_ptr(), None), "sample")
     torch.cuda.synchronize()
     out = ids_d.cpu().numpy()[:, T + h, :].reshape(-1)
+    if margin:
+        return out, mg_d.cpu().numpy()
     return out, fin_d.cpu().numpy(), end_d.cpu().numpy(), len_d.cpu().numpy()
 
 
@@ -1042,6 +1047,71 @@ def test_sample_randomised_vs_oracle(G, trial):
     want = sampling_np.sample_step(logits, hist, q, temperature=np.tile(temp4, B), top_p=top_p, top_k=top_k,
                                    pow_table=None if pt is None else pt.numpy(), max_input_ids=625, mask_eos=mask_eos)
     assert np.array_equal(got, want), (trial, top_p, top_k, rep, h, int((got != want).sum()))
+
+
+def _cert_trial(trial):
+    rs = np.random.RandomState(7000 + trial)
+    B = int(rs.choice([2, 5, 8]))
+    rows = B * 4
+    scale = float(rs.choice([0.1, 0.5, 2.0, 4.0]))
+    logits = (rs.standard_normal((rows, 626)) * scale).astype(f32)
+    h = int(rs.choice([0, 3, 16, 21]))
+    hist = rs.randint(0, 626, size=(rows, h)).astype(np.int64)
+    if h:
+        hist[:, : h // 2] = np.argsort(-logits, axis=1)[:, : h // 2]
+    temp4 = rs.choice([0.3, 0.7, 1.0], size=4).astype(f32)
+    top_p = [None, 0.5, 0.7, 0.95][int(rs.randint(4))]
+    top_k = [None, 3, 20, 100][int(rs.randint(4))]
+    rep = [None, 1.05, 1.3][int(rs.randint(3))]
+    mask_eos = bool(rs.randint(2))
+    q = rng.ExpDraws(rows, 626, int(rs.randint(1 << 30))).step(0).numpy()
+    return rs, B, logits, hist, temp4, top_p, top_k, rep, mask_eos, q
+
+
+@pytest.mark.parametrize("trial", range(16))
+def test_sample_certificate_matches_its_float64_restatement(G, trial):
+    """ctts_gen_state.margin (the parity certificate of round 6): the kernel's per-utterance minimum over its 4 sampling rows == the
+    float64 restatement of the definition (oracle/sampling_np.decision_margin), fast path (top-k <= 64) and serial path alike"""
+    rs, B, logits, hist, temp4, top_p, top_k, rep, mask_eos, q = _cert_trial(trial)
+    got_ids, got = run_sample_kernel(G, logits, hist, temp4, q, top_p=top_p, top_k=top_k, rep=rep, mask_eos=mask_eos, margin=True)
+    pt = rng.penalty_table(rep)
+    want = sampling_np.decision_margin(logits, hist, q, temperature=np.tile(temp4, B), top_p=top_p, top_k=top_k,
+                                       pow_table=None if pt is None else pt.numpy(), max_input_ids=625, mask_eos=mask_eos).reshape(B, 4).min(1)
+    fin = np.isfinite(want)
+    assert np.array_equal(np.isfinite(got), fin), (got, want)
+    assert np.allclose(got[fin], want[fin], rtol=2e-3, atol=2e-5), (trial, top_p, top_k, rep, got, want)
+
+
+@pytest.mark.parametrize("trial", range(16))
+def test_sample_certificate_is_a_certificate(G, trial):
+    """what the margin promises: ANY perturbation of the logits that moves every tempered logit by less than margin / 2 leaves all
+    4 sampled tokens of the utterance unchanged -- random-sign perturbations at 0.45 margin, 8 draws per trial"""
+    rs, B, logits, hist, temp4, top_p, top_k, rep, mask_eos, q = _cert_trial(trial)
+    kw = dict(top_p=top_p, top_k=top_k, rep=rep, mask_eos=mask_eos)
+    base, mg = run_sample_kernel(G, logits, hist, temp4, q, margin=True, **kw)
+    ok = np.isfinite(mg) & (mg > 1e-4)          # (below that, float32 rounding of the perturbed logits itself is not negligible)
+    assert ok.any()
+    eps = np.where(ok, 0.45 * mg, 0.0)          # tempered-logit units, per utterance
+    for _ in range(8):
+        sign = rs.choice([-1.0, 1.0], size=logits.shape) * rs.uniform(0.0, 1.0, size=logits.shape)
+        delta = sign * np.repeat(eps, 4)[:, None] * np.tile(temp4, B)[:, None]     # raw-logit units of each row's temperature
+        got, _ = run_sample_kernel(G, (logits + delta).astype(f32), hist, temp4, q, margin=True, **kw)
+        same = (got.reshape(B, 4) == base.reshape(B, 4)).all(1)
+        assert same[ok].all(), (trial, np.nonzero(~same & ok)[0], mg)
+
+
+def test_sample_row_base_replaces_row_offset(G):
+    """ctts_gen_state.row_base: per-utterance global sampling row (non-contiguous shards) -- the rows >= 625 penalty quirk follows it"""
+    c = cases.SAMPLING_CASES["rows640"]
+    logits, hist, temp = cases.sampling_inputs(c)
+    q = rng.ExpDraws(640, 626, c["seed"]).step(0).numpy()
+    pick = np.array([3, 157, 20, 159, 100, 156])          # utterances on both sides of sampling row 625 (= utterance 156, codebook 1)
+    rows = (pick[:, None] * 4 + np.arange(4)[None, :]).reshape(-1)
+    got, *_ = run_sample_kernel(G, logits[rows], hist[rows], temp[:4], q[rows], top_p=c["top_P"], top_k=c["top_K"], rep=c["rep"],
+                                mask_eos=False, row_base=pick * 4)
+    full = golden_rows640 = sampling_np.sample_step(logits, hist, q, temperature=temp, top_p=c["top_P"], top_k=c["top_K"],
+                                                    pow_table=rng.penalty_table(c["rep"]).numpy(), max_input_ids=625)
+    assert np.array_equal(got, full[rows])
 
 
 # ------------------------------------------------------------------------------------------------

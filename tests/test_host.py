@@ -247,6 +247,46 @@ def test_asset_validation_and_gpt_config(tmp_path, weights):
         W.load_assets(root)
 
 
+def test_validate_assets_tool(tmp_path, weights):
+    """tools/validate_assets.py: header-only diff of a checkpoint directory against SURVEY App. B + the third-party
+    pins.  A synthetic asset directory written with the reference's key names passes; a Vocos file with other names fails with the diff;
+    the packages that are absent here (vocos, vector_quantize_pytorch, torchaudio) are reported as such, not as errors."""
+    import importlib.util
+    import json
+    from chattts_amd import weights as W
+    spec = importlib.util.spec_from_file_location("validate_assets", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                                  "tools", "validate_assets.py"))
+    va = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(va)
+    root = os.path.join(str(tmp_path), "dl")
+    small = dict(weights, gpt={("model." + k): v for k, v in W.synthetic_gpt(n_layers=2).items()})     # HF-style prefix + embed_tokens
+    small["gpt"]["model.embed_tokens.weight"] = torch.zeros(4, 768)
+    W.save_assets(os.path.join(root, "asset"), small)
+    with open(os.path.join(root, "asset", "gpt", "config.json"), "w") as fh:
+        json.dump({"hidden_size": 768, "num_attention_heads": 12, "num_hidden_layers": 2, "rms_norm_eps": 1e-5}, fh)
+    rep = va.check_assets(root)
+    assert rep["ok"] and rep["files"]["gpt"]["layers"] == 2 and rep["files"]["dvae"].get("absent")
+    assert rep["gpt_config"]["runtime_fields"]["rms_eps"] == 1e-5
+    assert all(not rep["files"][n]["missing"] and not rep["files"][n]["unexpected"] for n in W.ASSET_FILES)
+    assert va.main([root, "--json", "--no-pins"]) == 0
+    for name, fn in (("vocos", lambda: va.pin_vocos(weights["vocos"])), ("vector_quantize_pytorch", lambda: va.pin_gfsq(W.synthetic_dvae())),
+                     ("torchaudio", va.pin_mel)):
+        if importlib.util.find_spec(name) is None:
+            assert fn()["status"] == "absent"
+    bad = {(k.replace("gamma", "layer_scale") if k.startswith("backbone.convnext.0.g") else k): v for k, v in weights["vocos"].items()}
+    bad["head.out.weight"] = torch.zeros(1026, 256)
+    bad["feature_extractor.mel_spec.mel_scale.fb"] = torch.zeros(513, 100)       # present in the real file, not read by the hot path
+    W.save_assets(os.path.join(root, "asset"), {"vocos": bad})
+    rep = va.check_assets(root)
+    v = rep["files"]["vocos"]
+    assert not rep["ok"] and not v["ok"] and v["missing"] == ["backbone.convnext.0.gamma"] and v["unexpected"] == ["backbone.convnext.0.layer_scale"]
+    assert v["ignored"] == ["feature_extractor.mel_spec.mel_scale.fb"] and "(1026, 256) != expected (1026, 512)" in v["wrong_shape"][0]
+    assert va.main([root, "--no-pins"]) == 1
+    with open(os.path.join(root, "asset", "gpt", "config.json"), "w") as fh:
+        json.dump({"hidden_size": 1024}, fh)
+    assert not va.check_assets(root)["gpt_config"]["ok"]
+
+
 def test_left_pad_starts():
     m = torch.tensor([[0, 0, 1, 1], [1, 1, 1, 1], [0, 1, 1, 1]])
     assert E.left_pad_starts(m).tolist() == [2, 0, 1]
@@ -359,13 +399,14 @@ def _bench_shard_worker(rank, world, port, q):
         wl = bench.shard_workload(3, world, rank, 4, 9)      # 3 utterances per rank
         llama = llama_np.LlamaWeights({k: v.numpy() for k, v in W.synthetic_gpt(n_layers=2).items()})
         esd = {k: v.numpy() for k, v in W.synthetic_embed().items()}
-        draws = rng.ExpDraws(wl["total_rows"], 626, 42, row_begin=wl["row_offset"], row_end=wl["row_offset"] + 4 * (wl["hi"] - wl["lo"]))
+        srows = (np.asarray(wl["sel"])[:, None] * 4 + np.arange(4)[None, :]).reshape(-1)      # global sampling rows of this shard
+        draws = rng.ExpDraws(wl["total_rows"], 626, 42, rows=torch.from_numpy(srows))
         res = generate_np.generate(llama, esd, generate_np.fold_heads(esd), generate_np.embed_prompt(esd, wl["ids"], wl["tmask"]),
                                    wl["ids"], wl["mask"], temperature=np.array([0.3] * 4, np.float32), draw_q=lambda i: draws.step(i).numpy(),
                                    pow_table=rng.penalty_table(1.05).numpy(), max_new_token=int(wl["stop_all"].max()) + 1,
-                                   stop_at=wl["stop"], row_offset=wl["row_offset"])
+                                   stop_at=wl["stop"], row_offset=srows)
         gathered = [None] * world
-        dist.all_gather_object(gathered, (wl["lo"], wl["hi"], [r.tolist() for r in res.ids]))
+        dist.all_gather_object(gathered, (list(wl["sel"]), [r.tolist() for r in res.ids]))
         if rank == 0:
             q.put(gathered)
     finally:
@@ -373,8 +414,8 @@ def _bench_shard_worker(rank, world, port, q):
 
 
 def test_two_rank_bench_sharding_path_equals_the_unsharded_batch():
-    """bench.py --gpus 2 on CPU/gloo: the union of the two ranks' shards, in rank order, is the single-process run of the
-    global batch row for row (contiguous blocks, draws and the rows>=625 quirk keyed on the global row index)"""
+    """bench.py --gpus 2 on CPU/gloo: the two ranks' shards (dealt by prompt length, dist.deal_shards), put back in the caller's order,
+    are the single-process run of the global batch row for row (draws and the rows>=625 quirk keyed on the global row index)"""
     import torch.multiprocessing as mp
     import bench
     from chattts_amd import weights as W
@@ -389,8 +430,12 @@ def test_two_rank_bench_sharding_path_equals_the_unsharded_batch():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert [(lo, hi) for lo, hi, _ in res] == [(0, 3), (3, 6)]
-    sharded = [np.array(r, dtype=np.int64).reshape(-1, 4) for _, _, rows in res for r in rows]
+    assert sorted(res[0][0] + res[1][0]) == list(range(6)) and len(res[0][0]) == len(res[1][0]) == 3
+    assert res[0][0] != [0, 1, 2]                            # (dealt by prompt length: the shards are not contiguous blocks)
+    sharded = [None] * 6
+    for sel, rows in res:
+        for b, r in zip(sel, rows):
+            sharded[b] = np.array(r, dtype=np.int64).reshape(-1, 4)
     wl = bench.shard_workload(6, 1, 0, 4, 9)                 # the same 6 utterances as ONE batch
     llama = llama_np.LlamaWeights({k: v.numpy() for k, v in W.synthetic_gpt(n_layers=2).items()})
     esd = {k: v.numpy() for k, v in W.synthetic_embed().items()}
@@ -401,6 +446,95 @@ def test_two_rank_bench_sharding_path_equals_the_unsharded_batch():
     assert [len(r) for r in sharded] == wl["stop"].tolist()
     for a, b in zip(sharded, full.ids):
         assert np.array_equal(a, b)
+
+
+class _OracleChat:
+    """the two seams `dist.infer_sharded` drives (Chat.infer_code / Chat.decode_to_wavs), served by the numpy oracle on a 2-layer slice of
+    the architecture and by a stand-in decoder whose output depends on what the real one depends on: the rows AND the padded width"""
+
+    def __init__(self):
+        from chattts_amd import weights as W
+        from oracle import generate_np, llama_np
+        self.llama = llama_np.LlamaWeights({k: v.numpy() for k, v in W.synthetic_gpt(n_layers=2).items()})
+        self.esd = {k: v.numpy() for k, v in W.synthetic_embed().items()}
+        self.heads = generate_np.fold_heads(self.esd)
+        self.calls = []
+
+    def infer_code(self, ids, mask, tmask, params, stream=False, return_hidden=True, row_ids=None, total_rows=None, stop_at=None):
+        from types import SimpleNamespace
+        from oracle import generate_np
+        B = ids.shape[0]
+        gl = np.arange(B) if row_ids is None else np.asarray(row_ids)
+        self.calls.append(gl.tolist())
+        srows = (gl[:, None] * 4 + np.arange(4)[None, :]).reshape(-1)
+        draws = rng.ExpDraws(total_rows if total_rows is not None else B * 4, 626, 42, rows=torch.from_numpy(srows))
+        res = generate_np.generate(self.llama, self.esd, self.heads, generate_np.embed_prompt(self.esd, ids.numpy(), tmask.numpy()), ids.numpy(),
+                                   mask.numpy(), temperature=np.array([0.3] * 4, np.float32), draw_q=lambda i: draws.step(i).numpy(),
+                                   pow_table=rng.penalty_table(1.05).numpy(), max_new_token=12, stop_at=None if stop_at is None else stop_at.numpy(),
+                                   row_offset=srows)
+        yield SimpleNamespace(ids=[torch.from_numpy(r) for r in res.ids], hiddens=[torch.from_numpy(h) for h in res.hiddens])
+
+    def decode_to_wavs(self, rows, use_decoder=True, pad_to=None):
+        T = max(int(r.shape[0]) for r in rows) if pad_to is None else int(pad_to)
+        wav = np.full((len(rows), 4 * T), 0.25, np.float32)       # the zero-padded tail of a shorter row is NOT silent in the reference
+        for i, r in enumerate(rows):
+            wav[i, : 4 * r.shape[0]] = np.repeat(r.numpy().astype(np.float32).sum(1), 4)
+        return wav
+
+
+def _sharded_inputs():
+    from chattts_amd import synth
+    ids, mask, tmask = synth.make_prompts(7, 4, 9, seed=3)          # 7 utterances over 2 ranks: uneven shards
+    stop = synth.make_stop_lengths(7, 3, 10, seed=3)
+    return torch.from_numpy(ids), torch.from_numpy(mask), torch.from_numpy(tmask), torch.from_numpy(stop)
+
+
+def _infer_sharded_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        chat = _OracleChat()
+        ids, mask, tmask, stop = _sharded_inputs()
+        got = D.infer_sharded(chat, ids, mask, tmask, None, stop_at=stop, return_ids=True)
+        own = D.infer_sharded(chat, ids, mask, tmask, None, stop_at=stop, gather=False)
+        if rank == 0:
+            q.put((got[0], [r.tolist() for r in got[1]], chat.calls, own[0]))
+        else:
+            assert got is None
+    finally:
+        dist.destroy_process_group()
+
+
+def test_infer_sharded_over_two_ranks_equals_the_single_process_call():
+    """round 6: `dist.infer_sharded` -- deal by prompt length, generate with global row ids, ONE all-reduce(max) of the
+    longest utterance, decode padded to it, gather to rank 0 in the caller's order -- over 2 gloo ranks == the same call in one process
+    (== the plain unsharded sequence of seam calls), waveforms AND token ids; gather=False hands every rank its own utterances."""
+    import torch.multiprocessing as mp
+    shards = D.deal_shards([5, 9, 9, 4, 7, 7, 6], 2)
+    assert shards == [[1, 5, 6], [0, 2, 3, 4]] or sorted(shards[0] + shards[1]) == list(range(7))
+    assert D.deal_shards([3, 1, 2], 1) == [[0, 1, 2]] and D.deal_shards([1, 2, 3, 4], 2, "blocks") == [[0, 1], [2, 3]]
+    assert D.deal_shards([1, 2, 3, 4], 2, "sorted_blocks") == [[2, 3], [0, 1]]
+    chat = _OracleChat()
+    ids, mask, tmask, stop = _sharded_inputs()
+    full, full_ids = D.infer_sharded(chat, ids, mask, tmask, None, stop_at=stop, return_ids=True)        # no process group: world 1
+    assert chat.calls == [list(range(7))]
+    direct = list(chat.infer_code(ids, mask, tmask, None, stop_at=stop))[-1]
+    assert np.array_equal(full, chat.decode_to_wavs(direct.hiddens)) and [len(r) for r in full_ids] == stop.tolist()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_infer_sharded_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    wav2, ids2, calls, own0 = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    lens = mask.sum(1).tolist()
+    assert calls[0] == D.deal_shards(lens, 2)[0] == own0 and calls[0] != list(range(len(calls[0])))
+    assert wav2.shape == full.shape and np.array_equal(wav2, full)
+    assert all(np.array_equal(np.asarray(a), b) for a, b in zip(ids2, full_ids))
 
 
 def _run_bench(*argv, env_drop=("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")):
@@ -424,17 +558,22 @@ def test_bench_gpus_2_spawns_its_own_ranks():
     j = json.loads(lines[0])
     assert j["plumbing_only"] is True and j["value"] is None            # cannot be mistaken for a measurement
     assert j["n_gpus"] == 2 and j["ranks"]["world"] == 2 and j["global_batch"] == 128
-    assert [s["rows"] for s in j["ranks"]["shards"]] == [[0, 64], [64, 128]]
+    shards = [s["utterances"] for s in j["ranks"]["shards"]]
+    assert [len(x) for x in shards] == [64, 64] and sorted(shards[0] + shards[1]) == list(range(128))
+    assert all(x == sorted(x) for x in shards) and shards[0] != list(range(64))           # dealt by prompt length, not contiguous blocks
+    pt = [s["prompt_tokens"] for s in j["ranks"]["shards"]]
+    assert abs(pt[0] - pt[1]) <= 48                                                       # ... which balances the ranks' prompt tokens
     assert j["ranks"]["weights_equal_on_all_ranks"] and j["ranks"]["rows_cover_global_batch"]
 
 
 def test_bench_gpus_2_without_gpus_fails_loudly_about_the_gpu():
-    """... and the real thing on a box without GPUs: both spawned ranks say which GPU they miss, the launcher exits non-zero and NO
+    """... and the real thing on a box without GPUs: the spawned ranks say which GPU they miss, the launcher exits non-zero and NO
     result line is printed -- never a 1-rank number labelled n_gpus = 2."""
     r = _run_bench("--gpus", "2", "--steps", "1", "--warmup", "0")
     assert r.returncode != 0
     assert not any(ln.startswith("{") for ln in r.stdout.splitlines()), r.stdout
-    assert "needs GPU 1 of 2" in r.stderr and "needs GPU 0 of 2" in r.stderr and "no CPU fallback" in r.stderr
+    # (the launcher tears the other rank down as soon as the first one exits: at least one of them got to say which GPU it misses)
+    assert ("needs GPU 1 of 2" in r.stderr or "needs GPU 0 of 2" in r.stderr) and "no CPU fallback" in r.stderr
     assert "NO result line is printed for --gpus 2" in r.stderr
 
 

@@ -1,0 +1,44 @@
+#!/bin/bash
+# round 6: one GPU-box visit.  usage: r6_visit.sh TAG "stage ..."   stages: tests testsel:<expr> smoke bound bench benchd prof pmc
+cd "${GRAFT_REPO_ROOT:-/root/repo}"; R=$PWD; mkdir -p gpurun_out; export TMPDIR=/tmp
+TAG=${1:-r6a}
+STAGES=${2:-"tests smoke bench"}
+NOLEGS="--no-cpu-baseline --no-roofline --no-ttfs --no-parity-mode --no-configs --no-slot-pool --no-ids-check --no-bf16-mode --no-refine-text"
+for S in $STAGES; do
+  case $S in
+    tests)
+      timeout 2400 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/${TAG}_tests.log 2>&1
+      echo "pytest exit $?" >> gpurun_out/${TAG}_tests.log; grep -E "^FAILED|^ERROR|passed|failed|pytest exit" gpurun_out/${TAG}_tests.log | tail -25 ;;
+    testsel:*)
+      timeout 1800 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -k "$(echo "${S#testsel:}" | tr '+' ' ')" > gpurun_out/${TAG}_testsel.log 2>&1
+      echo "pytest exit $?" >> gpurun_out/${TAG}_testsel.log; grep -E "^FAILED|^ERROR|passed|failed|pytest exit" gpurun_out/${TAG}_testsel.log | tail -25 ;;
+    smoke)
+      timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${TAG}_smoke.log 2>&1; echo "smoke exit $?" >> gpurun_out/${TAG}_smoke.log; tail -2 gpurun_out/${TAG}_smoke.log ;;
+    bound)
+      timeout 900 python tools/x3_logit_bound.py > gpurun_out/${TAG}_x3_logit_bound.log 2>&1; echo "exit $?" >> gpurun_out/${TAG}_x3_logit_bound.log; tail -40 gpurun_out/${TAG}_x3_logit_bound.log ;;
+    bench)
+      timeout 1200 python bench.py --steps 3 --warmup 1 > gpurun_out/${TAG}_bench.log 2>&1; echo "bench exit $?" >> gpurun_out/${TAG}_bench.log
+      grep "^{" gpurun_out/${TAG}_bench.log | tail -1 | cut -c1-1500; tail -3 gpurun_out/${TAG}_bench.log | cut -c1-300 ;;
+    benchd)   # the driver's command
+      timeout 1500 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${TAG}_benchd.log 2>&1; echo "bench exit $?" >> gpurun_out/${TAG}_benchd.log
+      grep "^{" gpurun_out/${TAG}_benchd.log | tail -1 | cut -c1-1500 ;;
+    benchfb)  # with the exact fallback inside the timed passes
+      timeout 600 python bench.py --steps 3 --warmup 1 --exact-fallback $NOLEGS > gpurun_out/${TAG}_benchfb.log 2>&1; echo "bench exit $?" >> gpurun_out/${TAG}_benchfb.log
+      grep "^{" gpurun_out/${TAG}_benchfb.log | tail -1 | cut -c1-1500 ;;
+    prof|prof16)
+      D=""; SUF=f32x3; [ $S = prof16 ] && { D="--dtype bf16"; SUF=bf16; }
+      cd /tmp; timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${TAG}_$SUF -o ${TAG} -- python $R/bench.py $D --steps 1 --warmup 0 $NOLEGS > $R/gpurun_out/${TAG}_rocprof_$SUF.log 2>&1
+      f=$(find /tmp/prof_${TAG}_$SUF -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $R/gpurun_out/${TAG}_kernel_stats_$SUF.csv; cd $R; head -8 gpurun_out/${TAG}_kernel_stats_$SUF.csv | cut -c1-160 ;;
+    pmc|pmc16)
+      cd /tmp
+      D=""; SUF=f32; [ $S = pmc16 ] && { D="--dtype bf16"; SUF=bf16; }
+      for C in FETCH_SIZE WRITE_SIZE; do
+        CTTS_SYNC_POLL=1 timeout 400 rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/pmc_${TAG}_${SUF}_$C -o ${TAG}_$C -- python $R/bench.py $D --steps 1 --warmup 0 $NOLEGS > $R/gpurun_out/${TAG}_pmc_${SUF}_$C.log 2>&1
+      done
+      python $R/tools/pmc_summary.py /tmp/pmc_${TAG}_${SUF}_FETCH_SIZE /tmp/pmc_${TAG}_${SUF}_WRITE_SIZE $R/gpurun_out/${TAG}_pmc_traffic.json > $R/gpurun_out/${TAG}_pmc_summary_${SUF}.txt 2>&1
+      cd $R; head -12 gpurun_out/${TAG}_pmc_summary_${SUF}.txt | cut -c1-150 ;;
+    reftext)  # refine-text legs + a kernel trace of them
+      timeout 600 python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-ttfs --no-parity-mode --no-configs --no-slot-pool --no-ids-check --no-bf16-mode > gpurun_out/${TAG}_reftext.log 2>&1
+      grep "^{" gpurun_out/${TAG}_reftext.log | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(json.dumps(d['configs']['refine_text'], indent=1))" | head -80 ;;
+  esac
+done

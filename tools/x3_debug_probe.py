@@ -14,12 +14,7 @@ dev = torch.device("cuda:0")
 
 def make(nl, exact):
     sds = {"gpt": W.synthetic_gpt(n_layers=nl), "embed": W.synthetic_embed()}
-    if exact:
-        os.environ["CTTS_D32_EXACT"] = "1"
-    try:
-        return E.GptEngine(sds["gpt"], sds["embed"], dev, dtype="f32")
-    finally:
-        os.environ.pop("CTTS_D32_EXACT", None)
+    return E.GptEngine(sds["gpt"], sds["embed"], dev, dtype="f32" if exact else "f32x3", exact_fallback=False)
 
 
 def run(eng, B, steps, **kw):
