@@ -123,6 +123,7 @@ SIGNATURES = {
     "ctts_k_qkv_rope": (C.c_int, [P, P, I32, P, F, P, P, P, I32, P, P, I32, P, P, I32, P]),
     "ctts_k_gemm_dec": (C.c_int, [P, P, I32, I32, I32, P, P, F, I32, P, I32, P, I32, P, I32, P]),
     "ctts_k_gemm_dec32x": (C.c_int, [P, C.c_int64, P, C.c_int64, I32, I32, I32, P, P, I32, F, I32, P, I32, P, I32, P, C.c_int64, I32, P, I32, P, P, P]),
+    "ctts_k_gemm_pre_x3": (C.c_int, [P, I32, P, P, I32, I32, I32, I32, I32, P, P, P, I32, P]),
     "ctts_k_dec32_last_variant": (C.c_char_p, []),
     "ctts_k_gemm_dec32": (C.c_int, [P, P, I32, I32, I32, P, P, I32, P, F, I32, P, I32, P, I32, P, I32, I32, I32, P]),
     "ctts_k_rows_prep": (C.c_int, [P, P, P, I32, P]),

@@ -17,7 +17,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libchattts_amd.so")
-SOURCES = ["gemm.hip", "decode.hip", "decode32.hip", "decode32x.hip", "prefill.hip", "prefill32.hip", "gpt.hip", "codec.hip", "codec_gemm.hip", "dvae.hip", "capi.hip"]
+SOURCES = ["gemm.hip", "decode.hip", "decode32.hip", "decode32x.hip", "prefill.hip", "prefill32.hip", "prefill32x.hip", "gpt.hip", "codec.hip", "codec_gemm.hip", "dvae.hip", "capi.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result"]
 HEADERS = [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "kernels.hpp"), os.path.join(CSRC, "decode_dev.hpp"),
            os.path.join(HERE, "..", "include", "chattts_amd.h")]

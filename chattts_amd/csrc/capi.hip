@@ -48,6 +48,7 @@ struct ctts_gpt {
   int pf_mask = 0;             // env CTTS_PF: cross-kernel weight prefetch, bit mask (1 QKV->o_proj, 16 QKV->gate/up, 2 attention->gate/up)
   int temporal_layers = 0;     // env CTTS_W_TEMPORAL_LAYERS: decode weights of layers [0, N) loaded WITHOUT the non-temporal hint (A/B)
   bool pre32_packed = true;    // parity mode: prompt pass on the packed f32 kernels (env CTTS_PRE32_PACKED=0: row-major gemm_skinny_k)
+  bool pre_x3 = true;          // "f32x3" mode: prompt pass on the LDS-tiled split-bf16 GEMM (prefill32x.hip); env CTTS_PRE_X3=0: the f32 MFMA kernels
   bool fnorm_fuse = true;      // decode: final norm + hidden capture + heads in one launch (env CTTS_FNORM_FUSE=0: separate launches)
   std::vector<const float*> ln1, ln2;
   hipGraph_t graph = nullptr;
@@ -181,6 +182,7 @@ extern "C" int ctts_gpt_create(ctts_gpt** out, const ctts_gpt_weights* w) {
   // spins on device memory the default
   { const char* e = getenv("CTTS_QKV_ATT"); g->qkv_att = e && atoi(e) == 1; }
   { const char* e = getenv("CTTS_PRE32_PACKED"); if (e && atoi(e) == 0) g->pre32_packed = false; }
+  { const char* e = getenv("CTTS_PRE_X3"); if (e && atoi(e) == 0) g->pre_x3 = false; }
   {
     int dev = 0, cus = 0;
     // OFF by default: measured on the C3 bench it does not pay (attention 9.3 -> 9.8 us per launch, 1296 -> 1280 audio-s/s,
@@ -463,7 +465,10 @@ static int run_step(ctts_gpt* g, const ctts_gen_state* s, int q_per_b, hipStream
   // class, same ((s0+s1)+s2)+s3, 1/rms per row from wave_row_rstd like gemm_skinny_k), RoPE + KV append run in the QKV epilogue from
   // per-row descriptors, attention writes its output packed.  Bit-identical to the row-major prefill (CTTS_PRE32_PACKED=0), which
   // the goldens were made with.  (The decode kernels' generic 64-row body was tried first: no faster than row-major at this M.)
-  const bool pre32 = !fast && !dec && g->dec_packed32 && g->pre32_packed;
+  // "f32x3" mode (round 6): the prompt rows go through the row-major path below with its four projections on the LDS-tiled split-bf16
+  // GEMM (prefill32x.hip) -- 3 bf16 MFMAs per product instead of f32 MFMA at a sixteenth of the rate; an exact call keeps the f32 kernels
+  const bool pre_x3 = !fast && !dec && g->dec_x3 && !s->proj_exact && g->pre_x3;
+  const bool pre32 = !fast && !dec && g->dec_packed32 && g->pre32_packed && !pre_x3;
   if (pre32) {
     CK(launch_prefill_prep32(ws.x, ws.xp32, ws.desc, q_per_b, slot0, s->kv_start, s->row_map, M, st));
   }
@@ -500,21 +505,25 @@ static int run_step(ctts_gpt* g, const ctts_gen_state* s, int q_per_b, hipStream
     // RMSNorm + QKV
     a.A = ws.x; a.lda = HID; a.W = g->wqkv[l]; a.C = ws.qkv; a.ldc = 3 * HID; a.M = M; a.N = 3 * HID; a.K = HID; a.wt = wt;
     a.epi = EPI_STORE; a.norm_w = g->ln1[l]; a.eps = g->w.rms_eps;
-    { Prof p(g, 1, st, prof_ok); CK(launch_gemm_skinny(a, st)); }
+    if (pre_x3) { CK(launch_rows_rstd32(ws.x, HID, M, g->w.rms_eps, ws.rstd, st)); CK(launch_gemm_pre_x3(a, ws.rstd, st)); }
+    else { Prof p(g, 1, st, prof_ok); CK(launch_gemm_skinny(a, st)); }
     { Prof p(g, 2, st, prof_ok); CK(launch_rope_append(ws.qkv, kc, vc, kt, cmax, g->w.rope_cos, g->w.rope_sin, rm, M, st)); }
     { Prof p(g, 3, st, prof_ok); CK(launch_attention(ws.qkv, kc, vc, kt, cmax, ws.ao, 0, rm, M, st)); }
     // o_proj + residual
     a.A = ws.ao; a.lda = HID; a.W = g->wo[l]; a.C = ws.x; a.ldc = HID; a.N = HID; a.K = HID; a.epi = EPI_RES; a.norm_w = nullptr;
     a.res = ws.x; a.ldr = HID;
-    { Prof p(g, 4, st, prof_ok); CK(launch_gemm_skinny(a, st)); }
+    if (pre_x3) CK(launch_gemm_pre_x3(a, nullptr, st));
+    else { Prof p(g, 4, st, prof_ok); CK(launch_gemm_skinny(a, st)); }
     // RMSNorm + gate/up + SiLU*up
     a.A = ws.x; a.W = g->wgu[l]; a.C = ws.act; a.ldc = INTER; a.N = INTER; a.K = HID; a.epi = EPI_SILU_MUL; a.norm_w = g->ln2[l];
     a.res = nullptr;
-    { Prof p(g, 5, st, prof_ok); CK(launch_gemm_skinny(a, st)); }
+    if (pre_x3) { CK(launch_rows_rstd32(ws.x, HID, M, g->w.rms_eps, ws.rstd, st)); CK(launch_gemm_pre_x3(a, ws.rstd, st)); }
+    else { Prof p(g, 5, st, prof_ok); CK(launch_gemm_skinny(a, st)); }
     // down_proj + residual
     a.A = ws.act; a.lda = INTER; a.W = g->wd[l]; a.C = ws.x; a.ldc = HID; a.N = HID; a.K = INTER; a.epi = EPI_RES; a.norm_w = nullptr;
     a.res = ws.x; a.ldr = HID;
-    { Prof p(g, 6, st, prof_ok); CK(launch_gemm_skinny(a, st)); }
+    if (pre_x3) CK(launch_gemm_pre_x3(a, nullptr, st));
+    else { Prof p(g, 6, st, prof_ok); CK(launch_gemm_skinny(a, st)); }
   }
   if (!heads) return 0;   // a prompt chunk that is not the last one: its K/V rows are in the cache, nothing is sampled
   if (fuse_fnorm) {
@@ -1065,6 +1074,15 @@ extern "C" int ctts_k_embed_codes(const float* emb_code, const int64_t* ids_buf,
 extern "C" int ctts_k_final_norm(const float* x, int32_t q_per_b, const float* w, float eps, float* hfin, float* hiddens,
                                  int32_t max_new, const int32_t* len, int32_t T, int32_t B, void* stream) {
   CK(launch_final_norm(x, q_per_b, w, eps, hfin, hiddens, max_new, len, T, B, nullptr, nullptr, nullptr, (hipStream_t)stream));
+  return 0;
+}
+extern "C" int ctts_k_gemm_pre_x3(const float* A, int32_t lda, const float* W, float* C, int32_t ldc, int32_t M, int32_t N, int32_t K, int32_t epi,
+                                  const float* norm_w, const float* rstd, const float* res, int32_t ldr, void* stream) {
+  GemmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.taps = 1; a.A = A; a.lda = lda; a.W = W; a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.wt = WT_F32; a.epi = epi;
+  a.norm_w = norm_w; a.res = res; a.ldr = ldr;
+  CK(launch_gemm_pre_x3(a, rstd, (hipStream_t)stream));
   return 0;
 }
 extern "C" int ctts_k_sample(const ctts_gen_state* s, const float* logits, void* stream) {

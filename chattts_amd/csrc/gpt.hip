@@ -1918,22 +1918,26 @@ __device__ __forceinline__ void block_argmaxN(float v, int idx, BlockRed& r, int
 // two barriers; 256 threads with the row in LDS and a rolled load loop took 64-84 us per launch, 256 threads with the row in registers
 // 44-60 us (one wave per SIMD grinding through 83 elements x ~100 instructions); 1024 threads cut that serial stream by four.
 // Same sort-free prefix description of the kept set as sample_k:
-//   FAST PATH (top-k <= 64, the reference's refine default 20, core.py:182-193): t = the largest, over the waves, of the kk-th largest
-//   THREAD maximum of a wave -- kk elements are >= t, so {x >= t} holds the whole prefix (a wave is a 1/16 sample of the row: ~300
-//   candidates for kk = 20).  They are compacted into LDS (deterministic order: a block prefix sum of the per-thread counts), ranked by
+//   FAST PATH (top-k <= 64, the reference's refine default 20, core.py:182-193): t = the kk-th largest of the 64 column maxima (column =
+//   the same lane of all 16 waves) -- kk elements are >= t, so {x >= t} holds the whole prefix (~25 candidates for kk = 20).  They are
+//   compacted into LDS (deterministic order: a block prefix sum of the per-thread counts), ranked by
 //   counting in the order (value desc, index asc) with the probability mass before them in double, and every candidate applies the warpers'
 //   tests to itself.
 //   SERIAL PATH (no top-k, top-k > 64, or more than TEXT_CAND candidates): repeated extraction of the block-wide maximum.
 // Both leave (v_last, i_last, n_kept); the last three passes (max, sum, argmax(p / q)) are shared and read q only for kept tokens.
-#define TEXT_CAND 1024
+#define TEXT_CAND 256
 __global__ __launch_bounds__(TEXT_NT) void sample_text_k(SampleArgs a, int V) {
   __shared__ BlockRed red;
   __shared__ float cand_v[TEXT_CAND], cand_e[TEXT_CAND];
   __shared__ int cand_i[TEXT_CAND];
   __shared__ int wave_cnt[TEXT_NW];
+  __shared__ float lane_max[TEXT_NW][64];
   __shared__ float sh_f[6];   // kth_val, v_last, nxt, c_p(last kept), c_p(first p-dropped), spare
   __shared__ int sh_i[2];     // i_last
   const int m = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  long long* dbg = a.dbg ? a.dbg + (size_t)m * 8 : nullptr;   // probes only (tools/text_phase_probe.py)
+#define TSTAMP(i) do { if (dbg && tid == 0) dbg[i] = wall_clock64(); } while (0)
+  TSTAMP(0);
   if (row_absent(a.n_active, m)) return;
   const int b = a.row_map ? a.row_map[m] : m;
   const int len = a.len[b];
@@ -1945,10 +1949,13 @@ __global__ __launch_bounds__(TEXT_NT) void sample_text_k(SampleArgs a, int V) {
   const float* lrow = a.logits + (size_t)m * V;
   const float temp = a.temperature[0];
   const bool cert = a.margin != nullptr;
+  TSTAMP(1);   // row known
 
   float x[TEXT_PER];
 #pragma unroll
   for (int i = 0; i < TEXT_PER; ++i) { const int v = tid + TEXT_NT * i; x[i] = (v < V) ? lrow[v] : 0.f; }   // all loads in flight at once
+  if (dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+  TSTAMP(2);   // row landed
   float mx = -INFINITY;
 #pragma unroll
   for (int i = 0; i < TEXT_PER; ++i) {
@@ -1958,15 +1965,16 @@ __global__ __launch_bounds__(TEXT_NT) void sample_text_k(SampleArgs a, int V) {
   const float tmax = mx;   // this thread's maximum
   if (tid < 6) sh_f[tid] = INFINITY;
   mx = block_maxN(mx, red, wave, lane);
-  float zs = 0.f;
+  float zs = 0.f, ex[TEXT_PER];
 #pragma unroll
-  for (int i = 0; i < TEXT_PER; ++i) if (tid + TEXT_NT * i < V) zs += expf(x[i] - mx);
+  for (int i = 0; i < TEXT_PER; ++i) { ex[i] = (tid + TEXT_NT * i < V) ? expf(x[i] - mx) : 0.f; zs += ex[i]; }
   zs = block_sumN(zs, red, wave, lane);
   const float rz = 1.0f / zs;
   double sall = 0.0;
 #pragma unroll
-  for (int i = 0; i < TEXT_PER; ++i) if (tid + TEXT_NT * i < V) sall += (double)(expf(x[i] - mx) * rz);
+  for (int i = 0; i < TEXT_PER; ++i) if (tid + TEXT_NT * i < V) sall += (double)(ex[i] * rz);
   sall = block_sumNd(sall, red, wave, lane);
+  TSTAMP(3);   // softmax statistics
 
   const int kk = a.use_top_k ? min(max(a.top_k, 3), V) : V;
   const float thr = a.top_p_thr;
@@ -1974,15 +1982,25 @@ __global__ __launch_bounds__(TEXT_NT) void sample_text_k(SampleArgs a, int V) {
   float v_last = INFINITY; int i_last = -1, n_kept = 0;
   float c_cut = INFINITY, c_p = INFINITY;
   bool done = !any_filter;
+  bool fast = false;                     // the kept set was found on the candidate list: (cand_rank, cand_val, cand_idx) of this thread's candidate
+  int cand_rank = 0x7fffffff, cand_idx = 0x7fffffff;
+  float cand_val = -INFINITY;
   if (any_filter && a.use_top_k && kk <= 64) {
+    // threshold: the kk-th largest of the 64 COLUMN maxima (column l = lane l of every wave, 16 x 21 elements).  kk columns hold an
+    // element >= t, so {x >= t} contains the prefix -- and only ~1.2 kk candidates survive (the kk-th largest thread maximum of ONE wave,
+    // a 1/16 sample of the row, left ~370 of them, and ranking those by counting was 38 of the kernel's 50 us: profiles/r6g_text_phase.log)
+    lane_max[wave][lane] = tmax;
+    __syncthreads();
+    float sm = lane_max[0][lane];
+#pragma unroll
+    for (int w = 1; w < TEXT_NW; ++w) sm = fmaxf(sm, lane_max[w][lane]);
     int gtc = 0;
 #pragma unroll 8
     for (int j = 0; j < 64; ++j) {
-      const float o = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tmax), j));
-      gtc += (o > tmax) ? 1 : 0;
+      const float o = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sm), j));
+      gtc += (o > sm) ? 1 : 0;
     }
-    const float tw = -wave_max_dpp(gtc < kk ? -tmax : -INFINITY);   // the kk-th largest thread maximum of this wave
-    const float t = block_maxN(tw, red, wave, lane);
+    const float t = -wave_max_dpp(gtc < kk ? -sm : -INFINITY);   // the same value in every wave
     // deterministic compaction of {x >= t}: per-thread counts -> block exclusive prefix sum -> each thread writes its own, ascending index
     int cnt = 0;
 #pragma unroll
@@ -2002,7 +2020,7 @@ __global__ __launch_bounds__(TEXT_NT) void sample_text_k(SampleArgs a, int V) {
       if (cnt > 0) {
 #pragma unroll
         for (int i = 0; i < TEXT_PER; ++i)
-          if (x[i] >= t) { cand_v[base] = x[i]; cand_i[base] = tid + TEXT_NT * i; cand_e[base] = expf(x[i] - mx) * rz; ++base; }
+          if (x[i] >= t) { cand_v[base] = x[i]; cand_i[base] = tid + TEXT_NT * i; cand_e[base] = ex[i] * rz; ++base; }
       }
       __syncthreads();
       const bool act = tid < C;
@@ -2049,6 +2067,8 @@ __global__ __launch_bounds__(TEXT_NT) void sample_text_k(SampleArgs a, int V) {
         c_p = fminf(sh_f[3], sh_f[4]);
       }
       done = true;
+      fast = true;
+      if (act) { cand_rank = rank; cand_val = cv; cand_idx = ci; }
     }
   }
   if (!done) {
@@ -2093,35 +2113,59 @@ __global__ __launch_bounds__(TEXT_NT) void sample_text_k(SampleArgs a, int V) {
     if (sa >= 0) { mask_eos = mask_eos || (gen < sa); force_eos = gen >= sa; }
   }
   const float* qrow = a.q + ((size_t)(gen % a.nq) * a.q_rows + b) * V;
+  float wv; int wi;
+  float c_arg = INFINITY;
+  TSTAMP(4);   // kept set known
+  if (dbg && tid == 0) dbg[7] = fast ? 1 : 0;
+  if (fast) {
+    // the kept tokens ARE candidates: softmax over them and argmax(p / q) on the candidate list, q gathered for the kept tokens only, in
+    // ONE parallel round trip (measured: the same gather as conditional loads inside an unrolled loop over the row was ~20 SERIAL misses,
+    // 40 of the kernel's 57 us, profiles/r6e_kernel_stats_text.csv).  Every other token has p = 0, hence p / q = 0 for any draw: it can only
+    // win when every kept token's p / q underflowed to 0 too, and then the lowest index of the row (0) wins, as in the row-wide argmax.
+    const bool live = cand_rank < n_kept && !(mask_eos && cand_idx == a.eos);
+    const float qj = live ? qrow[cand_idx] : 1.f;
+    const float m2 = block_maxN(live ? cand_val : -INFINITY, red, wave, lane);
+    const float z2 = block_sumN(live ? expf(cand_val - m2) : 0.f, red, wave, lane);
+    const float rz2 = 1.0f / z2;
+    const float r = live ? (expf(cand_val - m2) * rz2) / qj : -1.f;
+    block_argmaxN(r, live ? cand_idx : 0x7fffffff, red, wave, lane, wv, wi);
+    if (cert) {
+      const float r2 = fmaxf(block_maxN((live && cand_idx != wi) ? r : -1.f, red, wave, lane), 0.f);   // (every removed token: p / q = 0)
+      c_arg = !(wv > 0.f) ? 0.f : (r2 > 0.f ? __logf(wv / r2) : INFINITY);
+    }
+    if (!(wv > 0.f)) wi = 0;
+  } else {
+    float qv[TEXT_PER];
+#pragma unroll
+    for (int i = 0; i < TEXT_PER; ++i) { const int v = tid + TEXT_NT * i; qv[i] = (v < V) ? qrow[v] : 1.f; }   // one round trip
 #define TEXT_LIVE(x_, v_) ((v_) < V && (!any_filter || (n_kept > 0 && ((x_) > v_last || ((x_) == v_last && (v_) <= i_last)))) && !(mask_eos && (v_) == a.eos))
-  float m2 = -INFINITY;
+    float m2 = -INFINITY;
 #pragma unroll
-  for (int i = 0; i < TEXT_PER; ++i) if (TEXT_LIVE(x[i], tid + TEXT_NT * i)) m2 = fmaxf(m2, x[i]);
-  m2 = block_maxN(m2, red, wave, lane);
-  float z2 = 0.f;
+    for (int i = 0; i < TEXT_PER; ++i) if (TEXT_LIVE(x[i], tid + TEXT_NT * i)) m2 = fmaxf(m2, x[i]);
+    m2 = block_maxN(m2, red, wave, lane);
+    float z2 = 0.f;
 #pragma unroll
-  for (int i = 0; i < TEXT_PER; ++i) if (TEXT_LIVE(x[i], tid + TEXT_NT * i)) z2 += expf(x[i] - m2);
-  z2 = block_sumN(z2, red, wave, lane);
-  const float rz2 = 1.0f / z2;
-  float bv = -1.f, bv2 = -1.f; int bi = 0x7fffffff;
+    for (int i = 0; i < TEXT_PER; ++i) if (TEXT_LIVE(x[i], tid + TEXT_NT * i)) z2 += expf(x[i] - m2);
+    z2 = block_sumN(z2, red, wave, lane);
+    const float rz2 = 1.0f / z2;
+    float bv = -1.f, bv2 = -1.f; int bi = 0x7fffffff;
 #pragma unroll
-  for (int i = 0; i < TEXT_PER; ++i) {
-    const int v = tid + TEXT_NT * i;
-    if (v < V) {
-      // p = 0 for a removed token: 0 / q = 0 for any draw, so q is read for the kept tokens only
-      const float r = TEXT_LIVE(x[i], v) ? (expf(x[i] - m2) * rz2) / qrow[v] : 0.f;
-      if (r > bv) { bv2 = bv; bv = r; bi = v; }
-      else bv2 = fmaxf(bv2, r);
+    for (int i = 0; i < TEXT_PER; ++i) {
+      const int v = tid + TEXT_NT * i;
+      if (v < V) {
+        const float r = (TEXT_LIVE(x[i], v) ? expf(x[i] - m2) * rz2 : 0.f) / qv[i];
+        if (r > bv) { bv2 = bv; bv = r; bi = v; }
+        else bv2 = fmaxf(bv2, r);
+      }
+    }
+#undef TEXT_LIVE
+    block_argmaxN(bv, bi, red, wave, lane, wv, wi);
+    if (cert) {
+      const float r2 = block_maxN(bi == wi ? bv2 : bv, red, wave, lane);
+      c_arg = !(wv > 0.f) ? 0.f : (r2 > 0.f ? __logf(wv / r2) : INFINITY);
     }
   }
-#undef TEXT_LIVE
-  float wv; int wi;
-  block_argmaxN(bv, bi, red, wave, lane, wv, wi);
-  float c_arg = INFINITY;
-  if (cert) {
-    const float r2 = block_maxN(bi == wi ? bv2 : bv, red, wave, lane);
-    c_arg = !(wv > 0.f) ? 0.f : (r2 > 0.f ? __logf(wv / r2) : INFINITY);
-  }
+  TSTAMP(5);   // token drawn
   if (force_eos) wi = a.eos;
   if (tid < NVQ) a.ids_buf[((size_t)b * a.tcap + len) * NVQ + tid] = (int64_t)wi;   // gpt.py:522-525: replicated over the 4 slots
   if (tid == 0) {
@@ -2131,6 +2175,8 @@ __global__ __launch_bounds__(TEXT_NT) void sample_text_k(SampleArgs a, int V) {
     a.len[b] = len + 1;
     if (cert && !force_eos) a.margin[b] = fminf(a.margin[b], fminf(c_arg, fminf(c_cut, c_p)));
   }
+  TSTAMP(6);
+#undef TSTAMP
 }
 
 hipError_t launch_sample_text(const SampleArgs& a, int V, hipStream_t st) {

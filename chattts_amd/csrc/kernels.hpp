@@ -83,6 +83,9 @@ struct GemmArgs {
 };
 
 hipError_t launch_gemm_skinny(const GemmArgs& a, hipStream_t st);  // weight-streaming, M-tiles of <=64 rows
+// prompt pass of the "f32x3" parity mode (prefill32x.hip): C = epi(rstd[row] * ((A diag(norm_w)) W^T)) on split-bf16 operands, LDS-tiled;
+// A / W float32 row-major, split by the tile loader; epi: EPI_STORE | EPI_RES | EPI_SILU_MUL
+hipError_t launch_gemm_pre_x3(const GemmArgs& a, const float* rstd, hipStream_t st);
 
 // ---- bf16 fast path of the GPT projections (perf mode) ------------------------------------------
 // Activations travel between kernels as bf16 (the f32 residual stream is kept beside its bf16

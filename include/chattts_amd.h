@@ -406,6 +406,12 @@ int ctts_k_gemm_dec32x(const uint16_t* Ap, int64_t a_plane, const uint16_t* Wp, 
                        const int32_t* n_active, const float* X, int32_t ldx, float eps, int32_t epi, float* C, int32_t ldc, const float* res,
                        int32_t ldr, uint16_t* Cp, int64_t c_plane, int32_t kch_out, float* Cp32, int32_t force_mb, const float* ssq_in,
                        float* ssq_out, void* stream);
+/* Round 6: the LDS-tiled split-bf16 GEMM of the "f32x3" mode's PROMPT pass (csrc/prefill32x.hip): C = epi(rstd[row] * ((A diag(norm_w)) W^T)),
+ * A [M, lda] and W [N (2N for epi 2: gate rows then up rows), K] float32 row-major, split hi | lo by the tile loader, three bf16 MFMAs per
+ * product, f32 accumulation.  epi 0 = store, 1 = C = res + acc, 2 = silu(gate) * up.  norm_w / rstd: both or neither.  K % 32 == 0,
+ * N % 128 == 0 (epi 2: % 64).  Reference ops: HF Llama projections, examples/onnx/modeling_llama.py:259-295,455-505. */
+int ctts_k_gemm_pre_x3(const float* A, int32_t lda, const float* W, float* C, int32_t ldc, int32_t M, int32_t N, int32_t K, int32_t epi,
+                       const float* norm_w, const float* rstd, const float* res, int32_t ldr, void* stream);
 /* which decode32 kernel the calling thread's last ctts_k_gemm_dec32 / decode step picked: "rms16" | "m16" | "generic" (all bit-identical) */
 const char* ctts_k_dec32_last_variant(void);
 int ctts_k_rows_prep(const float* x32, uint16_t* xb, float* ssq, int32_t M, void* stream);

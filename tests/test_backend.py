@@ -169,3 +169,110 @@ def test_chat_warm_hands_the_first_request_a_ready_session(weights):
     assert warm.gpt._session is sess                         # not rebuilt: the request found its geometry
     assert len(got) == len(want) >= 3 and all(np.array_equal(x, y) for x, y in zip(got, want))
     assert warm.warm(4, ids.shape[1], p) < 5.0               # idempotent, and cheap the second time
+
+
+# ---- the OpenAI-compatible endpoint (reference: examples/api/openai_api.py:149-294) ------------------------------------
+class _FakeChat:
+    """records the call, returns deterministic int16 audio: what `Chat.infer(..., pcm16=True)` hands the endpoint"""
+
+    class InferCodeParams:
+        def __init__(self, **kw):
+            self.__dict__.update(kw)
+
+    def __init__(self):
+        self.calls = []
+
+    def has_loaded(self):
+        return True
+
+    def infer(self, text, stream=False, **kw):
+        self.calls.append((list(text), stream, kw))
+        n = 1000 + 10 * len(text[0])
+        full = (np.arange(n) % 1000 - 500).astype(np.int16)
+        if not stream:
+            return [full]
+        return (c[None, :] for c in (full[:300], full[300:300], full[300:]))     # an empty chunk in the middle, like a dropped yield
+
+
+def test_openai_endpoint_shapes_the_reference_responses():
+    """POST /v1/audio/speech (openai_api.py:149-288): parameter whitelist + validation, the reference's InferCodeParams, WAV file for a
+    plain request, open-ended RIFF header + raw PCM16 chunks for a streamed one, "pcm" = the bare samples, mp3 / ogg refused with a message
+    that names PyAV where it is absent; GET /health."""
+    import importlib.util
+    import io
+    import wave
+    from starlette.testclient import TestClient
+    from chattts_amd import server
+    chat = _FakeChat()
+    app = server.create_app(chat, voices={"default": "SPK-D", "alloy": "SPK-A"})
+    with TestClient(app) as c:
+        assert c.get("/health").json()["model_loaded"] is True
+        r = c.post("/v1/audio/speech", json={"model": "whatever", "input": "hello there", "voice": "alloy", "response_format": "wav", "bogus": 1})
+        assert r.status_code == 200 and r.headers["content-type"] == "audio/wav" and "output.wav" in r.headers["content-disposition"]
+        with wave.open(io.BytesIO(r.content), "rb") as wf:
+            assert (wf.getnchannels(), wf.getsampwidth(), wf.getframerate()) == (1, 2, 24000)
+            pcm = np.frombuffer(wf.readframes(wf.getnframes()), dtype="<i2")
+        want = (np.arange(1000 + 10 * len("hello there")) % 1000 - 500).astype(np.int16)
+        assert np.array_equal(pcm, want)
+        text, stream, kw = chat.calls[-1]
+        p = kw["params_infer_code"]
+        assert text == ["hello there"] and stream is False and kw["skip_refine_text"] is True and kw["pcm16"] is True
+        assert (p.prompt, p.top_P, p.top_K, p.temperature, p.repetition_penalty, p.manual_seed, p.spk_emb) == ("[speed_5]", 0.5, 10, 0.1, 1.1, 42, "SPK-A")
+        assert (p.stream_batch, p.stream_speed, p.pass_first_n_batches, p.max_new_token) == (24, 12000, 2, 2048)
+        r = c.post("/v1/audio/speech", json={"input": "hello there", "voice": "nobody", "response_format": "pcm"})
+        assert r.status_code == 200 and np.array_equal(np.frombuffer(r.content, dtype="<i2"), want)
+        assert chat.calls[-1][2]["params_infer_code"].spk_emb == "SPK-D"                   # unknown voice -> default
+        r = c.post("/v1/audio/speech", json={"input": "hello there", "response_format": "wav", "stream": True})
+        assert r.status_code == 200 and r.content[:44] == server.wav_stream_header() and r.content[4:8] == b"\xff\xff\xff\xff"
+        assert np.array_equal(np.frombuffer(r.content[44:], dtype="<i2"), want) and chat.calls[-1][1] is True
+        assert c.post("/v1/audio/speech", json={"input": "x", "response_format": "flac"}).status_code == 400
+        if importlib.util.find_spec("av") is None:
+            r = c.post("/v1/audio/speech", json={"input": "x", "response_format": "mp3"})
+            assert r.status_code == 400 and "PyAV" in r.text
+        assert c.post("/v1/audio/speech", json={"input": "x" * 2049, "response_format": "wav"}).status_code == 422
+        assert c.post("/v1/audio/speech", json={"input": "x", "speed": 3.0, "response_format": "wav"}).status_code == 422
+        assert c.post("/v1/audio/speech", json={"response_format": "wav"}).status_code == 422
+
+
+@pytest.mark.gpu
+def test_openai_endpoint_streams_what_chat_infer_streams(weights):
+    """the endpoint on the real engine: a plain request's WAV samples == `float_to_int16` of `Chat.infer`'s waveform, a streamed request's
+    body == the open-ended header + `float_to_int16` of every chunk `Chat.infer(stream=True)` yields (openai_api.py:259-288), byte for byte."""
+    import io
+    import wave
+    from starlette.testclient import TestClient
+    from chattts_amd import server
+    from chattts_amd.core import Chat
+    dev = torch.device("cuda:0")
+    gold_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    with open(os.path.join(gold_dir, "spk_stat.txt"), encoding="utf-8") as f:
+        spk_stat = f.read()
+    chat = Chat()
+    assert chat.load(state_dicts=weights, device=dev, dtype="bf16", tokenizer=os.path.join(gold_dir, "tokenizer"), spk_stat=spk_stat)
+    torch.manual_seed(11)
+    spk = chat.sample_random_speaker()
+    text = "What is [uv_break]your favorite english food?[lbreak]"
+    app = server.create_app(chat, voices={"default": spk})
+
+    def direct(stream):
+        p = Chat.InferCodeParams(prompt="[speed_5]", top_P=0.5, top_K=10, temperature=0.1, repetition_penalty=1.1, max_new_token=144, min_new_token=0,
+                                 show_tqdm=False, ensure_non_empty=True, manual_seed=42, spk_emb=spk, stream_batch=24, stream_speed=12000,
+                                 pass_first_n_batches=2)
+        return chat.infer([text], stream=stream, skip_refine_text=True, params_infer_code=p)
+    orig = chat.InferCodeParams
+    # (random weights do not emit [Ebreak] on cue: cap the length the endpoint's fixed max_new_token = 2048 would otherwise run to)
+    chat.InferCodeParams = lambda **kw: orig(**{**kw, "max_new_token": 144})
+    try:
+        want = direct(False)
+        chunks = list(direct(True))
+        with TestClient(app) as c:
+            r = c.post("/v1/audio/speech", json={"input": text, "response_format": "wav"})
+            assert r.status_code == 200
+            with wave.open(io.BytesIO(r.content), "rb") as wf:
+                got = np.frombuffer(wf.readframes(wf.getnframes()), dtype="<i2")
+            assert np.array_equal(got, audio.float_to_int16(want[0]))
+            r = c.post("/v1/audio/speech", json={"input": text, "response_format": "wav", "stream": True})
+            body = server.wav_stream_header() + b"".join(audio.float_to_int16(ch).astype("<i2").tobytes() for ch in chunks if ch.size)
+            assert r.status_code == 200 and r.content == body and len(chunks) >= 2
+    finally:
+        chat.InferCodeParams = orig

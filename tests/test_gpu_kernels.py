@@ -226,6 +226,56 @@ def test_gemm_dec32_bit_identical(G, M, n_act, force_mb):
             assert np.isnan(got_p[live:M]).all()
 
 
+@pytest.mark.parametrize("M", [3072, 200, 37])
+def test_gemm_pre_x3_split_bf16_prefill(G, M):
+    """round 6: the LDS-tiled split-bf16 GEMM of the f32x3 mode's prompt pass (csrc/prefill32x.hip) for the four projection shapes of a
+    layer -- f32 row-major operands split by the tile loader, RMSNorm gain applied before the split, 1 / rms on the accumulator --
+    (a) against the float64 value of exactly what it is defined to compute ((hi+lo)(hi+lo) - lo*lo over the split operands) within f32
+    accumulation noise, (b) within 2e-5 of the output's scale of the float64 product of the UNSPLIT operands; 128- and 64-row tiles,
+    a partial last tile."""
+    lib = _lib.lib()
+    rs = np.random.RandomState(M)
+
+    def split64(a):
+        t = torch.from_numpy(a.astype(f32))
+        hi = t.to(torch.bfloat16)
+        lo = (t - hi.float()).to(torch.bfloat16)
+        return hi.double().numpy(), lo.double().numpy()
+
+    for N, K, epi, rms in [(2304, 768, 0, True), (768, 768, 1, False), (3072, 768, 2, True), (768, 3072, 1, False)]:
+        A = (rs.standard_normal((M, K)) * (2.0 if rms else 1.0)).astype(f32)
+        nrows = 2 * N if epi == 2 else N
+        Wm = (rs.standard_normal((nrows, K)) * 0.03).astype(f32)
+        g = (1.0 + 0.1 * rs.standard_normal(K)).astype(f32) if rms else None
+        rstd = (1.0 / np.sqrt((A.astype(np.float64) ** 2).mean(1) + 1e-6)).astype(f32) if rms else None
+        res = rs.standard_normal((M, N)).astype(f32) if epi == 1 else None
+        C_d = torch.full((M, N), float("nan"), dtype=torch.float32, device=G.DEV)
+        keep = [G.dev(A), G.dev(Wm)] + [None if t is None else G.dev(t) for t in (g, rstd, res)]
+        _lib.check(lib.ctts_k_gemm_pre_x3(keep[0].data_ptr(), K, keep[1].data_ptr(), C_d.data_ptr(), N, M, N, K, epi, _lib.ptr(keep[2]),
+                                          _lib.ptr(keep[3]), _lib.ptr(keep[4]), N, None), "gemm_pre_x3")
+        torch.cuda.synchronize()
+        got = C_d.cpu().numpy().astype(np.float64)
+        Ag = (A * g[None, :]).astype(f32) if rms else A          # the loader's f32 multiply, then the split
+        ah, al = split64(Ag)
+        wh, wl = split64(Wm)
+        acc_def = (ah + al) @ (wh + wl).T - al @ wl.T
+        acc_full = Ag.astype(np.float64) @ Wm.astype(np.float64).T
+        outs = []
+        for acc in (acc_def, acc_full):
+            if rms:
+                acc = acc * rstd.astype(np.float64)[:, None]
+            if epi == 1:
+                acc = res.astype(np.float64) + acc
+            elif epi == 2:
+                gate, up = acc[:, :N], acc[:, N:]
+                acc = gate / (1.0 + np.exp(-gate)) * up
+            outs.append(acc)
+        scale = np.abs(outs[1]).max()
+        assert np.isfinite(got).all()
+        assert np.abs(got - outs[0]).max() < 3e-6 * scale, (M, N, K, epi, np.abs(got - outs[0]).max() / scale)
+        assert np.abs(got - outs[1]).max() < 2e-5 * scale, (M, N, K, epi, np.abs(got - outs[1]).max() / scale)
+
+
 @pytest.mark.parametrize("force_mb", [0, 1, 2, 4, 9, 10, 12, 17])  # rows per workgroup (x 16); + 8: eight waves split K instead of four; 17: sixteen (down_proj only, else eight)
 @pytest.mark.parametrize("M,n_act", [(64, None), (64, 37), (16, None), (5, None), (33, 20), (48, 48)])
 def test_gemm_dec32x_split_bf16(G, M, n_act, force_mb):

@@ -22,6 +22,15 @@ for S in $STAGES; do
     benchd)   # the driver's command
       timeout 1500 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${TAG}_benchd.log 2>&1; echo "bench exit $?" >> gpurun_out/${TAG}_benchd.log
       grep "^{" gpurun_out/${TAG}_benchd.log | tail -1 | cut -c1-1500 ;;
+    benchq)   # headline leg only
+      timeout 600 python bench.py --steps 5 --warmup 2 $NOLEGS > gpurun_out/${TAG}_benchq.log 2>&1; echo "bench exit $?" >> gpurun_out/${TAG}_benchq.log
+      grep "^{" gpurun_out/${TAG}_benchq.log | tail -1 | cut -c1-400 ;;
+    benchq0)  # headline leg only, prompt pass on the f32 MFMA kernels (A/B of prefill32x.hip)
+      CTTS_PRE_X3=0 timeout 600 python bench.py --steps 5 --warmup 2 $NOLEGS > gpurun_out/${TAG}_benchq0.log 2>&1; echo "bench exit $?" >> gpurun_out/${TAG}_benchq0.log
+      grep "^{" gpurun_out/${TAG}_benchq0.log | tail -1 | cut -c1-400 ;;
+    ttfs)     # time to first sample, headline engine
+      timeout 600 python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-parity-mode --no-configs --no-slot-pool --no-ids-check --no-bf16-mode --no-refine-text > gpurun_out/${TAG}_ttfs.log 2>&1
+      grep "^{" gpurun_out/${TAG}_ttfs.log | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print({k: d.get(k) for k in ('value','ttfs_ms_p50','ttfs_ms_cold','ttfs_ms_cold_prewarmed')})" ;;
     benchfb)  # with the exact fallback inside the timed passes
       timeout 600 python bench.py --steps 3 --warmup 1 --exact-fallback $NOLEGS > gpurun_out/${TAG}_benchfb.log 2>&1; echo "bench exit $?" >> gpurun_out/${TAG}_benchfb.log
       grep "^{" gpurun_out/${TAG}_benchfb.log | tail -1 | cut -c1-1500 ;;
@@ -37,6 +46,9 @@ for S in $STAGES; do
       done
       python $R/tools/pmc_summary.py /tmp/pmc_${TAG}_${SUF}_FETCH_SIZE /tmp/pmc_${TAG}_${SUF}_WRITE_SIZE $R/gpurun_out/${TAG}_pmc_traffic.json > $R/gpurun_out/${TAG}_pmc_summary_${SUF}.txt 2>&1
       cd $R; head -12 gpurun_out/${TAG}_pmc_summary_${SUF}.txt | cut -c1-150 ;;
+    proftext)  # rocprofv3 kernel trace of the refine-text legs
+      cd /tmp; timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${TAG}_text -o ${TAG} -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-ttfs --no-parity-mode --no-configs --no-slot-pool --no-ids-check --no-bf16-mode > $R/gpurun_out/${TAG}_rocprof_text.log 2>&1
+      f=$(find /tmp/prof_${TAG}_text -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $R/gpurun_out/${TAG}_kernel_stats_text.csv; cd $R; grep -E "sample_text|fnorm16|embed_text|Name" gpurun_out/${TAG}_kernel_stats_text.csv | cut -c1-200 ;;
     reftext)  # refine-text legs + a kernel trace of them
       timeout 600 python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-ttfs --no-parity-mode --no-configs --no-slot-pool --no-ids-check --no-bf16-mode > gpurun_out/${TAG}_reftext.log 2>&1
       grep "^{" gpurun_out/${TAG}_reftext.log | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(json.dumps(d['configs']['refine_text'], indent=1))" | head -80 ;;
