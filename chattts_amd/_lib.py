@@ -42,7 +42,7 @@ class GenState(C.Structure):
         ("cap", C.c_int32), ("hid_cap", C.c_int32), ("kv_batch", C.c_int32), ("q_batch", C.c_int32), ("prompt_len", P),
         ("infer_text", C.c_int32), ("teacher_ids", P), ("sampled_ids", P), ("order", P),
         ("rng_device", C.c_int32), ("rng_per_step", C.c_int32), ("rng_seed", P), ("rng_nonce", P),
-        ("margin", P), ("row_base", P), ("proj_exact", C.c_int32),
+        ("margin", P), ("row_base", P), ("proj_exact", C.c_int32), ("prefill_valid_rows", C.c_int32),
     ]
 
 

@@ -373,6 +373,31 @@ class Chat:
         return self.infer_code(ids, attn, tmask, params, stream=stream, return_hidden=return_hidden,
                                spk_emb_ids=self.tokenizer.spk_emb_ids)
 
+    def infer_sharded(self, text, params_infer_code: InferCodeParams = InferCodeParams(), lang=None, do_text_normalization: bool = True,
+                      do_homophone_replacement: bool = True, policy: str = "snake", group=None, dst: int = 0):
+        """`Chat.infer(text, skip_refine_text=True, split_text=False)` (core.py:208-270) over the ranks of the `torch.distributed` process
+        group: every rank calls this with the SAME texts and parameters; the batch is tokenised everywhere (host work, deterministic), dealt
+        by prompt length, generated and decoded shard by shard (`dist.infer_sharded`: global row numbering for the CPU draws and the
+        rows >= 625 quirk, decode padded to the global longest utterance) and rank `dst` returns the list of stripped waveforms in the
+        caller's order -- what the single-process call returns; the other ranks return None.  The reference has no data-parallel mode."""
+        from .dist import infer_sharded
+        self._need_tokenizer()
+        self.context.set(False)
+        if not isinstance(text, list):
+            text = [text]
+        if len(text) == 0:
+            return []
+        text = [self.normalizer(t, do_text_normalization, do_homophone_replacement, lang) for t in text]
+        params = params_infer_code
+        prompt = Speaker.decode_prompt(params.spk_smp) if params.spk_smp is not None else None
+        ids, attn, tmask = self.tokenizer.encode(
+            Speaker.decorate_code_prompts(text, params.prompt, params.txt_smp, params.spk_emb), GPT.n_vq, prompt=prompt)
+        wavs = infer_sharded(self, ids, attn, tmask, params, policy=policy, group=group, dst=dst, spk_emb_ids=self.tokenizer.spk_emb_ids)
+        if wavs is None:
+            return None
+        thr = np.float32(1e-5)
+        return [wav[np.abs(wav) > thr] for wav in wavs]     # core.py:258-266: the sample-level strip
+
     def _refine_text(self, text, device, params: RefineTextParams) -> GenerationOutputs:
         """core.py:665-751"""
         self._need_tokenizer()

@@ -48,6 +48,7 @@ struct ctts_gpt {
   int pf_mask = 0;             // env CTTS_PF: cross-kernel weight prefetch, bit mask (1 QKV->o_proj, 16 QKV->gate/up, 2 attention->gate/up)
   int temporal_layers = 0;     // env CTTS_W_TEMPORAL_LAYERS: decode weights of layers [0, N) loaded WITHOUT the non-temporal hint (A/B)
   bool pre32_packed = true;    // parity mode: prompt pass on the packed f32 kernels (env CTTS_PRE32_PACKED=0: row-major gemm_skinny_k)
+  bool pre_compact = true;     // "f32x3" mode: the prompt pass over the valid prompt tokens only (env CTTS_PRE_COMPACT=0: all B * T rows)
   bool pre_x3 = true;          // "f32x3" mode: prompt pass on the LDS-tiled split-bf16 GEMM (prefill32x.hip); env CTTS_PRE_X3=0: the f32 MFMA kernels
   bool fnorm_fuse = true;      // decode: final norm + hidden capture + heads in one launch (env CTTS_FNORM_FUSE=0: separate launches)
   std::vector<const float*> ln1, ln2;
@@ -183,6 +184,7 @@ extern "C" int ctts_gpt_create(ctts_gpt** out, const ctts_gpt_weights* w) {
   { const char* e = getenv("CTTS_QKV_ATT"); g->qkv_att = e && atoi(e) == 1; }
   { const char* e = getenv("CTTS_PRE32_PACKED"); if (e && atoi(e) == 0) g->pre32_packed = false; }
   { const char* e = getenv("CTTS_PRE_X3"); if (e && atoi(e) == 0) g->pre_x3 = false; }
+  { const char* e = getenv("CTTS_PRE_COMPACT"); if (e && atoi(e) == 0) g->pre_compact = false; }
   {
     int dev = 0, cus = 0;
     // OFF by default: measured on the C3 bench it does not pay (attention 9.3 -> 9.8 us per launch, 1296 -> 1280 audio-s/s,
@@ -282,12 +284,18 @@ static bool dev_compact(const ctts_gpt* g, const ctts_gen_state* s) {
 }
 
 // the 20-layer body + heads + sampling over M = B * q_per_b rows
+static bool prefill_compacts(const ctts_gpt* g, const ctts_gen_state* s) {   // the prompt pass of this call runs over the valid tokens only
+  return g->w.weight_dtype != CTTS_BF16 && g->dec_x3 && !s->proj_exact && g->pre_x3 && g->pre_compact && s->row_map == nullptr &&
+         s->prefill_valid_rows > 0 && s->prefill_valid_rows < s->B * s->T;
+}
+
 static int run_step(ctts_gpt* g, const ctts_gen_state* s, int q_per_b, hipStream_t st, bool prof_ok, int slot0 = 0, bool heads = true,
-                    int ws_T = 0, int rows = 0) {
+                    int ws_T = 0, int rows = 0, int pre_rows = 0) {
   const GptWs ws = carve(s->workspace, s->B, ws_T ? ws_T : s->T);
   // `rows` (decode only): a bound on the live compact rows this step can have -- grids and M are sized for it instead of B (buffer
   // geometry, the KV cache's batch stride above all, stays B's)
-  const int B = s->B, Bh = (q_per_b == 1 && rows > 0 && rows < s->B) ? rows : s->B, M = q_per_b == 1 ? Bh : B * q_per_b;
+  // pre_rows (whole-prompt pass, "f32x3"): the compact rows of the valid prompt tokens (prefill_compact_k wrote ws.x, ws.desc, ws.row_map = last_row)
+  const int B = s->B, Bh = (q_per_b == 1 && rows > 0 && rows < s->B) ? rows : s->B, M = q_per_b == 1 ? Bh : (pre_rows > 0 ? pre_rows : B * q_per_b);
   const int cmax = s->cap ? s->cap : s->T + s->max_new;
   const int wt = g->w.weight_dtype, kt = g->w.kv_dtype;
   const size_t kv_layer = (size_t)(s->kv_batch ? s->kv_batch : B) * NHEAD * cmax * HDIM * (kt == CTTS_BF16 ? 2 : 4);
@@ -302,7 +310,7 @@ static int run_step(ctts_gpt* g, const ctts_gen_state* s, int q_per_b, hipStream
   GptRowMap rm{q_per_b, s->len, s->kv_start, rmap, nact, (dec && g->skip_finished) ? s->finish : nullptr, nullptr, nullptr, nullptr, 0, slot0, 0};
   const bool fast = wt == CTTS_BF16;  // perf mode: bf16 activations, RMSNorm gain folded into wqkv / wgu by the loader
   const bool packed = fast && dec && g->dec_packed;   // decode step on fragment-packed operands (decode.hip)
-  if (dec) rm.desc = ws.desc;                          // written by the embedding kernel at the head of the step
+  if (dec || pre_rows > 0) rm.desc = ws.desc;          // written by the embedding kernel at the head of the step / by prefill_compact_k
   if (dec && dev_compact(g, s)) rm.desc_covers_all = 1; // ... for every row of the grid (absent rows: b = -1)
   if (packed && g->n_cu > 0) { rm.sp_part = ws.att_part; rm.sp_cnt = ws.att_cnt; rm.sp_cus = g->n_cu; }
   if (packed) { const char* e = getenv("CTTS_ATT_DBG_PTR"); if (e) rm.dbg = (long long*)strtoull(e, nullptr, 0); }   // probes only
@@ -539,7 +547,7 @@ static int run_step(ctts_gpt* g, const ctts_gen_state* s, int q_per_b, hipStream
   } else {
   { Prof p(g, 7, st, prof_ok);
     CK(launch_final_norm(ws.x, q_per_b, g->w.norm, g->w.rms_eps, ws.hfin, s->hiddens, s->hid_cap ? s->hid_cap : s->max_new, s->len, s->T, Bh, rmap,
-                         nact, s->prompt_len, st, ws.hfinp)); }
+                         nact, s->prompt_len, st, ws.hfinp, pre_rows > 0 ? ws.row_map : nullptr)); }
   {
     const int nlog = s->infer_text ? g->w.n_text : NVQ * NAUDIO;   // gpt.py:439-440 text head | :441-454 four code heads
     const float* hpk = s->infer_text ? g->w.head_text_pk : g->w.heads_pk;
@@ -579,6 +587,13 @@ extern "C" int ctts_gpt_prefill(ctts_gpt* g, const ctts_gen_state* s, const floa
   hipStream_t st = (hipStream_t)stream;
   const GptWs ws = carve(s->workspace, s->B, s->T);
   CK(hipMemsetAsync(ws.att_cnt, 0, cnt_bytes(s->B), st));   // arrival counters of the attention split
+  if (prefill_compacts(g, s)) {
+    // the prompt pass over the valid prompt tokens only: their embeddings gathered into consecutive rows, descriptors per row
+    CK(launch_prefill_compact(emb, ws.x, ws.desc, ws.row_map, s->B, s->T, s->kv_start, st));
+    if (run_step(g, s, s->T, st, false, 0, true, 0, 0, s->prefill_valid_rows)) return -1;
+    CK(hipMemsetAsync(carve(s->workspace, s->B, 1).att_cnt, 0, cnt_bytes(s->B), st));
+    return 0;
+  }
   CK(hipMemcpyAsync(ws.x, emb, (size_t)s->B * s->T * HID * 4, hipMemcpyDeviceToDevice, st));
   if (g->w.weight_dtype == CTTS_BF16) CK(launch_rows_prep(ws.x, ws.xb, ws.ssq, s->B * s->T, st));
   if (run_step(g, s, s->T, st, false)) return -1;

@@ -189,6 +189,35 @@ hipError_t launch_prefill_prep32(const float* x, float* xp32, RowDesc* desc, int
   return hipGetLastError();
 }
 
+// Prompt pass over the VALID prompt tokens only (round 6, "f32x3" mode): the caller's batch is left-padded to its longest prompt
+// (tokenizer.py:73-110) and the reference pushes every pad row through every layer (their outputs are never consumed: attention masks
+// them as keys, gpt.py:234-241).  One workgroup per utterance: its first compact row = the number of valid tokens of the utterances before
+// it; rows [first, first + T - kv_start[b]) take the embeddings of its valid slots, their descriptors (utterance, slot, RoPE position,
+// first visible key) drive rope_append_k and attention_k, last_row[b] is the row the final norm / heads / sampler read.
+__global__ __launch_bounds__(192) void prefill_compact_k(const float* __restrict__ emb, float* __restrict__ x, RowDesc* __restrict__ desc,
+                                                         int32_t* __restrict__ last_row, int T, const int32_t* __restrict__ kv_start) {
+  __shared__ int part[3];
+  const int b = blockIdx.x, t = threadIdx.x;
+  int acc = 0;
+  for (int i = t; i < b; i += 192) acc += T - kv_start[i];
+  acc = (int)wave_sum((float)acc);     // (exact: < 2^24 rows)
+  if ((t & 63) == 0) part[t >> 6] = acc;
+  __syncthreads();
+  const int first = part[0] + part[1] + part[2];
+  const int ks = kv_start[b], n = T - ks;
+  for (int j = 0; j < n; ++j) {
+    const float4 v = *reinterpret_cast<const float4*>(emb + ((size_t)b * T + ks + j) * HID + t * 4);
+    *reinterpret_cast<float4*>(x + (size_t)(first + j) * HID + t * 4) = v;
+    if (t == 0) desc[first + j] = RowDesc{b, ks + j, j, ks};
+  }
+  if (t == 0) last_row[b] = first + n - 1;
+}
+hipError_t launch_prefill_compact(const float* emb, float* x, RowDesc* desc, int32_t* last_row, int B, int T, const int32_t* kv_start,
+                                  hipStream_t st) {
+  CTTS_LAUNCH(prefill_compact_k, dim3(B), dim3(192), st, emb, x, desc, last_row, T, kv_start);
+  return hipGetLastError();
+}
+
 hipError_t launch_rows_prep(const float* x32, uint16_t* xb, float* ssq, int M, hipStream_t st) {
   CTTS_LAUNCH(rows_prep_k, dim3(M), dim3(192), st, x32, xb, ssq);
   return hipGetLastError();
@@ -210,10 +239,15 @@ __global__ __launch_bounds__(384) void rope_append_k(float* __restrict__ qkv, KT
                                                      GptRowMap rm) {
   const int m = blockIdx.x, t = threadIdx.x;  // t: head = t / 32, pair d = t % 32
   if (rm.q_per_b == 1 && row_absent(rm.n_active, m)) return;
-  int b, slot;
-  row_to_b_slot(rm, m, b, slot);
-  int pos = slot - rm.kv_start[b];
-  if (pos < 0) pos = 1;
+  int b, slot, pos;
+  if (rm.q_per_b != 1 && rm.desc != nullptr) {   // compact prompt rows (prefill_compact_k): the row's descriptor says where it belongs
+    const RowDesc d = rm.desc[m];
+    b = d.b; slot = d.slot; pos = d.pos;
+  } else {
+    row_to_b_slot(rm, m, b, slot);
+    pos = slot - rm.kv_start[b];
+    if (pos < 0) pos = 1;
+  }
   const int h = t >> 5, d = t & 31;
   const float c = cos_t[pos * 32 + d], s = sin_t[pos * 32 + d];
   float* row = qkv + (size_t)m * (3 * HID);
@@ -1381,13 +1415,14 @@ __global__ __launch_bounds__(192) void final_norm_k(const float* __restrict__ x,
                                                     float* __restrict__ hfin, float* __restrict__ hiddens, int max_new,
                                                     const int32_t* __restrict__ len, int T, const int32_t* __restrict__ row_map,
                                                     const int32_t* __restrict__ n_active, const int32_t* __restrict__ prompt_len,
-                                                    float* __restrict__ hfin_p) {
+                                                    float* __restrict__ hfin_p, const int32_t* __restrict__ last_row) {
   __shared__ float part[3];
   CTTS_PROBE_RETURN();
   const int m = blockIdx.x, t = threadIdx.x;
   if (row_absent(n_active, m)) return;
   const int b = row_map ? row_map[m] : m;   // compact activation row m belongs to utterance b
-  const float* row = x + ((size_t)m * q_per_b + (q_per_b - 1)) * HID;
+  // (last_row: the prompt pass ran over the valid tokens only -- prefill_compact_k says where utterance m's last token sits)
+  const float* row = x + (last_row != nullptr ? (size_t)last_row[m] : (size_t)m * q_per_b + (q_per_b - 1)) * HID;
   const float4 v = *reinterpret_cast<const float4*>(row + t * 4);
   float ss = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
   ss = wave_sum(ss);
@@ -1406,8 +1441,9 @@ __global__ __launch_bounds__(192) void final_norm_k(const float* __restrict__ x,
 
 hipError_t launch_final_norm(const float* x, int q_per_b, const float* w, float eps, float* hfin, float* hiddens, int max_new,
                              const int32_t* len, int T, int B, const int32_t* row_map, const int32_t* n_active,
-                             const int32_t* prompt_len, hipStream_t st, float* hfin_packed) {
-  CTTS_LAUNCH(final_norm_k, dim3(B), dim3(192), st, x, q_per_b, w, eps, hfin, hiddens, max_new, len, T, row_map, n_active, prompt_len, hfin_packed);
+                             const int32_t* prompt_len, hipStream_t st, float* hfin_packed, const int32_t* last_row) {
+  CTTS_LAUNCH(final_norm_k, dim3(B), dim3(192), st, x, q_per_b, w, eps, hfin, hiddens, max_new, len, T, row_map, n_active, prompt_len, hfin_packed,
+              last_row);
   return hipGetLastError();
 }
 

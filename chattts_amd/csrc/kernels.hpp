@@ -315,7 +315,12 @@ hipError_t launch_qkv_attention(const DecGemmArgs& d, const void* kcache, const 
 hipError_t launch_final_norm(const float* x, int q_per_b, const float* w, float eps, float* hfin /*[B,768]*/,
                              float* hiddens /*[slots,max_new,768]*/, int max_new, const int32_t* len, int T, int B,
                              const int32_t* row_map, const int32_t* n_active, const int32_t* prompt_len, hipStream_t st,
-                             float* hfin_packed = nullptr /* the same rows in the packed f32 order of decode32.hip, or null */);
+                             float* hfin_packed = nullptr /* the same rows in the packed f32 order of decode32.hip, or null */,
+                             const int32_t* last_row = nullptr /* [B]: row of utterance m's last prompt token (compact prompt pass), or null */);
+// prompt pass over the valid prompt tokens only: gathers emb[b, kv_start[b] .. T) into consecutive rows of x, writes their descriptors
+// and last_row[b]; the host knows the row count (sum of the attention mask)
+hipError_t launch_prefill_compact(const float* emb, float* x, RowDesc* desc, int32_t* last_row, int B, int T, const int32_t* kv_start,
+                                  hipStream_t st);
 
 struct SampleArgs {
   const float* logits;      // [B, 4*626]

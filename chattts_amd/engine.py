@@ -577,6 +577,7 @@ class GptEngine:
                 s.rng_device, s.rng_per_step, s.rng_seed = int(device_rng), int(manual_seed is None), sess["seed"].data_ptr()
                 s.rng_nonce = _lib.ptr(ln.nonce)
                 s.margin, s.row_base, s.proj_exact = _lib.ptr(ln.margin), _lib.ptr(ln.row_base), int(exact)
+                s.prefill_valid_rows = 0      # set per call below (the session is keyed on geometry, not on the mask)
                 # compaction order: utterances by descending context = ascending left padding (contexts of a batch differ only by
                 # the static valid prompt length), so the attention grid starts its longest units first.  CTTS_ORDER=0: ascending slot
                 s.order = ln.order.data_ptr() if os.environ.get("CTTS_ORDER", "1") != "0" else None
@@ -606,6 +607,8 @@ class GptEngine:
                 ln.n_active.fill_(Bl)
                 ln.end_idx.zero_()
                 ln.kv_start.copy_(kv_start_all[lo:hi])
+                # "f32x3": the prompt pass runs over the valid prompt tokens only (ctts_gen_state.prefill_valid_rows; whole-prompt prefill only)
+                ln.s.prefill_valid_rows = int((T - kv_start_all[lo:hi].to(torch.int64)).sum()) if self.x3 is not None else 0
                 if ln.stop_d is not None:
                     ln.stop_d.copy_(stop_at[lo:hi].to(torch.int32))
                 if ln.margin is not None:

@@ -179,6 +179,10 @@ typedef struct {
    * (csrc/decode32.hip) although the split-bf16 planes are there -- the exact fallback of a certificate that fired.  A captured graph
    * holds the choice it was built with. */
   int32_t proj_exact;
+  /* "f32x3" mode, ctts_gpt_prefill only: the number of VALID prompt tokens of the batch (sum of the attention mask = sum of T - kv_start[b]),
+   * known to the host.  > 0: the prompt pass runs over those rows only instead of over all B * T left-padded rows (the reference computes
+   * the pad rows and never consumes them, gpt.py:234-241).  0: every row.  Same KV cache contents for the valid slots, same token. */
+  int32_t prefill_valid_rows;
 } ctts_gen_state;
 
 int ctts_gpt_create(ctts_gpt** out, const ctts_gpt_weights* w);

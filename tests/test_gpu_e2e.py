@@ -194,6 +194,37 @@ def test_scattered_shard_with_row_ids_equals_the_unsharded_reference(gpt_f32, go
             assert np.array_equal(out.ids[i].cpu().numpy(), rows[b]), (b, use_graph)
 
 
+def test_two_shards_decoded_as_part_of_the_global_batch_equal_the_unsharded_call(weights):
+    """`dist.infer_sharded`'s recipe on the real engine, the two ranks of a world of 2 played one after the other: shards dealt by prompt
+    length (`deal_shards`), generated with `row_ids` = global utterance indices, decoded padded to the GLOBAL longest utterance
+    (`pad_to`) -- token ids identical and waveforms equal (1e-6) to the single unsharded `Chat.infer_ids` call, row for row; and
+    `Chat.infer_sharded` / `dist.infer_sharded` without a process group ARE that call."""
+    from chattts_amd import dist as D
+    from chattts_amd.core import Chat, InferCodeParams
+    chat = Chat()
+    assert chat.load(state_dicts=weights, device=DEV, dtype="f32")
+    ids, mask, tmask = synth.make_prompts(6, 5, 14, seed=9)
+    stop = torch.from_numpy(synth.make_stop_lengths(6, 6, 30, seed=9))
+    a = (torch.from_numpy(ids), torch.from_numpy(mask), torch.from_numpy(tmask))
+    p = InferCodeParams(max_new_token=31, manual_seed=5, show_tqdm=False)
+    full = chat.infer_ids(*a, p, stop_at=stop)
+    full_ids = [t.cpu().numpy() for t in list(chat.infer_code(*a, p, stop_at=stop))[-1].ids]
+    assert np.array_equal(D.infer_sharded(chat, *a, p, stop_at=stop), full)            # world of one
+    shards = D.deal_shards(mask.sum(1).tolist(), 2)
+    assert sorted(shards[0] + shards[1]) == list(range(6)) and shards[0] != [0, 1, 2]
+    t_max = int(stop.max())
+    got = np.zeros_like(full)
+    for sel in shards:
+        st = torch.tensor(sel)
+        out = list(chat.infer_code(a[0][st], a[1][st], a[2][st], p, stop_at=stop[st], row_ids=st, total_rows=6 * 4))[-1]
+        for j, b in enumerate(sel):
+            assert np.array_equal(out.ids[j].cpu().numpy(), full_ids[b]), b
+        wav = chat.decode_to_wavs(out.hiddens, pad_to=t_max)
+        for j, b in enumerate(sel):
+            got[b] = wav[j]
+    assert np.abs(got - full).max() < 1e-6
+
+
 def _cert_engines(weights, embed=None):
     emb_sd = weights["embed"] if embed is None else embed
     exact = E.GptEngine(weights["gpt"], emb_sd, DEV, dtype="f32")
