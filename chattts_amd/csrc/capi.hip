@@ -48,6 +48,7 @@ struct ctts_gpt {
   int pf_mask = 0;             // env CTTS_PF: cross-kernel weight prefetch, bit mask (1 QKV->o_proj, 16 QKV->gate/up, 2 attention->gate/up)
   int temporal_layers = 0;     // env CTTS_W_TEMPORAL_LAYERS: decode weights of layers [0, N) loaded WITHOUT the non-temporal hint (A/B)
   bool pre32_packed = true;    // parity mode: prompt pass on the packed f32 kernels (env CTTS_PRE32_PACKED=0: row-major gemm_skinny_k)
+  bool embed_fold = false;     // multi-step graphs: steps 2..n take their input rows from the previous step's sampling launch (env CTTS_EMBED_FOLD=1)
   bool pre_compact = true;     // "f32x3" mode: the prompt pass over the valid prompt tokens only (env CTTS_PRE_COMPACT=0: all B * T rows)
   bool pre_x3 = true;          // "f32x3" mode: prompt pass on the LDS-tiled split-bf16 GEMM (prefill32x.hip); env CTTS_PRE_X3=0: the f32 MFMA kernels
   bool fnorm_fuse = true;      // decode: final norm + hidden capture + heads in one launch (env CTTS_FNORM_FUSE=0: separate launches)
@@ -185,6 +186,7 @@ extern "C" int ctts_gpt_create(ctts_gpt** out, const ctts_gpt_weights* w) {
   { const char* e = getenv("CTTS_PRE32_PACKED"); if (e && atoi(e) == 0) g->pre32_packed = false; }
   { const char* e = getenv("CTTS_PRE_X3"); if (e && atoi(e) == 0) g->pre_x3 = false; }
   { const char* e = getenv("CTTS_PRE_COMPACT"); if (e && atoi(e) == 0) g->pre_compact = false; }
+  { const char* e = getenv("CTTS_EMBED_FOLD"); if (e) g->embed_fold = atoi(e) != 0; }
   {
     int dev = 0, cus = 0;
     // OFF by default: measured on the C3 bench it does not pay (attention 9.3 -> 9.8 us per launch, 1296 -> 1280 audio-s/s,
@@ -251,6 +253,7 @@ static SampleArgs make_sample_args(const ctts_gen_state* s, const float* logits)
   a.desc = nullptr; a.rng_device = s->rng_device; a.rng_per_step = s->rng_per_step; a.rng_seed = reinterpret_cast<const unsigned long long*>(s->rng_seed);
   a.rng_nonce = s->rng_nonce;
   a.margin = s->margin; a.row_base = s->row_base;
+  memset(&a.next, 0, sizeof(a.next));
   return a;
 }
 
@@ -290,7 +293,7 @@ static bool prefill_compacts(const ctts_gpt* g, const ctts_gen_state* s) {   // 
 }
 
 static int run_step(ctts_gpt* g, const ctts_gen_state* s, int q_per_b, hipStream_t st, bool prof_ok, int slot0 = 0, bool heads = true,
-                    int ws_T = 0, int rows = 0, int pre_rows = 0) {
+                    int ws_T = 0, int rows = 0, int pre_rows = 0, const EmbedNext* next = nullptr) {
   const GptWs ws = carve(s->workspace, s->B, ws_T ? ws_T : s->T);
   // `rows` (decode only): a bound on the live compact rows this step can have -- grids and M are sized for it instead of B (buffer
   // geometry, the KV cache's batch stride above all, stays B's)
@@ -575,6 +578,7 @@ static int run_step(ctts_gpt* g, const ctts_gen_state* s, int q_per_b, hipStream
     sa.B = Bh;   // (the grid; q_rows keeps the batch geometry)
     sa.row_map = rmap; sa.n_active = nact;
     if (dec && dev_compact(g, s)) sa.desc = ws.desc;   // one load instead of the n_active -> row_map -> len chain
+    if (next != nullptr && sa.desc != nullptr && !s->infer_text) sa.next = *next;   // the next step's first kernel, folded into this launch
     if (s->infer_text) CK(launch_sample_text(sa, g->w.n_text, st));
     else CK(launch_sample(sa, st));
   }
@@ -623,8 +627,13 @@ extern "C" int ctts_gpt_prefill_chunk(ctts_gpt* g, const ctts_gen_state* s, cons
 // The decode step carves the workspace for ONE row per utterance (ctts_gpt_workspace_bytes(B, 1)) whatever the prompt length was: a
 // caller that prefills in chunks of tc slots needs max(bytes(B, tc), bytes(B, 1)), not bytes(B, T).  Nothing in the workspace
 // survives from the prefill into the decode steps (all generation state lives in ctts_gen_state's own arrays).
-static int decode_body(ctts_gpt* g, const ctts_gen_state* s, hipStream_t st, bool prof_ok, int rows = 0) {
+// skip_embed / fold_next (multi-step graphs, env CTTS_EMBED_FOLD=1): step i > 0 of the group finds its input rows written by step i - 1's
+// sampling launch (EmbedNext), step i < n - 1 writes them for step i + 1
+static int decode_body(ctts_gpt* g, const ctts_gen_state* s, hipStream_t st, bool prof_ok, int rows = 0, bool skip_embed = false,
+                       bool fold_next = false) {
   const GptWs ws = carve(s->workspace, s->B, 1);
+  EmbedNext nx;
+  memset(&nx, 0, sizeof(nx));
   { Prof p(g, 0, st, prof_ok); const bool fast = g->w.weight_dtype == CTTS_BF16;
     const bool packed = fast && g->dec_packed;
     const bool dc = dev_compact(g, s);
@@ -639,13 +648,16 @@ static int decode_body(ctts_gpt* g, const ctts_gen_state* s, hipStream_t st, boo
     const int32_t* nact0 = (!g->skip_finished && s->row_map == nullptr) ? nullptr : s->n_active;
     uint16_t* xb = fast ? (packed ? ws.xp : ws.xb) : x3 ? reinterpret_cast<uint16_t*>(ws.xp32) : nullptr;
     if (x3) sp.xb_lo_plane = ((size_t)((rows > 0 && rows < s->B) ? rows : s->B) + 15) / 16 * 16 * HID;   // = run_step's plane stride for this bound
-    if (s->infer_text)
+    const bool foldable = dc && !s->infer_text && sp.zero_p == nullptr;
+    if (fold_next && foldable) { nx.emb_code = g->w.emb_code; nx.x = ws.x; nx.xb = xb; nx.ssq = (fast || x3) ? ws.ssq : nullptr; nx.sp = sp; }
+    if (skip_embed && foldable) { /* written by the previous step's sampling launch */ }
+    else if (s->infer_text)
       CK(launch_embed_text(g->w.emb_text, g->w.n_text, s->ids_buf, s->cap ? s->cap : s->T + s->max_new, s->len, ws.x, xb,
                            (fast || x3) ? ws.ssq : nullptr, s->B, s->row_map, nact0, st, &sp));
     else
       CK(launch_embed_codes(g->w.emb_code, s->ids_buf, s->cap ? s->cap : s->T + s->max_new, s->len, ws.x, xb, (fast || x3) ? ws.ssq : nullptr, s->B,
                             s->row_map, nact0, st, &sp)); }
-  return run_step(g, s, 1, st, prof_ok, 0, true, 1, rows);
+  return run_step(g, s, 1, st, prof_ok, 0, true, 1, rows, 0, nx.x != nullptr ? &nx : nullptr);
 }
 
 extern "C" int ctts_gpt_decode_step(ctts_gpt* g, const ctts_gen_state* s, void* stream) {
@@ -668,7 +680,8 @@ static int capture_graphs(ctts_gpt* g, const ctts_gen_state* s, hipStream_t st, 
   if (g->multi_steps > 1) {
     CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
     int rc2 = 0;
-    for (int i = 0; i < g->multi_steps && rc2 == 0; ++i) rc2 = decode_body(g, s, st, false, rows);
+    for (int i = 0; i < g->multi_steps && rc2 == 0; ++i)
+      rc2 = decode_body(g, s, st, false, rows, g->embed_fold && i > 0, g->embed_fold && i + 1 < g->multi_steps);
     hipGraph_t g2 = nullptr;
     hipError_t e3 = hipStreamEndCapture(st, &g2);
     if (rc2 != 0) { if (g2) (void)hipGraphDestroy(g2); return -1; }

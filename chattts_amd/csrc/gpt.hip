@@ -1526,6 +1526,7 @@ __device__ __forceinline__ float wave_minf_dpp(float v) { return -wave_max_dpp(-
 __global__ __launch_bounds__(256) void sample_k(SampleArgs a) {
   __shared__ int tok_s[NVQ];
   __shared__ float marg_s[NVQ];
+  __shared__ int fin_s;
   __shared__ float cand_v[NVQ][64], cand_e[NVQ][64];
   __shared__ int cand_i[NVQ][64];
   CTTS_PROBE_RETURN();
@@ -1833,6 +1834,30 @@ __global__ __launch_bounds__(256) void sample_k(SampleArgs a) {
     a.len[b] = len + 1;
     // (a forced EOS -- the bench harness's stop_at -- decides nothing; one workgroup per utterance and step: no atomics needed)
     if (cert && !force_eos) a.margin[b] = fminf(a.margin[b], fminf(fminf(marg_s[0], marg_s[1]), fminf(marg_s[2], marg_s[3])));
+    fin_s = fin ? 1 : 0;
+  }
+  if (a.next.x != nullptr) {
+    // the next step's input row of this utterance, at the same compact row m (EmbedNext, kernels.hpp): what embed_codes_k writes
+    __syncthreads();
+    const int t = threadIdx.x;
+    const bool fin = fin_s != 0;
+    if (t == 0) {
+      const int ks = a.next.sp.kv_start[b];
+      a.next.sp.desc[m] = RowDesc{fin ? -1 : b, len, len - ks < 0 ? 1 : len - ks, ks > len ? len : ks};   // as write_desc, slot = len
+    }
+    if (!fin && t < 192) {
+      write_rope_cs(a.next.sp, m, b, len, t);
+      float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int c = 0; c < NVQ; ++c) {
+        const int id = min(max(tok_s[c], 0), NAUDIO - 1);
+        const float4 v = *reinterpret_cast<const float4*>(a.next.emb_code + ((size_t)c * NAUDIO + id) * HID + t * 4);
+        if (c == 0) s4 = v; else { s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w; }
+      }
+      emit_row(s4, t, a.next.x + (size_t)m * HID, xb_row_ptr(a.next.xb, m, t, a.next.sp.xb_packed),
+               a.next.ssq ? a.next.ssq + (size_t)m * SSQ_PARTS : nullptr,
+               a.next.sp.xp32 ? a.next.sp.xp32 + pk32_off(m, 4 * t, HID / 16) : nullptr, a.next.sp.xb_lo_plane);
+    }
   }
   SSTAMP(7);
 #undef SSTAMP

@@ -322,6 +322,15 @@ hipError_t launch_final_norm(const float* x, int q_per_b, const float* w, float 
 hipError_t launch_prefill_compact(const float* emb, float* x, RowDesc* desc, int32_t* last_row, int B, int T, const int32_t* kv_start,
                                   hipStream_t st);
 
+// The NEXT decode step's first kernel folded into sample_k's tail (multi-step graphs, device-side compaction): the workgroup that drew
+// utterance b's tokens also writes that utterance's next input row -- embedding sum, its bf16 / split / packed copies, partial sums of
+// squares, row descriptor, RoPE factors: everything embed_codes_k would -- at the SAME compact row m.  Compaction then lags: a row that
+// finished keeps its (dead) compact row until the next embed_codes_k launch re-ranks the finish flags.  x == null: off.
+struct EmbedNext {
+  const float* emb_code; float* x; uint16_t* xb; float* ssq;
+  StepPrep sp;
+};
+
 struct SampleArgs {
   const float* logits;      // [B, 4*626]
   int64_t* ids_buf;         // [B, Tcap, 4]
@@ -354,6 +363,7 @@ struct SampleArgs {
                             // every step (manual_seed set: the reference re-seeds its generator at every step, gpt.py:504-507)
   const uint32_t* rng_nonce;            // [slots] or null: per-slot fourth counter word of the device generator (slot pools: bumped per admission)
   const unsigned long long* rng_seed;   // device scalar
+  EmbedNext next;           // fold of the next step's embedding kernel (next.x == null: off)
   float* margin;            // [slots] or null: parity certificate, lowered to the step's smallest decision margin (include/chattts_amd.h)
   const int32_t* row_base;  // [B] or null: global index of sampling row 0 of utterance b (replaces row_offset + 4 b)
   long long* dbg;           // probes only (tools/sample_phase_probe.py, env CTTS_SAMPLE_DBG_PTR): [rows][8] phase stamps (100 MHz), or null

@@ -25,6 +25,23 @@ for S in $STAGES; do
     benchq)   # headline leg only
       timeout 600 python bench.py --steps 5 --warmup 2 $NOLEGS > gpurun_out/${TAG}_benchq.log 2>&1; echo "bench exit $?" >> gpurun_out/${TAG}_benchq.log
       grep "^{" gpurun_out/${TAG}_benchq.log | tail -1 | cut -c1-400 ;;
+    foldtests) # e2e ids / hidden-state goldens with the embedding fold on
+      CTTS_EMBED_FOLD=1 timeout 1800 python -m pytest tests/test_gpu_e2e.py -m gpu -q --tb=short -p no:cacheprovider -k "bit_exact or bench_workload or teacher or certificate or shard or interrupt or stream" > gpurun_out/${TAG}_foldtests.log 2>&1
+      echo "pytest exit $?" >> gpurun_out/${TAG}_foldtests.log; grep -E "^FAILED|^ERROR|passed|failed|pytest exit" gpurun_out/${TAG}_foldtests.log | tail -12 ;;
+    ab:*)     # ab:<ENV=VAL>: the headline leg (10 timed passes) and the bf16 leg with / without one environment switch, alternating
+      KV="${S#ab:}"
+      for rep in 1 2; do for on in 1 0; do
+        if [ $on = 1 ]; then export "$KV"; else unset "${KV%%=*}"; fi
+        for D in f32x3 bf16; do
+          timeout 600 python bench.py --dtype $D --steps 10 --warmup 2 $NOLEGS 2>/dev/null | grep "^{" | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$KV on=$on $D', d['value'], d['ms_per_step'])" | tee -a gpurun_out/${TAG}_ab.log
+        done
+      done; done; unset "${KV%%=*}" ;;
+    ttfs0)    # time to first sample with the prompt pass over all rows
+      CTTS_PRE_COMPACT=0 timeout 600 python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-parity-mode --no-configs --no-slot-pool --no-ids-check --no-bf16-mode --no-refine-text > gpurun_out/${TAG}_ttfs0.log 2>&1
+      grep "^{" gpurun_out/${TAG}_ttfs0.log | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('no compaction', {k: d.get(k) for k in ('value','ttfs_ms_p50','ttfs_ms_cold','ttfs_ms_cold_prewarmed')})" ;;
+    benchqc0) # headline leg only, prompt pass over all B * T rows (A/B of the valid-token compaction)
+      CTTS_PRE_COMPACT=0 timeout 600 python bench.py --steps 5 --warmup 2 $NOLEGS > gpurun_out/${TAG}_benchqc0.log 2>&1; echo "bench exit $?" >> gpurun_out/${TAG}_benchqc0.log
+      grep "^{" gpurun_out/${TAG}_benchqc0.log | tail -1 | cut -c1-400 ;;
     benchq0)  # headline leg only, prompt pass on the f32 MFMA kernels (A/B of prefill32x.hip)
       CTTS_PRE_X3=0 timeout 600 python bench.py --steps 5 --warmup 2 $NOLEGS > gpurun_out/${TAG}_benchq0.log 2>&1; echo "bench exit $?" >> gpurun_out/${TAG}_benchq0.log
       grep "^{" gpurun_out/${TAG}_benchq0.log | tail -1 | cut -c1-400 ;;
