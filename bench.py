@@ -79,7 +79,7 @@ def shard_workload(batch_per_gpu: int, world: int, rank: int, min_len: int, max_
     sel = D.deal_shards(mask.sum(1).tolist(), world, policy)[rank]
     contiguous = sel == list(range(sel[0], sel[0] + len(sel))) if sel else True
     return dict(Bg=Bg, sel=sel, lo=sel[0] if sel else 0, hi=(sel[-1] + 1) if sel else 0, ids=ids[sel], mask=mask[sel], tmask=tmask[sel], stop=stop[sel],
-                stop_all=stop, mask_all=mask, row_offset=(sel[0] * GPT.n_vq) if (sel and contiguous) else 0,
+                stop_all=stop, mask_all=mask, ids_all=ids, tmask_all=tmask, row_offset=(sel[0] * GPT.n_vq) if (sel and contiguous) else 0,
                 row_ids=None if contiguous else np.asarray(sel, np.int64), total_rows=Bg * GPT.n_vq)
 
 
@@ -650,13 +650,29 @@ def main():
             pass
         return out
 
+    def sharded_pass(eng, cdc):
+        """the same pass through the PRODUCT's data-parallel entry (chattts_amd.dist.infer_sharded, gather=False: every rank ends with ITS
+        utterances' float32 waveforms on its host): deal by prompt length, generate with global row ids, ONE 8-byte all-reduce(max) of the
+        longest utterance, decode padded to it.  What `bench.py --gpus N` times whenever a process group exists."""
+        from chattts_amd.core import Chat, InferCodeParams
+        chat = Chat()
+        chat.gpt, chat.codec = eng, cdc
+        p = InferCodeParams(top_P=0.7, top_K=20, temperature=0.3, repetition_penalty=1.05, max_new_token=max_new, min_new_token=0, manual_seed=42,
+                            show_tqdm=False)
+        mine, wav, ids_rows = D.infer_sharded(chat, torch.from_numpy(wl["ids_all"]), torch.from_numpy(wl["mask_all"]), torch.from_numpy(wl["tmask_all"]),
+                                              p, gather=False, stop_at=torch.from_numpy(stop.astype(np.int32)), return_ids=True,
+                                              use_graph=not args.no_graph, lanes=args.lanes)
+        assert mine == list(wl["sel"]), "bench.shard_workload and dist.infer_sharded disagree on the shards"
+        return [int(r.shape[0]) for r in ids_rows], wav, None
+
     def timed(eng, cdc, steps, warmup, tag=None, pipeline=None):
         """K passes, one batch after the other -- or (pipeline) SOFTWARE-PIPELINED over the queue of batches: the acoustic decode + waveform
         D2H of batch i run on the codec engine's side stream while batch i+1 is generated (CodecEngine.decode_to_wavs_async; every
         batch's float32 waveforms are on the host, as numpy, before the clock stops)."""
         pipeline = args.pipeline if pipeline is None else pipeline
+        a_pass = (lambda: sharded_pass(eng, cdc)) if (dist is not None and not pipeline) else (lambda: one_pass(eng, cdc, use_graph=not args.no_graph))
         for _ in range(warmup):
-            one_pass(eng, cdc, use_graph=not args.no_graph)
+            a_pass()
         if pipeline:     # the side stream's buffers exist before the clock starts
             cdc.decode_to_wavs_async(gpt_pass(eng).hiddens).result()
         barrier()
@@ -664,7 +680,7 @@ def main():
         pend, lens, wav = None, None, None
         for _ in range(steps):
             if not pipeline:
-                lens, wav, _ = one_pass(eng, cdc, use_graph=not args.no_graph)
+                lens, wav, _ = a_pass()
                 continue
             out = gpt_pass(eng)
             lens = [int(t.shape[0]) for t in out.ids]
@@ -761,6 +777,8 @@ def main():
                    "global_batch": Bg, "decode_steps_per_pass": gpt_steps, "parallelism": f"dp{world}", "lanes_per_gpu": args.lanes,
                    "tokens_per_pass": int(stop.sum()), "audio_s_per_pass": round(audio_seconds(stop), 2)},
         "ids_check": ids_check,
+        "data_parallel_entry": ("chattts_amd.dist.infer_sharded(gather=False): shards dealt by prompt length, global row ids, one all-reduce(max) "
+                                "before decoding" if dist is not None else "single process: GptEngine.generate + CodecEngine directly"),
         "known_deviations": ["top-p ties straddling the cut: engine and oracle keep lowest-index-first, the reference keeps whatever "
                              "torch.sort(stable=False) does (DESIGN.md 5; such a tie sets the certificate's margin to 0)"],
     }
@@ -1093,11 +1111,23 @@ def main():
 
     # ---- same-box CPU baseline: torch/MKL restatement on the reference's own stack (HF LlamaModel + DynamicCache) ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        note("cpu baseline (separate process, hard 200 s limit)")
+        note("cpu baseline (separate process, hard 170 s limit)")
         result["cpu_baseline"] = cpu_baseline_guarded(args)
 
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        def finite(o):      # strict JSON: no Infinity / NaN (e.g. the margin of a call that drew nothing)
+            if isinstance(o, float):
+                return o if np.isfinite(o) else None
+            if isinstance(o, dict):
+                return {k: finite(v) for k, v in o.items()}
+            if isinstance(o, (list, tuple)):
+                return [finite(v) for v in o]
+            return o
+        try:
+            line = json.dumps(finite(result), allow_nan=False)
+        except (TypeError, ValueError):
+            line = json.dumps(result, default=float)
+        print(line, flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -1160,7 +1190,7 @@ def cold_start_guarded(args, mode: str, limit_s: float = 240.0):
         return {"first_chunk_ms": None, "error": f"cold-start child exceeded {limit_s:.0f} s and was stopped"}
 
 
-def cpu_baseline_guarded(args, limit_s: float = 200.0):
+def cpu_baseline_guarded(args, limit_s: float = 170.0):
     """The CPU leg runs in its OWN process under a hard wall-clock limit: whatever the host does with 256 torch threads, the
     GPU numbers of this run are printed.  The child rebuilds the (seeded, fingerprinted) synthetic weights itself."""
     import subprocess
@@ -1180,7 +1210,7 @@ def cpu_baseline_guarded(args, limit_s: float = 200.0):
         return {"value": None, "error": f"cpu baseline child exceeded {limit_s:.0f} s and was stopped"}
 
 
-def cpu_baseline(sds, ids, mask, tmask, stop, budget_s: float = 140.0, codec_group: int = 8):
+def cpu_baseline(sds, ids, mask, tmask, stop, budget_s: float = 100.0, codec_group: int = 8):
     """oracle/torch_port.py timed on this box's host cores: the reference's own stack restated -- transformers'
     `LlamaModel` + `DynamicCache` + TopP/TopK warpers, torch.multinomial on the re-seeded CPU generator, DVAE and Vocos
     as torch conv1d / layer_norm / linear / istft -- float32 under torch/MKL.

@@ -1218,8 +1218,9 @@ def test_unseeded_stream_batch_not_aligned_to_the_draw_ring(gpt_f32, weights):
         assert np.array_equal(outs[-1].ids[b].cpu().numpy(), ref.ids[b]), b
 
 
-def test_chat_infer_text_level_matches_oracle(weights):
-    """`Chat.infer(text, ...)` (core.py:208-270) end to end in f32 parity mode: normalise -> decorate -> tokenise ->
+@pytest.mark.parametrize("dtype", ["f32", "f32x3"])
+def test_chat_infer_text_level_matches_oracle(weights, dtype):
+    """`Chat.infer(text, ...)` (core.py:208-270) end to end in both parity modes: normalise -> decorate -> tokenise ->
     embed -> speaker vector at [spk_emb] -> generate, and the refine-text leg; token ids and refined strings equal the
     numpy oracle driven by the same host front end (the front end itself is pinned in tests/test_frontend.py)."""
     import os
@@ -1229,7 +1230,7 @@ def test_chat_infer_text_level_matches_oracle(weights):
     with open(os.path.join(gold, "spk_stat.txt"), encoding="utf-8") as f:
         spk_stat = f.read()
     chat = Chat()
-    assert chat.load(state_dicts=weights, device=DEV, dtype="f32", tokenizer=os.path.join(gold, "tokenizer"), spk_stat=spk_stat)
+    assert chat.load(state_dicts=weights, device=DEV, dtype=dtype, tokenizer=os.path.join(gold, "tokenizer"), spk_stat=spk_stat)
     tok = chat.tokenizer
     torch.manual_seed(11)
     spk = chat.sample_random_speaker()
@@ -1241,6 +1242,8 @@ def test_chat_infer_text_level_matches_oracle(weights):
     wavs = chat.infer(list(texts), skip_refine_text=True, split_text=False, params_infer_code=p)
     full = chat.decode_to_wavs(out.hiddens)
     assert len(wavs) == 2 and all(np.array_equal(w, r[np.abs(r) > 1e-5]) for w, r in zip(wavs, full))
+    sharded = chat.infer_sharded(list(texts), params_infer_code=p)        # no process group: the unsharded call
+    assert len(sharded) == 2 and all(np.array_equal(a, b) for a, b in zip(sharded, wavs))
 
     # oracle leg: same normaliser + decoration + tokenizer, numpy embedding with the unit speaker vector substituted
     ids, mask, tmask = tok.encode(F.Speaker.decorate_code_prompts(normed, p.prompt, None, spk), 4)

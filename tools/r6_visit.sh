@@ -39,6 +39,9 @@ for S in $STAGES; do
     ttfs0)    # time to first sample with the prompt pass over all rows
       CTTS_PRE_COMPACT=0 timeout 600 python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-parity-mode --no-configs --no-slot-pool --no-ids-check --no-bf16-mode --no-refine-text > gpurun_out/${TAG}_ttfs0.log 2>&1
       grep "^{" gpurun_out/${TAG}_ttfs0.log | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('no compaction', {k: d.get(k) for k in ('value','ttfs_ms_p50','ttfs_ms_cold','ttfs_ms_cold_prewarmed')})" ;;
+    torchrun1) # the N-rank code path on one GPU: torch.distributed.run, RCCL world 1, dist.infer_sharded inside the clock
+      timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_torchrun1.log 2>&1
+      echo "exit $?" >> gpurun_out/${TAG}_torchrun1.log; grep "^{" gpurun_out/${TAG}_torchrun1.log | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print({k: d.get(k) for k in ('value','n_gpus','data_parallel_entry')}, d.get('ranks',{}).get('weight_broadcast',{}).get('ms'), d['ids_check'])"; tail -2 gpurun_out/${TAG}_torchrun1.log | cut -c1-200 ;;
     benchqc0) # headline leg only, prompt pass over all B * T rows (A/B of the valid-token compaction)
       CTTS_PRE_COMPACT=0 timeout 600 python bench.py --steps 5 --warmup 2 $NOLEGS > gpurun_out/${TAG}_benchqc0.log 2>&1; echo "bench exit $?" >> gpurun_out/${TAG}_benchqc0.log
       grep "^{" gpurun_out/${TAG}_benchqc0.log | tail -1 | cut -c1-400 ;;
