@@ -161,7 +161,7 @@ extern "C" int ctts_gpt_create(ctts_gpt** out, const ctts_gpt_weights* w) {
     g->dec_packed32 = on && w->weight_dtype != CTTS_BF16 && w->kv_dtype != CTTS_BF16;
   }
   { const char* e = getenv("CTTS_DEC_PACKED"); g->heads_packed = w->heads_pk != nullptr && !(e && atoi(e) == 0); }
-  if (w->wqkv_x3 && w->wo_x3 && w->wgu_x3 && w->wd_x3 && g->dec_packed32) {
+  if (w->wqkv_x3 && w->wo_x3 && w->wgu_x3 && w->wd_x3 && w->weight_dtype != CTTS_BF16 && w->kv_dtype != CTTS_BF16) {   // (w*_pk: optional beside them)
     g->wqkv_x3.assign(w->wqkv_x3, w->wqkv_x3 + L);
     g->wo_x3.assign(w->wo_x3, w->wo_x3 + L);
     g->wgu_x3.assign(w->wgu_x3, w->wgu_x3 + L);
@@ -319,7 +319,8 @@ static int run_step(ctts_gpt* g, const ctts_gen_state* s, int q_per_b, hipStream
   if (packed) { const char* e = getenv("CTTS_ATT_DBG_PTR"); if (e) rm.dbg = (long long*)strtoull(e, nullptr, 0); }   // probes only
   // decode on packed operands: final RMSNorm + hidden capture + heads are ONE launch (decode32.hip gemm_dec32_fnorm16_k; the residual
   // stream reaches it in the packed f32 order: parity mode keeps it that way anyway, perf mode has the last down_proj write it)
-  const bool packed32_ = !fast && dec && g->dec_packed32;
+  // (the fused launch reads the last down_proj's packed f32 rows: written by the x3 step and by the packed f32 step, not by the row-major one)
+  const bool packed32_ = !fast && dec && ((g->dec_x3 && !s->proj_exact) || g->dec_packed32);
   const bool fuse_fnorm = dec && heads && g->fnorm_fuse && g->heads_packed && (packed || packed32_) &&
                           (s->infer_text ? g->w.head_text_pk : g->w.heads_pk) != nullptr;
   for (int l = 0; packed && l < g->w.n_layers; ++l) {
@@ -409,7 +410,7 @@ static int run_step(ctts_gpt* g, const ctts_gen_state* s, int q_per_b, hipStream
   }
   // parity mode decode step on SPLIT-bf16 operands (decode32x.hip): hi | lo planes in the buffers the f32 kernels use for their packed
   // operands (same bytes: 2 planes x 2 B), the heads' packed f32 operand in ws.hfinp
-  const bool x3 = !fast && dec && g->dec_packed32 && g->dec_x3 && !s->proj_exact;
+  const bool x3 = !fast && dec && g->dec_x3 && !s->proj_exact;
   const size_t Bp16 = ((size_t)M + 15) / 16 * 16;
   for (int l = 0; x3 && l < g->w.n_layers; ++l) {
     void* kc = (char*)s->kcache + kv_layer * l;
@@ -637,7 +638,7 @@ static int decode_body(ctts_gpt* g, const ctts_gen_state* s, hipStream_t st, boo
   { Prof p(g, 0, st, prof_ok); const bool fast = g->w.weight_dtype == CTTS_BF16;
     const bool packed = fast && g->dec_packed;
     const bool dc = dev_compact(g, s);
-    const bool x3 = !fast && g->dec_packed32 && g->dec_x3 && !s->proj_exact;   // split-bf16 parity mode: the residual rows as hi | lo planes (decode32x.hip)
+    const bool x3 = !fast && g->dec_x3 && !s->proj_exact;   // split-bf16 parity mode: the residual rows as hi | lo planes (decode32x.hip)
     StepPrep sp{ws.desc, s->kv_start, g->skip_finished ? s->finish : nullptr, (packed || x3) ? 1 : 0, (!fast && g->dec_packed32 && !x3) ? ws.xp32 : nullptr,
                 dc ? ws.row_map : nullptr,
                 dc ? const_cast<int32_t*>(s->n_active) : nullptr, dc ? s->order : nullptr,

@@ -308,23 +308,26 @@ class GptEngine:
         # decode32.hip); the row-major copy stays for the prefill kernels (+0.38 GB / +0.75 GB of the 288 GB)
         # (CTTS_DEC_PACKED=0, the A/B switch back to the row-major decode kernels, skips building them)
         use_packed = os.environ.get("CTTS_DEC_PACKED", "1") != "0"
+        self.certify = (dtype == "f32x3") if certify is None else bool(certify)
+        self.exact_fallback = bool(exact_fallback) and dtype == "f32x3"
         pk = pack_frag if dtype == "bf16" else pack_frag32
         self.packed, self._pk_arrs = None, None
-        if use_packed:
+        rp = rope_row_perm().to(dev)
+        qk_perm = torch.cat([rp, GPT.hidden + rp, 2 * GPT.hidden + torch.arange(GPT.hidden, device=dev)])
+        # "f32x3" reads the packed f32 copies only on an exact call (the fallback of its certificate, generate(exact=True)): without
+        # `exact_fallback` they are not built (0.75 GB, and the packing time at load) -- an exact call then runs the row-major f32
+        # kernels, bit-identical results (test_packed_f32_decode_is_bit_identical_to_row_major)
+        if use_packed and (dtype != "f32x3" or self.exact_fallback):
             self.packed = [[pk(t) for t in ws] for ws in (self.wqkv, self.wo, self.wgu, self.wd)]
             if dtype != "bf16":
                 # the packed f32 QKV matrix carries the RoPE row permutation too (its decode kernel rotates in the epilogue); an
                 # output column's dot product does not depend on where the column sits, so the parity arithmetic is untouched
-                rp = rope_row_perm().to(dev)
-                qk_perm = torch.cat([rp, GPT.hidden + rp, 2 * GPT.hidden + torch.arange(GPT.hidden, device=dev)])
                 self.packed[0] = [pack_frag32(t[qk_perm]) for t in self.wqkv]
             self._pk_arrs = [_lib.ptr_array(x) for x in self.packed]
         # dtype "f32x3": decode step on split-bf16 operands (csrc/decode32x.hip): the four matrices once more as hi | lo bf16 planes (the
-        # float32 bytes again), the RMSNorm gains folded in before the split.  The packed f32 copies above stay: the prompt pass reads
-        # them (prefill32.hip) and so does the exact fallback of a certificate that fired (ctts_gen_state.proj_exact)
+        # float32 bytes again), the RMSNorm gains folded in before the split; the prompt pass splits the row-major f32 matrices in its
+        # tile loader (csrc/prefill32x.hip)
         self.x3, self._x3_arrs = None, None
-        self.certify = (dtype == "f32x3") if certify is None else bool(certify)
-        self.exact_fallback = bool(exact_fallback) and dtype == "f32x3"
         if use_packed and dtype == "f32x3":
             gain = lambda w_, g_: w_.float() * g_.float()[None, :]
             self.x3 = [[pack_frag_x3(gain(t[qk_perm], g_)) for t, g_ in zip(self.wqkv, self.ln1)], [pack_frag_x3(t) for t in self.wo],

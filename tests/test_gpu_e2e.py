@@ -247,6 +247,15 @@ def test_parity_certificate_and_exact_fallback(weights, monkeypatch):
     want_bound = 2.0 * E.GptEngine.REL_ERR_X3 * x3.logit_scale[False] / min(c["temperature"])
     assert abs(st["margin_bound"] - want_bound) < 1e-9 * max(1.0, want_bound) and st["exact_rerun_rows"] == []
     assert "min_margin" not in exact.last_stats                      # one arithmetic: nothing to certify
+    # an exact call on the engine that did not build the packed f32 copies (no fallback asked for): the row-major f32 kernels, same bits
+    assert x3.packed is None and exact.packed is not None
+    ids_c, mask_c, tmask_c = cases.gen_inputs(c)
+    ids_t, mask_t = torch.from_numpy(ids_c), torch.from_numpy(mask_c)
+    warpers, procs = E.gen_logits(625, c["top_P"], c["top_K"], c["rep"])
+    out_xe = list(x3.generate(x3.embed_prompt(ids_t, torch.from_numpy(tmask_c)), ids_t, torch.tensor(c["temperature"]), 625, mask_t, c["max_new"],
+                              c["min_new"], (*procs, *warpers), return_hidden=True, manual_seed=c["manual_seed"], exact=True))[-1]
+    for b in range(8):
+        assert torch.equal(out_xe.ids[b], out_e.ids[b]) and torch.equal(out_xe.hiddens[b], out_e.hiddens[b]), b
     fb = E.GptEngine(weights["gpt"], weights["embed"], DEV, dtype="f32x3", exact_fallback=True)
     monkeypatch.setattr(E.GptEngine, "REL_ERR_X3", 1e3)              # (2) everything is "unsafe"
     out_f = run_case(fb, c, use_graph=True)[0][-1]
