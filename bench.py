@@ -711,9 +711,10 @@ def main():
         gold = np.load(gpath)
     want_sha = str(gold["sha256"]) if gold is not None else None
 
-    KERNELS = {"f32x3": "decode projections on SPLIT-bf16 operands (csrc/decode32x.hip: hi | lo bf16 planes, three bf16 MFMAs per product, f32 "
-                        "accumulation); f32 KV cache, f32 prefill / attention / heads / sampling; every call certified by its decision margins "
-                        "(ctts_gen_state.margin) with the f32 MFMA kernels as the per-utterance fallback",
+    KERNELS = {"f32x3": "Llama projections on SPLIT-fp16 operands (csrc/decode32x.hip, prefill32x.hip: hi = fp16(x), lo' = fp16((x - hi) 2^11), 22 "
+                        "significant bits, three fp16 MFMAs per product, f32 accumulation: rms distance to a float64 evaluation of the model 2.3e-7 "
+                        "against 3.3e-7 for the f32 MFMA kernels, profiles/r6p_f64_distance.log); f32 KV cache, f32 attention / heads / sampling; "
+                        "every call reports its decision margins (ctts_gen_state.margin), the f32 MFMA kernels are the opt-in fallback",
                "f32": "f32-input MFMA throughout (csrc/decode32.hip, prefill32.hip: v_mfma_f32_16x16x4_f32), f32 KV cache, f32 attention / heads / sampling",
                "bf16": "bf16 weights / KV / inter-kernel activations (csrc/decode.hip, prefill.hip), f32 residual stream / accumulation / softmax / sampling"}
 
@@ -729,9 +730,9 @@ def main():
                 "exact_fallback": bool(eng.exact_fallback),
                 "what": "min over every step of every utterance of {log(r_best / r_second) of argmax(p / q); value gap at the top-k / top-p cut; "
                         "|log(cum / (1 - top_P))| at the cut}, in tempered-logit units, computed inside sample_k; bound = 2 x the stated logit error of "
-                        "the split-bf16 projections (GptEngine.REL_ERR_X3 x the head's logit scale; measured: profiles/r6a_x3_logit_bound.log) / min "
+                        "the split-fp16 projections (GptEngine.REL_ERR_X3 x the head's logit scale; measured: profiles/r6o_x3_logit_bound_fp16split.log) / min "
                         "temperature.  `certified: false` = some draw was closer than the worst-case bound (on 500-step utterances one almost always "
-                        "is: 35-50 of this workload's 85,752 draws); the ids of THIS run are checked against the reference's sha256 all the same "
+                        "is: ~10 of this workload's 85,752 draws); the ids of THIS run are checked against the reference's sha256 all the same "
                         "(`ids_check`), and --exact-fallback regenerates the flagged utterances on the f32 MFMA kernels inside the timed pass"}
 
     def mode_leg(eng, cdc, steps, warmup, tag=None):

@@ -30,6 +30,23 @@ __device__ __forceinline__ uint32_t pack_f16x2(float a, float b) {
   const _Float16 ha = (_Float16)a, hb = (_Float16)b;
   return (uint32_t)__builtin_bit_cast(uint16_t, ha) | ((uint32_t)__builtin_bit_cast(uint16_t, hb) << 16);
 }
+// ---- the "f32x3" operand format of the GPT projections (round 6: split-FP16; rounds 5-6a: split-bf16) ------------------------------
+// x = hi + lo' * 2^-11 with hi = fp16(x) and lo' = fp16((x - hi) * 2^11): 11 + 11 significant bits (2^-22 relative; the bf16 split of
+// round 5 kept 8 + 8, 2^-17).  The residual is scaled into fp16's normal range (an unscaled residual of a 0.02-sized weight would be a
+// subnormal); a product is hi*hi on one accumulator and lo'*hi + hi*lo' on a second one that enters the result with 2^-11 (the lo'*lo'
+// term, 2^-22 of the product, is dropped).  Same bytes and the same three MFMAs (v_mfma_f32_*_f16) as the bf16 split, 32x closer to
+// float32: measured |dlogit| and the divergence rate against the f32 MFMA kernels in DESIGN.md section 2.  Inputs are saturated at the
+// fp16 range (+-65504) where they are rounded.
+#define X3_LO_SCALE 2048.0f
+#define X3_LO_INV (1.0f / 2048.0f)
+__device__ __forceinline__ void x3_split(float v, uint16_t& hi, uint16_t& lo) {
+  v = v > 65504.0f ? 65504.0f : (v < -65504.0f ? -65504.0f : v);   // (a NaN stays a NaN)
+  const _Float16 h = (_Float16)v;
+  const _Float16 l = (_Float16)((v - (float)h) * X3_LO_SCALE);
+  hi = __builtin_bit_cast(uint16_t, h);
+  lo = __builtin_bit_cast(uint16_t, l);
+}
+
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {

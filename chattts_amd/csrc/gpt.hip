@@ -41,10 +41,10 @@ __device__ __forceinline__ void emit_row(float4 s, int t, float* __restrict__ x_
     ushort4 o;
     o.x = f32_to_bf16(s.x); o.y = f32_to_bf16(s.y); o.z = f32_to_bf16(s.z); o.w = f32_to_bf16(s.w);
     *reinterpret_cast<ushort4*>(xb_row + t * 4) = o;   // columns 4t..4t+3 share one 8-column group in either layout
-    if (lo_plane) {   // split-bf16 parity mode (decode32x.hip): the lo plane, lo = bf16(x - hi), lo_plane elements behind the hi plane
-      ushort4 l;
-      l.x = f32_to_bf16(s.x - bf16_to_f32(o.x)); l.y = f32_to_bf16(s.y - bf16_to_f32(o.y));
-      l.z = f32_to_bf16(s.z - bf16_to_f32(o.z)); l.w = f32_to_bf16(s.w - bf16_to_f32(o.w));
+    if (lo_plane) {   // "f32x3" parity mode (decode32x.hip): BOTH planes in the split-fp16 format (common.hpp x3_split), lo_plane elements apart
+      ushort4 h, l;
+      x3_split(s.x, h.x, l.x); x3_split(s.y, h.y, l.y); x3_split(s.z, h.z, l.z); x3_split(s.w, h.w, l.w);
+      *reinterpret_cast<ushort4*>(xb_row + t * 4) = h;
       *reinterpret_cast<ushort4*>(xb_row + lo_plane + t * 4) = l;
     }
   }
@@ -320,9 +320,10 @@ template <> __device__ __forceinline__ void store_out<x3p_t>(x3p_t* p, float v) 
 template <typename OT> __device__ __forceinline__ void store_pko(OT* out, int m, int c, float v, size_t);
 template <> __device__ __forceinline__ void store_pko<x3p_t>(x3p_t* out, int m, int c, float v, size_t plane) {
   uint16_t* p = reinterpret_cast<uint16_t*>(out) + pk_off(m, c, HID / 32);
-  const bf16_t h = f32_to_bf16(v);
+  uint16_t h, l;
+  x3_split(v, h, l);
   p[0] = h;
-  p[plane] = f32_to_bf16(v - bf16_to_f32(h));
+  p[plane] = l;
 }
 template <> __device__ __forceinline__ void store_out<float>(float* p, float v) { *p = v; }
 template <> __device__ __forceinline__ void store_out<bf16_t>(bf16_t* p, float v) { *p = f32_to_bf16(v); }

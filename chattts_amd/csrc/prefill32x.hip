@@ -1,10 +1,10 @@
-// Prompt pass of the "f32x3" parity mode (round 6): the four projections of a layer over M = B * T prompt rows on SPLIT-bf16 operands,
+// Prompt pass of the "f32x3" parity mode (round 6): the four projections of a layer over M = B * T prompt rows on SPLIT-fp16 operands,
 // LDS-tiled.  Until round 5 the f32x3 mode ran its prompt on the f32-input MFMA kernels of prefill32.hip (v_mfma_f32_16x16x4_f32, a
 // sixteenth of the bf16 rate): 694 us per layer = 13.9 ms per pass at 3072 prompt rows, a fifth of the time to the first streamed chunk.
 // Here both operands are read as FLOAT32, row-major (the residual stream / activations the row-major parity path keeps, and the plain
-// [N, K] weight matrices the loader keeps for it), split into hi = bf16(x), lo = bf16(x - hi) by the tile loader on their way into LDS,
-// and a product is lo*hi + hi*lo + hi*hi on v_mfma_f32_32x32x16_bf16 with f32 accumulation -- the arithmetic of the mode's decode step
-// (decode32x.hip), no extra copy of any weight.  The RMSNorm gain multiplies the activation BEFORE the split (a' = a * g[k], one f32
+// [N, K] weight matrices the loader keeps for it), split into hi = fp16(x), lo' = fp16((x - hi) 2^11) (common.hpp x3_split: 22
+// significant bits) by the tile loader on their way into LDS, and a product is hi*hi on one accumulator and lo'*hi + hi*lo' on a second
+// one (x 2^-11) on v_mfma_f32_32x32x16_f16 -- the arithmetic of the mode's decode step (decode32x.hip), no extra copy of any weight.  The RMSNorm gain multiplies the activation BEFORE the split (a' = a * g[k], one f32
 // multiply in the loader); the row's 1 / rms (launch_rows_rstd32, the f32 kernels' bits) scales the accumulator.
 //   EPI_STORE     C = rstd * acc                      (QKV; RoPE + KV append stay the row-major path's rope_append_k)
 //   EPI_RES       C = res + acc                       (o_proj / down_proj)
@@ -21,17 +21,18 @@ constexpr int XBK = 32, XLD = XBK + 8;   // 80-byte LDS rows
 constexpr int XNT = 256;
 
 typedef float xf2 __attribute__((ext_vector_type(2)));
-typedef __bf16 xb2 __attribute__((ext_vector_type(2)));
+typedef _Float16 xb2 __attribute__((ext_vector_type(2)));
 
-// hi = bf16(v) (round to nearest even: v_cvt_pk_bf16_f32, two values per instruction), lo = bf16(v - hi).  The split runs once per
-// element and k-step in the tile loader, so its VALU cost is on the critical path beside 24 MFMAs per wave: the software conversion of
-// common.hpp (7 integer ops per value) made the loader VALU-bound (257 us per gate/up launch, profiles/r6h_kernel_stats_f32x3.csv).
+// The split runs once per element and k-step in the tile loader, so its VALU cost is on the critical path beside 24 MFMAs per wave:
+// hardware conversions, two values per instruction (the first version, a software bf16 conversion of 7 integer ops per value, made the
+// loader VALU-bound: 257 us per gate/up launch against 170, profiles/r6h / r6i_kernel_stats_f32x3.csv).
 __device__ __forceinline__ void split2(const float a, const float b, uint32_t& hi, uint32_t& lo) {
-  const xf2 v = {a, b};
+  // the split-fp16 format of common.hpp x3_split, two values per packed conversion (v_cvt_pk / v_cvt_f16_f32, round to nearest even)
+  const xf2 v = {a > 65504.0f ? 65504.0f : (a < -65504.0f ? -65504.0f : a), b > 65504.0f ? 65504.0f : (b < -65504.0f ? -65504.0f : b)};
   const xb2 h = __builtin_convertvector(v, xb2);
   hi = __builtin_bit_cast(uint32_t, h);
-  const xf2 hf = {__uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u)};
-  const xb2 l = __builtin_convertvector(v - hf, xb2);
+  const xf2 hf = __builtin_convertvector(h, xf2);
+  const xb2 l = __builtin_convertvector((v - hf) * X3_LO_SCALE, xb2);
   lo = __builtin_bit_cast(uint32_t, l);
 }
 __device__ __forceinline__ void split4(const float4 v, ushort4& hi, ushort4& lo) {
@@ -95,13 +96,13 @@ __global__ __launch_bounds__(XNT) void gemm_pre_x3_k(GemmArgs a, const float* __
     }                                                                                                             \
   } while (0)
 
-  f32x16 acc[MBLK][2];
+  f32x16 acc[MBLK][2], accx[MBLK][2];   // hi*hi | the cross terms (they enter with 2^-11)
 #pragma unroll
   for (int i = 0; i < MBLK; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; accx[i][j][r] = 0.f; }
 
   X_FETCH(0);
   X_STAGE(0);
@@ -117,22 +118,22 @@ __global__ __launch_bounds__(XNT) void gemm_pre_x3_k(GemmArgs a, const float* __
     if (k0 + 2 * XBK < K) X_FETCH(k0 + 2 * XBK);
 #pragma unroll
     for (int kk = 0; kk < XBK; kk += 16) {
-      const bf16x8 wh0 = *reinterpret_cast<const bf16x8*>(&Ws[sb][0][wrow0 + ri][kk + kg]);
-      const bf16x8 wl0 = *reinterpret_cast<const bf16x8*>(&Ws[sb][1][wrow0 + ri][kk + kg]);
-      const bf16x8 wh1 = *reinterpret_cast<const bf16x8*>(&Ws[sb][0][wrow1 + ri][kk + kg]);
-      const bf16x8 wl1 = *reinterpret_cast<const bf16x8*>(&Ws[sb][1][wrow1 + ri][kk + kg]);
+      const f16x8 wh0 = *reinterpret_cast<const f16x8*>(&Ws[sb][0][wrow0 + ri][kk + kg]);
+      const f16x8 wl0 = *reinterpret_cast<const f16x8*>(&Ws[sb][1][wrow0 + ri][kk + kg]);
+      const f16x8 wh1 = *reinterpret_cast<const f16x8*>(&Ws[sb][0][wrow1 + ri][kk + kg]);
+      const f16x8 wl1 = *reinterpret_cast<const f16x8*>(&Ws[sb][1][wrow1 + ri][kk + kg]);
 #pragma unroll
       for (int i = 0; i < MBLK; ++i) {
-        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&As[sb][0][(wm * MBLK + i) * 32 + ri][kk + kg]);
-        const bf16x8 al = *reinterpret_cast<const bf16x8*>(&As[sb][1][(wm * MBLK + i) * 32 + ri][kk + kg]);
-        f32x16 c0 = acc[i][0], c1 = acc[i][1];   // small terms first
-        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wh0, c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wh1, c1, 0, 0, 0);
-        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wl0, c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wl1, c1, 0, 0, 0);
-        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wh0, c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wh1, c1, 0, 0, 0);
-        acc[i][0] = c0; acc[i][1] = c1;
+        const f16x8 ah = *reinterpret_cast<const f16x8*>(&As[sb][0][(wm * MBLK + i) * 32 + ri][kk + kg]);
+        const f16x8 al = *reinterpret_cast<const f16x8*>(&As[sb][1][(wm * MBLK + i) * 32 + ri][kk + kg]);
+        f32x16 x0 = accx[i][0], x1 = accx[i][1];
+        x0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, wh0, x0, 0, 0, 0);
+        x1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, wh1, x1, 0, 0, 0);
+        x0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wl0, x0, 0, 0, 0);
+        x1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wl1, x1, 0, 0, 0);
+        accx[i][0] = x0; accx[i][1] = x1;
+        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wh0, acc[i][0], 0, 0, 0);
+        acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wh1, acc[i][1], 0, 0, 0);
       }
     }
     __syncthreads();
@@ -142,6 +143,12 @@ __global__ __launch_bounds__(XNT) void gemm_pre_x3_k(GemmArgs a, const float* __
 #undef X_STAGE
 
   // ---- epilogue: lane holds column (lane & 31) of a 32-column block, rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5) ----
+#pragma unroll
+  for (int i = 0; i < MBLK; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] += accx[i][j][r] * X3_LO_INV;
   const int cl = lane & 31;
 #pragma unroll
   for (int i = 0; i < MBLK; ++i) {

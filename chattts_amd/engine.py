@@ -177,19 +177,29 @@ def pack_frag(w: torch.Tensor) -> torch.Tensor:
     return w.reshape(R // 16, 16, Cc // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous()
 
 
+X3_LO_SCALE = 2048.0
+
+
+def split_f16(w: torch.Tensor):
+    """float32 -> (hi, lo') float16: the "f32x3" operand format of the GPT projections (csrc/common.hpp x3_split): hi = fp16(w),
+    lo' = fp16((w - hi) * 2^11), w = hi + lo' / 2^11 to 22 significant bits; inputs saturated at the fp16 range."""
+    w = w.to(torch.float32).clamp(-65504.0, 65504.0)
+    hi = w.to(torch.float16)
+    lo = ((w - hi.to(torch.float32)) * X3_LO_SCALE).to(torch.float16)
+    return hi, lo
+
+
 def pack_frag_x3(w: torch.Tensor) -> torch.Tensor:
-    """float32 [R, C] -> the SPLIT-bf16 planes of csrc/decode32x.hip: [2][R/16][C/32][64][8] bf16, plane 0 = hi = bf16(w), plane 1 = lo =
-    bf16(w - hi) (w = hi + lo to 16-17 significant bits), each plane in pack_frag's fragment order.  Three bf16 MFMAs (lo*hi + hi*lo +
-    hi*hi, f32 accumulation) then stand for one float32 product."""
-    w = w.to(torch.float32)
-    hi = w.to(torch.bfloat16)
-    lo = (w - hi.to(torch.float32)).to(torch.bfloat16)
+    """float32 [R, C] -> the SPLIT-fp16 planes of csrc/decode32x.hip: [2][R/16][C/32][64][8] float16, plane 0 = hi = fp16(w), plane 1 =
+    lo' = fp16((w - hi) * 2^11) (w = hi + lo' / 2^11 to 22 significant bits), each plane in pack_frag's fragment order.  Three fp16 MFMAs
+    (hi*hi; lo'*hi + hi*lo' on a second accumulator, x 2^-11; f32 accumulation) then stand for one float32 product."""
+    hi, lo = split_f16(w)
     return torch.stack([pack_frag(hi), pack_frag(lo)], 0).contiguous()
 
 
 def unpack_frag_x3(p: torch.Tensor, R: int, Cc: int) -> torch.Tensor:
-    """planes -> float32 hi + lo (tests)"""
-    return unpack_frag(p[0].float(), R, Cc) + unpack_frag(p[1].float(), R, Cc)
+    """planes -> float32 hi + lo' / 2048 (tests)"""
+    return unpack_frag(p[0].float(), R, Cc) + unpack_frag(p[1].float(), R, Cc) / X3_LO_SCALE
 
 
 def pack_wo_heads(wo: torch.Tensor) -> torch.Tensor:
@@ -236,21 +246,23 @@ class GptEngine:
     # Stated bound on what the split-bf16 decode projections ("f32x3") move a PRE-temperature logit by, against the exact f32 kernels
     # under the same token history, RELATIVE to the head's logit scale (rms over the vocabulary of |W_v| * rms(final norm gain): the
     # standard deviation a logit has for a unit-rms hidden state; 4.02 for the synthetic checkpoint).  Measured with tools/x3_logit_bound.py
-    # on the bench workload (all 64 rows, every step, teacher-forced on the reference's stream; profiles/r6a_x3_logit_bound.log): max
-    # |dlogit| 8.6e-5 = 2.14e-5 of the scale over 13.4 M logits (rms 3.3e-6), stated here with a 1.5x allowance; re-measure on a trained
-    # checkpoint.  The certificate compares 2 * REL_ERR_X3 * scale / min(temperature) with the smallest decision margin of the call
+    # on the bench workload (all 64 rows, every step, teacher-forced on the reference's stream; profiles/r6o_x3_logit_bound_fp16split.log):
+    # max |dlogit| 1.42e-5 = 3.5e-6 of the scale over 13.4 M logits (rms 3.5e-7; the bf16 split of round 5: 2.1e-5 / 3.3e-6), stated here
+    # with a 1.5x allowance; re-measure on a trained checkpoint.  The certificate compares 2 * REL_ERR_X3 * scale / min(temperature) with the smallest decision margin of the call
     # (ctts_gen_state.margin).  What the same measurement says about LONG calls: the margins of the workload's 85,752 draws have density
-    # ~0.8 per tempered-logit unit near 0 (smallest 1.3e-5), so ~50 draws sit below the bound and most 500-step utterances hold one -- a
-    # worst-case bound cannot certify them, although not one of the 85,752 draws actually differs between the two arithmetics.
-    REL_ERR_X3 = 3.2e-5
+    # ~0.8 per tempered-logit unit near 0 (smallest 1.3e-5), so ~10 draws sit below the bound: a worst-case bound flags several 500-step
+    # utterances per batch although not one of the 85,752 draws actually differs between the two arithmetics (empirical rate on random
+    # inputs: 1.3e-6 per draw, every divergence flagged: profiles/r6o_x3_flip_rate_fp16split.log).
+    REL_ERR_X3 = 5.3e-6
 
     def __init__(self, gpt_sd: dict, embed_sd: dict, device: torch.device, dtype: str = "bf16",
                  max_pos: int = GPT.max_pos, logger: logging.Logger = log, rms_eps: float = GPT.rms_eps,
                  rope_theta: float = GPT.rope_theta, certify: Optional[bool] = None, exact_fallback: bool = False):
         """`dtype` names the arithmetic, explicitly:
           "f32"   -- the parity mode on float32 arithmetic throughout (f32-input MFMA, csrc/decode32.hip / prefill32.hip);
-          "f32x3" -- the parity mode with the DECODE projections on split-bf16 operands (csrc/decode32x.hip: 16-17 significant bits per
-                     operand, f32 accumulation; prefill, attention, heads and sampling stay float32).  Same token ids as "f32" whenever no
+          "f32x3" -- the parity mode with the Llama projections on SPLIT-fp16 operands (csrc/decode32x.hip, prefill32x.hip: 22 significant
+                     bits per operand, exact products, f32 accumulation -- measured closer to a float64 evaluation of the model than the
+                     f32 MFMA kernels, profiles/r6p_f64_distance.log; attention, heads and sampling stay float32).  Same token ids as "f32" whenever no
                      draw of the call was decided by less than the arithmetic's logit error: every call computes its smallest decision
                      margin on the device (`certify`, default on in this mode; `last_stats["min_margin"]`, `["certified"]`).  With
                      `exact_fallback=True` the utterances whose margin is below the stated bound are generated again on the exact kernels

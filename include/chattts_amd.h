@@ -82,9 +82,9 @@ typedef struct {
    * two launches (profiles/r4b_ab_oproj.log), so by default the pointer is ignored and o_proj stays its own launch. */
   const void* const* wo_hd;
   /* optional (NULL: the f32 MFMA kernels of csrc/decode32.hip), parity mode only, together with the *_pk copies above: the same four
-   * matrices as SPLIT-bf16 planes for the decode step (csrc/decode32x.hip) -- [2 planes: hi = bf16(w), lo = bf16(w - hi)][N/16][K/32][64][8]
-   * bf16, the bf16 fragment order above per plane; wqkv_x3 / wgu_x3 carry the RMSNorm gain of ln1 / ln2 (w' = w * gain[k], folded BEFORE
-   * the split) and the q / k row permutation of wqkv_pk.  Three bf16 MFMAs per product instead of f32 MFMA at a sixteenth of the rate; the
+   * matrices as SPLIT-fp16 planes for the decode step (csrc/decode32x.hip; round 5: bf16 planes) -- [2 planes: hi = fp16(w), lo' = fp16((w - hi) * 2^11)]
+   * [N/16][K/32][64][8], 22 significant bits, the bf16 fragment order above per plane; wqkv_x3 / wgu_x3 carry the RMSNorm gain of ln1 / ln2 (w' = w * gain[k], folded BEFORE
+   * the split) and the q / k row permutation of wqkv_pk.  Three fp16 MFMAs per product (hi*hi, and lo'*hi + hi*lo' on a second accumulator that enters with 2^-11) instead of f32 MFMA at a sixteenth of the rate; the
    * reference's token ids hold on every golden (tests/test_gpu_e2e.py).  The HOST chooses the arithmetic: no planes = exact f32 MFMA; planes =
    * split-bf16 decode steps, certified per call by ctts_gen_state.margin, with ctts_gen_state.proj_exact as the per-call exact fallback. */
   const void* const* wqkv_x3;

@@ -228,19 +228,18 @@ def test_gemm_dec32_bit_identical(G, M, n_act, force_mb):
 
 @pytest.mark.parametrize("M", [3072, 200, 37])
 def test_gemm_pre_x3_split_bf16_prefill(G, M):
-    """round 6: the LDS-tiled split-bf16 GEMM of the f32x3 mode's prompt pass (csrc/prefill32x.hip) for the four projection shapes of a
-    layer -- f32 row-major operands split by the tile loader, RMSNorm gain applied before the split, 1 / rms on the accumulator --
-    (a) against the float64 value of exactly what it is defined to compute ((hi+lo)(hi+lo) - lo*lo over the split operands) within f32
-    accumulation noise, (b) within 2e-5 of the output's scale of the float64 product of the UNSPLIT operands; 128- and 64-row tiles,
-    a partial last tile."""
+    """round 6: the LDS-tiled split-fp16 GEMM of the f32x3 mode's prompt pass (csrc/prefill32x.hip) for the four projection shapes of a
+    layer -- f32 row-major operands split by the tile loader (hi = fp16(x), lo' = fp16((x - hi) 2^11)), RMSNorm gain applied before the
+    split, 1 / rms on the accumulator -- (a) against the float64 value of exactly what it is defined to compute ((hi+lo)(hi+lo) - lo*lo
+    over the split operands) within f32 accumulation noise, (b) within 3e-6 of the output's scale of the float64 product of the UNSPLIT
+    operands (the bf16 split of round 5 needed 2e-5); 128- and 64-row tiles, a partial last tile."""
     lib = _lib.lib()
     rs = np.random.RandomState(M)
 
-    def split64(a):
-        t = torch.from_numpy(a.astype(f32))
-        hi = t.to(torch.bfloat16)
-        lo = (t - hi.float()).to(torch.bfloat16)
-        return hi.double().numpy(), lo.double().numpy()
+    def split64(a):       # the split-fp16 operand format (engine.split_f16 / common.hpp x3_split): value = hi + lo' / 2048
+        from chattts_amd.engine import X3_LO_SCALE, split_f16
+        hi, lo = split_f16(torch.from_numpy(a.astype(f32)))
+        return hi.double().numpy(), lo.double().numpy() / X3_LO_SCALE
 
     for N, K, epi, rms in [(2304, 768, 0, True), (768, 768, 1, False), (3072, 768, 2, True), (768, 3072, 1, False)]:
         A = (rs.standard_normal((M, K)) * (2.0 if rms else 1.0)).astype(f32)
@@ -273,17 +272,17 @@ def test_gemm_pre_x3_split_bf16_prefill(G, M):
         scale = np.abs(outs[1]).max()
         assert np.isfinite(got).all()
         assert np.abs(got - outs[0]).max() < 3e-6 * scale, (M, N, K, epi, np.abs(got - outs[0]).max() / scale)
-        assert np.abs(got - outs[1]).max() < 2e-5 * scale, (M, N, K, epi, np.abs(got - outs[1]).max() / scale)
+        assert np.abs(got - outs[1]).max() < 3e-6 * scale, (M, N, K, epi, np.abs(got - outs[1]).max() / scale)   # 22-bit operands: f32-class
 
 
 @pytest.mark.parametrize("force_mb", [0, 1, 2, 4, 9, 10, 12, 17])  # rows per workgroup (x 16); + 8: eight waves split K instead of four; 17: sixteen (down_proj only, else eight)
 @pytest.mark.parametrize("M,n_act", [(64, None), (64, 37), (16, None), (5, None), (33, 20), (48, 48)])
 def test_gemm_dec32x_split_bf16(G, M, n_act, force_mb):
-    """parity-mode decode projections on SPLIT-bf16 operands (csrc/decode32x.hip: hi | lo bf16 planes, three bf16 MFMAs per product,
-    f32 accumulation) for the o_proj / gate-up / down shapes of a layer: (a) against the float64 value of EXACTLY what the kernel is
-    defined to compute -- (hi+lo)(hi+lo) - lo*lo over the split operands, 1 / rms from the f32 rows, residual / SiLU epilogue --
-    within f32 accumulation noise; (b) within 2e-5 (relative to the output's scale) of the float64 product of the UNSPLIT operands:
-    the 2^-17-class operand error the mode is priced on; the output planes re-assemble to the row-major result; partial row tiles,
+    """parity-mode decode projections on SPLIT-fp16 operands (csrc/decode32x.hip: hi | lo' fp16 planes, value = hi + lo' / 2048, three
+    fp16 MFMAs per product, f32 accumulation) for the o_proj / gate-up / down shapes of a layer: (a) against the float64 value of EXACTLY
+    what the kernel is defined to compute -- (hi+lo)(hi+lo) - lo*lo over the split operands, 1 / rms from the f32 rows, residual / SiLU
+    epilogue -- within f32 accumulation noise; (b) within 5e-6 (relative to the output's scale) of the float64 product of the UNSPLIT
+    operands: 22-bit operands (the bf16 split of round 5 needed 2e-5); the output planes re-assemble to the row-major result; partial row tiles,
     a device-side live-row count, rows beyond it untouched."""
     from chattts_amd.engine import pack_frag, pack_frag_x3, unpack_frag, unpack_frag32
     lib = _lib.lib()
@@ -292,11 +291,10 @@ def test_gemm_dec32x_split_bf16(G, M, n_act, force_mb):
     live = M if n_act is None else n_act
     na_d = None if n_act is None else G.dev(np.array([n_act], np.int32))
 
-    def split(a):
-        t = torch.from_numpy(a)
-        hi = t.to(torch.bfloat16)
-        lo = (t - hi.float()).to(torch.bfloat16)
-        return hi, lo
+    from chattts_amd.engine import X3_LO_SCALE, split_f16
+
+    def split(a):         # the split-fp16 operand format: value = hi + lo' / 2048 (NaN pad rows stay NaN)
+        return split_f16(torch.from_numpy(a))
 
     for N, K, epi, rms in [(768, 768, 1, False), (3072, 768, 2, True), (768, 3072, 1, False)]:
         A = (rs.standard_normal((M, K)) * (2.0 if rms else 1.0)).astype(f32)
@@ -325,6 +323,7 @@ def test_gemm_dec32x_split_bf16(G, M, n_act, force_mb):
         # float64 models
         a_h, a_l = (x.float().numpy().astype(np.float64)[:live] for x in split(A))
         w_h, w_l = (x.float().numpy().astype(np.float64) for x in split(Wm))
+        a_l, w_l = a_l / X3_LO_SCALE, w_l / X3_LO_SCALE
         exact = (a_h + a_l) @ (w_h + w_l).T - a_l @ w_l.T          # what three MFMAs sum
         full = A[:live].astype(np.float64) @ Wm.astype(np.float64).T
         if rms:
@@ -335,20 +334,21 @@ def test_gemm_dec32x_split_bf16(G, M, n_act, force_mb):
             exact, full = sil(exact[:, :N]) * exact[:, N:], sil(full[:, :N]) * full[:, N:]
         else:
             exact, full = exact + res[:live], full + res[:live]
-        got_planes = unpack_frag(Cp[0].float().cpu(), Mp, N).numpy().astype(np.float64) + unpack_frag(Cp[1].float().cpu(), Mp, N).numpy()
+        got_planes = (unpack_frag(Cp[0].view(torch.float16).float().cpu(), Mp, N).numpy().astype(np.float64)
+                      + unpack_frag(Cp[1].view(torch.float16).float().cpu(), Mp, N).numpy() / X3_LO_SCALE)
         scale = np.abs(full).max()
         if epi == 1:
             got = Cc.cpu().numpy()
             assert np.isnan(got[live:]).all()                       # rows beyond the live count are not written
             assert np.abs(got[:live] - exact).max() < 5e-6 * scale, (N, K, np.abs(got[:live] - exact).max() / scale)
-            assert np.abs(got[:live] - full).max() < 2e-5 * scale, (N, K, np.abs(got[:live] - full).max() / scale)
+            assert np.abs(got[:live] - full).max() < 5e-6 * scale, (N, K, np.abs(got[:live] - full).max() / scale)   # 22-bit operands
             assert np.array_equal(unpack_frag32(Cp32.cpu(), Mp, N).numpy()[:live], got[:live])
-            assert np.abs(got_planes[:live] - got[:live]).max() < 2e-5 * scale      # planes hold the row to 16-17 bits
+            assert np.abs(got_planes[:live] - got[:live]).max() < 2e-6 * scale      # planes hold the row to 22 bits
             sq = ssq_out.cpu().numpy()
             want_sq = (got[:live].astype(np.float64).reshape(live, 48, 16) ** 2).sum(-1)
             assert np.abs(sq[:live] - want_sq).max() < 1e-5 * want_sq.max() and np.isnan(sq[live:]).all()
         else:
-            assert np.abs(got_planes[:live] - exact).max() < 2e-5 * scale, (N, K, np.abs(got_planes[:live] - exact).max() / scale)
+            assert np.abs(got_planes[:live] - exact).max() < 5e-6 * scale, (N, K, np.abs(got_planes[:live] - exact).max() / scale)
         assert np.isnan(got_planes[live:M]).all()
 
 
@@ -841,18 +841,17 @@ def test_attention_decode_persistent_grid(G, mode, n_live):
 
             unit = run(0, 0, 0)
             live = [m for m in range(n_live) if m != dead]
-            if not bf:     # the split-bf16 parity mode's output: the SAME f32 result, stored as hi = bf16(o), lo = bf16(o - hi) planes
+            if not bf:     # the f32x3 parity mode's output: the SAME f32 result, stored as split-fp16 planes (hi = fp16(o), lo' = fp16((o - hi) 2^11))
+                from chattts_amd.engine import split_f16
                 for persist in (0, 1):
                     _lib.check(lib.ctts_k_attention_cfg(persist, 256, 4), "attention_cfg")
                     pl = torch.full((2, Bp * H), float("nan"), dtype=torch.float32, device=G.DEV).to(torch.bfloat16)
                     _lib.check(lib.ctts_k_attention_dec2(q_d.data_ptr(), kc.data_ptr(), vc.data_ptr(), 2, cmax, pl.data_ptr(), desc_d.data_ptr(),
                                                          None if covers_all else na.data_ptr(), covers_all, Bp, None), "attention_dec2 planes")
                     torch.cuda.synchronize()
-                    hi = unpack_frag(pl[0].float().cpu(), Bp, H)
-                    lo = unpack_frag(pl[1].float().cpu(), Bp, H)
-                    o32 = torch.from_numpy(unit)
-                    want_hi = o32.to(torch.bfloat16).float()
-                    want_lo = (o32 - want_hi).to(torch.bfloat16).float()
+                    hi = unpack_frag(pl[0].view(torch.float16).cpu(), Bp, H)
+                    lo = unpack_frag(pl[1].view(torch.float16).cpu(), Bp, H)
+                    want_hi, want_lo = split_f16(torch.from_numpy(unit))
                     assert torch.equal(hi[live], want_hi[live]) and torch.equal(lo[live], want_lo[live]), persist
             ref = np.zeros((Bp, H))
             for m in live:
@@ -881,10 +880,9 @@ def test_attention_decode_persistent_grid(G, mode, n_live):
                     _lib.check(lib.ctts_k_attention_dec2(q_d.data_ptr(), kc.data_ptr(), vc.data_ptr(), 2, cmax, pl.data_ptr(), desc_d.data_ptr(),
                                                          None if covers_all else na.data_ptr(), covers_all, Bp, None), "attention_dec2 planes")
                     torch.cuda.synchronize()
-                    o32 = torch.from_numpy(unit)
-                    want_hi = o32.to(torch.bfloat16).float()
-                    assert torch.equal(unpack_frag(pl[0].float().cpu(), Bp, H)[live], want_hi[live])
-                    assert torch.equal(unpack_frag(pl[1].float().cpu(), Bp, H)[live], (o32 - want_hi).to(torch.bfloat16).float()[live])
+                    want_hi, want_lo = split_f16(torch.from_numpy(unit))
+                    assert torch.equal(unpack_frag(pl[0].view(torch.float16).cpu(), Bp, H)[live], want_hi[live])
+                    assert torch.equal(unpack_frag(pl[1].view(torch.float16).cpu(), Bp, H)[live], want_lo[live])
             _lib.check(lib.ctts_k_attention_heads_per_wg(1), "heads_per_wg")
     finally:
         ncu = torch.cuda.get_device_properties(0).multi_processor_count
