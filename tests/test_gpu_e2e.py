@@ -225,6 +225,30 @@ def test_two_shards_decoded_as_part_of_the_global_batch_equal_the_unsharded_call
     assert np.abs(got - full).max() < 1e-6
 
 
+def test_bf16_free_running_stream_regression_guard(gpt_bf16):
+    """the perf mode has no bit-exact bar, so a real regression could hide inside its teacher-forced bounds.  This pins the
+    bf16 engine's OWN free-running ids of case `b8` (tests/golden/bf16_guard.npz, tools/make_bf16_guard.py): on the tree that wrote the
+    file every row is identical; a deliberate change of the bf16 arithmetic moves rows apart after tens of steps (then the file is
+    regenerated); a bug moves them apart at once -- at least 6 of the 8 rows must agree on their first 8 steps, graph replay == eager."""
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bf16_guard.npz")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/bf16_guard.npz not generated (python tools/make_bf16_guard.py on the GPU box)")
+    g = np.load(path)
+    off = np.concatenate([[0], np.cumsum(g["lens"])])
+    want = [g["ids"][off[b]: off[b + 1]] for b in range(len(g["lens"]))]
+    c = cases.GEN_CASES["b8"]
+    got = [t.cpu().numpy() for t in run_case(gpt_bf16, c, use_graph=True)[0][-1].ids]
+    eager = [t.cpu().numpy() for t in run_case(gpt_bf16, c, use_graph=False)[0][-1].ids]
+    assert all(np.array_equal(a, b) for a, b in zip(got, eager))
+    first = []
+    for a, b in zip(got, want):
+        n = min(len(a), len(b))
+        neq = np.nonzero((a[:n] != b[:n]).any(1))[0]
+        first.append(int(neq[0]) if len(neq) else n)
+    assert sum(f >= 8 for f in first) >= 6, first
+
+
 def _cert_engines(weights, embed=None):
     emb_sd = weights["embed"] if embed is None else embed
     exact = E.GptEngine(weights["gpt"], emb_sd, DEV, dtype="f32")
