@@ -94,7 +94,7 @@ class Chat:
         `"custom"` (assets already on disk; there is no network path here, `"huggingface"` returns False): the four
         hot-path safetensors files under `custom_path` (default: the working directory, like the reference's "local"
         source) and `asset/tokenizer`.  Keyword-only extras of this engine: `dtype` ("bf16" perf mode | "f32" parity mode on float32 arithmetic
-        throughout | "f32x3" parity mode with split-bf16 decode projections, certified per call with an exact fallback -- GptEngine),
+        throughout | "f32x3" parity mode with split-fp16 Llama projections (float32-class, faster), every call reports its decision margins -- GptEngine),
         `state_dicts` short-circuits disk I/O (synthetic weights); `tokenizer` is a directory or a `Tokenizer`;
         `spk_stat` is the reference's `Config.spk_stat` string (needed by `sample_random_speaker` only); `codec_gemm` picks the
         acoustic decoder's dense-layer arithmetic (`CodecEngine`: "f16" | "bf16x3" | "f32"; default: "f16" in perf mode --

@@ -243,7 +243,7 @@ class GptEngine:
 
     NQ_RING = 64   # unseeded sampling: ring of per-step Exp(1) draws uploaded ahead of the GPU
     POLL = 16      # decode steps enqueued between two looks at the device-side finish flags
-    # Stated bound on what the split-bf16 decode projections ("f32x3") move a PRE-temperature logit by, against the exact f32 kernels
+    # Stated bound on what the split-fp16 projections ("f32x3") move a PRE-temperature logit by, against the exact f32 kernels
     # under the same token history, RELATIVE to the head's logit scale (rms over the vocabulary of |W_v| * rms(final norm gain): the
     # standard deviation a logit has for a unit-rms hidden state; 4.02 for the synthetic checkpoint).  Measured with tools/x3_logit_bound.py
     # on the bench workload (all 64 rows, every step, teacher-forced on the reference's stream; profiles/r6o_x3_logit_bound_fp16split.log):
@@ -273,7 +273,7 @@ class GptEngine:
         `rms_eps` / `rope_theta` / `max_pos`: the run-time fields of `asset/gpt/config.json` (weights.check_gpt_config;
         `LlamaModel.from_pretrained`, gpt.py:75); everything else in that file is the geometry the kernels are compiled for."""
         if dtype not in ("bf16", "f32", "f32x3"):
-            raise ValueError("dtype must be 'bf16' (perf), 'f32' (parity, exact float32) or 'f32x3' (parity, split-bf16 decode projections)")
+            raise ValueError("dtype must be 'bf16' (perf), 'f32' (parity, exact float32) or 'f32x3' (parity, split-fp16 projections)")
         self.lib = _lib.lib()
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -336,7 +336,7 @@ class GptEngine:
                 # output column's dot product does not depend on where the column sits, so the parity arithmetic is untouched
                 self.packed[0] = [pack_frag32(t[qk_perm]) for t in self.wqkv]
             self._pk_arrs = [_lib.ptr_array(x) for x in self.packed]
-        # dtype "f32x3": decode step on split-bf16 operands (csrc/decode32x.hip): the four matrices once more as hi | lo bf16 planes (the
+        # dtype "f32x3": decode step on split-fp16 operands (csrc/decode32x.hip): the four matrices once more as hi | lo' fp16 planes (the
         # float32 bytes again), the RMSNorm gains folded in before the split; the prompt pass splits the row-major f32 matrices in its
         # tile loader (csrc/prefill32x.hip)
         self.x3, self._x3_arrs = None, None
@@ -961,7 +961,7 @@ class GptEngine:
         final = outputs()
         if certify:
             # ---- parity certificate: the smallest decision margin of every utterance (tempered-logit units) against twice the stated
-            # logit error of the split-bf16 projections.  The lanes are idle here (wait_stream above).
+            # logit error of the split-fp16 projections.  The lanes are idle here (wait_stream above).
             marg = torch.cat([ln.margin for ln in L]).cpu().numpy()
             x3_run = self.x3 is not None and not exact
             bound = 2.0 * self.REL_ERR_X3 * self.logit_scale[bool(infer_text)] / max(float(temperature.min()), 1e-6) if x3_run else 0.0
@@ -974,7 +974,7 @@ class GptEngine:
                                     "parity certificate: %d of %d utterances had a draw decided by less than %.2e tempered-logit units "
                                     "(smallest margin %.2e)%s", len(unsafe), B, bound, float(marg.min()),
                                     "; generating them again on the exact f32 kernels" if (self.exact_fallback and not stream and not interrupted)
-                                    else "; the split-bf16 result stands uncertified")
+                                    else "; the split-fp16 result stands as it is")
                 if self.exact_fallback and not stream and not interrupted:
                     final = self._rerun_exact(final, unsafe, emb, inputs_ids, temperature, eos_token, attention_mask, max_new_token, min_new_token,
                                               logits_processors, infer_text, return_hidden, stream_batch, manual_seed, context, use_graph, stop_at,
@@ -1013,7 +1013,7 @@ class GptEngine:
         rerun_stats = self.last_stats
         self.last_stats = stats
         if sub is None:     # (an EOS at step 0 of the exact run: the seeded reference yields nothing, gpt.py:570)
-            self.logger.warning("parity certificate: the exact re-run ended at step 0; the split-bf16 rows stand")
+            self.logger.warning("parity certificate: the exact re-run ended at step 0; the split-fp16 rows stand")
             return final
         same_len = all(int(sub.ids[j].shape[0]) == int(final.ids[b].shape[0]) for j, b in enumerate(rows))
         padded = getattr(final.hiddens, "padded", None)

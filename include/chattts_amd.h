@@ -86,7 +86,7 @@ typedef struct {
    * [N/16][K/32][64][8], 22 significant bits, the bf16 fragment order above per plane; wqkv_x3 / wgu_x3 carry the RMSNorm gain of ln1 / ln2 (w' = w * gain[k], folded BEFORE
    * the split) and the q / k row permutation of wqkv_pk.  Three fp16 MFMAs per product (hi*hi, and lo'*hi + hi*lo' on a second accumulator that enters with 2^-11) instead of f32 MFMA at a sixteenth of the rate; the
    * reference's token ids hold on every golden (tests/test_gpu_e2e.py).  The HOST chooses the arithmetic: no planes = exact f32 MFMA; planes =
-   * split-bf16 decode steps, certified per call by ctts_gen_state.margin, with ctts_gen_state.proj_exact as the per-call exact fallback. */
+   * split-fp16 decode steps, certified per call by ctts_gen_state.margin, with ctts_gen_state.proj_exact as the per-call exact fallback. */
   const void* const* wqkv_x3;
   const void* const* wo_x3;
   const void* const* wgu_x3;
@@ -167,7 +167,7 @@ typedef struct {
    * utterance b was decided: (1) log(r_best / r_second) of the multinomial's argmax(p / q) (gpt.py:497-508); (2) the value gap between the
    * last kept and the first dropped token at the cut the warpers make (processors.py:38-58, TopK / TopP prefix); (3) |log(cum / (1 - top_P))|
    * of the top-p test at the last kept and at the first top-p-dropped rank.  A perturbation of every tempered logit by less than
-   * margin / 2 cannot change any sampled token of that utterance: the split-bf16 parity arithmetic (wqkv_x3 ...) is certified per call
+   * margin / 2 cannot change any sampled token of that utterance: the split-fp16 parity arithmetic (wqkv_x3 ...) is certified per call
    * against its measured logit error bound instead of by sample (chattts_amd/engine.py GptEngine.certify).  NULL: nothing is computed. */
   float* margin;
   /* [B] or NULL: global index of sampling row 0 of utterance b (b_global * 4 in code mode) -- replaces row_offset + 4 b when a shard holds a
@@ -176,7 +176,7 @@ typedef struct {
    * generator's counter; `q` stays indexed by the local slot (the host uploads the selected rows of the CPU draw). */
   const int32_t* row_base;
   /* parity mode with BOTH decode copies loaded (wqkv_pk ... and wqkv_x3 ...): 1 = this call's decode steps run the f32 MFMA kernels
-   * (csrc/decode32.hip) although the split-bf16 planes are there -- the exact fallback of a certificate that fired.  A captured graph
+   * (csrc/decode32.hip) although the split-fp16 planes are there -- the exact fallback of a certificate that fired.  A captured graph
    * holds the choice it was built with. */
   int32_t proj_exact;
   /* "f32x3" mode, ctts_gpt_prefill only: the number of VALID prompt tokens of the batch (sum of the attention mask = sum of T - kv_start[b]),
