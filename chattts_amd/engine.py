@@ -1008,8 +1008,12 @@ class GptEngine:
                                      lanes=1, prefill_chunk=prefill_chunk, rng=rng, rng_seed=rng_seed, rng_nonce=nz, row_ids=gid, exact=True):
                 pass
         finally:
+            # where the global generator is left: the reference draws once per step of its loop, which ends when the LAST utterance
+            # finishes -- the run (main or re-run) that executed more steps decides; a re-run of every utterance IS the call
             if state_after is not None:
-                torch.set_rng_state(state_after)
+                keep_rerun = sub is not None and (len(rows) == len(final.ids) or self.last_stats.get("steps", 0) > stats.get("steps", 0))
+                if not keep_rerun:
+                    torch.set_rng_state(state_after)
         rerun_stats = self.last_stats
         self.last_stats = stats
         if sub is None:     # (an EOS at step 0 of the exact run: the seeded reference yields nothing, gpt.py:570)

@@ -300,6 +300,25 @@ def test_parity_certificate_and_exact_fallback(weights, monkeypatch):
     assert all(torch.equal(a, b_) for a, b_ in zip(out_h.ids, out_h2.ids))
 
 
+def test_exact_fallback_replays_the_unseeded_draws(weights, golden, monkeypatch):
+    """the reference's DEFAULT is manual_seed=None: every step draws from torch's global CPU generator (gpt.py:498-500).  The exact
+    fallback then has to re-run flagged utterances with the SAME per-step draws the main call consumed and leave the generator where the
+    reference would: with every utterance flagged, the f32x3 engine returns the reference's golden ids of case `unseeded` (== the "f32"
+    engine's) and the global generator ends in the state the "f32" engine's own call leaves."""
+    c = cases.GEN_CASES["unseeded"]
+    Gd = golden["generate"]
+    exact = E.GptEngine(weights["gpt"], weights["embed"], DEV, dtype="f32")
+    out_e = run_case(exact, c, use_graph=True)[0][-1]
+    state_e = torch.get_rng_state()
+    fb = E.GptEngine(weights["gpt"], weights["embed"], DEV, dtype="f32x3", exact_fallback=True)
+    monkeypatch.setattr(E.GptEngine, "REL_ERR_X3", 1e3)              # everything is flagged
+    out_f = run_case(fb, c, use_graph=True)[0][-1]
+    assert fb.last_stats["exact_rerun_rows"] == list(range(c["B"]))
+    assert torch.equal(torch.get_rng_state(), state_e)
+    got = np.concatenate([t.cpu().numpy() for t in out_f.ids], 0)
+    assert np.array_equal(got, Gd["unseeded.ids"]) and all(torch.equal(a, b) for a, b in zip(out_f.ids, out_e.ids))
+
+
 @pytest.mark.parametrize("gain", [1.0 / 16.0, 1.0, 8.0])
 def test_split_bf16_ids_diverge_only_where_the_certificate_fired(weights, gain):
     """the certificate is sound on a head-gain sweep (flatter and peakier logits than the synthetic checkpoint's): wherever
