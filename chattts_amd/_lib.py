@@ -143,6 +143,7 @@ SIGNATURES = {
     "ctts_k_embed_codes": (C.c_int, [P, P, I32, P, P, I32, P]),
     "ctts_k_final_norm": (C.c_int, [P, I32, P, F, P, P, I32, P, I32, I32, P]),
     "ctts_k_sample": (C.c_int, [C.POINTER(GenState), P, P]),
+    "ctts_k_sample_text": (C.c_int, [C.POINTER(GenState), P, I32, P]),
     "ctts_k_exp_draws": (C.c_int, [C.c_uint64, I32, I32, I32, I32, P, P]),
     "ctts_k_dwconv_ln": (C.c_int, [P, P, P, P, P, F, I32, P, I32, I32, P]),
     "ctts_k_layernorm": (C.c_int, [P, P, P, F, P, I32, P]),

@@ -1119,6 +1119,11 @@ extern "C" int ctts_k_sample(const ctts_gen_state* s, const float* logits, void*
   CK(launch_sample(make_sample_args(s, logits), (hipStream_t)stream));
   return 0;
 }
+extern "C" int ctts_k_sample_text(const ctts_gen_state* s, const float* logits, int32_t n_text, void* stream) {
+  if (!s || !logits || n_text <= 0 || n_text > NTEXT_MAX) return fail("ctts_k_sample_text: bad arguments");
+  CK(launch_sample_text(make_sample_args(s, logits), n_text, (hipStream_t)stream));
+  return 0;
+}
 // what CttsDeviceGuard (kernels.hpp) does for `stream` on the calling thread: the device current before, the device that owns the stream,
 // the device current INSIDE the guard, and whether it had to switch (tests: the guard's path runs on a 1-GPU box too)
 extern "C" int ctts_k_device_guard_probe(void* stream, int32_t* before, int32_t* stream_dev, int32_t* inside, int32_t* switched) {

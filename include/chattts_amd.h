@@ -461,6 +461,9 @@ int ctts_k_embed_codes(const float* emb_code, const int64_t* ids_buf, int32_t tc
 int ctts_k_final_norm(const float* x, int32_t q_per_b, const float* w, float eps, float* hfin, float* hiddens, int32_t max_new,
                       const int32_t* len, int32_t T, int32_t B, void* stream);
 int ctts_k_sample(const ctts_gen_state* s, const float* logits, void* stream);
+/* the refine-text sampler alone (sample_text_k, gpt.py:439-440,477-525): logits [B, n_text], q [nq, B, n_text], temperature[0], ONE
+ * sampling row per utterance, the token replicated over the 4 slots; no repetition penalty */
+int ctts_k_sample_text(const ctts_gen_state* s, const float* logits, int32_t n_text, void* stream);
 /* the device generator's Exp(1) draws (ctts_gen_state.rng_device) of sampling rows row0 .. row0+rows-1 at generation step `step`
  * as a [rows, V] float32 tensor -- distribution tests */
 int ctts_k_exp_draws(uint64_t seed, int32_t step, int32_t row0, int32_t rows, int32_t V, float* out, void* stream);

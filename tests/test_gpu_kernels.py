@@ -1148,6 +1148,59 @@ def test_sample_certificate_is_a_certificate(G, trial):
         assert same[ok].all(), (trial, np.nonzero(~same & ok)[0], mg)
 
 
+@pytest.mark.parametrize("trial", range(12))
+def test_sample_text_kernel_vs_oracle_and_certificate(G, trial):
+    """round 6: the rebuilt refine-text sampler alone (sample_text_k: 1024 threads, row in registers, column-maxima threshold, counting
+    rank; serial extraction when there is no top-k, top-k > 64 or too many candidates) on random 21178-wide rows: the token == the numpy
+    oracle of the reference chain (gpt.py:487-508 with one sampling row per utterance), the certificate == its float64 restatement, EOS
+    masking, a row with many exact ties at the top."""
+    lib = _lib.lib()
+    rs = np.random.RandomState(9000 + trial)
+    V = 21178
+    B = int(rs.choice([1, 3, 6]))
+    scale = float(rs.choice([0.5, 2.0, 4.0]))
+    logits = (rs.standard_normal((B, V)) * scale).astype(f32)
+    if trial % 4 == 3:
+        logits = (np.round(logits * 4) / 4).astype(f32)          # exact ties everywhere, also at the k-th value
+    temp = float(rs.choice([0.3, 0.7, 1.0]))
+    top_p = [None, 0.5, 0.7, 0.95][int(rs.randint(4))]
+    top_k = [20, 20, 3, 64, 100, None][int(rs.randint(6))]
+    if trial % 4 == 3:
+        top_p = None       # (tie order inside the top-p cut is unspecified in the reference: ties are tested with top-k only)
+    if top_p is None and top_k is None:
+        top_k = 20
+    mask_eos = bool(rs.randint(2))
+    eos = int(np.argmax(logits[0])) if mask_eos else 21000      # mask the likeliest token of row 0
+    q = rng.ExpDraws(B, V, int(rs.randint(1 << 30))).step(0).numpy()
+    T, tcap = 1, 4
+    keep = []
+    d = lambda a: (keep.append(G.dev(a)), keep[-1])[1]
+    s = _lib.GenState()
+    s.B, s.T, s.max_new = B, T, 3
+    ids_d = d(np.zeros((B, tcap, 4), np.int64))
+    len_d, fin_d, end_d = d(np.full(B, T, np.int32)), d(np.zeros(B, np.uint8)), d(np.zeros(B, np.int32))
+    mg_d = d(np.full(B, np.inf, f32))
+    s.ids_buf, s.len, s.finish, s.end_idx = ids_d.data_ptr(), len_d.data_ptr(), fin_d.data_ptr(), end_d.data_ptr()
+    s.q, s.nq = d(q.reshape(1, B, V)).data_ptr(), 1
+    s.temperature = d(np.array([temp], f32)).data_ptr()
+    s.top_p_thr = float(np.float32(1.0 - top_p)) if top_p is not None else 0.0
+    s.use_top_p, s.top_k, s.use_top_k = int(top_p is not None), int(top_k or 0), int(top_k is not None)
+    s.min_new, s.eos, s.infer_text = (1 if mask_eos else 0), eos, 1
+    s.margin = mg_d.data_ptr()
+    _lib.check(lib.ctts_k_sample_text(C.byref(s), d(logits).data_ptr(), V, None), "sample_text")
+    torch.cuda.synchronize()
+    got = ids_d.cpu().numpy()[:, T, :]
+    assert (got == got[:, :1]).all()                             # gpt.py:522-525: replicated over the 4 slots
+    kw = dict(temperature=np.full(B, temp, f32), top_p=top_p, top_k=top_k, pow_table=None, max_input_ids=V - 1, mask_eos=mask_eos, eos=eos)
+    want = sampling_np.sample_step(logits, np.zeros((B, 0), np.int64), q, **kw)
+    assert np.array_equal(got[:, 0], want), (trial, top_p, top_k, temp, got[:, 0], want)
+    assert np.array_equal(fin_d.cpu().numpy(), (want == eos).astype(np.uint8)) and (len_d.cpu().numpy() == T + 1).all()
+    mg = mg_d.cpu().numpy()
+    wm = sampling_np.decision_margin(logits, np.zeros((B, 0), np.int64), q, **kw)
+    fin = np.isfinite(wm)
+    assert np.array_equal(np.isfinite(mg), fin) and np.allclose(mg[fin], wm[fin], rtol=2e-3, atol=2e-5), (trial, top_p, top_k, mg, wm)
+
+
 def test_sample_row_base_replaces_row_offset(G):
     """ctts_gen_state.row_base: per-utterance global sampling row (non-contiguous shards) -- the rows >= 625 penalty quirk follows it"""
     c = cases.SAMPLING_CASES["rows640"]
