@@ -12,6 +12,8 @@
 // 128 x 128 x 32 tiles (64-row tiles when the launch would not fill the chip), 256 threads = 2 x 2 waves, register-staged global loads
 // one tile ahead, two LDS buffers of four planes (A hi | A lo | W hi | W lo), one barrier per k-step.  Reference ops: HF Llama
 // q/k/v/o_proj, gate/up/down_proj (examples/onnx/modeling_llama.py:259-295,455-505).
+#include <stdlib.h>
+
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -185,7 +187,11 @@ hipError_t launch_gemm_pre_x3(const GemmArgs& a, const float* rstd, hipStream_t 
   if (a.epi == EPI_RES && !a.res) return hipErrorInvalidValue;
   const dim3 block(XNT);
   const int nx = a.epi == EPI_SILU_MUL ? a.N / 64 : a.N / 128;
-  const bool small = (long)nx * ((a.M + 127) / 128) < 256;     // 64-row tiles when 128-row tiles would leave CUs without a workgroup
+  static int force_small = -1;
+  if (force_small < 0) { const char* e = getenv("CTTS_PREX3_SMALL"); force_small = e ? atoi(e) : 0; }   // A/B: 64-row tiles everywhere (61 KB of LDS: 2 workgroups per CU)
+  // 64-row tiles (61 KB of LDS: two workgroups per CU) unless 128-row tiles fill the chip four times over: at the 2048 valid prompt rows of
+  // the bench workload QKV 82.8 -> 66.2 us, gate/up 136 -> 127 us (profiles/r6v_ab_prefill_x3_tiles.log); CTTS_PREX3_SMALL=1 / 2: always / never
+  const bool small = force_small == 1 || (force_small != 2 && (long)nx * ((a.M + 127) / 128) < 1024);
   const dim3 grid(nx, small ? (a.M + 63) / 64 : (a.M + 127) / 128);
   switch (a.epi) {
     case EPI_SILU_MUL:
