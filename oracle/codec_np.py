@@ -113,9 +113,11 @@ def vocos_backbone(sd: dict, mel: np.ndarray) -> np.ndarray:
     return layer_norm(x, g("backbone.final_layer_norm.weight"), g("backbone.final_layer_norm.bias"), 1e-6)
 
 
-def istft_center(spec: np.ndarray, window: np.ndarray, n_fft: int, hop: int) -> np.ndarray:
+def istft_center(spec: np.ndarray, window: np.ndarray, n_fft: int, hop: int, trim: int = None) -> np.ndarray:
     """torch.istft(spec, n_fft, hop, n_fft, window, center=True): per-frame irfft (1/n norm),
-    x window, overlap-add, / window-envelope, trim n_fft/2 each side.  spec [B, F, n_fft/2+1] complex."""
+    x window, overlap-add, / window-envelope, trim n_fft/2 each side.  spec [B, F, n_fft/2+1] complex.
+    `trim` = (n_fft - hop) / 2 gives Vocos' own "same"-padding ISTFT (vocos/spectral_ops.py; ChatTTS configures "center",
+    config.py:83-121) -- used by the test that pins this head against transformers' port of it (Xcodec2ISTFTHead)."""
     B, F, _ = spec.shape
     frames = np.fft.irfft(spec.astype(np.complex128), n=n_fft, axis=-1) * window.astype(np.float64)
     total = n_fft + hop * (F - 1)
@@ -125,11 +127,12 @@ def istft_center(spec: np.ndarray, window: np.ndarray, n_fft: int, hop: int) -> 
     for f in range(F):
         y[:, f * hop: f * hop + n_fft] += frames[:, f]
         env[f * hop: f * hop + n_fft] += w2
-    s, e = n_fft // 2, total - n_fft // 2
+    t = n_fft // 2 if trim is None else int(trim)
+    s, e = t, total - t
     return (y[:, s:e] / env[s:e]).astype(f32)
 
 
-def vocos_head(sd: dict, x: np.ndarray, n_fft: int = 1024, hop: int = 256) -> np.ndarray:
+def vocos_head(sd: dict, x: np.ndarray, n_fft: int = 1024, hop: int = 256, trim: int = None) -> np.ndarray:
     """vocos.heads.ISTFTHead.forward (exporter.py:395-404): Linear(512->1026), chunk(mag, phase),
     mag = clip(exp(mag), max=1e2), S = mag (cos p + i sin p), ISTFT."""
     g = lambda k: np.asarray(sd[k], dtype=f32)
@@ -138,7 +141,7 @@ def vocos_head(sd: dict, x: np.ndarray, n_fft: int = 1024, hop: int = 256) -> np
     mag = np.minimum(np.exp(y[..., :nb]), f32(1e2))
     ph = y[..., nb:]
     spec = mag * (np.cos(ph) + 1j * np.sin(ph))
-    return istft_center(spec, g("head.istft.window"), n_fft, hop)
+    return istft_center(spec, g("head.istft.window"), n_fft, hop, trim)
 
 
 def vocos_decode(sd: dict, mel: np.ndarray) -> np.ndarray:

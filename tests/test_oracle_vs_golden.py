@@ -451,3 +451,85 @@ def test_mel_restatement_vs_torchaudio():
     if got.shape != want.shape:
         got = got.transpose(0, 2, 1)
     assert np.abs(got - want).max() < 1e-3
+
+
+# ---- third-party pins that ARE available offline: transformers ships line-cited ports of two of the restated pieces -----------------
+def _xcodec2():
+    try:
+        from transformers.models.xcodec2 import modeling_xcodec2 as X
+        from transformers.models.xcodec2.configuration_xcodec2 import Xcodec2Config
+    except ImportError:
+        pytest.skip("this transformers build has no xcodec2 model")
+    return X, Xcodec2Config
+
+
+@pytest.mark.parametrize("levels", [(5, 5, 5, 5), (4, 4, 4, 4), (8, 5, 5, 5)])
+def test_fsq_core_vs_transformers_port_of_vector_quantize_pytorch(levels):
+    """`vector_quantize_pytorch` is not installed, but transformers' `Xcodec2FiniteScalarQuantization` is a port of its FSQ class
+    (it cites finite_scalar_quantization.py#L64): bound -> round -> codes / indices and index -> codes of oracle/dvae_np.py equal it on
+    random inputs, for ChatTTS' levels (5,5,5,5) (config.py:24-28) and for even levels (the offset / shift branch).  Still restated:
+    the GroupedResidual wrapper (group split, residual scales), pinned only by its own round trip."""
+    from oracle import dvae_np
+    X, Cfg = _xcodec2()
+    q = X.Xcodec2FiniteScalarQuantization(Cfg(quantization_levels=list(levels)))
+    rs = np.random.RandomState(sum(levels))
+    z = (rs.standard_normal((3, 50, len(levels))) * 1.5).astype(np.float32)
+    lv = np.asarray(levels, dtype=np.int64)
+    with torch.inference_mode():
+        codes_t, idx_t = q(torch.from_numpy(z))
+        bound_t = q.bound(torch.from_numpy(z))
+        back_t = q._indices_to_codes(idx_t.long())
+    assert np.abs(dvae_np.fsq_bound(z, lv) - bound_t.numpy()).max() < 1e-6
+    codes, idx = dvae_np.fsq_quantize(z, lv)
+    assert np.array_equal(idx, idx_t.numpy()) and np.abs(codes - codes_t.numpy()).max() < 1e-6
+    assert np.abs(dvae_np.fsq_codes_from_index(idx, lv) - back_t.numpy()).max() < 1e-6
+    # the library seeds its residual loop with bound(project_in(x)) ("for consistency with original checkpoint" in the port's
+    # Xcodec2Quantizer.forward): bounding twice is what `bound_first=True` restates
+    assert "self.quantizer.bound(hidden_states)" in __import__("inspect").getsource(X.Xcodec2Quantizer.forward)
+
+
+def test_vocos_istft_head_vs_transformers_port():
+    """the `vocos` package is not installed, but transformers' `Xcodec2ISTFTHead` is a port of `vocos.heads.ISTFTHead` (Linear ->
+    chunk -> exp -> clamp(max=1e2) -> polar -> ISTFT; it cites vocos/spectral_ops.py).  It uses Vocos' "same" padding where ChatTTS
+    configures "center" (= torch.istft, config.py:83-121), so the oracle head is compared in its same-padding form (the only difference is
+    where the overlap-added signal is trimmed); the center form is torch.istft itself (oracle/torch_port.py).  Still restated: VocosBackbone."""
+    from chattts_amd import weights as W
+    from oracle import codec_np
+    X, Cfg = _xcodec2()
+    from types import SimpleNamespace
+    head = X.Xcodec2ISTFTHead(SimpleNamespace(hidden_size=512, n_fft=1024, hop_length=256))   # (the three fields the class reads)
+    sd = {k: v.float() for k, v in W.synthetic_vocos().items()}
+    head.linear.weight.data.copy_(sd["head.out.weight"])
+    head.linear.bias.data.copy_(sd["head.out.bias"])
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn((2, 37, 512), generator=g) * 0.5
+    with torch.inference_mode():
+        want = head(x)[:, 0].numpy()
+    assert torch.equal(head.window, sd["head.istft.window"])                      # the same periodic hann window
+    got = codec_np.vocos_head({k: v.numpy() for k, v in sd.items()}, x.numpy(), trim=(1024 - 256) // 2)
+    assert got.shape == want.shape and np.sqrt(np.mean((got - want) ** 2)) < 1e-6 * max(1.0, float(np.abs(want).max()))
+    center = codec_np.vocos_head({k: v.numpy() for k, v in sd.items()}, x.numpy())
+    ref = torch.istft(torch.polar(torch.exp((x @ sd["head.out.weight"].T + sd["head.out.bias"])[..., :513]).clamp(max=1e2),
+                                  (x @ sd["head.out.weight"].T + sd["head.out.bias"])[..., 513:]).transpose(1, 2), 1024, 256, 1024,
+                      sd["head.istft.window"], center=True).numpy()
+    assert np.sqrt(np.mean((center - ref) ** 2)) < 1e-6 * max(1.0, float(np.abs(ref).max()))
+
+
+def test_mel_front_end_vs_transformers_audio_utils():
+    """`torchaudio` is not installed; `transformers.audio_utils` is an independent implementation of the same front end (its
+    mel_filter_bank / spectrogram are written to match torchaudio's and librosa's).  The restated `MelSpectrogram(24000, n_fft 1024, hop 256,
+    n_mels 100, center, power 1)` + `log(clip(., 1e-5))` of dvae.py:175-206 -- periodic hann, reflect padding, one-sided |rfft|, HTK mel
+    filterbank without normalisation -- equals it: filterbank to 1e-7, log-mel features to 1e-6."""
+    from transformers import audio_utils as A
+    from oracle import dvae_np
+    fb = A.mel_filter_bank(513, 100, 0.0, 12000.0, 24000, norm=None, mel_scale="htk")
+    assert np.abs(fb - np.asarray(dvae_np.melscale_fbanks())).max() < 1e-7
+    win = A.window_function(1024, "hann", periodic=True)
+    assert np.abs(win - dvae_np.hann_periodic(1024)).max() < 1e-7
+    rs = np.random.RandomState(0)
+    wav = (rs.standard_normal(9000) * 0.1).astype(np.float32)
+    want = A.spectrogram(wav, win, frame_length=1024, hop_length=256, fft_length=1024, power=1.0, center=True, pad_mode="reflect", mel_filters=fb,
+                         mel_floor=1e-5, log_mel="log")
+    got = np.asarray(dvae_np.mel_features(wav, dvae_np.hann_periodic(1024), dvae_np.melscale_fbanks()))
+    got = got if got.shape == want.shape else got.T
+    assert got.shape == want.shape and np.abs(got - want).max() < 2e-6
