@@ -115,6 +115,25 @@ def gfsq_encode(sd: dict, x: np.ndarray, levels=(5, 5, 5, 5), G: int = 2, R: int
     return np.stack(out, -1)
 
 
+def gfsq_round_margin(sd: dict, x: np.ndarray, levels=(5, 5, 5, 5), G: int = 2, R: int = 2, bound_first: bool = True) -> np.ndarray:
+    """x [..., 1024] -> [..., G*R]: for every emitted index, the distance of the NEAREST of its pre-rounding FSQ coordinates from a
+    rounding boundary (half-integer).  An index can differ between two float32 evaluations of the trunk only where this is within their
+    rounding noise -- what tests/test_gpu_dvae.py demands of every code that differs from the golden."""
+    lv = np.asarray(levels, dtype=np.int64)
+    D = x.shape[-1] // G
+    out = []
+    for g in range(G):
+        z = (x[..., g * D: (g + 1) * D].astype(f32) @ _q(sd, g, "project_in.weight").T + _q(sd, g, "project_in.bias")).astype(f32)
+        residual = fsq_bound(z, lv) if bound_first else z
+        for r in range(R):
+            scale = ((lv - 1).astype(f32) ** f32(-r)).astype(f32)
+            pre = fsq_bound((residual / scale).astype(f32), lv).astype(np.float64)
+            out.append(np.abs(np.abs(pre - np.floor(pre)) - 0.5).min(-1))
+            codes, _ = fsq_quantize((residual / scale).astype(f32), lv)
+            residual = (residual - codes * scale).astype(f32)
+    return np.stack(out, -1)
+
+
 def gfsq_embed(sd: dict, idx: np.ndarray, levels=(5, 5, 5, 5), G: int = 2, R: int = 2) -> np.ndarray:
     """indices [..., G*R] -> features [..., 1024] (`get_output_from_indices`)."""
     lv = np.asarray(levels, dtype=np.int64)

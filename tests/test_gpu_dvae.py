@@ -45,11 +45,20 @@ def test_encode_codes_match_golden(eng, gold, dvae_sd, name):
     got = codes.numpy().T
     assert got.min() >= 0 and got.max() < 625
     same = (got == want)
-    # a code flips only where a pre-rounding FSQ coordinate sits within float noise of a .5 boundary; on these clips none does
+    # round 6: no blanket tolerance.  A code may differ from the golden ONLY where one of its pre-rounding FSQ
+    # coordinates sits within float32 noise (1e-3) of a rounding boundary -- checked per differing code on the oracle's own features
+    # (dvae_np.gfsq_round_margin; the FSQ core itself is pinned against transformers' port, tests/test_oracle_vs_golden.py) -- and a
+    # residual level r > 0 may also differ downstream of a flipped level r - 1 of the same group.
     if not same.all():
         nsd = {k: v.numpy() for k, v in dvae_sd.items()}
-        near = np.abs(dvae_np.gfsq_embed(nsd, got) - dvae_np.gfsq_embed(nsd, want)).max()
-        print(f"{name}: {int((~same).sum())} of {same.size} codes differ (max feature distance {near:.3f})")
+        g = lambda k: np.asarray(nsd[k], dtype=np.float32)
+        mel = dvae_np.mel_features(wav, g("preprocessor_mel.mel_spec.spectrogram.window"), g("preprocessor_mel.mel_spec.mel_scale.fb"))
+        marg = dvae_np.gfsq_round_margin(nsd, dvae_np.encoder_features(nsd, mel))          # [T, 4]: (g0 r0, g0 r1, g1 r0, g1 r1)
+        for t, c in zip(*np.nonzero(~same)):
+            near = marg[t, c] < 1e-3
+            downstream = (c % 2 == 1) and not same[t, c - 1]
+            assert near or downstream, (name, int(t), int(c), float(marg[t, c]))
+        print(f"{name}: {int((~same).sum())} of {same.size} codes differ, every one at a rounding boundary")
     assert same.mean() >= 0.98
     assert same.all() or name != "short"
 
