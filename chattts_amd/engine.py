@@ -376,18 +376,20 @@ class GptEngine:
         self.stream = torch.cuda.Stream(device=dev)
         self._lane_res = [(self.handle, self.stream)]
         self._lane_res_alt = []
+        self._lane_res_text = []
         self.default_lanes = 1
         self.rng = "host"         # default source of the multinomial's Exp(1) draws: "host" (the reference's CPU stream) | "device"
         self.last_stats = {}
         self._session = None      # buffers + instantiated graph of the last generate() geometry (see generate)
         self._session_alt = None  # ... and of the last exact re-run of certificate-flagged utterances (kept apart: it must not evict the main one)
+        self._session_text = None  # ... and of the last refine-text call: the default `Chat.infer` alternates text and code calls (core.py:341-360)
         self._draws_cache = None  # (key, ExpDraws) of the last seeded call: the constant Exp(1) tensor
 
     def __del__(self):
         try:
-            for h, _ in [*getattr(self, "_lane_res", []), *getattr(self, "_lane_res_alt", [])]:
+            for h, _ in [*getattr(self, "_lane_res", []), *getattr(self, "_lane_res_alt", []), *getattr(self, "_lane_res_text", [])]:
                 self.lib.ctts_gpt_destroy(h)
-            self._lane_res, self._lane_res_alt = [], []
+            self._lane_res, self._lane_res_alt, self._lane_res_text = [], [], []
             self.handle = None
         except Exception:
             pass
@@ -410,10 +412,11 @@ class GptEngine:
         return torch.where(tm[..., None], et, ec).contiguous()
 
     # -- a3: GPT.generate
-    def _lane_resources(self, n: int, alt: bool = False):
-        """(handle, stream) pairs for n concurrent lanes; lane 0 is the engine's own handle/stream.  `alt`: the handles of the exact
-        re-run's session -- a handle owns ONE captured decode graph, and that session must not replace the main one's."""
-        pool = self._lane_res_alt if alt else self._lane_res
+    def _lane_resources(self, n: int, pool: str = ""):
+        """(handle, stream) pairs for n concurrent lanes; lane 0 of the main pool is the engine's own handle/stream.  `pool`: "" (code
+        mode), "_alt" (the exact re-run of flagged utterances), "_text" (refine-text) -- a handle owns ONE captured decode graph, so every
+        session slot decodes on handles of its own and none of them replaces another's graph."""
+        pool = getattr(self, "_lane_res" + pool)
         while len(pool) < n:
             h = C.c_void_p()
             _lib.check(self.lib.ctts_gpt_create(C.byref(h), C.byref(self._w)), "ctts_gpt_create")
@@ -488,7 +491,8 @@ class GptEngine:
             n_lanes = 1
         from .dist import shard_bounds
         bounds = [shard_bounds(B, n_lanes, i) for i in range(n_lanes)]
-        res = self._lane_resources(n_lanes, alt=bool(exact) and self.x3 is not None)
+        slot_sfx = "_alt" if exact else ("_text" if infer_text else "")
+        res = self._lane_resources(n_lanes, slot_sfx)
         caller = torch.cuda.current_stream(dev)
         # seeded sampling re-seeds the CPU generator at every step (gpt.py:504-507): ONE constant tensor per (seed, batch
         # geometry).  Drawing it costs ~4 ms of host time per 256 rows (30 ms for the 2048 rows of an 8-GPU batch), so the
@@ -532,7 +536,9 @@ class GptEngine:
                ptab is not None, teacher_ids is not None, bool(return_sampled),
                None if prefill_chunk is None else int(prefill_chunk), device_rng, manual_seed is None, device_rng and rng_nonce is not None,
                exact, certify, rid is not None)
-        slot = "_session_alt" if exact else "_session"       # an exact re-run keeps the main call's session (and graph) alive
+        # three slots: code mode, the exact re-run, refine-text -- an exact re-run keeps the main call's session (and graph) alive, and
+        # the text / code calls the default `Chat.infer` alternates between each find theirs from the previous request
+        slot = "_session" + slot_sfx
         sess = getattr(self, slot)
         sess = sess if (sess is not None and sess["key"] == key) else None
         if sess is None:

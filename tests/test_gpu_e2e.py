@@ -1166,6 +1166,36 @@ def test_refine_text_mode_bit_exact(gpt_f32, golden, name, use_graph):
         assert np.abs(out.hiddens[b].cpu().numpy() - Gd[name + f".hid{b}"]).max() < 2e-4
 
 
+def test_text_and_code_calls_keep_a_session_each(weights, golden):
+    """The default `Chat.infer` (core.py:341-360) alternates a refine-text call and a code call per request: each mode has a session slot
+    and decode-graph handles of its own, so the second request finds BOTH from the first (no reallocation, no graph re-capture), and the
+    results are what a fresh engine gives."""
+    eng = E.GptEngine(weights["gpt"], weights["embed"], DEV, dtype="f32x3")
+    name = list(cases.TEXT_CASES)[0]
+    ct, cc = cases.TEXT_CASES[name], cases.BIG_CASES["c3w"]
+
+    def text_call():
+        ids, mask, tmask = cases.gen_inputs(ct)
+        ids_t, mask_t = torch.from_numpy(ids), torch.from_numpy(mask)
+        warpers, procs = E.gen_logits(21178, ct["top_P"], ct["top_K"], ct["rep"])
+        out = list(eng.generate(eng.embed_prompt(ids_t, torch.from_numpy(tmask)), ids_t, torch.tensor(ct["temperature"]), cases.TEXT_EOS, mask_t,
+                                ct["max_new"], ct["min_new"], (*procs, *warpers), infer_text=True, manual_seed=ct["manual_seed"]))[-1]
+        return np.concatenate([t.cpu().numpy() for t in out.ids])
+
+    def code_call():
+        out, _ = run_case(eng, cc, use_graph=True)
+        return np.concatenate([t.cpu().numpy().reshape(-1) for t in out[-1].ids])
+
+    t0, c0 = text_call(), code_call()
+    st, sc = eng._session_text, eng._session
+    assert st is not None and sc is not None and st is not sc and st["graph"] and sc["graph"]
+    assert {id(ln.handle) for ln in st["lanes"]}.isdisjoint({id(ln.handle) for ln in sc["lanes"]})
+    t1, c1 = text_call(), code_call()
+    assert eng._session_text is st and eng._session is sc
+    assert np.array_equal(t0, t1) and np.array_equal(c0, c1)
+    assert np.array_equal(t0, golden["text"][name + ".ids"])
+
+
 def test_refine_text_facade_and_rejections(weights):
     from chattts_amd.core import Chat, RefineTextParams
     chat = Chat()

@@ -18,7 +18,7 @@ ids_t, mask_t = torch.from_numpy(ids), torch.from_numpy(mask)
 emb = gpt.embed_prompt(ids_t, torch.from_numpy(tmask))
 stop = torch.full((B,), 30, dtype=torch.int32)
 list(gpt.generate(emb, ids_t, torch.tensor([0.7]), 21000, mask_t, 64, 0, (*procs, *warpers), infer_text=True, manual_seed=42, stop_at=stop, use_graph=False))
-ln = gpt._session["lanes"][0]
+ln = gpt._session_text["lanes"][0]
 with torch.cuda.stream(ln.st):
     ln.finish.zero_(); ln.stop_d.fill_(100000); ln.len_d.fill_(48 + 20)
 torch.cuda.synchronize()
