@@ -228,15 +228,13 @@ class Chat:
     def decode_to_wavs(self, result_list: List[torch.Tensor], use_decoder: bool = True, pad_to: Optional[int] = None) -> np.ndarray:
         """`Chat._decode_to_wavs` (core.py:513-539) -> np.float32 [B, n]: per-row hidden states [T_b,768] through the
         decoder, or (use_decoder=False) per-row token ids [T_b,4] through the full DVAE's codebook; then Vocos.
-        `pad_to` (decoder path): decode as rows of a batch whose longest row has that many tokens (dist.infer_sharded)."""
+        `pad_to`: decode as rows of a batch whose longest row has that many tokens (dist.infer_sharded)."""
         assert self.has_loaded(use_decoder)
         if len(result_list) == 0:
             return np.array([], dtype=np.float32)
         if use_decoder:
             return self.codec.to_host(self.codec.decode_to_wavs(result_list, pad_to=pad_to))
-        if pad_to is not None:
-            raise NotImplementedError("pad_to is implemented for the decoder path (use_decoder=True)")
-        return self.codec.to_host(self.codec.vocos_decode(self.dvae.decode_codes(result_list)))
+        return self.codec.to_host(self.codec.vocos_decode(self.dvae.decode_codes(result_list, pad_to=pad_to)))
 
     def decode_to_pcm16(self, result_list: List[torch.Tensor], use_decoder: bool = True, strip: bool = True,
                         product: str = "f64") -> List[np.ndarray]:
@@ -374,13 +372,14 @@ class Chat:
                                spk_emb_ids=self.tokenizer.spk_emb_ids)
 
     def infer_sharded(self, text, params_infer_code: InferCodeParams = InferCodeParams(), lang=None, do_text_normalization: bool = True,
-                      do_homophone_replacement: bool = True, policy: str = "snake", group=None, dst: int = 0):
-        """`Chat.infer(text, skip_refine_text=True, split_text=False)` (core.py:208-270) over the ranks of the `torch.distributed` process
+                      do_homophone_replacement: bool = True, policy: str = "snake", group=None, dst: int = 0, use_decoder: bool = True):
+        """`Chat.infer(text, skip_refine_text=True, split_text=False, use_decoder=...)` (core.py:208-270) over the ranks of the `torch.distributed` process
         group: every rank calls this with the SAME texts and parameters; the batch is tokenised everywhere (host work, deterministic), dealt
         by prompt length, generated and decoded shard by shard (`dist.infer_sharded`: global row numbering for the CPU draws and the
         rows >= 625 quirk, decode padded to the global longest utterance) and rank `dst` returns the list of stripped waveforms in the
         caller's order -- what the single-process call returns; the other ranks return None.  The reference has no data-parallel mode."""
         from .dist import infer_sharded
+        assert self.has_loaded(use_decoder=use_decoder)
         self._need_tokenizer()
         self.context.set(False)
         if not isinstance(text, list):
@@ -392,7 +391,8 @@ class Chat:
         prompt = Speaker.decode_prompt(params.spk_smp) if params.spk_smp is not None else None
         ids, attn, tmask = self.tokenizer.encode(
             Speaker.decorate_code_prompts(text, params.prompt, params.txt_smp, params.spk_emb), GPT.n_vq, prompt=prompt)
-        wavs = infer_sharded(self, ids, attn, tmask, params, policy=policy, group=group, dst=dst, spk_emb_ids=self.tokenizer.spk_emb_ids)
+        wavs = infer_sharded(self, ids, attn, tmask, params, policy=policy, group=group, dst=dst, use_decoder=use_decoder,
+                             spk_emb_ids=self.tokenizer.spk_emb_ids)
         if wavs is None:
             return None
         thr = np.float32(1e-5)

@@ -200,7 +200,7 @@ __global__ __launch_bounds__(512, 2) void gemm_x3p_k(X3pArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int rr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          scr[rr * 36 + (lane & 31)] = gelu_erf(acc[i][j][r] + bias);
+          scr[rr * 36 + (lane & 31)] = gelu_erf(acc[i][j][r] + bias);   // libm erff: 6 % of the pass's point-wise GEMM time over gelu_fast (profiles/r6z_x3p_gelu_ab.log), kept -- this is the f32-class decoder
         }
         __builtin_amdgcn_wave_barrier();
 #pragma unroll

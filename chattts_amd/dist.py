@@ -70,8 +70,6 @@ def infer_sharded(chat, input_ids: torch.Tensor, attention_mask: torch.Tensor, t
     if any rank's generation yields nothing, the result is empty everywhere.
     `chat`: anything with `infer_code(ids, mask, text_mask, params, stream=False, return_hidden=..., **kw)` and
     `decode_to_wavs(rows, use_decoder, pad_to=...)` (chattts_amd.core.Chat; the CPU tests plug a stand-in)."""
-    if not use_decoder:
-        raise NotImplementedError("infer_sharded decodes through the decoder path (use_decoder=True): the code-book path has no pad_to")
     world, rank, dist = _world_rank(group)
     B = int(input_ids.shape[0])
     nvq = int(input_ids.shape[2])

@@ -11,7 +11,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
-from typing import List, Union
+from typing import List, Optional, Union
 
 import numpy as np
 import torch
@@ -121,10 +121,14 @@ class DvaeEngine:
         _lib.check(self.lib.ctts_dvae_encode(self.handle, wav.data_ptr(), n, codes.data_ptr(), ws.data_ptr(), nb, st), "ctts_dvae_encode")
         return codes.t().contiguous().cpu()
 
-    def decode_codes(self, ids: Union[torch.Tensor, List[torch.Tensor]]) -> torch.Tensor:
-        """[B,T,4] int64, or a list of [T_b,4] rows (zero padded to the longest: core.py:519-534) -> mel [B,2T,100]."""
+    def decode_codes(self, ids: Union[torch.Tensor, List[torch.Tensor]], pad_to: Optional[int] = None) -> torch.Tensor:
+        """[B,T,4] int64, or a list of [T_b,4] rows (zero padded to the longest: core.py:519-534) -> mel [B,2T,100].
+        `pad_to` (rows): pad to that many tokens instead -- the rows of a batch whose longest row is elsewhere (dist.infer_sharded)."""
         if isinstance(ids, (list, tuple)):
             Tmax = max(int(r.size(0)) for r in ids)
+            if pad_to is not None:
+                assert int(pad_to) >= Tmax, "pad_to is shorter than the longest row"
+                Tmax = int(pad_to)
             batch = torch.zeros((len(ids), Tmax, self.G * self.R), dtype=torch.int64, device=self.device)
             for i, r in enumerate(ids):
                 batch[i, : r.size(0)] = r.to(self.device)

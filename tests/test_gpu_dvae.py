@@ -118,6 +118,15 @@ def test_chat_split_text_and_use_decoder_false(weights, dvae_sd):
     for w, r in zip(wavs, ref):
         r = r[np.abs(r) > 1e-5]
         assert w.shape == r.shape and float(np.sqrt(np.mean((w - r) ** 2))) < 1e-4
+    # (c) the same call over dealt shards (dist.infer_sharded, the world of 2 played in turn): ids rows through the code book padded to the
+    # GLOBAL longest utterance are the rows of the unsharded decode
+    from chattts_amd import dist as D
+    full = chat.decode_to_wavs(out.ids, use_decoder=False)
+    for sel in ([1], [0]):
+        part = chat.decode_to_wavs([out.ids[b] for b in sel], use_decoder=False, pad_to=max(lens))
+        assert part.shape == (1, full.shape[1]) and np.abs(part[0] - full[sel[0]]).max() < 1e-6
+    sharded = chat.infer_sharded(list(texts), p, use_decoder=False)           # world of one == Chat.infer
+    assert all(np.array_equal(x, y) for x, y in zip(sharded, wavs))
     # (a)
     p2 = Chat.InferCodeParams(max_new_token=24, manual_seed=3, show_tqdm=False)
     one = chat.infer("hello world. the time of day. chat tts test string", skip_refine_text=True, split_text=True, max_split_batch=2,

@@ -521,6 +521,8 @@ def test_infer_sharded_over_two_ranks_equals_the_single_process_call():
     assert chat.calls == [list(range(7))]
     direct = list(chat.infer_code(ids, mask, tmask, None, stop_at=stop))[-1]
     assert np.array_equal(full, chat.decode_to_wavs(direct.hiddens)) and [len(r) for r in full_ids] == stop.tolist()
+    # the code-book path (use_decoder=False, core.py:518,535): the token-id rows travel through the same recipe
+    assert np.array_equal(D.infer_sharded(chat, ids, mask, tmask, None, stop_at=stop, use_decoder=False), chat.decode_to_wavs(direct.ids, False))
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
