@@ -28,6 +28,118 @@ __device__ __forceinline__ size_t x3p_off(int r, int k, int p, int kb16) {
   return ((((size_t)(r >> 5) * kb16 + (k >> 4)) * 2 + p) * 64 + (((k & 15) >> 3) << 5) + (r & 31)) * 8 + (k & 7);
 }
 
+// the fp16 plane of gemm_h1p_k (below): the x3p layout without the hi | lo axis
+__device__ __forceinline__ size_t h1p_off(int r, int k, int kb16) {
+  return (((size_t)(r >> 5) * kb16 + (k >> 4)) * 64 + (((k & 15) >> 3) << 5) + (r & 31)) * 8 + (k & 7);
+}
+
+// ---- epilogues, shared by the 256 x 256 tiles (one workgroup of 8 waves per CU) and the 128 x 256 tiles (two workgroups of 4 waves
+// per CU, round 6).  A wave owns 64 rows x 128 columns = acc[2][4] MFMA blocks of 32 x 32 whose first row / column are mb / nb.
+// C layout of a block: one column per lane (lane & 31), 16 rows: rr(r) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
+template <bool FULL>
+__device__ __forceinline__ void epi_scale_res(const X3pArgs& a, const f32x16 (&acc)[2][4], int mb, int nb, int lane, int M) {
+  // X3P_SCALE_RES: C = res + gamma * (acc + bias), f32 row-major (the residual stream the depthwise conv reads).  C and res are the
+  // SAME buffer (the residual stream is updated in place): written element by element, every load would have to wait for the
+  // previous store (may-alias), one memory round trip per element -- 62 of a 122 us tile (profiles/r3ag_h1p_phase_probe.log).  Each
+  // thread reads and writes only its own elements, so a column block's 32 residuals are requested together, then the 32 results are
+  // stored.  FULL: every row of the tile exists -> straight-line loads and stores (the ragged last tile clamps and predicates).
+  // ADDRESSING (round 6): one 32-bit byte offset per lane and column block + a UNIFORM row offset per element (scalar base +
+  // vector offset form of global_load / global_store).  With a 64-bit address per element the 64 addresses of a column block sat
+  // in 128 VGPRs next to the 128 accumulators: since round 3 every SCALE_RES kernel had been spilling 131-135 VGPRs (472-496 bytes
+  // of scratch per lane, -Rpass-analysis=kernel-resource-usage) around its epilogue.  The launcher checks M * ld * 4 < 2^32.
+  // ORDER (round 6): the vector-memory counter is in order, stores included -- a wait for a load drains every store issued before
+  // it.  The 34 loads of column block j + 1 used to follow the 32 stores of block j: four store drains per tile, and the same in
+  // the GELU epilogue (a bias load per block behind the previous block's stores: eight drains, 10 us of a 27 us tile,
+  // profiles/r3ah_h1p_phase_probe.log).  Now bias / gamma are loaded once, up front, and the residuals of unit u + 1 (16 rows of
+  // one column block) are requested BEFORE the results of unit u are stored: a wait only ever covers loads.
+  const char* resb = reinterpret_cast<const char*>(a.res);
+  char* cb = reinterpret_cast<char*>(a.C);
+  const int lrow = mb + 4 * (lane >> 5);
+  float bias[4], gam[4];
+  uint32_t off_r[4], off_c[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int col = nb + j * 32 + (lane & 31);
+    bias[j] = a.bias[col];
+    gam[j] = a.gamma[col];
+    off_r[j] = ((uint32_t)lrow * (uint32_t)a.ldr + (uint32_t)col) * 4u;
+    off_c[j] = ((uint32_t)lrow * (uint32_t)a.ldc + (uint32_t)col) * 4u;
+  }
+  float rv[2][16];
+  auto load_unit = [&](int u, float* v) {   // unit u = (column block u / 2, row block u % 2)
+    const int j = u >> 1, i = u & 1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int dr = i * 32 + (r & 3) + 8 * (r >> 2);   // compile-time row offset inside the wave's 64 rows
+      if (FULL) {
+        v[r] = __builtin_nontemporal_load(reinterpret_cast<const float*>(resb + (size_t)dr * a.ldr * 4 + off_r[j]));
+      } else {   // clamped, never predicated
+        const uint32_t o = ((uint32_t)min(lrow + dr, M - 1) * (uint32_t)a.ldr + (uint32_t)(nb + j * 32 + (lane & 31))) * 4u;
+        v[r] = __builtin_nontemporal_load(reinterpret_cast<const float*>(resb + o));
+      }
+    }
+  };
+  load_unit(0, rv[0]);
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int j = u >> 1, i = u & 1;
+    if (u + 1 < 8) load_unit(u + 1, rv[(u + 1) & 1]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int dr = i * 32 + (r & 3) + 8 * (r >> 2);
+      if (FULL || lrow + dr < M) *reinterpret_cast<float*>(cb + (size_t)dr * a.ldc * 4 + off_c[j]) = rv[u & 1][r] + gam[j] * (acc[i][j][r] + bias[j]);
+    }
+  }
+}
+
+// X3P_GELU_PACKED: C layout -> 8 consecutive columns of one row per lane through a wave-private LDS tile (`scr`, 32 x 36 floats):
+// bias + GELU, then the operand planes of the NEXT GEMM (K' = N) in fragment order.  H1P: one fp16 plane (gelu_fast: within
+// 1.5e-7 |x| of the erf form, common.hpp; a 2^-11 rounding follows); else the hi | lo bf16 planes (libm erff: 6 % of the pass's
+// point-wise GEMM time over gelu_fast, profiles/r6z_x3p_gelu_ab.log, kept -- this is the f32-class decoder).
+// Rows >= M land in the buffer's padding (allocated to a multiple of 256 rows).
+template <bool H1P>
+__device__ __forceinline__ void epi_gelu_packed(const X3pArgs& a, const f32x16 (&acc)[2][4], float* scr, int mb, int nb, int lane) {
+  constexpr int FRAG = 512;
+  const int nb16 = a.N >> 4;
+  float bias4[4];   // loaded up front: a load between two blocks' stores would drain the stores (in-order vmcnt, see epi_scale_res)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) bias4[j] = a.bias[nb + j * 32 + (lane & 31)];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int cb = nb + j * 32;
+      const float bias = bias4[j];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        scr[rr * 36 + (lane & 31)] = H1P ? gelu_fast(acc[i][j][r] + bias) : gelu_erf(acc[i][j][r] + bias);
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int item = lane + 64 * it, rr = item >> 2, cg = item & 3;
+        const float4 v0 = *reinterpret_cast<const float4*>(scr + rr * 36 + cg * 8);
+        const float4 v1 = *reinterpret_cast<const float4*>(scr + rr * 36 + cg * 8 + 4);
+        const int row = mb + i * 32 + rr;
+        if (H1P) {
+          *reinterpret_cast<uint4*>(a.Cp + h1p_off(row, cb + cg * 8, nb16)) =
+              make_uint4(pack_f16x2(v0.x, v0.y), pack_f16x2(v0.z, v0.w), pack_f16x2(v1.x, v1.y), pack_f16x2(v1.z, v1.w));
+        } else {
+          const uint32_t h0 = pack_bf16x2(v0.x, v0.y), h1 = pack_bf16x2(v0.z, v0.w), h2 = pack_bf16x2(v1.x, v1.y), h3 = pack_bf16x2(v1.z, v1.w);
+          const uint32_t l0 = pack_bf16x2(v0.x - __uint_as_float(h0 << 16), v0.y - __uint_as_float(h0 & 0xffff0000u));
+          const uint32_t l1 = pack_bf16x2(v0.z - __uint_as_float(h1 << 16), v0.w - __uint_as_float(h1 & 0xffff0000u));
+          const uint32_t l2 = pack_bf16x2(v1.x - __uint_as_float(h2 << 16), v1.y - __uint_as_float(h2 & 0xffff0000u));
+          const uint32_t l3 = pack_bf16x2(v1.z - __uint_as_float(h3 << 16), v1.w - __uint_as_float(h3 & 0xffff0000u));
+          const size_t o = x3p_off(row, cb + cg * 8, 0, nb16);
+          *reinterpret_cast<uint4*>(a.Cp + o) = make_uint4(h0, h1, h2, h3);
+          *reinterpret_cast<uint4*>(a.Cp + o + FRAG) = make_uint4(l0, l1, l2, l3);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+}
+
 template <int EPI, int VAR>
 __global__ __launch_bounds__(512, 2) void gemm_x3p_k(X3pArgs a) {
   constexpr int BM = 256, BN = 256;
@@ -186,71 +298,199 @@ __global__ __launch_bounds__(512, 2) void gemm_x3p_k(X3pArgs a) {
 #undef X3P_MARK
   __syncthreads();   // everybody is done with the ring: the epilogue below reuses it as scratch
 
-  if (EPI == X3P_GELU_PACKED) {
-    // C layout (one column per lane, 16 rows) -> 8 consecutive columns of one row per lane, through a wave-private LDS tile:
-    // bias + GELU, split hi / lo, and store the two planes in fragment order for the NEXT gemm_x3p_k (K' = N)
-    float* scr = reinterpret_cast<float*>(lds) + wave * (32 * 36);
-    const int nb16 = N >> 4;
+  if (EPI == X3P_GELU_PACKED) epi_gelu_packed<false>(a, acc, reinterpret_cast<float*>(lds) + wave * (32 * 36), m0 + wm * 64, n0 + wn * 128, lane);
+  else if (m0 + BM <= M) epi_scale_res<true>(a, acc, m0 + wm * 64, n0 + wn * 128, lane, M);
+  else epi_scale_res<false>(a, acc, m0 + wm * 64, n0 + wn * 128, lane, M);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Round 6: the same two GEMMs on 128 x 256 tiles, TWO workgroups of four waves per CU.
+// What the micro-benchmarks said (tools/fill_probe.hip, tools/loop_probe.hip; profiles/r6z_fill_probe.log, r6z_loop_probe.log): the
+// operand movement of the 256 x 256 tile alone runs at 94 GB/s per CU (24 TB/s over the chip, 2.7 x what the loop draws), the k loop
+// without an epilogue at 0.50 of the dense fp16 peak (110 us for the roofline shape) -- and the shipped kernel takes 268 us, because
+// its ONE workgroup per CU (128 KiB of ring) runs prologue -> k loop -> epilogue back to back: while its eight waves convert, transpose
+// and store 256 x 256 results (10 us of a 27 us tile) or wait for the first stage (2.5 us) the matrix pipe idles, and every workgroup
+// of the launch is in the same phase.  Here a workgroup holds a ring of 3 slots x 24 KiB (72 KiB): two are resident per CU with
+// independent barriers, so one's epilogue and prologue run under the other's MFMAs.  A slot = (4 A + 8 W row tiles) x 2 fragments:
+// 32 of k on the fp16 plane (h1p), 16 of k x {hi, lo} on the split-bf16 planes (x3p); one barrier per slot, the slot after the one
+// being multiplied already landed and the one after that in flight (counted vmcnt).  The loop moves 1.5 x the operand bytes per flop
+// of the 256 x 256 tile (loop_probe variant 4: same 109 us).  Same MFMAs in the same k order per accumulator, same epilogues: bit-identical
+// to the 256 x 256 kernels (tests/test_gpu_kernels.py).  Which launch takes which tiling: codec_tile128 below.
+// ------------------------------------------------------------------------------------------------
+#define T128_GLL(g, l) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g), (__attribute__((address_space(3))) void*)(l), 16, 0, 0)
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_h1p128_k(X3pArgs a) {
+  constexpr int BM = 128, BN = 256, FRAG = 512, SLOT = 24 * FRAG, NSLOT = 3;
+  __shared__ __attribute__((aligned(16))) uint16_t lds[NSLOT * SLOT];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = wave & 1, wn = wave >> 1;   // 2 x 2 waves, each 64 rows x 128 columns
+  const int M = a.M, N = a.N, K = a.K;
+  const int nx = N / BN, ny = (M + BM - 1) / BM, T = nx * ny, per = (T + 7) / 8;   // XCD-aware tile order, as gemm_x3p_k
+  const int t = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= per || t >= T) return;
+  const int m0 = (t / nx) * BM, n0 = (t % nx) * BN;
+  const int kb16 = K >> 4, nq = K >> 5;
+  // wave w stages A row tile w and W row tiles w, 4 + w: per 32-wide k block two consecutive fragments each = 6 KiB-pieces
+  const uint16_t* ag = a.Ap + ((size_t)((m0 >> 5) + wave) * kb16) * FRAG + lane * 8;
+  const uint16_t* wg0 = a.Wp + ((size_t)((n0 >> 5) + wave) * kb16) * FRAG + lane * 8;
+  const uint16_t* wg1 = a.Wp + ((size_t)((n0 >> 5) + 4 + wave) * kb16) * FRAG + lane * 8;
+  auto issue = [&](int q) {   // slot layout: A row tile r at fragments 2 r + h, W row tile c at 8 + 2 c + h
+    uint16_t* l = lds + (q % NSLOT) * SLOT + wave * 2 * FRAG;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      T128_GLL(ag + ((size_t)q * 2 + h) * FRAG, l + h * FRAG);
+      T128_GLL(wg0 + ((size_t)q * 2 + h) * FRAG, l + (8 + h) * FRAG);
+      T128_GLL(wg1 + ((size_t)q * 2 + h) * FRAG, l + (16 + h) * FRAG);
+    }
+  };
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  f16x8 fa0[2], fw0[4], fa1[2], fw1[4];
+  auto rd = [&](f16x8* fa, f16x8* fw, int u) {   // fragments of 16-wide k block u: slot u / 2, half u % 2
+    const uint16_t* l = lds + ((u >> 1) % NSLOT) * SLOT + lane * 8;
+    const int h = u & 1;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const f16x8*>(l + ((wm * 2 + i) * 2 + h) * FRAG);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fw[j] = *reinterpret_cast<const f16x8*>(l + (8 + (wn * 4 + j) * 2 + h) * FRAG);
+  };
+  // as gemm_h1p_k: the block's first MFMA, then the next block's reads, then the other seven (which cover the reads' latency)
+  auto mm_a = [&](const f16x8* fa, const f16x8* fw) { acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0], fw[0], acc[0][0], 0, 0, 0); };
+  auto mm_b = [&](const f16x8* fa, const f16x8* fw) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int cb = n0 + (wn * 4 + j) * 32;
-        const float bias = a.bias[cb + (lane & 31)];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int rr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          scr[rr * 36 + (lane & 31)] = gelu_erf(acc[i][j][r] + bias);   // libm erff: 6 % of the pass's point-wise GEMM time over gelu_fast (profiles/r6z_x3p_gelu_ab.log), kept -- this is the f32-class decoder
-        }
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-          const int item = lane + 64 * it, rr = item >> 2, cg = item & 3;
-          const float4 v0 = *reinterpret_cast<const float4*>(scr + rr * 36 + cg * 8);
-          const float4 v1 = *reinterpret_cast<const float4*>(scr + rr * 36 + cg * 8 + 4);
-          const uint32_t h0 = pack_bf16x2(v0.x, v0.y), h1 = pack_bf16x2(v0.z, v0.w), h2 = pack_bf16x2(v1.x, v1.y), h3 = pack_bf16x2(v1.z, v1.w);
-          const uint32_t l0 = pack_bf16x2(v0.x - __uint_as_float(h0 << 16), v0.y - __uint_as_float(h0 & 0xffff0000u));
-          const uint32_t l1 = pack_bf16x2(v0.z - __uint_as_float(h1 << 16), v0.w - __uint_as_float(h1 & 0xffff0000u));
-          const uint32_t l2 = pack_bf16x2(v1.x - __uint_as_float(h2 << 16), v1.y - __uint_as_float(h2 & 0xffff0000u));
-          const uint32_t l3 = pack_bf16x2(v1.z - __uint_as_float(h3 << 16), v1.w - __uint_as_float(h3 & 0xffff0000u));
-          const int row = m0 + (wm * 2 + i) * 32 + rr;   // rows >= M land in the buffer's padding (allocated to a multiple of 256)
-          const size_t o = x3p_off(row, cb + cg * 8, 0, nb16);
-          *reinterpret_cast<uint4*>(a.Cp + o) = make_uint4(h0, h1, h2, h3);
-          *reinterpret_cast<uint4*>(a.Cp + o + FRAG) = make_uint4(l0, l1, l2, l3);
-        }
-        __builtin_amdgcn_wave_barrier();
-      }
-  } else {   // X3P_SCALE_RES: C = res + gamma * (acc + bias), f32 row-major (the residual stream the depthwise conv reads)
-    // C and res are the SAME buffer (the residual stream is updated in place): written element by element, every load would have
-    // to wait for the previous store (may-alias), one memory round trip per element -- 62 of a 122 us tile
-    // (profiles/r3ag_h1p_phase_probe.log).  Each thread reads and writes only its own elements, so a column block's 32 residuals
-    // are requested together, then the 32 results are stored.
-    auto scale_res = [&](auto whole_tile) {   // whole_tile: all 256 rows exist -> straight-line loads and stores (the ragged last tile predicates)
-      constexpr bool FULL = decltype(whole_tile)::value;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int col = n0 + (wn * 4 + j) * 32 + (lane & 31);
-        const float bias = a.bias[col], gam = a.gamma[col];
-        float rv[2][16];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = m0 + (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            rv[i][r] = __builtin_nontemporal_load(a.res + (size_t)(FULL ? row : min(row, M - 1)) * a.ldr + col);   // clamped, never predicated
-          }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = m0 + (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (FULL || row < M) a.C[(size_t)row * a.ldc + col] = rv[i][r] + gam * (acc[i][j][r] + bias);
-          }
-      }
-    };
-    if (m0 + BM <= M) scale_res(std::true_type{});
-    else scale_res(std::false_type{});
+      for (int j = 0; j < 4; ++j)
+        if (i + j > 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fw[j], acc[i][j], 0, 0, 0);
+  };
+#define T128_SB() __builtin_amdgcn_sched_barrier(0)
+  issue(0);
+  if (nq > 1) issue(1);
+  if (nq > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (nq > 2) issue(2);
+  rd(fa0, fw0, 0);
+  for (int q = 0; q < nq; ++q) {
+    T128_SB(); mm_a(fa0, fw0); T128_SB(); rd(fa1, fw1, 2 * q + 1); T128_SB(); mm_b(fa0, fw0);
+    T128_SB(); mm_a(fa1, fw1); T128_SB();
+    if (q + 1 < nq) {
+      // this wave's pieces of slot q + 1 (its 6 of slot q + 2 may stay in flight); the barrier: everybody's pieces of q + 1 are in,
+      // and everybody holds their last fragments of slot q in registers -> slot q is refilled with q + 3
+      if (q + 2 < nq) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (q + 3 < nq) issue(q + 3);
+      rd(fa0, fw0, 2 * q + 2);
+      T128_SB();
+    }
+    mm_b(fa1, fw1);
   }
+  __syncthreads();   // the ring becomes the epilogue's scratch
+  if (EPI == X3P_GELU_PACKED) epi_gelu_packed<true>(a, acc, reinterpret_cast<float*>(lds) + wave * (32 * 36), m0 + wm * 64, n0 + wn * 128, lane);
+  else if (m0 + BM <= M) epi_scale_res<true>(a, acc, m0 + wm * 64, n0 + wn * 128, lane, M);
+  else epi_scale_res<false>(a, acc, m0 + wm * 64, n0 + wn * 128, lane, M);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_x3p128_k(X3pArgs a) {
+  constexpr int BM = 128, BN = 256, FRAG = 512, SLOT = 24 * FRAG, NSLOT = 3;
+  __shared__ __attribute__((aligned(16))) uint16_t lds[NSLOT * SLOT];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int M = a.M, N = a.N, K = a.K;
+  const int nx = N / BN, ny = (M + BM - 1) / BM, T = nx * ny, per = (T + 7) / 8;
+  const int t = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= per || t >= T) return;
+  const int m0 = (t / nx) * BM, n0 = (t % nx) * BN;
+  const int kb16 = K >> 4;
+  // wave w stages A row tile w and W row tiles w, 4 + w: per 16-wide k block the hi and the lo fragment, 2 contiguous KiB each
+  const uint16_t* ag = a.Ap + ((size_t)((m0 >> 5) + wave) * kb16) * 2 * FRAG + lane * 8;
+  const uint16_t* wg0 = a.Wp + ((size_t)((n0 >> 5) + wave) * kb16) * 2 * FRAG + lane * 8;
+  const uint16_t* wg1 = a.Wp + ((size_t)((n0 >> 5) + 4 + wave) * kb16) * 2 * FRAG + lane * 8;
+  auto issue = [&](int kb) {   // slot layout: A row tile r at fragments 2 r + {hi, lo}, W row tile c at 8 + 2 c + {hi, lo}
+    uint16_t* l = lds + (kb % NSLOT) * SLOT + wave * 2 * FRAG;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      T128_GLL(ag + ((size_t)kb * 2 + p) * FRAG, l + p * FRAG);
+      T128_GLL(wg0 + ((size_t)kb * 2 + p) * FRAG, l + (8 + p) * FRAG);
+      T128_GLL(wg1 + ((size_t)kb * 2 + p) * FRAG, l + (16 + p) * FRAG);
+    }
+  };
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  issue(0);
+  if (kb16 > 1) issue(1);
+  for (int s = 0; s < kb16; ++s) {
+    // this wave's pieces of block s (its 6 of block s + 1 may stay in flight); the barrier: everybody's pieces of s are in, and
+    // everybody is done reading slot (s - 1) % 3 -> it is refilled with block s + 2
+    if (s + 1 < kb16) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (s + 2 < kb16) issue(s + 2);
+    const uint16_t* l = lds + (s % NSLOT) * SLOT + lane * 8;
+    bf16x8 fah[2], fal[2], fwh[4], fwl[4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      fah[i] = *reinterpret_cast<const bf16x8*>(l + ((wm * 2 + i) * 2 + 0) * FRAG);
+      fal[i] = *reinterpret_cast<const bf16x8*>(l + ((wm * 2 + i) * 2 + 1) * FRAG);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      fwh[j] = *reinterpret_cast<const bf16x8*>(l + (8 + (wn * 4 + j) * 2 + 0) * FRAG);
+      fwl[j] = *reinterpret_cast<const bf16x8*>(l + (8 + (wn * 4 + j) * 2 + 1) * FRAG);
+    }
+    // per accumulator lo.hi, hi.lo, hi.hi (small terms first), term-major: gemm_x3p_k's order
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[i], fwh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fwl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fwh[j], acc[i][j], 0, 0, 0);
+  }
+  __syncthreads();   // everybody is done with the ring: the epilogue reuses it as scratch
+  if (EPI == X3P_GELU_PACKED) epi_gelu_packed<false>(a, acc, reinterpret_cast<float*>(lds) + wave * (32 * 36), m0 + wm * 64, n0 + wn * 128, lane);
+  else if (m0 + BM <= M) epi_scale_res<true>(a, acc, m0 + wm * 64, n0 + wn * 128, lane, M);
+  else epi_scale_res<false>(a, acc, m0 + wm * 64, n0 + wn * 128, lane, M);
+}
+#undef T128_SB
+#undef T128_GLL
+
+// Which tiling (profiles/r6z_tile_real_shapes_ab.log, both bit-identical): the fp16-plane kernel is faster on 128 x 256 tiles at every
+// shape of the decoder (-3 ... -25 %, streaming windows -25 ... -30 %); the split-bf16 kernel (three MFMAs per staged byte, the erf epilogue)
+// only where the 256 x 256 tiling leaves CUs without a tile (streaming windows, the DVAE decoder's 256-wide output: -25 ... -30 %) -- on
+// the large launches its 256 x 256 tiles stay 3-6 % ahead.  CTTS_CODEC_TILE=256|128 forces one (A/B, the bit-identity test; read at every launch).
+static bool codec_tile128(const X3pArgs& a, bool h1p) {
+  const char* e = getenv("CTTS_CODEC_TILE");
+  if (e && atoi(e) == 256) return false;
+  if (e && atoi(e) == 128) return true;
+  return h1p || (a.N / 256) * ((a.M + 255) / 256) < 256;
+}
+static hipError_t launch_tile128(const X3pArgs& a, bool h1p, hipStream_t st) {
+  const int tiles = (a.N / 256) * ((a.M + 127) / 128);
+  const dim3 grid(((tiles + 7) / 8) * 8);
+  if (h1p) {
+    if (a.epi == X3P_GELU_PACKED) CTTS_LAUNCH((gemm_h1p128_k<X3P_GELU_PACKED>), grid, dim3(256), st, a);
+    else CTTS_LAUNCH((gemm_h1p128_k<X3P_SCALE_RES>), grid, dim3(256), st, a);
+  } else {
+    if (a.epi == X3P_GELU_PACKED) CTTS_LAUNCH((gemm_x3p128_k<X3P_GELU_PACKED>), grid, dim3(256), st, a);
+    else CTTS_LAUNCH((gemm_x3p128_k<X3P_SCALE_RES>), grid, dim3(256), st, a);
+  }
+  return hipGetLastError();
 }
 
 template <int VAR>
@@ -262,9 +502,13 @@ static void x3p_launch(const X3pArgs& a, dim3 grid, hipStream_t st) {
 hipError_t launch_gemm_x3p(const X3pArgs& a, hipStream_t st) {
   if (a.M <= 0 || (a.N % 256) != 0 || (a.K % 32) != 0 || a.K < 32) return hipErrorInvalidValue;
   if (a.epi != X3P_GELU_PACKED && a.epi != X3P_SCALE_RES) return hipErrorInvalidValue;
+  if (a.epi == X3P_SCALE_RES && ((unsigned long long)a.M * (unsigned)a.ldc >= (1ull << 30) || (unsigned long long)a.M * (unsigned)a.ldr >= (1ull << 30)))
+    return hipErrorInvalidValue;   // the residual epilogue's 32-bit byte offsets
   const int tiles = (a.N / 256) * ((a.M + 255) / 256);
   dim3 grid(((tiles + 7) / 8) * 8);
   static int var = -1;   // CTTS_X3P_VAR: MFMA issue order / priority variant (A/B, tools/x3p_probe.py)
+  if (var < 0) { const char* e = getenv("CTTS_X3P_VAR"); var = e ? atoi(e) : 4; }
+  if (var == 4 && codec_tile128(a, false)) return launch_tile128(a, false, st);
   // default 4: two k blocks per barrier (-1.7 ... -2.6 % per GEMM against the 4-slot ring of variant 1, profiles/r3q_x3p_probe.log; bit-identical)
   if (var < 0) { const char* e = getenv("CTTS_X3P_VAR"); var = e ? atoi(e) : 4; }
   if (var == 0) x3p_launch<0>(a, grid, st);
@@ -285,9 +529,6 @@ hipError_t launch_gemm_x3p(const X3pArgs& a, hipStream_t st) {
 // A ring slot holds a 32-wide k block (two 16-wide fragments per 32-row tile where x3p holds hi | lo of one), a stage is two
 // slots = 64 of k: one barrier per 32 MFMAs of a wave.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ size_t h1p_off(int r, int k, int kb16) {
-  return (((size_t)(r >> 5) * kb16 + (k >> 4)) * 64 + (((k & 15) >> 3) << 5) + (r & 31)) * 8 + (k & 7);
-}
 
 // PROBE (CTTS_H1P_PROBE=1 + CTTS_X3_DBG_PTR, tools/x3p_phase_probe.py --h1p): wave 0 accumulates 100 MHz phase times.
 // NS: ring slots.  4 = stages of two slots, one in flight (64 KiB) while the other is multiplied; 5 (CTTS_H1P_RING=5, all 160 KiB of
@@ -428,63 +669,9 @@ __global__ __launch_bounds__(512, 2) void gemm_h1p_k(X3pArgs a) {
 #undef H1P_SB
   __syncthreads();   // the ring becomes the epilogue's scratch
 
-  if (EPI == X3P_GELU_PACKED) {
-    // C layout (one column per lane, 16 rows) -> 8 consecutive columns of one row per lane through a wave-private LDS tile:
-    // bias + GELU (gelu_fast: within 1.5e-7 |x| of the erf form, common.hpp), round to fp16, one 16-byte slot of the NEXT
-    // gemm_h1p_k's A plane (K' = N)
-    float* scr = reinterpret_cast<float*>(lds) + wave * (32 * 36);
-    const int nb16 = N >> 4;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int cb = n0 + (wn * 4 + j) * 32;
-        const float bias = a.bias[cb + (lane & 31)];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int rr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          scr[rr * 36 + (lane & 31)] = gelu_fast(acc[i][j][r] + bias);
-        }
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-          const int item = lane + 64 * it, rr = item >> 2, cg = item & 3;
-          const float4 v0 = *reinterpret_cast<const float4*>(scr + rr * 36 + cg * 8);
-          const float4 v1 = *reinterpret_cast<const float4*>(scr + rr * 36 + cg * 8 + 4);
-          const int row = m0 + (wm * 2 + i) * 32 + rr;   // rows >= M land in the buffer's padding (allocated to a multiple of 256)
-          *reinterpret_cast<uint4*>(a.Cp + h1p_off(row, cb + cg * 8, nb16)) =
-              make_uint4(pack_f16x2(v0.x, v0.y), pack_f16x2(v0.z, v0.w), pack_f16x2(v1.x, v1.y), pack_f16x2(v1.z, v1.w));
-        }
-        __builtin_amdgcn_wave_barrier();
-      }
-  } else {   // X3P_SCALE_RES: C = res + gamma * (acc + bias), f32 row-major (the residual stream stays f32)
-    // in place (C == res): a column block's 32 residuals are requested together, then the 32 results stored (see gemm_x3p_k)
-    auto scale_res = [&](auto whole_tile) {   // whole_tile: all 256 rows exist -> straight-line loads and stores (the ragged last tile predicates)
-      constexpr bool FULL = decltype(whole_tile)::value;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int col = n0 + (wn * 4 + j) * 32 + (lane & 31);
-        const float bias = a.bias[col], gam = a.gamma[col];
-        float rv[2][16];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = m0 + (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            rv[i][r] = __builtin_nontemporal_load(a.res + (size_t)(FULL ? row : min(row, M - 1)) * a.ldr + col);   // clamped, never predicated
-          }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = m0 + (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (FULL || row < M) a.C[(size_t)row * a.ldc + col] = rv[i][r] + gam * (acc[i][j][r] + bias);
-          }
-      }
-    };
-    if (m0 + BM <= M) scale_res(std::true_type{});
-    else scale_res(std::false_type{});
-  }
+  if (EPI == X3P_GELU_PACKED) epi_gelu_packed<true>(a, acc, reinterpret_cast<float*>(lds) + wave * (32 * 36), m0 + wm * 64, n0 + wn * 128, lane);
+  else if (m0 + BM <= M) epi_scale_res<true>(a, acc, m0 + wm * 64, n0 + wn * 128, lane, M);
+  else epi_scale_res<false>(a, acc, m0 + wm * 64, n0 + wn * 128, lane, M);
   if (PROBE && a.dbg != nullptr && tid == 0) {
     H1P_MARK(5);   // epilogue (from the end of the k loop)
     long long* d = a.dbg + (size_t)blockIdx.x * 8;
@@ -497,6 +684,8 @@ __global__ __launch_bounds__(512, 2) void gemm_h1p_k(X3pArgs a) {
 hipError_t launch_gemm_h1p(const X3pArgs& a, hipStream_t st) {
   if (a.M <= 0 || (a.N % 256) != 0 || (a.K % 64) != 0 || a.K < 64) return hipErrorInvalidValue;
   if (a.epi != X3P_GELU_PACKED && a.epi != X3P_SCALE_RES) return hipErrorInvalidValue;
+  if (a.epi == X3P_SCALE_RES && ((unsigned long long)a.M * (unsigned)a.ldc >= (1ull << 30) || (unsigned long long)a.M * (unsigned)a.ldr >= (1ull << 30)))
+    return hipErrorInvalidValue;   // the residual epilogue's 32-bit byte offsets
   const int tiles = (a.N / 256) * ((a.M + 255) / 256);
   dim3 grid(((tiles + 7) / 8) * 8);
   static int probe = -1, ring = 4;
@@ -504,6 +693,7 @@ hipError_t launch_gemm_h1p(const X3pArgs& a, hipStream_t st) {
     const char* e = getenv("CTTS_H1P_PROBE"); probe = (e && atoi(e) > 0) ? 1 : 0;
     const char* r = getenv("CTTS_H1P_RING"); if (r && atoi(r) == 5) ring = 5;
   }
+  if (ring == 4 && !probe && codec_tile128(a, true)) return launch_tile128(a, true, st);
   if (ring == 5) {
     if (probe && a.dbg != nullptr) {
       if (a.epi == X3P_GELU_PACKED) CTTS_LAUNCH((gemm_h1p_k<X3P_GELU_PACKED, true, 5>), grid, dim3(512), st, a);

@@ -577,6 +577,48 @@ def test_gemm_x3p(G, M, N, K, epi):
     assert G.relerr(got, ref) < 3e-5, G.relerr(got, ref)
 
 
+@pytest.mark.parametrize("kind", ["x3p", "h1p"])
+@pytest.mark.parametrize("M", [16400, 300, 100, 129])
+@pytest.mark.parametrize("N,K,epi", [(1536, 512, 0), (512, 1536, 1), (1024, 256, 0), (256, 1024, 1)])
+def test_codec_gemm_tilings_are_bit_identical(G, monkeypatch, kind, M, N, K, epi):
+    """round 6: the 128 x 256 tiles (two workgroups of four waves per CU: one's epilogue under the other's MFMAs) issue the same MFMAs in
+    the same k order per accumulator and run the same epilogues as the 256 x 256 tiles (CTTS_CODEC_TILE=256) -- every output bit equal,
+    whole and ragged row tiles (the last 128-row tile empty, half full, one row), both epilogues, both operand formats."""
+    from chattts_amd.engine import pack_h1p, pack_x3p
+    lib = _lib.lib()
+    rs = np.random.RandomState(M + N + K + 7)
+    Mp = (M + 255) // 256 * 256
+    A = np.zeros((Mp, K), f32)
+    A[:M] = rs.standard_normal((M, K)).astype(f32)
+    W = (rs.standard_normal((N, K)) / np.sqrt(K)).astype(f32)
+    pack, fn, planes, dt = (pack_x3p, lib.ctts_k_gemm_x3p, 2, torch.bfloat16) if kind == "x3p" else (pack_h1p, lib.ctts_k_gemm_h1p, 1, torch.float16)
+    Ap, Wp = pack(torch.from_numpy(A)).to(G.DEV), pack(torch.from_numpy(W)).to(G.DEV)
+    b_d, g_d = G.dev(rs.standard_normal(N).astype(f32) * 0.1), G.dev((0.05 + 0.1 * rs.rand(N)).astype(f32))
+    res = rs.standard_normal((M, N)).astype(f32)
+    outs = []
+    for tile in ("256", "128"):
+        monkeypatch.setenv("CTTS_CODEC_TILE", tile)
+        if epi == 0:
+            Cp = torch.zeros((Mp * N * planes,), dtype=dt, device=G.DEV)
+            _lib.check(fn(Ap.data_ptr(), Wp.data_ptr(), M, N, K, 0, b_d.data_ptr(), None, None, None, Cp.data_ptr(), None), kind)
+            torch.cuda.synchronize()
+            full = Cp.view(torch.int16).cpu().numpy()
+            # rows >= M of the last 256-row tile are padding: the 128-row tiling does not write the second half when it holds no row
+            if kind == "x3p":
+                keep = full.reshape(Mp // 32, N // 16, 2, 2, 32, 8)[:, :, :, :, :, :]
+                rows = (np.arange(Mp // 32)[:, None] * 32 + np.arange(32)[None, :])            # [tile, r]
+                outs.append(keep[np.broadcast_to((rows < M)[:, None, None, None, :, None], keep.shape)])
+            else:
+                keep = full.reshape(Mp // 32, N // 16, 2, 32, 8)
+                rows = (np.arange(Mp // 32)[:, None] * 32 + np.arange(32)[None, :])
+                outs.append(keep[np.broadcast_to((rows < M)[:, None, None, :, None], keep.shape)])
+        else:
+            C_d = G.dev(res).clone()
+            _lib.check(fn(Ap.data_ptr(), Wp.data_ptr(), M, N, K, 1, b_d.data_ptr(), g_d.data_ptr(), C_d.data_ptr(), C_d.data_ptr(), None, None), kind)
+            torch.cuda.synchronize()
+            outs.append(C_d.cpu().numpy().view(np.int32))
+    assert outs[0].size > 0 and np.array_equal(outs[0], outs[1])
+
 def test_gemm_tiled_bf16x3_big_tile_conv(G):
     """conv-as-GEMM gather (taps 3, zero padding at both utterance ends) on the two-buffer 256x256 tile: conv_in.2 of the
     DVAE decoder at 4 x 3100 frames (M = 12400 >= 12288)"""
