@@ -305,17 +305,20 @@ __global__ __launch_bounds__(512, 2) void gemm_x3p_k(X3pArgs a) {
 
 // ------------------------------------------------------------------------------------------------
 // Round 6: the same two GEMMs on 128 x 256 tiles, TWO workgroups of four waves per CU.
-// What the micro-benchmarks said (tools/fill_probe.hip, tools/loop_probe.hip; profiles/r6z_fill_probe.log, r6z_loop_probe.log): the
-// operand movement of the 256 x 256 tile alone runs at 94 GB/s per CU (24 TB/s over the chip, 2.7 x what the loop draws), the k loop
-// without an epilogue at 0.50 of the dense fp16 peak (110 us for the roofline shape) -- and the shipped kernel takes 268 us, because
-// its ONE workgroup per CU (128 KiB of ring) runs prologue -> k loop -> epilogue back to back: while its eight waves convert, transpose
-// and store 256 x 256 results (10 us of a 27 us tile) or wait for the first stage (2.5 us) the matrix pipe idles, and every workgroup
-// of the launch is in the same phase.  Here a workgroup holds a ring of 3 slots x 24 KiB (72 KiB): two are resident per CU with
-// independent barriers, so one's epilogue and prologue run under the other's MFMAs.  A slot = (4 A + 8 W row tiles) x 2 fragments:
-// 32 of k on the fp16 plane (h1p), 16 of k x {hi, lo} on the split-bf16 planes (x3p); one barrier per slot, the slot after the one
-// being multiplied already landed and the one after that in flight (counted vmcnt).  The loop moves 1.5 x the operand bytes per flop
-// of the 256 x 256 tile (loop_probe variant 4: same 109 us).  Same MFMAs in the same k order per accumulator, same epilogues: bit-identical
-// to the 256 x 256 kernels (tests/test_gpu_kernels.py).  Which launch takes which tiling: codec_tile128 below.
+// What the micro-benchmarks said (tools/fill_probe.hip, tools/loop_probe.hip; profiles/r6z_fill_probe.log, r6z_loop_probe.log) about
+// the 256 x 256 kernel at the roofline shape (M 65,536, N 2048, K 512, fp16 planes: 268 us, MFMA floor 55): its operand movement alone
+// runs at 94 GB/s per CU (24 TB/s over the chip: the L2 -> LDS fill is NOT the wall round 3 took it for), its k loop without an
+// epilogue at 0.50 of the dense fp16 peak (110 us) -- the other 160 us are prologue and epilogue, during which the ONE workgroup a CU
+// holds (128 KiB of ring) leaves the matrix pipe idle.  Here a workgroup holds a ring of 3 slots x 24 KiB (72 KiB), so two are resident
+// per CU with independent barriers.  A slot = (4 A + 8 W row tiles) x 2 fragments: 32 of k on the fp16 plane (h1p), 16 of k x {hi, lo}
+// on the split-bf16 planes (x3p); one barrier per slot, the slot after the one being multiplied already landed and the one after
+// that in flight (counted vmcnt).  The loop moves 1.5 x the operand bytes per flop of the 256 x 256 tile and runs as fast (loop_probe
+// variant 4: 114 vs 110 us).  MEASURED GAIN: modest on the large launches -- loop, GELU arithmetic (+42 us), transposes + stores
+// (+56 us) add up almost linearly even with two workgroups per CU (193 us in the probe, staggering them changes nothing), the epilogue's
+// VALU and store work is simply there -- and 25-30 % on launches whose 256 x 256 tiling leaves CUs empty (streaming windows, the DVAE
+// decoder's narrow outputs).  The larger win of the round sits in the shared epilogue (epi_scale_res: no spills, loads ahead of stores).
+// Same MFMAs in the same k order per accumulator, same epilogues: bit-identical to the 256 x 256 kernels
+// (tests/test_gpu_kernels.py::test_codec_gemm_tilings_are_bit_identical).  Which launch takes which tiling: codec_tile128 below.
 // ------------------------------------------------------------------------------------------------
 #define T128_GLL(g, l) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g), (__attribute__((address_space(3))) void*)(l), 16, 0, 0)
 
