@@ -706,10 +706,29 @@ def main():
         assert wav is not None and wav.dtype == np.float32 and bool(np.isfinite(wav).all())
         return dt
 
-    gold, gpath = None, os.path.join(ROOT, "tests", "golden", "bench_c3.npz")
-    if os.path.exists(gpath) and (args.batch, args.min_len, args.max_len) == (64, 128, 512) and world == 1:
+    # the reference's own run of the GLOBAL batch (oracle/make_bench_golden.py [--world N]): one rank compares all rows, N ranks each their
+    # shard's rows (the reference has no data-parallel mode -- it ran the 64 N utterances as one batch) and the line carries the AND
+    gname = "bench_c3.npz" if world == 1 else "bench_c3_w%d.npz" % world
+    gold, gpath = None, os.path.join(ROOT, "tests", "golden", gname)
+    if os.path.exists(gpath) and (args.batch, args.min_len, args.max_len) == (64, 128, 512):
         gold = np.load(gpath)
-    want_sha = str(gold["sha256"]) if gold is not None else None
+    want_sha = None
+    if gold is not None and world == 1:
+        want_sha = str(gold["sha256"])
+    elif gold is not None:
+        g_off = np.concatenate([[0], np.cumsum(gold["lens"].astype(np.int64))])
+        want_sha = ids_digest([gold["ids"][g_off[b]: g_off[b + 1]].astype(np.int64) for b in wl["sel"]])
+
+    def matches_reference(rows):
+        """this rank's rows == the reference's rows of the same utterances; with N ranks: every rank's"""
+        if want_sha is None:
+            return None
+        ok = ids_digest(rows) == want_sha
+        if dist is not None and world > 1:
+            t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            ok = bool(int(t.item()))
+        return ok
 
     KERNELS = {"f32x3": "Llama projections on SPLIT-fp16 operands (csrc/decode32x.hip, prefill32x.hip: hi = fp16(x), lo' = fp16((x - hi) 2^11), 22 "
                         "significant bits, three fp16 MFMAs per product, f32 accumulation: rms distance to a float64 evaluation of the model 2.3e-7 "
@@ -752,8 +771,11 @@ def main():
             leg["ids_check"] = {"ids_sha256": ids_digest(ids_g), "graph_equals_eager": ids_digest(ids_g) == ids_digest(ids_e)}
             assert leg["ids_check"]["graph_equals_eager"], "graph replay and eager launches disagree on the sampled token ids"
             if eng.dtype != "bf16":
-                leg["ids_check"].update({"golden_sha256": want_sha, "ids_match_reference": (ids_digest(ids_g) == want_sha) if want_sha else None,
-                                         "golden": "tests/golden/bench_c3.npz: the reference's GPT.generate on this workload (oracle/make_bench_golden.py)"})
+                leg["ids_check"].update({"golden_sha256": want_sha, "ids_match_reference": matches_reference(ids_g),
+                                         "golden": ("tests/golden/%s: the reference's GPT.generate on this workload (oracle/make_bench_golden.py)" % gname)
+                                         + ("" if world == 1 else "; every rank compares its shard's rows, the verdict is the AND over the %d ranks" % world)
+                                         + ("" if gold is not None else " -- NOT in the tree for this world size (the reference run of %d utterances does not fit "
+                                                                        "the build container)" % (args.batch * world))})
         return leg, dt_, n_st, dec_ms_
 
     note("timed passes (%s)" % args.dtype)
@@ -991,7 +1013,7 @@ def main():
             result["parity_mode"]["exact_f32_mfma"] = {"dtype": "f32", "value": round(audio_seconds(stop) * 2 / dte, 2), "unit": "audio-s/s", "steps": 2,
                                                        "ms_per_step": round(1000.0 * dte / 2, 3),
                                                        "decode_ms_per_gpt_step": round(dece_ms / max(1, stepse - 1), 4),
-                                                       "ids_match_reference": (ids_digest(rows_e) == want_sha) if want_sha else None,
+                                                       "ids_match_reference": matches_reference(rows_e),
                                                        "kernels": KERNELS["f32"]}
             del gpt32e
             torch.cuda.empty_cache()

@@ -2,6 +2,9 @@
 utterances, default sampling at manual_seed 42, per-row forced output lengths U{128..512}.
 
 Run in the build container only (~6 min of reference CPU time):   python -m oracle.make_bench_golden
+`--world N` (2, 4): the GLOBAL batch `bench.py --gpus N` deals to its ranks (64 N utterances, the reference has no data-parallel mode: it
+runs them as ONE batch) -> tests/golden/bench_c3_w{N}.npz, what every rank compares its shard's rows with.  12 / 45 min, 9 / 18 GB of KV
+cache (+ the DynamicCache's concatenation copies); N = 8 (512 utterances, 35 GB + copies) does not fit this container's 64 GB.
 
 The reference has no length-forcing feature; SURVEY.md 8d prescribes a harness-side logits processor that is identical
 on both sides: EOS is masked while fewer than N_b tokens exist and forced from then on.  It is appended LAST in the
@@ -61,9 +64,12 @@ class ForceLength:
 def main():
     assert ref_harness.available()
     torch.set_num_threads(os.cpu_count())
+    world = int(sys.argv[sys.argv.index("--world") + 1]) if "--world" in sys.argv else 1
+    name = "bench_c3.npz" if world == 1 else "bench_c3_w%d.npz" % world
     sds = W.synthetic_all()
     embed, gpt = ref_harness.build_gpt(sds)
-    ids, mask, tmask, stop = bench_workload()
+    ids, mask, tmask, stop = bench_workload(64 * world)
+    print(name, "batch", ids.shape[0], "threads", torch.get_num_threads(), "load average", os.getloadavg(), flush=True)
     t0 = time.time()
     res, emb, _ = ref_harness.run_generate(embed, gpt, ids, mask, tmask, temperature=[0.3] * 4, top_P=0.7, top_K=20,
                                            repetition_penalty=1.05, max_new_token=int(stop.max()) + 1, min_new_token=0,
@@ -73,9 +79,9 @@ def main():
     rows = [r.numpy() for r in res.ids]
     flat = np.concatenate(rows, 0)
     assert flat.max() < 32767
-    np.savez_compressed(os.path.join(OUT, "bench_c3.npz"), lens=lens, ids=flat.astype(np.int16),
+    np.savez_compressed(os.path.join(OUT, name), lens=lens, ids=flat.astype(np.int16),
                         sha256=np.array(ids_digest(rows)), hid0_first=res.hiddens[0][:4].numpy(), hid0_last=res.hiddens[0][-4:].numpy())
-    print("bench_c3.npz", lens.sum(), "tokens", ids_digest(rows), f"{time.time() - t0:.0f}s")
+    print(name, lens.sum(), "tokens", ids_digest(rows), f"{time.time() - t0:.0f}s")
 
 
 if __name__ == "__main__":

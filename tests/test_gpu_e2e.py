@@ -382,6 +382,38 @@ def test_bench_workload_f32_equals_reference_golden(gpt_f32):
     assert np.abs(out.hiddens[0][-4:].cpu().numpy() - gold["hid0_last"]).max() < 2e-4
 
 
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_workload_dealt_over_ranks_equals_the_reference_run_of_the_global_batch(gpt_f32, world):
+    """What `bench.py --gpus N` runs, the N ranks played one after the other on this GPU: the GLOBAL batch of 64 N utterances dealt by prompt
+    length (bench.shard_workload -> dist.deal_shards), every shard generated with its global row ids / total_rows -- each of its token rows
+    equals the reference's row of the SAME utterance in its single run of the whole global batch (tests/golden/bench_c3_w{N}.npz,
+    `python -m oracle.make_bench_golden --world N`: the reference has no data-parallel mode).  This is the comparison behind
+    `ids_check.ids_match_reference` on an N-rank bench line; the Exp(1) draws of a row and the rows >= 625 penalty quirk (row 157 onwards:
+    N = 4 has 99 such utterances) follow the global numbering."""
+    import os
+    import bench
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bench_c3_w%d.npz" % world)
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/bench_c3_w%d.npz not generated (python -m oracle.make_bench_golden --world %d, build container)" % (world, world))
+    gold = np.load(path)
+    off = np.concatenate([[0], np.cumsum(gold["lens"].astype(np.int64))])
+    warpers, procs = E.gen_logits(625, 0.7, 20, 1.05)
+    seen = []
+    for rank in range(world):
+        wl = bench.shard_workload(64, world, rank, 128, 512)
+        assert len(wl["sel"]) == 64 and wl["total_rows"] == 64 * world * 4
+        ids_t, mask_t = torch.from_numpy(wl["ids"]), torch.from_numpy(wl["mask"])
+        emb = gpt_f32.embed_prompt(ids_t, torch.from_numpy(wl["tmask"]))
+        out = list(gpt_f32.generate(emb, ids_t, torch.tensor([0.3] * 4), 625, mask_t, int(wl["stop_all"].max()) + 1, 0, (*procs, *warpers),
+                                    manual_seed=42, stop_at=torch.from_numpy(wl["stop"]), row_offset=wl["row_offset"], row_ids=wl["row_ids"],
+                                    total_rows=wl["total_rows"]))[-1]
+        rows = [t.cpu().numpy() for t in out.ids]
+        bad = [b for r, b in zip(rows, wl["sel"]) if not np.array_equal(r, gold["ids"][off[b]: off[b + 1]].astype(np.int64))]
+        assert not bad, (rank, bad)
+        assert bench.ids_digest(rows) == bench.ids_digest([gold["ids"][off[b]: off[b + 1]].astype(np.int64) for b in wl["sel"]])
+        seen += list(wl["sel"])
+    assert sorted(seen) == list(range(64 * world))
+
 def _golden_rows(Gd, name, B):
     lens = Gd[name + ".lens"]
     off = np.concatenate([[0], np.cumsum(lens)])
