@@ -579,11 +579,12 @@ def test_gemm_x3p(G, M, N, K, epi):
 
 @pytest.mark.parametrize("kind", ["x3p", "h1p"])
 @pytest.mark.parametrize("M", [16400, 300, 100, 129])
-@pytest.mark.parametrize("N,K,epi", [(1536, 512, 0), (512, 1536, 1), (1024, 256, 0), (256, 1024, 1)])
+@pytest.mark.parametrize("N,K,epi", [(1536, 512, 0), (512, 1536, 1), (1024, 256, 0), (256, 1024, 1), (256, 64, 0), (256, 64, 1), (512, 128, 1), (256, 192, 0)])
 def test_codec_gemm_tilings_are_bit_identical(G, monkeypatch, kind, M, N, K, epi):
     """round 6: the 128 x 256 tiles (two workgroups of four waves per CU: one's epilogue under the other's MFMAs) issue the same MFMAs in
     the same k order per accumulator and run the same epilogues as the 256 x 256 tiles (CTTS_CODEC_TILE=256) -- every output bit equal,
-    whole and ragged row tiles (the last 128-row tile empty, half full, one row), both epilogues, both operand formats."""
+    whole and ragged row tiles (the last 128-row tile empty, half full, one row), both epilogues, both operand formats; K down to 64 (one
+    or two ring slots: the prologue's short paths)."""
     from chattts_amd.engine import pack_h1p, pack_x3p
     lib = _lib.lib()
     rs = np.random.RandomState(M + N + K + 7)
