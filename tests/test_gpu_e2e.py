@@ -382,7 +382,7 @@ def test_bench_workload_f32_equals_reference_golden(gpt_f32):
     assert np.abs(out.hiddens[0][-4:].cpu().numpy() - gold["hid0_last"]).max() < 2e-4
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_bench_workload_dealt_over_ranks_equals_the_reference_run_of_the_global_batch(gpt_f32, world):
     """What `bench.py --gpus N` runs, the N ranks played one after the other on this GPU: the GLOBAL batch of 64 N utterances dealt by prompt
     length (bench.shard_workload -> dist.deal_shards), every shard generated with its global row ids / total_rows -- each of its token rows
