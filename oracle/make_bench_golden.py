@@ -2,9 +2,9 @@
 utterances, default sampling at manual_seed 42, per-row forced output lengths U{128..512}.
 
 Run in the build container only (~6 min of reference CPU time):   python -m oracle.make_bench_golden
-`--world N` (2, 4): the GLOBAL batch `bench.py --gpus N` deals to its ranks (64 N utterances, the reference has no data-parallel mode: it
-runs them as ONE batch) -> tests/golden/bench_c3_w{N}.npz, what every rank compares its shard's rows with.  12 / 45 min, 9 / 18 GB of KV
-cache (+ the DynamicCache's concatenation copies); N = 8 (512 utterances, 35 GB + copies) does not fit this container's 64 GB.
+`--world N` (2, 4, 8): the GLOBAL batch `bench.py --gpus N` deals to its ranks (64 N utterances, the reference has no data-parallel mode: it
+runs them as ONE batch) -> tests/golden/bench_c3_w{N}.npz, what every rank compares its shard's rows with.  Measured on 8 vCPU: 1238 /
+1362 / 2884 s; N = 8 (BASELINE config C4, 512 utterances) peaks at 37 GB (35 GB of f32 KV cache + one layer's concatenation copy).
 
 The reference has no length-forcing feature; SURVEY.md 8d prescribes a harness-side logits processor that is identical
 on both sides: EOS is masked while fewer than N_b tokens exist and forced from then on.  It is appended LAST in the
