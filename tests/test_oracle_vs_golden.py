@@ -70,7 +70,7 @@ def test_generate(golden, np_model, name):
             assert np.abs(got - G[key]).max() < 2e-3, s
 
 
-@pytest.mark.parametrize("name,k", [("c3w", 9), ("c2", 40)])
+@pytest.mark.parametrize("name,k", [("c3w", 5), ("c2", 32)])
 def test_generate_baseline_sizes_prefix(golden, np_model, name, k):
     """BASELINE-size goldens (generate_big.npz: C3 at B = 64, C2 at 512 steps): the oracle reproduces their first k
     steps bit-exactly (generation is causal, so a k-step run equals the k-step prefix; the full runs take minutes of
@@ -198,10 +198,10 @@ def test_generate_random_sweep_subset(golden, np_model):
 
 def test_generate_wide_batch_prefix(golden, np_model):
     """generate_params.npz `wide160`: the reference's own run of 160 utterances = 640 sampling rows, of which rows >= 625
-    (utterance 156 from its 2nd codebook on) get no repetition penalty (processors.py:24-27).  The oracle reproduces the first 6
+    (utterance 156 from its 2nd codebook on) get no repetition penalty (processors.py:24-27).  The oracle reproduces the first 5
     steps of all 160 rows bit-exactly (rows finish from step 4 on); the full 24 steps run on the GPU side."""
     llama, esd, heads = np_model
-    c, k = cases.PARAM_CASES["wide160"], 6
+    c, k = cases.PARAM_CASES["wide160"], 5
     G = golden["generate_params"]
     ids, mask, tmask = cases.gen_inputs(c)
     emb = generate_np.embed_prompt(esd, ids, tmask)
