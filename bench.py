@@ -67,6 +67,31 @@ def ids_digest(rows) -> str:
     return h.hexdigest()
 
 
+def reference_verdict(rows, gold_rows, sel, uncertified_local, dist, world: int):
+    """One rank's token rows against the reference's rows of the same utterances (`sel`: their global indices); with N ranks the verdict
+    is over all of them (one all_gather_object).  Returns (all equal, {detail}): which utterances differ (global indices) and -- when the
+    engine carries the parity certificate (`uncertified_local`: the LOCAL indices it flagged, else None) -- whether every one of them was
+    flagged by it (a draw decided by less than the stated arithmetic distance: two correct float32 evaluations of the model can fall on
+    either side of such a draw)."""
+    bad = [int(b) for r, g, b in zip(rows, gold_rows, sel) if not np.array_equal(np.asarray(r, dtype=np.int64), g)]
+    flagged = None
+    if uncertified_local is not None:
+        fl = {int(sel[j]) for j in uncertified_local}
+        flagged = [b in fl for b in bad]
+    n = len(sel)
+    if dist is not None and world > 1:
+        box = [None] * world
+        dist.all_gather_object(box, (bad, flagged, n))
+        bad = sorted(b for bb, _, _ in box for b in bb)
+        flagged = None if any(f is None for _, f, _ in box) else [x for _, f, _ in box for x in f]
+        n = sum(k for _, _, k in box)
+    det = {}
+    if bad:
+        det = {"differing_utterances": bad, "utterances_compared": int(n),
+               "differing_all_flagged_by_certificate": None if flagged is None else bool(all(flagged))}
+    return (not bad), det
+
+
 def shard_workload(batch_per_gpu: int, world: int, rank: int, min_len: int, max_len: int, policy: str = "snake"):
     """The global C3 batch (64 utterances per GPU) and this rank's shard of it: prompts, masks, forced lengths, the GLOBAL indices of its
     utterances (chattts_amd.dist.deal_shards: sorted by prompt length and dealt in snake order, so every rank gets an equal share of long
@@ -718,29 +743,13 @@ def main():
         gold_rows = [gold["ids"][g_off[b]: g_off[b + 1]].astype(np.int64) for b in wl["sel"]]
         want_sha = str(gold["sha256"]) if world == 1 else ids_digest(gold_rows)
 
-    def reference_verdict(rows, eng=None):
-        """this rank's token rows against the reference's rows of the same utterances; with N ranks the verdict is over all of them.  Returns
-        (all equal | None without a golden, {detail}): which utterances differ (global indices) and -- when the engine carries the parity
-        certificate -- whether every one of them was flagged by it (a draw decided by less than the stated arithmetic distance: two correct
-        float32 evaluations of the model can fall on either side of such a draw)."""
+    def verdict(rows, eng=None):
+        """reference_verdict for this run's golden; (None, {}) without one"""
         if gold_rows is None:
             return None, {}
-        bad = [int(b) for r, g, b in zip(rows, gold_rows, wl["sel"]) if not np.array_equal(np.asarray(r, dtype=np.int64), g)]
-        assert (not bad) == (ids_digest(rows) == want_sha)
-        flagged = None
-        if eng is not None and "uncertified_rows" in eng.last_stats:
-            fl = {int(wl["sel"][j]) for j in eng.last_stats["uncertified_rows"]}
-            flagged = [b in fl for b in bad]
-        if dist is not None and world > 1:
-            box = [None] * world
-            dist.all_gather_object(box, (bad, flagged))
-            bad = sorted(b for bb, _ in box for b in bb)
-            flagged = None if any(f is None for _, f in box) else [x for _, f in box for x in f]
-        det = {}
-        if bad:
-            det = {"differing_utterances": bad, "utterances_compared": int(args.batch * world),
-                   "differing_all_flagged_by_certificate": None if flagged is None else bool(all(flagged))}
-        return (not bad), det
+        unc = eng.last_stats["uncertified_rows"] if (eng is not None and "uncertified_rows" in eng.last_stats) else None
+        ok, det = reference_verdict(rows, gold_rows, wl["sel"], unc, dist, world)
+        return ok, det
 
     KERNELS = {"f32x3": "Llama projections on SPLIT-fp16 operands (csrc/decode32x.hip, prefill32x.hip: hi = fp16(x), lo' = fp16((x - hi) 2^11), 22 "
                         "significant bits, three fp16 MFMAs per product, f32 accumulation: rms distance to a float64 evaluation of the model 2.3e-7 "
@@ -783,7 +792,7 @@ def main():
             leg["ids_check"] = {"ids_sha256": ids_digest(ids_g), "graph_equals_eager": ids_digest(ids_g) == ids_digest(ids_e)}
             assert leg["ids_check"]["graph_equals_eager"], "graph replay and eager launches disagree on the sampled token ids"
             if eng.dtype != "bf16":
-                ok_ref, det_ref = reference_verdict(ids_g, eng)
+                ok_ref, det_ref = verdict(ids_g, eng)
                 leg["ids_check"].update({"golden_sha256": want_sha, "ids_match_reference": ok_ref, **det_ref,
                                          "golden": ("tests/golden/%s: the reference's GPT.generate on this workload (oracle/make_bench_golden.py)" % gname)
                                          + ("" if world == 1 else "; every rank compares its shard's rows, the verdict is the AND over the %d ranks" % world)
@@ -1030,7 +1039,7 @@ def main():
             result["parity_mode"]["exact_f32_mfma"] = {"dtype": "f32", "value": round(audio_seconds(stop) * 2 / dte, 2), "unit": "audio-s/s", "steps": 2,
                                                        "ms_per_step": round(1000.0 * dte / 2, 3),
                                                        "decode_ms_per_gpt_step": round(dece_ms / max(1, stepse - 1), 4),
-                                                       "ids_match_reference": reference_verdict(rows_e)[0],
+                                                       "ids_match_reference": verdict(rows_e)[0],
                                                        "kernels": KERNELS["f32"]}
             del gpt32e
             torch.cuda.empty_cache()

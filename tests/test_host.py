@@ -539,6 +539,51 @@ def test_infer_sharded_over_two_ranks_equals_the_single_process_call():
     assert all(np.array_equal(np.asarray(a), b) for a, b in zip(ids2, full_ids))
 
 
+def _verdict_worker(rank, world, port, q):
+    import torch.distributed as dist
+    import bench
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bench_c3_w2.npz"))
+        off = np.concatenate([[0], np.cumsum(gold["lens"].astype(np.int64))])
+        wl = bench.shard_workload(64, world, rank, 128, 512)
+        gold_rows = [gold["ids"][off[b]: off[b + 1]].astype(np.int64) for b in wl["sel"]]
+        same = bench.reference_verdict([r.copy() for r in gold_rows], gold_rows, wl["sel"], [], dist, world)
+        rows = [r.copy() for r in gold_rows]
+        if rank == 0:
+            rows[3][5, 2] += 1                              # one token of this rank's 4th utterance
+        flagged = bench.reference_verdict(rows, gold_rows, wl["sel"], [3, 7] if rank == 0 else [1], dist, world)
+        unflagged = bench.reference_verdict(rows, gold_rows, wl["sel"], [7] if rank == 0 else [], dist, world)
+        nocert = bench.reference_verdict(rows, gold_rows, wl["sel"], None, dist, world)
+        q.put((rank, same, flagged, unflagged, nocert, int(wl["sel"][3])))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_reference_verdict_over_two_ranks():
+    """`bench.reference_verdict` (what `ids_check.ids_match_reference` of an N-rank line is made of): every rank compares ITS shard's token
+    rows with the reference's rows of the same utterances of the N = 2 global batch (tests/golden/bench_c3_w2.npz, the reference's own run),
+    one all_gather_object makes the verdict the same on every rank -- the AND, the global indices of the differing utterances, and whether
+    the certificate had flagged every one of them."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_verdict_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=300) for _ in range(2)])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    b = got[0][5]                                            # global index of rank 0's 4th utterance
+    for rank, same, flagged, unflagged, nocert, _ in got:
+        assert same == (True, {})
+        assert flagged == (False, {"differing_utterances": [b], "utterances_compared": 128, "differing_all_flagged_by_certificate": True})
+        assert unflagged[0] is False and unflagged[1]["differing_all_flagged_by_certificate"] is False
+        assert nocert[0] is False and nocert[1]["differing_all_flagged_by_certificate"] is None
+
 def _run_bench(*argv, env_drop=("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")):
     import subprocess
     import sys
