@@ -559,6 +559,10 @@ def main():
                     help="dense-layer arithmetic of the acoustic decoder in the main leg (default: f16 with --dtype bf16, bf16x3 with f32; "
                          "the parity-mode leg always decodes with bf16x3)")
     ap.add_argument("--lanes", type=int, default=1, help="concurrent decode lanes (HIP streams) the batch is cut into")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="(debug) the N ranks of a torch.distributed.run launch all use GPU 0 and rendezvous over gloo: a FUNCTIONAL run of the N-rank "
+                         "path (shards, global row ids, the all-reduce before decoding, the per-rank reference verdict) on a one-GPU box; the line is marked "
+                         "and is not a throughput measurement")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) run the CPU baseline leg alone and print its JSON")
     ap.add_argument("--cold-start-only", choices=["plain", "prewarmed"], default=None,
                     help="(internal) a FRESH process: load, optionally Chat.warm the workload's geometry, then time the first streamed chunk")
@@ -587,7 +591,9 @@ def main():
     if args.plumbing_only:
         return plumbing_only(args, world, rank, local_rank)
     n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
-    if n_dev < max(1, args.gpus if "LOCAL_RANK" in os.environ else 1) or local_rank >= n_dev:
+    if args.share_gpu:
+        local_rank = 0
+    if n_dev < max(1, args.gpus if ("LOCAL_RANK" in os.environ and not args.share_gpu) else 1) or local_rank >= n_dev:
         raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank} of {args.gpus} but this host shows {n_dev} HIP device(s): the hot path has no "
                          "CPU fallback (the CPU leg is the oracle's, `cpu_baseline`)")
     torch.cuda.set_device(local_rank)
@@ -597,7 +603,11 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.share_gpu:
+            dist.init_process_group("gloo")        # RCCL refuses two ranks on one device; gloo moves HIP tensors (tools/gloo_cuda_probe.py)
+            args.no_capi_broadcast_check = True
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from chattts_amd import dist as D
     from chattts_amd import engine as E
@@ -806,7 +816,7 @@ def main():
     ids_check = main_leg.get("ids_check")
 
     result = {
-        "metric": "audio seconds/sec (RTF), batch=64 per GPU", "value": round(value, 2), "unit": "audio-s/s",
+        "metric": "audio seconds/sec (RTF), batch=64 per GPU", "value": None if args.share_gpu else round(value, 2), "unit": "audio-s/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000.0 * dt / args.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "C3: batch=64/GPU mixed-length (prompts 16-48 tok, outputs U{%d..%d} tok), top-p .7/top-k 20/rep 1.05/"
@@ -831,6 +841,9 @@ def main():
                              "the certificate (float64 evaluation: 9.3e-6 tempered-logit units = 3 ulps, DESIGN.md 2, profiles/r6D_*.log); the 64 utterances of "
                              "`value` and the 512 of C4 (N = 8) are equal row for row"],
     }
+    if args.share_gpu:
+        result["shared_gpu_debug"] = {"what": "the %d ranks of this run shared ONE GPU and met over gloo (--share-gpu): a functional run of the N-rank path "
+                                              "-- `value` is withheld, the sum over ranks was %.1f audio-s/s on the shared device" % (world, value)}
     if parity:
         # `value` IS the parity-holding number: ids sha256 == the reference's own run of this workload, certified per call
         result["parity_mode"] = dict(main_leg, is_headline=True)

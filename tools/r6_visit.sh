@@ -69,6 +69,9 @@ for S in $STAGES; do
     proftext)  # rocprofv3 kernel trace of the refine-text legs
       cd /tmp; timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${TAG}_text -o ${TAG} -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-ttfs --no-parity-mode --no-configs --no-slot-pool --no-ids-check --no-bf16-mode > $R/gpurun_out/${TAG}_rocprof_text.log 2>&1
       f=$(find /tmp/prof_${TAG}_text -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $R/gpurun_out/${TAG}_kernel_stats_text.csv; cd $R; grep -E "sample_text|fnorm16|embed_text|Name" gpurun_out/${TAG}_kernel_stats_text.csv | cut -c1-200 ;;
+    share2)   # the N = 2 path on ONE GPU (functional, not a measurement): two ranks share GPU 0 and meet over gloo
+      timeout 1200 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29534 bench.py --gpus 2 --share-gpu --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-ttfs --no-configs --no-slot-pool --no-bf16-mode --no-refine-text > gpurun_out/${TAG}_share2.log 2>&1
+      echo "exit $?" >> gpurun_out/${TAG}_share2.log; grep "^{" gpurun_out/${TAG}_share2.log | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print({k: d.get(k) for k in ('value','n_gpus','data_parallel_entry','shared_gpu_debug')}, d['ids_check'])"; tail -3 gpurun_out/${TAG}_share2.log | cut -c1-300 ;;
     reftext)  # refine-text legs + a kernel trace of them
       timeout 600 python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-ttfs --no-parity-mode --no-configs --no-slot-pool --no-ids-check --no-bf16-mode > gpurun_out/${TAG}_reftext.log 2>&1
       grep "^{" gpurun_out/${TAG}_reftext.log | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(json.dumps(d['configs']['refine_text'], indent=1))" | head -80 ;;
