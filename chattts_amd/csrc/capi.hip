@@ -874,6 +874,14 @@ static int convnext_stack(const ctts_codec* c, int n, const std::vector<const fl
     uint16_t* bp = reinterpret_cast<uint16_t*>(ws.b);     // [R256][512] as hi / lo planes: the bytes of the f32 buffer
     uint16_t* bigp = reinterpret_cast<uint16_t*>(ws.big);
     CK(launch_dwconv_ln(ws.a, p[0][i], p[1][i], p[2][i], p[3][i], 1e-6f, dil, nullptr, B, F, 512, st, bp, f16 ? 1 : 0));
+    if (f16 && mlp_fused_pays(R)) {   // round 6: the pair in one launch, the inter-wide activation stays on the CU (bit-identical)
+      MlpArgs m;
+      memset(&m, 0, sizeof(m));
+      m.Ap = bp; m.W1p = (const uint16_t*)px[0][i]; m.W2p = (const uint16_t*)px[1][i]; m.M = R; m.inter = inter;
+      m.b1 = p[5][i]; m.b2 = p[7][i]; m.gamma = p[8][i]; m.C = ws.a;
+      CK(launch_mlp_fused_h1p(m, st));
+      continue;
+    }
     X3pArgs g;
     memset(&g, 0, sizeof(g));
     g.Ap = bp; g.Wp = (const uint16_t*)px[0][i]; g.M = R; g.N = inter; g.K = 512; g.epi = X3P_GELU_PACKED; g.bias = p[5][i]; g.Cp = bigp;
@@ -973,6 +981,16 @@ extern "C" int ctts_k_gemm_h1p(const uint16_t* Ap, const uint16_t* Wp, int32_t M
   g.Ap = Ap; g.Wp = Wp; g.M = M; g.N = N; g.K = K; g.epi = epi; g.bias = bias; g.gamma = gamma; g.res = res; g.ldr = N; g.C = C; g.ldc = N; g.Cp = Cp;
   { const char* e = getenv("CTTS_X3_DBG_PTR"); if (e) g.dbg = (long long*)strtoull(e, nullptr, 0); }   // probe variant only (CTTS_H1P_PROBE=1)
   CK(launch_gemm_h1p(g, (hipStream_t)stream));
+  return 0;
+}
+extern "C" int ctts_k_mlp_fused(const uint16_t* Ap, const uint16_t* W1p, const uint16_t* W2p, int32_t M, int32_t inter, const float* b1,
+                                const float* b2, const float* gamma, float* C, int32_t planes, void* stream) {
+  if (planes != 1) return fail("ctts_k_mlp_fused: planes must be 1 (fp16 plane)");
+  MlpArgs m;
+  memset(&m, 0, sizeof(m));
+  m.Ap = Ap; m.W1p = W1p; m.W2p = W2p; m.M = M; m.inter = inter; m.b1 = b1; m.b2 = b2; m.gamma = gamma; m.C = C;
+  { const char* e = getenv("CTTS_X3_DBG_PTR"); if (e) m.dbg = (long long*)strtoull(e, nullptr, 0); }   // probe only
+  CK(launch_mlp_fused_h1p(m, (hipStream_t)stream));
   return 0;
 }
 extern "C" int ctts_k_gemm_fast(const uint16_t* A, int32_t lda, const uint16_t* W, int32_t M, int32_t N, int32_t K, const float* ssq_in,

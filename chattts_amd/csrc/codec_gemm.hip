@@ -716,3 +716,265 @@ hipError_t launch_gemm_h1p(const X3pArgs& a, hipStream_t st) {
   else CTTS_LAUNCH((gemm_h1p_k<X3P_SCALE_RES>), grid, dim3(512), st, a);
   return hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Round 6: the ConvNeXt MLP in ONE launch (fp16 plane).  out = res + gamma * (GELU(A W1^T + b1) W2^T + b2) for a tile of 128 frames.
+// VERDICT r5 item 4c.  BUILT, MEASURED, NOT THE DEFAULT (mlp_fused_pays below): bit-identical to the two launches, 3-10 % ahead of them at
+// 65,536 frames, behind at every other shape.
+//
+// Why it was tried: as two launches the pair moves the 2048-wide activation through HBM (268 MB written, 537-805 MB read at 65,536
+// frames) and each launch pays a prologue and an epilogue during which the matrix pipe idles.  Here a workgroup (8 waves, one per CU: the
+// 128 x 512 f32 output tile is 128 accumulator registers per lane) walks the hidden dimension in CHUNKS of 128:
+//   P1  H^T[128 hidden x 128 frames] = W1[chunk] A^T   (K = 512: 16 ring steps of 32)     2 MFMA blocks per wave (1 x 2)
+//       bias + GELU + fp16 in registers -> the chunk's H as phase 3's A fragments in LDS (32 KiB), no transpose:
+//       W1's rows enter the MFMA with bits 2 and 3 of the row index swapped (a lane permutation of the DMA's SOURCE addresses),
+//       so that a lane's 16 accumulators of H^T are hidden units 16 (r / 8) + 8 (lane / 32) + r % 8 -- exactly the eight consecutive
+//       k values per 16-block an A fragment holds; one ds_write_b128 per block and k block
+//   P3  out[128 frames x 512] += H[chunk] W2[:, chunk]^T (K = 128: 8 ring steps of 16)    8 MFMA blocks per wave (2 x 4)
+// and after the last chunk the residual epilogue of the two-launch path (epi_scale_res).  ONE ring of 7 slots x 16 KiB carries both
+// phases' operands (P1 step: 8 A + 8 W1 fragments; P3 step: 16 W2 fragments; two pieces per wave and step), the DMA six steps (96 KiB)
+// ahead of the MFMAs across the phase and chunk boundaries (counted vmcnt), fragment reads one k block ahead of the MFMAs across the
+// step's barrier.  Every output element sees the same products in the same k order as the two launches: bit-identical
+// (tests/test_gpu_kernels.py::test_mlp_fused_equals_the_two_launches).
+// What the compiler taught (kept in the code as comments): several __shared__ objects, or any LDS access it can see between an LDS-DMA
+// issue and its counted wait, get a `s_waitcnt vmcnt(0)` -- one DMA latency per ring step.
+// ------------------------------------------------------------------------------------------------
+#define MLP_GLL(g, l) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g), (__attribute__((address_space(3))) void*)(l), 16, 0, 0)
+#define MLP_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+template <bool PROBE>
+__global__ __launch_bounds__(512) void mlp_fused_h1p_k(MlpArgs a) {
+  constexpr int BM = 128, BH = 128, FRAG = 512, SLOT = 16 * FRAG, NSLOT = 7, DEPTH = NSLOT - 1;
+  constexpr int KB1 = 512 / 16;            // k blocks of GEMM 1
+  constexpr int S1 = 16, S3 = BH / 16, SC = S1 + S3;   // ring steps per chunk: P1 (32 of k each), P3 (16 of k each)
+  // ONE LDS object (H | bias | ring): with several, LDS lowering tags them with alias scopes and the waitcnt pass then puts a
+  // `s_waitcnt vmcnt(0)` between every LDS-DMA issue and the next fragment read of the ring (measured: the DMA's latency per step)
+  constexpr int HELEMS = (BM / 32) * (BH / 16) * FRAG;
+  __shared__ __attribute__((aligned(16))) uint16_t lds_all[HELEMS + 2 * 2048 + NSLOT * SLOT];
+  uint16_t* const hbuf = lds_all;                                   // 32 KiB: [frame tile][k block of the chunk] fragments (first: its offsets fit ds_read's immediate)
+  float* const b1s = reinterpret_cast<float*>(lds_all + HELEMS);    // 8 KiB
+  uint16_t* const ring = lds_all + HELEMS + 2 * 2048;               // 7 x 16 KiB
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;   // wave: an SGPR (fragment offsets, DMA bases)
+  const int M = a.M, inter = a.inter, NC = inter / BH, kb2 = inter >> 4;
+  const int m0 = blockIdx.x * BM;
+  const int wh = wave & 3, wf = wave >> 2;   // P1: hidden tile wh x frame tiles 2 wf, 2 wf + 1
+  const int wm = wave & 1, wn = wave >> 1;   // P3: frame tiles 2 wm, 2 wm + 1 x column tiles 4 wn .. 4 wn + 3
+
+  for (int i = tid; i < inter; i += 512) b1s[i] = a.b1[i];
+
+  // DMA pieces of this wave: fragments 2 wave, 2 wave + 1 of the slot.  P1 step (c, j): waves 0-3 bring A (frame tile wave, the two k halves of
+  // the 32-wide block), waves 4-7 W1 (hidden tile wave - 4 of the chunk) with the row permutation in the SOURCE lane; P3 step (c, j): W2 column
+  // tiles 2 wave, 2 wave + 1.  Wave-uniform bases (SGPRs) + the lane's 16 bytes.
+  const int sl = (lane & 32) | (lane & 19) | ((lane & 4) << 1) | ((lane & 8) >> 1);   // bits 2 <-> 3
+  const bool w1w = wave >= 4;
+  const uint16_t* src1 = w1w ? a.W1p + (size_t)(wave - 4) * KB1 * FRAG : a.Ap + (size_t)((m0 >> 5) + wave) * KB1 * FRAG;
+  const size_t cs1 = w1w ? (size_t)(BH / 32) * KB1 * FRAG : 0;
+  const int lo1 = (w1w ? sl : lane) * 8;
+  const uint16_t* src3 = a.W2p + (size_t)(2 * wave) * kb2 * FRAG;
+  const int ln8 = lane * 8;
+
+  // PROBE (CTTS_MLP_PROBE=1 + MlpArgs.dbg, tools/mlp_phase_probe.py): wave 0 accumulates 100 MHz phase times:
+  // 0 DMA wait, 1 barrier, 2 DMA issue, 3 P1 reads + MFMAs, 4 GELU + H writes, 5 P3 reads + MFMAs, 6 epilogue, 7 whole kernel
+  long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0, t_begin = 0;
+#define MLP_MARK(i) do { if (PROBE) { const long long tn = wall_clock64(); tacc[i] += tn - tprev; tprev = tn; } } while (0)
+  int slot_w = 0;   // slot the next issue fills
+  auto issue = [&](int c, int s) {   // ring step s of chunk c
+    uint16_t* l = ring + slot_w * SLOT + 2 * wave * FRAG;
+    if (s < S1) {
+      const uint16_t* g = src1 + (size_t)c * cs1 + (size_t)s * 2 * FRAG + lo1;
+      MLP_GLL(g, l);
+      MLP_GLL(g + FRAG, l + FRAG);
+    } else {
+      const uint16_t* g = src3 + (size_t)(c * S3 + s - S1) * FRAG + ln8;
+      MLP_GLL(g, l);
+      MLP_GLL(g + (size_t)kb2 * FRAG, l + FRAG);
+    }
+    slot_w = slot_w == NSLOT - 1 ? 0 : slot_w + 1;
+  };
+  // step s of chunk c: wait for this wave's two pieces of it (the pieces of the next DEPTH - 1 steps stay in flight: vmcnt counts in order),
+  // barrier (everybody's pieces are in; everybody is done with the slot of the previous step), refill that slot with step + DEPTH
+  auto step_sync = [&](int c, int s) {
+    const bool last = c == NC - 1;
+    const int left = SC - 1 - s;   // steps behind this one in the chunk
+    if (!last || left >= DEPTH - 1) MLP_VMCNT(10);
+    else if (left == 4) MLP_VMCNT(8);
+    else if (left == 3) MLP_VMCNT(6);
+    else if (left == 2) MLP_VMCNT(4);
+    else if (left == 1) MLP_VMCNT(2);
+    else MLP_VMCNT(0);
+    MLP_MARK(0);
+    __builtin_amdgcn_s_barrier();
+    MLP_MARK(1);
+  };
+  // STAGGERED refill: the 16 pieces of a step are 420 cycles of the CU's address path; issued by all 8 waves right behind the barrier they
+  // queue up there while nobody multiplies (phase probe: 55 of a tile's 240 us in the issue, 61 in the barrier skew that follows).  Wave w
+  // issues its two pieces at position w % 4 of the step's four (between the read / MFMA groups), so the refill trickles in under the MFMAs.
+  const int ipos = wave & 3;
+  auto refill = [&](int c, int s, int pos) {
+    if (pos != ipos) return;
+    if (s + DEPTH < SC) issue(c, s + DEPTH);
+    else if (c != NC - 1) issue(c + 1, s + DEPTH - SC);
+    MLP_MARK(2);
+  };
+
+  f32x16 acc2[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[i][j][r] = 0.f;
+
+  MLP_VMCNT(0);   // the bias loads: the counted waits below count DMA pieces only
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < DEPTH; ++s) issue(0, s);
+  if (PROBE) t_begin = tprev = wall_clock64();
+  int slot_r = 0;   // slot of the step being multiplied
+  // LDS byte offsets for the two places that touch LDS through inline asm (below)
+  const uint32_t hb_off = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) void*)hbuf);
+  const uint32_t b1_off = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) void*)b1s);
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  typedef float f32x4v __attribute__((ext_vector_type(4)));
+#define MLP_SB() __builtin_amdgcn_sched_barrier(0)
+  for (int c = 0; c < NC; ++c) {
+    f32x16 acc1[2];
+#pragma unroll
+    for (int y = 0; y < 2; ++y)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc1[y][r] = 0.f;
+    // ---- P1: the fragment reads run one 16-wide k block ahead of the MFMAs (two register sets), across the step's barrier: the
+    // second half's MFMAs of step j - 1 are issued behind the barrier of step j and the first reads of its slot, whose latency they cover
+    f16x8 fa0[2], fw0, fa1[2], fw1;
+    auto rd1 = [&](f16x8* fa, f16x8& fw, const uint16_t* l, int h) {
+#pragma unroll
+      for (int y = 0; y < 2; ++y) fa[y] = *reinterpret_cast<const f16x8*>(l + ((2 * wf + y) * 2 + h) * FRAG);
+      fw = *reinterpret_cast<const f16x8*>(l + (8 + wh * 2 + h) * FRAG);
+    };
+    auto mm1 = [&](const f16x8* fa, const f16x8& fw) {
+#pragma unroll
+      for (int y = 0; y < 2; ++y) acc1[y] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw, fa[y], acc1[y], 0, 0, 0);
+    };
+#pragma unroll
+    for (int j = 0; j < S1; ++j) {
+      step_sync(c, j);
+      const uint16_t* l = ring + slot_r * SLOT + lane * 8;
+      slot_r = slot_r == NSLOT - 1 ? 0 : slot_r + 1;
+      refill(c, j, 0);
+      MLP_SB(); rd1(fa0, fw0, l, 0); MLP_SB();
+      refill(c, j, 1);
+      if (j > 0) mm1(fa1, fw1);
+      MLP_SB(); rd1(fa1, fw1, l, 1); MLP_SB();
+      refill(c, j, 2);
+      mm1(fa0, fw0);
+      MLP_SB();
+      refill(c, j, 3);
+      if (PROBE) { asm volatile("s_nop 15\n\ts_nop 15" :: "v"(acc1[1][0])); MLP_MARK(3); }
+    }
+    mm1(fa1, fw1);
+    // ---- bias + GELU + fp16 -> the chunk's H as A fragments.  The bias reads and the H writes go through inline asm: an LDS access
+    // the compiler can see gets a `s_waitcnt vmcnt(0)` in front of it while LDS-DMA is in flight (the waitcnt pass takes every LDS
+    // access for a possible reader of the DMA's destination), which would drain the ring once per chunk
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const uint32_t ba = b1_off + (uint32_t)(c * BH + 32 * wh + 16 * s2 + 8 * (lane >> 5)) * 4u;
+      f32x4v bA, bB;
+      asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)" : "=&v"(bA), "=&v"(bB) : "v"(ba) : "memory");
+      const float bb[8] = {bA[0], bA[1], bA[2], bA[3], bB[0], bB[1], bB[2], bB[3]};
+#pragma unroll
+      for (int y = 0; y < 2; ++y) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = gelu_fast(acc1[y][8 * s2 + e] + bb[e]);
+        u32x4 pk;
+        pk[0] = pack_f16x2(v[0], v[1]); pk[1] = pack_f16x2(v[2], v[3]); pk[2] = pack_f16x2(v[4], v[5]); pk[3] = pack_f16x2(v[6], v[7]);
+        const uint32_t ha = hb_off + (uint32_t)(((2 * wf + y) * S3 + 2 * wh + s2) * 64 + lane) * 16u;
+        asm volatile("ds_write_b128 %0, %1" :: "v"(ha), "v"(pk) : "memory");
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // H is in LDS before the barrier of P3's first step
+    MLP_MARK(4);
+    // ---- P3: the same pipeline, one 16-wide k block per step ----
+    f16x8 fh0[2], fv0[4], fh1[2], fv1[4];
+    auto rd3 = [&](f16x8* fh, f16x8* fv, const uint16_t* l, int j) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fh[i] = *reinterpret_cast<const f16x8*>(hbuf + ((size_t)((2 * wm + i) * S3 + j) * 64 + lane) * 8);
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) fv[jj] = *reinterpret_cast<const f16x8*>(l + (4 * wn + jj) * FRAG);
+    };
+    auto mm3h = [&](const f16x8* fh, const f16x8* fv, int i) {
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) acc2[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[i], fv[jj], acc2[i][jj], 0, 0, 0);
+    };
+    auto mm3 = [&](const f16x8* fh, const f16x8* fv) { mm3h(fh, fv, 0); mm3h(fh, fv, 1); };
+#pragma unroll
+    for (int j = 0; j < S3; j += 2) {
+      step_sync(c, S1 + j);
+      {
+        const uint16_t* l = ring + slot_r * SLOT + lane * 8;
+        slot_r = slot_r == NSLOT - 1 ? 0 : slot_r + 1;
+        refill(c, S1 + j, 0);
+        MLP_SB(); rd3(fh0, fv0, l, j); MLP_SB();
+        refill(c, S1 + j, 1);
+        if (j > 0) mm3h(fh1, fv1, 0);
+        MLP_SB();
+        refill(c, S1 + j, 2);
+        if (j > 0) mm3h(fh1, fv1, 1);
+        MLP_SB();
+        refill(c, S1 + j, 3);
+        if (PROBE) { asm volatile("s_nop 15\n\ts_nop 15" :: "v"(acc2[1][3][0])); MLP_MARK(5); }
+      }
+      step_sync(c, S1 + j + 1);
+      {
+        const uint16_t* l = ring + slot_r * SLOT + lane * 8;
+        slot_r = slot_r == NSLOT - 1 ? 0 : slot_r + 1;
+        refill(c, S1 + j + 1, 0);
+        MLP_SB(); rd3(fh1, fv1, l, j + 1); MLP_SB();
+        refill(c, S1 + j + 1, 1);
+        mm3h(fh0, fv0, 0);
+        MLP_SB();
+        refill(c, S1 + j + 1, 2);
+        mm3h(fh0, fv0, 1);
+        MLP_SB();
+        refill(c, S1 + j + 1, 3);
+        if (PROBE) { asm volatile("s_nop 15\n\ts_nop 15" :: "v"(acc2[1][3][0])); MLP_MARK(5); }
+      }
+    }
+    mm3(fh1, fv1);
+  }
+#undef MLP_SB
+  X3pArgs e;
+  e.bias = a.b2; e.gamma = a.gamma; e.res = a.C; e.ldr = 512; e.C = a.C; e.ldc = 512;
+  if (m0 + BM <= M) epi_scale_res<true>(e, acc2, m0 + wm * 64, wn * 128, lane, M);
+  else epi_scale_res<false>(e, acc2, m0 + wm * 64, wn * 128, lane, M);
+  if (PROBE && a.dbg != nullptr && tid == 0) {
+    MLP_MARK(6);
+    long long* d = a.dbg + (size_t)blockIdx.x * 8;
+    for (int i = 0; i < 7; ++i) d[i] = tacc[i];
+    d[7] = wall_clock64() - t_begin;
+  }
+}
+#undef MLP_MARK
+#undef MLP_GLL
+#undef MLP_VMCNT
+
+bool mlp_fused_pays(int M) {
+  // CTTS_MLP_FUSED=1 always, 2 where the launch fills whole rounds of 256 workgroups; DEFAULT 0 = never: measured (tools/mlp_ab.py,
+  // profiles/r6M_mlp_ab.log) the one launch is 3-10 % ahead of the two at 65,536 frames and behind everywhere else -- one workgroup of 8
+  // waves per CU runs its phases in lock-step (phase probe, profiles/r6L_mlp_phase.log: of a tile's 240 us, 61 in the barrier, 55 issuing the
+  // LDS-DMA, 53 in P1's LDS-bound reads + MFMAs, 28 in P3's MFMAs, 26 in the GELU), where the two-launch kernels keep TWO workgroups
+  // per CU whose phases overlap.  Kept as an A/B switch and as the bit-identity test's subject.
+  static int mode = -1;
+  if (mode < 0) { const char* e = getenv("CTTS_MLP_FUSED"); mode = e ? atoi(e) : 0; }
+  if (mode == 0) return false;
+  if (mode == 1) return true;
+  const int tiles = (M + 127) / 128;
+  return tiles >= 256 && (tiles % 256 == 0 || tiles % 256 >= 192 || tiles >= 2048);
+}
+
+hipError_t launch_mlp_fused_h1p(const MlpArgs& a, hipStream_t st) {
+  if (a.M <= 0 || a.inter % 128 != 0 || a.inter < 128 || a.inter > 2048) return hipErrorInvalidValue;
+  if ((unsigned long long)a.M * 512ull >= (1ull << 30)) return hipErrorInvalidValue;   // epi_scale_res: 32-bit byte offsets
+  if (a.dbg != nullptr) CTTS_LAUNCH(mlp_fused_h1p_k<true>, dim3((a.M + 127) / 128), dim3(512), st, a);
+  else CTTS_LAUNCH(mlp_fused_h1p_k<false>, dim3((a.M + 127) / 128), dim3(512), st, a);
+  return hipGetLastError();
+}

@@ -395,6 +395,23 @@ hipError_t launch_gemm_x3p(const X3pArgs& a, hipStream_t st);
 // The same GEMM on ONE fp16 plane per operand ("h1p", gemm_mode 2): [rows/32][K/16][lane = (k%16)/8*32 + row%32][k%8] fp16, one
 // v_mfma_f32_32x32x16_f16 per product instead of three bf16 ones, f32 accumulation.  K % 64 == 0.  Ap / Wp / Cp are that plane.
 hipError_t launch_gemm_h1p(const X3pArgs& a, hipStream_t st);
+// Round 6: one ConvNeXt MLP (pwconv1 -> GELU -> pwconv2 -> * gamma -> + residual, dvae.py:46-66) in ONE launch on the fp16 plane
+// (mlp_fused_h1p_k, codec_gemm.hip): the `inter`-wide activation never leaves the CU.  Same MFMAs in the same k order per output
+// element and the same epilogue arithmetic as launch_gemm_h1p(GELU_PACKED) followed by launch_gemm_h1p(SCALE_RES): bit-identical.
+struct MlpArgs {
+  const uint16_t* Ap;    // LayerNorm output, fp16 plane [rows/32][512/16][64][8], rows padded to a multiple of 256
+  const uint16_t* W1p;   // pwconv1 [inter][512] as a plane
+  const uint16_t* W2p;   // pwconv2 [512][inter] as a plane
+  int M, inter;          // inter % 128 == 0, inter <= 2048
+  const float* b1;       // [inter]
+  const float* b2;       // [512]
+  const float* gamma;    // [512]
+  float* C;              // [M][512] f32 row-major residual stream, updated in place
+  long long* dbg;        // probe only (CTTS_X3_DBG_PTR, tools/mlp_phase_probe.py): [n_workgroups][8] accumulated phase times
+};
+hipError_t launch_mlp_fused_h1p(const MlpArgs& a, hipStream_t st);
+// whether convnext_stack takes the one-launch kernel: CTTS_MLP_FUSED=1|2, default off (measured: profiles/r6M_mlp_ab.log)
+bool mlp_fused_pays(int M);
 
 // ---- codec kernels (channels-last [B, F, C]) ---------------------------------------------------
 // yp != null (C = 512 only): the output goes out as the two bf16 planes gemm_x3p_k reads (plane_f16 = 0) or as the one fp16 plane

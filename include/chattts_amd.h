@@ -377,6 +377,11 @@ int ctts_k_gemm_x3p(const uint16_t* Ap, const uint16_t* Wp, int32_t M, int32_t N
 /* the same on ONE fp16 plane per operand (gemm_mode 2): Ap / Wp / Cp are [rows/32][K/16][64][8] fp16; K % 64 == 0 */
 int ctts_k_gemm_h1p(const uint16_t* Ap, const uint16_t* Wp, int32_t M, int32_t N, int32_t K, int32_t epi, const float* bias,
                     const float* gamma, const float* res, float* C, uint16_t* Cp, void* stream);
+/* one ConvNeXt MLP in ONE launch: C = C + gamma * (GELU(A W1^T + b1) W2^T + b2), A [M][512] / W1 [inter][512] / W2 [512][inter] as
+ * fp16 planes (planes = 1), C [M][512] f32 in place; bit-identical to ctts_k_gemm_h1p(epi 0) followed by ctts_k_gemm_h1p(epi 1)
+ * (ConvNeXtBlock.pwconv1 -> act -> pwconv2 -> gamma -> residual, ChatTTS/model/dvae.py:46-66) */
+int ctts_k_mlp_fused(const uint16_t* Ap, const uint16_t* W1p, const uint16_t* W2p, int32_t M, int32_t inter, const float* b1,
+                     const float* b2, const float* gamma, float* C, int32_t planes, void* stream);
 /* perf-mode projection: bf16 activations/weights, optional per-row 1/rms from 48 partial sums of squares,
  * epi 0 = f32 store, 1 = residual add (+ bf16 copy + new partial sums), 2 = SiLU(gate)*up -> bf16 */
 int ctts_k_gemm_fast(const uint16_t* A, int32_t lda, const uint16_t* W, int32_t M, int32_t N, int32_t K, const float* ssq_in, float eps,

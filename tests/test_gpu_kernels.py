@@ -620,6 +620,46 @@ def test_codec_gemm_tilings_are_bit_identical(G, monkeypatch, kind, M, N, K, epi
             outs.append(C_d.cpu().numpy().view(np.int32))
     assert outs[0].size > 0 and np.array_equal(outs[0], outs[1])
 
+@pytest.mark.parametrize("M", [32768 + 128, 1000, 128, 77])
+@pytest.mark.parametrize("inter", [1536, 2048, 256])
+def test_mlp_fused_equals_the_two_launches(G, M, inter):
+    """round 6: one ConvNeXt MLP (pwconv1 -> GELU -> pwconv2 -> gamma -> residual, dvae.py:46-66) in ONE launch, the inter-wide activation
+    kept on the CU (csrc/codec_gemm.hip mlp_fused_h1p_k) -- every output bit equal to ctts_k_gemm_h1p(GELU_PACKED) followed by
+    ctts_k_gemm_h1p(SCALE_RES): whole and ragged 128-row tiles, more tiles than CUs, both widths of the decoder (Vocos 1536, DVAE 2048) and a
+    single chunk; and the pair itself against float64 within the fp16 plane's bound."""
+    from chattts_amd.engine import pack_h1p
+    lib = _lib.lib()
+    rs = np.random.RandomState(M + inter)
+    Mp = (M + 255) // 256 * 256
+    A = np.zeros((Mp, 512), f32)
+    A[:M] = rs.standard_normal((M, 512)).astype(f32)
+    W1 = (rs.standard_normal((inter, 512)) / np.sqrt(512)).astype(f32)
+    W2 = (rs.standard_normal((512, inter)) / np.sqrt(inter)).astype(f32)
+    b1, b2 = rs.standard_normal(inter).astype(f32) * 0.1, rs.standard_normal(512).astype(f32) * 0.1
+    gam = (0.05 + 0.1 * rs.rand(512)).astype(f32)
+    res = rs.standard_normal((M, 512)).astype(f32)
+    Ap, W1p, W2p = (pack_h1p(torch.from_numpy(x)).to(G.DEV) for x in (A, W1, W2))
+    b1_d, b2_d, g_d = G.dev(b1), G.dev(b2), G.dev(gam)
+    # the two launches
+    Hp = torch.zeros((Mp * inter,), dtype=torch.float16, device=G.DEV)
+    C2 = G.dev(res).clone()
+    _lib.check(lib.ctts_k_gemm_h1p(Ap.data_ptr(), W1p.data_ptr(), M, inter, 512, 0, b1_d.data_ptr(), None, None, None, Hp.data_ptr(), None), "pwconv1")
+    _lib.check(lib.ctts_k_gemm_h1p(Hp.data_ptr(), W2p.data_ptr(), M, 512, inter, 1, b2_d.data_ptr(), g_d.data_ptr(), C2.data_ptr(), C2.data_ptr(), None, None), "pwconv2")
+    # one launch
+    C1 = G.dev(res).clone()
+    _lib.check(lib.ctts_k_mlp_fused(Ap.data_ptr(), W1p.data_ptr(), W2p.data_ptr(), M, inter, b1_d.data_ptr(), b2_d.data_ptr(), g_d.data_ptr(),
+                                    C1.data_ptr(), 1, None), "mlp_fused")
+    torch.cuda.synchronize()
+    got, two = C1.cpu().numpy(), C2.cpu().numpy()
+    assert np.isfinite(got).all()
+    assert np.array_equal(got.view(np.int32), two.view(np.int32)), float(np.abs(got - two).max())
+    from scipy.special import erf
+    h = A[:M].astype(np.float64) @ W1.astype(np.float64).T + b1
+    h = 0.5 * h * (1.0 + erf(h / np.sqrt(2.0)))
+    ref = res + gam * (h @ W2.astype(np.float64).T + b2)
+    assert G.relerr(got, ref) < 2e-4, G.relerr(got, ref)
+
+
 def test_gemm_tiled_bf16x3_big_tile_conv(G):
     """conv-as-GEMM gather (taps 3, zero padding at both utterance ends) on the two-buffer 256x256 tile: conv_in.2 of the
     DVAE decoder at 4 x 3100 frames (M = 12400 >= 12288)"""

@@ -72,6 +72,10 @@ for S in $STAGES; do
     share2)   # the N = 2 path on ONE GPU (functional, not a measurement): two ranks share GPU 0 and meet over gloo
       timeout 1200 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29534 bench.py --gpus 2 --share-gpu --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-ttfs --no-configs --no-slot-pool --no-bf16-mode --no-refine-text > gpurun_out/${TAG}_share2.log 2>&1
       echo "exit $?" >> gpurun_out/${TAG}_share2.log; grep "^{" gpurun_out/${TAG}_share2.log | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print({k: d.get(k) for k in ('value','n_gpus','data_parallel_entry','shared_gpu_debug')}, d['ids_check'])"; tail -3 gpurun_out/${TAG}_share2.log | cut -c1-300 ;;
+    mlpab)    # the ConvNeXt MLP as two launches / as one (tools/mlp_ab.py) + the kernel-level bit-identity test
+      timeout 600 python tools/mlp_ab.py > gpurun_out/${TAG}_mlp_ab.log 2>&1; echo "exit $?" >> gpurun_out/${TAG}_mlp_ab.log; tail -12 gpurun_out/${TAG}_mlp_ab.log | cut -c1-260 ;;
+    mlpprobe) # in-kernel phase stamps of the fused MLP
+      timeout 300 python tools/mlp_phase_probe.py > gpurun_out/${TAG}_mlp_phase.log 2>&1; INTER=1536 M=9216 timeout 300 python tools/mlp_phase_probe.py >> gpurun_out/${TAG}_mlp_phase.log 2>&1; tail -22 gpurun_out/${TAG}_mlp_phase.log | cut -c1-200 ;;
     reftext)  # refine-text legs + a kernel trace of them
       timeout 600 python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-ttfs --no-parity-mode --no-configs --no-slot-pool --no-ids-check --no-bf16-mode > gpurun_out/${TAG}_reftext.log 2>&1
       grep "^{" gpurun_out/${TAG}_reftext.log | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(json.dumps(d['configs']['refine_text'], indent=1))" | head -80 ;;
