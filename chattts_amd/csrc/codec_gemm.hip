@@ -963,8 +963,8 @@ bool mlp_fused_pays(int M) {
   // waves per CU runs its phases in lock-step (phase probe, profiles/r6L_mlp_phase.log: of a tile's 240 us, 61 in the barrier, 55 issuing the
   // LDS-DMA, 53 in P1's LDS-bound reads + MFMAs, 28 in P3's MFMAs, 26 in the GELU), where the two-launch kernels keep TWO workgroups
   // per CU whose phases overlap.  Kept as an A/B switch and as the bit-identity test's subject.
-  static int mode = -1;
-  if (mode < 0) { const char* e = getenv("CTTS_MLP_FUSED"); mode = e ? atoi(e) : 0; }
+  const char* e = getenv("CTTS_MLP_FUSED");   // read at every launch, like CTTS_CODEC_TILE (A/B inside one process, the tests)
+  const int mode = e ? atoi(e) : 0;
   if (mode == 0) return false;
   if (mode == 1) return true;
   const int tiles = (M + 127) / 128;

@@ -1053,6 +1053,20 @@ def test_codec_f16_mode_holds_the_waveform_bar(weights):
     assert float(np.sqrt(np.mean((alone[:n2] - w_f16[2, :n2]) ** 2))) < 2e-5
 
 
+def test_codec_fused_mlp_switch_is_bit_identical(weights, monkeypatch):
+    """CTTS_MLP_FUSED=1 (round 6: every ConvNeXt MLP of the gemm="f16" decoder in ONE launch, csrc/codec_gemm.hip mlp_fused_h1p_k; off by
+    default -- measured no faster) through the whole acoustic decoder: the waveforms of a ragged 16 x 400-token batch (12800 frames: whole and
+    ragged 128-row tiles, both widths 1536 / 2048) equal the default path's bit for bit."""
+    rs = np.random.RandomState(34)
+    rows = [torch.from_numpy(rs.standard_normal((n, 768)).astype(np.float32)) for n in [400, 390, 120, 400] + [300] * 12]
+    eng = E.CodecEngine(weights["decoder"], weights["vocos"], DEV, gemm="f16")
+    w_two = eng.decode_to_wavs(rows).cpu().numpy()
+    monkeypatch.setenv("CTTS_MLP_FUSED", "1")
+    w_one = eng.decode_to_wavs(rows).cpu().numpy()
+    assert w_one.shape == w_two.shape == (16, 256 * 799) and np.isfinite(w_one).all()
+    assert np.array_equal(w_one.view(np.int32), w_two.view(np.int32)), float(np.abs(w_one - w_two).max())
+
+
 def test_codec_f16_mode_threshold_straddle(weights, golden):
     """gemm="f16" on both sides of the frame count from which the point-wise pairs take the fp16 kernels (ctts_codec.x3p_min_rows = 1024;
     ADVICE r4): 8 utterances x 64 tokens = 1024 frames run gemm_h1p_k, 8 x 63 = 1008 frames run the split-bf16 tiles -- i.e. equal
