@@ -808,7 +808,9 @@ __global__ __launch_bounds__(512) void mlp_fused_h1p_k(MlpArgs a) {
   // STAGGERED refill: the 16 pieces of a step are 420 cycles of the CU's address path; issued by all 8 waves right behind the barrier they
   // queue up there while nobody multiplies (phase probe: 55 of a tile's 240 us in the issue, 61 in the barrier skew that follows).  Wave w
   // issues its two pieces at position w % 4 of the step's four (between the read / MFMA groups), so the refill trickles in under the MFMAs.
-  const int ipos = wave & 3;
+  // the two waves of a SIMD (w, w + 4) must NOT share a position: a wave blocked on the address path's queue then leaves its SIMD to the other
+  const int ipos_mode = a.ipos_mode;
+  const int ipos = ipos_mode == 1 ? (wave & 3) : ipos_mode == 2 ? 0 : 2 * (wave >> 2) + (wave & 1);
   auto refill = [&](int c, int s, int pos) {
     if (pos != ipos) return;
     if (s + DEPTH < SC) issue(c, s + DEPTH);
@@ -974,7 +976,9 @@ bool mlp_fused_pays(int M) {
 hipError_t launch_mlp_fused_h1p(const MlpArgs& a, hipStream_t st) {
   if (a.M <= 0 || a.inter % 128 != 0 || a.inter < 128 || a.inter > 2048) return hipErrorInvalidValue;
   if ((unsigned long long)a.M * 512ull >= (1ull << 30)) return hipErrorInvalidValue;   // epi_scale_res: 32-bit byte offsets
-  if (a.dbg != nullptr) CTTS_LAUNCH(mlp_fused_h1p_k<true>, dim3((a.M + 127) / 128), dim3(512), st, a);
-  else CTTS_LAUNCH(mlp_fused_h1p_k<false>, dim3((a.M + 127) / 128), dim3(512), st, a);
+  MlpArgs b = a;
+  { const char* e = getenv("CTTS_MLP_IPOS"); b.ipos_mode = e ? atoi(e) : 0; }
+  if (a.dbg != nullptr) CTTS_LAUNCH(mlp_fused_h1p_k<true>, dim3((a.M + 127) / 128), dim3(512), st, b);
+  else CTTS_LAUNCH(mlp_fused_h1p_k<false>, dim3((a.M + 127) / 128), dim3(512), st, b);
   return hipGetLastError();
 }

@@ -408,6 +408,7 @@ struct MlpArgs {
   const float* gamma;    // [512]
   float* C;              // [M][512] f32 row-major residual stream, updated in place
   long long* dbg;        // probe only (CTTS_X3_DBG_PTR, tools/mlp_phase_probe.py): [n_workgroups][8] accumulated phase times
+  int ipos_mode;         // A/B (CTTS_MLP_IPOS): where in a ring step a wave issues its refill: 0 by SIMD pair (default), 1 wave % 4, 2 all behind the barrier
 };
 hipError_t launch_mlp_fused_h1p(const MlpArgs& a, hipStream_t st);
 // whether convnext_stack takes the one-launch kernel: CTTS_MLP_FUSED=1|2, default off (measured: profiles/r6M_mlp_ab.log)
