@@ -533,6 +533,7 @@ def main():
     ap.add_argument("--no-bf16-mode", action="store_true", help="skip the bf16 perf-mode legs (value_bf16, its kernels, the queue / pcm16 / slot-pool "
                     "/ C2 / C5 legs that run on it)")
     ap.add_argument("--no-refine-text", action="store_true", help="skip the refine-text legs (configs.refine_text)")
+    ap.add_argument("--no-projection", action="store_true", help="skip the weak-scaling projection (every rank's shard of the N = 2, 4, 8 global batches timed on this GPU)")
     ap.add_argument("--exact-fallback", action="store_true", help="f32x3: generate the utterances the certificate flags again on the exact f32 "
                     "kernels inside the timed passes (default: the certificate is reported, the ids are checked against the reference's sha256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -1082,6 +1083,47 @@ def main():
         note("time to first sample (%s)" % args.dtype)
         result["ttfs_ms_p50"], result["ttfs_samples"] = ttfs_leg(gpt, codec)
         result["ttfs_dtype"] = args.dtype
+
+    # ---- weak-scaling PROJECTION ("report 1-GPU measured + weak-scaling projection, clearly labelled") ----
+    # The data path has no collective, so an N-GPU pass lasts as long as its SLOWEST rank's shard.  Every shard of the N = 2, 4, 8 global
+    # batches (64 N utterances dealt by dist.deal_shards -- the workload `bench.py --gpus N` runs, N = 8 = BASELINE's C4) is generated and
+    # decoded HERE, one after the other, with its global row ids and padded to the global longest utterance; projected value = audio of the
+    # global batch / slowest shard's time.  What one GPU cannot show: host-side contention of N processes and the load-time broadcast.
+    def projection_leg(eng, cdc):
+        out = {"what": "PROJECTION, NOT A MEASUREMENT beyond one GPU: each rank's shard of the N-rank workload timed on this GPU (second of two "
+                       "passes), N-GPU value = audio seconds of the 64 N utterances / the slowest shard's time; no data-path collective exists "
+                       "(one 8-byte all-reduce(max) before decoding, not modelled)", "dtype": args.dtype, "n_gpus": {}}
+        for n in (2, 4, 8):
+            times = []
+            for r in range(n):
+                w = shard_workload(args.batch, n, r, args.min_len, args.max_len)
+                i_d, t_d = torch.from_numpy(w["ids"]).to(dev), torch.from_numpy(w["tmask"]).to(dev)
+                m_t, s_t = torch.from_numpy(w["mask"]), torch.from_numpy(w["stop"])
+                mx = int(w["stop_all"].max()) + 1
+                dt_r = None
+                for rep in range(2):
+                    torch.cuda.synchronize(dev)
+                    t1 = time.perf_counter()
+                    res = None
+                    emb = eng.embed_prompt(i_d, t_d)
+                    for res in eng.generate(emb, i_d, temp, 625, m_t, mx, 0, (*procs, *warpers), return_hidden=True, manual_seed=42,
+                                            use_graph=not args.no_graph, stop_at=s_t, row_offset=w["row_offset"], row_ids=w["row_ids"],
+                                            total_rows=w["total_rows"], lanes=args.lanes):
+                        pass
+                    wv = cdc.to_host(cdc.decode_to_wavs(res.hiddens, pad_to=int(w["stop_all"].max())))
+                    torch.cuda.synchronize(dev)
+                    dt_r = time.perf_counter() - t1
+                    assert [int(t.shape[0]) for t in res.ids] == w["stop"].tolist() and wv.dtype == np.float32
+                times.append(dt_r)
+            tot = audio_seconds(w["stop_all"])
+            out["n_gpus"][str(n)] = {"projected_value": round(tot / max(times), 1), "unit": "audio-s/s", "utterances": int(w["Bg"]),
+                                     "shard_ms": [round(1e3 * t, 1) for t in times], "slowest_shard_ms": round(1e3 * max(times), 1)}
+        return out
+
+    if rank == 0 and world == 1 and parity and not args.no_projection and not args.pipeline:
+        note("weak-scaling projection: the shards of the N = 2, 4, 8 workloads, one after the other on this GPU")
+        result["weak_scaling_projection"] = projection_leg(gpt, codec)
+        result["weak_scaling_projection"]["n_gpus"]["1"] = {"measured_value": result["value"], "unit": "audio-s/s", "utterances": args.batch}
 
     # ---- refine-text (runs before every default infer() call) on the headline engine ----
     if rank == 0 and world == 1 and not args.no_refine_text:

@@ -3,7 +3,7 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; R=$PWD; mkdir -p gpurun_out; export TMPDIR=/tmp
 TAG=${1:-r6a}
 STAGES=${2:-"tests smoke bench"}
-NOLEGS="--no-cpu-baseline --no-roofline --no-ttfs --no-parity-mode --no-configs --no-slot-pool --no-ids-check --no-bf16-mode --no-refine-text"
+NOLEGS="--no-projection --no-cpu-baseline --no-roofline --no-ttfs --no-parity-mode --no-configs --no-slot-pool --no-ids-check --no-bf16-mode --no-refine-text"
 for S in $STAGES; do
   case $S in
     tests)
@@ -78,6 +78,9 @@ for S in $STAGES; do
       timeout 300 python tools/mlp_phase_probe.py > gpurun_out/${TAG}_mlp_phase.log 2>&1; INTER=1536 M=9216 timeout 300 python tools/mlp_phase_probe.py >> gpurun_out/${TAG}_mlp_phase.log 2>&1; tail -22 gpurun_out/${TAG}_mlp_phase.log | cut -c1-200 ;;
     mlpipos)  # fused MLP: where in the ring step a wave issues its refill (CTTS_MLP_IPOS 0 by SIMD pair / 1 wave % 4 / 2 all behind the barrier)
       for m in 0 1 2 0 1 2; do echo "CTTS_MLP_IPOS=$m" >> gpurun_out/${TAG}_mlp_ipos.log; CTTS_MLP_IPOS=$m timeout 300 python tools/mlp_ab.py 2>&1 | grep "M=65536\|M=32768" | cut -c1-200 >> gpurun_out/${TAG}_mlp_ipos.log; done; cat gpurun_out/${TAG}_mlp_ipos.log ;;
+    proj)     # the weak-scaling projection leg alone
+      timeout 900 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-ttfs --no-parity-mode --no-configs --no-slot-pool --no-bf16-mode --no-refine-text > gpurun_out/${TAG}_proj.log 2>&1; echo "exit $?" >> gpurun_out/${TAG}_proj.log
+      grep "^{" gpurun_out/${TAG}_proj.log | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], json.dumps(d.get('weak_scaling_projection'))[:1500])"; tail -2 gpurun_out/${TAG}_proj.log | cut -c1-300 ;;
     reftext)  # refine-text legs + a kernel trace of them
       timeout 600 python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-ttfs --no-parity-mode --no-configs --no-slot-pool --no-ids-check --no-bf16-mode > gpurun_out/${TAG}_reftext.log 2>&1
       grep "^{" gpurun_out/${TAG}_reftext.log | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(json.dumps(d['configs']['refine_text'], indent=1))" | head -80 ;;
