@@ -805,10 +805,11 @@ __global__ __launch_bounds__(512) void mlp_fused_h1p_k(MlpArgs a) {
     __builtin_amdgcn_s_barrier();
     MLP_MARK(1);
   };
-  // STAGGERED refill: the 16 pieces of a step are 420 cycles of the CU's address path; issued by all 8 waves right behind the barrier they
-  // queue up there while nobody multiplies (phase probe: 55 of a tile's 240 us in the issue, 61 in the barrier skew that follows).  Wave w
-  // issues its two pieces at position w % 4 of the step's four (between the read / MFMA groups), so the refill trickles in under the MFMAs.
-  // the two waves of a SIMD (w, w + 4) must NOT share a position: a wave blocked on the address path's queue then leaves its SIMD to the other
+  // WHERE a wave issues its two refill pieces inside the ring step (MlpArgs.ipos_mode, CTTS_MLP_IPOS): 0 (default) position 2 (w / 4) + w % 2 of
+  // the step's four (between the read / MFMA groups), so that the two waves of a SIMD (w, w + 4) never issue together; 1 position w % 4; 2 all
+  // eight waves right behind the barrier.  The idea: the 16 pieces of a step are 420 cycles of the CU's address path, and the phase probe shows
+  // 55 of a tile's 240 us in the issue and 61 in the barrier skew behind it.  MEASURED: no difference between the three
+  // (profiles/r6Q_mlp_ipos.log) -- the issue cost is per instruction, not queueing behind the other waves.
   const int ipos_mode = a.ipos_mode;
   const int ipos = ipos_mode == 1 ? (wave & 3) : ipos_mode == 2 ? 0 : 2 * (wave >> 2) + (wave & 1);
   auto refill = [&](int c, int s, int pos) {
