@@ -35,7 +35,7 @@ __device__ __forceinline__ void ln_finish(float* y, const float* __restrict__ lw
     else { y[4 * q] = o.x; y[4 * q + 1] = o.y; y[4 * q + 2] = o.z; y[4 * q + 3] = o.w; }
   }
   if constexpr (CPL == 8) {
-   if (planes != nullptr) {
+   if (planes != nullptr && row >= 0) {   // row < 0 (ln_pack): the caller packs and stores
     constexpr int KB16 = C / 16;
     if constexpr (F16) {   // one fp16 plane (codec_gemm.hip: gemm_h1p_k): a lane's 8 channels are one 16-byte slot of it
       const size_t o = (((size_t)(row >> 5) * KB16 + (c0 >> 4)) * 64 + (((c0 & 15) >> 3) << 5) + (row & 31)) * 8;
@@ -161,6 +161,117 @@ __global__ __launch_bounds__(256) void dwconv_ln_run_k(const float* __restrict__
   }
 }
 
+// Round 6 (third session): the planes' WRITES.  dwconv_ln_run_k hands every normalised row to the GEMMs' fragment order as 64 isolated
+// 16-byte stores per plane (a lane's 8 channels of one row; the other rows of a 128-byte line come from other iterations or other waves,
+// microseconds apart).  Per-dispatch PMC (profiles/r6V_pmc_dwconv_per_dispatch.txt): 415 MB written per Vocos launch (dilation 1) and
+// 231 MB per DVAE launch (dilation 2) for 134 MB of planes -- partial lines leave the L2 before their neighbours arrive.  Here a wave walks
+// RUN CONSECUTIVE frames of one utterance (any dilation: the register ring holds rows t - 3 DIL .. t + 3 DIL + prefetch), parks the packed
+// planes of FOUR consecutive rows in a wave-private LDS tile and writes them transposed: lanes 4 q .. 4 q + 3 hold rows r .. r + 3 of
+// channel block q, so every store instruction covers 64 contiguous bytes per lane quad -- whole 64-byte requests.  Same arithmetic per
+// frame (acc = bias, taps 0..6 in order, ln_finish's statistics): the planes are bit-identical to dwconv_ln_run_k's.
+template <int CPL, bool F16>
+__device__ __forceinline__ void ln_pack(float* y, const float* __restrict__ lw, const float* __restrict__ lb, float eps, int c0, uint4& hi, uint4& lo) {
+  ln_finish<CPL, F16>(y, lw, lb, eps, c0, nullptr, reinterpret_cast<uint16_t*>(1), -1);   // planes != null, row < 0: normalise in place, no store
+  if constexpr (F16) {
+    hi = make_uint4(pack_f16x2(y[0], y[1]), pack_f16x2(y[2], y[3]), pack_f16x2(y[4], y[5]), pack_f16x2(y[6], y[7]));
+    lo = hi;
+  } else {
+    uint32_t h[4], l[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      h[q] = pack_bf16x2(y[2 * q], y[2 * q + 1]);
+      l[q] = pack_bf16x2(y[2 * q] - __uint_as_float(h[q] << 16), y[2 * q + 1] - __uint_as_float(h[q] & 0xffff0000u));
+    }
+    hi = make_uint4(h[0], h[1], h[2], h[3]);
+    lo = make_uint4(l[0], l[1], l[2], l[3]);
+  }
+}
+
+template <bool F16, int DIL>
+__global__ __launch_bounds__(256) void dwconv_ln_seq_k(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                                       const float* __restrict__ lw, const float* __restrict__ lb, float eps, int F, int B, int runs,
+                                                       uint16_t* __restrict__ yp) {
+  constexpr int CPL = 8, C = 512, KB16 = C / 16;
+  constexpr int NSL = DIL == 1 ? 9 : 16, RUN = DIL == 1 ? 36 : 48;   // ring slots (6 DIL + 1 taps' span + 2 | 3 rows ahead); RUN % NSL == 0, RUN % 4 == 0
+  constexpr int NP = F16 ? 1 : 2, RS = 65;                           // planes; LDS row stride in 16-byte units (65: the transposed reads hit distinct banks)
+  __shared__ uint4 stg[4][NP][4][RS];
+  const int per = gridDim.x >> 3;    // XCD-aware order: one contiguous range of (utterance, run) per XCD (see dwconv_ln_k)
+  const int blk = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  const int wave = threadIdx.x >> 6, gw = blk * 4 + wave;
+  if (gw >= B * runs) return;
+  const int bi = gw / runs, run = gw - bi * runs;
+  const int f0 = run * RUN;
+  if (f0 >= F) return;
+  const int lane = threadIdx.x & 63, c0 = lane * CPL;
+  float wt[7][CPL], bias[CPL];
+#pragma unroll
+  for (int q = 0; q < CPL / 4; ++q) {
+    const float4 b0 = *reinterpret_cast<const float4*>(b + c0 + 4 * q);
+    bias[4 * q] = b0.x; bias[4 * q + 1] = b0.y; bias[4 * q + 2] = b0.z; bias[4 * q + 3] = b0.w;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      const float4 w0 = *reinterpret_cast<const float4*>(w + j * C + c0 + 4 * q);
+      wt[j][4 * q] = w0.x; wt[j][4 * q + 1] = w0.y; wt[j][4 * q + 2] = w0.z; wt[j][4 * q + 3] = w0.w;
+    }
+  }
+  const float* xb = x + (size_t)bi * F * C + c0;
+  float s[NSL][CPL];
+  auto ldrow = [&](float* dst, int t_rel) {   // row f0 + t_rel, zeros outside the utterance (Conv1d zero padding)
+    const int r = f0 + t_rel;
+    const bool ok = r >= 0 && r < F;
+    const float* xp = xb + (size_t)min(max(r, 0), F - 1) * C;
+#pragma unroll
+    for (int q = 0; q < CPL / 4; ++q) {
+      const float4 v = *reinterpret_cast<const float4*>(xp + 4 * q);
+      dst[4 * q] = ok ? v.x : 0.f; dst[4 * q + 1] = ok ? v.y : 0.f; dst[4 * q + 2] = ok ? v.z : 0.f; dst[4 * q + 3] = ok ? v.w : 0.f;
+    }
+  };
+  // the four parked rows go out transposed: lane 4 q + j writes row j of channel block 16 i + q (i = 0..3)
+  const int fj = lane & 3, fq = lane >> 2;
+  auto flush = [&](int row0, int n) {   // rows row0 .. row0 + n - 1 (global row index) are parked in slots 0 .. n - 1
+    if (fj < n) {
+      const int row = row0 + fj;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int bk = 16 * i + fq;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          const uint4 v = stg[wave][p][fj][bk];
+          const size_t o = F16 ? (((size_t)(row >> 5) * KB16 + (bk >> 1)) * 64 + ((bk & 1) << 5) + (row & 31)) * 8
+                               : ((((size_t)(row >> 5) * KB16 + (bk >> 1)) * 2 + p) * 64 + ((bk & 1) << 5) + (row & 31)) * 8;
+          *reinterpret_cast<uint4*>(yp + o) = v;
+        }
+      }
+    }
+  };
+  // slot (t + k) % NSL holds row t - 3 DIL + k: the 7 taps of frame t are k = 0, DIL, .., 6 DIL; the slots behind them are on their way
+#pragma unroll
+  for (int k = 0; k < NSL - 1; ++k) ldrow(s[k], k - 3 * DIL);
+  for (int t0 = 0; t0 < RUN; t0 += NSL) {
+#pragma unroll
+    for (int u = 0; u < NSL; ++u) {
+      const int t = t0 + u, f = f0 + t;
+      if (f >= F) {                             // wave-uniform: the utterance ends inside this run
+        if (t & 3) flush(bi * F + f - (t & 3), t & 3);
+        return;
+      }
+      ldrow(s[(u + NSL - 1) % NSL], t - 3 * DIL + NSL - 1);
+      float acc[CPL];
+#pragma unroll
+      for (int i = 0; i < CPL; ++i) acc[i] = bias[i];
+#pragma unroll
+      for (int j = 0; j < 7; ++j)
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) acc[i] = fmaf(wt[j][i], s[(u + j * DIL) % NSL][i], acc[i]);
+      uint4 hi, lo;
+      ln_pack<CPL, F16>(acc, lw, lb, eps, c0, hi, lo);
+      stg[wave][0][t & 3][lane] = hi;
+      if (!F16) stg[wave][NP - 1][t & 3][lane] = lo;
+      if ((t & 3) == 3) flush(bi * F + f - 3, 4);
+    }
+  }
+}
+
 hipError_t launch_dwconv_ln(const float* x, const float* w, const float* b, const float* ln_w, const float* ln_b, float eps, int dil,
                             float* y, int B, int F, int C, hipStream_t st, uint16_t* yp, int plane_f16) {
   const int rows = B * F;
@@ -169,6 +280,23 @@ hipError_t launch_dwconv_ln(const float* x, const float* w, const float* b, cons
   static int run_min = -1;   // CTTS_DWCONV_RUN_MIN_ROWS: frames from which the sliding-window kernel is used (0 = never); below it one wave per frame
   if (run_min < 0) { const char* e = getenv("CTTS_DWCONV_RUN_MIN_ROWS"); run_min = e ? atoi(e) : 12288; }
   if (C == 512 && run_min > 0 && rows >= run_min && dil >= 1 && dil <= 4) {
+    // CTTS_DWCONV_SEQ (A/B, the bit-identity test; read at every launch): 0 = dwconv_ln_run_k's isolated 16-byte plane stores everywhere; 1 (default) =
+    // dwconv_ln_seq_k at dilation 1 (Vocos: 415 -> 141 MB written, 148 -> 92 us per launch at 65,536 frames); 2 = also at dilation 2 (DVAE: 231 -> 169 MB
+    // written but 107 -> 110 us: the 16-row register ring and its halo cost what the writes save; profiles/r6W_dwconv_ab.txt)
+    const char* es = getenv("CTTS_DWCONV_SEQ");
+    const int seq = es ? atoi(es) : 1;
+    if (yp != nullptr && ((seq >= 1 && dil == 1) || (seq >= 2 && dil == 2))) {
+      const int run = dil == 1 ? 36 : 48, nruns = (F + run - 1) / run;
+      const int nbs = ((B * nruns + 3) / 4 + 7) / 8 * 8;
+      if (dil == 1) {
+        if (plane_f16) hipLaunchKernelGGL((dwconv_ln_seq_k<true, 1>), dim3(nbs), dim3(256), 0, st, x, w, b, ln_w, ln_b, eps, F, B, nruns, yp);
+        else hipLaunchKernelGGL((dwconv_ln_seq_k<false, 1>), dim3(nbs), dim3(256), 0, st, x, w, b, ln_w, ln_b, eps, F, B, nruns, yp);
+      } else {
+        if (plane_f16) hipLaunchKernelGGL((dwconv_ln_seq_k<true, 2>), dim3(nbs), dim3(256), 0, st, x, w, b, ln_w, ln_b, eps, F, B, nruns, yp);
+        else hipLaunchKernelGGL((dwconv_ln_seq_k<false, 2>), dim3(nbs), dim3(256), 0, st, x, w, b, ln_w, ln_b, eps, F, B, nruns, yp);
+      }
+      return hipGetLastError();
+    }
     const int runs = (F + 36 * dil - 1) / (36 * dil);
     const int waves = B * runs * dil;
     const int nb = ((waves + 3) / 4 + 7) / 8 * 8;

@@ -81,6 +81,24 @@ for S in $STAGES; do
     proj)     # the weak-scaling projection leg alone
       timeout 900 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-ttfs --no-parity-mode --no-configs --no-slot-pool --no-bf16-mode --no-refine-text > gpurun_out/${TAG}_proj.log 2>&1; echo "exit $?" >> gpurun_out/${TAG}_proj.log
       grep "^{" gpurun_out/${TAG}_proj.log | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], json.dumps(d.get('weak_scaling_projection'))[:1500])"; tail -2 gpurun_out/${TAG}_proj.log | cut -c1-300 ;;
+    pmcdw)    # per-dispatch WRITE_SIZE / FETCH_SIZE of the depthwise-conv + LayerNorm launches of one pass (DVAE: 12 x dilation 2, then Vocos: 8 x dilation 1)
+      cd /tmp
+      for C in WRITE_SIZE FETCH_SIZE; do
+        CTTS_SYNC_POLL=1 timeout 400 rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/pmcdw_${TAG}_$C -o ${TAG}_$C -- python $R/bench.py --steps 1 --warmup 0 $NOLEGS > $R/gpurun_out/${TAG}_pmcdw_$C.log 2>&1
+        python - "$C" "/tmp/pmcdw_${TAG}_$C" <<'P' >> $R/gpurun_out/${TAG}_pmcdw.txt
+import csv, glob, sys
+c, d = sys.argv[1], sys.argv[2]
+f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
+vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if "dwconv_ln" in r["Kernel_Name"] and r["Counter_Name"] == c]
+print(c, "KiB per dwconv_ln dispatch, in launch order:", [round(v) for v in vals])
+P
+      done
+      cd $R; cat gpurun_out/${TAG}_pmcdw.txt | cut -c1-600 ;;
+    dwab)     # depthwise conv + LayerNorm: transposed plane writes (default) vs isolated 16-byte stores (CTTS_DWCONV_SEQ=0): kernel stats of one pass each
+      for m in 1 0; do
+        cd /tmp; CTTS_DWCONV_SEQ=$m timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/dw_${TAG}_$m -o ${TAG} -- python $R/bench.py --steps 1 --warmup 0 $NOLEGS > $R/gpurun_out/${TAG}_dwab_$m.log 2>&1
+        f=$(find /tmp/dw_${TAG}_$m -name "*kernel_stats.csv" | head -1); echo "CTTS_DWCONV_SEQ=$m" >> $R/gpurun_out/${TAG}_dwab.txt; grep "dwconv\|gemm_x3p" $f | cut -c1-60,150-260 >> $R/gpurun_out/${TAG}_dwab.txt; cd $R
+      done; cat gpurun_out/${TAG}_dwab.txt ;;
     reftext)  # refine-text legs + a kernel trace of them
       timeout 600 python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-ttfs --no-parity-mode --no-configs --no-slot-pool --no-ids-check --no-bf16-mode > gpurun_out/${TAG}_reftext.log 2>&1
       grep "^{" gpurun_out/${TAG}_reftext.log | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(json.dumps(d['configs']['refine_text'], indent=1))" | head -80 ;;
