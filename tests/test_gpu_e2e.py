@@ -1053,22 +1053,24 @@ def test_codec_f16_mode_holds_the_waveform_bar(weights):
     assert float(np.sqrt(np.mean((alone[:n2] - w_f16[2, :n2]) ** 2))) < 2e-5
 
 
+@pytest.mark.parametrize("tmax", [400, 399])
 @pytest.mark.parametrize("gemm", ["bf16x3", "f16"])
-def test_codec_dwconv_transposed_plane_writes_are_bit_identical(weights, monkeypatch, gemm):
+def test_codec_dwconv_transposed_plane_writes_are_bit_identical(weights, monkeypatch, gemm, tmax):
     """round 6: from 12288 frames the depthwise-conv + LayerNorm kernel hands the GEMMs their operand planes through a wave-private LDS
     transpose -- 64 contiguous bytes per lane quad instead of 64 isolated 16-byte stores per row (csrc/codec.hip dwconv_ln_seq_k: consecutive
     frames per wave at both dilations; PMC: 415 / 231 MB written per launch for 134 MB of planes before) -- same arithmetic per frame: the
     waveforms of a ragged 16 x 400-token batch (12800 frames; DVAE dilation 2 and Vocos dilation 1; the last run of every utterance partial)
-    equal CTTS_DWCONV_SEQ=0's bit for bit, in both operand formats."""
+    equal CTTS_DWCONV_SEQ=0's bit for bit, in both operand formats; 399 tokens = 798 frames: the last group of four rows of every utterance is
+    half full (the partial flush)."""
     rs = np.random.RandomState(35)
-    rows = [torch.from_numpy(rs.standard_normal((n, 768)).astype(np.float32)) for n in [400, 390, 120, 397] + [300] * 12]
+    rows = [torch.from_numpy(rs.standard_normal((n, 768)).astype(np.float32)) for n in [tmax, 390, 120, 397] + [300] * 12]
     eng = E.CodecEngine(weights["decoder"], weights["vocos"], DEV, gemm=gemm)
     w_def = eng.decode_to_wavs(rows).cpu().numpy()              # default: the transposed writes at dilation 1 (Vocos)
     monkeypatch.setenv("CTTS_DWCONV_SEQ", "2")                  # ... and at dilation 2 (DVAE decoder)
     w_new = eng.decode_to_wavs(rows).cpu().numpy()
     monkeypatch.setenv("CTTS_DWCONV_SEQ", "0")
     w_old = eng.decode_to_wavs(rows).cpu().numpy()
-    assert w_new.shape == w_old.shape == (16, 256 * 799) and np.isfinite(w_new).all()
+    assert w_new.shape == w_old.shape == (16, 256 * (2 * tmax - 1)) and np.isfinite(w_new).all()
     assert np.array_equal(w_new.view(np.int32), w_old.view(np.int32)), float(np.abs(w_new - w_old).max())
     assert np.array_equal(w_def.view(np.int32), w_old.view(np.int32)), float(np.abs(w_def - w_old).max())
 
