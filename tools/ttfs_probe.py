@@ -13,7 +13,7 @@ from chattts_amd.core import Chat, InferCodeParams  # noqa: E402
 dev = torch.device("cuda:0")
 sds = W.synthetic_all()
 chat = Chat()
-chat.load(state_dicts=sds, device=dev, dtype="bf16")
+chat.load(state_dicts=sds, device=dev, dtype=os.environ.get("DTYPE", "bf16"))
 ids, mask, tmask = synth.make_prompts(64, 16, 48, seed=0)
 stop = torch.from_numpy(synth.make_stop_lengths(64, 128, 512, seed=0))
 a = (torch.from_numpy(ids), torch.from_numpy(mask), torch.from_numpy(tmask))
