@@ -119,6 +119,8 @@ SIGNATURES = {
     "ctts_k_gemm": (C.c_int, [I32, P, P, P, I32, I32, I32, I32, I32, I32, I32, P, F, P, I32, P, P, I32, I32, I32, I32, I32, P]),
     "ctts_k_gemm_x3p": (C.c_int, [P, P, I32, I32, I32, I32, P, P, P, P, P, P]),
     "ctts_k_gemm_h1p": (C.c_int, [P, P, I32, I32, I32, I32, P, P, P, P, P, P]),
+    "ctts_stream_create_cu_mask": (C.c_int, [I32, I32, I32, I32, P]),
+    "ctts_stream_destroy": (C.c_int, [P]),
     "ctts_k_mlp_fused": (C.c_int, [P, P, P, I32, I32, P, P, P, P, I32, P]),
     "ctts_k_gemm_fast": (C.c_int, [P, I32, P, I32, I32, I32, P, F, I32, P, I32, P, I32, P, P]),
     "ctts_k_qkv_rope": (C.c_int, [P, P, I32, P, F, P, P, P, I32, P, P, I32, P, P, I32, P]),

@@ -983,6 +983,38 @@ extern "C" int ctts_k_gemm_h1p(const uint16_t* Ap, const uint16_t* Wp, int32_t M
   CK(launch_gemm_h1p(g, (hipStream_t)stream));
   return 0;
 }
+// ------------------------------------------------------------------------------------------------
+// A HIP stream confined to a subset of the CUs (hipExtStreamCreateWithCUMask): the acoustic decoder of batch i on a side stream of a few CUs
+// while batch i + 1 is generated on the rest (CodecEngine.decode_to_wavs_async, CTTS_CODEC_CUS).  CUs first, first + stride, ... (n of them).
+// ------------------------------------------------------------------------------------------------
+extern "C" int ctts_stream_create_cu_mask(int32_t first_cu, int32_t n_cus, int32_t stride, int32_t complement, void** stream) {
+  if (!stream || n_cus <= 0 || first_cu < 0 || stride <= 0) return fail("ctts_stream_create_cu_mask: bad arguments");
+  int dev = 0, ncu = 0;
+  CK(hipGetDevice(&dev));
+  CK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+  std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+  int set = 0;
+  for (int i = 0; i < n_cus; ++i) {
+    const int cu = first_cu + i * stride;
+    if (cu >= ncu) break;
+    mask[cu >> 5] |= 1u << (cu & 31);
+    ++set;
+  }
+  if (complement) {   // every CU of the device EXCEPT those: the stream of the work the confined stream must not disturb
+    for (int cu = 0; cu < ncu; ++cu) mask[cu >> 5] ^= 1u << (cu & 31);
+    set = ncu - set;
+  }
+  if (set <= 0) return fail("ctts_stream_create_cu_mask: no CU selected");
+  hipStream_t st = nullptr;
+  CK(hipExtStreamCreateWithCUMask(&st, (uint32_t)mask.size(), mask.data()));
+  *stream = (void*)st;
+  return 0;
+}
+extern "C" int ctts_stream_destroy(void* stream) {
+  if (stream) CK(hipStreamDestroy((hipStream_t)stream));
+  return 0;
+}
+
 extern "C" int ctts_k_mlp_fused(const uint16_t* Ap, const uint16_t* W1p, const uint16_t* W2p, int32_t M, int32_t inter, const float* b1,
                                 const float* b2, const float* gamma, float* C, int32_t planes, void* stream) {
   if (planes != 1) return fail("ctts_k_mlp_fused: planes must be 1 (fp16 plane)");

@@ -142,6 +142,23 @@ class _EventGroup:
             wait_event(e)
 
 
+def cu_masked_stream(lib, dev, first: int, n: int, stride: int, complement: bool) -> "torch.cuda.Stream":
+    """a HIP stream confined to CUs first, first + stride, ... (n of them) -- or to every OTHER CU (complement): ctts_stream_create_cu_mask"""
+    h = C.c_void_p()
+    with torch.cuda.device(dev):
+        _lib.check(lib.ctts_stream_create_cu_mask(first, n, stride, 1 if complement else 0, C.byref(h)), "ctts_stream_create_cu_mask")
+    return torch.cuda.ExternalStream(h.value, device=dev)
+
+
+def codec_cu_spec():
+    """CTTS_CODEC_CUS="n[:stride[:first]]" -> (first, n, stride) or None"""
+    spec = os.environ.get("CTTS_CODEC_CUS", "")
+    if not spec:
+        return None
+    parts = [int(v) for v in spec.split(":")]
+    return (parts[2] if len(parts) > 2 else 0), parts[0], (parts[1] if len(parts) > 1 else 1)
+
+
 def left_pad_starts(attention_mask: torch.Tensor) -> torch.Tensor:
     """kv_start[b] = number of leading zeros; raises unless the mask is left padding (tokenizer.py:73-110)."""
     m = attention_mask.to(torch.bool).cpu()
@@ -373,7 +390,9 @@ class GptEngine:
         h = C.c_void_p()
         _lib.check(self.lib.ctts_gpt_create(C.byref(h), C.byref(w)), "ctts_gpt_create")
         self.handle = h
-        self.stream = torch.cuda.Stream(device=dev)
+        # CTTS_GPT_COMPLEMENT=1 (with CTTS_CODEC_CUS): the generator's stream runs on every CU EXCEPT the acoustic decoder's side-stream CUs
+        spec = codec_cu_spec() if os.environ.get("CTTS_GPT_COMPLEMENT") == "1" else None
+        self.stream = cu_masked_stream(self.lib, dev, *spec, True) if spec else torch.cuda.Stream(device=dev)
         self._lane_res = [(self.handle, self.stream)]
         self._lane_res_alt = []
         self._lane_res_text = []
@@ -1354,7 +1373,13 @@ class CodecEngine:
         (`GptEngine.generate` hands out copies, so its outputs qualify).  Results are bit-identical to the synchronous calls."""
         dev = self.device
         if not hasattr(self, "_side"):
-            self._side = torch.cuda.Stream(device=dev)
+            # CTTS_CODEC_CUS="n[:stride[:first]]": the side stream is confined to n compute units (ctts_stream_create_cu_mask), so the big
+            # MFMA kernels of the decode of batch i do not take the CUs the latency-bound decode steps of batch i + 1 run on
+            spec = codec_cu_spec()
+            if spec:
+                self._side = cu_masked_stream(self.lib, dev, *spec, False)
+            else:
+                self._side = torch.cuda.Stream(device=dev)
             self._side_pins = [None, None]     # two staging buffers: a result may still be in its buffer when the next decode is enqueued
             self._side_n = 0
         caller = torch.cuda.current_stream(dev)

@@ -377,6 +377,11 @@ int ctts_k_gemm_x3p(const uint16_t* Ap, const uint16_t* Wp, int32_t M, int32_t N
 /* the same on ONE fp16 plane per operand (gemm_mode 2): Ap / Wp / Cp are [rows/32][K/16][64][8] fp16; K % 64 == 0 */
 int ctts_k_gemm_h1p(const uint16_t* Ap, const uint16_t* Wp, int32_t M, int32_t N, int32_t K, int32_t epi, const float* bias,
                     const float* gamma, const float* res, float* C, uint16_t* Cp, void* stream);
+/* a HIP stream confined to n_cus compute units (first_cu, first_cu + stride, ...): hipExtStreamCreateWithCUMask.  The host runs the acoustic
+ * decoder of one batch on such a stream while the next batch is generated on the others (the overlapped DVAE / ISTFT side stream of BASELINE
+ * config 4, at batch level: CodecEngine.decode_to_wavs_async); destroy with ctts_stream_destroy */
+int ctts_stream_create_cu_mask(int32_t first_cu, int32_t n_cus, int32_t stride, int32_t complement /* 1: every CU but those */, void** stream);
+int ctts_stream_destroy(void* stream);
 /* one ConvNeXt MLP in ONE launch: C = C + gamma * (GELU(A W1^T + b1) W2^T + b2), A [M][512] / W1 [inter][512] / W2 [512][inter] as
  * fp16 planes (planes = 1), C [M][512] f32 in place; bit-identical to ctts_k_gemm_h1p(epi 0) followed by ctts_k_gemm_h1p(epi 1)
  * (ConvNeXtBlock.pwconv1 -> act -> pwconv2 -> gamma -> residual, ChatTTS/model/dvae.py:46-66) */

@@ -99,6 +99,18 @@ P
         cd /tmp; CTTS_DWCONV_SEQ=$m timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/dw_${TAG}_$m -o ${TAG} -- python $R/bench.py --steps 1 --warmup 0 $NOLEGS > $R/gpurun_out/${TAG}_dwab_$m.log 2>&1
         f=$(find /tmp/dw_${TAG}_$m -name "*kernel_stats.csv" | head -1); echo "CTTS_DWCONV_SEQ=$m" >> $R/gpurun_out/${TAG}_dwab.txt; grep "dwconv\|gemm_x3p" $f | cut -c1-60,150-260 >> $R/gpurun_out/${TAG}_dwab.txt; cd $R
       done; cat gpurun_out/${TAG}_dwab.txt ;;
+    cumask)   # queue of batches (--pipeline: decode of batch i on the side stream under the generation of batch i + 1): side stream unconfined / on n CUs
+      for spec in "" "32" "64" "32:8" "16" "" "32" "64:4"; do
+        for D in f32x3 bf16; do
+          CTTS_CODEC_CUS="$spec" timeout 600 python bench.py --pipeline --dtype $D --steps 8 --warmup 2 $NOLEGS 2>/dev/null | grep "^{" | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('CTTS_CODEC_CUS=[$spec] $D pipelined', d['value'], d['ms_per_step'])" | tee -a gpurun_out/${TAG}_cumask.log
+        done
+      done ;;
+    cumask2)  # as cumask, the generator confined to the complement of the decoder's CUs
+      for spec in "" "32:8" "64:4" "32" "16:16" "32:8"; do
+        for D in f32x3 bf16; do
+          CTTS_GPT_COMPLEMENT=1 CTTS_CODEC_CUS="$spec" timeout 600 python bench.py --pipeline --dtype $D --steps 8 --warmup 2 $NOLEGS 2>/dev/null | grep "^{" | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('complement CTTS_CODEC_CUS=[$spec] $D pipelined', d['value'], d['ms_per_step'])" | tee -a gpurun_out/${TAG}_cumask2.log
+        done
+      done ;;
     reftext)  # refine-text legs + a kernel trace of them
       timeout 600 python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-ttfs --no-parity-mode --no-configs --no-slot-pool --no-ids-check --no-bf16-mode > gpurun_out/${TAG}_reftext.log 2>&1
       grep "^{" gpurun_out/${TAG}_reftext.log | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(json.dumps(d['configs']['refine_text'], indent=1))" | head -80 ;;
