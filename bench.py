@@ -858,6 +858,44 @@ def main():
                 "what": "the acoustic decode + waveform D2H of batch i on the codec engine's side HIP stream while batch i+1 is "
                         "generated; all waveforms on the host before the clock stops"}
 
+    def two_lanes_leg(eng, cdc):
+        """Throughput headroom beyond BASELINE's batch of 64: 128 utterances (the batch the reference ran as ONE for the N = 2 golden) as TWO
+        concurrent lanes of 64 rows (two HIP streams, two decode graphs) in one generate() call.  Not the headline's configuration."""
+        w = shard_workload(128, 1, 0, args.min_len, args.max_len)
+        i_d, t_d = torch.from_numpy(w["ids"]).to(dev), torch.from_numpy(w["tmask"]).to(dev)
+        m_t, s_t = torch.from_numpy(w["mask"]), torch.from_numpy(w["stop"])
+        mx = int(w["stop"].max()) + 1
+
+        def a_pass():
+            res = None
+            emb = eng.embed_prompt(i_d, t_d)
+            for res in eng.generate(emb, i_d, temp, 625, m_t, mx, 0, (*procs, *warpers), return_hidden=True, manual_seed=42,
+                                    use_graph=not args.no_graph, stop_at=s_t, lanes=2):
+                pass
+            return res, cdc.to_host(cdc.decode_to_wavs(res.hiddens))
+        a_pass()
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for _ in range(3):
+            res, wv = a_pass()
+        torch.cuda.synchronize(dev)
+        dtl = time.perf_counter() - t1
+        out = {"dtype": eng.dtype, "utterances": 128, "lanes": 2, "value": round(audio_seconds(w["stop"]) * 3 / dtl, 2), "unit": "audio-s/s", "steps": 3,
+               "ms_per_step": round(1000.0 * dtl / 3, 3),
+               "what": "128 utterances as two concurrent lanes of 64 rows in one call (same engine, same kernels; float32 waveforms of all 128 on the "
+                       "host inside the clock): what the latency-bound decode chain leaves idle at batch 64.  NOT BASELINE's batch-64 configuration"}
+        g2 = os.path.join(ROOT, "tests", "golden", "bench_c3_w2.npz")
+        if os.path.exists(g2) and (args.min_len, args.max_len) == (128, 512):
+            g = np.load(g2)
+            off = np.concatenate([[0], np.cumsum(g["lens"].astype(np.int64))])
+            grow = [g["ids"][off[b]: off[b + 1]].astype(np.int64) for b in range(128)]
+            unc = eng.last_stats.get("uncertified_rows") if "uncertified_rows" in eng.last_stats else None
+            ok, det = reference_verdict([t.cpu().numpy() for t in res.ids], grow, list(range(128)), unc, None, 1)
+            out["ids_match_reference"] = ok
+            out.update(det)
+            out["golden"] = "tests/golden/bench_c3_w2.npz: the reference's run of these 128 utterances as one batch (utterance 32: the documented near-tie draw)"
+        return out
+
     def pcm16_leg(eng, cdc):
         def pcm_pass():
             emb = eng.embed_prompt(ids_d, tm_d)
@@ -1042,6 +1080,8 @@ def main():
         # the same passes ending in 16-bit PCM instead of float32: float_to_int16 (tools/audio/np.py:7-11, what every caller of the reference
         # does next) + the silence strip's mask ON THE DEVICE, int16 + 1 bit per sample over PCIe (Chat.decode_to_pcm16)
         result["pcm16_output"] = pcm16_leg(gpt, codec)
+        note("two lanes of 64 (128 utterances in flight)")
+        result["two_lanes_of_64"] = two_lanes_leg(gpt, codec)
         if args.dtype == "f32x3":
             # the same leg on the f32 MFMA kernels throughout (dtype "f32": what the certificate's fallback runs, and what the split-bf16
             # decode step is measured against)
